@@ -1,0 +1,123 @@
+"""Drop-in for the reference's pybind module ``MultiScaleDeformableAttention``.
+
+The reference builds a torch C++/CUDA extension of that name exposing two functions
+(/root/reference/models/ops/src/vision.cpp:13-16, ms_deform_attn.h:20-62) and imports it as
+``MSDA`` (models/ops/functions/ms_deform_attn_func.py:18-21).  This module offers the same two
+functions with the same argument lists and error behaviour, implemented on the gfx950 HIP
+library through its C ABI (include/snipper_msda.h).  ``snipper_amd.install()`` registers it
+under the reference's module name.
+
+Differences, all additive: bfloat16 ``value`` is accepted (loc/attn are then float32), launch
+errors raise instead of being printed (.cuh:948-952), and ``im2col_step`` only has to satisfy
+the reference's divisibility rule -- the HIP kernels take the whole batch in one launch.
+"""
+from __future__ import annotations
+
+from typing import List
+
+import torch
+
+from . import _lib
+
+_SUFFIX = {torch.float32: "f32", torch.float64: "f64", torch.bfloat16: "bf16"}
+
+
+def _require(cond: bool, msg: str) -> None:
+    if not cond:
+        raise RuntimeError(msg)
+
+
+def _check_common(named, value, spatial_shapes, level_start_index, im2col_step):
+    # ms_deform_attn.h:38,60 -- the reference has no CPU implementation either
+    _require(value.is_cuda, "Not implemented on the CPU")
+    for name, t in named:   # ms_deform_attn_cuda.cu:28-38,93-105
+        _require(t.is_contiguous(), f"{name} tensor has to be contiguous")
+        _require(t.is_cuda, f"{name} must be a CUDA tensor")
+        _require(t.device == value.device, f"{name} must be on the same device as value")
+    _require(value.dtype in _SUFFIX, f"ms_deform_attn not implemented for '{value.dtype}'")
+    _require(spatial_shapes.dtype == torch.int64 and level_start_index.dtype == torch.int64,
+             "spatial_shapes and level_start_index must be int64")
+    batch = value.size(0)
+    step = min(batch, int(im2col_step))      # ms_deform_attn_cuda.cu:50-52
+    _require(step > 0 and batch % step == 0, f"batch({batch}) must divide im2col_step({step})")
+
+
+def _dims(value, spatial_shapes, sampling_loc, attn_weight):
+    _require(value.dim() == 4 and sampling_loc.dim() == 6 and attn_weight.dim() == 5, "bad tensor ranks")
+    N, S, M, D = value.shape
+    L = spatial_shapes.size(0)
+    Lq, P = sampling_loc.size(1), sampling_loc.size(4)
+    _require(tuple(sampling_loc.shape) == (N, Lq, M, L, P, 2), "sampling_loc shape mismatch")
+    _require(tuple(attn_weight.shape) == (N, Lq, M, L, P), "attn_weight shape mismatch")
+    _require(level_start_index_ok(spatial_shapes), "spatial_shapes must be [L,2]")
+    return N, S, M, D, L, Lq, P
+
+
+def level_start_index_ok(spatial_shapes) -> bool:
+    return spatial_shapes.dim() == 2 and spatial_shapes.size(1) == 2
+
+
+def _coord_dtype(value):
+    return torch.float32 if value.dtype == torch.bfloat16 else value.dtype
+
+
+def _stream(device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def ms_deform_attn_forward(value: torch.Tensor, spatial_shapes: torch.Tensor,
+                           level_start_index: torch.Tensor, sampling_loc: torch.Tensor,
+                           attn_weight: torch.Tensor, im2col_step: int) -> torch.Tensor:
+    """-> Tensor[N, Lq, M*D]   (ms_deform_attn_cuda.cu:20-80)"""
+    _check_common([("value", value), ("spatial_shapes", spatial_shapes),
+                   ("level_start_index", level_start_index), ("sampling_loc", sampling_loc),
+                   ("attn_weight", attn_weight)], value, spatial_shapes, level_start_index, im2col_step)
+    cd = _coord_dtype(value)
+    _require(sampling_loc.dtype == cd and attn_weight.dtype == cd,
+             f"sampling_loc/attn_weight must be {cd} for {value.dtype} value")
+    N, S, M, D, L, Lq, P = _dims(value, spatial_shapes, sampling_loc, attn_weight)
+    out = torch.empty((N, Lq, M * D), dtype=value.dtype, device=value.device)
+    lib = _lib.load()
+    fn = getattr(lib, "snipper_msda_forward_" + _SUFFIX[value.dtype])
+    with torch.cuda.device(value.device):
+        rc = fn(_stream(value.device), value.data_ptr(), spatial_shapes.data_ptr(),
+                level_start_index.data_ptr(), sampling_loc.data_ptr(), attn_weight.data_ptr(),
+                N, S, M, D, L, Lq, P, out.data_ptr())
+    _lib.check(rc, "ms_deform_attn_forward")
+    return out
+
+
+def ms_deform_attn_backward(value: torch.Tensor, spatial_shapes: torch.Tensor,
+                            level_start_index: torch.Tensor, sampling_loc: torch.Tensor,
+                            attn_weight: torch.Tensor, grad_output: torch.Tensor,
+                            im2col_step: int) -> List[torch.Tensor]:
+    """-> [grad_value, grad_sampling_loc, grad_attn_weight]   (ms_deform_attn_cuda.cu:83-153)
+
+    For bfloat16 ``value`` the returned grad_value is bfloat16 (accumulated in float32).
+    """
+    _check_common([("value", value), ("spatial_shapes", spatial_shapes),
+                   ("level_start_index", level_start_index), ("sampling_loc", sampling_loc),
+                   ("attn_weight", attn_weight), ("grad_output", grad_output)],
+                  value, spatial_shapes, level_start_index, im2col_step)
+    cd = _coord_dtype(value)
+    _require(sampling_loc.dtype == cd and attn_weight.dtype == cd,
+             f"sampling_loc/attn_weight must be {cd} for {value.dtype} value")
+    _require(grad_output.dtype == value.dtype, "grad_output dtype must match value")
+    N, S, M, D, L, Lq, P = _dims(value, spatial_shapes, sampling_loc, attn_weight)
+    _require(grad_output.numel() == N * Lq * M * D, "grad_output shape mismatch")
+    acc_dtype = torch.float32 if value.dtype == torch.bfloat16 else value.dtype
+    # grad_value is zeroed by the callee (include/snipper_msda.h, "Outputs")
+    grad_value = torch.empty(value.shape, dtype=acc_dtype, device=value.device)
+    grad_loc = torch.empty_like(sampling_loc)
+    grad_attn = torch.empty_like(attn_weight)
+    lib = _lib.load()
+    fn = getattr(lib, "snipper_msda_backward_" + _SUFFIX[value.dtype])
+    with torch.cuda.device(value.device):
+        rc = fn(_stream(value.device), grad_output.data_ptr(), value.data_ptr(),
+                spatial_shapes.data_ptr(), level_start_index.data_ptr(), sampling_loc.data_ptr(),
+                attn_weight.data_ptr(), N, S, M, D, L, Lq, P,
+                grad_value.data_ptr(), grad_loc.data_ptr(), grad_attn.data_ptr())
+    _lib.check(rc, "ms_deform_attn_backward")
+    if grad_value.dtype != value.dtype:
+        grad_value = grad_value.to(value.dtype)
+    return [grad_value, grad_loc, grad_attn]

@@ -1,0 +1,85 @@
+"""ctypes binding of libsnipper_msda.so (C ABI: include/snipper_msda.h).
+
+The product path has no CPU or PyTorch fallback: if the HIP library cannot be loaded the
+import of the op raises, loudly.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_int, c_void_p
+
+from . import build as _build
+
+_lib = None
+
+_FWD_ARGS = [c_void_p] * 6 + [c_int] * 7 + [c_void_p]          # stream, value, shapes, lsi, loc, attn, dims, out
+_BWD_ARGS = [c_void_p] * 7 + [c_int] * 7 + [c_void_p] * 3      # stream, grad_out, value, ..., dims, 3 grads
+
+EXPORTS = {
+    "snipper_msda_abi_version": ([], c_int),
+    "snipper_msda_strerror": ([c_int], c_char_p),
+    "snipper_msda_last_variant": ([], c_char_p),
+    "snipper_msda_set_policy": ([c_int], c_int),
+    "snipper_msda_forward_f32": (_FWD_ARGS, c_int),
+    "snipper_msda_forward_f64": (_FWD_ARGS, c_int),
+    "snipper_msda_forward_bf16": (_FWD_ARGS, c_int),
+    "snipper_msda_backward_f32": (_BWD_ARGS, c_int),
+    "snipper_msda_backward_f64": (_BWD_ARGS, c_int),
+    "snipper_msda_backward_bf16": (_BWD_ARGS, c_int),
+}
+
+ABI_VERSION = 1
+
+
+class SnipperLibraryError(RuntimeError):
+    pass
+
+
+def lib_path() -> str:
+    return _build.LIB_PATH
+
+
+def load():
+    """Load (building first if the .so is absent and hipcc is present) and type the library."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.LIB_PATH
+    if not os.path.exists(path):
+        try:
+            _build.build_hip()
+        except Exception as e:  # no silent fallback: the op is unusable without its HIP library
+            raise SnipperLibraryError(
+                f"libsnipper_msda.so is missing at {path} and could not be built ({e}). "
+                "Run `python -m snipper_amd.build` (needs hipcc, gfx950).") from e
+    try:
+        lib = ctypes.CDLL(path)
+    except OSError as e:
+        raise SnipperLibraryError(f"cannot load {path}: {e}") from e
+    for name, (argtypes, restype) in EXPORTS.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise SnipperLibraryError(f"{path} does not export {name}") from e
+        fn.argtypes = argtypes
+        fn.restype = restype
+    got = lib.snipper_msda_abi_version()
+    if got != ABI_VERSION:
+        raise SnipperLibraryError(f"ABI mismatch: library {got}, binding {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(code: int, what: str) -> None:
+    if code != 0:
+        msg = load().snipper_msda_strerror(code).decode()
+        raise RuntimeError(f"{what} failed: {msg} (code {code})")
+
+
+def last_variant() -> str:
+    return load().snipper_msda_last_variant().decode()
+
+
+def set_policy(policy: int) -> None:
+    check(load().snipper_msda_set_policy(int(policy)), "snipper_msda_set_policy")

@@ -1,0 +1,234 @@
+// msda_capi.hip -- extern "C" entry points of libsnipper_msda.so (see include/snipper_msda.h).
+//
+// Replaces the reference's two launchers, ms_deformable_im2col_cuda / ms_deformable_col2im_cuda
+// (/root/reference/models/ops/src/cuda/ms_deform_im2col_cuda.cuh:923-954, :956-1327): validate,
+// pick a kernel variant, launch on the caller's stream, report errors.  No allocation, no host
+// synchronisation, no global mutable state besides a thread-local "last variant" string and the
+// process-wide variant policy (tests / benchmarks only).
+#include <hip/hip_runtime.h>
+#include <atomic>
+#include <cstdint>
+
+#include "../../include/snipper_msda.h"
+#include "msda_d48.cuh"
+#include "msda_generic.cuh"
+
+using namespace snipper;
+
+namespace {
+
+thread_local const char *g_last_variant = "none";
+std::atomic<int> g_policy{0};  // 0 auto, 1 generic only
+
+int check_dims(int N, int S, int M, int D, int L, int Lq, int P) {
+  if (N <= 0 || S <= 0 || M <= 0 || D <= 0 || L <= 0 || Lq <= 0 || P <= 0) return SNIPPER_E_SHAPE;
+  if ((long long)S * M * D >= (1LL << 31)) return SNIPPER_E_SHAPE;
+  if ((long long)Lq * M * L * P * 2 >= (1LL << 31)) return SNIPPER_E_SHAPE;
+  if ((long long)L * P > 1024) return SNIPPER_E_SHAPE;
+  return SNIPPER_OK;
+}
+
+int launch_status() {
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? SNIPPER_OK : (int)e;
+}
+
+// smallest lane-group size covering D whose sample-point staging fits 64 KiB of LDS
+template <typename CT> int pick_group(int D, int LP, size_t *lds) {
+  const int cands[3] = {4, 16, 64};
+  for (int i = 0; i < 3; ++i) {
+    const int G = cands[i];
+    if (G < D && G != 64) continue;
+    const size_t need = (size_t)(kGenericBlock / G) * LP * sizeof(SamplePoint<CT>);
+    if (need <= 64 * 1024) {
+      *lds = need;
+      return G;
+    }
+  }
+  return 0;
+}
+
+int generic_grid(long long rows, int rows_per_block) {
+  const long long want = (rows + rows_per_block - 1) / rows_per_block;
+  const long long cap = 256LL * 16;  // 256 CUs x 16 resident blocks, grid-stride beyond
+  return (int)(want < cap ? want : cap);
+}
+
+template <typename VT, typename CT>
+int forward_generic(hipStream_t st, const VT *value, const int64_t *shapes, const int64_t *lsi,
+                    const CT *loc, const CT *attn, CoreDims d, VT *out) {
+  size_t lds = 0;
+  const int G = pick_group<CT>(d.D, d.L * d.P, &lds);
+  if (!G) return SNIPPER_E_SHAPE;
+  const long long rows = (long long)d.N * d.Lq * d.M;
+  const int grid = generic_grid(rows, kGenericBlock / G);
+  g_last_variant = "generic";
+  switch (G) {
+    case 4: hipLaunchKernelGGL((msda_fwd_generic_kernel<VT, CT, 4>), dim3(grid), dim3(kGenericBlock), lds, st, value, shapes, lsi, loc, attn, d, out); break;
+    case 16: hipLaunchKernelGGL((msda_fwd_generic_kernel<VT, CT, 16>), dim3(grid), dim3(kGenericBlock), lds, st, value, shapes, lsi, loc, attn, d, out); break;
+    default: hipLaunchKernelGGL((msda_fwd_generic_kernel<VT, CT, 64>), dim3(grid), dim3(kGenericBlock), lds, st, value, shapes, lsi, loc, attn, d, out); break;
+  }
+  return launch_status();
+}
+
+template <typename VT, typename CT, typename GVT>
+int backward_generic(hipStream_t st, const VT *grad_out, const VT *value, const int64_t *shapes,
+                     const int64_t *lsi, const CT *loc, const CT *attn, CoreDims d,
+                     GVT *grad_value, CT *grad_loc, CT *grad_attn) {
+  size_t lds = 0;
+  const int G = pick_group<CT>(d.D, d.L * d.P, &lds);
+  if (!G) return SNIPPER_E_SHAPE;
+  const long long rows = (long long)d.N * d.Lq * d.M;
+  const int grid = generic_grid(rows, kGenericBlock / G);
+  g_last_variant = "generic";
+  switch (G) {
+    case 4: hipLaunchKernelGGL((msda_bwd_generic_kernel<VT, CT, GVT, 4>), dim3(grid), dim3(kGenericBlock), lds, st, grad_out, value, shapes, lsi, loc, attn, d, grad_value, grad_loc, grad_attn); break;
+    case 16: hipLaunchKernelGGL((msda_bwd_generic_kernel<VT, CT, GVT, 16>), dim3(grid), dim3(kGenericBlock), lds, st, grad_out, value, shapes, lsi, loc, attn, d, grad_value, grad_loc, grad_attn); break;
+    default: hipLaunchKernelGGL((msda_bwd_generic_kernel<VT, CT, GVT, 64>), dim3(grid), dim3(kGenericBlock), lds, st, grad_out, value, shapes, lsi, loc, attn, d, grad_value, grad_loc, grad_attn); break;
+  }
+  return launch_status();
+}
+
+// The D=48 kernels address `value` through one raw-buffer descriptor with 32-bit byte offsets.
+template <typename VT> bool d48_eligible(const CoreDims &d) {
+  if (g_policy.load(std::memory_order_relaxed) == 1) return false;
+  if (d.D != kD48 || d.L > kMaxLevelsFast) return false;
+  if ((long long)d.N * d.S * d.M * kD48 * (long long)sizeof(VT) >= (1LL << 31)) return false;
+  return d.L * d.P <= 64;
+}
+
+template <typename VT>
+int forward_d48(hipStream_t st, const VT *value, const int64_t *shapes, const int64_t *lsi,
+                const float *loc, const float *attn, CoreDims d, VT *out) {
+  constexpr int kRows = kD48Block / D48Fwd<VT>::G;
+  const long long rows = (long long)d.N * d.Lq * d.M;
+  const int LP = d.L * d.P;
+  const int nblk = (int)((rows + kRows - 1) / kRows);
+  const int nblk_padded = (nblk + 7) & ~7;
+  const size_t lds = (size_t)kRows * (LP * sizeof(FwdRecord) + 16);
+  if (LP == 12 && d.P == 4) {
+    g_last_variant = "d48_lp12";
+    hipLaunchKernelGGL((msda_fwd_d48_kernel<VT, 12>), dim3(nblk_padded), dim3(kD48Block), lds, st, value, shapes, lsi, loc, attn, d, out, nblk_padded);
+  } else {
+    g_last_variant = "d48";
+    hipLaunchKernelGGL((msda_fwd_d48_kernel<VT, 0>), dim3(nblk_padded), dim3(kD48Block), lds, st, value, shapes, lsi, loc, attn, d, out, nblk_padded);
+  }
+  return launch_status();
+}
+
+int backward_d48_f32(hipStream_t st, const float *grad_out, const float *value, const int64_t *shapes,
+                     const int64_t *lsi, const float *loc, const float *attn, CoreDims d,
+                     float *grad_value, float *grad_loc, float *grad_attn) {
+  constexpr int kRows = kD48Block / 16;
+  const long long rows = (long long)d.N * d.Lq * d.M;
+  const int LP = d.L * d.P;
+  const int nblk = (int)((rows + kRows - 1) / kRows);
+  const int nblk_padded = (nblk + 7) & ~7;
+  const size_t lds = (size_t)kRows * (LP * sizeof(BwdRecord) + 16);
+  if (LP == 12 && d.P == 4) {
+    g_last_variant = "d48_lp12";
+    hipLaunchKernelGGL((msda_bwd_d48_f32_kernel<12>), dim3(nblk_padded), dim3(kD48Block), lds, st, grad_out, value, shapes, lsi, loc, attn, d, grad_value, grad_loc, grad_attn, nblk_padded);
+  } else {
+    g_last_variant = "d48";
+    hipLaunchKernelGGL((msda_bwd_d48_f32_kernel<0>), dim3(nblk_padded), dim3(kD48Block), lds, st, grad_out, value, shapes, lsi, loc, attn, d, grad_value, grad_loc, grad_attn, nblk_padded);
+  }
+  return launch_status();
+}
+
+template <typename GVT> int zero_grad_value(hipStream_t st, GVT *gv, const CoreDims &d) {
+  const hipError_t e = hipMemsetAsync(gv, 0, sizeof(GVT) * (size_t)d.N * d.S * d.M * d.D, st);
+  return e == hipSuccess ? SNIPPER_OK : (int)e;
+}
+
+}  // namespace
+
+extern "C" {
+
+int snipper_msda_abi_version(void) { return SNIPPER_MSDA_ABI_VERSION; }
+
+const char *snipper_msda_strerror(int code) {
+  switch (code) {
+    case SNIPPER_OK: return "ok";
+    case SNIPPER_E_NULL: return "null pointer argument";
+    case SNIPPER_E_SHAPE: return "size <= 0 or beyond the documented limits";
+    case SNIPPER_E_UNSUPPORTED: return "variant not built";
+    default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown snipper_msda error";
+  }
+}
+
+const char *snipper_msda_last_variant(void) { return g_last_variant; }
+
+int snipper_msda_set_policy(int policy) {
+  if (policy < 0 || policy > 1) return SNIPPER_E_UNSUPPORTED;
+  g_policy.store(policy, std::memory_order_relaxed);
+  return SNIPPER_OK;
+}
+
+#define SNIPPER_CHECK_FWD()                                                              \
+  if (!value || !shapes || !level_start || !loc || !attn || !out) return SNIPPER_E_NULL; \
+  if (int rc = check_dims(N, S, M, D, L, Lq, P)) return rc;                              \
+  const CoreDims d{N, S, M, D, L, Lq, P};                                                \
+  hipStream_t st = (hipStream_t)stream;
+
+int snipper_msda_forward_f32(void *stream, const float *value, const int64_t *shapes,
+                             const int64_t *level_start, const float *loc, const float *attn,
+                             int N, int S, int M, int D, int L, int Lq, int P, float *out) {
+  SNIPPER_CHECK_FWD();
+  if (d48_eligible<float>(d)) return forward_d48<float>(st, value, shapes, level_start, loc, attn, d, out);
+  return forward_generic<float, float>(st, value, shapes, level_start, loc, attn, d, out);
+}
+
+int snipper_msda_forward_f64(void *stream, const double *value, const int64_t *shapes,
+                             const int64_t *level_start, const double *loc, const double *attn,
+                             int N, int S, int M, int D, int L, int Lq, int P, double *out) {
+  SNIPPER_CHECK_FWD();
+  return forward_generic<double, double>(st, value, shapes, level_start, loc, attn, d, out);
+}
+
+int snipper_msda_forward_bf16(void *stream, const uint16_t *value, const int64_t *shapes,
+                              const int64_t *level_start, const float *loc, const float *attn,
+                              int N, int S, int M, int D, int L, int Lq, int P, uint16_t *out) {
+  SNIPPER_CHECK_FWD();
+  if (d48_eligible<uint16_t>(d)) return forward_d48<uint16_t>(st, value, shapes, level_start, loc, attn, d, out);
+  return forward_generic<uint16_t, float>(st, value, shapes, level_start, loc, attn, d, out);
+}
+
+#define SNIPPER_CHECK_BWD()                                                                   \
+  if (!grad_out || !value || !shapes || !level_start || !loc || !attn || !grad_value ||      \
+      !grad_loc || !grad_attn)                                                                \
+    return SNIPPER_E_NULL;                                                                    \
+  if (int rc = check_dims(N, S, M, D, L, Lq, P)) return rc;                                   \
+  const CoreDims d{N, S, M, D, L, Lq, P};                                                     \
+  hipStream_t st = (hipStream_t)stream;                                                       \
+  if (int rc = zero_grad_value(st, grad_value, d)) return rc;
+
+int snipper_msda_backward_f32(void *stream, const float *grad_out, const float *value,
+                              const int64_t *shapes, const int64_t *level_start,
+                              const float *loc, const float *attn,
+                              int N, int S, int M, int D, int L, int Lq, int P,
+                              float *grad_value, float *grad_loc, float *grad_attn) {
+  SNIPPER_CHECK_BWD();
+  if (d48_eligible<float>(d))
+    return backward_d48_f32(st, grad_out, value, shapes, level_start, loc, attn, d, grad_value, grad_loc, grad_attn);
+  return backward_generic<float, float, float>(st, grad_out, value, shapes, level_start, loc, attn, d, grad_value, grad_loc, grad_attn);
+}
+
+int snipper_msda_backward_f64(void *stream, const double *grad_out, const double *value,
+                              const int64_t *shapes, const int64_t *level_start,
+                              const double *loc, const double *attn,
+                              int N, int S, int M, int D, int L, int Lq, int P,
+                              double *grad_value, double *grad_loc, double *grad_attn) {
+  SNIPPER_CHECK_BWD();
+  return backward_generic<double, double, double>(st, grad_out, value, shapes, level_start, loc, attn, d, grad_value, grad_loc, grad_attn);
+}
+
+int snipper_msda_backward_bf16(void *stream, const uint16_t *grad_out, const uint16_t *value,
+                               const int64_t *shapes, const int64_t *level_start,
+                               const float *loc, const float *attn,
+                               int N, int S, int M, int D, int L, int Lq, int P,
+                               float *grad_value, float *grad_loc, float *grad_attn) {
+  SNIPPER_CHECK_BWD();
+  return backward_generic<uint16_t, float, float>(st, grad_out, value, shapes, level_start, loc, attn, d, grad_value, grad_loc, grad_attn);
+}
+
+}  // extern "C"

@@ -1,0 +1,266 @@
+"""Spatiotemporal deformable transformer (host side, PyTorch) over the gfx950 MSDeformAttn.
+
+API mirror of /root/reference/models/deformable_transformer.py: the classes
+``DeformableTransformer``, ``DeformableTransformerEncoderLayer`` / ``Encoder``,
+``DeformableTransformerDecoderLayer`` / ``Decoder`` and the builder
+``build_deforamble_transformer`` (sic) keep the reference's constructor arguments, forward
+signatures, return values and state_dict keys (checked against a state_dict saved from the
+reference: tests/test_transformer.py).  The implementation is this repository's own; the hot
+call -- ``MSDeformAttn`` -- runs one HIP launch per module forward (ms_deform_attn.py).
+"""
+from __future__ import annotations
+
+import copy
+from typing import List, Optional
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from .ms_deform_attn import MSDeformAttn
+
+
+def inverse_sigmoid(x, eps=1e-5):
+    """logit with clamping (reference util/misc.py:481-485)."""
+    x = x.clamp(min=0, max=1)
+    return torch.log(x.clamp(min=eps) / (1 - x).clamp(min=eps))
+
+
+def _clones(module, n):
+    return nn.ModuleList([copy.deepcopy(module) for _ in range(n)])
+
+
+def _activation(name):
+    try:
+        return {"relu": F.relu, "gelu": F.gelu, "glu": F.glu}[name]
+    except KeyError:
+        raise RuntimeError(f"activation should be relu/gelu, not {name}.")
+
+
+class _FFNMixin:
+    """Linear -> act -> dropout -> Linear, residual, LayerNorm (shared by both layer types)."""
+
+    def _ffn(self, x, drop_a, drop_b, norm):
+        y = self.linear2(drop_a(self.activation(self.linear1(x))))
+        return norm(x + drop_b(y))
+
+
+class DeformableTransformerEncoderLayer(nn.Module, _FFNMixin):
+    def __init__(self, d_model=256, d_ffn=1024, dropout=0.1, activation="relu",
+                 n_levels=4, n_heads=8, n_points=4, n_frame=4, use_pytroch_deform=False):
+        super().__init__()
+        self.self_attn = MSDeformAttn(d_model, n_levels, n_heads, n_points, n_frame, 'encoder', use_pytroch_deform)
+        self.dropout1 = nn.Dropout(dropout)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.linear1 = nn.Linear(d_model, d_ffn)
+        self.activation = _activation(activation)
+        self.dropout2 = nn.Dropout(dropout)
+        self.linear2 = nn.Linear(d_ffn, d_model)
+        self.dropout3 = nn.Dropout(dropout)
+        self.norm2 = nn.LayerNorm(d_model)
+
+    @staticmethod
+    def with_pos_embed(tensor, pos):
+        return tensor if pos is None else tensor + pos
+
+    def forward_ffn(self, src):
+        return self._ffn(src, self.dropout2, self.dropout3, self.norm2)
+
+    def forward(self, src, pos, reference_points, spatial_shapes, level_start_index, padding_mask=None):
+        attended = self.self_attn(self.with_pos_embed(src, pos), reference_points, src,
+                                  spatial_shapes, level_start_index, padding_mask)
+        src = self.norm1(src + self.dropout1(attended))
+        return self.forward_ffn(src)
+
+
+class DeformableTransformerEncoder(nn.Module):
+    def __init__(self, encoder_layer, num_layers):
+        super().__init__()
+        self.layers = _clones(encoder_layer, num_layers)
+        self.num_layers = num_layers
+
+    @staticmethod
+    def get_reference_points(spatial_shapes, valid_ratios, device):
+        """Pixel centres of every level, normalised by the valid extent, then re-expressed in each
+        level's padded frame: [B, S, L, 2] (reference :220-232)."""
+        hw = getattr(spatial_shapes, "_snipper_host", None) or spatial_shapes.tolist()
+        per_level = []
+        for lvl, (H, W) in enumerate(hw):
+            ys = torch.arange(H, dtype=torch.float32, device=device) + 0.5
+            xs = torch.arange(W, dtype=torch.float32, device=device) + 0.5
+            gy = ys.view(1, H, 1) / (valid_ratios[:, lvl, 1].view(-1, 1, 1) * H)
+            gx = xs.view(1, 1, W) / (valid_ratios[:, lvl, 0].view(-1, 1, 1) * W)
+            per_level.append(torch.stack([gx.expand(-1, H, W), gy.expand(-1, H, W)], -1).flatten(1, 2))
+        centres = torch.cat(per_level, 1)                       # [B, S, 2]
+        return centres[:, :, None] * valid_ratios[:, None]      # [B, S, L, 2]
+
+    def forward(self, src, spatial_shapes, level_start_index, valid_ratios, pos=None, padding_mask=None, n_frame=1):
+        ref = self.get_reference_points(spatial_shapes, valid_ratios, device=src.device)
+        ref = ref.unsqueeze(1).expand(-1, n_frame, -1, -1, -1)  # same grid for every frame
+        out = src
+        for layer in self.layers:
+            out = layer(out, pos, ref, spatial_shapes, level_start_index, padding_mask)
+        return out
+
+
+class DeformableTransformerDecoderLayer(nn.Module, _FFNMixin):
+    def __init__(self, d_model=256, d_ffn=1024, dropout=0.1, activation="relu",
+                 n_levels=4, n_heads=8, n_points=4, n_frame=4, use_pytroch_deform=False):
+        super().__init__()
+        self.cross_attn = MSDeformAttn(d_model, n_levels, n_heads, n_points, n_frame,
+                                       'decoder', use_pytroch_deform, True)
+        self.dropout1 = nn.Dropout(dropout)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.self_attn = nn.MultiheadAttention(d_model, n_heads, dropout=dropout)
+        self.dropout2 = nn.Dropout(dropout)
+        self.norm2 = nn.LayerNorm(d_model)
+        self.linear1 = nn.Linear(d_model, d_ffn)
+        self.activation = _activation(activation)
+        self.dropout3 = nn.Dropout(dropout)
+        self.linear2 = nn.Linear(d_ffn, d_model)
+        self.dropout4 = nn.Dropout(dropout)
+        self.norm3 = nn.LayerNorm(d_model)
+
+    @staticmethod
+    def with_pos_embed(tensor, pos):
+        return tensor if pos is None else tensor + pos
+
+    def forward_ffn(self, tgt):
+        return self._ffn(tgt, self.dropout3, self.dropout4, self.norm3)
+
+    def forward(self, tgt, query_pos, reference_points, src, src_spatial_shapes, level_start_index,
+                src_padding_mask=None):
+        bs, t, lq, c = tgt.shape
+        # dense self-attention over all (frame, query) tokens of a sample (reference :282-287)
+        flat = tgt.reshape(bs, t * lq, c)
+        qk = self.with_pos_embed(flat, query_pos.reshape(bs, t * lq, c)).transpose(0, 1)
+        mixed = self.self_attn(qk, qk, flat.transpose(0, 1), need_weights=False)[0].transpose(0, 1)
+        tgt = self.norm2(flat + self.dropout2(mixed)).view(bs, t, lq, c)
+        # deformable cross-attention into the encoder memory (reference :290-295)
+        attended, atten_data = self.cross_attn(self.with_pos_embed(tgt, query_pos.view(bs, t, lq, c)),
+                                               reference_points, src, src_spatial_shapes,
+                                               level_start_index, src_padding_mask)
+        tgt = self.norm1(tgt + self.dropout1(attended))
+        return self.forward_ffn(tgt), atten_data
+
+
+class DeformableTransformerDecoder(nn.Module):
+    def __init__(self, decoder_layer, num_layers, return_intermediate=False):
+        super().__init__()
+        self.layers = _clones(decoder_layer, num_layers)
+        self.num_layers = num_layers
+        self.return_intermediate = return_intermediate
+        # assigned by the model after construction (reference :310-311, model.py:103-104)
+        self.root_embed = None
+        self.class_embed = None
+
+    def forward(self, query_obj, reference_points, src, src_spatial_shapes, src_level_start_index,
+                src_valid_ratios, query_pos=None, src_padding_mask=None):
+        out = query_obj
+        inter, inter_ref, inter_att = [], [], []
+        for lid, layer in enumerate(self.layers):
+            ref_in = reference_points[:, :, :, None, :] * src_valid_ratios[:, None, None, :, :]
+            out, atten_data = layer(out, query_pos, ref_in, src, src_spatial_shapes,
+                                    src_level_start_index, src_padding_mask)
+            if self.root_embed is not None:   # iterative refinement of the reference points (:329-333)
+                delta = self.root_embed[lid](out)[..., 0:2]
+                reference_points = (delta + inverse_sigmoid(reference_points)).sigmoid().detach()
+            if self.return_intermediate:
+                inter.append(out)
+                inter_ref.append(reference_points)
+                inter_att.append(atten_data)
+        if self.return_intermediate:
+            return torch.stack(inter), torch.stack(inter_ref), inter_att
+        return out, reference_points, inter_att
+
+
+class DeformableTransformer(nn.Module):
+    def __init__(self, d_model=256, nhead=8, num_encoder_layers=6, num_decoder_layers=6,
+                 dim_feedforward=1024, dropout=0.1, activation="relu", return_intermediate_dec=False,
+                 num_feature_levels=4, dec_n_points=4, enc_n_points=4,
+                 n_frame=4, n_future_frame=2, use_pytroch_deform=False, num_keypoints=15):
+        super().__init__()
+        self.d_model, self.nhead = d_model, nhead
+        self.n_frame, self.n_future_frame = n_frame, n_future_frame
+        self.num_keypoints = num_keypoints
+        enc_layer = DeformableTransformerEncoderLayer(d_model, dim_feedforward, dropout, activation,
+                                                      num_feature_levels, nhead, enc_n_points, n_frame,
+                                                      use_pytroch_deform)
+        self.encoder = DeformableTransformerEncoder(enc_layer, num_encoder_layers)
+        dec_layer = DeformableTransformerDecoderLayer(d_model, dim_feedforward, dropout, activation,
+                                                      num_feature_levels, nhead, dec_n_points, n_frame,
+                                                      use_pytroch_deform)
+        self.decoder = DeformableTransformerDecoder(dec_layer, num_decoder_layers, return_intermediate_dec)
+        self.level_embed = nn.Parameter(torch.Tensor(num_feature_levels, d_model))
+        self.temporal_embed = nn.Parameter(torch.Tensor(n_frame + n_future_frame, d_model))
+        self.reference_points = nn.Linear(d_model, 2)
+        self._reset_parameters()
+
+    def _reset_parameters(self):
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)   # includes temporal_embed, as in the reference (:59-61)
+        for m in self.modules():
+            if isinstance(m, MSDeformAttn):
+                m._reset_parameters()
+        nn.init.xavier_uniform_(self.reference_points.weight, gain=1.0)
+        nn.init.constant_(self.reference_points.bias, 0.)
+        nn.init.normal_(self.level_embed)
+
+    def get_valid_ratio(self, mask):
+        """mask [bs, c, t, h, w] -> fraction of each axis that is not padding, (w, h) (reference :69-77)."""
+        H, W = mask.shape[-2:]
+        live_h = (~mask[:, 0, 0, :, 0]).sum(1).float() / H
+        live_w = (~mask[:, 0, 0, 0, :]).sum(1).float() / W
+        return torch.stack([live_w, live_h], -1)
+
+    def forward(self, srcs, masks, pos_embeds, query_embed):
+        """srcs / masks / pos_embeds: per level [bs, c, t, h, w]; query_embed [(T+F)*n_query, 2c].
+
+        Returns (hs, heatmaps, init_reference, inter_references, inter_att_data) as the reference (:167).
+        """
+        hw = [tuple(s.shape[-2:]) for s in srcs]
+        tokens = lambda x: x.flatten(3).permute(0, 2, 3, 1)              # [bs, t, h*w, c]
+        src = torch.cat([tokens(s) for s in srcs], 2)
+        mask = torch.cat([tokens(m) for m in masks], 2)
+        pos = torch.cat([tokens(p) + self.level_embed[lvl].view(1, 1, 1, -1)
+                         for lvl, p in enumerate(pos_embeds)], 2)
+        spatial_shapes = torch.as_tensor(hw, dtype=torch.long, device=src.device)
+        spatial_shapes._snipper_host = [(int(h), int(w)) for h, w in hw]  # spares the modules a device sync
+        sizes = [h * w for h, w in hw]
+        starts = [0]
+        for s in sizes[:-1]:
+            starts.append(starts[-1] + s)
+        level_start_index = torch.as_tensor(starts, dtype=torch.long, device=src.device)
+        valid_ratios = torch.stack([self.get_valid_ratio(m) for m in masks], 1)   # [bs, L, 2]
+
+        memory = self.encoder(src, spatial_shapes, level_start_index, valid_ratios, pos, mask, self.n_frame)
+
+        bs, _, _, c = memory.shape
+        heatmaps = []   # first num_keypoints channels of every head, per level (views; reference :141-149)
+        for chunk, (h, w) in zip(memory.split(sizes, dim=2), hw):
+            grid = chunk.reshape(bs, self.n_frame, h, w, self.nhead, c // self.nhead)
+            heatmaps.append(grid[..., 0:self.num_keypoints])
+
+        t_all = self.n_frame + self.n_future_frame
+        n_query = query_embed.shape[0] // t_all
+        query_pos, query_obj = torch.split(query_embed, c, dim=-1)
+        query_pos = query_pos.reshape(t_all, n_query, c).unsqueeze(0).expand(bs, -1, -1, -1)
+        query_pos = query_pos + self.temporal_embed.view(1, t_all, 1, c)
+        query_obj = query_obj.reshape(t_all, n_query, c).unsqueeze(0).expand(bs, -1, -1, -1)
+        init_reference = self.reference_points(query_pos).sigmoid()      # [bs, t, n_query, 2]
+
+        hs, inter_references, inter_att = self.decoder(query_obj, init_reference, memory, spatial_shapes,
+                                                       level_start_index, valid_ratios, query_pos, mask)
+        return hs, heatmaps, init_reference, inter_references, inter_att
+
+
+def build_deforamble_transformer(args):
+    return DeformableTransformer(
+        d_model=args.hidden_dim, nhead=args.nheads,
+        num_encoder_layers=args.enc_layers, num_decoder_layers=args.dec_layers,
+        dim_feedforward=args.dim_feedforward, dropout=args.dropout, activation="relu",
+        return_intermediate_dec=True, num_feature_levels=args.num_feature_levels,
+        dec_n_points=args.dec_n_points, enc_n_points=args.enc_n_points,
+        n_frame=args.num_frames, n_future_frame=args.num_future_frames,
+        use_pytroch_deform=args.use_pytorch_deform, num_keypoints=args.num_kpts)

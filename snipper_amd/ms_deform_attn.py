@@ -1,0 +1,187 @@
+"""Spatiotemporal multi-scale deformable attention module (host side, PyTorch).
+
+API mirror of /root/reference/models/ops/modules/ms_deform_attn.py (``MSDeformAttn``): same
+constructor (including the ``use_pytroch_deform`` spelling), same parameters and state_dict keys
+(the per-frame offset / weight Linears are ONE module listed ``n_frame`` times, :68-71), same
+``forward`` signature and return value (a tensor, or ``(tensor, (loc_list, weight_list))`` when
+``attention_vis``).
+
+What is different is how the forward is evaluated.  The reference walks every (query frame t1,
+value frame t2) pair in Python and launches one core op per pair (:130-226; 10 launches per
+encoder layer at T=4).  Here:
+
+* tied path (the Linears of all frames are the same object, which is how the reference always
+  builds them): offsets and logits do not depend on t2, so the joint softmax over L*P*|t2| is
+  softmax_{L*P}/|t2| and, the core op being linear in ``value``, the sum over t2 equals ONE core
+  op on the temporal mean of the neighbouring value frames.  All T1 query frames are folded into
+  the batch dimension: one kernel launch per module forward (SURVEY.md section 0 fact 4 verified
+  this identity against the reference in fp64).
+* general path (someone untied the Linears, e.g. by loading a checkpoint into separately
+  constructed modules): the per-pair formulation, one core op per pair, as the reference.
+
+The core op is the gfx950 HIP kernel behind ``MSDeformAttnFunction``; there is no fallback.
+``use_pytroch_deform=True`` selects the reference's own pure-PyTorch debug formulation, exactly
+as the reference's flag does.
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from .ms_deform_attn_func import MSDeformAttnFunction, ms_deform_attn_core_pytorch
+
+
+def frame_neighbours(t1: int, n_frame: int, n_value_frames: int) -> List[int]:
+    """Value frames that query frame ``t1`` attends to (reference :132-140, :184-189)."""
+    if t1 < n_frame:   # observed frame: itself and its temporal neighbours
+        return [t for t in (t1 - 1, t1, t1 + 1) if 0 <= t < n_frame]
+    return list(range(n_value_frames))   # future (forecast) frame: every value frame
+
+
+class MSDeformAttn(nn.Module):
+    def __init__(self, d_model=256, n_levels=4, n_heads=8, n_points=4, n_frame=4,
+                 mode='encoder', use_pytroch_deform=False, attention_vis=False):
+        super().__init__()
+        if d_model % n_heads != 0:
+            raise ValueError('d_model must be divisible by n_heads, but got {} and {}'.format(d_model, n_heads))
+        assert mode in ('encoder', 'decoder')
+        self.im2col_step = 64
+        self.d_model, self.n_levels, self.n_heads, self.n_points = d_model, n_levels, n_heads, n_points
+        self.n_frame = n_frame
+        self.mode = mode
+        self.use_pytroch_deform = use_pytroch_deform
+        self.attention_vis = attention_vis
+
+        shared_offsets = nn.Linear(d_model, n_heads * n_levels * n_points * 2)
+        shared_weights = nn.Linear(d_model, n_heads * n_levels * n_points)
+        # one Linear per value frame in name, one Linear in fact (reference :68-71)
+        self.sampling_offsets = nn.ModuleList([shared_offsets] * n_frame)
+        self.attention_weights = nn.ModuleList([shared_weights] * n_frame)
+        self.value_proj = nn.Linear(d_model, d_model)
+        self.output_proj = nn.Linear(d_model, d_model)
+        self._reset_parameters()
+
+    def _reset_parameters(self):
+        """Reference :78-97: zero offset weights, offsets biased onto n_heads directions scaled by
+        the point index, zero attention logits, Xavier projections."""
+        M, L, P = self.n_heads, self.n_levels, self.n_points
+        theta = torch.arange(M, dtype=torch.float32) * (2.0 * math.pi / M)
+        direction = torch.stack([theta.cos(), theta.sin()], -1)
+        direction = direction / direction.abs().max(-1, keepdim=True)[0]
+        grid = direction.view(M, 1, 1, 2) * torch.arange(1, P + 1, dtype=torch.float32).view(1, 1, P, 1)
+        grid = grid.expand(M, L, P, 2).reshape(-1)
+        with torch.no_grad():
+            for lin in self.sampling_offsets:
+                lin.weight.zero_()
+                lin.bias.copy_(grid)
+            for lin in self.attention_weights:
+                lin.weight.zero_()
+                lin.bias.zero_()
+            nn.init.xavier_uniform_(self.value_proj.weight)
+            self.value_proj.bias.zero_()
+            nn.init.xavier_uniform_(self.output_proj.weight)
+            self.output_proj.bias.zero_()
+
+    # ------------------------------------------------------------------------------------
+    def weights_are_tied(self) -> bool:
+        o0, a0 = self.sampling_offsets[0], self.attention_weights[0]
+        return all(m is o0 for m in self.sampling_offsets) and all(m is a0 for m in self.attention_weights)
+
+    def _core(self, value, shapes, lsi, loc, attn):
+        if self.use_pytroch_deform:
+            return ms_deform_attn_core_pytorch(value, shapes, loc, attn)
+        return MSDeformAttnFunction.apply(value.contiguous(), shapes, lsi, loc.contiguous(),
+                                          attn.contiguous(), self.im2col_step)
+
+    def forward(self, query, reference_points, input_flatten, input_spatial_shapes,
+                input_level_start_index, input_padding_mask=None):
+        """
+        query            [N, T1, Lq, C]
+        reference_points [N, T1, Lq, n_levels, 2]   in [0,1], (x, y)
+        input_flatten    [N, T2, S, C]              S = sum_l H_l*W_l
+        input_spatial_shapes [n_levels, 2] (H, W), input_level_start_index [n_levels]
+        input_padding_mask   [N, T2, S, C] bool (True = padding), or None
+        ->  [N, T1, Lq, C]
+        """
+        N, T1, Lq, C = query.shape
+        _, T2, S, _ = input_flatten.shape
+        M, L, P = self.n_heads, self.n_levels, self.n_points
+        shapes = input_spatial_shapes
+        hw = getattr(shapes, "_snipper_host", None)     # host copy cached by our transformer
+        if hw is None:
+            hw = shapes.tolist()                         # reference :112 pays the same host sync
+        assert sum(h * w for h, w in hw) == S
+
+        value = self.value_proj(input_flatten)
+        if input_padding_mask is not None:
+            value = value.masked_fill(input_padding_mask, 0.0)
+        value = value.view(N, T2, S, M, C // M)
+        scale = torch.tensor([[w, h] for h, w in hw], dtype=query.dtype, device=query.device)  # (W_l, H_l)
+        groups = [frame_neighbours(t1, self.n_frame, T2) for t1 in range(T1)]
+
+        if self.weights_are_tied():
+            out, locs, wts = self._forward_tied(query, reference_points, value, shapes,
+                                                input_level_start_index, scale, groups)
+        else:
+            out, locs, wts = self._forward_pairs(query, reference_points, value, shapes,
+                                                 input_level_start_index, scale, groups)
+        out = self.output_proj(out)
+        if self.attention_vis:
+            return out, (locs, wts)
+        return out
+
+    # -- one launch for the whole module ---------------------------------------------------
+    def _forward_tied(self, query, ref, value, shapes, lsi, scale, groups):
+        N, T1, Lq, C = query.shape
+        T2, S = value.shape[1], value.shape[2]
+        M, L, P = self.n_heads, self.n_levels, self.n_points
+        off = self.sampling_offsets[0](query).view(N, T1, Lq, M, L, P, 2)
+        loc = ref[:, :, :, None, :, None, :] + off / scale[None, None, None, None, :, None, :]
+        prob = F.softmax(self.attention_weights[0](query).view(N, T1, Lq, M, L * P), -1).view(N, T1, Lq, M, L, P)
+
+        # temporal mean of the neighbouring value frames, per query frame
+        if all(g == [t] for t, g in enumerate(groups)):          # T=1: nothing to average
+            vbar = value
+        else:
+            mix = torch.zeros(T1, T2, dtype=value.dtype, device=value.device)
+            for t1, g in enumerate(groups):
+                mix[t1, g] = 1.0 / len(g)
+            vbar = torch.einsum('ts,nsx->ntx', mix, value.reshape(N, T2, -1)).view(N, T1, S, M, C // M)
+        out = self._core(vbar.reshape(N * T1, S, M, C // M), shapes, lsi,
+                         loc.reshape(N * T1, Lq, M, L, P, 2), prob.reshape(N * T1, Lq, M, L, P))
+        out = out.view(N, T1, Lq, C)
+
+        locs = wts = None
+        if self.attention_vis:   # same lists as reference :228-233, built as views
+            locs, wts = [], []
+            for t1, g in enumerate(groups):
+                k = len(g)
+                locs.append(loc[:, t1].detach().unsqueeze(-2).expand(N, Lq, M, L, P, k, 2))
+                wts.append((prob[:, t1].detach() / k).unsqueeze(-1).expand(N, Lq, M, L, P, k))
+        return out, locs, wts
+
+    # -- the reference's per-pair evaluation, for untied Linears ------------------------------
+    def _forward_pairs(self, query, ref, value, shapes, lsi, scale, groups):
+        N, T1, Lq, C = query.shape
+        M, L, P = self.n_heads, self.n_levels, self.n_points
+        outs, locs, wts = [], [], []
+        for t1, g in enumerate(groups):
+            q = query[:, t1]
+            logits = torch.stack([self.attention_weights[t2](q).view(N, Lq, M, L, P) for t2 in g], -1)
+            prob = F.softmax(logits.flatten(-3), -1).view(N, Lq, M, L, P, len(g))
+            acc, loc_t1 = None, []
+            for k, t2 in enumerate(g):
+                off = self.sampling_offsets[t2](q).view(N, Lq, M, L, P, 2)
+                loc = ref[:, t1, :, None, :, None, :] + off / scale[None, None, None, :, None, :]
+                loc_t1.append(loc)
+                o = self._core(value[:, t2], shapes, lsi, loc, prob[..., k])
+                acc = o if acc is None else acc + o
+            outs.append(acc)
+            if self.attention_vis:
+                locs.append(torch.stack(loc_t1, dim=-2).detach())
+                wts.append(prob.detach())
+        return torch.stack(outs, dim=1), (locs or None), (wts or None)

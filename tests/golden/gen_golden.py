@@ -1,0 +1,223 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by running the REFERENCE itself.
+
+Runs only in the build container (needs /root/reference); the GPU box never
+sees the reference, only the .npz/.pt files written here.  Nothing from the
+reference is copied: it is imported (PYTHONDONTWRITEBYTECODE=1, read-only tree),
+fed seeded inputs, and its outputs / autograd gradients are stored as tensors.
+
+    python tests/golden/gen_golden.py            # rewrites every fixture
+
+Fixtures:
+  g1_testpy.npz        the cases of models/ops/test.py (seed 3, CPU RNG, call order of
+                       :31-78,85-86): use_pytorch_deform=1 outputs in fp64/fp32 and, for the
+                       seven gradcheck channel counts, autograd gradients in fp64.
+  g2_core_d48.npz      D=48, M=8, L=3, P=4 core op with out-of-range locations; fp64.
+  g3_module_*.pt       MSDeformAttn modules (encoder T=3, decoder T=3 and T=3+2) with randomised
+                       tied Linears and a padding mask: outputs, input grads, param grads, vis lists.
+  g4_transformer.pt    one DeformableTransformer forward (T=2+1, enc2/dec2) + its state_dict
+                       (pins the key schema) + gradients of a scalar loss.
+"""
+import os
+import sys
+import types
+
+os.environ["PYTHONDONTWRITEBYTECODE"] = "1"
+sys.dont_write_bytecode = True
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+REF = "/root/reference"
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def import_reference():
+    # util/misc.py:19-49 gates on torchvision.__version__ at import time; torchvision is absent here.
+    tv = types.ModuleType("torchvision")
+    tv.__version__ = "0.9.0"
+    tv.ops = types.ModuleType("torchvision.ops")
+    tv.ops.misc = types.ModuleType("torchvision.ops.misc")
+    tv.ops.misc.interpolate = F.interpolate
+    sys.modules.setdefault("torchvision", tv)
+    sys.modules.setdefault("torchvision.ops", tv.ops)
+    sys.modules.setdefault("torchvision.ops.misc", tv.ops.misc)
+    sys.path.insert(0, REF)
+    from models.ops.functions.ms_deform_attn_func import ms_deform_attn_core_pytorch
+    from models.ops.modules import MSDeformAttn
+    from models.deformable_transformer import DeformableTransformer
+    return ms_deform_attn_core_pytorch, MSDeformAttn, DeformableTransformer
+
+
+def lsi_of(shapes):
+    return torch.cat((shapes.new_zeros((1,)), shapes.prod(1).cumsum(0)[:-1]))
+
+
+def testpy_inputs(channels, gen=None):
+    """The draw sequence every check in models/ops/test.py uses (:33-36)."""
+    N, M, Lq, L, P, S = 1, 2, 2, 2, 2, 30
+    value = torch.rand(N, S, M, channels) * 0.01
+    loc = torch.rand(N, Lq, M, L, P, 2)
+    attn = torch.rand(N, Lq, M, L, P) + 1e-5
+    attn /= attn.sum(-1, keepdim=True).sum(-2, keepdim=True)
+    return value, loc, attn
+
+
+def gen_g1(core):
+    shapes = torch.as_tensor([(6, 4), (3, 2)], dtype=torch.long)
+    torch.manual_seed(3)                                      # test.py:28
+    out = {"shapes": shapes.numpy()}
+    v, l, a = testpy_inputs(2)                                # check_forward_equal_with_pytorch_double
+    out["fwd64_value"], out["fwd64_loc"], out["fwd64_attn"] = v.numpy(), l.numpy(), a.numpy()
+    out["fwd64_out"] = core(v.double(), shapes, l.double(), a.double()).numpy()
+    v, l, a = testpy_inputs(2)                                # check_forward_equal_with_pytorch_float
+    out["fwd32_value"], out["fwd32_loc"], out["fwd32_attn"] = v.numpy(), l.numpy(), a.numpy()
+    out["fwd32_out"] = core(v, shapes, l, a).numpy()
+    for D in [30, 32, 64, 71, 1025, 2048, 3096]:              # test.py:85-86
+        v, l, a = testpy_inputs(D)
+        v64 = v.double().requires_grad_(True)
+        l64 = l.double().requires_grad_(True)
+        a64 = a.double().requires_grad_(True)
+        o = core(v64, shapes, l64, a64)
+        go = torch.from_numpy(np.random.RandomState(D).standard_normal(tuple(o.shape)))
+        gv, gl, ga = torch.autograd.grad(o, (v64, l64, a64), go)
+        out[f"gc{D}_out"] = o.detach().numpy()
+        out[f"gc{D}_grad_out"] = go.numpy()
+        out[f"gc{D}_grad_loc"] = gl.numpy()
+        out[f"gc{D}_grad_attn"] = ga.numpy()
+        if D <= 71:
+            out[f"gc{D}_value"], out[f"gc{D}_loc"], out[f"gc{D}_attn"] = v.numpy(), l.numpy(), a.numpy()
+            out[f"gc{D}_grad_value"] = gv.numpy()
+        else:  # keep the file small: every 64th channel plus the channel sum pin grad_value
+            out[f"gc{D}_grad_value_s64"] = gv[..., ::64].contiguous().numpy()
+            out[f"gc{D}_grad_value_sum"] = gv.sum(-1).numpy()
+            out[f"gc{D}_value_sum"] = v.double().sum().numpy()    # pins the RNG stream
+    np.savez_compressed(os.path.join(OUT, "g1_testpy.npz"), **out)
+
+
+def gen_g2(core):
+    g = torch.Generator().manual_seed(1234)
+    N, M, D, L, P, Lq = 2, 8, 48, 3, 4, 50
+    shapes = torch.as_tensor([(12, 16), (6, 8), (3, 4)], dtype=torch.long)
+    S = int(shapes.prod(1).sum())
+    value = torch.randn(N, S, M, D, generator=g)
+    loc = torch.rand(N, Lq, M, L, P, 2, generator=g) * 1.4 - 0.2          # exercises the >-1 / <H edges
+    # a few exact-boundary locations: loc*H-0.5 == -1 (excluded) and == H-... (edge taps)
+    loc[0, 0, 0, 0, 0] = torch.tensor([-0.5 / 16, -0.5 / 12])
+    loc[0, 0, 0, 0, 1] = torch.tensor([0.5 / 16, 0.5 / 12])
+    loc[0, 0, 0, 0, 2] = torch.tensor([1.0 + 0.5 / 16, 1.0])
+    loc[0, 0, 0, 0, 3] = torch.tensor([1.0 - 0.5 / 16, 1.0 - 0.5 / 12])
+    attn = torch.softmax(torch.randn(N, Lq, M, L * P, generator=g), -1).view(N, Lq, M, L, P)
+    grad_out = torch.randn(N, Lq, M * D, generator=g)
+    v64, l64, a64 = (t.double().requires_grad_(True) for t in (value, loc, attn))
+    o = core(v64, shapes, l64, a64)
+    gv, gl, ga = torch.autograd.grad(o, (v64, l64, a64), grad_out.double())
+    np.savez_compressed(
+        os.path.join(OUT, "g2_core_d48.npz"), shapes=shapes.numpy(),
+        value=value.numpy(), loc=loc.numpy(), attn=attn.numpy(), grad_out=grad_out.numpy(),
+        out=o.detach().numpy(), grad_value=gv.numpy().astype(np.float32), grad_loc=gl.numpy(),
+        grad_attn=ga.numpy(),
+        out32=core(value, shapes, loc, attn).numpy())
+
+
+def randomise_(module, gen, scale=0.3):
+    """Give the zero-initialised offset/weight Linears (ms_deform_attn.py:78-97) real values."""
+    with torch.no_grad():
+        for name, p in module.named_parameters():
+            if "sampling_offsets" in name and name.endswith("weight"):
+                p.copy_(torch.randn(p.shape, generator=gen) * 0.05)
+            elif "attention_weights" in name:
+                p.copy_(torch.randn(p.shape, generator=gen) * scale)
+
+
+def gen_g3(MSDeformAttn):
+    d_model, M, L, P = 48, 4, 3, 4
+    shapes = torch.as_tensor([(6, 8), (3, 4), (2, 2)], dtype=torch.long)
+    S = int(shapes.prod(1).sum())
+    lsi = lsi_of(shapes)
+    cases = {"enc_t3": ("encoder", 3, 3, S), "dec_t3": ("decoder", 3, 3, 5), "dec_t3f2": ("decoder", 3, 5, 5)}
+    for name, (mode, n_frame, T1, Lq) in cases.items():
+        g = torch.Generator().manual_seed({"enc_t3": 101, "dec_t3": 102, "dec_t3f2": 103}[name])
+        torch.manual_seed(11)
+        mod = MSDeformAttn(d_model, L, M, P, n_frame, mode, True, mode == "decoder").double()
+        randomise_(mod, g)
+        N, T2 = 2, n_frame
+        query = torch.randn(N, T1, Lq, d_model, generator=g).double().requires_grad_(True)
+        ref = (torch.rand(N, T1, Lq, L, 2, generator=g).double() * 1.1 - 0.05).requires_grad_(True)
+        src = torch.randn(N, T2, S, d_model, generator=g).double().requires_grad_(True)
+        mask = torch.zeros(N, T2, S, dtype=torch.bool)
+        mask[1, :, -3:] = True
+        mask[0, :, 5] = True
+        mask_c = mask[..., None].expand(-1, -1, -1, d_model).contiguous()   # model.py:156-157 C-expanded
+        res = mod(query, ref, src, shapes, lsi, mask_c)
+        vis = None
+        if isinstance(res, tuple):
+            res, vis = res
+        go = torch.randn(res.shape, generator=g).double()
+        params = dict(mod.named_parameters())   # de-duplicated (tied) parameters
+        grads = torch.autograd.grad(res, [query, ref, src] + list(params.values()), go)
+        blob = {
+            "cfg": dict(d_model=d_model, n_levels=L, n_heads=M, n_points=P, n_frame=n_frame, mode=mode),
+            "state_dict": {k: v.detach().clone() for k, v in mod.state_dict().items()},
+            "shapes": shapes, "lsi": lsi, "query": query.detach(), "ref": ref.detach(), "src": src.detach(),
+            "mask": mask_c, "out": res.detach(), "grad_out": go,
+            "grad_query": grads[0], "grad_ref": grads[1], "grad_src": grads[2],
+            "param_grads": {k: g_ for k, g_ in zip(params.keys(), grads[3:])},
+        }
+        if vis is not None:
+            blob["vis_loc"] = [t.clone() for t in vis[0]]
+            blob["vis_w"] = [t.clone() for t in vis[1]]
+        torch.save(blob, os.path.join(OUT, f"g3_module_{name}.pt"))
+
+
+def gen_g4(DeformableTransformer):
+    torch.manual_seed(5)
+    d_model, nhead, L = 48, 4, 3
+    T, Fu, nq = 2, 1, 4
+    tr = DeformableTransformer(d_model=d_model, nhead=nhead, num_encoder_layers=2, num_decoder_layers=2,
+                               dim_feedforward=32, dropout=0.0, activation="relu",
+                               return_intermediate_dec=True, num_feature_levels=L, dec_n_points=4,
+                               enc_n_points=4, n_frame=T, n_future_frame=Fu, use_pytroch_deform=True,
+                               num_keypoints=3)
+    g = torch.Generator().manual_seed(99)
+    with torch.no_grad():
+        tr.temporal_embed.copy_(torch.randn(tr.temporal_embed.shape, generator=g))   # :52 is uninitialised
+    randomise_(tr, g)
+    tr = tr.double()
+    bs = 2
+    hw = [(6, 8), (3, 4), (2, 2)]
+    srcs = [torch.randn(bs, d_model, T, h, w, generator=g).double() for h, w in hw]
+    masks = []
+    for h, w in hw:   # right/bottom padding on sample 1 -> valid_ratios != 1
+        m = torch.zeros(bs, d_model, T, h, w, dtype=torch.bool)
+        m[1, :, :, :, w - max(1, w // 4):] = True
+        m[1, :, :, h - max(1, h // 3):, :] = True
+        masks.append(m)
+    pos = [torch.randn(bs, d_model, T, h, w, generator=g).double() for h, w in hw]
+    query_embed = torch.randn(nq * (T + Fu), 2 * d_model, generator=g).double()
+    hs, heatmaps, init_ref, inter_refs, att = tr(srcs, masks, pos, query_embed)
+    loss = (hs * torch.linspace(-1, 1, hs.numel(), dtype=torch.float64).view_as(hs)).sum()
+    names = [k for k, _ in tr.named_parameters()]
+    grads = torch.autograd.grad(loss, list(tr.parameters()), allow_unused=True)
+    torch.save({
+        "cfg": dict(d_model=d_model, nhead=nhead, num_encoder_layers=2, num_decoder_layers=2,
+                    dim_feedforward=32, dropout=0.0, num_feature_levels=L, dec_n_points=4, enc_n_points=4,
+                    n_frame=T, n_future_frame=Fu, num_keypoints=3),
+        "state_dict": {k: v.detach().clone() for k, v in tr.state_dict().items()},
+        "srcs": srcs, "masks": masks, "pos": pos, "query_embed": query_embed,
+        "hs": hs.detach(), "heatmaps": [h.detach().clone() for h in heatmaps], "init_ref": init_ref.detach(),
+        "inter_refs": inter_refs.detach(), "loss": loss.detach(),
+        "att_loc": [[t.clone() for t in a[0]] for a in att], "att_w": [[t.clone() for t in a[1]] for a in att],
+        "param_grads": {k: (g_ if g_ is not None else None) for k, g_ in zip(names, grads)},
+    }, os.path.join(OUT, "g4_transformer.pt"))
+
+
+if __name__ == "__main__":
+    core, MSDeformAttn, DeformableTransformer = import_reference()
+    gen_g1(core)
+    gen_g2(core)
+    gen_g3(MSDeformAttn)
+    gen_g4(DeformableTransformer)
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(os.path.join(OUT, f)))
