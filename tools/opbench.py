@@ -1,0 +1,108 @@
+#!/usr/bin/env python3
+"""Op-level timing of the deformable-attention core op on one MI355X (not the contract bench).
+
+Encoder call (Lq=S=9875) and decoder call (Lq=60) at 600x800 geometry; HIP kernels (tuned and
+generic) next to the PyTorch grid_sample formulation on the same GPU (the ">=3x" denominator of
+BASELINE.json).  Prints one JSON line per measurement.
+"""
+import argparse
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from snipper_amd import MultiScaleDeformableAttention as MSDA   # noqa: E402
+from snipper_amd import _lib                                     # noqa: E402
+from snipper_amd.ms_deform_attn_func import ms_deform_attn_core_pytorch  # noqa: E402
+
+SHAPES = [(75, 100), (38, 50), (19, 25)]
+M, D, L, P = 8, 48, 3, 4
+
+
+def make(N, Lq, local, dtype, seed=0, dev="cuda:0"):
+    g = torch.Generator().manual_seed(seed)
+    S = sum(h * w for h, w in SHAPES)
+    value = torch.randn(N, S, M, D, generator=g)
+    if local and Lq == S:
+        refs = []
+        for h, w in SHAPES:
+            ys, xs = torch.meshgrid(torch.arange(h) + 0.5, torch.arange(w) + 0.5, indexing="ij")
+            refs.append(torch.stack([xs.reshape(-1) / w, ys.reshape(-1) / h], -1))
+        ref = torch.cat(refs)[None, :, None, None, None, :]
+        norm = torch.tensor([[w, h] for h, w in SHAPES], dtype=torch.float32)[None, None, None, :, None, :]
+        loc = ref + torch.randn(N, Lq, M, L, P, 2, generator=g) * 3.0 / norm
+    else:
+        loc = torch.rand(N, Lq, M, L, P, 2, generator=g)
+    attn = torch.softmax(torch.randn(N, Lq, M, L * P, generator=g), -1).view(N, Lq, M, L, P)
+    go = torch.randn(N, Lq, M * D, generator=g)
+    shapes = torch.tensor(SHAPES, dtype=torch.long, device=dev)
+    lsi = torch.cat((shapes.new_zeros(1), shapes.prod(1).cumsum(0)[:-1]))
+    return value.to(dev).to(dtype), shapes, lsi, loc.to(dev), attn.to(dev), go.to(dev).to(dtype)
+
+
+def timeit(fn, iters, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(iters + 1)]
+    ev[0].record()
+    for i in range(iters):
+        fn()
+        ev[i + 1].record()
+    torch.cuda.synchronize()
+    ts = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(iters))
+    return ts[len(ts) // 2], ts[0]
+
+
+def alg_bytes(N, Lq, S, e, bwd):
+    if not bwd:
+        return e * (N * S * M * D + N * Lq * M * D) + 4 * 3 * N * Lq * M * L * P
+    return e * (2 * N * S * M * D + N * Lq * M * D) + 4 * 6 * N * Lq * M * L * P
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--N", type=int, nargs="+", default=[1, 2, 8])
+    ap.add_argument("--skip-torch", action="store_true")
+    args = ap.parse_args()
+    S = sum(h * w for h, w in SHAPES)
+    for N in args.N:
+        for name, Lq, local in [("enc_local", S, True), ("enc_uniform", S, False), ("dec", 60, False)]:
+            for dtype in (torch.float32, torch.bfloat16):
+                v, shapes, lsi, loc, attn, go = make(N, Lq, local, dtype)
+                for policy in ((0, 1) if dtype == torch.float32 else (0,)):
+                    _lib.set_policy(policy)
+                    f = lambda: MSDA.ms_deform_attn_forward(v, shapes, lsi, loc, attn, 64)
+                    b = lambda: MSDA.ms_deform_attn_backward(v, shapes, lsi, loc, attn, go, 64)
+                    f(); var_f = _lib.last_variant()
+                    b(); var_b = _lib.last_variant()
+                    tf, tf0 = timeit(f, args.iters)
+                    tb, tb0 = timeit(b, args.iters)
+                    e = v.element_size()
+                    print(json.dumps({
+                        "case": name, "N": N, "dtype": str(dtype).split(".")[-1], "fwd_variant": var_f,
+                        "bwd_variant": var_b, "fwd_ms": round(tf, 4), "fwd_min_ms": round(tf0, 4),
+                        "bwd_ms": round(tb, 4), "bwd_min_ms": round(tb0, 4),
+                        "fwd_alg_GBps": round(alg_bytes(N, Lq, S, e, False) / tf / 1e6, 1),
+                        "bwd_alg_GBps": round(alg_bytes(N, Lq, S, e, True) / tb / 1e6, 1)}), flush=True)
+                _lib.set_policy(0)
+            if not args.skip_torch:
+                v, shapes, lsi, loc, attn, go = make(N, Lq, local, torch.float32)
+                hw = [tuple(x) for x in SHAPES]
+                vv, ll, aa = v.clone().requires_grad_(True), loc.clone().requires_grad_(True), attn.clone().requires_grad_(True)
+                f = lambda: ms_deform_attn_core_pytorch(vv, hw, ll, aa)
+                def fb():
+                    o = ms_deform_attn_core_pytorch(vv, hw, ll, aa)
+                    torch.autograd.grad(o, (vv, ll, aa), go)
+                with torch.no_grad():
+                    tf, _ = timeit(f, max(3, args.iters // 4), warm=1)
+                tfb, _ = timeit(fb, max(3, args.iters // 4), warm=1)
+                print(json.dumps({"case": name, "N": N, "dtype": "float32", "fwd_variant": "torch_grid_sample",
+                                  "fwd_ms": round(tf, 3), "fwd_bwd_ms": round(tfb, 3)}), flush=True)
+
+
+if __name__ == "__main__":
+    main()
