@@ -106,11 +106,15 @@ def gen_g2(core):
     loc = (torch.round(loc * 4096) + 0.5) / 4096   # half-offset 2^-12 lattice: pixel coordinates exact in
     # fp32 and fp64 and never ON a pixel boundary (where the CUDA op's `> -1` rule and grid_sample's
     # gradient differ on a measure-zero set)
-    # a few exact-boundary locations: loc*H-0.5 == -1 (excluded) and == H-... (edge taps)
+    # exact-boundary locations along x at level 0 (W=16, so the pixel coordinate is exact in fp32 too):
+    # pixel x = -1 (skipped by the `> -1` rule), 0 (lw = 0), W (skipped), W-1 (right tap outside).
+    # y stays on the lattice, except for the first one where y = -1 as well (with only x = -1 the
+    # CUDA op's rule and grid_sample's gradient differ on this measure-zero set).
+    ylat = (1234 + 0.5) / 4096
     loc[0, 0, 0, 0, 0] = torch.tensor([-0.5 / 16, -0.5 / 12])
-    loc[0, 0, 0, 0, 1] = torch.tensor([0.5 / 16, 0.5 / 12])
-    loc[0, 0, 0, 0, 2] = torch.tensor([1.0 + 0.5 / 16, 1.0])
-    loc[0, 0, 0, 0, 3] = torch.tensor([1.0 - 0.5 / 16, 1.0 - 0.5 / 12])
+    loc[0, 0, 0, 0, 1] = torch.tensor([0.5 / 16, ylat])
+    loc[0, 0, 0, 0, 2] = torch.tensor([1.0 + 0.5 / 16, ylat])
+    loc[0, 0, 0, 0, 3] = torch.tensor([1.0 - 0.5 / 16, ylat])
     attn = torch.softmax(torch.randn(N, Lq, M, L * P, generator=g), -1).view(N, Lq, M, L, P)
     grad_out = torch.randn(N, Lq, M * D, generator=g)
     v64, l64, a64 = (t.double().requires_grad_(True) for t in (value, loc, attn))
