@@ -1,0 +1,307 @@
+#!/usr/bin/env python3
+"""bench.py -- snippets/sec of one training step of the Snipper hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json `metric` / configs[2..3]): T=4 frames of 600x800 per snippet, ResNet-50
+backbone -> 3 feature levels -> hidden_dim 384, 8 heads, enc6/dec6, 60 queries, batch 2 snippets per
+GPU, fp32 (the reference has no AMP), synthetic images, random-init weights.  One step = forward,
+loss, backward, gradient clipping (0.1, engine.py:74) and an AdamW update.  One process per GPU;
+gradients are all-reduced by DistributedDataParallel over RCCL, overlapped with backward
+(weak scaling: every rank keeps its own 2 snippets per step).
+
+The loss is a fixed-assignment surrogate over every decoder layer's outputs: the reference's
+SetCriterion + Hungarian matcher (models/model.py:240-545, matcher.py) is SURVEY.md section 8f rank 2 and
+not built yet; `config.loss` says so.
+
+One JSON line on stdout (rank 0).  Besides the contract's keys:
+  roofline      the dominant hand-written kernel (deformable-attention backward, encoder shape),
+                timed live with events on the launch stream, against the 8 TB/s HBM peak with the
+                algorithmic bytes of SURVEY.md section 8(d) / DESIGN.md;
+  cpu_baseline  the CPU oracle's use_pytorch_deform=1 formulation of the encoder MSDeformAttn module
+                (fwd+bwd, 1 snippet) on the host cores, converted to an attention-only snippets/s bound;
+  msda          MSDeformAttn fwd+bwd ms (encoder / decoder module), the second half of the metric.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from types import SimpleNamespace
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+
+HBM_PEAK_GBPS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+
+
+def model_args(a):
+    return SimpleNamespace(
+        hidden_dim=a.hidden_dim, nheads=8, enc_layers=a.enc_layers, dec_layers=a.dec_layers, dim_feedforward=1024,
+        dropout=0.1, num_feature_levels=3, dec_n_points=4, enc_n_points=4, num_frames=a.frames,
+        num_future_frames=a.future_frames, use_pytorch_deform=bool(a.use_pytorch_deform), num_kpts=15,
+        position_embedding="sine", backbone="resnet50", lr_backbone=1e-5, masks=False, dilation=False,
+        num_queries=60, aux_loss=True)
+
+
+def surrogate_loss(out, tgt):
+    """Fixed assignment: query i <-> synthetic person i for i < m; the rest are background."""
+    def one(o):
+        m = tgt["kpts2d"].shape[1]
+        logits = o["pred_logits"]                                   # [bs, nq, t, 2]
+        loss = F.cross_entropy(logits.flatten(0, 2), tgt["labels"].flatten())
+        loss = loss + F.l1_loss(o["pred_kpts2d"][:, :m], tgt["kpts2d"]) * 5.0
+        loss = loss + F.l1_loss(o["pred_depth"][:, :m], tgt["depth"])
+        return loss
+    total = one(out)
+    for aux in out.get("aux_outputs", []):
+        total = total + one(aux)
+    for hm in out["heatmaps"]:
+        total = total + hm.pow(2).mean() * 0.01
+    return total
+
+
+def make_batches(a, device, n_batches, seed):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    t_all = a.frames + a.future_frames
+    m = 8
+    batches = []
+    for _ in range(n_batches):
+        imgs = torch.rand(a.batch, a.frames * 3, a.height, a.width, generator=g).to(device)
+        labels = torch.zeros(a.batch, 60, t_all, dtype=torch.long)
+        labels[:, :m] = 1
+        tgt = {"labels": labels.to(device),
+               "kpts2d": torch.rand(a.batch, m, t_all, 15, 3, generator=g).to(device),
+               "depth": torch.rand(a.batch, m, t_all, 15, 1, generator=g).to(device)}
+        batches.append((imgs, tgt))
+    return batches
+
+
+def build_optimizer(model):
+    """AdamW with the reference's three groups (main.py:201-221)."""
+    def named(pred):
+        return [p for n, p in model.named_parameters() if p.requires_grad and pred(n)]
+    slow = lambda n: ("reference_points" in n or "sampling_offsets" in n) and "backbone" not in n
+    groups = [
+        {"params": named(lambda n: "backbone" not in n and not slow(n)), "lr": 1e-4},
+        {"params": named(lambda n: "backbone" in n), "lr": 1e-5},
+        {"params": named(slow), "lr": 1e-5},
+    ]
+    return torch.optim.AdamW(groups, lr=1e-4, weight_decay=1e-4)
+
+
+def msda_alg_bytes(d, bwd):
+    """Algorithmic HBM bytes of one core-op launch; coordinates/weights are fp32."""
+    e = d["esize"]
+    rows = d["N"] * d["Lq"] * d["M"]
+    v = d["N"] * d["S"] * d["M"] * d["D"]
+    o = rows * d["D"]
+    lp = rows * d["L"] * d["P"]
+    ce = 4 if e == 2 else e
+    if not bwd:
+        return e * (v + o) + ce * 3 * lp
+    ge = 4 if e == 2 else e            # grad_value accumulates in f32 for bf16 inputs
+    return e * (v + o) + ge * v + ce * 6 * lp
+
+
+def cpu_baseline(a, budget_s=40.0):
+    """Time the CPU oracle (use_pytorch_deform=1 formulation, per-pair spatiotemporal module) on the host."""
+    from oracle import msda_oracle as O
+    shapes = [(-(-a.height // s), -(-a.width // s)) for s in (8, 16, 32)]
+    S = sum(h * w for h, w in shapes)
+    C, M, L, P, T = a.hidden_dim, 8, 3, 4, a.frames
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    g = torch.Generator().manual_seed(0)
+    r = lambda *s: torch.randn(*s, generator=g)
+    q = r(1, T, S, C).requires_grad_(True)
+    src = r(1, T, S, C).requires_grad_(True)
+    ref = torch.rand(1, T, S, L, 2, generator=g)
+    vw, vb, ow, ob = r(C, C) * 0.05, torch.zeros(C), r(C, C) * 0.05, torch.zeros(C)
+    offw, offb = [r(M * L * P * 2, C) * 0.01] * T, [r(M * L * P * 2)] * T
+    attw, attb = [r(M * L * P, C) * 0.05] * T, [torch.zeros(M * L * P)] * T
+    t0 = time.perf_counter()
+    out, _, _ = O.st_msdeform_attn(q, ref, src, shapes, None, vw, vb, offw, offb, attw, attb, ow, ob, M, L, P, T)
+    out.sum().backward()
+    dt = time.perf_counter() - t0
+    per_snippet = dt * a.enc_layers            # encoder attention only; decoder/dense/backbone not counted
+    return {"value": round(1.0 / per_snippet, 5), "unit": "snippets/s", "cores": cores, "kind": "port",
+            "sample": (f"oracle use_pytorch_deform=1 formulation: ONE encoder MSDeformAttn module fwd+bwd, 1 snippet, "
+                       f"T={T}, {dt:.2f} s on {cores} host threads; value = 1/({a.enc_layers} encoder layers x that), "
+                       "i.e. attention-only upper bound of the CPU rate (dense layers, decoder, backbone excluded)"),
+            "module_fwd_bwd_s": round(dt, 3)}
+
+
+def time_msda_modules(a, device):
+    """MSDeformAttn module fwd+bwd ms at the bench geometry (encoder Lq=S, decoder Lq=60)."""
+    from snipper_amd.ms_deform_attn import MSDeformAttn
+    shapes = [(-(-a.height // s), -(-a.width // s)) for s in (8, 16, 32)]
+    S = sum(h * w for h, w in shapes)
+    sh = torch.tensor(shapes, device=device)
+    sh._snipper_host = shapes
+    lsi = torch.cat((sh.new_zeros(1), sh.prod(1).cumsum(0)[:-1]))
+    res = {}
+    for mode, Lq, T1 in (("encoder", S, a.frames), ("decoder", 60, a.frames + a.future_frames)):
+        mod = MSDeformAttn(a.hidden_dim, 3, 8, 4, a.frames, mode, False, mode == "decoder").to(device)
+        q = torch.randn(a.batch, T1, Lq, a.hidden_dim, device=device, requires_grad=True)
+        src = torch.randn(a.batch, a.frames, S, a.hidden_dim, device=device, requires_grad=True)
+        ref = torch.rand(a.batch, T1, Lq, 3, 2, device=device)
+
+        def run():
+            o = mod(q, ref, src, sh, lsi, None)
+            o = o[0] if isinstance(o, tuple) else o
+            o.sum().backward()
+        for _ in range(2):
+            run()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = 5
+        for _ in range(n):
+            run()
+        torch.cuda.synchronize()
+        res[f"{mode}_module_fwd_bwd_ms"] = round((time.perf_counter() - t0) / n * 1e3, 3)
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=2, help="snippets per GPU")
+    ap.add_argument("--frames", type=int, default=4)
+    ap.add_argument("--future-frames", type=int, default=0)
+    ap.add_argument("--height", type=int, default=600)
+    ap.add_argument("--width", type=int, default=800)
+    ap.add_argument("--hidden-dim", type=int, default=384)
+    ap.add_argument("--enc-layers", type=int, default=6)
+    ap.add_argument("--dec-layers", type=int, default=6)
+    ap.add_argument("--precision", choices=["fp32", "bf16"], default="fp32")
+    ap.add_argument("--use-pytorch-deform", type=int, default=0, help="1 = reference debug path (comparison only)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip roofline/msda extras (profiling runs)")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            sys.exit(f"--gpus {a.gpus} needs torch.distributed.run --nproc-per-node {a.gpus}")
+        a.gpus = world
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)      # "nccl" is RCCL on ROCm
+
+    from snipper_amd import MultiScaleDeformableAttention as MSDA
+    from snipper_amd import _lib
+    from snipper_amd.model import build_model
+    _lib.load()                                                   # fail loudly if the HIP library is missing
+
+    torch.manual_seed(42 + rank)                                  # main.py:48,175
+    margs = model_args(a)
+    model = build_model(margs).to(device)
+    if world > 1:
+        torch.manual_seed(42)   # same init on every rank is DDP's job anyway (broadcast at wrap time)
+    model.train()
+    opt = build_optimizer(model)
+    net = model
+    if world > 1:
+        net = torch.nn.parallel.DistributedDataParallel(
+            model, device_ids=[local_rank], broadcast_buffers=False, gradient_as_bucket_view=True,
+            bucket_cap_mb=50, static_graph=True)
+    batches = make_batches(a, device, 2, seed=1000 + rank)
+    amp = a.precision == "bf16"
+
+    def step(i):
+        imgs, tgt = batches[i % len(batches)]
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+            out, _ = net(list(imgs))
+        loss = surrogate_loss(out, tgt)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 0.1)
+        opt.step()
+        return loss
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(a.warmup):
+        step(i)
+    fence()
+    timing = (rank == 0) and not a.no_extras
+    if timing:
+        MSDA.enable_launch_timing(True)
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        loss = step(a.warmup + i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    launches = MSDA.launch_timings() if timing else []
+    MSDA.enable_launch_timing(False)
+    loss_val = float(loss.detach())
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+
+    if rank == 0:
+        snippets = a.batch * world * a.steps
+        line = {
+            "metric": "snippets/sec (T=4, 600x800, hidden_dim=384) training step; MSDeformAttn fwd+bwd ms",
+            "value": round(snippets / elapsed, 4), "unit": "snippets/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32" if not amp else "bf16", "data": "synthetic",
+            "config": {"workload": (f"T={a.frames}+{a.future_frames} enc{a.enc_layers}/dec{a.dec_layers} "
+                                    f"hidden_dim={a.hidden_dim} L=3 nq=60 {a.height}x{a.width} ResNet-50, "
+                                    f"train step fwd+bwd+clip+AdamW (BASELINE configs[2]/[3])"),
+                       "global_batch": a.batch * world, "per_gpu_batch": a.batch, "parallelism": f"dp{world}",
+                       "loss": "fixed-assignment surrogate (SetCriterion+Hungarian matcher not built: SURVEY 8f rank 2)",
+                       "backbone_convs": "PyTorch/MIOpen (hand-written gfx950 conv kernels not built yet)",
+                       "msda_path": "pytorch grid_sample" if a.use_pytorch_deform else "snipper_amd HIP (tied single-launch)"},
+            "final_loss": round(loss_val, 5),
+        }
+        if launches:
+            by = {}
+            for kind, variant, d, ms in launches:
+                key = (kind, variant, d["N"], d["Lq"])
+                by.setdefault(key, [d, []])[1].append(ms)
+            tot = {k: sum(v[1]) for k, v in by.items()}
+            dom = max(tot, key=tot.get)
+            d, times = by[dom]
+            avg_ms = sum(times) / len(times)
+            bts = msda_alg_bytes(d, dom[0] == "bwd")
+            ach = bts / (avg_ms * 1e-3) / 1e9
+            line["roofline"] = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": None,
+                                "kernel": f"msda_{dom[0]}_{dom[1]} N={d['N']} Lq={d['Lq']}",
+                                "avg_launch_ms": round(avg_ms, 4), "alg_bytes_per_launch": bts,
+                                "launches_timed": len(times)}
+            line["msda_launch_ms_per_step"] = {f"{k[0]}_{k[1]}_N{k[2]}_Lq{k[3]}": round(v / a.steps, 3) for k, v in tot.items()}
+        if not a.no_extras:
+            line["msda"] = time_msda_modules(a, device)
+        if world == 1 and not a.no_cpu_baseline and not a.no_extras:
+            line["cpu_baseline"] = cpu_baseline(a)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

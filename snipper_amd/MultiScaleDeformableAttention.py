@@ -65,6 +65,44 @@ def _stream(device) -> int:
     return torch.cuda.current_stream(device).cuda_stream
 
 
+# ---- optional launch timing (bench.py) --------------------------------------------------------
+# When enabled, every C-ABI call is bracketed by two events recorded on the SAME stream the
+# kernel is launched on; nothing synchronises until the caller reads the list.
+_timing = None
+
+
+def enable_launch_timing(on: bool = True) -> None:
+    global _timing
+    _timing = [] if on else None
+
+
+def launch_timings():
+    """[(kind, variant, dims dict, elapsed_ms)] for the calls since enable_launch_timing(True);
+    synchronises the device."""
+    if not _timing:
+        return []
+    torch.cuda.synchronize()
+    return [(k, v, d, s.elapsed_time(e)) for (k, v, d, s, e) in _timing]
+
+
+class _Timed:
+    def __init__(self, kind, dims, device):
+        self.kind, self.dims, self.device = kind, dims, device
+
+    def __enter__(self):
+        if _timing is not None:
+            self.start = torch.cuda.Event(enable_timing=True)
+            self.start.record(torch.cuda.current_stream(self.device))
+        return self
+
+    def __exit__(self, *exc):
+        if _timing is not None and exc[0] is None:
+            end = torch.cuda.Event(enable_timing=True)
+            end.record(torch.cuda.current_stream(self.device))
+            _timing.append((self.kind, _lib.last_variant(), self.dims, self.start, end))
+        return False
+
+
 def ms_deform_attn_forward(value: torch.Tensor, spatial_shapes: torch.Tensor,
                            level_start_index: torch.Tensor, sampling_loc: torch.Tensor,
                            attn_weight: torch.Tensor, im2col_step: int) -> torch.Tensor:
@@ -79,7 +117,8 @@ def ms_deform_attn_forward(value: torch.Tensor, spatial_shapes: torch.Tensor,
     out = torch.empty((N, Lq, M * D), dtype=value.dtype, device=value.device)
     lib = _lib.load()
     fn = getattr(lib, "snipper_msda_forward_" + _SUFFIX[value.dtype])
-    with torch.cuda.device(value.device):
+    dims = dict(N=N, S=S, M=M, D=D, L=L, Lq=Lq, P=P, esize=value.element_size())
+    with torch.cuda.device(value.device), _Timed("fwd", dims, value.device):
         rc = fn(_stream(value.device), value.data_ptr(), spatial_shapes.data_ptr(),
                 level_start_index.data_ptr(), sampling_loc.data_ptr(), attn_weight.data_ptr(),
                 N, S, M, D, L, Lq, P, out.data_ptr())
@@ -112,7 +151,8 @@ def ms_deform_attn_backward(value: torch.Tensor, spatial_shapes: torch.Tensor,
     grad_attn = torch.empty_like(attn_weight)
     lib = _lib.load()
     fn = getattr(lib, "snipper_msda_backward_" + _SUFFIX[value.dtype])
-    with torch.cuda.device(value.device):
+    dims = dict(N=N, S=S, M=M, D=D, L=L, Lq=Lq, P=P, esize=value.element_size())
+    with torch.cuda.device(value.device), _Timed("bwd", dims, value.device):
         rc = fn(_stream(value.device), grad_output.data_ptr(), value.data_ptr(),
                 spatial_shapes.data_ptr(), level_start_index.data_ptr(), sampling_loc.data_ptr(),
                 attn_weight.data_ptr(), N, S, M, D, L, Lq, P,

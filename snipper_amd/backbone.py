@@ -1,0 +1,194 @@
+"""ResNet-50 feature extractor with frozen BatchNorm, and the (t, y, x) sine position encoding.
+
+API mirror of /root/reference/models/backbone.py (``FrozenBatchNorm2d``, ``BackboneBase``
+semantics, ``Backbone``, ``Joiner``, ``build_backbone``) and models/position_encoding.py
+(``PositionEmbeddingSine``, ``build_position_encoding``).
+
+The reference does not contain the network itself: it instantiates ``torchvision.models.resnet50``
+(backbone.py:105-107, un-vendored, version unpinned) and taps layer2/3/4 through
+``IntermediateLayerGetter`` (:78-85).  torchvision is absent here, so the ResNet-50 (v1.5:
+stride on the 3x3 convolution, as torchvision's) is restated in ``ResNet50Body`` with
+torchvision's parameter names, so a reference checkpoint's ``backbone.0.body.*`` keys load
+unchanged.  Parity status of this file: UNPINNED against torchvision (no reference test or
+golden vector exists for it); it is checked layer by layer against ``F.conv2d`` compositions.
+
+Round-1 status: convolutions run through PyTorch (MIOpen); the hand-written gfx950
+implicit-GEMM kernels named in BASELINE.json's north_star are the next row.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from .misc import NestedTensor
+
+
+class FrozenBatchNorm2d(nn.Module):
+    """BatchNorm2d with fixed statistics and affine parameters (reference backbone.py:27-64):
+    y = x * w * rsqrt(var + eps) + (b - mean * w * rsqrt(var + eps)); all four are buffers."""
+
+    def __init__(self, n, eps=1e-5):
+        super().__init__()
+        self.register_buffer("weight", torch.ones(n))
+        self.register_buffer("bias", torch.zeros(n))
+        self.register_buffer("running_mean", torch.zeros(n))
+        self.register_buffer("running_var", torch.ones(n))
+        self.eps = eps
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        state_dict.pop(prefix + "num_batches_tracked", None)     # reference :43-51
+        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+
+    def scale_bias(self):
+        scale = self.weight * (self.running_var + self.eps).rsqrt()
+        return scale, self.bias - self.running_mean * scale
+
+    def forward(self, x):
+        scale, bias = self.scale_bias()
+        return x * scale.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1)
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, width, stride=1, downsample=False):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, width, 1, bias=False)
+        self.bn1 = FrozenBatchNorm2d(width)
+        self.conv2 = nn.Conv2d(width, width, 3, stride=stride, padding=1, bias=False)
+        self.bn2 = FrozenBatchNorm2d(width)
+        self.conv3 = nn.Conv2d(width, width * 4, 1, bias=False)
+        self.bn3 = FrozenBatchNorm2d(width * 4)
+        self.downsample = None
+        if downsample:
+            self.downsample = nn.Sequential(nn.Conv2d(inplanes, width * 4, 1, stride=stride, bias=False),
+                                            FrozenBatchNorm2d(width * 4))
+
+    def forward(self, x):
+        y = F.relu(self.bn1(self.conv1(x)))
+        y = F.relu(self.bn2(self.conv2(y)))
+        y = self.bn3(self.conv3(y))
+        skip = x if self.downsample is None else self.downsample(x)
+        return F.relu(y + skip)
+
+
+class ResNet50Body(nn.Module):
+    """conv1..layer4 of ResNet-50; forward returns {"0": layer2, "1": layer3, "2": layer4}
+    (or {"0": layer4}) like IntermediateLayerGetter with the reference's return_layers."""
+
+    def __init__(self, return_interm_layers=True, dilation=False):
+        super().__init__()
+        if dilation:
+            raise NotImplementedError("dilation (DC5) is not used by any Snipper recipe")
+        self.conv1 = nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)
+        self.bn1 = FrozenBatchNorm2d(64)
+        inplanes = 64
+        for i, (width, blocks, stride) in enumerate([(64, 3, 1), (128, 4, 2), (256, 6, 2), (512, 3, 2)]):
+            layers = [Bottleneck(inplanes, width, stride, downsample=True)]
+            inplanes = width * 4
+            layers += [Bottleneck(inplanes, width) for _ in range(blocks - 1)]
+            setattr(self, f"layer{i + 1}", nn.Sequential(*layers))
+        self.return_interm_layers = return_interm_layers
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+
+    def forward(self, x) -> Dict[str, torch.Tensor]:
+        x = F.relu(self.bn1(self.conv1(x)))
+        x = F.max_pool2d(x, 3, stride=2, padding=1)
+        c2 = self.layer1(x)
+        c3 = self.layer2(c2)
+        c4 = self.layer3(c3)
+        c5 = self.layer4(c4)
+        if self.return_interm_layers:
+            return {"0": c3, "1": c4, "2": c5}
+        return {"0": c5}
+
+
+class Backbone(nn.Module):
+    """ResNet backbone with frozen BatchNorm (reference ``BackboneBase`` + ``Backbone``, :67-110)."""
+
+    def __init__(self, name: str = "resnet50", train_backbone: bool = True,
+                 return_interm_layers: bool = True, dilation: bool = False):
+        super().__init__()
+        if name != "resnet50":
+            raise ValueError("only resnet50 is restated here (the Snipper recipes use nothing else)")
+        self.body = ResNet50Body(return_interm_layers, dilation)
+        for pname, p in self.body.named_parameters():     # conv1 + layer1 are always frozen (:71-73)
+            if not train_backbone or not any(k in pname for k in ("layer2", "layer3", "layer4")):
+                p.requires_grad_(False)
+        if return_interm_layers:
+            self.strides, self.num_channels = [8, 16, 32], [512, 1024, 2048]
+        else:
+            self.strides, self.num_channels = [32], [2048]
+
+    def forward(self, tensor_list: NestedTensor):
+        feats = self.body(tensor_list.tensors)
+        out: Dict[str, NestedTensor] = {}
+        for name, x in feats.items():
+            m = tensor_list.mask
+            assert m is not None
+            mask = F.interpolate(m[None].float(), size=x.shape[-2:]).to(torch.bool)[0]    # nearest (:93)
+            out[name] = NestedTensor(x, mask)
+        return out
+
+
+class PositionEmbeddingSine(nn.Module):
+    """Normalised sine embedding over (t, y, x): [b*t,h,w] mask -> [b, t, 3*num_pos_feats, h, w]
+    (reference position_encoding.py:20-63)."""
+
+    def __init__(self, num_pos_feats=64, num_frames=8, temperature=10000, normalize=False, scale=None):
+        super().__init__()
+        if scale is not None and normalize is False:
+            raise ValueError("normalize should be True if scale is passed")
+        self.num_pos_feats, self.frames = num_pos_feats, num_frames
+        self.temperature, self.normalize = temperature, normalize
+        self.scale = 2 * math.pi if scale is None else scale
+
+    def forward(self, tensor_list: NestedTensor):
+        mask = tensor_list.mask
+        n, h, w = mask.shape
+        live = ~mask.reshape(n // self.frames, self.frames, h, w)
+        axes = []
+        for dim in (1, 2, 3):                                   # t, y, x running counts of valid cells
+            e = live.cumsum(dim, dtype=torch.float32)
+            if self.normalize:
+                last = e.select(dim, e.shape[dim] - 1).unsqueeze(dim)
+                e = e / (last + 1e-6) * self.scale
+            axes.append(e)
+        k = torch.arange(self.num_pos_feats, dtype=torch.float32, device=mask.device)
+        freq = self.temperature ** (2 * torch.div(k, 2, rounding_mode="floor") / self.num_pos_feats)
+        parts = []
+        for e in axes:
+            ang = e[..., None] / freq                           # [b,t,h,w,F]
+            parts.append(torch.stack((ang[..., 0::2].sin(), ang[..., 1::2].cos()), dim=5).flatten(4))
+        return torch.cat(parts, dim=4).permute(0, 1, 4, 2, 3)   # (z, y, x) blocks -> [b,t,3F,h,w]
+
+
+class Joiner(nn.Sequential):
+    def __init__(self, backbone, position_embedding):
+        super().__init__(backbone, position_embedding)
+        self.strides = backbone.strides
+        self.num_channels = backbone.num_channels
+
+    def forward(self, tensor_list: NestedTensor):
+        xs = self[0](tensor_list)
+        out: List[NestedTensor] = [x for _, x in sorted(xs.items())]
+        pos = [self[1](x).to(x.tensors.dtype) for x in out]
+        return out, pos
+
+
+def build_position_encoding(args):
+    if args.position_embedding not in ("v2", "sine"):
+        raise ValueError(f"not supported {args.position_embedding}")
+    return PositionEmbeddingSine(args.hidden_dim // 3, num_frames=args.num_frames, normalize=True)
+
+
+def build_backbone(args):
+    backbone = Backbone(args.backbone, args.lr_backbone > 0,
+                        args.masks or (args.num_feature_levels > 1), args.dilation)
+    return Joiner(backbone, build_position_encoding(args))
