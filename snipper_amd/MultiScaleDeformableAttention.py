@@ -13,6 +13,7 @@ the reference's divisibility rule -- the HIP kernels take the whole batch in one
 """
 from __future__ import annotations
 
+import ctypes
 from typing import List
 
 import torch
@@ -129,10 +130,13 @@ def ms_deform_attn_forward(value: torch.Tensor, spatial_shapes: torch.Tensor,
 def ms_deform_attn_backward(value: torch.Tensor, spatial_shapes: torch.Tensor,
                             level_start_index: torch.Tensor, sampling_loc: torch.Tensor,
                             attn_weight: torch.Tensor, grad_output: torch.Tensor,
-                            im2col_step: int) -> List[torch.Tensor]:
+                            im2col_step: int, host_shapes=None) -> List[torch.Tensor]:
     """-> [grad_value, grad_sampling_loc, grad_attn_weight]   (ms_deform_attn_cuda.cu:83-153)
 
     For bfloat16 ``value`` the returned grad_value is bfloat16 (accumulated in float32).
+    ``host_shapes`` (extension, optional): the values of ``spatial_shapes`` as a host list
+    [(H, W), ...]; lets the library use its owner-computes kernels for the encoder shape
+    (include/snipper_msda.h, snipper_msda_backward_hs_f32) without a device-to-host copy.
     """
     _check_common([("value", value), ("spatial_shapes", spatial_shapes),
                    ("level_start_index", level_start_index), ("sampling_loc", sampling_loc),
@@ -150,13 +154,21 @@ def ms_deform_attn_backward(value: torch.Tensor, spatial_shapes: torch.Tensor,
     grad_loc = torch.empty_like(sampling_loc)
     grad_attn = torch.empty_like(attn_weight)
     lib = _lib.load()
-    fn = getattr(lib, "snipper_msda_backward_" + _SUFFIX[value.dtype])
     dims = dict(N=N, S=S, M=M, D=D, L=L, Lq=Lq, P=P, esize=value.element_size())
     with torch.cuda.device(value.device), _Timed("bwd", dims, value.device):
-        rc = fn(_stream(value.device), grad_output.data_ptr(), value.data_ptr(),
-                spatial_shapes.data_ptr(), level_start_index.data_ptr(), sampling_loc.data_ptr(),
+        if host_shapes is not None and value.dtype == torch.float32 and len(host_shapes) == L:
+            hs = (ctypes.c_int64 * (2 * L))(*[int(v) for hw in host_shapes for v in hw])
+            rc = lib.snipper_msda_backward_hs_f32(
+                _stream(value.device), grad_output.data_ptr(), value.data_ptr(), spatial_shapes.data_ptr(),
+                level_start_index.data_ptr(), ctypes.cast(hs, ctypes.c_void_p), sampling_loc.data_ptr(),
                 attn_weight.data_ptr(), N, S, M, D, L, Lq, P,
                 grad_value.data_ptr(), grad_loc.data_ptr(), grad_attn.data_ptr())
+        else:
+            fn = getattr(lib, "snipper_msda_backward_" + _SUFFIX[value.dtype])
+            rc = fn(_stream(value.device), grad_output.data_ptr(), value.data_ptr(),
+                    spatial_shapes.data_ptr(), level_start_index.data_ptr(), sampling_loc.data_ptr(),
+                    attn_weight.data_ptr(), N, S, M, D, L, Lq, P,
+                    grad_value.data_ptr(), grad_loc.data_ptr(), grad_attn.data_ptr())
     _lib.check(rc, "ms_deform_attn_backward")
     if grad_value.dtype != value.dtype:
         grad_value = grad_value.to(value.dtype)

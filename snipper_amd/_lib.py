@@ -21,6 +21,8 @@ EXPORTS = {
     "snipper_msda_strerror": ([c_int], c_char_p),
     "snipper_msda_last_variant": ([], c_char_p),
     "snipper_msda_set_policy": ([c_int], c_int),
+    "snipper_msda_set_param": ([c_char_p, ctypes.c_double], c_int),
+    "snipper_msda_backward_hs_f32": ([c_void_p] * 8 + [c_int] * 7 + [c_void_p] * 3, c_int),
     "snipper_msda_forward_f32": (_FWD_ARGS, c_int),
     "snipper_msda_forward_f64": (_FWD_ARGS, c_int),
     "snipper_msda_forward_bf16": (_FWD_ARGS, c_int),
@@ -83,3 +85,7 @@ def last_variant() -> str:
 
 def set_policy(policy: int) -> None:
     check(load().snipper_msda_set_policy(int(policy)), "snipper_msda_set_policy")
+
+
+def set_param(name: str, value: float) -> None:
+    check(load().snipper_msda_set_param(name.encode(), float(value)), f"snipper_msda_set_param({name})")

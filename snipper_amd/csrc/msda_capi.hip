@@ -8,9 +8,11 @@
 #include <hip/hip_runtime.h>
 #include <atomic>
 #include <cstdint>
+#include <string_view>
 
 #include "../../include/snipper_msda.h"
 #include "msda_d48.cuh"
+#include "msda_d48_owner.cuh"
 #include "msda_generic.cuh"
 
 using namespace snipper;
@@ -18,7 +20,9 @@ using namespace snipper;
 namespace {
 
 thread_local const char *g_last_variant = "none";
-std::atomic<int> g_policy{0};  // 0 auto, 1 generic only
+std::atomic<int> g_policy{0};  // 0 auto, 1 generic only, 2 no owner-computes path
+std::atomic<float> g_near_radius{6.0f};
+std::atomic<int> g_tile_edge[3] = {{16}, {8}, {4}};   // level area > 4096 px / > 1024 px / smaller
 
 int check_dims(int N, int S, int M, int D, int L, int Lq, int P) {
   if (N <= 0 || S <= 0 || M <= 0 || D <= 0 || L <= 0 || Lq <= 0 || P <= 0) return SNIPPER_E_SHAPE;
@@ -127,10 +131,85 @@ int backward_d48_f32(hipStream_t st, const float *grad_out, const float *value, 
   const size_t lds = (size_t)kRows * (LP * sizeof(BwdRecord) + 16);
   if (LP == 12 && d.P == 4) {
     g_last_variant = "d48_lp12";
-    hipLaunchKernelGGL((msda_bwd_d48_f32_kernel<12>), dim3(nblk_padded), dim3(kD48Block), lds, st, grad_out, value, shapes, lsi, loc, attn, d, grad_value, grad_loc, grad_attn, nblk_padded);
+    hipLaunchKernelGGL((msda_bwd_d48_f32_kernel<12, false>), dim3(nblk_padded), dim3(kD48Block), lds, st, grad_out, value, shapes, lsi, loc, attn, d, grad_value, grad_loc, grad_attn, nblk_padded, 0.f);
   } else {
     g_last_variant = "d48";
-    hipLaunchKernelGGL((msda_bwd_d48_f32_kernel<0>), dim3(nblk_padded), dim3(kD48Block), lds, st, grad_out, value, shapes, lsi, loc, attn, d, grad_value, grad_loc, grad_attn, nblk_padded);
+    hipLaunchKernelGGL((msda_bwd_d48_f32_kernel<0, false>), dim3(nblk_padded), dim3(kD48Block), lds, st, grad_out, value, shapes, lsi, loc, attn, d, grad_value, grad_loc, grad_attn, nblk_padded, 0.f);
+  }
+  return launch_status();
+}
+
+// ---- owner-computes path (msda_d48_owner.cuh): needs the level shapes on the HOST to size its grid ----
+bool owner_eligible(const CoreDims &d, const int64_t *hs) {
+  if (g_policy.load(std::memory_order_relaxed) != 0 || !hs) return false;
+  if (!d48_eligible<float>(d) || d.L > kOwnerMaxLevels || d.Lq != d.S) return false;
+  long long sum = 0;
+  for (int l = 0; l < d.L; ++l) {
+    if (hs[2 * l] <= 0 || hs[2 * l + 1] <= 0) return false;
+    sum += hs[2 * l] * hs[2 * l + 1];
+  }
+  return sum == d.S && d.S < (1 << 24);
+}
+
+OwnerPlan make_owner_plan(const CoreDims &d, const int64_t *hs) {
+  OwnerPlan p{};
+  p.L = d.L;
+  p.radius = g_near_radius.load(std::memory_order_relaxed);
+  int start = 0;
+  for (int l = 0; l < d.L; ++l) {
+    OwnerLevel &v = p.lv[l];
+    v.H = (int)hs[2 * l];
+    v.W = (int)hs[2 * l + 1];
+    v.start = start;
+    start += v.H * v.W;
+    const int area = v.H * v.W;
+    const int e = g_tile_edge[area > 4096 ? 0 : (area > 1024 ? 1 : 2)].load(std::memory_order_relaxed);
+    v.th = v.tw = e;
+    v.ntx = (v.W + e - 1) / e;
+    v.nty = (v.H + e - 1) / e;
+    if (e * e > p.max_tile_px) p.max_tile_px = e * e;
+  }
+  // launch order: coarse (small) levels first -- their tiles scan the most candidates
+  int base = 0;
+  for (int l = d.L - 1; l >= 0; --l) {
+    p.lv[l].tile_base = base;
+    base += p.lv[l].ntx * p.lv[l].nty;
+  }
+  p.total_tiles = base;
+  return p;
+}
+
+int backward_d48_owner_f32(hipStream_t st, const float *grad_out, const float *value, const int64_t *shapes,
+                           const int64_t *lsi, const int64_t *hs, const float *loc, const float *attn,
+                           CoreDims d, float *grad_value, float *grad_loc, float *grad_attn) {
+  const OwnerPlan plan = make_owner_plan(d, hs);
+  const size_t lds_owner = owner_lds_bytes(plan.max_tile_px);
+  static std::atomic<size_t> lds_granted{0};
+  if (lds_owner > 64 * 1024 && lds_granted.load() < lds_owner) {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_bwd_d48_owner_kernel),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_owner);
+    if (e != hipSuccess) return (int)e;
+    lds_granted.store(lds_owner);
+  }
+  const long long nblk_owner = (long long)plan.total_tiles * d.M * d.N;
+  if (nblk_owner >= (1LL << 31)) return SNIPPER_E_SHAPE;
+  // 1) every pixel of grad_value is written by its owner tile (no memset needed) ...
+  hipLaunchKernelGGL(msda_bwd_d48_owner_kernel, dim3((unsigned)nblk_owner), dim3(kOwnerBlock), lds_owner, st,
+                     grad_out, loc, attn, d, plan, grad_value);
+  if (int rc = launch_status()) return rc;
+  // 2) ... then grad_loc / grad_attn for all samples and HBM atomics for the far ones only
+  constexpr int kRows = kD48Block / 16;
+  const long long rows = (long long)d.N * d.Lq * d.M;
+  const int LP = d.L * d.P;
+  const int nblk = (int)((rows + kRows - 1) / kRows);
+  const int nblk_padded = (nblk + 7) & ~7;
+  const size_t lds = (size_t)kRows * (LP * sizeof(BwdRecord) + 16);
+  if (LP == 12 && d.P == 4) {
+    g_last_variant = "d48_owner_lp12";
+    hipLaunchKernelGGL((msda_bwd_d48_f32_kernel<12, true>), dim3(nblk_padded), dim3(kD48Block), lds, st, grad_out, value, shapes, lsi, loc, attn, d, grad_value, grad_loc, grad_attn, nblk_padded, plan.radius);
+  } else {
+    g_last_variant = "d48_owner";
+    hipLaunchKernelGGL((msda_bwd_d48_f32_kernel<0, true>), dim3(nblk_padded), dim3(kD48Block), lds, st, grad_out, value, shapes, lsi, loc, attn, d, grad_value, grad_loc, grad_attn, nblk_padded, plan.radius);
   }
   return launch_status();
 }
@@ -159,8 +238,24 @@ const char *snipper_msda_strerror(int code) {
 const char *snipper_msda_last_variant(void) { return g_last_variant; }
 
 int snipper_msda_set_policy(int policy) {
-  if (policy < 0 || policy > 1) return SNIPPER_E_UNSUPPORTED;
+  if (policy < 0 || policy > 2) return SNIPPER_E_UNSUPPORTED;
   g_policy.store(policy, std::memory_order_relaxed);
+  return SNIPPER_OK;
+}
+
+int snipper_msda_set_param(const char *name, double v) {
+  if (!name) return SNIPPER_E_NULL;
+  const std::string_view k(name);
+  auto edge_ok = [&](int e) { return e >= 1 && e * e <= kOwnerMaxTilePixels; };
+  if (k == "near_radius") {
+    if (!(v >= 0.0 && v <= 64.0)) return SNIPPER_E_SHAPE;
+    g_near_radius.store((float)v);
+  } else if (k == "owner_tile_edge_big" || k == "owner_tile_edge_mid" || k == "owner_tile_edge_small") {
+    if (!edge_ok((int)v)) return SNIPPER_E_SHAPE;
+    g_tile_edge[k == "owner_tile_edge_big" ? 0 : (k == "owner_tile_edge_mid" ? 1 : 2)].store((int)v);
+  } else {
+    return SNIPPER_E_UNSUPPORTED;
+  }
   return SNIPPER_OK;
 }
 
@@ -199,8 +294,7 @@ int snipper_msda_forward_bf16(void *stream, const uint16_t *value, const int64_t
     return SNIPPER_E_NULL;                                                                    \
   if (int rc = check_dims(N, S, M, D, L, Lq, P)) return rc;                                   \
   const CoreDims d{N, S, M, D, L, Lq, P};                                                     \
-  hipStream_t st = (hipStream_t)stream;                                                       \
-  if (int rc = zero_grad_value(st, grad_value, d)) return rc;
+  hipStream_t st = (hipStream_t)stream;
 
 int snipper_msda_backward_f32(void *stream, const float *grad_out, const float *value,
                               const int64_t *shapes, const int64_t *level_start,
@@ -208,9 +302,24 @@ int snipper_msda_backward_f32(void *stream, const float *grad_out, const float *
                               int N, int S, int M, int D, int L, int Lq, int P,
                               float *grad_value, float *grad_loc, float *grad_attn) {
   SNIPPER_CHECK_BWD();
+  if (int rc = zero_grad_value(st, grad_value, d)) return rc;
   if (d48_eligible<float>(d))
     return backward_d48_f32(st, grad_out, value, shapes, level_start, loc, attn, d, grad_value, grad_loc, grad_attn);
   return backward_generic<float, float, float>(st, grad_out, value, shapes, level_start, loc, attn, d, grad_value, grad_loc, grad_attn);
+}
+
+int snipper_msda_backward_hs_f32(void *stream, const float *grad_out, const float *value,
+                                 const int64_t *shapes, const int64_t *level_start,
+                                 const int64_t *host_shapes,
+                                 const float *loc, const float *attn,
+                                 int N, int S, int M, int D, int L, int Lq, int P,
+                                 float *grad_value, float *grad_loc, float *grad_attn) {
+  SNIPPER_CHECK_BWD();
+  if (owner_eligible(d, host_shapes))
+    return backward_d48_owner_f32(st, grad_out, value, shapes, level_start, host_shapes, loc, attn, d,
+                                  grad_value, grad_loc, grad_attn);
+  return snipper_msda_backward_f32(stream, grad_out, value, shapes, level_start, loc, attn, N, S, M, D, L, Lq, P,
+                                   grad_value, grad_loc, grad_attn);
 }
 
 int snipper_msda_backward_f64(void *stream, const double *grad_out, const double *value,
@@ -219,6 +328,7 @@ int snipper_msda_backward_f64(void *stream, const double *grad_out, const double
                               int N, int S, int M, int D, int L, int Lq, int P,
                               double *grad_value, double *grad_loc, double *grad_attn) {
   SNIPPER_CHECK_BWD();
+  if (int rc = zero_grad_value(st, grad_value, d)) return rc;
   return backward_generic<double, double, double>(st, grad_out, value, shapes, level_start, loc, attn, d, grad_value, grad_loc, grad_attn);
 }
 
@@ -228,6 +338,7 @@ int snipper_msda_backward_bf16(void *stream, const uint16_t *grad_out, const uin
                                int N, int S, int M, int D, int L, int Lq, int P,
                                float *grad_value, float *grad_loc, float *grad_attn) {
   SNIPPER_CHECK_BWD();
+  if (int rc = zero_grad_value(st, grad_value, d)) return rc;
   return backward_generic<uint16_t, float, float>(st, grad_out, value, shapes, level_start, loc, attn, d, grad_value, grad_loc, grad_attn);
 }
 

@@ -27,6 +27,8 @@ class MSDeformAttnFunction(Function):
     def forward(ctx, value, value_spatial_shapes, value_level_start_index,
                 sampling_locations, attention_weights, im2col_step):
         ctx.im2col_step = im2col_step
+        # host copy of the level shapes, when our transformer attached one (spares a device sync)
+        ctx.host_shapes = getattr(value_spatial_shapes, "_snipper_host", None)
         if value.dtype == torch.bfloat16:   # coordinates and weights stay fp32 beside bf16 values
             sampling_locations = sampling_locations.float()
             attention_weights = attention_weights.float()
@@ -41,7 +43,8 @@ class MSDeformAttnFunction(Function):
     def backward(ctx, grad_output):
         value, shapes, lsi, loc, attn = ctx.saved_tensors
         grad_value, grad_loc, grad_attn = MSDA.ms_deform_attn_backward(
-            value, shapes, lsi, loc, attn, grad_output.contiguous(), ctx.im2col_step)
+            value, shapes, lsi, loc, attn, grad_output.contiguous(), ctx.im2col_step,
+            host_shapes=ctx.host_shapes)
         return grad_value, None, None, grad_loc, grad_attn, None   # reference :42
 
 

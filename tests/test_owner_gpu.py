@@ -1,0 +1,124 @@
+"""GPU tests of the owner-computes backward (csrc/msda_d48_owner.cuh), ``-m gpu``.
+
+The path is taken when the host knows the level shapes, D == 48 and Lq == S (encoder).  Its result
+must be the same function of the inputs for ANY locations: near samples are accumulated in LDS by
+the tile owners, far ones by HBM atomics; the split must be a partition.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import msda_oracle as O
+from snipper_amd import MultiScaleDeformableAttention as MSDA
+from snipper_amd import _lib
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def grid_case(N, shapes, M, P, seed, spread_px, frac_far=0.0, dtype=np.float32):
+    """Encoder-like inputs: Lq == S, query q sits on pixel q; offsets ~ N(0, spread_px) pixels, a
+    fraction `frac_far` of samples uniformly anywhere (incl. outside the map)."""
+    rng = np.random.RandomState(seed)
+    shapes = np.asarray(shapes, dtype=np.int64)
+    L = len(shapes)
+    S = int((shapes[:, 0] * shapes[:, 1]).sum())
+    refs = []
+    for h, w in shapes:
+        ys, xs = np.meshgrid(np.arange(h) + 0.5, np.arange(w) + 0.5, indexing="ij")
+        refs.append(np.stack([xs.reshape(-1) / w, ys.reshape(-1) / h], -1))
+    ref = np.concatenate(refs)[None, :, None, None, None, :]
+    norm = np.array([[w, h] for h, w in shapes], dtype=np.float64)[None, None, None, :, None, :]
+    loc = ref + rng.standard_normal((N, S, M, L, P, 2)) * spread_px / norm
+    far = rng.uniform(size=(N, S, M, L, P, 1)) < frac_far
+    loc = np.where(far, rng.uniform(-0.2, 1.2, loc.shape), loc)
+    loc = ((np.round(loc * 4096) + 0.5) / 4096).astype(dtype)     # exact pixel coordinates (see test_msda_gpu)
+    value = rng.standard_normal((N, S, M, 48)).astype(dtype)
+    attn = rng.uniform(0, 1, (N, S, M, L, P)).astype(dtype)
+    attn /= attn.sum((-1, -2), keepdims=True)
+    go = rng.standard_normal((N, S, M * 48)).astype(dtype)
+    return value, shapes, O.level_start_index(shapes), loc, attn, go
+
+
+def run_hip(v, shapes, lsi, loc, attn, go, host_shapes):
+    t = lambda a: torch.from_numpy(a).to(DEV)
+    out = MSDA.ms_deform_attn_backward(t(v), t(shapes), t(lsi), t(loc), t(attn), t(go), 64, host_shapes=host_shapes)
+    return [x.cpu().numpy() for x in out], _lib.last_variant()
+
+
+CASES = {
+    "snipper_small_local": (2, [(19, 25), (10, 13), (5, 7)], 8, 4, 2.0, 0.0),
+    "snipper_small_mixed": (2, [(19, 25), (10, 13), (5, 7)], 8, 4, 3.0, 0.2),
+    "all_far": (1, [(19, 25), (10, 13), (5, 7)], 3, 4, 1.0, 1.0),
+    "big_level_tiles16": (1, [(70, 67), (35, 34)], 2, 2, 4.0, 0.05),       # 4690 px -> 16x16 tiles, ragged edges
+    "single_level": (3, [(9, 31)], 5, 3, 2.5, 0.1),
+    "four_levels_runtime_lp": (1, [(24, 20), (12, 10), (6, 5), (3, 3)], 4, 1, 2.0, 0.1),
+}
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_owner_backward_matches_oracle(name):
+    N, shapes, M, P, spread, far = CASES[name]
+    v, sh, lsi, loc, attn, go = grid_case(N, shapes, M, P, seed=len(name), spread_px=spread, frac_far=far)
+    f64 = lambda a: a.astype(np.float64)
+    ref = O.core_c_backward(f64(v), sh, lsi, f64(loc), f64(attn), f64(go), threads=4)
+    (gv, gl, ga), variant = run_hip(v, sh, lsi, loc, attn, go, [tuple(x) for x in sh.tolist()])
+    assert variant.startswith("d48_owner"), variant
+    np.testing.assert_allclose(gv, ref[0], rtol=1e-4, atol=5e-5)
+    s = float(np.abs(ref[1]).max())
+    np.testing.assert_allclose(gl / s, ref[1] / s, rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(ga, ref[2], rtol=1e-4, atol=1e-4)
+    # and against the atomics-only path of the same library (no host shapes)
+    (gv2, gl2, ga2), variant2 = run_hip(v, sh, lsi, loc, attn, go, None)
+    assert variant2.startswith("d48") and "owner" not in variant2
+    np.testing.assert_allclose(gv, gv2, rtol=1e-4, atol=5e-5)
+    np.testing.assert_array_equal(gl, gl2)          # grad_loc / grad_attn do not depend on the split
+    np.testing.assert_array_equal(ga, ga2)
+
+
+@pytest.mark.parametrize("radius", [0.0, 0.75, 3.0, 40.0])
+@pytest.mark.parametrize("edges", [(16, 8, 4), (8, 8, 8), (4, 4, 2), (16, 16, 16)])
+def test_partition_holds_for_any_radius_and_tiling(radius, edges):
+    """Whatever the near radius / tile sizes, near + far must add up to the same gradient."""
+    v, sh, lsi, loc, attn, go = grid_case(2, [(21, 26), (11, 13), (6, 7)], 4, 4, seed=5, spread_px=2.5, frac_far=0.1)
+    f64 = lambda a: a.astype(np.float64)
+    ref = O.core_c_backward(f64(v), sh, lsi, f64(loc), f64(attn), f64(go), threads=4)[0]
+    try:
+        _lib.set_param("near_radius", radius)
+        for k, e in zip(("big", "mid", "small"), edges):
+            _lib.set_param(f"owner_tile_edge_{k}", e)
+        (gv, _, _), variant = run_hip(v, sh, lsi, loc, attn, go, [tuple(x) for x in sh.tolist()])
+    finally:
+        _lib.set_param("near_radius", 6.0)
+        for k, e in zip(("big", "mid", "small"), (16, 8, 4)):
+            _lib.set_param(f"owner_tile_edge_{k}", e)
+    assert variant.startswith("d48_owner")
+    np.testing.assert_allclose(gv, ref, rtol=1e-4, atol=5e-5)
+
+
+def test_owner_not_taken_when_not_encoder_shape():
+    v, sh, lsi, loc, attn, go = grid_case(1, [(9, 8), (4, 4)], 2, 2, seed=1, spread_px=1.0)
+    Lq = 10
+    (_, _, _), variant = run_hip(v, sh, lsi, loc[:, :Lq].copy(), attn[:, :Lq].copy(), go[:, :Lq].copy(),
+                                 [tuple(x) for x in sh.tolist()])
+    assert "owner" not in variant
+    with pytest.raises(RuntimeError):
+        _lib.set_param("no_such_knob", 1.0)
+
+
+def test_full_size_encoder_backward_owner_vs_atomics():
+    """BASELINE geometry (600x800 -> 9875 tokens, N=2): owner path == atomics path, and the gradient
+    checksum identity holds:  sum(grad_value) == <out(value=1), grad_out>."""
+    shapes = [(75, 100), (38, 50), (19, 25)]
+    v, sh, lsi, loc, attn, go = grid_case(2, shapes, 8, 4, seed=3, spread_px=3.0, frac_far=0.01)
+    (gv, gl, ga), variant = run_hip(v, sh, lsi, loc, attn, go, shapes)
+    assert variant == "d48_owner_lp12"
+    (gv2, gl2, ga2), _ = run_hip(v, sh, lsi, loc, attn, go, None)
+    np.testing.assert_allclose(gv, gv2, rtol=2e-4, atol=2e-4)
+    np.testing.assert_array_equal(gl, gl2)
+    t = lambda a: torch.from_numpy(a).to(DEV)
+    ones = torch.ones_like(t(v))
+    out1 = MSDA.ms_deform_attn_forward(ones, t(sh), t(lsi), t(loc), t(attn), 64)
+    (gv1, _, _), _ = run_hip(np.ones_like(v), sh, lsi, loc, attn, go, shapes)
+    lhs, rhs = float(gv1.astype(np.float64).sum()), float((out1.double() * t(go).double()).sum())
+    assert abs(lhs - rhs) <= 1e-5 * float(np.abs(go).sum())

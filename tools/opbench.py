@@ -67,16 +67,29 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--N", type=int, nargs="+", default=[1, 2, 8])
     ap.add_argument("--skip-torch", action="store_true")
+    ap.add_argument("--owner", type=int, default=1, help="pass host shapes (owner-computes backward)")
+    ap.add_argument("--radius", type=float, default=None)
+    ap.add_argument("--edges", type=int, nargs=3, default=None)
+    ap.add_argument("--cases", nargs="+", default=["enc_local", "enc_uniform", "dec"])
+    ap.add_argument("--dtypes", nargs="+", default=["float32", "bfloat16"])
     args = ap.parse_args()
     S = sum(h * w for h, w in SHAPES)
+    if args.radius is not None:
+        _lib.set_param("near_radius", args.radius)
+    if args.edges:
+        for k, e in zip(("big", "mid", "small"), args.edges):
+            _lib.set_param(f"owner_tile_edge_{k}", e)
     for N in args.N:
         for name, Lq, local in [("enc_local", S, True), ("enc_uniform", S, False), ("dec", 60, False)]:
-            for dtype in (torch.float32, torch.bfloat16):
+            if name not in args.cases:
+                continue
+            for dtype in [getattr(torch, x) for x in args.dtypes]:
                 v, shapes, lsi, loc, attn, go = make(N, Lq, local, dtype)
                 for policy in ((0, 1) if dtype == torch.float32 else (0,)):
                     _lib.set_policy(policy)
                     f = lambda: MSDA.ms_deform_attn_forward(v, shapes, lsi, loc, attn, 64)
-                    b = lambda: MSDA.ms_deform_attn_backward(v, shapes, lsi, loc, attn, go, 64)
+                    hs = SHAPES if (policy == 0 and args.owner) else None
+                    b = lambda: MSDA.ms_deform_attn_backward(v, shapes, lsi, loc, attn, go, 64, host_shapes=hs)
                     f(); var_f = _lib.last_variant()
                     b(); var_b = _lib.last_variant()
                     tf, tf0 = timeit(f, args.iters)
