@@ -68,8 +68,10 @@ const char *snipper_msda_last_variant(void);
 /* Kernel-variant policy for tests and benchmarks: 0 = auto (tuned kernels where eligible),
  * 1 = generic kernels only.  Process-wide; returns 0 or SNIPPER_E_UNSUPPORTED. */
 int snipper_msda_set_policy(int policy);   /* 2 = tuned kernels but never the owner-computes backward */
-/* Tuning knobs (tests / benchmarks): "near_radius" (pixels, default 6), "owner_tile_edge_big" /
- * "_mid" / "_small" (tile edge for levels of > 4096 / > 1024 / fewer pixels; default 16 / 8 / 4). */
+/* Tuning knobs (tests / benchmarks): "owner_enable" (0/1, default 0: the owner-computes backward is
+ * experimental and currently slower than the atomic kernel), "near_radius" (pixels,
+ * default 6), "owner_tile_edge_big" / "_mid" / "_small" (tile edge for levels of > 4096 / > 1024 /
+ * fewer pixels; default 16 / 8 / 4), "owner_debug" (timing ablations; wrong results when != 0). */
 int snipper_msda_set_param(const char *name, double value);
 
 /* ---- core op: replaces ms_deformable_im2col_cuda (.cuh:923-954) ------------------ */
@@ -95,7 +97,7 @@ int snipper_msda_backward_f32(void *stream, const float *grad_out, const float *
 /* Same contract as snipper_msda_backward_f32 plus `host_shapes`: the SAME [L,2] (H,W) values as
  * `shapes`, readable by the host (NULL = unknown).  With them, D == 48 and Lq == S == sum(H*W) --
  * the encoder's self-attention, whose queries are the pixels of the L maps in level-major raster
- * order -- grad_value is built by the owner-computes kernels (csrc/msda_d48_owner.cuh): LDS
+ * order -- and "owner_enable" set, grad_value is built by the owner-computes kernels (csrc/msda_d48_owner.cuh): LDS
  * accumulation per tile and plain stores instead of HBM float atomics.  The result is the same
  * function of the inputs for ANY locations; only the speed depends on how local they are. */
 int snipper_msda_backward_hs_f32(void *stream, const float *grad_out, const float *value,

@@ -22,6 +22,8 @@ namespace {
 thread_local const char *g_last_variant = "none";
 std::atomic<int> g_policy{0};  // 0 auto, 1 generic only, 2 no owner-computes path
 std::atomic<float> g_near_radius{6.0f};
+std::atomic<int> g_owner_debug{0};
+std::atomic<int> g_owner_enable{0};   // experimental path, off by default ('owner-computes backward')
 std::atomic<int> g_tile_edge[3] = {{16}, {8}, {4}};   // level area > 4096 px / > 1024 px / smaller
 
 int check_dims(int N, int S, int M, int D, int L, int Lq, int P) {
@@ -141,8 +143,8 @@ int backward_d48_f32(hipStream_t st, const float *grad_out, const float *value, 
 
 // ---- owner-computes path (msda_d48_owner.cuh): needs the level shapes on the HOST to size its grid ----
 bool owner_eligible(const CoreDims &d, const int64_t *hs) {
-  if (g_policy.load(std::memory_order_relaxed) != 0 || !hs) return false;
-  if (!d48_eligible<float>(d) || d.L > kOwnerMaxLevels || d.Lq != d.S) return false;
+  if (g_policy.load(std::memory_order_relaxed) != 0 || !hs || !g_owner_enable.load(std::memory_order_relaxed)) return false;
+  if (!d48_eligible<float>(d) || d.L > kOwnerMaxLevels || d.P > kOwnerMaxPoints || d.Lq != d.S) return false;
   long long sum = 0;
   for (int l = 0; l < d.L; ++l) {
     if (hs[2 * l] <= 0 || hs[2 * l + 1] <= 0) return false;
@@ -155,6 +157,7 @@ OwnerPlan make_owner_plan(const CoreDims &d, const int64_t *hs) {
   OwnerPlan p{};
   p.L = d.L;
   p.radius = g_near_radius.load(std::memory_order_relaxed);
+  p.debug = g_owner_debug.load(std::memory_order_relaxed);
   int start = 0;
   for (int l = 0; l < d.L; ++l) {
     OwnerLevel &v = p.lv[l];
@@ -183,7 +186,7 @@ int backward_d48_owner_f32(hipStream_t st, const float *grad_out, const float *v
                            const int64_t *lsi, const int64_t *hs, const float *loc, const float *attn,
                            CoreDims d, float *grad_value, float *grad_loc, float *grad_attn) {
   const OwnerPlan plan = make_owner_plan(d, hs);
-  const size_t lds_owner = owner_lds_bytes(plan.max_tile_px);
+  const size_t lds_owner = owner_lds_bytes(plan.max_tile_px, d.P);
   static std::atomic<size_t> lds_granted{0};
   if (lds_owner > 64 * 1024 && lds_granted.load() < lds_owner) {
     const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_bwd_d48_owner_kernel),
@@ -253,6 +256,10 @@ int snipper_msda_set_param(const char *name, double v) {
   } else if (k == "owner_tile_edge_big" || k == "owner_tile_edge_mid" || k == "owner_tile_edge_small") {
     if (!edge_ok((int)v)) return SNIPPER_E_SHAPE;
     g_tile_edge[k == "owner_tile_edge_big" ? 0 : (k == "owner_tile_edge_mid" ? 1 : 2)].store((int)v);
+  } else if (k == "owner_debug") {
+    g_owner_debug.store((int)v);
+  } else if (k == "owner_enable") {
+    g_owner_enable.store(v != 0.0);
   } else {
     return SNIPPER_E_UNSUPPORTED;
   }

@@ -16,6 +16,14 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
+@pytest.fixture(autouse=True)
+def _owner_enabled():
+    """The path is opt-in (experimental: correct, but not yet faster than the atomic kernel)."""
+    _lib.set_param("owner_enable", 1)
+    yield
+    _lib.set_param("owner_enable", 0)
+
+
 def grid_case(N, shapes, M, P, seed, spread_px, frac_far=0.0, dtype=np.float32):
     """Encoder-like inputs: Lq == S, query q sits on pixel q; offsets ~ N(0, spread_px) pixels, a
     fraction `frac_far` of samples uniformly anywhere (incl. outside the map)."""
