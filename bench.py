@@ -119,7 +119,7 @@ def cpu_baseline(a, budget_s=40.0):
     shapes = [(-(-a.height // s), -(-a.width // s)) for s in (8, 16, 32)]
     S = sum(h * w for h, w in shapes)
     C, M, L, P, T = a.hidden_dim, 8, 3, 4, a.frames
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 32)      # more threads than this only slow torch's CPU grid_sample down
     torch.set_num_threads(cores)
     g = torch.Generator().manual_seed(0)
     r = lambda *s: torch.randn(*s, generator=g)

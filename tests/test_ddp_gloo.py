@@ -1,0 +1,98 @@
+"""World-size-2 data-parallel step on CPU (gloo): the N>1 path of bench.py, minus the GPUs.
+
+Same code path as the benchmark (model assembly, surrogate loss, the three AdamW groups,
+DistributedDataParallel with the bench's options); the core op runs through the reference's
+pure-PyTorch switch because HIP kernels cannot run here.
+"""
+import importlib.util
+import os
+import socket
+import sys
+from types import SimpleNamespace
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench():
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+ARGS = SimpleNamespace(hidden_dim=96, enc_layers=1, dec_layers=2, frames=2, future_frames=1,
+                       use_pytorch_deform=1, batch=1, height=64, width=96)
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    b = _bench()
+    from snipper_amd.model import build_model
+    torch.manual_seed(0)
+    model = build_model(b.model_args(ARGS))
+    model.train()
+    for mod in model.modules():          # dropout off: the single-process reference below must match
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+        if isinstance(mod, torch.nn.MultiheadAttention):
+            mod.dropout = 0.0
+    ddp = torch.nn.parallel.DistributedDataParallel(model, broadcast_buffers=False, gradient_as_bucket_view=True,
+                                                    bucket_cap_mb=50, static_graph=True)
+    opt = b.build_optimizer(model)
+    imgs, tgt = b.make_batches(ARGS, "cpu", 1, seed=1000 + rank)[0]
+    for it in range(2):
+        out, _ = ddp(list(imgs))
+        loss = b.surrogate_loss(out, tgt)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        if it == 0:
+            grads = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 0.1)
+        opt.step()
+    torch.save({"grads": grads, "params": {k: p.detach().clone() for k, p in model.named_parameters()},
+                "loss": float(loss)}, os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_step_matches_single_process(tmp_path):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = (torch.load(tmp_path / f"rank{r}.pt") for r in (0, 1))
+    # (1) replicas stay identical
+    for k in r0["params"]:
+        torch.testing.assert_close(r0["params"][k], r1["params"][k], rtol=0, atol=0, msg=lambda m: f"{k}: {m}")
+    # (2) the all-reduced gradient of step 0 is the mean of the two ranks' local gradients
+    b = _bench()
+    from snipper_amd.model import build_model
+    torch.manual_seed(0)
+    model = build_model(b.model_args(ARGS))
+    model.train()
+    for mod in model.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+        if isinstance(mod, torch.nn.MultiheadAttention):
+            mod.dropout = 0.0
+    acc = None
+    for rank in (0, 1):
+        imgs, tgt = b.make_batches(ARGS, "cpu", 1, seed=1000 + rank)[0]
+        out, _ = model(list(imgs))
+        model.zero_grad(set_to_none=True)
+        b.surrogate_loss(out, tgt).backward()
+        g = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+        acc = g if acc is None else {k: acc[k] + g[k] for k in g}
+    assert set(acc) == set(r0["grads"])
+    for k, v in acc.items():
+        torch.testing.assert_close(r0["grads"][k], v / 2, rtol=2e-4, atol=2e-6, msg=lambda m: f"{k}: {m}")
+    # frozen parts (conv1 + layer1) never receive gradients
+    assert not any(k.startswith("backbone.0.body.layer1") or k.startswith("backbone.0.body.conv1") for k in acc)
