@@ -68,10 +68,10 @@ const char *snipper_msda_last_variant(void);
 /* Kernel-variant policy for tests and benchmarks: 0 = auto (tuned kernels where eligible),
  * 1 = generic kernels only.  Process-wide; returns 0 or SNIPPER_E_UNSUPPORTED. */
 int snipper_msda_set_policy(int policy);   /* 2 = tuned kernels but never the owner-computes backward */
-/* Tuning knobs (tests / benchmarks): "owner_enable" (0/1, default 0: the owner-computes backward is
- * experimental and currently slower than the atomic kernel), "near_radius" (pixels,
- * default 6), "owner_tile_edge_big" / "_mid" / "_small" (tile edge for levels of > 4096 / > 1024 /
- * fewer pixels; default 16 / 8 / 4), "owner_debug" (timing ablations; wrong results when != 0). */
+/* Tuning knobs (tests / benchmarks): "owner_enable" (0/1, default 1: owner-computes backward when
+ * a host copy of the shapes and a workspace are supplied), "near_radius" (pixels,
+ * default 6), "owner_tile_edge_big" / "_mid" / "_small" (tile edge, a power of two <= 16, for levels of > 4096 /
+ * > 1024 / fewer pixels; default 16 / 8 / 4), "owner_debug" (timing ablations; wrong results when != 0). */
 int snipper_msda_set_param(const char *name, double value);
 
 /* ---- core op: replaces ms_deformable_im2col_cuda (.cuh:923-954) ------------------ */
@@ -94,15 +94,22 @@ int snipper_msda_backward_f32(void *stream, const float *grad_out, const float *
                               const float *loc, const float *attn,
                               int N, int S, int M, int D, int L, int Lq, int P,
                               float *grad_value, float *grad_loc, float *grad_attn);
-/* Same contract as snipper_msda_backward_f32 plus `host_shapes`: the SAME [L,2] (H,W) values as
- * `shapes`, readable by the host (NULL = unknown).  With them, D == 48 and Lq == S == sum(H*W) --
- * the encoder's self-attention, whose queries are the pixels of the L maps in level-major raster
- * order -- and "owner_enable" set, grad_value is built by the owner-computes kernels (csrc/msda_d48_owner.cuh): LDS
- * accumulation per tile and plain stores instead of HBM float atomics.  The result is the same
- * function of the inputs for ANY locations; only the speed depends on how local they are. */
-int snipper_msda_backward_hs_f32(void *stream, const float *grad_out, const float *value,
+/* Owner-computes backward (csrc/msda_d48_owner.cuh); "owner_enable" = 0 switches it off.
+ * Same contract as snipper_msda_backward_f32 plus
+ *   host_shapes : the SAME [L,2] (H,W) values as `shapes`, readable by the host (NULL = unknown);
+ *   workspace   : device scratch of at least snipper_msda_backward_workspace_bytes(...) bytes
+ *                 (the library never allocates); contents are overwritten.
+ * With D == 48, P == 4, L <= 4 and Lq == S == sum(H*W) -- the encoder's self-attention, whose queries
+ * are the pixels of the L maps in level-major raster order -- grad_value is summed per tile by owner
+ * workgroups instead of per tap by HBM float atomics.  The result is the same function of the inputs
+ * for ANY locations; only the speed depends on how local they are.  Whenever the shape, the knobs or
+ * the workspace do not qualify, the call is exactly snipper_msda_backward_f32.
+ * snipper_msda_backward_workspace_bytes returns 0 when the fast path would not be taken. */
+long long snipper_msda_backward_workspace_bytes(int N, int S, int M, int D, int L, int Lq, int P,
+                                                const int64_t *host_shapes);
+int snipper_msda_backward_ws_f32(void *stream, const float *grad_out, const float *value,
                                  const int64_t *shapes, const int64_t *level_start,
-                                 const int64_t *host_shapes,
+                                 const int64_t *host_shapes, void *workspace, long long workspace_bytes,
                                  const float *loc, const float *attn,
                                  int N, int S, int M, int D, int L, int Lq, int P,
                                  float *grad_value, float *grad_loc, float *grad_attn);

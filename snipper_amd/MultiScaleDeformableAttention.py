@@ -156,11 +156,16 @@ def ms_deform_attn_backward(value: torch.Tensor, spatial_shapes: torch.Tensor,
     lib = _lib.load()
     dims = dict(N=N, S=S, M=M, D=D, L=L, Lq=Lq, P=P, esize=value.element_size())
     with torch.cuda.device(value.device), _Timed("bwd", dims, value.device):
+        ws_bytes = 0
         if host_shapes is not None and value.dtype == torch.float32 and len(host_shapes) == L:
             hs = (ctypes.c_int64 * (2 * L))(*[int(v) for hw in host_shapes for v in hw])
-            rc = lib.snipper_msda_backward_hs_f32(
+            hs_p = ctypes.cast(hs, ctypes.c_void_p)
+            ws_bytes = lib.snipper_msda_backward_workspace_bytes(N, S, M, D, L, Lq, P, hs_p)
+        if ws_bytes > 0:
+            workspace = torch.empty(ws_bytes, dtype=torch.uint8, device=value.device)
+            rc = lib.snipper_msda_backward_ws_f32(
                 _stream(value.device), grad_output.data_ptr(), value.data_ptr(), spatial_shapes.data_ptr(),
-                level_start_index.data_ptr(), ctypes.cast(hs, ctypes.c_void_p), sampling_loc.data_ptr(),
+                level_start_index.data_ptr(), hs_p, workspace.data_ptr(), ws_bytes, sampling_loc.data_ptr(),
                 attn_weight.data_ptr(), N, S, M, D, L, Lq, P,
                 grad_value.data_ptr(), grad_loc.data_ptr(), grad_attn.data_ptr())
         else:

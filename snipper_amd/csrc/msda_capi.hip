@@ -23,7 +23,8 @@ thread_local const char *g_last_variant = "none";
 std::atomic<int> g_policy{0};  // 0 auto, 1 generic only, 2 no owner-computes path
 std::atomic<float> g_near_radius{6.0f};
 std::atomic<int> g_owner_debug{0};
-std::atomic<int> g_owner_enable{0};   // experimental path, off by default ('owner-computes backward')
+std::atomic<int> g_owner_chunk{64};
+std::atomic<int> g_owner_enable{1};   // owner-computes backward for the encoder shape
 std::atomic<int> g_tile_edge[3] = {{16}, {8}, {4}};   // level area > 4096 px / > 1024 px / smaller
 
 int check_dims(int N, int S, int M, int D, int L, int Lq, int P) {
@@ -133,18 +134,17 @@ int backward_d48_f32(hipStream_t st, const float *grad_out, const float *value, 
   const size_t lds = (size_t)kRows * (LP * sizeof(BwdRecord) + 16);
   if (LP == 12 && d.P == 4) {
     g_last_variant = "d48_lp12";
-    hipLaunchKernelGGL((msda_bwd_d48_f32_kernel<12, false>), dim3(nblk_padded), dim3(kD48Block), lds, st, grad_out, value, shapes, lsi, loc, attn, d, grad_value, grad_loc, grad_attn, nblk_padded, 0.f);
+    hipLaunchKernelGGL((msda_bwd_d48_f32_kernel<12>), dim3(nblk_padded), dim3(kD48Block), lds, st, grad_out, value, shapes, lsi, loc, attn, d, grad_value, grad_loc, grad_attn, nblk_padded);
   } else {
     g_last_variant = "d48";
-    hipLaunchKernelGGL((msda_bwd_d48_f32_kernel<0, false>), dim3(nblk_padded), dim3(kD48Block), lds, st, grad_out, value, shapes, lsi, loc, attn, d, grad_value, grad_loc, grad_attn, nblk_padded, 0.f);
+    hipLaunchKernelGGL((msda_bwd_d48_f32_kernel<0>), dim3(nblk_padded), dim3(kD48Block), lds, st, grad_out, value, shapes, lsi, loc, attn, d, grad_value, grad_loc, grad_attn, nblk_padded);
   }
   return launch_status();
 }
 
-// ---- owner-computes path (msda_d48_owner.cuh): needs the level shapes on the HOST to size its grid ----
-bool owner_eligible(const CoreDims &d, const int64_t *hs) {
-  if (g_policy.load(std::memory_order_relaxed) != 0 || !hs || !g_owner_enable.load(std::memory_order_relaxed)) return false;
-  if (!d48_eligible<float>(d) || d.L > kOwnerMaxLevels || d.P > kOwnerMaxPoints || d.Lq != d.S) return false;
+// ---- owner-computes path (msda_d48_owner.cuh): needs the level shapes on the HOST and a workspace ----
+bool owner_shape_ok(const CoreDims &d, const int64_t *hs) {
+  if (!hs || !d48_eligible<float>(d) || d.L > kOwnerMaxLevels || d.P != kOwnerP || d.Lq != d.S) return false;
   long long sum = 0;
   for (int l = 0; l < d.L; ++l) {
     if (hs[2 * l] <= 0 || hs[2 * l + 1] <= 0) return false;
@@ -158,7 +158,7 @@ OwnerPlan make_owner_plan(const CoreDims &d, const int64_t *hs) {
   p.L = d.L;
   p.radius = g_near_radius.load(std::memory_order_relaxed);
   p.debug = g_owner_debug.load(std::memory_order_relaxed);
-  int start = 0;
+  int start = 0, base = 0;
   for (int l = 0; l < d.L; ++l) {
     OwnerLevel &v = p.lv[l];
     v.H = (int)hs[2 * l];
@@ -167,53 +167,65 @@ OwnerPlan make_owner_plan(const CoreDims &d, const int64_t *hs) {
     start += v.H * v.W;
     const int area = v.H * v.W;
     const int e = g_tile_edge[area > 4096 ? 0 : (area > 1024 ? 1 : 2)].load(std::memory_order_relaxed);
-    v.th = v.tw = e;
-    v.ntx = (v.W + e - 1) / e;
-    v.nty = (v.H + e - 1) / e;
-    if (e * e > p.max_tile_px) p.max_tile_px = e * e;
-  }
-  // launch order: coarse (small) levels first -- their tiles scan the most candidates
-  int base = 0;
-  for (int l = d.L - 1; l >= 0; --l) {
-    p.lv[l].tile_base = base;
-    base += p.lv[l].ntx * p.lv[l].nty;
+    v.shift = e >= 16 ? 4 : (e >= 8 ? 3 : (e >= 4 ? 2 : (e >= 2 ? 1 : 0)));
+    const int edge = 1 << v.shift;
+    v.ntx = (v.W + edge - 1) / edge;
+    v.nty = (v.H + edge - 1) / edge;
+    v.tile_base = base;
+    base += v.ntx * v.nty;
   }
   p.total_tiles = base;
+  // byte-map geometry: bounds of the candidate rectangles (msda_d48_owner.cuh, anchor_range: the span
+  // (edge + 1 + 2R) pixels of level l rescaled to level lq, +2 cells of margin, +2 for rounding)
+  long long lvl_base = 0;
+  for (int l = 0; l < d.L; ++l) {
+    const int edge = 1 << p.lv[l].shift;
+    int off = 0;
+    for (int lq = 0; lq < d.L; ++lq) {
+      const double span = (double)edge + 1.0 + 2.0 * p.radius;
+      int rw = (int)(span * p.lv[lq].W / p.lv[l].W) + 5, rh = (int)(span * p.lv[lq].H / p.lv[l].H) + 5;
+      if (rw > p.lv[lq].W) rw = p.lv[lq].W;
+      if (rh > p.lv[lq].H) rh = p.lv[lq].H;
+      p.rw[l][lq] = rw;
+      p.rh[l][lq] = rh;
+      p.coff[l][lq] = off;
+      off += rw * rh;
+    }
+    p.tstride[l] = (off + 15) & ~15;
+    p.lvl_base[l] = lvl_base;
+    lvl_base += (long long)p.lv[l].ntx * p.lv[l].nty * p.tstride[l];
+  }
+  p.bytes_per_nm = lvl_base;
   return p;
 }
 
-int backward_d48_owner_f32(hipStream_t st, const float *grad_out, const float *value, const int64_t *shapes,
-                           const int64_t *lsi, const int64_t *hs, const float *loc, const float *attn,
-                           CoreDims d, float *grad_value, float *grad_loc, float *grad_attn) {
-  const OwnerPlan plan = make_owner_plan(d, hs);
-  const size_t lds_owner = owner_lds_bytes(plan.max_tile_px, d.P);
-  static std::atomic<size_t> lds_granted{0};
-  if (lds_owner > 64 * 1024 && lds_granted.load() < lds_owner) {
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_bwd_d48_owner_kernel),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_owner);
-    if (e != hipSuccess) return (int)e;
-    lds_granted.store(lds_owner);
-  }
-  const long long nblk_owner = (long long)plan.total_tiles * d.M * d.N;
-  if (nblk_owner >= (1LL << 31)) return SNIPPER_E_SHAPE;
-  // 1) every pixel of grad_value is written by its owner tile (no memset needed) ...
-  hipLaunchKernelGGL(msda_bwd_d48_owner_kernel, dim3((unsigned)nblk_owner), dim3(kOwnerBlock), lds_owner, st,
-                     grad_out, loc, attn, d, plan, grad_value);
-  if (int rc = launch_status()) return rc;
-  // 2) ... then grad_loc / grad_attn for all samples and HBM atomics for the far ones only
+int backward_d48_owner_f32(hipStream_t st, const float *grad_out, const float *value, const float *loc,
+                           const float *attn, CoreDims d, OwnerPlan plan, void *workspace,
+                           float *grad_value, float *grad_loc, float *grad_attn) {
+  const long long nm = (long long)d.N * d.M;
+  plan.bitmap = reinterpret_cast<unsigned char *>(workspace);
+  hipError_t e = hipMemsetAsync(plan.bitmap, 0, (size_t)(nm * plan.bytes_per_nm), st);
+  if (e != hipSuccess) return (int)e;
+  // 1) grad_loc / grad_attn, marking of the near samples, HBM atomics for everything not marked
   constexpr int kRows = kD48Block / 16;
   const long long rows = (long long)d.N * d.Lq * d.M;
   const int LP = d.L * d.P;
   const int nblk = (int)((rows + kRows - 1) / kRows);
   const int nblk_padded = (nblk + 7) & ~7;
-  const size_t lds = (size_t)kRows * (LP * sizeof(BwdRecord) + 16);
-  if (LP == 12 && d.P == 4) {
-    g_last_variant = "d48_owner_lp12";
-    hipLaunchKernelGGL((msda_bwd_d48_f32_kernel<12, true>), dim3(nblk_padded), dim3(kD48Block), lds, st, grad_out, value, shapes, lsi, loc, attn, d, grad_value, grad_loc, grad_attn, nblk_padded, plan.radius);
-  } else {
-    g_last_variant = "d48_owner";
-    hipLaunchKernelGGL((msda_bwd_d48_f32_kernel<0, true>), dim3(nblk_padded), dim3(kD48Block), lds, st, grad_out, value, shapes, lsi, loc, attn, d, grad_value, grad_loc, grad_attn, nblk_padded, plan.radius);
-  }
+  const size_t lds = (size_t)kRows * (LP * sizeof(BinRecord) + 16);
+  hipLaunchKernelGGL(msda_bwd_d48_bin_kernel, dim3(nblk_padded), dim3(kD48Block), lds, st, grad_out, value, loc,
+                     attn, d, plan, grad_value, grad_loc, grad_attn, nblk_padded);
+  if (int rc = launch_status()) return rc;
+  // 2) every tile adds what it owns
+  const long long nblk_tiles = nm * plan.total_tiles;
+  if (nblk_tiles >= (1LL << 31)) return SNIPPER_E_SHAPE;
+  if (g_owner_chunk.load(std::memory_order_relaxed) == 128)
+    hipLaunchKernelGGL(msda_bwd_d48_tile_kernel<128>, dim3((unsigned)nblk_tiles), dim3(kOwnerBlock), 0, st, grad_out,
+                       loc, attn, d, plan, grad_value);
+  else
+    hipLaunchKernelGGL(msda_bwd_d48_tile_kernel<64>, dim3((unsigned)nblk_tiles), dim3(kOwnerBlock), 0, st, grad_out,
+                       loc, attn, d, plan, grad_value);
+  g_last_variant = "d48_owner";
   return launch_status();
 }
 
@@ -249,7 +261,7 @@ int snipper_msda_set_policy(int policy) {
 int snipper_msda_set_param(const char *name, double v) {
   if (!name) return SNIPPER_E_NULL;
   const std::string_view k(name);
-  auto edge_ok = [&](int e) { return e >= 1 && e * e <= kOwnerMaxTilePixels; };
+  auto edge_ok = [&](int e) { return e >= 1 && e * e <= kOwnerMaxTilePx && (e & (e - 1)) == 0; };
   if (k == "near_radius") {
     if (!(v >= 0.0 && v <= 64.0)) return SNIPPER_E_SHAPE;
     g_near_radius.store((float)v);
@@ -258,6 +270,9 @@ int snipper_msda_set_param(const char *name, double v) {
     g_tile_edge[k == "owner_tile_edge_big" ? 0 : (k == "owner_tile_edge_mid" ? 1 : 2)].store((int)v);
   } else if (k == "owner_debug") {
     g_owner_debug.store((int)v);
+  } else if (k == "owner_chunk") {
+    if (v != 64 && v != 128) return SNIPPER_E_SHAPE;
+    g_owner_chunk.store((int)v);
   } else if (k == "owner_enable") {
     g_owner_enable.store(v != 0.0);
   } else {
@@ -315,16 +330,29 @@ int snipper_msda_backward_f32(void *stream, const float *grad_out, const float *
   return backward_generic<float, float, float>(st, grad_out, value, shapes, level_start, loc, attn, d, grad_value, grad_loc, grad_attn);
 }
 
-int snipper_msda_backward_hs_f32(void *stream, const float *grad_out, const float *value,
+long long snipper_msda_backward_workspace_bytes(int N, int S, int M, int D, int L, int Lq, int P,
+                                                const int64_t *host_shapes) {
+  const CoreDims d{N, S, M, D, L, Lq, P};
+  if (check_dims(N, S, M, D, L, Lq, P) != SNIPPER_OK) return 0;
+  if (g_policy.load(std::memory_order_relaxed) != 0 || !g_owner_enable.load(std::memory_order_relaxed)) return 0;
+  if (!owner_shape_ok(d, host_shapes)) return 0;
+  const OwnerPlan p = make_owner_plan(d, host_shapes);
+  return (long long)N * M * p.bytes_per_nm;
+}
+
+int snipper_msda_backward_ws_f32(void *stream, const float *grad_out, const float *value,
                                  const int64_t *shapes, const int64_t *level_start,
-                                 const int64_t *host_shapes,
+                                 const int64_t *host_shapes, void *workspace, long long workspace_bytes,
                                  const float *loc, const float *attn,
                                  int N, int S, int M, int D, int L, int Lq, int P,
                                  float *grad_value, float *grad_loc, float *grad_attn) {
   SNIPPER_CHECK_BWD();
-  if (owner_eligible(d, host_shapes))
-    return backward_d48_owner_f32(st, grad_out, value, shapes, level_start, host_shapes, loc, attn, d,
+  const long long need = snipper_msda_backward_workspace_bytes(N, S, M, D, L, Lq, P, host_shapes);
+  if (need > 0 && workspace && workspace_bytes >= need) {
+    if (int rc = zero_grad_value(st, grad_value, d)) return rc;
+    return backward_d48_owner_f32(st, grad_out, value, loc, attn, d, make_owner_plan(d, host_shapes), workspace,
                                   grad_value, grad_loc, grad_attn);
+  }
   return snipper_msda_backward_f32(stream, grad_out, value, shapes, level_start, loc, attn, N, S, M, D, L, Lq, P,
                                    grad_value, grad_loc, grad_attn);
 }

@@ -196,7 +196,7 @@ __device__ __forceinline__ float row16_sum(float v) {
   return v;
 }
 
-// ---- shared geometry of the grid ("owner-computes") backward: msda_d48_owner.cuh ---------------
+// ---- shared geometry of the owner-computes backward (msda_d48_owner.cuh) -----------------------
 // Both kernels of that path must classify a sample as near/far identically, so the arithmetic is
 // pinned with explicit intrinsics (no compiler-chosen fma contraction).
 __device__ __forceinline__ float px_coord(float l, int size) { return __fmaf_rn(l, (float)size, -0.5f); }
@@ -215,16 +215,13 @@ __device__ __forceinline__ void query_to_grid(int q, const int *start, const int
   qx = r - qy * W[lq];
 }
 
-// GRID = true: second kernel of the owner-computes path.  Samples within `radius` pixels of their
-// query's anchor were already accumulated by msda_bwd_d48_owner_kernel; their grad_value atomics are
-// dropped here (offset forced out of the descriptor's range), everything else is unchanged.
-template <int LP_T, bool GRID>
+template <int LP_T>
 __global__ __launch_bounds__(kD48Block) void msda_bwd_d48_f32_kernel(
     const float *__restrict__ grad_out, const float *__restrict__ value,
     const int64_t *__restrict__ shapes, const int64_t *__restrict__ level_start,
     const float *__restrict__ loc, const float *__restrict__ attn, CoreDims d,
     float *__restrict__ grad_value, float *__restrict__ grad_loc, float *__restrict__ grad_attn,
-    int nblk_padded, float radius) {
+    int nblk_padded) {
   constexpr int G = 16, kRows = kD48Block / G;
   __shared__ LevelTable lv;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -244,8 +241,6 @@ __global__ __launch_bounds__(kD48Block) void msda_bwd_d48_f32_kernel(
     const long long n = row / ((long long)d.M * d.Lq);
     const unsigned px_stride = (unsigned)d.M * kD48 * 4u;
     const unsigned base = (unsigned)(n * d.S) * px_stride + (unsigned)m * (kD48 * 4u);
-    int lq = 0, qy = 0, qx = 0;
-    if (GRID) query_to_grid((int)((row / d.M) % d.Lq), lv.start, lv.W, d.L, lq, qy, qx);
     for (int s = lane; s < LP; s += G) {
       const int l = s / d.P;
       const int H = lv.H[l], W = lv.W[l];
@@ -253,8 +248,6 @@ __global__ __launch_bounds__(kD48Block) void msda_bwd_d48_f32_kernel(
       const float lx = loc[2 * li], ly = loc[2 * li + 1], a = attn[li];
       const float y = px_coord(ly, H), x = px_coord(lx, W);
       const bool inside = (y > -1.f) && (x > -1.f) && (y < (float)H) && (x < (float)W);
-      const bool owned = GRID && inside &&
-                         near_anchor(x, y, anchor_coord(qx, W, lv.W[lq]), anchor_coord(qy, H, lv.H[lq]), radius);
       const float yf = floorf(y), xf = floorf(x);
       const int y0 = (int)yf, x0 = (int)xf;
       const bool yok0 = inside && y0 >= 0, yok1 = inside && y0 + 1 <= H - 1;
@@ -263,7 +256,7 @@ __global__ __launch_bounds__(kD48Block) void msda_bwd_d48_f32_kernel(
       const float ai = inside ? a : 0.f;
       BwdRecord r;
       r.q0.x = inside ? y - yf : 0.f; r.q0.y = inside ? x - xf : 0.f; r.q0.z = ai; r.q0.w = ai * (float)W;
-      r.q2.x = ai * (float)H; r.q2.y = owned ? 1.f : 0.f; r.q2.z = 0.f; r.q2.w = 0.f;
+      r.q2.x = ai * (float)H; r.q2.y = 0.f; r.q2.z = 0.f; r.q2.w = 0.f;
       r.off.x = (yok0 && xok0) ? p00 : kOobOffset;
       r.off.y = (yok0 && xok1) ? p00 + px_stride : kOobOffset;
       r.off.z = (yok1 && xok0) ? p00 + (unsigned)W * px_stride : kOobOffset;
@@ -300,11 +293,9 @@ __global__ __launch_bounds__(kD48Block) void msda_bwd_d48_f32_kernel(
       const float v2 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(vsrc, o + 128u, 0, 0));
       dot[k] = g0 * v0 + g1 * v1 + g2 * v2;
       const float wa = w[k] * a;
-      // a tap the owner kernel already added gets an out-of-range offset: the atomic is dropped
-      const unsigned go = (GRID && r.q2.y != 0.f) ? kOobOffset : o;
-      __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(wa * g0, gsrc, go, 0, 0);
-      __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(wa * g1, gsrc, go + 64u, 0, 0);
-      __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(wa * g2, gsrc, go + 128u, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(wa * g0, gsrc, o, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(wa * g1, gsrc, o + 64u, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(wa * g2, gsrc, o + 128u, 0, 0);
     }
     float pa = w[0] * dot[0] + w[1] * dot[1] + w[2] * dot[2] + w[3] * dot[3];
     float px = hh * (dot[1] - dot[0]) + lh * (dot[3] - dot[2]);

@@ -55,6 +55,7 @@ class MSDeformAttn(nn.Module):
         self.mode = mode
         self.use_pytroch_deform = use_pytroch_deform
         self.attention_vis = attention_vis
+        self.core_in_fp32 = True    # see _core
 
         shared_offsets = nn.Linear(d_model, n_heads * n_levels * n_points * 2)
         shared_weights = nn.Linear(d_model, n_heads * n_levels * n_points)
@@ -94,6 +95,10 @@ class MSDeformAttn(nn.Module):
     def _core(self, value, shapes, lsi, loc, attn):
         if self.use_pytroch_deform:
             return ms_deform_attn_core_pytorch(value, shapes, loc, attn)
+        if value.dtype == torch.bfloat16 and self.core_in_fp32:
+            # under bf16 autocast the sampling itself stays in fp32: its f32 backward has the
+            # owner-computes kernels (3x faster than the atomic one), which dwarfs the bf16 forward's gain
+            value, loc, attn = value.float(), loc.float(), attn.float()
         return MSDeformAttnFunction.apply(value.contiguous(), shapes, lsi, loc.contiguous(),
                                           attn.contiguous(), self.im2col_step)
 

@@ -70,12 +70,14 @@ def main():
     ap.add_argument("--owner", type=int, default=0, help="pass host shapes (owner-computes backward)")
     ap.add_argument("--radius", type=float, default=None)
     ap.add_argument("--owner-debug", type=int, default=0)
+    ap.add_argument("--owner-chunk", type=int, default=64)
     ap.add_argument("--edges", type=int, nargs=3, default=None)
     ap.add_argument("--cases", nargs="+", default=["enc_local", "enc_uniform", "dec"])
     ap.add_argument("--dtypes", nargs="+", default=["float32", "bfloat16"])
     args = ap.parse_args()
     S = sum(h * w for h, w in SHAPES)
     _lib.set_param("owner_enable", 1 if args.owner else 0)
+    _lib.set_param("owner_chunk", args.owner_chunk)
     if args.owner_debug:
         _lib.set_param("owner_debug", args.owner_debug)
     if args.radius is not None:
