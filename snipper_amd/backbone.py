@@ -52,6 +52,20 @@ class FrozenBatchNorm2d(nn.Module):
         return x * scale.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1)
 
 
+def conv_frozen_bn(x, conv: nn.Conv2d, bn: FrozenBatchNorm2d, relu: bool):
+    """conv -> frozen BN (-> ReLU) with the BN folded into the convolution.
+
+    The BN is an affine map with constant coefficients (reference backbone.py:54-64), so
+    ``bn(conv(x, w)) == conv(x, w * scale[:, None, None, None]) + shift``: one convolution with a bias
+    instead of a convolution and two more passes over the activation.  The fold is recomputed from
+    the live weight every call (a few MB), so gradients reach ``conv.weight`` exactly as before.
+    """
+    scale, shift = bn.scale_bias()
+    w = conv.weight * scale.view(-1, 1, 1, 1).to(conv.weight.dtype)
+    y = F.conv2d(x, w, shift.to(w.dtype), conv.stride, conv.padding, conv.dilation, conv.groups)
+    return F.relu(y, inplace=True) if relu else y
+
+
 class Bottleneck(nn.Module):
     expansion = 4
 
@@ -69,11 +83,11 @@ class Bottleneck(nn.Module):
                                             FrozenBatchNorm2d(width * 4))
 
     def forward(self, x):
-        y = F.relu(self.bn1(self.conv1(x)))
-        y = F.relu(self.bn2(self.conv2(y)))
-        y = self.bn3(self.conv3(y))
-        skip = x if self.downsample is None else self.downsample(x)
-        return F.relu(y + skip)
+        y = conv_frozen_bn(x, self.conv1, self.bn1, relu=True)
+        y = conv_frozen_bn(y, self.conv2, self.bn2, relu=True)
+        y = conv_frozen_bn(y, self.conv3, self.bn3, relu=False)
+        skip = x if self.downsample is None else conv_frozen_bn(x, self.downsample[0], self.downsample[1], relu=False)
+        return F.relu(y + skip, inplace=True)
 
 
 class ResNet50Body(nn.Module):
@@ -98,9 +112,14 @@ class ResNet50Body(nn.Module):
                 nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
 
     def forward(self, x) -> Dict[str, torch.Tensor]:
-        x = F.relu(self.bn1(self.conv1(x)))
+        x = x.contiguous(memory_format=torch.channels_last)     # NHWC end to end: no layout shuffles around MIOpen
+        x = conv_frozen_bn(x, self.conv1, self.bn1, relu=True)
         x = F.max_pool2d(x, 3, stride=2, padding=1)
-        c2 = self.layer1(x)
+        if not any(p.requires_grad for p in self.layer1.parameters()):
+            with torch.no_grad():                                 # conv1 + layer1 are frozen: nothing to save
+                c2 = self.layer1(x)
+        else:
+            c2 = self.layer1(x)
         c3 = self.layer2(c2)
         c4 = self.layer3(c3)
         c5 = self.layer4(c4)

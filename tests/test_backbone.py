@@ -1,0 +1,96 @@
+"""ResNet-50 restatement: layer-by-layer against plain F.conv2d + the reference's FrozenBatchNorm2d
+formula (reference models/backbone.py:54-64).  Parity with torchvision itself is unpinned (absent here)."""
+import torch
+import torch.nn.functional as F
+
+from snipper_amd.backbone import (Backbone, Bottleneck, FrozenBatchNorm2d, PositionEmbeddingSine, conv_frozen_bn)
+from snipper_amd.misc import NestedTensor, nested_tensor_from_tensor_list
+
+
+def _randomise_bn(bn, g):
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(bn.weight.shape, generator=g) + 0.5)
+        bn.bias.copy_(torch.randn(bn.bias.shape, generator=g) * 0.1)
+        bn.running_mean.copy_(torch.randn(bn.bias.shape, generator=g) * 0.1)
+        bn.running_var.copy_(torch.rand(bn.bias.shape, generator=g) + 0.5)
+
+
+def _ref_bn(x, bn):   # the reference's forward, verbatim arithmetic
+    w, b = bn.weight.reshape(1, -1, 1, 1), bn.bias.reshape(1, -1, 1, 1)
+    rv, rm = bn.running_var.reshape(1, -1, 1, 1), bn.running_mean.reshape(1, -1, 1, 1)
+    scale = w * (rv + bn.eps).rsqrt()
+    return x * scale + (b - rm * scale)
+
+
+def test_frozen_bn_and_folded_conv():
+    g = torch.Generator().manual_seed(0)
+    conv = torch.nn.Conv2d(5, 7, 3, stride=2, padding=1, bias=False).double()
+    bn = FrozenBatchNorm2d(7).double()
+    _randomise_bn(bn, g)
+    x = torch.randn(2, 5, 9, 11, generator=g).double().requires_grad_(True)
+    ref = F.relu(_ref_bn(conv(x), bn))
+    torch.testing.assert_close(bn(conv(x)), _ref_bn(conv(x), bn), rtol=1e-12, atol=1e-12)
+    got = conv_frozen_bn(x, conv, bn, relu=True)
+    torch.testing.assert_close(got, ref, rtol=1e-11, atol=1e-12)
+    go = torch.randn(ref.shape, generator=g).double()
+    g_ref = torch.autograd.grad(ref, [x, conv.weight], go)
+    g_got = torch.autograd.grad(got, [x, conv.weight], go)
+    for a, b in zip(g_got, g_ref):
+        torch.testing.assert_close(a, b, rtol=1e-10, atol=1e-11)
+    assert "num_batches_tracked" not in bn.state_dict()
+    sd = dict(bn.state_dict(), num_batches_tracked=torch.tensor(3))
+    bn.load_state_dict(sd)   # key dropped like the reference (:43-51)
+
+
+def test_bottleneck_matches_unfused_composition():
+    g = torch.Generator().manual_seed(1)
+    blk = Bottleneck(16, 8, stride=2, downsample=True).double()
+    for m in blk.modules():
+        if isinstance(m, FrozenBatchNorm2d):
+            _randomise_bn(m, g)
+    x = torch.randn(2, 16, 10, 12, generator=g).double()
+    y = F.relu(_ref_bn(blk.conv1(x), blk.bn1))
+    y = F.relu(_ref_bn(blk.conv2(y), blk.bn2))
+    y = _ref_bn(blk.conv3(y), blk.bn3)
+    ref = F.relu(y + _ref_bn(blk.downsample[0](x), blk.downsample[1]))
+    torch.testing.assert_close(blk(x), ref, rtol=1e-10, atol=1e-11)
+
+
+def test_backbone_shapes_freezing_and_keys():
+    bb = Backbone("resnet50", train_backbone=True, return_interm_layers=True, dilation=False)
+    trainable = [n for n, p in bb.named_parameters() if p.requires_grad]
+    assert trainable and all(any(k in n for k in ("layer2", "layer3", "layer4")) for n in trainable)
+    assert sum(p.numel() for p in bb.parameters() if p.requires_grad) == 23232512
+    keys = bb.state_dict().keys()
+    for k in ("body.conv1.weight", "body.bn1.running_var", "body.layer1.0.downsample.0.weight",
+              "body.layer4.2.bn3.bias", "body.layer3.5.conv2.weight"):
+        assert k in keys                                                       # torchvision's names
+    imgs = [torch.rand(6, 64, 96)]                                             # one snippet, T=2
+    nt = nested_tensor_from_tensor_list(imgs)
+    assert nt.tensors.shape == (2, 3, 64, 96) and not nt.mask.any()
+    out = bb(nt)
+    assert [tuple(out[k].tensors.shape) for k in ("0", "1", "2")] == [(2, 512, 8, 12), (2, 1024, 4, 6), (2, 2048, 2, 3)]
+    assert out["2"].mask.shape == (2, 2, 3) and out["2"].mask.dtype == torch.bool
+
+
+def test_nested_tensor_padding():
+    a, b = torch.rand(3, 5, 7), torch.rand(3, 4, 9)
+    nt = nested_tensor_from_tensor_list([a, b], split=False)
+    assert nt.tensors.shape == (2, 3, 5, 9)
+    assert nt.mask[0, :, 7:].all() and not nt.mask[0, :5, :7].any()
+    assert nt.mask[1, 4:].all() and not nt.mask[1, :4].any()
+    torch.testing.assert_close(nt.tensors[1, :, :4, :9], b)
+
+
+def test_position_embedding_shapes_and_symmetry():
+    pe = PositionEmbeddingSine(16, num_frames=2, normalize=True)
+    mask = torch.zeros(4, 5, 6, dtype=torch.bool)       # 2 snippets x 2 frames
+    mask[:, :, -1] = True
+    pos = pe(NestedTensor(torch.zeros(4, 3, 5, 6), mask))
+    assert pos.shape == (2, 2, 48, 5, 6)
+    # z block depends on the frame only, y block on the row only, x block on the column only
+    torch.testing.assert_close(pos[:, :, :16, 0, 0], pos[:, :, :16, 3, 2])
+    torch.testing.assert_close(pos[:, 0, 16:32, :, 0], pos[:, 1, 16:32, :, 3])
+    torch.testing.assert_close(pos[:, 0, 32:, 1, :], pos[:, 1, 32:, 4, :])
+    # first valid cell: cumsum = 1 -> angle = 2*pi/(n_valid + eps) / dim_t[0]
+    assert abs(float(pos[0, 0, 32, 0, 0]) - float(torch.sin(torch.tensor(2 * torch.pi / (5 + 1e-6))))) < 1e-5
