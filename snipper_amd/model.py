@@ -66,6 +66,16 @@ class SnipperDeformable(nn.Module):
         self.transformer.decoder.root_embed = self.root_embed
         self.transformer.decoder.class_embed = self.class_embed
 
+    def _joints(self, l, h):
+        """The K-1 single-layer joint heads (reference :193-195 runs them one by one and concatenates)
+        evaluated as ONE matmul over their stacked weights: same parameters, same result."""
+        heads = self.joint_embed[l]
+        if all(hd.num_layers == 1 for hd in heads):
+            w = torch.cat([hd.layers[0].weight for hd in heads], 0)               # [(K-1)*4, d]
+            b = torch.cat([hd.layers[0].bias for hd in heads], 0)
+            return F.linear(h, w, b).view(*h.shape[:3], len(heads), 4)
+        return torch.cat([hd(h).reshape(*h.shape[:3], 1, 4) for hd in heads], dim=3)
+
     def forward(self, samples):
         if not isinstance(samples, NestedTensor):
             samples = nested_tensor_from_tensor_list(samples)
@@ -98,9 +108,7 @@ class SnipperDeformable(nn.Module):
             anchor = inverse_sigmoid(init_reference if l == 0 else inter_references[l - 1])
             root = self.root_embed[l](hs[l]).view(bs, t, self.num_queries, 1, 4)
             root = torch.cat([root[..., :2] + anchor[:, :, :, None, :], root[..., 2:]], -1).sigmoid()
-            joints = torch.cat([head(hs[l]).reshape(bs, t, self.num_queries, 1, 4)
-                                for head in self.joint_embed[l]], dim=3)
-            kpts.append(torch.cat([root, joints], dim=3).transpose(1, 2))          # [bs, nq, t, K, 4]
+            kpts.append(torch.cat([root, self._joints(l, hs[l])], dim=3).transpose(1, 2))   # [bs, nq, t, K, 4]
         classes, kpts = torch.stack(classes), torch.stack(kpts)
         out = {'pred_logits': classes[-1], 'pred_kpts2d': kpts[-1, ..., 0:3],
                'pred_depth': kpts[-1, ..., 3:4], 'heatmaps': heatmaps}
