@@ -7,7 +7,9 @@
 
 Workload (BASELINE.json `metric` / configs[2..3]): T=4 frames of 600x800 per snippet, ResNet-50
 backbone -> 3 feature levels -> hidden_dim 384, 8 heads, enc6/dec6, 60 queries, batch 2 snippets per
-GPU, fp32 (the reference has no AMP), synthetic images, random-init weights.  One step = forward,
+GPU, synthetic images, random-init weights.  Precision: bf16 autocast for the dense layers (BASELINE
+configs[2] names bf16; the reference itself has no AMP, `--precision fp32` reproduces that), fp32 master
+weights and optimizer, fp32 deformable-attention sampling.  One step = forward,
 loss, backward, gradient clipping (0.1, engine.py:74) and an AdamW update.  One process per GPU;
 gradients are all-reduced by DistributedDataParallel over RCCL, overlapped with backward
 (weak scaling: every rank keeps its own 2 snippets per step).
@@ -190,7 +192,8 @@ def main():
     ap.add_argument("--hidden-dim", type=int, default=384)
     ap.add_argument("--enc-layers", type=int, default=6)
     ap.add_argument("--dec-layers", type=int, default=6)
-    ap.add_argument("--precision", choices=["fp32", "bf16"], default="fp32")
+    ap.add_argument("--precision", choices=["fp32", "bf16"], default="bf16",
+                    help="bf16 = autocast for the dense layers (BASELINE configs[2]); fp32 master weights, fp32 sampling")
     ap.add_argument("--use-pytorch-deform", type=int, default=0, help="1 = reference debug path (comparison only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip roofline/msda extras (profiling runs)")
