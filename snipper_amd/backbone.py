@@ -12,8 +12,10 @@ torchvision's parameter names, so a reference checkpoint's ``backbone.0.body.*``
 unchanged.  Parity status of this file: UNPINNED against torchvision (no reference test or
 golden vector exists for it); it is checked layer by layer against ``F.conv2d`` compositions.
 
-Round-1 status: convolutions run through PyTorch (MIOpen); the hand-written gfx950
-implicit-GEMM kernels named in BASELINE.json's north_star are the next row.
+Round-1 status: the 1x1 convolutions of the frozen part (stem side of layer1) run on this repository's
+bf16 MFMA kernel with BN, residual and ReLU fused (csrc/gemm_bf16.cuh) when the activations are bf16
+NHWC; every other convolution runs through PyTorch (MIOpen).  Hand-written 3x3 / 7x7 / strided and
+backward convolution kernels are the next row.
 """
 from __future__ import annotations
 
@@ -52,8 +54,8 @@ class FrozenBatchNorm2d(nn.Module):
         return x * scale.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1)
 
 
-def conv_frozen_bn(x, conv: nn.Conv2d, bn: FrozenBatchNorm2d, relu: bool):
-    """conv -> frozen BN (-> ReLU) with the BN folded into the convolution.
+def conv_frozen_bn(x, conv: nn.Conv2d, bn: FrozenBatchNorm2d, relu: bool, residual=None):
+    """conv -> frozen BN (+ residual) (-> ReLU) with the BN folded into the convolution.
 
     The BN is an affine map with constant coefficients (reference backbone.py:54-64), so
     ``bn(conv(x, w)) == conv(x, w * scale[:, None, None, None]) + shift``: one convolution with a bias
@@ -62,8 +64,33 @@ def conv_frozen_bn(x, conv: nn.Conv2d, bn: FrozenBatchNorm2d, relu: bool):
     """
     scale, shift = bn.scale_bias()
     w = conv.weight * scale.view(-1, 1, 1, 1).to(conv.weight.dtype)
+    if _hip_pointwise_ok(x, conv, w):
+        return _hip_pointwise(x, w, shift, relu, residual)
     y = F.conv2d(x, w, shift.to(w.dtype), conv.stride, conv.padding, conv.dilation, conv.groups)
+    if residual is not None:
+        y = y + residual
     return F.relu(y, inplace=True) if relu else y
+
+
+def _hip_pointwise_ok(x, conv, w) -> bool:
+    """1x1 stride-1 convolution of a bf16 NHWC activation outside autograd (the frozen stem / layer1 under
+    autocast): in NHWC that is exactly the dense kernel Y[M, Cout] = X[M, Cin] . W[Cout, Cin]^T."""
+    return (x.is_cuda and x.dtype == torch.bfloat16 and not torch.is_grad_enabled() and
+            conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.groups == 1 and
+            conv.in_channels % 64 == 0 and conv.out_channels % 4 == 0 and
+            x.is_contiguous(memory_format=torch.channels_last))
+
+
+def _hip_pointwise(x, w, shift, relu, residual):
+    """conv1x1 + folded BN (+ residual) (+ ReLU) in ONE launch of the MFMA kernel (csrc/gemm_bf16.cuh)."""
+    from .dense import linear_bf16
+    b, c, h, wd = x.shape
+    rows = x.permute(0, 2, 3, 1).reshape(b * h * wd, c)                      # a view: NHWC is row-major [M, Cin]
+    res = None
+    if residual is not None:
+        res = residual.permute(0, 2, 3, 1).reshape(b * h * wd, -1)
+    y = linear_bf16(rows, w.view(w.shape[0], c).to(torch.bfloat16), shift.float(), res, relu)
+    return y.view(b, h, wd, -1).permute(0, 3, 1, 2)                          # logical NCHW, channels_last memory
 
 
 class Bottleneck(nn.Module):
@@ -85,9 +112,8 @@ class Bottleneck(nn.Module):
     def forward(self, x):
         y = conv_frozen_bn(x, self.conv1, self.bn1, relu=True)
         y = conv_frozen_bn(y, self.conv2, self.bn2, relu=True)
-        y = conv_frozen_bn(y, self.conv3, self.bn3, relu=False)
         skip = x if self.downsample is None else conv_frozen_bn(x, self.downsample[0], self.downsample[1], relu=False)
-        return F.relu(y + skip, inplace=True)
+        return conv_frozen_bn(y, self.conv3, self.bn3, relu=True, residual=skip)
 
 
 class ResNet50Body(nn.Module):

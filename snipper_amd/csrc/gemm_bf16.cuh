@@ -1,0 +1,135 @@
+// gemm_bf16.cuh -- bf16 MFMA kernel for the path's dense layers (gfx950).
+//
+//   Y[M,N] = act( X[M,K] . W[N,K]^T + bias[N] (+ R[M,N]) )        X, W, R, Y bf16; bias f32; f32 accumulate
+//
+// This is the shape of every projection on the hot path -- MSDeformAttn's value / output / offset /
+// weight Linears and the FFN of the encoder layer (reference models/ops/modules/ms_deform_attn.py:114,
+// 143-163,237 and models/deformable_transformer.py:194-198), M = B*T*S = 79 000 tokens, K, N <= 1024 --
+// and, in NHWC, of the ResNet bottleneck's 1x1 convolutions with the frozen BatchNorm folded into W /
+// bias, the ReLU and the residual add fused in the epilogue (reference models/backbone.py:54-64 plus
+// torchvision's Bottleneck).  K is short, so the kernel lives on the HBM side of the roofline: what it
+// has to do is stream X once, keep W in L2/LDS, and write Y once with the whole epilogue applied.
+//
+// Tiling (wave64): 256 threads = 2 x 2 waves, block tile 128 (M) x 128 (N), K step 64, each wave a
+// 64 x 64 sub-tile = 4 x 4 v_mfma_f32_16x16x32_bf16 tiles (16 accumulators x 4 VGPRs).  The product is
+// evaluated as Y^T = W . X^T, i.e. W is the MFMA "A" operand: the C/D layout (col = lane & 15,
+// row = 4 * (lane >> 4) + reg) then gives every lane 4 CONSECUTIVE n of one output row m, so the
+// epilogue stores 8 bytes per lane instead of scattered bf16s.  Both operands are K-contiguous in
+// memory and in LDS (rows padded 64 -> 72 elements: the 16 lanes of a ds_read_b128 group land on 16
+// distinct 4-bank slots), fetched with 16-byte loads, one K-step ahead in registers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace snipper {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 gemm_bf16x8;
+typedef __attribute__((ext_vector_type(4))) float gemm_f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int gemm_u32x4;
+
+constexpr int kGemmBM = 128, kGemmBN = 128, kGemmBK = 64, kGemmPad = 72, kGemmThreads = 256;
+
+struct GemmArgs {
+  const uint16_t *X; long long ldx;      // [M][K]
+  const uint16_t *W;                     // [N][K]
+  const float *bias;                     // [N] or nullptr
+  const uint16_t *R; long long ldr;      // [M][N] residual or nullptr
+  uint16_t *Y; long long ldy;            // [M][N]
+  int M, N, K;
+};
+
+__device__ __forceinline__ float gemm_bf16_to_f32(uint16_t b) { return __uint_as_float((unsigned)b << 16); }
+__device__ __forceinline__ unsigned gemm_pack2(float a, float b) {
+  return (unsigned)__builtin_bit_cast(uint16_t, (__bf16)a) | ((unsigned)__builtin_bit_cast(uint16_t, (__bf16)b) << 16);
+}
+
+template <bool RELU>
+__global__ __launch_bounds__(kGemmThreads) void linear_bf16_kernel(GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) uint16_t Xs[kGemmBM * kGemmPad];
+  __shared__ __attribute__((aligned(16))) uint16_t Ws[kGemmBN * kGemmPad];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave & 1, wn = wave >> 1;
+  const int m0 = blockIdx.x * kGemmBM, n0 = blockIdx.y * kGemmBN;
+
+  // loader: 4 x 16 B per operand per thread and K-step; row = idx / 8, 8-element chunk = idx % 8
+  const uint16_t *xp[4], *wp[4];
+  int lds_off[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int idx = tid + kGemmThreads * i, row = idx >> 3, kc = idx & 7;
+    const int mr = min(m0 + row, g.M - 1), nr = min(n0 + row, g.N - 1);     // clamp: edge rows are never stored
+    xp[i] = g.X + (long long)mr * g.ldx + kc * 8;
+    wp[i] = g.W + (long long)nr * g.K + kc * 8;
+    lds_off[i] = row * kGemmPad + kc * 8;
+  }
+  gemm_u32x4 xr[4], wr[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    xr[i] = *reinterpret_cast<const gemm_u32x4 *>(xp[i]);
+    wr[i] = *reinterpret_cast<const gemm_u32x4 *>(wp[i]);
+  }
+  gemm_f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = gemm_f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int frag_row = lane & 15, frag_k = (lane >> 4) * 8;
+  for (int k0 = 0; k0 < g.K; k0 += kGemmBK) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      *reinterpret_cast<gemm_u32x4 *>(Xs + lds_off[i]) = xr[i];
+      *reinterpret_cast<gemm_u32x4 *>(Ws + lds_off[i]) = wr[i];
+    }
+    __syncthreads();
+    if (k0 + kGemmBK < g.K) {     // next K-step in flight while this one is multiplied
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        xr[i] = *reinterpret_cast<const gemm_u32x4 *>(xp[i] + k0 + kGemmBK);
+        wr[i] = *reinterpret_cast<const gemm_u32x4 *>(wp[i] + k0 + kGemmBK);
+      }
+    }
+#pragma unroll
+    for (int kk = 0; kk < kGemmBK; kk += 32) {
+      gemm_bf16x8 wf[4], xf[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        wf[i] = *reinterpret_cast<const gemm_bf16x8 *>(Ws + (wn * 64 + i * 16 + frag_row) * kGemmPad + kk + frag_k);
+        xf[i] = *reinterpret_cast<const gemm_bf16x8 *>(Xs + (wm * 64 + i * 16 + frag_row) * kGemmPad + kk + frag_k);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  // epilogue: lane holds n = nb + 4*(lane>>4) + r (r = 0..3) of output row m = mb + (lane & 15)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int n = n0 + wn * 64 + i * 16 + (lane >> 4) * 4;
+    if (n >= g.N) continue;
+    gemm_f32x4 b = {0.f, 0.f, 0.f, 0.f};
+    if (g.bias) b = *reinterpret_cast<const gemm_f32x4 *>(g.bias + n);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int m = m0 + wm * 64 + j * 16 + (lane & 15);
+      if (m >= g.M) continue;
+      gemm_f32x4 v = acc[i][j] + b;
+      if (g.R) {
+        const uint2 r = *reinterpret_cast<const uint2 *>(g.R + (long long)m * g.ldr + n);
+        v.x += __uint_as_float(r.x << 16); v.y += __uint_as_float(r.x & 0xffff0000u);
+        v.z += __uint_as_float(r.y << 16); v.w += __uint_as_float(r.y & 0xffff0000u);
+      }
+      if (RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      uint2 o;
+      o.x = gemm_pack2(v.x, v.y);
+      o.y = gemm_pack2(v.z, v.w);
+      *reinterpret_cast<uint2 *>(g.Y + (long long)m * g.ldy + n) = o;
+    }
+  }
+}
+
+}  // namespace snipper

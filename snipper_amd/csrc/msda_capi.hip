@@ -11,6 +11,8 @@
 #include <string_view>
 
 #include "../../include/snipper_msda.h"
+#include "../../include/snipper_dense.h"
+#include "gemm_bf16.cuh"
 #include "msda_d48.cuh"
 #include "msda_d48_owner.cuh"
 #include "msda_generic.cuh"
@@ -375,6 +377,22 @@ int snipper_msda_backward_bf16(void *stream, const uint16_t *grad_out, const uin
   SNIPPER_CHECK_BWD();
   if (int rc = zero_grad_value(st, grad_value, d)) return rc;
   return backward_generic<uint16_t, float, float>(st, grad_out, value, shapes, level_start, loc, attn, d, grad_value, grad_loc, grad_attn);
+}
+
+int snipper_linear_bf16(void *stream, const uint16_t *X, long long ldx, const uint16_t *W,
+                        const float *bias, const uint16_t *R, long long ldr, uint16_t *Y, long long ldy,
+                        int M, int N, int K, int relu) {
+  if (!X || !W || !Y) return SNIPPER_E_NULL;
+  if (M <= 0 || N <= 0 || K <= 0 || K % kGemmBK || N % 4 || ldx % 8 || ldy % 4 || ldx < K || ldy < N ||
+      (R && (ldr % 4 || ldr < N)))
+    return SNIPPER_E_SHAPE;
+  const GemmArgs g{X, ldx, W, bias, R, ldr, Y, ldy, M, N, K};
+  const dim3 grid((M + kGemmBM - 1) / kGemmBM, (N + kGemmBN - 1) / kGemmBN);
+  if (relu)
+    hipLaunchKernelGGL(linear_bf16_kernel<true>, grid, dim3(kGemmThreads), 0, (hipStream_t)stream, g);
+  else
+    hipLaunchKernelGGL(linear_bf16_kernel<false>, grid, dim3(kGemmThreads), 0, (hipStream_t)stream, g);
+  return launch_status();
 }
 
 }  // extern "C"
