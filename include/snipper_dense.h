@@ -28,6 +28,29 @@ int snipper_linear_bf16(void *stream, const uint16_t *X, long long ldx, const ui
                         const float *bias, const uint16_t *R, long long ldr, uint16_t *Y, long long ldy,
                         int M, int N, int K, int relu);
 
+/* ---- element-wise fusions around the core op (csrc/msda_prologue.cuh) --------------------------------
+ * dtype codes: 0 = float32, 1 = bfloat16 bits.
+ *
+ * snipper_temporal_mix: out[n,to,s,c] = sum_ti mix[to*Ti + ti] * in[n,ti,s,c]   (Ti, To <= 8, C % 4 == 0)
+ *   mask [N, (mask_on_input ? Ti : To), S] bytes or NULL: a non-zero byte makes that frame position read as 0
+ *   (mask_on_input, the forward: value.masked_fill of ms_deform_attn.py:116 folded in) or be written as 0
+ *   (the backward).  `mix` is a HOST array of To*Ti floats (copied into the launch).
+ *   Replaces masked_fill + the per-frame core-op loop's frame averaging + dtype casts. */
+int snipper_temporal_mix(void *stream, const void *in, int in_dtype, const unsigned char *mask, int mask_on_input,
+                         const float *mix, int N, int Ti, int To, long long S, int C, void *out, int out_dtype);
+
+/* snipper_msda_prologue_forward: rows = N*T*Lq*M, one row = the L*P samples of a (query, head) (L*P <= 16, L <= 8)
+ *   loc[row, l, p, :] = ref[row / M, l, :] + off[row, l, p, :] * (inv_w[l], inv_h[l])       (ms_deform_attn.py:164-165)
+ *   prob[row, :]      = softmax(logit[row, :])                                               (:149, tied weights)
+ *   off / logit: `dtype`;  ref, loc, prob: float32;  inv_w / inv_h: HOST arrays of L floats.
+ * snipper_msda_prologue_backward: the adjoint; grad_ref may be NULL; otherwise M must be a power of two <= 64. */
+int snipper_msda_prologue_forward(void *stream, const void *off, const void *logit, int dtype, const float *ref,
+                                  const float *inv_w, const float *inv_h, long long rows, int M, int L, int P,
+                                  float *loc, float *prob);
+int snipper_msda_prologue_backward(void *stream, const float *grad_loc, const float *grad_prob, const float *prob,
+                                   const float *inv_w, const float *inv_h, long long rows, int M, int L, int P,
+                                   void *grad_off, void *grad_logit, int dtype, float *grad_ref);
+
 #ifdef __cplusplus
 }
 #endif

@@ -30,6 +30,12 @@ EXPORTS = {
     "snipper_msda_backward_f32": (_BWD_ARGS, c_int),
     "snipper_msda_backward_f64": (_BWD_ARGS, c_int),
     "snipper_msda_backward_bf16": (_BWD_ARGS, c_int),
+    "snipper_temporal_mix": ([c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int,
+                              ctypes.c_longlong, c_int, c_void_p, c_int], c_int),
+    "snipper_msda_prologue_forward": ([c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                                       ctypes.c_longlong, c_int, c_int, c_int, c_void_p, c_void_p], c_int),
+    "snipper_msda_prologue_backward": ([c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_longlong,
+                                        c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p], c_int),
     "snipper_linear_bf16": ([c_void_p, c_void_p, ctypes.c_longlong, c_void_p, c_void_p, c_void_p, ctypes.c_longlong,
                              c_void_p, ctypes.c_longlong, c_int, c_int, c_int, c_int], c_int),
 }

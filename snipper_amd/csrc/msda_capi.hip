@@ -6,6 +6,7 @@
 // synchronisation, no global mutable state besides a thread-local "last variant" string and the
 // process-wide variant policy (tests / benchmarks only).
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <atomic>
 #include <cstdint>
 #include <string_view>
@@ -13,6 +14,7 @@
 #include "../../include/snipper_msda.h"
 #include "../../include/snipper_dense.h"
 #include "gemm_bf16.cuh"
+#include "msda_prologue.cuh"
 #include "msda_d48.cuh"
 #include "msda_d48_owner.cuh"
 #include "msda_generic.cuh"
@@ -392,6 +394,78 @@ int snipper_linear_bf16(void *stream, const uint16_t *X, long long ldx, const ui
     hipLaunchKernelGGL(linear_bf16_kernel<true>, grid, dim3(kGemmThreads), 0, (hipStream_t)stream, g);
   else
     hipLaunchKernelGGL(linear_bf16_kernel<false>, grid, dim3(kGemmThreads), 0, (hipStream_t)stream, g);
+  return launch_status();
+}
+
+int snipper_temporal_mix(void *stream, const void *in, int in_dtype, const unsigned char *mask, int mask_on_input,
+                         const float *mix, int N, int Ti, int To, long long S, int C, void *out, int out_dtype) {
+  if (!in || !out || !mix) return SNIPPER_E_NULL;
+  if (N <= 0 || Ti <= 0 || To <= 0 || Ti > kMixMaxFrames || To > kMixMaxFrames || S <= 0 || C <= 0 || C % 4)
+    return SNIPPER_E_SHAPE;
+  MixMatrix m{};
+  for (int a = 0; a < To; ++a)
+    for (int b = 0; b < Ti; ++b) m.w[a][b] = mix[a * Ti + b];
+  const long long total = (long long)N * S * C / 4;
+  const int grid = (int)std::min<long long>((total + 255) / 256, 256LL * 32);
+  hipStream_t st = (hipStream_t)stream;
+#define SNIPPER_MIX(TI, TO)                                                                                      \
+  do {                                                                                                           \
+    if (mask_on_input)                                                                                           \
+      hipLaunchKernelGGL((temporal_mix_kernel<TI, TO, true>), dim3(grid), dim3(256), 0, st, (const TI *)in, mask, m, \
+                         N, Ti, To, S, C, (TO *)out);                                                            \
+    else                                                                                                         \
+      hipLaunchKernelGGL((temporal_mix_kernel<TI, TO, false>), dim3(grid), dim3(256), 0, st, (const TI *)in, mask, m, \
+                         N, Ti, To, S, C, (TO *)out);                                                            \
+  } while (0)
+  if (in_dtype == 0 && out_dtype == 0) SNIPPER_MIX(float, float);
+  else if (in_dtype == 1 && out_dtype == 0) SNIPPER_MIX(uint16_t, float);
+  else if (in_dtype == 0 && out_dtype == 1) SNIPPER_MIX(float, uint16_t);
+  else if (in_dtype == 1 && out_dtype == 1) SNIPPER_MIX(uint16_t, uint16_t);
+  else return SNIPPER_E_UNSUPPORTED;
+#undef SNIPPER_MIX
+  return launch_status();
+}
+
+static int make_level_scale(const float *inv_w, const float *inv_h, int L, LevelScale *sc) {
+  if (!inv_w || !inv_h) return SNIPPER_E_NULL;
+  for (int l = 0; l < L; ++l) { sc->inv_w[l] = inv_w[l]; sc->inv_h[l] = inv_h[l]; }
+  return SNIPPER_OK;
+}
+
+int snipper_msda_prologue_forward(void *stream, const void *off, const void *logit, int dtype, const float *ref,
+                                  const float *inv_w, const float *inv_h, long long rows, int M, int L, int P,
+                                  float *loc, float *prob) {
+  if (!off || !logit || !ref || !loc || !prob) return SNIPPER_E_NULL;
+  if (rows <= 0 || M <= 0 || L <= 0 || P <= 0 || L > kPrologueMaxL || L * P > kPrologueMaxLP) return SNIPPER_E_SHAPE;
+  LevelScale sc{};
+  if (int rc = make_level_scale(inv_w, inv_h, L, &sc)) return rc;
+  const dim3 grid((unsigned)((rows + 255) / 256));
+  if (dtype == 0)
+    hipLaunchKernelGGL(prologue_fwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float *)off,
+                       (const float *)logit, ref, sc, rows, M, L, P, loc, prob);
+  else if (dtype == 1)
+    hipLaunchKernelGGL(prologue_fwd_kernel<uint16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t *)off,
+                       (const uint16_t *)logit, ref, sc, rows, M, L, P, loc, prob);
+  else return SNIPPER_E_UNSUPPORTED;
+  return launch_status();
+}
+
+int snipper_msda_prologue_backward(void *stream, const float *grad_loc, const float *grad_prob, const float *prob,
+                                   const float *inv_w, const float *inv_h, long long rows, int M, int L, int P,
+                                   void *grad_off, void *grad_logit, int dtype, float *grad_ref) {
+  if (!grad_loc || !grad_prob || !prob || !grad_off || !grad_logit) return SNIPPER_E_NULL;
+  if (rows <= 0 || M <= 0 || L <= 0 || P <= 0 || L > kPrologueMaxL || L * P > kPrologueMaxLP) return SNIPPER_E_SHAPE;
+  if (grad_ref && (M > 64 || (M & (M - 1)))) return SNIPPER_E_SHAPE;
+  LevelScale sc{};
+  if (int rc = make_level_scale(inv_w, inv_h, L, &sc)) return rc;
+  const dim3 grid((unsigned)((rows + 255) / 256));
+  if (dtype == 0)
+    hipLaunchKernelGGL(prologue_bwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, grad_loc, grad_prob, prob,
+                       sc, rows, M, L, P, (float *)grad_off, (float *)grad_logit, grad_ref);
+  else if (dtype == 1)
+    hipLaunchKernelGGL(prologue_bwd_kernel<uint16_t>, grid, dim3(256), 0, (hipStream_t)stream, grad_loc, grad_prob, prob,
+                       sc, rows, M, L, P, (uint16_t *)grad_off, (uint16_t *)grad_logit, grad_ref);
+  else return SNIPPER_E_UNSUPPORTED;
   return launch_status();
 }
 

@@ -1,0 +1,197 @@
+// msda_prologue.cuh -- the element-wise work around the deformable-attention core op, fused.
+//
+// In the reference every line below is its own PyTorch kernel over tensors of N*T*S*C (121 MB) or
+// N*T*Lq*M*L*P*2 (61 MB) elements, forward and backward
+// (/root/reference/models/ops/modules/ms_deform_attn.py):
+//   :116      value.masked_fill(mask, 0)                      \
+//   :172-225  one core op per neighbouring value frame, summed  > temporal_mix_kernel: one pass that
+//             (here: the temporal mean of the frames, cast)    /  reads every value frame once
+//   :164      sampling_offsets / normalizer                   \
+//   :165      reference_points + offsets                        > prologue_fwd_kernel / prologue_bwd_kernel
+//   :149      softmax over the L*P logits of a (query, head)  /
+// All are HBM-bound: the kernels move each byte once, 16 B per lane where the layout allows.
+#pragma once
+#include "msda_common.cuh"
+
+namespace snipper {
+
+constexpr int kMixMaxFrames = 8;
+struct MixMatrix { float w[kMixMaxFrames][kMixMaxFrames]; };   // [out frame][in frame]
+
+template <typename T> struct Vec4IO;
+template <> struct Vec4IO<float> {
+  static __device__ __forceinline__ void ld(const float *p, float (&v)[4]) {
+    const float4 t = *reinterpret_cast<const float4 *>(p); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+  }
+  static __device__ __forceinline__ void st(float *p, const float (&v)[4]) {
+    *reinterpret_cast<float4 *>(p) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+};
+template <> struct Vec4IO<uint16_t> {
+  static __device__ __forceinline__ void ld(const uint16_t *p, float (&v)[4]) {
+    const uint2 t = *reinterpret_cast<const uint2 *>(p);
+    v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
+    v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
+  }
+  static __device__ __forceinline__ void st(uint16_t *p, const float (&v)[4]) {
+    uint2 t;
+    t.x = (unsigned)f32_to_bf16_bits(v[0]) | ((unsigned)f32_to_bf16_bits(v[1]) << 16);
+    t.y = (unsigned)f32_to_bf16_bits(v[2]) | ((unsigned)f32_to_bf16_bits(v[3]) << 16);
+    *reinterpret_cast<uint2 *>(p) = t;
+  }
+};
+
+// out[n, to, s, c] = sum_ti mix[to][ti] * in[n, ti, s, c], masked positions (mask[n, t, s] != 0) reading as 0
+// (MASK_IN: the mask belongs to the input frames -- forward) or being written as 0 (the mask belongs to
+// the output frames -- backward, where `in` is the gradient of the mixed frames).
+template <typename TI, typename TO, bool MASK_IN>
+__global__ __launch_bounds__(256) void temporal_mix_kernel(const TI *__restrict__ in, const unsigned char *__restrict__ mask,
+                                                           MixMatrix mix, int N, int Ti, int To, long long S, int C,
+                                                           TO *__restrict__ out) {
+  const long long X4 = S * C / 4;                       // vectors of 4 channels per frame
+  const long long total = (long long)N * X4;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long n = i / X4, x4 = i - n * X4;
+    const long long s = (x4 * 4) / C;
+    float v[kMixMaxFrames][4];
+#pragma unroll
+    for (int ti = 0; ti < kMixMaxFrames; ++ti) {
+      if (ti < Ti) {
+        Vec4IO<TI>::ld(in + ((n * Ti + ti) * X4 + x4) * 4, v[ti]);
+        if (MASK_IN && mask && mask[(n * Ti + ti) * S + s]) v[ti][0] = v[ti][1] = v[ti][2] = v[ti][3] = 0.f;
+      }
+    }
+#pragma unroll
+    for (int to = 0; to < kMixMaxFrames; ++to) {
+      if (to < To) {
+        float o[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ti = 0; ti < kMixMaxFrames; ++ti) {
+          if (ti < Ti) {
+            const float w = mix.w[to][ti];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = fmaf(w, v[ti][k], o[k]);
+          }
+        }
+        if (!MASK_IN && mask && mask[(n * To + to) * S + s]) o[0] = o[1] = o[2] = o[3] = 0.f;
+        Vec4IO<TO>::st(out + ((n * To + to) * X4 + x4) * 4, o);
+      }
+    }
+  }
+}
+
+// ---- sampling locations + attention probabilities ---------------------------------------------------
+constexpr int kPrologueMaxLP = 16, kPrologueMaxL = 8;
+struct LevelScale { float inv_w[kPrologueMaxL], inv_h[kPrologueMaxL]; };
+
+template <typename T> __device__ __forceinline__ float ld_scalar(const T *p);
+template <> __device__ __forceinline__ float ld_scalar<float>(const float *p) { return *p; }
+template <> __device__ __forceinline__ float ld_scalar<uint16_t>(const uint16_t *p) { return bf16_bits_to_f32(*p); }
+template <typename T> __device__ __forceinline__ void st_scalar(T *p, float v);
+template <> __device__ __forceinline__ void st_scalar<float>(float *p, float v) { *p = v; }
+template <> __device__ __forceinline__ void st_scalar<uint16_t>(uint16_t *p, float v) { *p = f32_to_bf16_bits(v); }
+
+// one thread per row (n, t, q, m):  loc = ref + off * (1/W_l, 1/H_l),  prob = softmax(logits)
+template <typename TI>
+__global__ __launch_bounds__(256) void prologue_fwd_kernel(const TI *__restrict__ off, const TI *__restrict__ logit,
+                                                           const float *__restrict__ ref, LevelScale sc,
+                                                           long long rows, int M, int L, int P,
+                                                           float *__restrict__ loc, float *__restrict__ prob) {
+  const long long row = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= rows) return;
+  const int LP = L * P;
+  const TI *o = off + row * LP * 2;
+  const TI *g = logit + row * LP;
+  const float *r = ref + (row / M) * L * 2;
+  float *lo = loc + row * LP * 2;
+  float *pr = prob + row * LP;
+  float z[kPrologueMaxLP];
+  float zmax = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < kPrologueMaxLP; ++i) {
+    if (i < LP) {
+      z[i] = ld_scalar<TI>(g + i);
+      zmax = fmaxf(zmax, z[i]);
+    }
+  }
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < kPrologueMaxLP; ++i) {
+    if (i < LP) {
+      z[i] = __expf(z[i] - zmax);
+      sum += z[i];
+    }
+  }
+  const float inv = 1.f / sum;
+#pragma unroll
+  for (int i = 0; i < kPrologueMaxLP; ++i) {
+    if (i < LP) {
+      const int l = i / P;
+      pr[i] = z[i] * inv;
+      lo[2 * i] = fmaf(ld_scalar<TI>(o + 2 * i), sc.inv_w[l], r[2 * l]);
+      lo[2 * i + 1] = fmaf(ld_scalar<TI>(o + 2 * i + 1), sc.inv_h[l], r[2 * l + 1]);
+    }
+  }
+}
+
+// grad_off = grad_loc * (1/W, 1/H);  grad_logit = prob * (grad_prob - <prob, grad_prob>);
+// grad_ref[n,t,q,l,:] = sum over heads and points of grad_loc   (M a power of two <= 64, rows of a query adjacent)
+template <typename TI>
+__global__ __launch_bounds__(256) void prologue_bwd_kernel(const float *__restrict__ gloc, const float *__restrict__ gprob,
+                                                           const float *__restrict__ prob, LevelScale sc,
+                                                           long long rows, int M, int L, int P,
+                                                           TI *__restrict__ goff, TI *__restrict__ glogit,
+                                                           float *__restrict__ gref /* or nullptr */) {
+  const long long row = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = row < rows;
+  const long long rr = live ? row : 0;
+  const int LP = L * P;
+  const float *gl = gloc + rr * LP * 2, *gp = gprob + rr * LP, *pr = prob + rr * LP;
+  float dotp = 0.f;
+  float p[kPrologueMaxLP], g[kPrologueMaxLP];
+#pragma unroll
+  for (int i = 0; i < kPrologueMaxLP; ++i) {
+    if (i < LP) {
+      p[i] = pr[i];
+      g[i] = gp[i];
+      dotp = fmaf(p[i], g[i], dotp);
+    }
+  }
+  float rx[kPrologueMaxL], ry[kPrologueMaxL];
+#pragma unroll
+  for (int l = 0; l < kPrologueMaxL; ++l) rx[l] = ry[l] = 0.f;
+#pragma unroll
+  for (int i = 0; i < kPrologueMaxLP; ++i) {
+    if (i < LP) {
+      const int l = i / P;
+      const float gx = gl[2 * i], gy = gl[2 * i + 1];
+      if (live) {
+        st_scalar<TI>(glogit + rr * LP + i, p[i] * (g[i] - dotp));
+        st_scalar<TI>(goff + rr * LP * 2 + 2 * i, gx * sc.inv_w[l]);
+        st_scalar<TI>(goff + rr * LP * 2 + 2 * i + 1, gy * sc.inv_h[l]);
+      }
+#pragma unroll
+      for (int ll = 0; ll < kPrologueMaxL; ++ll) {
+        if (ll == l) { rx[ll] += live ? gx : 0.f; ry[ll] += live ? gy : 0.f; }
+      }
+    }
+  }
+  if (gref) {
+#pragma unroll
+    for (int l = 0; l < kPrologueMaxL; ++l) {
+      if (l < L) {
+        float ax = rx[l], ay = ry[l];
+        for (int o = M >> 1; o > 0; o >>= 1) {          // the M heads of a query sit in M adjacent lanes
+          ax += __shfl_xor(ax, o, 64);
+          ay += __shfl_xor(ay, o, 64);
+        }
+        if (live && (row % M) == 0) {
+          gref[(row / M) * L * 2 + 2 * l] = ax;
+          gref[(row / M) * L * 2 + 2 * l + 1] = ay;
+        }
+      }
+    }
+  }
+}
+
+}  // namespace snipper

@@ -222,7 +222,9 @@ class DeformableTransformer(nn.Module):
         hw = [tuple(s.shape[-2:]) for s in srcs]
         tokens = lambda x: x.flatten(3).permute(0, 2, 3, 1)              # [bs, t, h*w, c]
         src = torch.cat([tokens(s) for s in srcs], 2)
-        mask = torch.cat([tokens(m) for m in masks], 2)
+        # the padding mask is constant along channels (model.py:156-157 replicates it; get_valid_ratio reads
+        # channel 0 only): keep one channel and expand, so the modules can see that and skip the C-fold work
+        mask = torch.cat([tokens(m[:, :1]) for m in masks], 2).expand(-1, -1, -1, srcs[0].shape[1])
         pos = torch.cat([tokens(p) + self.level_embed[lvl].view(1, 1, 1, -1)
                          for lvl, p in enumerate(pos_embeds)], 2)
         spatial_shapes = torch.as_tensor(hw, dtype=torch.long, device=src.device)

@@ -56,6 +56,7 @@ class MSDeformAttn(nn.Module):
         self.use_pytroch_deform = use_pytroch_deform
         self.attention_vis = attention_vis
         self.core_in_fp32 = True    # see _core
+        self.fused_elementwise = True   # HIP kernels for mask / temporal mean / locations / softmax
 
         shared_offsets = nn.Linear(d_model, n_heads * n_levels * n_points * 2)
         shared_weights = nn.Linear(d_model, n_heads * n_levels * n_points)
@@ -122,16 +123,17 @@ class MSDeformAttn(nn.Module):
         assert sum(h * w for h, w in hw) == S
 
         value = self.value_proj(input_flatten)
-        if input_padding_mask is not None:
-            value = value.masked_fill(input_padding_mask, 0.0)
-        value = value.view(N, T2, S, M, C // M)
         scale = torch.tensor([[w, h] for h, w in hw], dtype=query.dtype, device=query.device)  # (W_l, H_l)
         groups = [frame_neighbours(t1, self.n_frame, T2) for t1 in range(T1)]
 
         if self.weights_are_tied():
-            out, locs, wts = self._forward_tied(query, reference_points, value, shapes,
-                                                input_level_start_index, scale, groups)
+            # (the padding mask is applied inside, fused with the temporal mean where possible)
+            out, locs, wts = self._forward_tied(query, reference_points, value.view(N, T2, S, M, C // M), shapes,
+                                                input_level_start_index, scale, groups, hw, input_padding_mask)
         else:
+            if input_padding_mask is not None:
+                value = value.masked_fill(input_padding_mask, 0.0)
+            value = value.view(N, T2, S, M, C // M)
             out, locs, wts = self._forward_pairs(query, reference_points, value, shapes,
                                                  input_level_start_index, scale, groups)
         out = self.output_proj(out)
@@ -140,22 +142,49 @@ class MSDeformAttn(nn.Module):
         return out
 
     # -- one launch for the whole module ---------------------------------------------------
-    def _forward_tied(self, query, ref, value, shapes, lsi, scale, groups):
+    def _fusable(self, query, ref, mask) -> bool:
+        """The fused element-wise kernels take CUDA f32 / bf16, L*P <= 16, a power-of-two head count and a
+        padding mask that is constant along C (how the model builds it: model.py:156-157)."""
+        from . import fused
+        M, L, P = self.n_heads, self.n_levels, self.n_points
+        return (self.fused_elementwise and not self.use_pytroch_deform and fused.supported(query) and
+                L * P <= 16 and L <= 8 and M <= 64 and (M & (M - 1)) == 0 and
+                (self.d_model // M) % 4 == 0 and
+                (mask is None or mask.stride(-1) == 0 or mask.dim() == 3))
+
+    def _forward_tied(self, query, ref, value, shapes, lsi, scale, groups, hw=None, mask=None):
         N, T1, Lq, C = query.shape
         T2, S = value.shape[1], value.shape[2]
         M, L, P = self.n_heads, self.n_levels, self.n_points
-        off = self.sampling_offsets[0](query).view(N, T1, Lq, M, L, P, 2)
-        loc = ref[:, :, :, None, :, None, :] + off / scale[None, None, None, None, :, None, :]
-        prob = F.softmax(self.attention_weights[0](query).view(N, T1, Lq, M, L * P), -1).view(N, T1, Lq, M, L, P)
-
-        # temporal mean of the neighbouring value frames, per query frame
-        if all(g == [t] for t, g in enumerate(groups)):          # T=1: nothing to average
-            vbar = value
+        off_raw = self.sampling_offsets[0](query)                                   # [N,T1,Lq, M*L*P*2]
+        logit_raw = self.attention_weights[0](query)                                # [N,T1,Lq, M*L*P]
+        fuse = hw is not None and self._fusable(query, ref, mask)
+        if fuse:
+            from .fused import MSDAPrologue, TemporalMix
+            loc, prob = MSDAPrologue.apply(off_raw, logit_raw, ref.expand(N, T1, Lq, L, 2), hw, M, L, P)
+            loc, prob = loc.view(N, T1, Lq, M, L, P, 2), prob.view(N, T1, Lq, M, L, P)
         else:
-            mix = torch.zeros(T1, T2, dtype=value.dtype, device=value.device)
-            for t1, g in enumerate(groups):
-                mix[t1, g] = 1.0 / len(g)
-            vbar = torch.einsum('ts,nsx->ntx', mix, value.reshape(N, T2, -1)).view(N, T1, S, M, C // M)
+            off = off_raw.view(N, T1, Lq, M, L, P, 2)
+            loc = ref[:, :, :, None, :, None, :] + off / scale[None, None, None, None, :, None, :]
+            prob = F.softmax(logit_raw.view(N, T1, Lq, M, L * P), -1).view(N, T1, Lq, M, L, P)
+
+        # temporal mean of the neighbouring value frames, per query frame (and the padding mask)
+        identity = all(g == [t] for t, g in enumerate(groups))                     # T=1: nothing to average
+        if fuse and not (identity and mask is None and value.dtype == torch.float32):
+            mix = [[(1.0 / len(g)) if t2 in g else 0.0 for t2 in range(T2)] for g in groups]
+            m2 = None if mask is None else (mask if mask.dim() == 3 else mask[..., 0])
+            vbar = TemporalMix.apply(value.reshape(N, T2, S, C), m2, mix).view(N, T1, S, M, C // M)
+        else:
+            if mask is not None:
+                value = value.masked_fill(mask.view(N, T2, S, -1, 1) if mask.dim() == 3 else
+                                          mask.view(N, T2, S, M, C // M), 0.0)
+            if identity:
+                vbar = value
+            else:
+                mixm = torch.zeros(T1, T2, dtype=value.dtype, device=value.device)
+                for t1, g in enumerate(groups):
+                    mixm[t1, g] = 1.0 / len(g)
+                vbar = torch.einsum('ts,nsx->ntx', mixm, value.reshape(N, T2, -1)).view(N, T1, S, M, C // M)
         out = self._core(vbar.reshape(N * T1, S, M, C // M), shapes, lsi,
                          loc.reshape(N * T1, Lq, M, L, P, 2), prob.reshape(N * T1, Lq, M, L, P))
         out = out.view(N, T1, Lq, C)
