@@ -209,9 +209,12 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
-    if world > 1:
+    use_ddp = world > 1 or os.environ.get("SNIPPER_FORCE_DDP") == "1"   # the latter: 1-GPU test of the RCCL path
+    if use_ddp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)      # "nccl" is RCCL on ROCm
+        os.environ.setdefault("MASTER_PORT", "29577")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)   # "nccl" is RCCL on ROCm
 
     from snipper_amd import MultiScaleDeformableAttention as MSDA
     from snipper_amd import _lib
@@ -221,12 +224,10 @@ def main():
     torch.manual_seed(42 + rank)                                  # main.py:48,175
     margs = model_args(a)
     model = build_model(margs).to(device)
-    if world > 1:
-        torch.manual_seed(42)   # same init on every rank is DDP's job anyway (broadcast at wrap time)
     model.train()
     opt = build_optimizer(model)
     net = model
-    if world > 1:
+    if use_ddp:
         net = torch.nn.parallel.DistributedDataParallel(
             model, device_ids=[local_rank], broadcast_buffers=False, gradient_as_bucket_view=True,
             bucket_cap_mb=50, static_graph=True)
@@ -245,7 +246,7 @@ def main():
         return loss
 
     def fence():
-        if world > 1:
+        if use_ddp:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -263,7 +264,7 @@ def main():
     launches = MSDA.launch_timings() if timing else []
     MSDA.enable_launch_timing(False)
     loss_val = float(loss.detach())
-    if world > 1:
+    if use_ddp:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
@@ -306,7 +307,7 @@ def main():
         if world == 1 and not a.no_cpu_baseline and not a.no_extras:
             line["cpu_baseline"] = cpu_baseline(a)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_ddp:
         dist.barrier()
         dist.destroy_process_group()
 
