@@ -224,6 +224,9 @@ def main():
     torch.manual_seed(42 + rank)                                  # main.py:48,175
     margs = model_args(a)
     model = build_model(margs).to(device)
+    # NHWC convolutions hand back NHWC weight gradients: keep the weights in the same format, so that DDP's
+    # gradient buckets alias them without a strided copy
+    model = model.to(memory_format=torch.channels_last)
     model.train()
     opt = build_optimizer(model)
     net = model
