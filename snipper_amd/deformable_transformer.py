@@ -26,6 +26,26 @@ def inverse_sigmoid(x, eps=1e-5):
     return torch.log(x.clamp(min=eps) / (1 - x).clamp(min=eps))
 
 
+_LEVEL_CACHE = {}
+
+
+def _level_tensors(hw, device):
+    """(spatial_shapes [L,2], level_start_index [L]) int64 on `device`, cached per geometry: creating them
+    from Python lists is a blocking host-to-device copy (the reference pays it every forward, :100-101).
+    The host copy rides along as an attribute so that the modules never have to read it back."""
+    key = (hw, str(device))
+    got = _LEVEL_CACHE.get(key)
+    if got is None:
+        shapes = torch.as_tensor(hw, dtype=torch.long, device=device)
+        shapes._snipper_host = [tuple(x) for x in hw]
+        starts = [0]
+        for h, w in hw[:-1]:
+            starts.append(starts[-1] + h * w)
+        got = (shapes, torch.as_tensor(starts, dtype=torch.long, device=device))
+        _LEVEL_CACHE[key] = got
+    return got
+
+
 def _clones(module, n):
     return nn.ModuleList([copy.deepcopy(module) for _ in range(n)])
 
@@ -227,13 +247,8 @@ class DeformableTransformer(nn.Module):
         mask = torch.cat([tokens(m[:, :1]) for m in masks], 2).expand(-1, -1, -1, srcs[0].shape[1])
         pos = torch.cat([tokens(p) + self.level_embed[lvl].view(1, 1, 1, -1)
                          for lvl, p in enumerate(pos_embeds)], 2)
-        spatial_shapes = torch.as_tensor(hw, dtype=torch.long, device=src.device)
-        spatial_shapes._snipper_host = [(int(h), int(w)) for h, w in hw]  # spares the modules a device sync
         sizes = [h * w for h, w in hw]
-        starts = [0]
-        for s in sizes[:-1]:
-            starts.append(starts[-1] + s)
-        level_start_index = torch.as_tensor(starts, dtype=torch.long, device=src.device)
+        spatial_shapes, level_start_index = _level_tensors(tuple((int(h), int(w)) for h, w in hw), src.device)
         valid_ratios = torch.stack([self.get_valid_ratio(m) for m in masks], 1)   # [bs, L, 2]
 
         memory = self.encoder(src, spatial_shapes, level_start_index, valid_ratios, pos, mask, self.n_frame)

@@ -42,6 +42,20 @@ def frame_neighbours(t1: int, n_frame: int, n_value_frames: int) -> List[int]:
     return list(range(n_value_frames))   # future (forecast) frame: every value frame
 
 
+_SCALE_CACHE = {}
+
+
+def _level_scale(hw, dtype, device):
+    """[(W_l, H_l)] as a device tensor.  Cached: building it from a Python list is a blocking host-to-device
+    copy, i.e. a hidden synchronisation point in every forward."""
+    key = (tuple(map(tuple, hw)), dtype, str(device))
+    t = _SCALE_CACHE.get(key)
+    if t is None:
+        t = torch.tensor([[w, h] for h, w in hw], dtype=dtype, device=device)
+        _SCALE_CACHE[key] = t
+    return t
+
+
 class MSDeformAttn(nn.Module):
     def __init__(self, d_model=256, n_levels=4, n_heads=8, n_points=4, n_frame=4,
                  mode='encoder', use_pytroch_deform=False, attention_vis=False):
@@ -123,7 +137,7 @@ class MSDeformAttn(nn.Module):
         assert sum(h * w for h, w in hw) == S
 
         value = self.value_proj(input_flatten)
-        scale = torch.tensor([[w, h] for h, w in hw], dtype=query.dtype, device=query.device)  # (W_l, H_l)
+        scale = _level_scale(hw, query.dtype, query.device)                       # (W_l, H_l), cached
         groups = [frame_neighbours(t1, self.n_frame, T2) for t1 in range(T1)]
 
         if self.weights_are_tied():
