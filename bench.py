@@ -56,17 +56,26 @@ def model_args(a):
 
 
 def surrogate_loss(out, tgt):
-    """Fixed assignment: query i <-> synthetic person i for i < m; the rest are background."""
-    def one(o):
-        m = tgt["kpts2d"].shape[1]
-        logits = o["pred_logits"]                                   # [bs, nq, t, 2]
-        loss = F.cross_entropy(logits.flatten(0, 2), tgt["labels"].flatten())
-        loss = loss + F.l1_loss(o["pred_kpts2d"][:, :m], tgt["kpts2d"]) * 5.0
-        loss = loss + F.l1_loss(o["pred_depth"][:, :m], tgt["depth"])
-        return loss
-    total = one(out)
-    for aux in out.get("aux_outputs", []):
-        total = total + one(aux)
+    """Fixed assignment: query i <-> synthetic person i for i < m; the rest are background.  Summed over the
+    decoder layers (main + auxiliary outputs, like the reference's aux_loss), plus a small heat-map term."""
+    m = tgt["kpts2d"].shape[1]
+    al = out.get("all_layers")
+    if al is not None:      # all decoder layers in one shot: sum_l mean_l(x) == n_layers * mean(x) for equal shapes
+        logits, kpts = al["pred_logits"], al["pred_kpts"]                # [n_dec, bs, nq, t, 2], [n_dec, bs, nq, t, K, 4]
+        n_dec = logits.shape[0]
+        labels = tgt["labels"].unsqueeze(0).expand(n_dec, -1, -1, -1)
+        total = F.cross_entropy(logits.flatten(0, 3).float(), labels.reshape(-1))
+        total = total + F.l1_loss(kpts[:, :, :m, ..., 0:3].float(), tgt["kpts2d"].unsqueeze(0).expand(n_dec, -1, -1, -1, -1, -1)) * 5.0
+        total = total + F.l1_loss(kpts[:, :, :m, ..., 3:4].float(), tgt["depth"].unsqueeze(0).expand(n_dec, -1, -1, -1, -1, -1))
+        total = total * n_dec
+    else:
+        def one(o):
+            loss = F.cross_entropy(o["pred_logits"].flatten(0, 2), tgt["labels"].flatten())
+            loss = loss + F.l1_loss(o["pred_kpts2d"][:, :m], tgt["kpts2d"]) * 5.0
+            return loss + F.l1_loss(o["pred_depth"][:, :m], tgt["depth"])
+        total = one(out)
+        for aux in out.get("aux_outputs", []):
+            total = total + one(aux)
     for hm in out["heatmaps"]:
         total = total + hm.pow(2).mean() * 0.01
     return total
@@ -88,7 +97,7 @@ def make_batches(a, device, n_batches, seed):
     return batches
 
 
-def build_optimizer(model):
+def build_optimizer(model, capturable=False):
     """AdamW with the reference's three groups (main.py:201-221)."""
     def named(pred):
         return [p for n, p in model.named_parameters() if p.requires_grad and pred(n)]
@@ -98,7 +107,9 @@ def build_optimizer(model):
         {"params": named(lambda n: "backbone" in n), "lr": 1e-5},
         {"params": named(slow), "lr": 1e-5},
     ]
-    return torch.optim.AdamW(groups, lr=1e-4, weight_decay=1e-4)
+    # fused = one multi-tensor kernel per group instead of a Python loop over ~250 parameters
+    fused = all(p.is_cuda for g in groups for p in g["params"])
+    return torch.optim.AdamW(groups, lr=1e-4, weight_decay=1e-4, capturable=capturable, fused=fused)
 
 
 def msda_alg_bytes(d, bwd):
@@ -195,6 +206,7 @@ def main():
     ap.add_argument("--precision", choices=["fp32", "bf16"], default="bf16",
                     help="bf16 = autocast for the dense layers (BASELINE configs[2]); fp32 master weights, fp32 sampling")
     ap.add_argument("--use-pytorch-deform", type=int, default=0, help="1 = reference debug path (comparison only)")
+    ap.add_argument("--graph", type=int, default=0, help="1 = capture the step in a hipGraph (measured: no gain on ROCm 7.2, 73 vs 71 ms; off by default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip roofline/msda extras (profiling runs)")
     a = ap.parse_args()
@@ -228,7 +240,7 @@ def main():
     # gradient buckets alias them without a strided copy
     model = model.to(memory_format=torch.channels_last)
     model.train()
-    opt = build_optimizer(model)
+    opt = build_optimizer(model, capturable=bool(a.graph))
     net = model
     if use_ddp:
         net = torch.nn.parallel.DistributedDataParallel(
@@ -237,8 +249,7 @@ def main():
     batches = make_batches(a, device, 2, seed=1000 + rank)
     amp = a.precision == "bf16"
 
-    def step(i):
-        imgs, tgt = batches[i % len(batches)]
+    def train_step(imgs, tgt):
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
             out, _ = net(list(imgs))
         loss = surrogate_loss(out, tgt)
@@ -248,6 +259,9 @@ def main():
         opt.step()
         return loss
 
+    def step(i):
+        return train_step(*batches[i % len(batches)])
+
     def fence():
         if use_ddp:
             dist.barrier()
@@ -256,21 +270,78 @@ def main():
     for i in range(a.warmup):
         step(i)
     fence()
-    timing = (rank == 0) and not a.no_extras
-    if timing:
-        MSDA.enable_launch_timing(True)
+
+    # ---- hipGraph: the step is ~3000 launches of mostly short kernels and the host cannot issue them as fast
+    #      as the GPU retires them; all shapes are static, so the whole step (forward, loss, backward, RCCL
+    #      all-reduce, clipping, AdamW) is captured once and replayed.  Inputs are copied into static buffers.
+    graph, static_loss, graph_note = None, None, "eager"
+    if a.graph:
+        try:
+            static_imgs = torch.empty_like(batches[0][0])
+            static_tgt = {k: torch.empty_like(v) for k, v in batches[0][1].items()}
+
+            def load(i):
+                imgs, tgt = batches[i % len(batches)]
+                static_imgs.copy_(imgs)
+                for k in static_tgt:
+                    static_tgt[k].copy_(tgt[k])
+
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for i in range(3 if not use_ddp else 11):    # DDP wants > 10 eager iterations before capture
+                    load(i)
+                    train_step(static_imgs, static_tgt)
+            torch.cuda.current_stream().wait_stream(side)
+            fence()
+            graph = torch.cuda.CUDAGraph()
+            opt.zero_grad(set_to_none=True)
+            with torch.cuda.graph(graph):
+                static_loss = train_step(static_imgs, static_tgt)
+            fence()
+
+            def step(i):                                      # noqa: F811  (replaces the eager step)
+                load(i)
+                graph.replay()
+                return static_loss
+            for i in range(2):
+                step(i)
+            fence()
+            graph_note = "hipGraph replay of the whole step"
+        except Exception as e:                                # capture is an optimisation, never a requirement
+            print(f"[bench] graph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
+            graph = None
+            torch.cuda.synchronize()
+
+            def step(i):                                      # noqa: F811
+                return train_step(*batches[i % len(batches)])
+
     t0 = time.perf_counter()
     for i in range(a.steps):
         loss = step(a.warmup + i)
     fence()
     elapsed = time.perf_counter() - t0
-    launches = MSDA.launch_timings() if timing else []
-    MSDA.enable_launch_timing(False)
     loss_val = float(loss.detach())
     if use_ddp:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
+
+    # kernel launch durations for the roofline: events on the launch stream around every core-op launch.  Under
+    # graph replay there is no per-launch host hook, so the same step is run eagerly (same kernels, same
+    # inputs) right after the timed region -- when the region itself was eager the events sit inside it.
+    launches = []
+    if (rank == 0) and not a.no_extras:
+        MSDA.enable_launch_timing(True)
+        for i in range(2):
+            train_step(*batches[i % len(batches)])
+        launches = MSDA.launch_timings()
+        MSDA.enable_launch_timing(False)
+    if use_ddp and not a.no_extras:      # the other ranks must run the same eager steps (collectives inside)
+        if rank != 0:
+            for i in range(2):
+                train_step(*batches[i % len(batches)])
+        fence()
 
     if rank == 0:
         snippets = a.batch * world * a.steps
@@ -285,7 +356,8 @@ def main():
                        "global_batch": a.batch * world, "per_gpu_batch": a.batch, "parallelism": f"dp{world}",
                        "loss": "fixed-assignment surrogate (SetCriterion+Hungarian matcher not built: SURVEY 8f rank 2)",
                        "backbone_convs": "PyTorch/MIOpen (hand-written gfx950 conv kernels not built yet)",
-                       "msda_path": "pytorch grid_sample" if a.use_pytorch_deform else "snipper_amd HIP (tied single-launch)"},
+                       "msda_path": "pytorch grid_sample" if a.use_pytorch_deform else "snipper_amd HIP (tied single-launch)",
+                       "launch": graph_note},
             "final_loss": round(loss_val, 5),
         }
         if launches:
@@ -304,7 +376,7 @@ def main():
                                 "kernel": f"msda_{dom[0]}_{dom[1]} N={d['N']} Lq={d['Lq']}",
                                 "avg_launch_ms": round(avg_ms, 4), "alg_bytes_per_launch": bts,
                                 "launches_timed": len(times)}
-            line["msda_launch_ms_per_step"] = {f"{k[0]}_{k[1]}_N{k[2]}_Lq{k[3]}": round(v / a.steps, 3) for k, v in tot.items()}
+            line["msda_launch_ms_per_step"] = {f"{k[0]}_{k[1]}_N{k[2]}_Lq{k[3]}": round(v / 2, 3) for k, v in tot.items()}
         if not a.no_extras:
             line["msda"] = time_msda_modules(a, device)
         if world == 1 and not a.no_cpu_baseline and not a.no_extras:

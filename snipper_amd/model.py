@@ -102,16 +102,31 @@ class SnipperDeformable(nn.Module):
         hs, heatmaps, init_reference, inter_references, inter_att = \
             self.transformer(srcs, masks, pos, self.query_embed.weight)
         n_dec, bs, t, _, c = hs.shape
-        classes, kpts = [], []
-        for l in range(n_dec):
-            classes.append(self.class_embed[l](hs[l]).transpose(1, 2))             # [bs, nq, t, 2]
-            anchor = inverse_sigmoid(init_reference if l == 0 else inter_references[l - 1])
-            root = self.root_embed[l](hs[l]).view(bs, t, self.num_queries, 1, 4)
-            root = torch.cat([root[..., :2] + anchor[:, :, :, None, :], root[..., 2:]], -1).sigmoid()
-            kpts.append(torch.cat([root, self._joints(l, hs[l])], dim=3).transpose(1, 2))   # [bs, nq, t, K, 4]
-        classes, kpts = torch.stack(classes), torch.stack(kpts)
+        tied = all(m is self.class_embed[0] for m in self.class_embed) and \
+            all(m is self.root_embed[0] for m in self.root_embed) and \
+            all(m is self.joint_embed[0] for m in self.joint_embed)
+        if tied:
+            # the heads are one set of modules shared by every decoder layer (reference :99-101), so the per-layer
+            # loop of reference :172-201 is one batched evaluation over the stacked decoder outputs
+            classes = self.class_embed[0](hs).transpose(2, 3)                              # [n_dec, bs, nq, t, 2]
+            anchors = inverse_sigmoid(torch.cat([init_reference[None], inter_references[:-1]], 0))
+            root = self.root_embed[0](hs).view(n_dec, bs, t, self.num_queries, 1, 4)
+            root = torch.cat([root[..., :2] + anchors[:, :, :, :, None, :], root[..., 2:]], -1).sigmoid()
+            joints = self._joints(0, hs.flatten(0, 1)).view(n_dec, bs, t, self.num_queries, -1, 4)
+            kpts = torch.cat([root, joints], dim=4).transpose(2, 3)                        # [n_dec, bs, nq, t, K, 4]
+        else:
+            classes, kpts = [], []
+            for l in range(n_dec):
+                classes.append(self.class_embed[l](hs[l]).transpose(1, 2))             # [bs, nq, t, 2]
+                anchor = inverse_sigmoid(init_reference if l == 0 else inter_references[l - 1])
+                root = self.root_embed[l](hs[l]).view(bs, t, self.num_queries, 1, 4)
+                root = torch.cat([root[..., :2] + anchor[:, :, :, None, :], root[..., 2:]], -1).sigmoid()
+                kpts.append(torch.cat([root, self._joints(l, hs[l])], dim=3).transpose(1, 2))   # [bs, nq, t, K, 4]
+            classes, kpts = torch.stack(classes), torch.stack(kpts)
         out = {'pred_logits': classes[-1], 'pred_kpts2d': kpts[-1, ..., 0:3],
-               'pred_depth': kpts[-1, ..., 3:4], 'heatmaps': heatmaps}
+               'pred_depth': kpts[-1, ..., 3:4], 'heatmaps': heatmaps,
+               # every decoder layer at once (not in the reference's dict; lets a loss avoid a per-layer loop)
+               'all_layers': {'pred_logits': classes, 'pred_kpts': kpts}}
         if self.aux_loss:
             out['aux_outputs'] = [{'pred_logits': classes[i], 'pred_kpts2d': kpts[i, ..., 0:3],
                                    'pred_depth': kpts[i, ..., 3:4]} for i in range(n_dec - 1)]
