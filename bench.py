@@ -355,7 +355,7 @@ def main():
                                     f"train step fwd+bwd+clip+AdamW (BASELINE configs[2]/[3])"),
                        "global_batch": a.batch * world, "per_gpu_batch": a.batch, "parallelism": f"dp{world}",
                        "loss": "fixed-assignment surrogate (SetCriterion+Hungarian matcher not built: SURVEY 8f rank 2)",
-                       "backbone_convs": "PyTorch/MIOpen (hand-written gfx950 conv kernels not built yet)",
+                       "backbone_convs": "MIOpen via PyTorch; frozen 1x1 convs on the bf16 MFMA kernel (conv+BN+residual+ReLU fused)",
                        "msda_path": "pytorch grid_sample" if a.use_pytorch_deform else "snipper_amd HIP (tied single-launch)",
                        "launch": graph_note},
             "final_loss": round(loss_val, 5),
