@@ -14,21 +14,21 @@
 //
 //   1. msda_bwd_d48_bin_kernel    query-stationary (one 16-lane group per (n,q,m) row, as the atomic
 //      kernel): computes grad_loc / grad_attn for every sample, and for the "near" samples of a
-//      (row, level) appends the query index to the list of every tile their taps touch (one
-//      returning global atomic per tile, usually one or two per (row, level)).  A tap whose tile
-//      accepted the entry is OWNED; every other tap (far sample, list full, footprint spread over
-//      > 16 tiles) is added right here with the usual HBM float atomic.
-//   2. msda_bwd_d48_tile_kernel   tile-stationary: walks its list in chunks of 64 queries, stages their
-//      grad_out rows in LDS, re-decodes their sampling points, counting-sorts the owned taps by pixel
-//      in LDS and lets each 16-lane group accumulate ITS pixels in registers (3 channels per lane),
-//      so LDS is only read, never read-modify-written (measured: ds_add_f32 ~127 cycles per
-//      wave-instruction; plain LDS RMW is bound by the 64 B/clk/CU LDS write path).
+//      (row, level) marks the query in the byte map of every tile their taps touch (a plain byte
+//      store at a slot fixed by (tile, query): no atomics, no capacity -- returning global atomics for
+//      list slots were measured at 1.0 ms per launch).  A tap whose tile got the mark is OWNED; every
+//      other tap (far sample, footprint spread over > 16 tiles) is added right here with the usual
+//      HBM float atomic.
+//   2. msda_bwd_d48_tile_kernel   tile-stationary: reads its byte map, walks the marked queries in chunks
+//      of 64, stages their grad_out rows in LDS, re-decodes their sampling points, counting-sorts the
+//      owned taps by pixel in LDS and lets each 16-lane group accumulate ITS pixels in registers
+//      (3 channels per lane), so LDS is only read, never read-modify-written (measured: ds_add_f32
+//      ~127 cycles per wave-instruction; plain LDS RMW is bound by the 64 B/clk/CU LDS write path).
 //
 // Exactness does not depend on locality.  "near" = inside the map and |pixel - anchor| <= R on both
 // axes, anchor being a fixed function of the query INDEX (its pixel centre rescaled to the sampled
 // level); both kernels evaluate it with the pinned arithmetic of msda_d48.cuh and derive a tap's tile
-// with the same integer shifts, and kernel 2 processes exactly the list entries kernel 1 saw accepted
-// (slot < capacity).  So every tap is added exactly once for ANY input; locality only decides how many
+// with the same integer shifts, and kernel 2 visits exactly the queries kernel 1 marked.  So every tap is added exactly once for ANY input; locality only decides how many
 // taps go the fast way.
 #pragma once
 #include "msda_d48.cuh"
