@@ -14,9 +14,9 @@ loss, backward, gradient clipping (0.1, engine.py:74) and an AdamW update.  One 
 gradients are all-reduced by DistributedDataParallel over RCCL, overlapped with backward
 (weak scaling: every rank keeps its own 2 snippets per step).
 
-The loss is a fixed-assignment surrogate over every decoder layer's outputs: the reference's
-SetCriterion + Hungarian matcher (models/model.py:240-545, matcher.py) is SURVEY.md section 8f rank 2 and
-not built yet; `config.loss` says so.
+The loss is the reference's SetCriterion with its Hungarian matcher (snipper_amd/criterion.py mirrors
+models/model.py:240-545 and models/matcher.py, all decoder layers per call, one host round trip per step) on
+synthetic targets in the dataloader's format; `--loss surrogate` is the earlier fixed-assignment stand-in.
 
 One JSON line on stdout (rank 0).  Besides the contract's keys:
   roofline      the dominant hand-written kernel (deformable-attention backward, encoder shape),
@@ -82,19 +82,40 @@ def surrogate_loss(out, tgt):
 
 
 def make_batches(a, device, n_batches, seed):
+    """Synthetic snippets in the reference dataloader's item format (datasets/hybrid_dataloader.py:1072-1098):
+    images [T*3, H, W] in [0,1]; per snippet a target dict with m persons: kpts2d [m, T+F, 15, 3] (x, y in [0,1],
+    visibility, 80 % visible), depth [m, T+F, 15, 2] (value, exists), traj_ids [m], max_depth."""
     g = torch.Generator(device="cpu").manual_seed(seed)
     t_all = a.frames + a.future_frames
-    m = 8
     batches = []
     for _ in range(n_batches):
         imgs = torch.rand(a.batch, a.frames * 3, a.height, a.width, generator=g).to(device)
+        targets = []
+        for i in range(a.batch):
+            m = 6 + 2 * i                                   # 6, 8, ... persons
+            k2 = torch.rand(m, t_all, 15, 3, generator=g)
+            k2[..., 2] = (torch.rand(m, t_all, 15, generator=g) < 0.8).float()
+            d = torch.rand(m, t_all, 15, 2, generator=g)
+            d[..., 1] = (torch.rand(m, t_all, 15, generator=g) < 0.8).float()
+            targets.append({"kpts2d": k2.to(device), "depth": d.to(device), "traj_ids": torch.arange(m, device=device),
+                            "max_depth": torch.tensor(15.0, device=device)})
         labels = torch.zeros(a.batch, 60, t_all, dtype=torch.long)
-        labels[:, :m] = 1
-        tgt = {"labels": labels.to(device),
-               "kpts2d": torch.rand(a.batch, m, t_all, 15, 3, generator=g).to(device),
-               "depth": torch.rand(a.batch, m, t_all, 15, 1, generator=g).to(device)}
+        labels[:, :8] = 1
+        tgt = {"targets": targets, "labels": labels.to(device),          # the last three feed the surrogate loss only
+               "kpts2d": torch.stack([t["kpts2d"][:6] for t in targets]),
+               "depth": torch.stack([t["depth"][:6, ..., :1] for t in targets])}
         batches.append((imgs, tgt))
     return batches
+
+
+def criterion_args(a):
+    """The loss / matcher coefficients of the reference's CLI defaults (main.py:109-146)."""
+    return SimpleNamespace(
+        max_depth=15, set_cost_is_human=1, set_cost_root=1, set_cost_root_depth=1, set_cost_root_vis=0.1,
+        set_cost_joint=1, set_cost_joint_depth=1, set_cost_joint_vis=0.1, is_human_loss_coef=1, root_loss_coef=1,
+        root_depth_loss_coef=1, root_vis_loss_coef=0.1, joint_loss_coef=1, joint_depth_loss_coef=1, joint_vis_loss_coef=1,
+        joint_disp_loss_coef=1, joint_disp_depth_loss_coef=1, cont_loss_coef=0.1, heatmap_loss_coef=0.01, eos_coef=0.5,
+        aux_loss=True, dec_layers=a.dec_layers)
 
 
 def build_optimizer(model, capturable=False):
@@ -206,6 +227,8 @@ def main():
     ap.add_argument("--precision", choices=["fp32", "bf16"], default="bf16",
                     help="bf16 = autocast for the dense layers (BASELINE configs[2]); fp32 master weights, fp32 sampling")
     ap.add_argument("--use-pytorch-deform", type=int, default=0, help="1 = reference debug path (comparison only)")
+    ap.add_argument("--loss", choices=["criterion", "surrogate"], default="criterion",
+                    help="criterion = SetCriterion + Hungarian matcher as the reference trains; surrogate = fixed assignment")
     ap.add_argument("--graph", type=int, default=0, help="1 = capture the step in a hipGraph (measured: no gain on ROCm 7.2, 73 vs 71 ms; off by default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip roofline/msda extras (profiling runs)")
@@ -249,10 +272,19 @@ def main():
     batches = make_batches(a, device, 2, seed=1000 + rank)
     amp = a.precision == "bf16"
 
+    criterion = None
+    if a.loss == "criterion":
+        from snipper_amd.criterion import build_criterion
+        criterion = build_criterion(criterion_args(a)).to(device)
+
     def train_step(imgs, tgt):
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
             out, _ = net(list(imgs))
-        loss = surrogate_loss(out, tgt)
+        if criterion is not None:        # Hungarian matching + the six loss families (models/model.py:240-545)
+            losses, _ = criterion(out, tgt["targets"])
+            loss = criterion.weighted_sum(losses)
+        else:
+            loss = surrogate_loss(out, tgt)
         opt.zero_grad(set_to_none=True)
         loss.backward()
         torch.nn.utils.clip_grad_norm_(model.parameters(), 0.1)
@@ -354,7 +386,8 @@ def main():
                                     f"hidden_dim={a.hidden_dim} L=3 nq=60 {a.height}x{a.width} ResNet-50, "
                                     f"train step fwd+bwd+clip+AdamW (BASELINE configs[2]/[3])"),
                        "global_batch": a.batch * world, "per_gpu_batch": a.batch, "parallelism": f"dp{world}",
-                       "loss": "fixed-assignment surrogate (SetCriterion+Hungarian matcher not built: SURVEY 8f rank 2)",
+                       "loss": ("SetCriterion + Hungarian matcher (reference coefficients, 6+8 synthetic persons)"
+                                if a.loss == "criterion" else "fixed-assignment surrogate"),
                        "backbone_convs": "MIOpen via PyTorch; frozen 1x1 convs on the bf16 MFMA kernel (conv+BN+residual+ReLU fused)",
                        "msda_path": "pytorch grid_sample" if a.use_pytorch_deform else "snipper_amd HIP (tied single-launch)",
                        "launch": graph_note},

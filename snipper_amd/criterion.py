@@ -1,0 +1,302 @@
+"""Training criterion of Snipper: Hungarian matching + the six loss families, every decoder layer at once.
+
+API mirror of ``HungarianMatcher`` (/root/reference/models/matcher.py:10-141) and ``SetCriterion``
+(/root/reference/models/model.py:240-545): same constructor arguments, same loss names (``loss_is_human``,
+``loss_root``, ``loss_root_depth``, ``loss_root_vis``, ``loss_joint_disp``, ``loss_joint_depth_disp``,
+``loss_joint``, ``loss_joint_depth``, ``loss_joint_vis``, ``loss_cont``, ``loss_heatmap`` and their ``_{i}``
+auxiliary copies), same values (tests/test_criterion.py checks them against golden vectors produced by the
+reference's own classes).
+
+What is different is the evaluation order.  The reference matches and scores the last decoder layer, then
+loops over the auxiliary layers, each with its own cost matrices, its own ``cost.cpu()`` round trip
+(matcher.py:132) and ~100 small kernels; ``num_traj`` is read back with ``.item()`` (model.py:526).  Here all
+``n_dec`` layers are stacked: one cost tensor [n_dec, n_query, m] per sample, ONE device-to-host copy for the
+whole step, SciPy's LSAP on the host for the n_dec x batch small matrices, and every loss evaluated over the
+layer axis in one go.  Each layer matches exactly min(n_query, m_i) pairs per sample, so the gathered tensors
+are regular [n_dec, sum_i m_i, ...] arrays.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from scipy.optimize import linear_sum_assignment
+from torch import nn
+
+# temporal-continuity weight per joint (reference datasets/hybrid_dataloader.py:20)
+ROOTJOINTCONT = (0, 0.2, 0.8, 0.8, 0.8, 0.2, 0.2, 0.1, 0.1, 0.8, 0.8, 0.2, 0.2, 0.1, 0.1)
+
+_EPS = 10e-6   # the reference's "eps" (matcher.py:33, model.py:264)
+
+
+def _stack_layers(outputs: dict) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """(logits [n_dec,bs,nq,T,2], kpts2d [n_dec,bs,nq,T,K,3], depth [n_dec,bs,nq,T,K,1]) with the MAIN output last
+    (reference order: aux_outputs[0..n_dec-2] are decoder layers 0..n_dec-2, the main output is the last layer)."""
+    al = outputs.get("all_layers")
+    if al is not None:
+        k = al["pred_kpts"]
+        return al["pred_logits"], k[..., 0:3], k[..., 3:4]
+    layers = list(outputs.get("aux_outputs", [])) + [outputs]
+    return (torch.stack([o["pred_logits"] for o in layers]), torch.stack([o["pred_kpts2d"] for o in layers]),
+            torch.stack([o["pred_depth"] for o in layers]))
+
+
+class HungarianMatcher(nn.Module):
+    def __init__(self, cost_is_human: float = 1, cost_root: float = 1, cost_root_vis: float = 1,
+                 cost_joint: float = 1, cost_joint_vis: float = 1, cost_joint_depth: float = 1,
+                 cost_root_depth: float = 1):
+        super().__init__()
+        self.cost_is_human, self.cost_root, self.cost_root_vis = cost_is_human, cost_root, cost_root_vis
+        self.cost_joint, self.cost_joint_vis = cost_joint, cost_joint_vis
+        self.cost_joint_depth, self.cost_root_depth = cost_joint_depth, cost_root_depth
+        self.eps = _EPS
+
+    @torch.no_grad()
+    def cost_matrices(self, logits, kpts2d, depth, targets) -> List[torch.Tensor]:
+        """Per sample i: cost [n_dec, n_query, m_i] (the seven terms of matcher.py:86-130)."""
+        costs = []
+        for i, tgt in enumerate(targets):
+            tk = tgt["kpts2d"][None, None]                       # 1 x 1 x m x T x K x 3
+            td = tgt["depth"][None, None]                        # 1 x 1 x m x T x K x 2
+            max_depth = tgt["max_depth"]
+            ok = kpts2d[:, i].unsqueeze(2)                       # n_dec x nq x 1 x T x K x 3
+            od = depth[:, i].unsqueeze(2)                        # n_dec x nq x 1 x T x K x 1
+            prob = logits[:, i].softmax(-1)[..., 1].unsqueeze(2)  # n_dec x nq x 1 x T
+
+            t_root, t_joint, j_vis = tk[..., :1, :], tk[..., 1:, 0:2], tk[..., 1:, 2:3]
+            td_root, td_root_ok = td[..., :1, 0:1], td[..., :1, 1:2]
+            td_joint, td_joint_ok = td[..., 1:, 0:1], td[..., 1:, 1:2]
+            o_root, o_joint_raw = ok[..., :1, :], ok[..., 1:, :]
+            o_joint = o_joint_raw[..., 0:2] + o_root[..., 0:2]                       # root + displacement
+            od_root = od[..., :1, :]
+            od_joint = od_root + od[..., 1:, :] / max_depth
+
+            vis = (j_vis.sum((-2, -1)) > 0).float()                                   # 1 x 1 x m x T
+            c_class = -(prob * vis).sum(-1) / (vis.sum(-1) + self.eps)
+            c_joint = (j_vis * (o_joint - t_joint)).abs().sum((-1, -2, -3)) / (j_vis.sum((-1, -2, -3)) + self.eps)
+            c_joint_vis = (o_joint_raw[..., 2:3] - j_vis).pow(2).mean((-1, -2, -3))
+            c_joint_depth = (td_joint_ok * (od_joint - td_joint)).abs().sum((-1, -2, -3)) / \
+                (td_joint_ok.sum((-1, -2, -3)) + self.eps)
+            r_vis = t_root[..., 2:3]
+            c_root = (r_vis * (o_root[..., 0:2] - t_root[..., 0:2])).abs().sum((-1, -2, -3)) / \
+                (r_vis.sum((-1, -2, -3)) + self.eps)
+            c_root_vis = (o_root[..., 2:3] - r_vis).pow(2).mean((-1, -2, -3))
+            c_root_depth = (td_root_ok * (od_root - td_root)).abs().sum((-1, -2, -3)) / \
+                (td_root_ok.sum((-1, -2, -3)) + self.eps)
+            costs.append(self.cost_is_human * c_class + self.cost_root * c_root + self.cost_root_vis * c_root_vis +
+                         self.cost_root_depth * c_root_depth + self.cost_joint * c_joint +
+                         self.cost_joint_vis * c_joint_vis + self.cost_joint_depth * c_joint_depth)
+        return costs
+
+    @torch.no_grad()
+    def match_all_layers(self, logits, kpts2d, depth, targets):
+        """-> (src [n_dec, Msum], batch [Msum], tgt [n_dec, Msum], offsets) as device long tensors, where the pairs
+        of sample i occupy columns offsets[i]:offsets[i+1].  One device-to-host copy for everything."""
+        costs = self.cost_matrices(logits.float(), kpts2d.float(), depth.float(), targets)
+        n_dec, nq = logits.shape[0], logits.shape[2]
+        flat = torch.cat([c.reshape(-1) for c in costs]).cpu().numpy()      # the step's only matcher sync
+        src_cols, tgt_cols, batch_cols, offsets, pos = [], [], [], [0], 0
+        for i, c in enumerate(costs):
+            m = c.shape[2]
+            mat = flat[pos:pos + n_dec * nq * m].reshape(n_dec, nq, m)
+            pos += n_dec * nq * m
+            k = min(nq, m)
+            s = np.zeros((n_dec, k), dtype=np.int64)
+            t = np.zeros((n_dec, k), dtype=np.int64)
+            for l in range(n_dec):
+                if k:
+                    s[l], t[l] = linear_sum_assignment(mat[l])                # rows ascending, as the reference
+            src_cols.append(s)
+            tgt_cols.append(t)
+            batch_cols.append(np.full((k,), i, dtype=np.int64))
+            offsets.append(offsets[-1] + k)
+        dev = logits.device
+        src = torch.from_numpy(np.concatenate(src_cols, 1)).to(dev, non_blocking=True)
+        tgt = torch.from_numpy(np.concatenate(tgt_cols, 1)).to(dev, non_blocking=True)
+        batch = torch.from_numpy(np.concatenate(batch_cols)).to(dev, non_blocking=True)
+        return src, batch, tgt, offsets
+
+    @torch.no_grad()
+    def forward(self, outputs, targets):
+        """The reference's call: indices of ONE layer's outputs, a list of (index_i, index_j) per sample."""
+        src, batch, tgt, offsets = self.match_all_layers(outputs["pred_logits"][None], outputs["pred_kpts2d"][None],
+                                                         outputs["pred_depth"][None], targets)
+        return [(src[0, a:b], tgt[0, a:b]) for a, b in zip(offsets[:-1], offsets[1:])]
+
+
+def gaussian_blur(img: torch.Tensor, kernel_size: int) -> torch.Tensor:
+    """torchvision.transforms.functional.gaussian_blur(img, [k, k]) restated (sigma = 0.3*((k-1)*0.5-1)+0.8,
+    reflect padding, separable kernel).  torchvision is not vendored by the reference: parity unpinned."""
+    if kernel_size <= 1:
+        return img
+    sigma = 0.3 * ((kernel_size - 1) * 0.5 - 1) + 0.8
+    half = (kernel_size - 1) * 0.5
+    x = torch.linspace(-half, half, kernel_size, device=img.device, dtype=img.dtype)
+    k1 = torch.exp(-0.5 * (x / sigma) ** 2)
+    k1 = k1 / k1.sum()
+    k2 = (k1[:, None] * k1[None, :])[None, None]
+    shape = img.shape
+    flat = img.reshape(-1, 1, shape[-2], shape[-1])
+    pad = kernel_size // 2
+    flat = F.pad(flat, [pad, pad, pad, pad], mode="reflect")
+    return F.conv2d(flat, k2).reshape(shape)
+
+
+class SetCriterion(nn.Module):
+    def __init__(self, matcher, losses, eos_coef, weight_dict, cont_weights=None):
+        super().__init__()
+        self.matcher, self.losses, self.eos_coef, self.weight_dict = matcher, losses, eos_coef, weight_dict
+        empty_weight = torch.ones(2)
+        empty_weight[0] = eos_coef
+        self.register_buffer("empty_weight", empty_weight)
+        self.eps = _EPS
+        if cont_weights is None:
+            cont_weights = torch.tensor(ROOTJOINTCONT).float()[None, None, :, None]
+        self.register_buffer("cont_weights", cont_weights)          # [1, 1, K, 1]
+
+    # ---- the losses, over [n_dec, Msum, ...] gathered pairs ------------------------------------------
+    def _all_losses(self, logits, sk, sd, tk, td, src, batch, max_depth, num_traj) -> Dict[str, torch.Tensor]:
+        """sk / sd: matched predictions [n_dec, Msum, T, K, 3] / [.., 1]; tk / td: their targets [.., 3] / [.., 2].
+        Every entry of the result is a [n_dec] tensor (one value per decoder layer)."""
+        eps, out = self.eps, {}
+        n_dec, bs, nq, T = logits.shape[:4]
+        per = lambda x: x.sum(-1) / num_traj                                        # sum over pairs -> [n_dec]
+
+        if "is_human" in self.losses:                                               # model.py:266-287
+            tgt_vis = (tk[..., 2].sum(-1) > 0).long()                               # [n_dec, Msum, T]
+            classes = torch.zeros(n_dec, bs, nq, T, dtype=torch.long, device=logits.device)
+            lidx = torch.arange(n_dec, device=logits.device)[:, None].expand_as(src)
+            classes[lidx, batch[None].expand_as(src), src] = tgt_vis
+            ce = F.cross_entropy(logits.reshape(-1, 2).float(), classes.reshape(-1), self.empty_weight, reduction="none")
+            out["loss_is_human"] = ce.view(n_dec, -1).mean(-1)
+
+        t_root_vis = tk[..., :1, 2:3]
+        if "root" in self.losses:                                                   # model.py:289-324
+            e = t_root_vis * (sk[..., :1, 0:2] - tk[..., :1, 0:2]).abs()
+            out["loss_root"] = per((e.sum((-2, -3)) / (t_root_vis.sum((-2, -3)) + eps)).sum(-1))
+            ok = td[..., :1, 1:2]
+            e = ok * (td[..., :1, 0:1] - sd[..., :1, :]).abs()
+            out["loss_root_depth"] = per((e.sum((-2, -3)) / (ok.sum((-2, -3)) + eps)).sum(-1))
+            out["loss_root_vis"] = per((sk[..., :1, 2:3] - t_root_vis).pow(2).mean((-2, -3)).sum(-1))
+
+        t_joint_vis = tk[..., 1:, 2:3]
+        if "joint_disp" in self.losses:                                             # model.py:364-400
+            vis = t_joint_vis * t_root_vis
+            e = vis * (sk[..., 1:, 0:2] - (tk[..., 1:, 0:2] - tk[..., :1, 0:2])).abs()
+            out["loss_joint_disp"] = per((e.sum((-2, -3)) / (vis.sum((-2, -3)) + eps)).sum(-1))
+            ok = td[..., 1:, 1:2] * td[..., :1, 1:2]
+            e = ok * (sd[..., 1:, :] - (td[..., 1:, 0:1] - td[..., :1, 0:1])).abs()
+            out["loss_joint_depth_disp"] = per((e.sum((-2, -3)) / (ok.sum((-2, -3)) + eps)).sum(-1))
+
+        if "joint" in self.losses:                                                  # model.py:326-362
+            s_joint = sk[..., 1:, 0:2] + sk[..., :1, 0:2]
+            e = t_joint_vis * (s_joint - tk[..., 1:, 0:2]).abs()
+            out["loss_joint"] = per((e.sum((-2, -3)) / (t_joint_vis.sum((-2, -3)) + eps)).sum(-1))
+            s_jd = sd[..., :1, :] + sd[..., 1:, :] / max_depth
+            ok = td[..., 1:, 1:2]
+            e = ok * (s_jd - td[..., 1:, 0:1]).abs()
+            out["loss_joint_depth"] = per((e.sum((-2, -3)) / (ok.sum((-2, -3)) + eps)).sum(-1))
+            out["loss_joint_vis"] = per((sk[..., 1:, 2:3] - t_joint_vis).pow(2).mean((-2, -3)).sum(-1))
+
+        if "joint_cont" in self.losses:                                             # model.py:402-427
+            vis = tk[..., 2:3]
+            depth_abs = torch.cat([sd[..., :1, :], sd[..., :1, :] + sd[..., 1:, :] / max_depth], -2)
+            kp = torch.cat([sk[..., 0:2], depth_abs], -1)                           # [.., T, K, 3]
+            kp = torch.cat([kp[..., :1, :], kp[..., 1:, :] - kp[..., :1, :].detach()], -2)
+            cont_vis = vis[:, :, 1:] * vis[:, :, :-1]
+            e = self.cont_weights * cont_vis * (kp[:, :, 1:] - kp[:, :, :-1]).pow(2)
+            out["loss_cont"] = per((e.sum((-2, -3)) / (cont_vis.sum((-2, -3)) + eps)).sum(-1))
+        return out
+
+    def heatmap_targets(self, targets, spatial, device) -> List[torch.Tensor]:
+        """Gaussian-blurred one-hot joint maps per level, [bs, t, h, w, K] (model.py:447-483)."""
+        maps = []
+        for (t, h, w) in spatial:
+            ksize = max(h // 10 + h // 10 % 2 - 1, w // 10 + w // 10 % 2 - 1)
+            per_sample = []
+            for tgt in targets:
+                k = tgt["kpts2d"][:, :t]                                            # [n, t, K, 3]
+                x, y = (k[..., 0] * w).long(), (k[..., 1] * h).long()
+                ok = (k[..., 2] > 0) & (x >= 0) & (x < w) & (y >= 0) & (y < h)
+                K = k.shape[2]
+                hm = torch.zeros(K, t, h, w, device=device)
+                ti = torch.arange(t, device=device)[None, :, None].expand_as(x)
+                ki = torch.arange(K, device=device)[None, None, :].expand_as(x)
+                hm[ki[ok], ti[ok], y[ok], x[ok]] = 1
+                per_sample.append(gaussian_blur(hm, ksize))
+            maps.append(torch.stack(per_sample).permute(0, 2, 3, 4, 1))              # [bs, t, h, w, K]
+        return maps
+
+    def loss_heatmap(self, outputs, targets):
+        heatmaps = outputs["heatmaps"]                                               # [(bs, t, h, w, nhead, K')]
+        tmaps = self.heatmap_targets(targets, [hm.shape[1:4] for hm in heatmaps], heatmaps[0].device)
+        total = 0
+        for hm, tm in zip(heatmaps, tmaps):
+            nhead = hm.shape[4]
+            total = total + F.mse_loss(tm.unsqueeze(4).expand(-1, -1, -1, -1, nhead, -1), hm.float(), reduction="sum") / nhead
+        return total
+
+    def forward(self, outputs, targets):
+        """-> (losses dict with the reference's keys, indices of the last layer as the reference returns them)."""
+        logits, kpts2d, depth = _stack_layers(outputs)
+        n_dec = logits.shape[0]
+        src, batch, tgt, offsets = self.matcher.match_all_layers(logits, kpts2d, depth, targets)
+
+        num_traj = torch.as_tensor([float(sum(len(t["traj_ids"]) for t in targets))], device=logits.device)
+        world = 1
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            torch.distributed.all_reduce(num_traj)
+            world = torch.distributed.get_world_size()
+        num_traj = torch.clamp(num_traj / world, min=1)          # stays on the device (the reference .item()s it)
+
+        lidx = torch.arange(n_dec, device=logits.device)[:, None].expand_as(src)
+        bidx = batch[None].expand_as(src)
+        sk = kpts2d[lidx, bidx, src].float()                     # [n_dec, Msum, T, K, 3]
+        sd = depth[lidx, bidx, src].float()
+        tk = torch.cat([t["kpts2d"][tgt[:, a:b]] for t, a, b in zip(targets, offsets[:-1], offsets[1:])], 1)
+        td = torch.cat([t["depth"][tgt[:, a:b]] for t, a, b in zip(targets, offsets[:-1], offsets[1:])], 1)
+        per_layer = self._all_losses(logits, sk, sd, tk, td, src, batch, targets[0]["max_depth"], num_traj)
+
+        losses = {}
+        for name, v in per_layer.items():
+            losses[name] = v[-1]                                 # main output = last decoder layer
+            for i in range(n_dec - 1):
+                losses[f"{name}_{i}"] = v[i]
+        if "heatmap" in self.losses:
+            losses["loss_heatmap"] = self.loss_heatmap(outputs, targets)
+        indices = [(src[-1, a:b], tgt[-1, a:b]) for a, b in zip(offsets[:-1], offsets[1:])]
+        return losses, indices
+
+    def weighted_sum(self, losses: Dict[str, torch.Tensor]) -> torch.Tensor:
+        """engine.py:56: sum(loss_dict[k] * weight_dict[k] for k in loss_dict if k in weight_dict)."""
+        return sum(losses[k] * self.weight_dict[k] for k in losses if k in self.weight_dict)
+
+
+def build_matcher(args):
+    if args.max_depth == -1:
+        args.set_cost_root_depth = 0
+        args.set_cost_joint_depth = 0
+    return HungarianMatcher(cost_is_human=args.set_cost_is_human, cost_root=args.set_cost_root,
+                            cost_root_vis=args.set_cost_root_vis, cost_root_depth=args.set_cost_root_depth,
+                            cost_joint=args.set_cost_joint, cost_joint_vis=args.set_cost_joint_vis,
+                            cost_joint_depth=args.set_cost_joint_depth)
+
+
+def build_criterion(args, matcher=None):
+    """The criterion half of the reference's build_model (models/model.py:635-676)."""
+    matcher = matcher or build_matcher(args)
+    losses = ["is_human", "root", "joint", "joint_disp", "joint_cont", "heatmap"]
+    if args.max_depth == -1:
+        args.root_depth_loss_coef = args.joint_disp_depth_loss_coef = args.joint_depth_loss_coef = 0
+    wd = {"loss_is_human": args.is_human_loss_coef, "loss_root": args.root_loss_coef,
+          "loss_root_vis": args.root_vis_loss_coef, "loss_root_depth": args.root_depth_loss_coef,
+          "loss_joint_disp": args.joint_disp_loss_coef, "loss_joint_depth_disp": args.joint_disp_depth_loss_coef,
+          "loss_joint": args.joint_loss_coef, "loss_joint_vis": args.joint_vis_loss_coef,
+          "loss_joint_depth": args.joint_depth_loss_coef, "loss_cont": args.cont_loss_coef,
+          "loss_heatmap": args.heatmap_loss_coef}
+    if args.aux_loss:
+        for i in range(args.dec_layers - 1):
+            wd.update({f"{k}_{i}": v for k, v in list(wd.items()) if not k[-1].isdigit()})
+    return SetCriterion(matcher, losses, args.eos_coef, wd)

@@ -15,6 +15,8 @@ Fixtures:
   g2_core_d48.npz      D=48, M=8, L=3, P=4 core op with out-of-range locations; fp64.
   g3_module_*.pt       MSDeformAttn modules (encoder T=3, decoder T=3 and T=3+2) with randomised
                        tied Linears and a padding mask: outputs, input grads, param grads, vis lists.
+  g5_criterion.pt      SetCriterion + HungarianMatcher (reference classes, torchvision / cv2 stubbed) on random
+                       3-layer outputs: every loss, the matching, gradients of the weighted sum.
   g4_transformer.pt    one DeformableTransformer forward (T=2+1, enc2/dec2) + its state_dict
                        (pins the key schema) + gradients of a scalar loss.
 """
@@ -220,11 +222,110 @@ def gen_g4(DeformableTransformer):
     }, os.path.join(OUT, "g4_transformer.pt"))
 
 
+def _blur_like_torchvision(img, kernel_size, sigma=None):
+    """Stand-in for torchvision.transforms.functional.gaussian_blur (torchvision is not installed and not
+    vendored by the reference): its documented algorithm -- sigma = 0.3*((k-1)*0.5-1)+0.8, reflect padding,
+    separable Gaussian.  The blur itself is therefore NOT pinned by these fixtures; everything around it is."""
+    k = kernel_size[0] if isinstance(kernel_size, (list, tuple)) else kernel_size
+    if k <= 1:
+        return img
+    sig = 0.3 * ((k - 1) * 0.5 - 1) + 0.8
+    x = torch.linspace(-(k - 1) * 0.5, (k - 1) * 0.5, k, dtype=img.dtype)
+    k1 = torch.exp(-0.5 * (x / sig) ** 2)
+    k1 = k1 / k1.sum()
+    k2 = (k1[:, None] * k1[None, :])[None, None]
+    shp = img.shape
+    flat = F.pad(img.reshape(-1, 1, shp[-2], shp[-1]), [k // 2] * 4, mode="reflect")
+    return F.conv2d(flat, k2).reshape(shp)
+
+
+def import_reference_criterion():
+    """models/model.py imports torchvision.transforms.functional, the backbone (torchvision.models) and
+    datasets.hybrid_dataloader (cv2): none of them is needed by SetCriterion / HungarianMatcher themselves, so
+    they are stubbed; ROOTJOINTCONT is read out of the reference's file."""
+    import re
+    import numpy as np
+    import_reference()
+    tv = sys.modules["torchvision"]
+    tv.transforms = types.ModuleType("torchvision.transforms")
+    tv.transforms.functional = types.ModuleType("torchvision.transforms.functional")
+    tv.transforms.functional.gaussian_blur = _blur_like_torchvision
+    tv.models = types.ModuleType("torchvision.models")
+    tv.models._utils = types.ModuleType("torchvision.models._utils")
+    tv.models._utils.IntermediateLayerGetter = object
+    sys.modules["torchvision.transforms"] = tv.transforms
+    sys.modules["torchvision.transforms.functional"] = tv.transforms.functional
+    sys.modules["torchvision.models"] = tv.models
+    sys.modules["torchvision.models._utils"] = tv.models._utils
+    text = open(os.path.join(REF, "datasets", "hybrid_dataloader.py")).read()
+    vals = re.search(r"ROOTJOINTCONT = np.array\(\[(.*?)\]\)", text).group(1)
+    ds = types.ModuleType("datasets")
+    ds.hybrid_dataloader = types.ModuleType("datasets.hybrid_dataloader")
+    ds.hybrid_dataloader.ROOTJOINTCONT = np.array([float(v) for v in vals.split(",")])
+    sys.modules["datasets"] = ds
+    sys.modules["datasets.hybrid_dataloader"] = ds.hybrid_dataloader
+    import models.matcher as ref_matcher
+    import models.model as ref_model
+
+    class _NoListEq(np.ndarray):         # matcher.py:134 compares the LSAP result with [] (breaks on numpy >= 1.25)
+        def __eq__(self, other):
+            return False if isinstance(other, list) else np.ndarray.__eq__(self, other)
+    lsa = ref_matcher.linear_sum_assignment
+    ref_matcher.linear_sum_assignment = lambda c: tuple(np.asarray(a).view(_NoListEq) for a in lsa(c))
+    return ref_model, ref_matcher
+
+
+def gen_g5():
+    ref_model, ref_matcher = import_reference_criterion()
+    g = torch.Generator().manual_seed(77)
+    n_dec, bs, nq, T, F_, K = 3, 2, 7, 2, 1, 15
+    Ta = T + F_
+    matcher = ref_matcher.HungarianMatcher(cost_is_human=1, cost_root=5, cost_root_vis=0.1, cost_joint=5,
+                                           cost_joint_vis=0.1, cost_joint_depth=5, cost_root_depth=5)
+    weight = {"loss_is_human": 1, "loss_root": 1, "loss_root_vis": 0.1, "loss_root_depth": 1, "loss_joint_disp": 1,
+              "loss_joint_depth_disp": 1, "loss_joint": 1, "loss_joint_vis": 1, "loss_joint_depth": 1, "loss_cont": 0.1,
+              "loss_heatmap": 0.01}
+    cont = torch.from_numpy(sys.modules["datasets.hybrid_dataloader"].ROOTJOINTCONT).float()[None, None, :, None]
+    crit = ref_model.SetCriterion(matcher, ["is_human", "root", "joint", "joint_disp", "joint_cont", "heatmap"],
+                                  0.5, weight, cont)
+    r = lambda *s: torch.rand(*s, generator=g)
+    layers = [{"pred_logits": torch.randn(bs, nq, Ta, 2, generator=g), "pred_kpts2d": r(bs, nq, Ta, K, 3),
+               "pred_depth": r(bs, nq, Ta, K, 1)} for _ in range(n_dec)]
+    hw = [(20, 30), (10, 15), (5, 8)]
+    heat = [torch.randn(bs, T, h, w, 4, K, generator=g) * 0.1 for h, w in hw]
+    outputs = dict(layers[-1], heatmaps=heat, aux_outputs=layers[:-1])
+    targets = []
+    for m in (3, 1):
+        k2 = r(m, Ta, K, 3) * 1.2 - 0.1
+        k2[..., 2] = (torch.rand(m, Ta, K, generator=g) < 0.8)
+        d = r(m, Ta, K, 2)
+        d[..., 1] = (torch.rand(m, Ta, K, generator=g) < 0.7)
+        targets.append({"kpts2d": k2, "depth": d, "traj_ids": torch.arange(m), "max_depth": torch.tensor(15.0)})
+    for o in layers:
+        for v in o.values():
+            v.requires_grad_(True)
+    for h in heat:
+        h.requires_grad_(True)
+    losses, indices = crit(outputs, targets)
+    total = sum(losses[k] * weight[k.rsplit("_", 1)[0] if k[-1].isdigit() else k] for k in losses)
+    leaves = [v for o in layers for v in o.values()] + heat
+    grads = torch.autograd.grad(total, leaves, allow_unused=True)
+    torch.save({
+        "layers": [{k: v.detach() for k, v in o.items()} for o in layers], "heatmaps": [h.detach() for h in heat],
+        "targets": targets, "weight": weight, "losses": {k: v.detach() for k, v in losses.items()},
+        "indices": [(a.clone(), b.clone()) for a, b in indices], "total": total.detach(),
+        "grads": [None if x is None else x.detach() for x in grads],
+        "matcher_costs": dict(cost_is_human=1, cost_root=5, cost_root_vis=0.1, cost_joint=5, cost_joint_vis=0.1,
+                              cost_joint_depth=5, cost_root_depth=5),
+    }, os.path.join(OUT, "g5_criterion.pt"))
+
+
 if __name__ == "__main__":
     core, MSDeformAttn, DeformableTransformer = import_reference()
     gen_g1(core)
     gen_g2(core)
     gen_g3(MSDeformAttn)
     gen_g4(DeformableTransformer)
+    gen_g5()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -25,7 +25,7 @@ def _bench():
     return mod
 
 
-ARGS = SimpleNamespace(hidden_dim=96, enc_layers=1, dec_layers=2, frames=2, future_frames=1,
+ARGS = SimpleNamespace(hidden_dim=192, enc_layers=1, dec_layers=2, frames=2, future_frames=1,
                        use_pytorch_deform=1, batch=1, height=64, width=96)
 
 
@@ -46,11 +46,14 @@ def _worker(rank, world, port, out_dir):
             mod.dropout = 0.0
     ddp = torch.nn.parallel.DistributedDataParallel(model, broadcast_buffers=False, gradient_as_bucket_view=True,
                                                     bucket_cap_mb=50, static_graph=True)
+    from snipper_amd.criterion import build_criterion
+    crit = build_criterion(b.criterion_args(ARGS))
     opt = b.build_optimizer(model)
     imgs, tgt = b.make_batches(ARGS, "cpu", 1, seed=1000 + rank)[0]
     for it in range(2):
         out, _ = ddp(list(imgs))
-        loss = b.surrogate_loss(out, tgt)
+        losses, _ = crit(out, tgt["targets"])
+        loss = crit.weighted_sum(losses)
         opt.zero_grad(set_to_none=True)
         loss.backward()
         if it == 0:
@@ -88,7 +91,9 @@ def test_two_rank_gloo_step_matches_single_process(tmp_path):
         imgs, tgt = b.make_batches(ARGS, "cpu", 1, seed=1000 + rank)[0]
         out, _ = model(list(imgs))
         model.zero_grad(set_to_none=True)
-        b.surrogate_loss(out, tgt).backward()
+        from snipper_amd.criterion import build_criterion
+        crit = build_criterion(b.criterion_args(ARGS))
+        crit.weighted_sum(crit(out, tgt["targets"])[0]).backward()
         g = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
         acc = g if acc is None else {k: acc[k] + g[k] for k in g}
     assert set(acc) == set(r0["grads"])
