@@ -51,6 +51,13 @@ int snipper_msda_prologue_backward(void *stream, const float *grad_loc, const fl
                                    const float *inv_w, const float *inv_h, long long rows, int M, int L, int P,
                                    void *grad_off, void *grad_logit, int dtype, float *grad_ref);
 
+/* ---- Hungarian matching on the device (csrc/lsap.cuh) ---------------------------------------------------
+ * Replaces the host round trip of models/matcher.py:132 (`linear_sum_assignment(cost.cpu())`).
+ * cost [P, n, m] float32 (P independent problems, n predictions, m targets, 1 <= m <= n <= 64), device memory.
+ * out_src / out_tgt [P, m] int64: the matched (prediction, target) pairs of each problem, predictions ascending
+ * (SciPy's order).  Float64 arithmetic inside. */
+int snipper_lsap_f32(void *stream, const float *cost, int P, int n, int m, long long *out_src, long long *out_tgt);
+
 #ifdef __cplusplus
 }
 #endif

@@ -52,6 +52,7 @@ class HungarianMatcher(nn.Module):
         self.cost_joint, self.cost_joint_vis = cost_joint, cost_joint_vis
         self.cost_joint_depth, self.cost_root_depth = cost_joint_depth, cost_root_depth
         self.eps = _EPS
+        self.device_lsap = True     # HIP assignment kernel for CUDA inputs (n_query <= 64); SciPy otherwise
 
     @torch.no_grad()
     def cost_matrices(self, logits, kpts2d, depth, targets) -> List[torch.Tensor]:
@@ -96,6 +97,8 @@ class HungarianMatcher(nn.Module):
         of sample i occupy columns offsets[i]:offsets[i+1].  One device-to-host copy for everything."""
         costs = self.cost_matrices(logits.float(), kpts2d.float(), depth.float(), targets)
         n_dec, nq = logits.shape[0], logits.shape[2]
+        if logits.is_cuda and self.device_lsap and nq <= 64 and all(c.shape[2] <= nq for c in costs):
+            return self._match_on_device(costs, n_dec, nq)
         flat = torch.cat([c.reshape(-1) for c in costs]).cpu().numpy()      # the step's only matcher sync
         src_cols, tgt_cols, batch_cols, offsets, pos = [], [], [], [0], 0
         for i, c in enumerate(costs):
@@ -117,6 +120,28 @@ class HungarianMatcher(nn.Module):
         tgt = torch.from_numpy(np.concatenate(tgt_cols, 1)).to(dev, non_blocking=True)
         batch = torch.from_numpy(np.concatenate(batch_cols)).to(dev, non_blocking=True)
         return src, batch, tgt, offsets
+
+    def _match_on_device(self, costs, n_dec, nq):
+        """One wave per (layer, sample) problem (csrc/lsap.cuh): no device-to-host copy at all."""
+        from . import _lib
+        lib = _lib.load()
+        dev = costs[0].device
+        srcs, tgts, batch, offsets = [], [], [], [0]
+        for i, c in enumerate(costs):
+            m = c.shape[2]
+            s = torch.empty((n_dec, m), dtype=torch.long, device=dev)
+            t = torch.empty((n_dec, m), dtype=torch.long, device=dev)
+            if m:
+                c = c.contiguous()
+                with torch.cuda.device(dev):
+                    rc = lib.snipper_lsap_f32(torch.cuda.current_stream(dev).cuda_stream, c.data_ptr(), n_dec, nq, m,
+                                              s.data_ptr(), t.data_ptr())
+                _lib.check(rc, "snipper_lsap_f32")
+            srcs.append(s)
+            tgts.append(t)
+            batch.append(torch.full((m,), i, dtype=torch.long, device=dev))
+            offsets.append(offsets[-1] + m)
+        return torch.cat(srcs, 1), torch.cat(batch), torch.cat(tgts, 1), offsets
 
     @torch.no_grad()
     def forward(self, outputs, targets):
@@ -224,7 +249,10 @@ class SetCriterion(nn.Module):
                 hm = torch.zeros(K, t, h, w, device=device)
                 ti = torch.arange(t, device=device)[None, :, None].expand_as(x)
                 ki = torch.arange(K, device=device)[None, None, :].expand_as(x)
-                hm[ki[ok], ti[ok], y[ok], x[ok]] = 1
+                # no boolean-mask indexing (it would read the count back to the host): invalid joints add 0 at a
+                # clamped position, valid ones add 1, several on one pixel still give 1
+                hm.index_put_((ki, ti, y.clamp(0, h - 1), x.clamp(0, w - 1)), ok.to(hm.dtype), accumulate=True)
+                hm.clamp_(max=1)
                 per_sample.append(gaussian_blur(hm, ksize))
             maps.append(torch.stack(per_sample).permute(0, 2, 3, 4, 1))              # [bs, t, h, w, K]
         return maps
@@ -244,12 +272,14 @@ class SetCriterion(nn.Module):
         n_dec = logits.shape[0]
         src, batch, tgt, offsets = self.matcher.match_all_layers(logits, kpts2d, depth, targets)
 
-        num_traj = torch.as_tensor([float(sum(len(t["traj_ids"]) for t in targets))], device=logits.device)
+        # normaliser = persons per rank (model.py:521-526); built with a fill kernel -- a tensor made from a Python
+        # list is a blocking host-to-device copy, and the reference's .item() a device-to-host one
+        num_traj = torch.full((1,), float(sum(len(t["traj_ids"]) for t in targets)), device=logits.device)
         world = 1
         if torch.distributed.is_available() and torch.distributed.is_initialized():
             torch.distributed.all_reduce(num_traj)
             world = torch.distributed.get_world_size()
-        num_traj = torch.clamp(num_traj / world, min=1)          # stays on the device (the reference .item()s it)
+        num_traj = torch.clamp(num_traj / world, min=1)
 
         lidx = torch.arange(n_dec, device=logits.device)[:, None].expand_as(src)
         bidx = batch[None].expand_as(src)

@@ -15,6 +15,7 @@
 #include "../../include/snipper_dense.h"
 #include "gemm_bf16.cuh"
 #include "msda_prologue.cuh"
+#include "lsap.cuh"
 #include "msda_d48.cuh"
 #include "msda_d48_owner.cuh"
 #include "msda_generic.cuh"
@@ -466,6 +467,13 @@ int snipper_msda_prologue_backward(void *stream, const float *grad_loc, const fl
     hipLaunchKernelGGL(prologue_bwd_kernel<uint16_t>, grid, dim3(256), 0, (hipStream_t)stream, grad_loc, grad_prob, prob,
                        sc, rows, M, L, P, (uint16_t *)grad_off, (uint16_t *)grad_logit, grad_ref);
   else return SNIPPER_E_UNSUPPORTED;
+  return launch_status();
+}
+
+int snipper_lsap_f32(void *stream, const float *cost, int P, int n, int m, long long *out_src, long long *out_tgt) {
+  if (!cost || !out_src || !out_tgt) return SNIPPER_E_NULL;
+  if (P <= 0 || m <= 0 || n < m || n > kLsapMaxCols || m > kLsapMaxRows) return SNIPPER_E_SHAPE;
+  hipLaunchKernelGGL(lsap_kernel, dim3(P), dim3(64), 0, (hipStream_t)stream, cost, n, m, out_src, out_tgt);
   return launch_status();
 }
 
