@@ -118,10 +118,10 @@ def criterion_args(a):
         aux_loss=True, dec_layers=a.dec_layers)
 
 
-def build_optimizer(model, capturable=False):
-    """AdamW with the reference's three groups (main.py:201-221)."""
+def build_optimizer(named_params, capturable=False):
+    """AdamW with the reference's three groups (main.py:201-221) over (name, parameter) pairs."""
     def named(pred):
-        return [p for n, p in model.named_parameters() if p.requires_grad and pred(n)]
+        return [p for n, p in named_params if p.requires_grad and pred(n)]
     slow = lambda n: ("reference_points" in n or "sampling_offsets" in n) and "backbone" not in n
     groups = [
         {"params": named(lambda n: "backbone" not in n and not slow(n)), "lr": 1e-4},
@@ -229,6 +229,8 @@ def main():
     ap.add_argument("--use-pytorch-deform", type=int, default=0, help="1 = reference debug path (comparison only)")
     ap.add_argument("--loss", choices=["criterion", "surrogate"], default="criterion",
                     help="criterion = SetCriterion + Hungarian matcher as the reference trains; surrogate = fixed assignment")
+    ap.add_argument("--master-weights", type=int, default=0,
+                    help="bf16 only: 1 = bf16 parameters + fp32 master copy in the optimizer; 0 = fp32 parameters under autocast")
     ap.add_argument("--graph", type=int, default=0, help="1 = capture the step in a hipGraph (measured: no gain on ROCm 7.2, 73 vs 71 ms; off by default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip roofline/msda extras (profiling runs)")
@@ -263,14 +265,34 @@ def main():
     # gradient buckets alias them without a strided copy
     model = model.to(memory_format=torch.channels_last)
     model.train()
-    opt = build_optimizer(model, capturable=bool(a.graph))
+    amp = a.precision == "bf16"
+    masters = None
+    if amp and a.master_weights:
+        # Mixed precision with fp32 MASTER weights: the model's parameters are stored in bf16 (no per-call
+        # autocast casts: ~780 tiny launches per step), the optimizer owns an fp32 copy, gradients are widened
+        # and the updated masters narrowed back with multi-tensor copies.  FrozenBN statistics stay fp32.
+        from snipper_amd.backbone import FrozenBatchNorm2d
+        named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+        master_named = [(n, p.detach().clone().float().requires_grad_(True)) for n, p in named]
+        bn_names = ("weight", "bias", "running_mean", "running_var")
+        bn_saved = [(mod, {k: getattr(mod, k).detach().clone() for k in bn_names})
+                    for mod in model.modules() if isinstance(mod, FrozenBatchNorm2d)]
+        model.to(torch.bfloat16)
+        for mod, sv in bn_saved:
+            for k, v in sv.items():
+                setattr(mod, k, v)
+        for (n, mp), (_, p) in zip(master_named, named):
+            mp.grad = torch.zeros_like(mp)
+        masters = ([mp for _, mp in master_named], [p for _, p in named])
+        opt = build_optimizer(master_named, capturable=bool(a.graph))
+    else:
+        opt = build_optimizer(list(model.named_parameters()), capturable=bool(a.graph))
     net = model
     if use_ddp:
         net = torch.nn.parallel.DistributedDataParallel(
             model, device_ids=[local_rank], broadcast_buffers=False, gradient_as_bucket_view=True,
             bucket_cap_mb=50, static_graph=True)
     batches = make_batches(a, device, 2, seed=1000 + rank)
-    amp = a.precision == "bf16"
 
     criterion = None
     if a.loss == "criterion":
@@ -285,10 +307,22 @@ def main():
             loss = criterion.weighted_sum(losses)
         else:
             loss = surrogate_loss(out, tgt)
-        opt.zero_grad(set_to_none=True)
-        loss.backward()
-        torch.nn.utils.clip_grad_norm_(model.parameters(), 0.1)
-        opt.step()
+        if masters is None:
+            opt.zero_grad(set_to_none=True)
+            loss.backward()
+            torch.nn.utils.clip_grad_norm_(model.parameters(), 0.1)
+            opt.step()
+        else:
+            mp, pp = masters
+            for p in pp:
+                p.grad = None
+            loss.backward()
+            with torch.no_grad():
+                torch._foreach_copy_([m.grad for m in mp], [p.grad for p in pp])  # bf16 -> fp32, multi-tensor
+            torch.nn.utils.clip_grad_norm_(mp, 0.1)
+            opt.step()
+            with torch.no_grad():
+                torch._foreach_copy_(pp, mp)                                      # fp32 -> bf16, multi-tensor
         return loss
 
     def step(i):
@@ -348,6 +382,15 @@ def main():
             def step(i):                                      # noqa: F811
                 return train_step(*batches[i % len(batches)])
 
+    if os.environ.get("SNIPPER_CPROFILE"):        # host-side profile of the step (development aid)
+        import cProfile, pstats
+        pr = cProfile.Profile()
+        pr.enable()
+        for i in range(3):
+            step(i)
+        torch.cuda.synchronize()
+        pr.disable()
+        pstats.Stats(pr, stream=sys.stderr).sort_stats("tottime").print_stats(45)
     t0 = time.perf_counter()
     for i in range(a.steps):
         loss = step(a.warmup + i)
@@ -390,7 +433,9 @@ def main():
                                 if a.loss == "criterion" else "fixed-assignment surrogate"),
                        "backbone_convs": "MIOpen via PyTorch; frozen 1x1 convs on the bf16 MFMA kernel (conv+BN+residual+ReLU fused)",
                        "msda_path": "pytorch grid_sample" if a.use_pytorch_deform else "snipper_amd HIP (tied single-launch)",
-                       "launch": graph_note},
+                       "launch": graph_note,
+                       "weights": ("bf16 parameters + fp32 master weights" if masters is not None else
+                                   "fp32 parameters" + (" under bf16 autocast" if amp else ""))},
             "final_loss": round(loss_val, 5),
         }
         if launches:

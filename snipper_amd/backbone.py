@@ -12,10 +12,11 @@ torchvision's parameter names, so a reference checkpoint's ``backbone.0.body.*``
 unchanged.  Parity status of this file: UNPINNED against torchvision (no reference test or
 golden vector exists for it); it is checked layer by layer against ``F.conv2d`` compositions.
 
-Round-1 status: the 1x1 convolutions of the frozen part (stem side of layer1) run on this repository's
-bf16 MFMA kernel with BN, residual and ReLU fused (csrc/gemm_bf16.cuh) when the activations are bf16
-NHWC; every other convolution runs through PyTorch (MIOpen).  Hand-written 3x3 / 7x7 / strided and
-backward convolution kernels are the next row.
+Round-1 status: every 1x1 convolution of the network (36 of its 53 convolutions, ~55 % of its FLOPs) runs on
+this repository's bf16 MFMA kernel when the activations are bf16 NHWC -- forward and data gradient with BN,
+residual and ReLU fused in the epilogue (csrc/gemm_bf16.cuh), weight gradient through hipBLASLt; the 3x3
+convolutions and the 7x7 stem still run through PyTorch (MIOpen).  Hand-written kernels for those are the
+next row.
 """
 from __future__ import annotations
 
@@ -63,9 +64,9 @@ def conv_frozen_bn(x, conv: nn.Conv2d, bn: FrozenBatchNorm2d, relu: bool, residu
     the live weight every call (a few MB), so gradients reach ``conv.weight`` exactly as before.
     """
     scale, shift = bn.scale_bias()
+    if _hip_pointwise_ok(x, conv, None):
+        return _hip_pointwise(x, conv, scale.float(), shift, relu, residual)
     w = conv.weight * scale.view(-1, 1, 1, 1).to(conv.weight.dtype)
-    if _hip_pointwise_ok(x, conv, w):
-        return _hip_pointwise(x, w, shift, relu, residual)
     y = F.conv2d(x, w, shift.to(w.dtype), conv.stride, conv.padding, conv.dilation, conv.groups)
     if residual is not None:
         y = y + residual
@@ -73,23 +74,58 @@ def conv_frozen_bn(x, conv: nn.Conv2d, bn: FrozenBatchNorm2d, relu: bool, residu
 
 
 def _hip_pointwise_ok(x, conv, w) -> bool:
-    """1x1 stride-1 convolution of a bf16 NHWC activation outside autograd (the frozen stem / layer1 under
-    autocast): in NHWC that is exactly the dense kernel Y[M, Cout] = X[M, Cin] . W[Cout, Cin]^T."""
-    return (x.is_cuda and x.dtype == torch.bfloat16 and not torch.is_grad_enabled() and
-            conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.groups == 1 and
-            conv.in_channels % 64 == 0 and conv.out_channels % 4 == 0 and
-            x.is_contiguous(memory_format=torch.channels_last))
+    """1x1 convolution (stride 1, or stride s handled by sub-sampling first) of a bf16 NHWC activation: in NHWC that
+    is exactly the dense kernel Y[M, Cout] = X[M, Cin] . W[Cout, Cin]^T (csrc/gemm_bf16.cuh)."""
+    return (x.is_cuda and x.dtype == torch.bfloat16 and conv.kernel_size == (1, 1) and conv.padding == (0, 0) and
+            conv.stride[0] == conv.stride[1] and conv.groups == 1 and conv.in_channels % 64 == 0 and
+            conv.out_channels % 64 == 0 and x.is_contiguous(memory_format=torch.channels_last))
 
 
-def _hip_pointwise(x, w, shift, relu, residual):
-    """conv1x1 + folded BN (+ residual) (+ ReLU) in ONE launch of the MFMA kernel (csrc/gemm_bf16.cuh)."""
-    from .dense import linear_bf16
+class _PointwiseConvBN(torch.autograd.Function):
+    """relu?(X . (W * scale)^T + shift (+ residual)) on [M, C] views of NHWC tensors, forward and backward.
+
+    Forward and the data gradient run on this repository's MFMA kernel (one launch each, epilogue fused); the
+    weight gradient (a [Cout, M] x [M, Cin] product, M = batch * H * W) goes through hipBLASLt.  Besides the fused
+    passes this avoids MIOpen's host-side cost per convolution call (~170 us measured: solver look-up), which was
+    the largest single item of the step's CPU time."""
+
+    @staticmethod
+    def forward(ctx, x2, weight, scale, shift, res2, relu):
+        from .dense import linear_bf16
+        cout, cin = weight.shape[0], weight.shape[1]
+        w_eff = (weight.reshape(cout, cin).float() * scale[:, None]).to(torch.bfloat16)
+        y = linear_bf16(x2, w_eff, shift, res2, relu)
+        ctx.relu, ctx.has_res = relu, res2 is not None
+        ctx.wshape, ctx.wdtype = weight.shape, weight.dtype
+        ctx.save_for_backward(x2, w_eff, scale, y if relu else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        from .dense import linear_bf16
+        x2, w_eff, scale, y = ctx.saved_tensors
+        g = gy.contiguous()
+        if ctx.relu:
+            g = torch.ops.aten.threshold_backward(g, y, 0)
+        dx = linear_bf16(g, w_eff.t().contiguous()) if ctx.needs_input_grad[0] else None
+        dw = None
+        if ctx.needs_input_grad[1]:
+            dw = (torch.mm(g.t(), x2).float() * scale[:, None]).reshape(ctx.wshape).to(ctx.wdtype)
+        return dx, dw, None, None, (g if ctx.has_res else None), None
+
+
+def _hip_pointwise(x, conv, scale, shift, relu, residual):
+    """conv1x1 + folded BN (+ residual) (+ ReLU) as ONE launch of the MFMA kernel."""
+    if conv.stride != (1, 1):
+        x = x[:, :, ::conv.stride[0], ::conv.stride[1]].contiguous(memory_format=torch.channels_last)
     b, c, h, wd = x.shape
     rows = x.permute(0, 2, 3, 1).reshape(b * h * wd, c)                      # a view: NHWC is row-major [M, Cin]
     res = None
     if residual is not None:
         res = residual.permute(0, 2, 3, 1).reshape(b * h * wd, -1)
-    y = linear_bf16(rows, w.view(w.shape[0], c).to(torch.bfloat16), shift.float(), res, relu)
+        if res.dtype != torch.bfloat16:
+            res = res.to(torch.bfloat16)
+    y = _PointwiseConvBN.apply(rows, conv.weight, scale, shift.float(), res, relu)
     return y.view(b, h, wd, -1).permute(0, 3, 1, 2)                          # logical NCHW, channels_last memory
 
 

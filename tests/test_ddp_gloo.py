@@ -48,7 +48,7 @@ def _worker(rank, world, port, out_dir):
                                                     bucket_cap_mb=50, static_graph=True)
     from snipper_amd.criterion import build_criterion
     crit = build_criterion(b.criterion_args(ARGS))
-    opt = b.build_optimizer(model)
+    opt = b.build_optimizer(list(model.named_parameters()))
     imgs, tgt = b.make_batches(ARGS, "cpu", 1, seed=1000 + rank)[0]
     for it in range(2):
         out, _ = ddp(list(imgs))

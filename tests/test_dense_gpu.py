@@ -47,24 +47,33 @@ def test_linear_bf16_strided_rows_and_batch_dims():
         linear_bf16(big[..., :100], torch.zeros(64, 100, dtype=torch.bfloat16, device=DEV))   # K % 64 != 0
 
 
-def test_frozen_bottleneck_on_hip_matches_miopen():
-    """bf16 NHWC, no grad: the Bottleneck's 1x1 convolutions take the MFMA kernel; compare with the
-    same block forced through F.conv2d."""
+@pytest.mark.parametrize("stride,down", [(1, False), (2, True)])
+@pytest.mark.parametrize("train", [False, True])
+def test_bottleneck_on_hip_matches_miopen(stride, down, train):
+    """bf16 NHWC: the Bottleneck's 1x1 convolutions take the MFMA kernel (forward AND backward when training);
+    compare outputs and gradients with the same block forced through F.conv2d."""
     import snipper_amd.backbone as bb
     torch.manual_seed(0)
-    blk = bb.Bottleneck(256, 64).to(DEV)
+    blk = bb.Bottleneck(256, 64, stride=stride, downsample=down).to(DEV)
     for m in blk.modules():
         if isinstance(m, bb.FrozenBatchNorm2d):
             m.weight.uniform_(0.5, 1.5); m.bias.normal_(0, 0.1); m.running_mean.normal_(0, 0.1); m.running_var.uniform_(0.5, 1.5)
-    x = torch.randn(2, 256, 20, 24, device=DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
-    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
-        assert bb._hip_pointwise_ok(x, blk.conv1, blk.conv1.weight)
-        got = blk(x)
-        saved = bb._hip_pointwise_ok
-        bb._hip_pointwise_ok = lambda *a: False
+    x0 = torch.randn(2, 256, 20, 24, device=DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    go = torch.randn(2, 256, 20 // stride, 24 // stride, device=DEV).to(torch.bfloat16)
+    res = {}
+    saved = bb._hip_pointwise_ok
+    for hip in (True, False):
+        bb._hip_pointwise_ok = saved if hip else (lambda *a: False)
         try:
-            ref = blk(x)
+            x = x0.clone().requires_grad_(train)
+            with torch.autocast("cuda", dtype=torch.bfloat16), torch.set_grad_enabled(train):
+                y = blk(x)
+            grads = torch.autograd.grad(y, [x] + list(blk.parameters()), go) if train else ()
+            res[hip] = (y, grads)
         finally:
             bb._hip_pointwise_ok = saved
-    assert got.shape == ref.shape and got.is_contiguous(memory_format=torch.channels_last)
-    torch.testing.assert_close(got.float(), ref.float(), rtol=3e-2, atol=3e-2)
+    assert res[True][0].is_contiguous(memory_format=torch.channels_last)
+    torch.testing.assert_close(res[True][0].float(), res[False][0].float(), rtol=3e-2, atol=3e-2)
+    for a, b in zip(res[True][1], res[False][1]):
+        s = max(float(b.float().abs().max()), 1e-3)
+        torch.testing.assert_close(a.float() / s, b.float() / s, rtol=5e-2, atol=2e-2)
