@@ -47,12 +47,23 @@ class FrozenBatchNorm2d(nn.Module):
         super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
 
     def scale_bias(self):
-        scale = self.weight * (self.running_var + self.eps).rsqrt()
-        return scale, self.bias - self.running_mean * scale
+        """(scale, shift) of the affine map (at least float32), cached until one of the four buffers is modified or moved
+        (they are constants during training; recomputing them cost ~5 tiny launches per convolution call)."""
+        bufs = (self.weight, self.bias, self.running_mean, self.running_var)
+        key = tuple((b._version, b.data_ptr(), b.dtype) for b in bufs)
+        cached = getattr(self, "_affine_cache", None)
+        if cached is None or cached[0] != key:
+            with torch.no_grad():
+                dt = torch.promote_types(self.weight.dtype, torch.float32)     # at least float32
+                scale = self.weight.to(dt) * (self.running_var.to(dt) + self.eps).rsqrt()
+                shift = self.bias.to(dt) - self.running_mean.to(dt) * scale
+            cached = (key, scale, shift)
+            self._affine_cache = cached
+        return cached[1], cached[2]
 
     def forward(self, x):
         scale, bias = self.scale_bias()
-        return x * scale.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1)
+        return x * scale.view(1, -1, 1, 1).to(x.dtype) + bias.view(1, -1, 1, 1).to(x.dtype)
 
 
 def conv_frozen_bn(x, conv: nn.Conv2d, bn: FrozenBatchNorm2d, relu: bool, residual=None):
@@ -65,7 +76,7 @@ def conv_frozen_bn(x, conv: nn.Conv2d, bn: FrozenBatchNorm2d, relu: bool, residu
     """
     scale, shift = bn.scale_bias()
     if _hip_pointwise_ok(x, conv, None):
-        return _hip_pointwise(x, conv, scale.float(), shift, relu, residual)
+        return _hip_pointwise(x, conv, scale.float(), shift.float(), relu, residual)
     w = conv.weight * scale.view(-1, 1, 1, 1).to(conv.weight.dtype)
     y = F.conv2d(x, w, shift.to(w.dtype), conv.stride, conv.padding, conv.dilation, conv.groups)
     if residual is not None:

@@ -74,6 +74,8 @@ def test_bottleneck_on_hip_matches_miopen(stride, down, train):
             bb._hip_pointwise_ok = saved
     assert res[True][0].is_contiguous(memory_format=torch.channels_last)
     torch.testing.assert_close(res[True][0].float(), res[False][0].float(), rtol=3e-2, atol=3e-2)
+    # gradients: a ReLU whose bf16 pre-activation lands on the other side of 0 flips a few mask bits, so compare in
+    # relative L2 norm instead of element by element
     for a, b in zip(res[True][1], res[False][1]):
-        s = max(float(b.float().abs().max()), 1e-3)
-        torch.testing.assert_close(a.float() / s, b.float() / s, rtol=5e-2, atol=2e-2)
+        err = float((a.float() - b.float()).norm() / (b.float().norm() + 1e-12))
+        assert err < 8e-2, err
