@@ -28,6 +28,12 @@ int snipper_linear_bf16(void *stream, const uint16_t *X, long long ldx, const ui
                         const float *bias, const uint16_t *R, long long ldr, uint16_t *Y, long long ldy,
                         int M, int N, int K, int relu);
 
+/* 3x3 convolution, padding 1, stride 1 or 2, NHWC bf16, as an implicit GEMM on the same MFMA tiles:
+ * Y[B,Ho,Wo,Cout] = act(conv(X[B,H,W,Cin], W[Cout,3,3,Cin]) + bias[Cout]), Ho = (H-1)/stride + 1 (same for Wo).
+ * Requirements: Cin % 64 == 0, Cout % 4 == 0.  (ResNet bottleneck conv2 with the frozen BatchNorm folded in.) */
+int snipper_conv3x3_bf16(void *stream, const uint16_t *X, const uint16_t *W, const float *bias, uint16_t *Y,
+                         int B, int H, int Wd, int Cin, int Cout, int stride, int relu);
+
 /* ---- element-wise fusions around the core op (csrc/msda_prologue.cuh) --------------------------------
  * dtype codes: 0 = float32, 1 = bfloat16 bits.
  *

@@ -36,6 +36,7 @@ EXPORTS = {
                                        ctypes.c_longlong, c_int, c_int, c_int, c_void_p, c_void_p], c_int),
     "snipper_msda_prologue_backward": ([c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_longlong,
                                         c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p], c_int),
+    "snipper_conv3x3_bf16": ([c_void_p] * 5 + [c_int] * 7, c_int),
     "snipper_lsap_f32": ([c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p], c_int),
     "snipper_linear_bf16": ([c_void_p, c_void_p, ctypes.c_longlong, c_void_p, c_void_p, c_void_p, ctypes.c_longlong,
                              c_void_p, ctypes.c_longlong, c_int, c_int, c_int, c_int], c_int),

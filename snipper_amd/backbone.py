@@ -12,11 +12,12 @@ torchvision's parameter names, so a reference checkpoint's ``backbone.0.body.*``
 unchanged.  Parity status of this file: UNPINNED against torchvision (no reference test or
 golden vector exists for it); it is checked layer by layer against ``F.conv2d`` compositions.
 
-Round-1 status: every 1x1 convolution of the network (36 of its 53 convolutions, ~55 % of its FLOPs) runs on
-this repository's bf16 MFMA kernel when the activations are bf16 NHWC -- forward and data gradient with BN,
-residual and ReLU fused in the epilogue (csrc/gemm_bf16.cuh), weight gradient through hipBLASLt; the 3x3
-convolutions and the 7x7 stem still run through PyTorch (MIOpen).  Hand-written kernels for those are the
-next row.
+Round-1 status, for bf16 NHWC activations: every 1x1 convolution of the network (36 of its 53 convolutions, ~55 %
+of its FLOPs) runs on this repository's bf16 MFMA kernel -- forward and data gradient with BN, residual and ReLU
+fused in the epilogue (csrc/gemm_bf16.cuh), weight gradient through hipBLASLt; the 16 3x3 convolutions run their
+forward and their stride-1 data gradient on the implicit-GEMM variant of the same kernel (stride-2 data gradient
+and weight gradients through MIOpen); the 7x7 stem (3 input
+channels, frozen) and the max-pool still run through PyTorch.
 """
 from __future__ import annotations
 
@@ -77,6 +78,8 @@ def conv_frozen_bn(x, conv: nn.Conv2d, bn: FrozenBatchNorm2d, relu: bool, residu
     scale, shift = bn.scale_bias()
     if _hip_pointwise_ok(x, conv, None):
         return _hip_pointwise(x, conv, scale.float(), shift.float(), relu, residual)
+    if residual is None and _hip_conv3x3_ok(x, conv):
+        return _Conv3x3BN.apply(x, conv.weight, scale.float(), shift.float(), conv.stride[0], relu)
     w = conv.weight * scale.view(-1, 1, 1, 1).to(conv.weight.dtype)
     y = F.conv2d(x, w, shift.to(w.dtype), conv.stride, conv.padding, conv.dilation, conv.groups)
     if residual is not None:
@@ -123,6 +126,51 @@ class _PointwiseConvBN(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             dw = (torch.mm(g.t(), x2).float() * scale[:, None]).reshape(ctx.wshape).to(ctx.wdtype)
         return dx, dw, None, None, (g if ctx.has_res else None), None
+
+
+def _hip_conv3x3_ok(x, conv) -> bool:
+    """3x3, padding 1, stride 1 or 2 (every bottleneck conv2) of a bf16 NHWC activation: implicit GEMM on the MFMA
+    tiles (csrc/gemm_bf16.cuh, conv3x3_bf16_kernel)."""
+    return (x.is_cuda and x.dtype == torch.bfloat16 and conv.kernel_size == (3, 3) and conv.padding == (1, 1) and
+            conv.stride in ((1, 1), (2, 2)) and conv.dilation == (1, 1) and conv.groups == 1 and
+            conv.in_channels % 64 == 0 and conv.out_channels % 4 == 0 and
+            x.is_contiguous(memory_format=torch.channels_last))
+
+
+class _Conv3x3BN(torch.autograd.Function):
+    """relu?(conv3x3(x, W * scale) + shift): forward on this repository's implicit-GEMM kernel (one launch, BN and
+    ReLU in the epilogue); the stride-1 data gradient on the same kernel (taps reversed, channel roles swapped); the
+    stride-2 data gradient and every weight gradient through ``aten.convolution_backward`` (MIOpen) for now."""
+
+    @staticmethod
+    def forward(ctx, x, weight, scale, shift, stride, relu):
+        from .dense import conv3x3_bf16
+        w_eff = (weight.float() * scale.view(-1, 1, 1, 1)).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        y = conv3x3_bf16(x, w_eff, shift, stride, relu)
+        ctx.stride, ctx.relu, ctx.wdtype = stride, relu, weight.dtype
+        ctx.save_for_backward(x, w_eff, scale, y if relu else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w_eff, scale, y = ctx.saved_tensors
+        g = gy.contiguous(memory_format=torch.channels_last)
+        if ctx.relu:
+            g = torch.ops.aten.threshold_backward(g, y, 0)
+        from .dense import conv3x3_bf16
+        own_dgrad = ctx.needs_input_grad[0] and ctx.stride == 1 and w_eff.shape[0] % 64 == 0
+        need = [ctx.needs_input_grad[0] and not own_dgrad, ctx.needs_input_grad[1], False]
+        dx, dw = None, None
+        if need[0] or need[1]:
+            dx, dw, _ = torch.ops.aten.convolution_backward(
+                g, x, w_eff, None, [ctx.stride] * 2, [1, 1], [1, 1], False, [0, 0], 1, need)
+        if own_dgrad:
+            # stride 1: the data gradient is the same convolution with the taps reversed and the channel roles swapped
+            w_t = w_eff.flip(2, 3).transpose(0, 1).contiguous(memory_format=torch.channels_last)
+            dx = conv3x3_bf16(g, w_t, None, 1, False)
+        if dw is not None:
+            dw = (dw.float() * scale.view(-1, 1, 1, 1)).to(ctx.wdtype)
+        return dx, dw, None, None, None, None
 
 
 def _hip_pointwise(x, conv, scale, shift, relu, residual):

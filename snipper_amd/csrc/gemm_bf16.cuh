@@ -132,4 +132,106 @@ __global__ __launch_bounds__(kGemmThreads) void linear_bf16_kernel(GemmArgs g) {
   }
 }
 
+// ---- 3x3 convolution, NHWC, as an implicit GEMM on the same tile machinery --------------------------------
+//   Y[b, oy, ox, :] = act( sum_{ky,kx} X[b, oy*s + ky - 1, ox*s + kx - 1, :] . W[:, ky, kx, :]^T + bias )
+// X [B, H, W, Cin] bf16, W [Cout, 3, 3, Cin] bf16 (the channels_last layout of a PyTorch conv weight), padding 1,
+// stride s in {1, 2}, Cin % 64 == 0.  The K loop runs over (tap, 64-channel slice): a row of the A tile is the
+// input pixel under that tap for one output pixel (zeros outside the image), so nothing is materialised.
+struct Conv3x3Args {
+  const uint16_t *X;   // [B][H][W][Cin]
+  const uint16_t *W;   // [Cout][3][3][Cin]
+  const float *bias;   // [Cout] or nullptr
+  uint16_t *Y;         // [B][Ho][Wo][Cout]
+  int B, H, Wd, Cin, Cout, Ho, Wo, stride;
+};
+
+template <bool RELU>
+__global__ __launch_bounds__(kGemmThreads) void conv3x3_bf16_kernel(Conv3x3Args g) {
+  __shared__ __attribute__((aligned(16))) uint16_t Xs[kGemmBM * kGemmPad];
+  __shared__ __attribute__((aligned(16))) uint16_t Ws[kGemmBN * kGemmPad];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave & 1, wn = wave >> 1;
+  const int M = g.B * g.Ho * g.Wo;
+  const int m0 = blockIdx.x * kGemmBM, n0 = blockIdx.y * kGemmBN;
+  const int kslices = g.Cin / kGemmBK, steps = 9 * kslices;
+
+  int pb[4], py[4], px[4], kc8[4], lds_off[4];
+  const uint16_t *wrow[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int idx = tid + kGemmThreads * i, row = idx >> 3, kc = idx & 7;
+    const int m = min(m0 + row, M - 1);
+    pb[i] = m / (g.Ho * g.Wo);
+    const int r = m - pb[i] * (g.Ho * g.Wo);
+    py[i] = (r / g.Wo) * g.stride - 1;
+    px[i] = (r % g.Wo) * g.stride - 1;
+    kc8[i] = kc * 8;
+    wrow[i] = g.W + (long long)min(n0 + row, g.Cout - 1) * 9 * g.Cin + kc * 8;
+    lds_off[i] = row * kGemmPad + kc * 8;
+  }
+  auto load_step = [&](int s, gemm_u32x4 (&xr)[4], gemm_u32x4 (&wr)[4]) {
+    const int tap = s / kslices, k0 = (s - tap * kslices) * kGemmBK;
+    const int ky = tap / 3, kx = tap - ky * 3;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int iy = py[i] + ky, ix = px[i] + kx;
+      const bool ok = iy >= 0 && iy < g.H && ix >= 0 && ix < g.Wd;
+      const uint16_t *xp = g.X + (((long long)pb[i] * g.H + (ok ? iy : 0)) * g.Wd + (ok ? ix : 0)) * g.Cin + k0 + kc8[i];
+      const gemm_u32x4 v = *reinterpret_cast<const gemm_u32x4 *>(xp);
+      xr[i] = ok ? v : gemm_u32x4{0u, 0u, 0u, 0u};
+      wr[i] = *reinterpret_cast<const gemm_u32x4 *>(wrow[i] + (long long)tap * g.Cin + k0);
+    }
+  };
+  gemm_u32x4 xr[4], wr[4];
+  load_step(0, xr, wr);
+  gemm_f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = gemm_f32x4{0.f, 0.f, 0.f, 0.f};
+  const int frag_row = lane & 15, frag_k = (lane >> 4) * 8;
+  for (int s = 0; s < steps; ++s) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      *reinterpret_cast<gemm_u32x4 *>(Xs + lds_off[i]) = xr[i];
+      *reinterpret_cast<gemm_u32x4 *>(Ws + lds_off[i]) = wr[i];
+    }
+    __syncthreads();
+    if (s + 1 < steps) load_step(s + 1, xr, wr);
+#pragma unroll
+    for (int kk = 0; kk < kGemmBK; kk += 32) {
+      gemm_bf16x8 wf[4], xf[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        wf[i] = *reinterpret_cast<const gemm_bf16x8 *>(Ws + (wn * 64 + i * 16 + frag_row) * kGemmPad + kk + frag_k);
+        xf[i] = *reinterpret_cast<const gemm_bf16x8 *>(Xs + (wm * 64 + i * 16 + frag_row) * kGemmPad + kk + frag_k);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int n = n0 + wn * 64 + i * 16 + (lane >> 4) * 4;
+    if (n >= g.Cout) continue;
+    gemm_f32x4 b = {0.f, 0.f, 0.f, 0.f};
+    if (g.bias) b = *reinterpret_cast<const gemm_f32x4 *>(g.bias + n);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int m = m0 + wm * 64 + j * 16 + (lane & 15);
+      if (m >= M) continue;
+      gemm_f32x4 v = acc[i][j] + b;
+      if (RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      uint2 o;
+      o.x = gemm_pack2(v.x, v.y);
+      o.y = gemm_pack2(v.z, v.w);
+      *reinterpret_cast<uint2 *>(g.Y + (long long)m * g.Cout + n) = o;
+    }
+  }
+}
+
 }  // namespace snipper

@@ -398,6 +398,23 @@ int snipper_linear_bf16(void *stream, const uint16_t *X, long long ldx, const ui
   return launch_status();
 }
 
+int snipper_conv3x3_bf16(void *stream, const uint16_t *X, const uint16_t *W, const float *bias, uint16_t *Y,
+                         int B, int H, int Wd, int Cin, int Cout, int stride, int relu) {
+  if (!X || !W || !Y) return SNIPPER_E_NULL;
+  if (B <= 0 || H <= 0 || Wd <= 0 || Cin <= 0 || Cout <= 0 || Cin % kGemmBK || Cout % 4 || (stride != 1 && stride != 2))
+    return SNIPPER_E_SHAPE;
+  const int Ho = (H - 1) / stride + 1, Wo = (Wd - 1) / stride + 1;
+  const long long M = (long long)B * Ho * Wo;
+  if (M >= (1LL << 31)) return SNIPPER_E_SHAPE;
+  const Conv3x3Args g{X, W, bias, Y, B, H, Wd, Cin, Cout, Ho, Wo, stride};
+  const dim3 grid((unsigned)((M + kGemmBM - 1) / kGemmBM), (Cout + kGemmBN - 1) / kGemmBN);
+  if (relu)
+    hipLaunchKernelGGL(conv3x3_bf16_kernel<true>, grid, dim3(kGemmThreads), 0, (hipStream_t)stream, g);
+  else
+    hipLaunchKernelGGL(conv3x3_bf16_kernel<false>, grid, dim3(kGemmThreads), 0, (hipStream_t)stream, g);
+  return launch_status();
+}
+
 int snipper_temporal_mix(void *stream, const void *in, int in_dtype, const unsigned char *mask, int mask_on_input,
                          const float *mix, int N, int Ti, int To, long long S, int C, void *out, int out_dtype) {
   if (!in || !out || !mix) return SNIPPER_E_NULL;

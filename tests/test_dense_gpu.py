@@ -1,6 +1,7 @@
 """GPU tests of the bf16 MFMA dense kernel against a float64 reference of the same bf16 inputs."""
 import pytest
 import torch
+import torch.nn.functional as F
 
 from snipper_amd.dense import linear_bf16
 
@@ -79,3 +80,41 @@ def test_bottleneck_on_hip_matches_miopen(stride, down, train):
     for a, b in zip(res[True][1], res[False][1]):
         err = float((a.float() - b.float()).norm() / (b.float().norm() + 1e-12))
         assert err < 8e-2, err
+
+
+@pytest.mark.parametrize("cin,cout,h,w,stride", [(64, 64, 150, 200, 1), (128, 128, 37, 51, 2), (256, 256, 38, 50, 1),
+                                                   (512, 512, 19, 25, 2), (64, 68, 5, 7, 1), (64, 64, 1, 1, 2)])
+@pytest.mark.parametrize("relu", [False, True])
+def test_conv3x3_kernel(cin, cout, h, w, stride, relu):
+    """Implicit-GEMM 3x3 convolution against F.conv2d in float32 on the same bf16-rounded operands."""
+    from snipper_amd.dense import conv3x3_bf16
+    g = torch.Generator().manual_seed(cin + h + stride)
+    x = torch.randn(3, cin, h, w, generator=g).to(DEV).bfloat16().contiguous(memory_format=torch.channels_last)
+    wt = (torch.randn(cout, cin, 3, 3, generator=g) / (3 * cin ** 0.5)).to(DEV).bfloat16()
+    b = torch.randn(cout, generator=g).to(DEV)
+    y = conv3x3_bf16(x, wt, b, stride, relu)
+    ref = F.conv2d(x.float(), wt.float(), b, stride, 1)
+    if relu:
+        ref = ref.relu()
+    assert y.shape == ref.shape and y.is_contiguous(memory_format=torch.channels_last)
+    err = (y.float() - ref).abs().max().item()
+    assert err <= 2e-2 * max(1.0, ref.abs().max().item()), err
+
+
+def test_conv3x3_bn_function_grads():
+    """The autograd wrapper used by the bottleneck: gradients against the plain composition."""
+    from snipper_amd.backbone import _Conv3x3BN
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 64, 20, 28, generator=g).to(DEV).bfloat16().contiguous(memory_format=torch.channels_last)
+    x.requires_grad_(True)
+    wt = (torch.randn(64, 64, 3, 3, generator=g) / 24).to(DEV).requires_grad_(True)
+    scale, shift = torch.rand(64, generator=g).to(DEV) + 0.5, torch.randn(64, generator=g).to(DEV)
+    for stride in (1, 2):
+        y = _Conv3x3BN.apply(x, wt, scale, shift, stride, True)
+        gy = torch.randn(y.shape, generator=g).to(DEV).bfloat16()
+        dx, dw = torch.autograd.grad(y, (x, wt), gy)
+        xr, wr = x.detach().float().requires_grad_(True), wt.detach().clone().requires_grad_(True)
+        yr = F.relu(F.conv2d(xr, wr * scale.view(-1, 1, 1, 1), shift, stride, 1))
+        dxr, dwr = torch.autograd.grad(yr, (xr, wr), gy.float())
+        rel = lambda a, b: ((a.float() - b).norm() / b.norm().clamp_min(1e-12)).item()
+        assert rel(y, yr) < 1e-2 and rel(dx, dxr) < 8e-2 and rel(dw, dwr) < 8e-2, (rel(y, yr), rel(dx, dxr), rel(dw, dwr))
