@@ -391,6 +391,16 @@ def main():
         torch.cuda.synchronize()
         pr.disable()
         pstats.Stats(pr, stream=sys.stderr).sort_stats("tottime").print_stats(45)
+    if os.environ.get("SNIPPER_ISSUE_TIME"):      # is the host or the GPU the limiter?  (development aid)
+        # host time to ISSUE three steps (no synchronisation) against the time until the GPU has retired them
+        torch.cuda.synchronize()
+        h0 = time.perf_counter()
+        for i in range(3):
+            step(i)
+        h1 = time.perf_counter()
+        torch.cuda.synchronize()
+        h2 = time.perf_counter()
+        print(f"[bench] issue {1e3 * (h1 - h0) / 3:.2f} ms/step, retire {1e3 * (h2 - h0) / 3:.2f} ms/step", file=sys.stderr)
     t0 = time.perf_counter()
     for i in range(a.steps):
         loss = step(a.warmup + i)

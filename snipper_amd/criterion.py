@@ -238,23 +238,26 @@ class SetCriterion(nn.Module):
     def heatmap_targets(self, targets, spatial, device) -> List[torch.Tensor]:
         """Gaussian-blurred one-hot joint maps per level, [bs, t, h, w, K] (model.py:447-483)."""
         maps = []
+        bs = len(targets)
+        counts = [int(tgt["kpts2d"].shape[0]) for tgt in targets]
+        sample = torch.cat([torch.full((n,), i, dtype=torch.long, device=device) for i, n in enumerate(counts)])
         for (t, h, w) in spatial:
             ksize = max(h // 10 + h // 10 % 2 - 1, w // 10 + w // 10 % 2 - 1)
-            per_sample = []
-            for tgt in targets:
-                k = tgt["kpts2d"][:, :t]                                            # [n, t, K, 3]
-                x, y = (k[..., 0] * w).long(), (k[..., 1] * h).long()
-                ok = (k[..., 2] > 0) & (x >= 0) & (x < w) & (y >= 0) & (y < h)
-                K = k.shape[2]
-                hm = torch.zeros(K, t, h, w, device=device)
-                ti = torch.arange(t, device=device)[None, :, None].expand_as(x)
-                ki = torch.arange(K, device=device)[None, None, :].expand_as(x)
-                # no boolean-mask indexing (it would read the count back to the host): invalid joints add 0 at a
-                # clamped position, valid ones add 1, several on one pixel still give 1
-                hm.index_put_((ki, ti, y.clamp(0, h - 1), x.clamp(0, w - 1)), ok.to(hm.dtype), accumulate=True)
-                hm.clamp_(max=1)
-                per_sample.append(gaussian_blur(hm, ksize))
-            maps.append(torch.stack(per_sample).permute(0, 2, 3, 4, 1))              # [bs, t, h, w, K]
+            k = torch.cat([tgt["kpts2d"][:, :t] for tgt in targets], 0)             # [Nsum, t, K, 3]
+            K = k.shape[2]
+            x, y = (k[..., 0] * w).long(), (k[..., 1] * h).long()
+            ok = (k[..., 2] > 0) & (x >= 0) & (x < w) & (y >= 0) & (y < h)
+            ti = torch.arange(t, device=device)[None, :, None]
+            ki = torch.arange(K, device=device)[None, None, :]
+            # One scatter-add over the flattened [bs, K, t, h, w] map for all samples.  No boolean-mask indexing (it
+            # would read the count back to the host) and no multi-index index_put_ (its accumulate path range-checks
+            # every index tensor with separate reductions and sorts: ~50 launches per call): invalid joints add 0 at
+            # a clamped position, valid ones add 1, several on one pixel still give 1.
+            lin = (((sample[:, None, None] * K + ki) * t + ti) * h + y.clamp(0, h - 1)) * w + x.clamp(0, w - 1)
+            hm = torch.zeros(bs * K * t * h * w, device=device)
+            hm.index_add_(0, lin.reshape(-1), ok.reshape(-1).to(hm.dtype))
+            hm = hm.clamp_(max=1).view(bs, K, t, h, w)
+            maps.append(gaussian_blur(hm, ksize).permute(0, 2, 3, 4, 1))             # [bs, t, h, w, K]
         return maps
 
     def loss_heatmap(self, outputs, targets):

@@ -148,8 +148,32 @@ class DeformableTransformerDecoderLayer(nn.Module, _FFNMixin):
     def forward_ffn(self, tgt):
         return self._ffn(tgt, self.dropout3, self.dropout4, self.norm3)
 
+    # Under autocast the layer's own tensors ([bs, T * queries, C]: a few hundred rows) stay in float32: at that
+    # size a GEMM is launch-bound in any precision, while every autocast cast (input, weight and bias of each
+    # Linear, and their gradients back) is one more launch -- ~75 per layer and step.  Only the cross-attention,
+    # whose value projection runs over the whole encoder memory, keeps the reduced precision.
+    small_in_fp32 = True
+
     def forward(self, tgt, query_pos, reference_points, src, src_spatial_shapes, level_start_index,
-                src_padding_mask=None):
+                src_padding_mask=None, cross_amp_dtype=None):
+        """``cross_amp_dtype``: set by a caller that has already left autocast (the decoder below) to the autocast
+        dtype the cross-attention should still run in."""
+        if cross_amp_dtype is None and self.small_in_fp32 and tgt.is_cuda and torch.is_autocast_enabled():
+            amp_dtype = torch.get_autocast_gpu_dtype()
+            with torch.autocast("cuda", enabled=False):
+                return self._forward(tgt.float(), query_pos.float(), reference_points, src, src_spatial_shapes,
+                                     level_start_index, src_padding_mask, amp_dtype)
+        return self._forward(tgt, query_pos, reference_points, src, src_spatial_shapes, level_start_index,
+                             src_padding_mask, cross_amp_dtype)
+
+    def _cross(self, amp_dtype, *args):
+        if amp_dtype is None:
+            return self.cross_attn(*args)
+        with torch.autocast("cuda", dtype=amp_dtype):
+            return self.cross_attn(*args)
+
+    def _forward(self, tgt, query_pos, reference_points, src, src_spatial_shapes, level_start_index,
+                 src_padding_mask, amp_dtype):
         bs, t, lq, c = tgt.shape
         # dense self-attention over all (frame, query) tokens of a sample (reference :282-287)
         flat = tgt.reshape(bs, t * lq, c)
@@ -157,9 +181,9 @@ class DeformableTransformerDecoderLayer(nn.Module, _FFNMixin):
         mixed = self.self_attn(qk, qk, flat.transpose(0, 1), need_weights=False)[0].transpose(0, 1)
         tgt = self.norm2(flat + self.dropout2(mixed)).view(bs, t, lq, c)
         # deformable cross-attention into the encoder memory (reference :290-295)
-        attended, atten_data = self.cross_attn(self.with_pos_embed(tgt, query_pos.view(bs, t, lq, c)),
-                                               reference_points, src, src_spatial_shapes,
-                                               level_start_index, src_padding_mask)
+        attended, atten_data = self._cross(amp_dtype, self.with_pos_embed(tgt, query_pos.view(bs, t, lq, c)),
+                                           reference_points, src, src_spatial_shapes,
+                                           level_start_index, src_padding_mask)
         tgt = self.norm1(tgt + self.dropout1(attended))
         return self.forward_ffn(tgt), atten_data
 
@@ -176,12 +200,25 @@ class DeformableTransformerDecoder(nn.Module):
 
     def forward(self, query_obj, reference_points, src, src_spatial_shapes, src_level_start_index,
                 src_valid_ratios, query_pos=None, src_padding_mask=None):
+        if query_obj.is_cuda and torch.is_autocast_enabled() and \
+                all(getattr(l, "small_in_fp32", False) for l in self.layers):
+            # the decoder's own tensors stay float32 (see DeformableTransformerDecoderLayer.small_in_fp32)
+            amp_dtype = torch.get_autocast_gpu_dtype()
+            with torch.autocast("cuda", enabled=False):
+                return self._forward(query_obj.float(), reference_points.float(), src, src_spatial_shapes,
+                                     src_level_start_index, src_valid_ratios,
+                                     None if query_pos is None else query_pos.float(), src_padding_mask, amp_dtype)
+        return self._forward(query_obj, reference_points, src, src_spatial_shapes, src_level_start_index,
+                             src_valid_ratios, query_pos, src_padding_mask, None)
+
+    def _forward(self, query_obj, reference_points, src, src_spatial_shapes, src_level_start_index,
+                 src_valid_ratios, query_pos, src_padding_mask, amp_dtype):
         out = query_obj
         inter, inter_ref, inter_att = [], [], []
         for lid, layer in enumerate(self.layers):
             ref_in = reference_points[:, :, :, None, :] * src_valid_ratios[:, None, None, :, :]
             out, atten_data = layer(out, query_pos, ref_in, src, src_spatial_shapes,
-                                    src_level_start_index, src_padding_mask)
+                                    src_level_start_index, src_padding_mask, cross_amp_dtype=amp_dtype)
             if self.root_embed is not None:   # iterative refinement of the reference points (:329-333)
                 delta = self.root_embed[lid](out)[..., 0:2]
                 reference_points = (delta + inverse_sigmoid(reference_points)).sigmoid().detach()

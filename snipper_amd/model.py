@@ -102,6 +102,15 @@ class SnipperDeformable(nn.Module):
         hs, heatmaps, init_reference, inter_references, inter_att = \
             self.transformer(srcs, masks, pos, self.query_embed.weight)
         n_dec, bs, t, _, c = hs.shape
+        if hs.is_cuda and torch.is_autocast_enabled():
+            # the heads see [n_dec, bs, T, queries, C] (a few thousand rows): float32, no autocast casts (the same
+            # reasoning as DeformableTransformerDecoderLayer.small_in_fp32)
+            with torch.autocast("cuda", enabled=False):
+                return self._heads(hs.float(), heatmaps, init_reference, inter_references, inter_att)
+        return self._heads(hs, heatmaps, init_reference, inter_references, inter_att)
+
+    def _heads(self, hs, heatmaps, init_reference, inter_references, inter_att):
+        n_dec, bs, t, _, c = hs.shape
         tied = all(m is self.class_embed[0] for m in self.class_embed) and \
             all(m is self.root_embed[0] for m in self.root_embed) and \
             all(m is self.joint_embed[0] for m in self.joint_embed)

@@ -8,6 +8,7 @@ ap.add_argument("trace")
 ap.add_argument("--frac", type=float, default=0.4)
 ap.add_argument("--top", type=int, default=40)
 ap.add_argument("--csv", default=None)
+ap.add_argument("--by", default="time", choices=["time", "count"])
 a = ap.parse_args()
 rows = list(csv.DictReader(open(a.trace)))
 st = [int(r["Start_Timestamp"]) for r in rows]
@@ -24,7 +25,7 @@ for r, s, e in zip(rows, st, en):
         busy += e - s
 win = t1 - cut
 print(f"window {win/1e6:.1f} ms, kernels busy {busy/1e6:.1f} ms ({100*busy/win:.1f}%), dispatches {sum(v[0] for v in agg.values())}")
-items = sorted(agg.items(), key=lambda kv: -kv[1][1])
+items = sorted(agg.items(), key=lambda kv: -kv[1][1 if a.by == "time" else 0])
 for k, (n, t) in items[:a.top]:
     short = re.sub(r"at::native::|\(anonymous namespace\)::|void ", "", k)[:110]
     print(f"{100*t/win:5.1f}% {n:6d} {t/n/1e3:9.1f}us  {short}")
