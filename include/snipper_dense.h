@@ -13,6 +13,7 @@
 #ifndef SNIPPER_DENSE_H_
 #define SNIPPER_DENSE_H_
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -27,6 +28,19 @@ extern "C" {
 int snipper_linear_bf16(void *stream, const uint16_t *X, long long ldx, const uint16_t *W,
                         const float *bias, const uint16_t *R, long long ldr, uint16_t *Y, long long ldy,
                         int M, int N, int K, int relu);
+
+/* Weight and bias gradient of the same layers (csrc/wgrad_bf16.cuh):
+ *   dW[N,Kc] (+)= scale[n] * sum_m G[m,n] * X[m,kc]      db[N] (+)= sum_m G[m,n]
+ * G [M,N] (leading dimension ldg) = gradient of the layer's output, X [M,Kc] (ldx) = its input, both bf16 bits;
+ * dW (leading dimension lddw) and db float32; scale [N] float32 or NULL (the folded BatchNorm factor of a 1x1
+ * convolution); db may be NULL; accumulate != 0 adds to dW / db instead of overwriting.  The reduction over M is
+ * split over the chip into per-range partial sums in `workspace` (>= snipper_wgrad_workspace_bytes(M,N,Kc) bytes,
+ * 16-byte aligned) and summed in a fixed order by a second kernel: results are deterministic.
+ * Requirements: N, Kc, ldg, ldx % 8 == 0, lddw % 4 == 0, 16-byte aligned pointers. */
+size_t snipper_wgrad_workspace_bytes(int M, int N, int Kc);
+int snipper_wgrad_bf16(void *stream, const uint16_t *G, long long ldg, const uint16_t *X, long long ldx,
+                       int M, int N, int Kc, const float *scale, float *dW, long long lddw, float *db,
+                       int accumulate, void *workspace, size_t workspace_bytes);
 
 /* 3x3 convolution, padding 1, stride 1 or 2, NHWC bf16, as an implicit GEMM on the same MFMA tiles:
  * Y[B,Ho,Wo,Cout] = act(conv(X[B,H,W,Cin], W[Cout,3,3,Cin]) + bias[Cout]), Ho = (H-1)/stride + 1 (same for Wo).

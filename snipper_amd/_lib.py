@@ -7,7 +7,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_char_p, c_int, c_void_p
+from ctypes import c_char_p, c_int, c_longlong, c_size_t, c_void_p
 
 from . import build as _build
 
@@ -36,6 +36,9 @@ EXPORTS = {
                                        ctypes.c_longlong, c_int, c_int, c_int, c_void_p, c_void_p], c_int),
     "snipper_msda_prologue_backward": ([c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_longlong,
                                         c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p], c_int),
+    "snipper_wgrad_workspace_bytes": ([c_int] * 3, c_size_t),
+    "snipper_wgrad_bf16": ([c_void_p, c_void_p, c_longlong, c_void_p, c_longlong, c_int, c_int, c_int, c_void_p,
+                            c_void_p, c_longlong, c_void_p, c_int, c_void_p, c_size_t], c_int),
     "snipper_conv3x3_bf16": ([c_void_p] * 5 + [c_int] * 7, c_int),
     "snipper_lsap_f32": ([c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p], c_int),
     "snipper_linear_bf16": ([c_void_p, c_void_p, ctypes.c_longlong, c_void_p, c_void_p, c_void_p, ctypes.c_longlong,

@@ -99,7 +99,8 @@ class _PointwiseConvBN(torch.autograd.Function):
     """relu?(X . (W * scale)^T + shift (+ residual)) on [M, C] views of NHWC tensors, forward and backward.
 
     Forward and the data gradient run on this repository's MFMA kernel (one launch each, epilogue fused); the
-    weight gradient (a [Cout, M] x [M, Cin] product, M = batch * H * W) goes through hipBLASLt.  Besides the fused
+    weight gradient (a [Cout, M] x [M, Cin] product, M = batch * H * W) runs on the split-reduction kernel
+    (csrc/wgrad_bf16.cuh).  Besides the fused
     passes this avoids MIOpen's host-side cost per convolution call (~170 us measured: solver look-up), which was
     the largest single item of the step's CPU time."""
 
@@ -124,7 +125,9 @@ class _PointwiseConvBN(torch.autograd.Function):
         dx = linear_bf16(g, w_eff.t().contiguous()) if ctx.needs_input_grad[0] else None
         dw = None
         if ctx.needs_input_grad[1]:
-            dw = (torch.mm(g.t(), x2).float() * scale[:, None]).reshape(ctx.wshape).to(ctx.wdtype)
+            from .dense import wgrad_bf16
+            dw, _ = wgrad_bf16(g, x2, want_bias=False, scale=scale)     # BN scale folded into the reduction kernel
+            dw = dw.reshape(ctx.wshape).to(ctx.wdtype)
         return dx, dw, None, None, (g if ctx.has_res else None), None
 
 

@@ -14,6 +14,7 @@
 #include "../../include/snipper_msda.h"
 #include "../../include/snipper_dense.h"
 #include "gemm_bf16.cuh"
+#include "wgrad_bf16.cuh"
 #include "msda_prologue.cuh"
 #include "lsap.cuh"
 #include "msda_d48.cuh"
@@ -29,6 +30,7 @@ std::atomic<int> g_policy{0};  // 0 auto, 1 generic only, 2 no owner-computes pa
 std::atomic<float> g_near_radius{6.0f};
 std::atomic<int> g_owner_debug{0};
 std::atomic<int> g_owner_chunk{64};
+std::atomic<int> g_wgrad_wgs{512};
 std::atomic<int> g_owner_enable{1};   // owner-computes backward for the encoder shape
 std::atomic<int> g_tile_edge[3] = {{16}, {8}, {4}};   // level area > 4096 px / > 1024 px / smaller
 
@@ -278,6 +280,9 @@ int snipper_msda_set_param(const char *name, double v) {
   } else if (k == "owner_chunk") {
     if (v != 64 && v != 128) return SNIPPER_E_SHAPE;
     g_owner_chunk.store((int)v);
+  } else if (k == "wgrad_wgs") {
+    if (!(v >= 1 && v <= 65536)) return SNIPPER_E_SHAPE;
+    g_wgrad_wgs.store((int)v);
   } else if (k == "owner_enable") {
     g_owner_enable.store(v != 0.0);
   } else {
@@ -395,6 +400,48 @@ int snipper_linear_bf16(void *stream, const uint16_t *X, long long ldx, const ui
     hipLaunchKernelGGL(linear_bf16_kernel<true>, grid, dim3(kGemmThreads), 0, (hipStream_t)stream, g);
   else
     hipLaunchKernelGGL(linear_bf16_kernel<false>, grid, dim3(kGemmThreads), 0, (hipStream_t)stream, g);
+  return launch_status();
+}
+
+namespace {
+struct WgradPlan { int tiles_n, tiles_k, S, rows; };
+// split the reduction axis so that the grid has about g_wgrad_wgs workgroups (2 per CU); a multiple of 8 row-ranges
+// lets the kernel keep the output tiles of one range on one XCD
+WgradPlan wgrad_plan(int M, int N, int Kc) {
+  WgradPlan p;
+  p.tiles_n = (N + kWgTile - 1) / kWgTile;
+  p.tiles_k = (Kc + kWgTile - 1) / kWgTile;
+  const int tiles = p.tiles_n * p.tiles_k;
+  int s0 = std::max(1, g_wgrad_wgs.load(std::memory_order_relaxed) / tiles);
+  if (s0 >= 8) s0 = (s0 + 7) / 8 * 8;
+  s0 = std::min(s0, std::max(1, M / kWgRows));
+  p.rows = (M + s0 - 1) / s0;
+  p.S = (M + p.rows - 1) / p.rows;
+  return p;
+}
+}  // namespace
+
+size_t snipper_wgrad_workspace_bytes(int M, int N, int Kc) {
+  if (M <= 0 || N <= 0 || Kc <= 0) return 0;
+  const WgradPlan p = wgrad_plan(M, N, Kc);
+  return ((size_t)p.S * N * Kc + (size_t)p.S * N) * sizeof(float);
+}
+
+int snipper_wgrad_bf16(void *stream, const uint16_t *G, long long ldg, const uint16_t *X, long long ldx,
+                       int M, int N, int Kc, const float *scale, float *dW, long long lddw, float *db,
+                       int accumulate, void *workspace, size_t workspace_bytes) {
+  if (!G || !X || !dW || !workspace) return SNIPPER_E_NULL;
+  if (M <= 0 || N <= 0 || Kc <= 0 || N % 8 || Kc % 8 || ldg % 8 || ldx % 8 || lddw % 4 || ldg < N || ldx < Kc || lddw < Kc)
+    return SNIPPER_E_SHAPE;
+  if (((uintptr_t)G | (uintptr_t)X | (uintptr_t)dW | (uintptr_t)workspace) & 15) return SNIPPER_E_SHAPE;
+  if (workspace_bytes < snipper_wgrad_workspace_bytes(M, N, Kc)) return SNIPPER_E_SHAPE;
+  const WgradPlan p = wgrad_plan(M, N, Kc);
+  float *P = (float *)workspace, *Pb = db ? P + (size_t)p.S * N * Kc : nullptr;
+  const WgradArgs a{G, ldg, X, ldx, P, Pb, M, N, Kc, p.S, p.rows, p.tiles_n, p.tiles_k};
+  hipLaunchKernelGGL(wgrad_bf16_kernel, dim3(p.tiles_n * p.tiles_k * p.S), dim3(kWgThreads), 0, (hipStream_t)stream, a);
+  const WgradReduceArgs r{P, Pb, dW, lddw, db, scale, N, Kc, p.S, accumulate};
+  const long long quads = (long long)N * Kc / 4;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, r);
   return launch_status();
 }
 

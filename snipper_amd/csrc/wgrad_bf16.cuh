@@ -1,0 +1,199 @@
+// wgrad_bf16.cuh -- weight (and bias) gradient of the path's dense layers on gfx950 MFMA.
+//
+//   dW[N, Kc] = sum_m G[m, n] * X[m, kc]        db[N] = sum_m G[m, n]        G, X bf16 row-major; dW, db f32
+//
+// G is the gradient of a Linear's (or NHWC 1x1 convolution's) output and X its input; M = B*T*S = 79 000 tokens
+// for the encoder's projections while N, Kc <= 1024: the reduction runs over the LONG axis and the output is tiny.
+// A library GEMM tiles the output (9 tiles of 128 x 128 for a 384 x 384 weight) and so keeps a handful of CUs busy
+// for ~0.3 ms; here the reduction axis is split over the whole chip instead:
+//
+//   * grid = output tiles x S row-ranges; each workgroup streams its range of G[:, 128 cols] and X[:, 128 cols]
+//     once, accumulates a 128 x 128 f32 tile in MFMA accumulators (4 waves x 4 x 4 v_mfma_f32_16x16x32_bf16), and
+//     writes it to a [S][N][Kc] partial buffer; a second kernel sums the S partials in a fixed order (deterministic,
+//     unlike atomics).  The workgroups of one row-range are placed on one XCD so that the re-reads of G / X by the
+//     other output tiles hit in that XCD's L2.
+//   * both operands have the reduction index m as their SLOW axis, but an MFMA lane needs 8 consecutive reduction
+//     elements of one output row.  The tiles are stored in LDS exactly as they arrive ([m][n], coalesced 16-byte
+//     loads) and read back with ds_read_b64_tr_b16, gfx950's transposing LDS read: a 16-lane group fetches a
+//     4 (m) x 16 (n) block and every lane receives one column = 4 reduction elements of its row; two reads make one
+//     operand.  Which m lands in which reduction slot is irrelevant as long as G and X agree, so lane group g takes
+//     rows {4g..4g+3} and {16+4g..16+4g+3} of each 32-row step: the two groups of a 32-lane half then read 8
+//     CONSECUTIVE rows, which with a row stride of 288 B (128 columns + 16 pad) covers the 64 banks exactly once.
+//   * the bias gradient is the column sum of the same G tile: the workgroups of the first output-tile column add up
+//     the values they stage anyway.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "gemm_bf16.cuh"
+
+namespace snipper {
+
+typedef __attribute__((__vector_size__(4 * sizeof(__bf16)))) __bf16 wgrad_bf16x4;
+
+constexpr int kWgTile = 128, kWgRows = 64, kWgStride = 144, kWgThreads = 256;
+
+struct WgradArgs {
+  const uint16_t *G; long long ldg;   // [M][N]
+  const uint16_t *X; long long ldx;   // [M][Kc]
+  float *P;                           // [S][N][Kc] partial sums
+  float *Pb;                          // [S][N] partial column sums of G, or nullptr
+  int M, N, Kc, S, rows_per_split, tiles_n, tiles_k;
+};
+
+__device__ __forceinline__ gemm_bf16x8 wgrad_frag(const uint16_t *tile, int byte_off) {
+  typedef __attribute__((address_space(3))) wgrad_bf16x4 lds_v4;
+  const char *base = reinterpret_cast<const char *>(tile) + byte_off;
+  const wgrad_bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4 *)(base));
+  const wgrad_bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4 *)(base + 16 * kWgStride * 2));
+  return gemm_bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+__global__ __launch_bounds__(kWgThreads) void wgrad_bf16_kernel(WgradArgs g) {
+  __shared__ __attribute__((aligned(16))) uint16_t Gs[kWgRows * kWgStride];
+  __shared__ __attribute__((aligned(16))) uint16_t Xs[kWgRows * kWgStride];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave & 1, wk = wave >> 1;
+
+  // workgroup -> (row-range s, output tile): consecutive workgroups go round-robin over the 8 XCDs, so the
+  // workgroups with the same (id % 8) run on one XCD; all output tiles of a row-range are given to one XCD
+  const int tiles = g.tiles_n * g.tiles_k, total = tiles * g.S;
+  int s, t;
+  if (g.S % 8 == 0) {
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    s = xcd + 8 * (j / tiles);
+    t = j % tiles;
+  } else {
+    s = blockIdx.x / tiles;
+    t = blockIdx.x % tiles;
+  }
+  (void)total;
+  const int tn = t / g.tiles_k, tk = t % g.tiles_k;
+  const int n0 = tn * kWgTile, k0 = tk * kWgTile;
+  const int m_begin = s * g.rows_per_split, m_end = min(g.M, m_begin + g.rows_per_split);
+  const bool do_bias = g.Pb != nullptr && tk == 0;
+
+  // loader: 4 x 16 B per operand per thread and step; row = idx / 16, 8-column chunk = idx % 16 (fixed per thread)
+  const int chunk = tid & 15, row0 = tid >> 4;
+  const bool g_col_ok = n0 + chunk * 8 < g.N, x_col_ok = k0 + chunk * 8 < g.Kc;
+  const uint16_t *gp = g.G + n0 + chunk * 8, *xp = g.X + k0 + chunk * 8;
+  const gemm_u32x4 zero4 = {0u, 0u, 0u, 0u};
+  auto load_step = [&](int m, gemm_u32x4 (&gr)[4], gemm_u32x4 (&xr)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = m + row0 + 16 * i;
+      const bool ok = r < m_end;
+      const long long rr = ok ? r : m_begin;
+      gr[i] = (ok && g_col_ok) ? *reinterpret_cast<const gemm_u32x4 *>(gp + rr * g.ldg) : zero4;
+      xr[i] = (ok && x_col_ok) ? *reinterpret_cast<const gemm_u32x4 *>(xp + rr * g.ldx) : zero4;
+    }
+  };
+  gemm_u32x4 gr[4], xr[4];
+  if (m_begin < m_end) load_step(m_begin, gr, xr);
+  gemm_f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = gemm_f32x4{0.f, 0.f, 0.f, 0.f};
+  float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+  // transposed-read addressing: lane 4q+p of a 16-lane group supplies row q, columns 4p..4p+3 of the block
+  const int grp = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+  const int frag_base = ((grp * 4 + q) * kWgStride + 4 * p) * 2;      // bytes; + 32-row step + column offset
+
+  for (int m = m_begin; m < m_end; m += kWgRows) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int off = (row0 + 16 * i) * kWgStride + chunk * 8;
+      *reinterpret_cast<gemm_u32x4 *>(Gs + off) = gr[i];
+      *reinterpret_cast<gemm_u32x4 *>(Xs + off) = xr[i];
+    }
+    if (do_bias) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const unsigned w[4] = {gr[i].x, gr[i].y, gr[i].z, gr[i].w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          bsum[2 * c] += __uint_as_float(w[c] << 16);
+          bsum[2 * c + 1] += __uint_as_float(w[c] & 0xffff0000u);
+        }
+      }
+    }
+    __syncthreads();
+    if (m + kWgRows < m_end) load_step(m + kWgRows, gr, xr);
+#pragma unroll
+    for (int kk = 0; kk < kWgRows; kk += 32) {
+      gemm_bf16x8 gf[4], xf[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        gf[i] = wgrad_frag(Gs, frag_base + (kk * kWgStride + wn * 64 + i * 16) * 2);
+        xf[i] = wgrad_frag(Xs, frag_base + (kk * kWgStride + wk * 64 + i * 16) * 2);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[i], xf[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  // partial tile: rows n = 4 * (lane >> 4) + reg, column kc = lane & 15 of each 16 x 16 block
+  float *P = g.P + (long long)s * g.N * g.Kc;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int kc = k0 + wk * 64 + j * 16 + (lane & 15);
+      const int n = n0 + wn * 64 + i * 16 + (lane >> 4) * 4;
+      if (kc >= g.Kc) continue;
+      const float v[4] = {acc[i][j].x, acc[i][j].y, acc[i][j].z, acc[i][j].w};
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (n + r < g.N) P[(long long)(n + r) * g.Kc + kc] = v[r];
+    }
+  if (do_bias) {                                   // 16 row-groups x 128 columns -> 128 column sums
+    float *red = reinterpret_cast<float *>(Gs);    // 8 KB of the 18 KB tile; all reads of it are behind a barrier
+#pragma unroll
+    for (int c = 0; c < 8; ++c) red[row0 * kWgTile + chunk * 8 + c] = bsum[c];
+    __syncthreads();
+    if (tid < kWgTile && n0 + tid < g.N) {
+      float sum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sum += red[r * kWgTile + tid];
+      g.Pb[(long long)s * g.N + n0 + tid] = sum;
+    }
+  }
+}
+
+// out[n][kc] (+)= scale[n] * sum_s P[s][n][kc];  db[n] (+)= sum_s Pb[s][n].  Fixed summation order.
+struct WgradReduceArgs {
+  const float *P; const float *Pb;
+  float *dW; long long lddw;     // [N][Kc] with leading dimension
+  float *db;                     // [N] or nullptr
+  const float *scale;            // [N] or nullptr: per-output-row factor (the folded BatchNorm scale)
+  int N, Kc, S, accumulate;
+};
+
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgradReduceArgs g) {
+  const long long total = (long long)g.N * g.Kc;
+  const long long e = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (e < total) {
+    gemm_f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < g.S; ++s) sum += *reinterpret_cast<const gemm_f32x4 *>(g.P + (long long)s * total + e);
+    const int n = (int)(e / g.Kc), kc = (int)(e - (long long)n * g.Kc);      // Kc % 4 == 0: one row per thread
+    if (g.scale) sum *= g.scale[n];
+    float *o = g.dW + (long long)n * g.lddw + kc;
+    if (g.accumulate) sum += *reinterpret_cast<const gemm_f32x4 *>(o);
+    *reinterpret_cast<gemm_f32x4 *>(o) = sum;
+  }
+  if (g.db && g.Pb) {
+    const long long n = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (n < g.N) {
+      float sum = 0.f;
+      for (int s = 0; s < g.S; ++s) sum += g.Pb[(long long)s * g.N + n];
+      g.db[n] = g.accumulate ? g.db[n] + sum : sum;
+    }
+  }
+}
+
+}  // namespace snipper

@@ -17,6 +17,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from .dense import big_linear
 from .ms_deform_attn import MSDeformAttn
 
 
@@ -61,7 +62,11 @@ class _FFNMixin:
     """Linear -> act -> dropout -> Linear, residual, LayerNorm (shared by both layer types)."""
 
     def _ffn(self, x, drop_a, drop_b, norm):
-        y = self.linear2(drop_a(self.activation(self.linear1(x))))
+        if self.activation is F.relu:
+            h = big_linear(x, self.linear1, relu=True)          # ReLU in the kernel's epilogue when it applies
+        else:
+            h = self.activation(big_linear(x, self.linear1))
+        y = big_linear(drop_a(h), self.linear2)
         return norm(x + drop_b(y))
 
 
@@ -158,8 +163,8 @@ class DeformableTransformerDecoderLayer(nn.Module, _FFNMixin):
                 src_padding_mask=None, cross_amp_dtype=None):
         """``cross_amp_dtype``: set by a caller that has already left autocast (the decoder below) to the autocast
         dtype the cross-attention should still run in."""
-        if cross_amp_dtype is None and self.small_in_fp32 and tgt.is_cuda and torch.is_autocast_enabled():
-            amp_dtype = torch.get_autocast_gpu_dtype()
+        if cross_amp_dtype is None and self.small_in_fp32 and tgt.is_cuda and torch.is_autocast_enabled('cuda'):
+            amp_dtype = torch.get_autocast_dtype('cuda')
             with torch.autocast("cuda", enabled=False):
                 return self._forward(tgt.float(), query_pos.float(), reference_points, src, src_spatial_shapes,
                                      level_start_index, src_padding_mask, amp_dtype)
@@ -200,10 +205,10 @@ class DeformableTransformerDecoder(nn.Module):
 
     def forward(self, query_obj, reference_points, src, src_spatial_shapes, src_level_start_index,
                 src_valid_ratios, query_pos=None, src_padding_mask=None):
-        if query_obj.is_cuda and torch.is_autocast_enabled() and \
+        if query_obj.is_cuda and torch.is_autocast_enabled('cuda') and \
                 all(getattr(l, "small_in_fp32", False) for l in self.layers):
             # the decoder's own tensors stay float32 (see DeformableTransformerDecoderLayer.small_in_fp32)
-            amp_dtype = torch.get_autocast_gpu_dtype()
+            amp_dtype = torch.get_autocast_dtype('cuda')
             with torch.autocast("cuda", enabled=False):
                 return self._forward(query_obj.float(), reference_points.float(), src, src_spatial_shapes,
                                      src_level_start_index, src_valid_ratios,

@@ -63,3 +63,95 @@ def conv3x3_bf16(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Ten
             bias.data_ptr() if bias is not None else None, out.data_ptr(), B, H, W, Cin, Cout, int(stride), int(relu))
     _lib.check(rc, "snipper_conv3x3_bf16")
     return out
+
+
+def wgrad_bf16(g: torch.Tensor, x: torch.Tensor, want_bias: bool = True, scale: Optional[torch.Tensor] = None,
+               out: Optional[torch.Tensor] = None, out_bias: Optional[torch.Tensor] = None, accumulate: bool = False):
+    """Weight / bias gradient of ``y = x @ W^T + b`` on the split-reduction MFMA kernel (csrc/wgrad_bf16.cuh).
+
+    g [M, N] bf16 = dL/dy, x [M, Kc] bf16 (both row-major, unit inner stride)  ->  (dW [N, Kc] float32,
+    db [N] float32 or None).  ``scale`` [N] float32 multiplies the rows of dW (folded BatchNorm).  ``out`` /
+    ``out_bias`` receive the result (``accumulate`` adds to them); deterministic."""
+    assert g.is_cuda and g.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and g.dim() == 2 and x.dim() == 2
+    assert g.shape[0] == x.shape[0]
+    if g.stride(1) != 1 or g.stride(0) % 8 or g.data_ptr() % 16:
+        g = g.contiguous()
+    if x.stride(1) != 1 or x.stride(0) % 8 or x.data_ptr() % 16:
+        x = x.contiguous()
+    M, N = g.shape
+    Kc = x.shape[1]
+    lib = _lib.load()
+    dW = out if out is not None else torch.empty((N, Kc), dtype=torch.float32, device=g.device)
+    assert dW.dtype == torch.float32 and dW.stride(1) == 1 and dW.shape == (N, Kc)
+    db = None
+    if want_bias:
+        db = out_bias if out_bias is not None else torch.empty((N,), dtype=torch.float32, device=g.device)
+        assert db.dtype == torch.float32 and db.is_contiguous()
+    nbytes = lib.snipper_wgrad_workspace_bytes(M, N, Kc)
+    ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=g.device)
+    if scale is not None and scale.dtype != torch.float32:
+        scale = scale.float()
+    with torch.cuda.device(g.device):
+        rc = lib.snipper_wgrad_bf16(
+            torch.cuda.current_stream(g.device).cuda_stream, g.data_ptr(), g.stride(0), x.data_ptr(), x.stride(0),
+            M, N, Kc, scale.data_ptr() if scale is not None else None, dW.data_ptr(), dW.stride(0),
+            db.data_ptr() if db is not None else None, int(accumulate), ws.data_ptr(), nbytes)
+    _lib.check(rc, "snipper_wgrad_bf16")
+    return dW, db
+
+
+class _BigLinear(torch.autograd.Function):
+    """act(x @ W^T + b) for activations with tens of thousands of rows (the encoder's 79 000 tokens), in bf16 on this
+    repository's kernels: forward on ``linear_bf16`` (bias / ReLU in the epilogue), weight + bias gradient on the
+    split-reduction ``wgrad_bf16`` (float32 results straight into the parameter's dtype: no cast kernels), data
+    gradient through hipBLASLt.  Reference: every nn.Linear of models/ops/modules/ms_deform_attn.py:60-66 and of the
+    encoder layer's FFN (models/deformable_transformer.py:180-198)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, relu):
+        n_out, k_in = weight.shape
+        x2 = x.reshape(-1, k_in)
+        xb = x2 if x2.dtype == torch.bfloat16 else x2.to(torch.bfloat16)
+        wb = weight if weight.dtype == torch.bfloat16 else weight.to(torch.bfloat16)
+        y = linear_bf16(xb, wb, None if bias is None else bias.float(), None, relu)
+        ctx.relu, ctx.has_bias = relu, bias is not None
+        ctx.x_shape, ctx.w_dtype = x.shape, weight.dtype
+        ctx.b_dtype = None if bias is None else bias.dtype
+        ctx.save_for_backward(xb, wb, y if relu else None)
+        return y.view(*x.shape[:-1], n_out)
+
+    @staticmethod
+    def backward(ctx, gy):
+        xb, wb, y = ctx.saved_tensors
+        g = gy.reshape(-1, wb.shape[0])
+        if g.dtype != torch.bfloat16:
+            g = g.to(torch.bfloat16)
+        g = g.contiguous()
+        if ctx.relu:
+            g = torch.ops.aten.threshold_backward(g, y, 0)
+        dx = torch.mm(g, wb).view(ctx.x_shape) if ctx.needs_input_grad[0] else None
+        dW = db = None
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            dW, db = wgrad_bf16(g, xb, want_bias=ctx.has_bias and ctx.needs_input_grad[2])
+            if dW.dtype != ctx.w_dtype:
+                dW = dW.to(ctx.w_dtype)
+            if db is not None and db.dtype != ctx.b_dtype:
+                db = db.to(ctx.b_dtype)
+        return dx, dW, db, None
+
+
+BIG_LINEAR_MIN_ROWS = 4096
+
+
+def big_linear(x: torch.Tensor, lin: torch.nn.Linear, relu: bool = False) -> torch.Tensor:
+    """``lin(x)`` (followed by ReLU if ``relu``), routed to the hand-written kernels when ``x`` is a CUDA tensor with
+    at least BIG_LINEAR_MIN_ROWS rows that is computed in bf16 (bf16 input, or autocast to bf16); plain PyTorch
+    otherwise, with identical semantics."""
+    rows = x.numel() // max(1, x.shape[-1])
+    in_bf16 = x.dtype == torch.bfloat16 or (torch.is_autocast_enabled('cuda') and
+                                             torch.get_autocast_dtype('cuda') == torch.bfloat16)
+    if (x.is_cuda and in_bf16 and rows >= BIG_LINEAR_MIN_ROWS and lin.in_features % 64 == 0 and
+            lin.out_features % 8 == 0 and x.dtype in (torch.bfloat16, torch.float32)):
+        return _BigLinear.apply(x, lin.weight, lin.bias, relu)
+    y = lin(x)
+    return torch.relu(y) if relu else y

@@ -102,7 +102,7 @@ class SnipperDeformable(nn.Module):
         hs, heatmaps, init_reference, inter_references, inter_att = \
             self.transformer(srcs, masks, pos, self.query_embed.weight)
         n_dec, bs, t, _, c = hs.shape
-        if hs.is_cuda and torch.is_autocast_enabled():
+        if hs.is_cuda and torch.is_autocast_enabled('cuda'):
             # the heads see [n_dec, bs, T, queries, C] (a few thousand rows): float32, no autocast casts (the same
             # reasoning as DeformableTransformerDecoderLayer.small_in_fp32)
             with torch.autocast("cuda", enabled=False):

@@ -32,6 +32,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from .dense import big_linear
 from .ms_deform_attn_func import MSDeformAttnFunction, ms_deform_attn_core_pytorch
 
 
@@ -136,7 +137,7 @@ class MSDeformAttn(nn.Module):
             hw = shapes.tolist()                         # reference :112 pays the same host sync
         assert sum(h * w for h, w in hw) == S
 
-        value = self.value_proj(input_flatten)
+        value = big_linear(input_flatten, self.value_proj)
         scale = _level_scale(hw, query.dtype, query.device)                       # (W_l, H_l), cached
         groups = [frame_neighbours(t1, self.n_frame, T2) for t1 in range(T1)]
 
@@ -150,7 +151,7 @@ class MSDeformAttn(nn.Module):
             value = value.view(N, T2, S, M, C // M)
             out, locs, wts = self._forward_pairs(query, reference_points, value, shapes,
                                                  input_level_start_index, scale, groups)
-        out = self.output_proj(out)
+        out = big_linear(out, self.output_proj)
         if self.attention_vis:
             return out, (locs, wts)
         return out
@@ -170,8 +171,8 @@ class MSDeformAttn(nn.Module):
         N, T1, Lq, C = query.shape
         T2, S = value.shape[1], value.shape[2]
         M, L, P = self.n_heads, self.n_levels, self.n_points
-        off_raw = self.sampling_offsets[0](query)                                   # [N,T1,Lq, M*L*P*2]
-        logit_raw = self.attention_weights[0](query)                                # [N,T1,Lq, M*L*P]
+        off_raw = big_linear(query, self.sampling_offsets[0])                       # [N,T1,Lq, M*L*P*2]
+        logit_raw = big_linear(query, self.attention_weights[0])                    # [N,T1,Lq, M*L*P]
         fuse = hw is not None and self._fusable(query, ref, mask)
         if fuse:
             from .fused import MSDAPrologue, TemporalMix

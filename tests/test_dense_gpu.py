@@ -118,3 +118,65 @@ def test_conv3x3_bn_function_grads():
         dxr, dwr = torch.autograd.grad(yr, (xr, wr), gy.float())
         rel = lambda a, b: ((a.float() - b).norm() / b.norm().clamp_min(1e-12)).item()
         assert rel(y, yr) < 1e-2 and rel(dx, dxr) < 8e-2 and rel(dw, dwr) < 8e-2, (rel(y, yr), rel(dx, dxr), rel(dw, dwr))
+
+
+@pytest.mark.parametrize("M,N,Kc", [(79000, 384, 384), (79000, 1024, 384), (79000, 384, 1024), (79000, 96, 384),
+                                    (60000, 192, 384), (1000, 8, 8), (63, 136, 72), (4097, 264, 128), (1, 128, 128)])
+def test_wgrad_kernel(M, N, Kc):
+    """Split-reduction weight/bias gradient against a float64 product of the same bf16 operands."""
+    from snipper_amd.dense import wgrad_bf16
+    gen = torch.Generator().manual_seed(M + N + Kc)
+    g = torch.randn(M, N, generator=gen).to(DEV).bfloat16()
+    x = torch.randn(M, Kc, generator=gen).to(DEV).bfloat16()
+    dW, db = wgrad_bf16(g, x)
+    ref = g.double().t() @ x.double()
+    refb = g.double().sum(0)
+    tol = 1e-5 * (M ** 0.5) * 4 + 1e-6
+    assert (dW.double() - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
+    assert (db.double() - refb).abs().max().item() <= tol * max(1.0, refb.abs().max().item())
+    # deterministic, strided operands, row scale and accumulation
+    dW2, db2 = wgrad_bf16(g, x)
+    assert torch.equal(dW, dW2) and torch.equal(db, db2)
+    if N % 16 == 0 and Kc % 16 == 0:
+        gs, xs = g[:, : N // 2], x[:, Kc // 2:]
+        scale = torch.rand(N // 2, generator=gen).to(DEV) + 0.5
+        acc = torch.ones(N // 2, Kc // 2, device=DEV)
+        wgrad_bf16(gs, xs, want_bias=False, scale=scale, out=acc, accumulate=True)
+        ref2 = 1.0 + scale.double()[:, None] * ref[: N // 2, Kc // 2:]
+        assert (acc.double() - ref2).abs().max().item() <= tol * max(1.0, ref2.abs().max().item())
+
+
+@pytest.mark.parametrize("relu", [False, True])
+@pytest.mark.parametrize("xdtype", [torch.float32, torch.bfloat16])
+def test_big_linear_matches_module(relu, xdtype):
+    """big_linear under bf16 autocast against nn.Linear under the same autocast: outputs and all three gradients."""
+    from snipper_amd.dense import big_linear
+    torch.manual_seed(3)
+    lin = torch.nn.Linear(384, 192).to(DEV)
+    x = torch.randn(2, 3000, 384, device=DEV).to(xdtype).requires_grad_(True)
+    gy = torch.randn(2, 3000, 192, device=DEV).bfloat16()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y = big_linear(x, lin, relu)
+        dx, dw, db = torch.autograd.grad(y, (x, lin.weight, lin.bias), gy)
+        yr = lin(x)
+        yr = yr.relu() if relu else yr
+        dxr, dwr, dbr = torch.autograd.grad(yr, (x, lin.weight, lin.bias), gy)
+    assert y.dtype == yr.dtype and dx.dtype == dxr.dtype and dw.dtype == torch.float32 and db.dtype == torch.float32
+    # reference in float64 on the bf16-rounded operands, to rank both against the truth
+    xd, wd = x.detach().bfloat16().double(), lin.weight.detach().bfloat16().double()
+    yd = xd @ wd.t() + lin.bias.detach().double()
+    gd = gy.double() * ((yd > 0) if relu else 1.0)
+    rel = lambda a, b: ((a.double() - b).norm() / b.norm().clamp_min(1e-30)).item()
+    dwd, dbd = gd.flatten(0, 1).t() @ xd.flatten(0, 1), gd.flatten(0, 1).sum(0)
+    assert rel(y, yr.double()) < 1e-2 and rel(dx, dxr.double()) < 2e-2
+    assert rel(dw, dwd) <= max(2e-3, 1.5 * rel(dwr, dwd)), (rel(dw, dwd), rel(dwr, dwd))
+    assert rel(db, dbd) <= max(2e-3, 1.5 * rel(dbr, dbd)), (rel(db, dbd), rel(dbr, dbd))
+
+
+def test_big_linear_small_inputs_use_pytorch():
+    from snipper_amd.dense import big_linear
+    lin = torch.nn.Linear(384, 96).to(DEV)
+    x = torch.randn(4, 60, 384, device=DEV)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        assert torch.equal(big_linear(x, lin), lin(x))
+    assert torch.equal(big_linear(x, lin), lin(x))          # no autocast: float32 module semantics
