@@ -441,7 +441,7 @@ int snipper_wgrad_bf16(void *stream, const uint16_t *G, long long ldg, const uin
   hipLaunchKernelGGL(wgrad_bf16_kernel, dim3(p.tiles_n * p.tiles_k * p.S), dim3(kWgThreads), 0, (hipStream_t)stream, a);
   const WgradReduceArgs r{P, Pb, dW, lddw, db, scale, N, Kc, p.S, accumulate};
   const long long quads = (long long)N * Kc / 4;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, r);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((quads + 63) / 64)), dim3(256), 0, (hipStream_t)stream, r);
   return launch_status();
 }
 

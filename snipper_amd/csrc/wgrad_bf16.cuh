@@ -174,13 +174,23 @@ struct WgradReduceArgs {
   int N, Kc, S, accumulate;
 };
 
+// 256 threads = 64 quads of 4 consecutive kc x 4 slices of the S partials; the slices meet in LDS
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgradReduceArgs g) {
+  __shared__ gemm_f32x4 red[4][64];
   const long long total = (long long)g.N * g.Kc;
-  const long long e = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+  const int qi = threadIdx.x & 63, slice = threadIdx.x >> 6;
+  const long long e = ((long long)blockIdx.x * 64 + qi) * 4;
+  gemm_f32x4 sum = {0.f, 0.f, 0.f, 0.f};
   if (e < total) {
-    gemm_f32x4 sum = {0.f, 0.f, 0.f, 0.f};
-    for (int s = 0; s < g.S; ++s) sum += *reinterpret_cast<const gemm_f32x4 *>(g.P + (long long)s * total + e);
-    const int n = (int)(e / g.Kc), kc = (int)(e - (long long)n * g.Kc);      // Kc % 4 == 0: one row per thread
+    const float *p = g.P + e;
+#pragma unroll 4
+    for (int s = slice; s < g.S; s += 4) sum += *reinterpret_cast<const gemm_f32x4 *>(p + (long long)s * total);
+  }
+  red[slice][qi] = sum;
+  __syncthreads();
+  if (slice == 0 && e < total) {
+    sum = (red[0][qi] + red[1][qi]) + (red[2][qi] + red[3][qi]);
+    const int n = (int)(e / g.Kc), kc = (int)(e - (long long)n * g.Kc);      // Kc % 4 == 0: one row per quad
     if (g.scale) sum *= g.scale[n];
     float *o = g.dW + (long long)n * g.lddw + kc;
     if (g.accumulate) sum += *reinterpret_cast<const gemm_f32x4 *>(o);
@@ -189,9 +199,9 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgradReduceArgs g) {
   if (g.db && g.Pb) {
     const long long n = (long long)blockIdx.x * 256 + threadIdx.x;
     if (n < g.N) {
-      float sum = 0.f;
-      for (int s = 0; s < g.S; ++s) sum += g.Pb[(long long)s * g.N + n];
-      g.db[n] = g.accumulate ? g.db[n] + sum : sum;
+      float bs = 0.f;
+      for (int s = 0; s < g.S; ++s) bs += g.Pb[(long long)s * g.N + n];
+      g.db[n] = g.accumulate ? g.db[n] + bs : bs;
     }
   }
 }

@@ -45,6 +45,13 @@ for si in range(max(1, len(ends) - a.steps), len(ends)):
             buckets[(seg[i][1] - seg[0][0]) // 5_000_000] += max(g, 0)
         print("   " + " ".join(f"{buckets[b]/1e6:.1f}" for b in range(int(wall // 5_000_000) + 1)))
 
+        agg = collections.defaultdict(lambda: [0, 0])
+        for s_, e_, k in seg:
+            agg[k][0] += 1
+            agg[k][1] += e_ - s_
+        print("kernels of the last step by time:")
+        for k, (n, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:45]:
+            print(f"   {t/1e6:6.2f} ms {n:5d} x {t/n/1e3:8.1f}us  {short(k)}")
         if a.region:
             lo, hi = a.region[0] * 1e6, a.region[1] * 1e6
             cnt = collections.Counter()
