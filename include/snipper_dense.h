@@ -42,6 +42,29 @@ int snipper_wgrad_bf16(void *stream, const uint16_t *G, long long ldg, const uin
                        int M, int N, int Kc, const float *scale, float *dW, long long lddw, float *db,
                        int accumulate, void *workspace, size_t workspace_bytes);
 
+/* Residual + dropout + LayerNorm, the tail of every transformer sub-layer (csrc/ln_fused.cuh; reference
+ * models/deformable_transformer.py:200-216, 266-300: ``src = src + self.dropoutN(src2); src = self.normN(src)``):
+ *   s = x + dropout_p(z);  y = LayerNorm(s) * gamma + beta
+ * x, z, pos [rows, C] with dtype codes 0 = float32, 1 = bfloat16 bits; z may be NULL (plain LayerNorm), pos only
+ * feeds yq16.  Outputs (any non-empty subset): y32 float32, y16 bfloat16, yq16 = bfloat16(y + pos).  For the
+ * backward: s_save [rows, C] float32, mean / rstd [rows], keep [rows, C/4] bytes (low 4 bits = kept elements; only
+ * written when z != NULL and p > 0).  seed selects the dropout mask (a counter-based hash of seed and element index).
+ * C % 4 == 0, C <= 1024, rows * C < 2^32. */
+int snipper_add_dropout_layernorm_forward(void *stream, const void *x, int x_dt, const void *z, int z_dt,
+                                          const void *pos, int pos_dt, const float *gamma, const float *beta,
+                                          int rows, int C, float p, float eps, uint64_t seed,
+                                          float *s_save, float *mean, float *rstd, uint8_t *keep,
+                                          float *y32, uint16_t *y16, uint16_t *yq16);
+/* Backward of the above.  g32 / g16 / gq16 = gradients of y32 / y16 / yq16 (any non-empty subset; they are summed).
+ * dx (= dL/ds) and dz (masked and rescaled) may each be NULL; dgamma / dbeta [C] float32 are overwritten (summed in
+ * a fixed order through `workspace`, >= snipper_add_dropout_layernorm_workspace_bytes(rows, C) bytes). */
+size_t snipper_add_dropout_layernorm_workspace_bytes(int rows, int C);
+int snipper_add_dropout_layernorm_backward(void *stream, const float *g32, const uint16_t *g16, const uint16_t *gq16,
+                                           const float *s_save, const float *mean, const float *rstd,
+                                           const float *gamma, const uint8_t *keep, int rows, int C, float p,
+                                           void *dx, int dx_dt, void *dz, int dz_dt, float *dgamma, float *dbeta,
+                                           void *workspace, size_t workspace_bytes);
+
 /* 3x3 convolution, padding 1, stride 1 or 2, NHWC bf16, as an implicit GEMM on the same MFMA tiles:
  * Y[B,Ho,Wo,Cout] = act(conv(X[B,H,W,Cin], W[Cout,3,3,Cin]) + bias[Cout]), Ho = (H-1)/stride + 1 (same for Wo).
  * Requirements: Cin % 64 == 0, Cout % 4 == 0.  (ResNet bottleneck conv2 with the frozen BatchNorm folded in.) */

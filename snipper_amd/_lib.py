@@ -39,6 +39,12 @@ EXPORTS = {
     "snipper_wgrad_workspace_bytes": ([c_int] * 3, c_size_t),
     "snipper_wgrad_bf16": ([c_void_p, c_void_p, c_longlong, c_void_p, c_longlong, c_int, c_int, c_int, c_void_p,
                             c_void_p, c_longlong, c_void_p, c_int, c_void_p, c_size_t], c_int),
+    "snipper_add_dropout_layernorm_forward": ([c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p,
+                                               c_void_p, c_int, c_int, ctypes.c_float, ctypes.c_float,
+                                               ctypes.c_uint64] + [c_void_p] * 7, c_int),
+    "snipper_add_dropout_layernorm_workspace_bytes": ([c_int, c_int], c_size_t),
+    "snipper_add_dropout_layernorm_backward": ([c_void_p] * 9 + [c_int, c_int, ctypes.c_float, c_void_p, c_int,
+                                                c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_size_t], c_int),
     "snipper_conv3x3_bf16": ([c_void_p] * 5 + [c_int] * 7, c_int),
     "snipper_lsap_f32": ([c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p], c_int),
     "snipper_linear_bf16": ([c_void_p, c_void_p, ctypes.c_longlong, c_void_p, c_void_p, c_void_p, ctypes.c_longlong,

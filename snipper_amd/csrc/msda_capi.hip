@@ -15,6 +15,7 @@
 #include "../../include/snipper_dense.h"
 #include "gemm_bf16.cuh"
 #include "wgrad_bf16.cuh"
+#include "ln_fused.cuh"
 #include "msda_prologue.cuh"
 #include "lsap.cuh"
 #include "msda_d48.cuh"
@@ -442,6 +443,51 @@ int snipper_wgrad_bf16(void *stream, const uint16_t *G, long long ldg, const uin
   const WgradReduceArgs r{P, Pb, dW, lddw, db, scale, N, Kc, p.S, accumulate};
   const long long quads = (long long)N * Kc / 4;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((quads + 63) / 64)), dim3(256), 0, (hipStream_t)stream, r);
+  return launch_status();
+}
+
+namespace {
+inline int ln_bwd_blocks(int rows) { return std::max(1, std::min((rows + 3) / 4, 1024)); }
+inline bool ln_dt_ok(int dt) { return dt == 0 || dt == 1; }
+}  // namespace
+
+int snipper_add_dropout_layernorm_forward(void *stream, const void *x, int x_dt, const void *z, int z_dt,
+                                          const void *pos, int pos_dt, const float *gamma, const float *beta,
+                                          int rows, int C, float p, float eps, uint64_t seed,
+                                          float *s_save, float *mean, float *rstd, uint8_t *keep,
+                                          float *y32, uint16_t *y16, uint16_t *yq16) {
+  if (!x || !gamma || !beta || (!y32 && !y16 && !yq16)) return SNIPPER_E_NULL;
+  if ((yq16 && !pos) || ((mean == nullptr) != (rstd == nullptr))) return SNIPPER_E_NULL;
+  if (rows <= 0 || C <= 0 || C % 4 || C > kLnMaxIter * 256 || !(p >= 0.f && p < 1.f) ||
+      (long long)rows * C >= (1LL << 32) || !ln_dt_ok(x_dt) || !ln_dt_ok(z_dt) || !ln_dt_ok(pos_dt))
+    return SNIPPER_E_SHAPE;
+  const LnFwdArgs a{x, x_dt, z, z_dt, pos, pos_dt, gamma, beta, s_save, mean, rstd, (z && p > 0.f) ? keep : nullptr,
+                    y32, y16, yq16, rows, C, z ? p : 0.f, eps, (uint32_t)seed, (uint32_t)(seed >> 32)};
+  hipLaunchKernelGGL(ln_fused_fwd_kernel, dim3((rows + 3) / 4), dim3(kLnThreads), 0, (hipStream_t)stream, a);
+  return launch_status();
+}
+
+size_t snipper_add_dropout_layernorm_workspace_bytes(int rows, int C) {
+  if (rows <= 0 || C <= 0) return 0;
+  return (size_t)ln_bwd_blocks(rows) * 2 * C * sizeof(float);
+}
+
+int snipper_add_dropout_layernorm_backward(void *stream, const float *g32, const uint16_t *g16, const uint16_t *gq16,
+                                           const float *s_save, const float *mean, const float *rstd,
+                                           const float *gamma, const uint8_t *keep, int rows, int C, float p,
+                                           void *dx, int dx_dt, void *dz, int dz_dt, float *dgamma, float *dbeta,
+                                           void *workspace, size_t workspace_bytes) {
+  if (!s_save || !mean || !rstd || !gamma || !dgamma || !dbeta || !workspace || (!g32 && !g16 && !gq16))
+    return SNIPPER_E_NULL;
+  if (rows <= 0 || C <= 0 || C % 4 || C > kLnMaxIter * 256 || !(p >= 0.f && p < 1.f) || !ln_dt_ok(dx_dt) || !ln_dt_ok(dz_dt))
+    return SNIPPER_E_SHAPE;
+  if (workspace_bytes < snipper_add_dropout_layernorm_workspace_bytes(rows, C)) return SNIPPER_E_SHAPE;
+  const int blocks = ln_bwd_blocks(rows);
+  const LnBwdArgs a{g32, g16, gq16, s_save, mean, rstd, gamma, p > 0.f ? keep : nullptr, dx, dx_dt, dz, dz_dt,
+                    (float *)workspace, rows, C, p};
+  hipLaunchKernelGGL(ln_fused_bwd_kernel, dim3(blocks), dim3(kLnThreads), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(ln_param_grad_kernel, dim3((2 * C + 63) / 64), dim3(256), 0, (hipStream_t)stream,
+                     (const float *)workspace, blocks, C, dgamma, dbeta);
   return launch_status();
 }
 

@@ -108,3 +108,96 @@ class MSDAPrologue(Function):
                 g_off.data_ptr(), g_logit.data_ptr(), _DT[dtype], g_ref.data_ptr() if g_ref is not None else None)
         _lib.check(rc, "snipper_msda_prologue_backward")
         return g_off, g_logit, g_ref, None, None, None, None
+
+
+_dropout_calls = 0
+
+
+def _next_seed() -> int:
+    """A fresh 64-bit seed per call: torch's seed in the high half, a process-wide call counter in the low half
+    (reproducible after ``torch.manual_seed`` for a fixed order of calls)."""
+    global _dropout_calls
+    _dropout_calls += 1
+    return ((torch.initial_seed() & 0xFFFFFFFF) << 32) | (_dropout_calls & 0xFFFFFFFF)
+
+
+class AddDropoutLayerNorm(Function):
+    """y = LayerNorm(x + dropout_p(z)) in one kernel each way (csrc/ln_fused.cuh).
+
+    x [..., C] float32 / bf16, z like x (float32 / bf16) or None, pos like x or None, gamma / beta [C] float32.
+    ``want`` = (y32, y16, yq16) flags; returns those three (None where not wanted): y in float32, y in bf16 and
+    bf16(y + pos).  ``seed`` None draws a fresh one."""
+
+    @staticmethod
+    def forward(ctx, x, z, pos, gamma, beta, p, eps, want, seed):
+        x = x.contiguous()
+        z = z.contiguous() if z is not None else None
+        pos = pos.contiguous() if pos is not None else None
+        C = x.shape[-1]
+        rows = x.numel() // C
+        dev = x.device
+        p = float(p) if z is not None else 0.0
+        need_bwd = any(ctx.needs_input_grad[:5])
+        s_save = torch.empty((rows, C), dtype=torch.float32, device=dev) if need_bwd else None
+        stats = torch.empty((2, rows), dtype=torch.float32, device=dev) if need_bwd else None
+        keep = torch.empty((rows, C // 4), dtype=torch.uint8, device=dev) if (need_bwd and p > 0) else None
+        y32 = torch.empty(x.shape, dtype=torch.float32, device=dev) if want[0] else None
+        y16 = torch.empty(x.shape, dtype=torch.bfloat16, device=dev) if want[1] else None
+        yq = torch.empty(x.shape, dtype=torch.bfloat16, device=dev) if want[2] else None
+        g32, b32 = gamma.float(), beta.float()
+        ptr = lambda t: t.data_ptr() if t is not None else None
+        with torch.cuda.device(dev):
+            rc = _lib.load().snipper_add_dropout_layernorm_forward(
+                _stream(dev), x.data_ptr(), _DT[x.dtype], ptr(z), _DT[z.dtype] if z is not None else 0,
+                ptr(pos), _DT[pos.dtype] if pos is not None else 0, g32.data_ptr(), b32.data_ptr(), rows, C,
+                p, float(eps), int(seed if seed is not None else _next_seed()), ptr(s_save),
+                stats[0].data_ptr() if stats is not None else None, stats[1].data_ptr() if stats is not None else None,
+                ptr(keep), ptr(y32), ptr(y16), ptr(yq))
+        _lib.check(rc, "snipper_add_dropout_layernorm_forward")
+        ctx.save_for_backward(s_save, stats, keep, g32)
+        ctx.meta = (p, x.dtype, None if z is None else z.dtype, None if pos is None else pos.dtype, x.shape,
+                    gamma.dtype, beta.dtype)
+        return y32, y16, yq
+
+    @staticmethod
+    def backward(ctx, g32, g16, gq):
+        s_save, stats, keep, gamma = ctx.saved_tensors
+        p, x_dt, z_dt, pos_dt, shape, gamma_dt, beta_dt = ctx.meta
+        rows, C = s_save.shape
+        dev = s_save.device
+        if g32 is None and g16 is None and gq is None:
+            return (None,) * 9
+        g32 = g32.contiguous().float() if g32 is not None else None
+        g16 = g16.contiguous().to(torch.bfloat16) if g16 is not None else None
+        gq = gq.contiguous().to(torch.bfloat16) if gq is not None else None
+        dx = torch.empty(shape, dtype=x_dt, device=dev) if ctx.needs_input_grad[0] else None
+        dz = torch.empty(shape, dtype=z_dt, device=dev) if (z_dt is not None and ctx.needs_input_grad[1]) else None
+        dgb = torch.empty((2, C), dtype=torch.float32, device=dev)
+        lib = _lib.load()
+        nbytes = lib.snipper_add_dropout_layernorm_workspace_bytes(rows, C)
+        ws = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
+        ptr = lambda t: t.data_ptr() if t is not None else None
+        with torch.cuda.device(dev):
+            rc = lib.snipper_add_dropout_layernorm_backward(
+                _stream(dev), ptr(g32), ptr(g16), ptr(gq), s_save.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(),
+                gamma.data_ptr(), ptr(keep), rows, C, p, ptr(dx), _DT[x_dt] if dx is not None else 0,
+                ptr(dz), _DT[z_dt] if dz is not None else 0, dgb[0].data_ptr(), dgb[1].data_ptr(), ws.data_ptr(), nbytes)
+        _lib.check(rc, "snipper_add_dropout_layernorm_backward")
+        dpos = gq if (pos_dt is not None and ctx.needs_input_grad[2]) else None
+        dgamma = dgb[0].to(gamma_dt) if ctx.needs_input_grad[3] else None
+        dbeta = dgb[1].to(beta_dt) if ctx.needs_input_grad[4] else None
+        return dx, dz, dpos, dgamma, dbeta, None, None, None, None
+
+
+def add_dropout_layer_norm(x, z, norm: torch.nn.LayerNorm, p: float, training: bool, pos=None,
+                           want=(True, False, False), seed=None):
+    """``norm(x + dropout(z, p, training))`` on the fused kernel -> (y32, y16, yq16) per ``want``.  The caller checks
+    ``ln_fusable`` first."""
+    return AddDropoutLayerNorm.apply(x, z, pos, norm.weight, norm.bias, p if training else 0.0, norm.eps, tuple(want), seed)
+
+
+def ln_fusable(x: torch.Tensor, norm: torch.nn.LayerNorm) -> bool:
+    C = x.shape[-1]
+    return (x.is_cuda and x.dtype in _DT and isinstance(norm, torch.nn.LayerNorm) and norm.elementwise_affine and
+            norm.bias is not None and tuple(norm.normalized_shape) == (C,) and C % 4 == 0 and C <= 1024 and
+            x.numel() < 2 ** 32)
