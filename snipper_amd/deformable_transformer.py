@@ -58,6 +58,19 @@ def _activation(name):
         raise RuntimeError(f"activation should be relu/gelu, not {name}.")
 
 
+def _amp_bf16(x) -> bool:
+    return x.is_cuda and torch.is_autocast_enabled('cuda') and torch.get_autocast_dtype('cuda') == torch.bfloat16
+
+
+def _residual_norm(x, z, norm, drop):
+    """norm(x + drop(z)): one launch of the fused kernel (csrc/ln_fused.cuh) when it applies."""
+    from .fused import add_dropout_layer_norm, ln_fusable
+    if ln_fusable(x, norm) and z.dtype in (torch.float32, torch.bfloat16) and z.shape == x.shape and \
+            isinstance(drop, nn.Dropout):
+        return add_dropout_layer_norm(x, z, norm, drop.p, drop.training)[0].to(torch.result_type(x, z))
+    return norm(x + drop(z))
+
+
 class _FFNMixin:
     """Linear -> act -> dropout -> Linear, residual, LayerNorm (shared by both layer types)."""
 
@@ -67,7 +80,7 @@ class _FFNMixin:
         else:
             h = self.activation(big_linear(x, self.linear1))
         y = big_linear(drop_a(h), self.linear2)
-        return norm(x + drop_b(y))
+        return _residual_norm(x, y, norm, drop_b)
 
 
 class DeformableTransformerEncoderLayer(nn.Module, _FFNMixin):
@@ -94,8 +107,32 @@ class DeformableTransformerEncoderLayer(nn.Module, _FFNMixin):
     def forward(self, src, pos, reference_points, spatial_shapes, level_start_index, padding_mask=None):
         attended = self.self_attn(self.with_pos_embed(src, pos), reference_points, src,
                                   spatial_shapes, level_start_index, padding_mask)
-        src = self.norm1(src + self.dropout1(attended))
+        src = _residual_norm(src, attended, self.norm1, self.dropout1)
         return self.forward_ffn(src)
+
+    # -- the same layer with the bf16 companions of the residual stream carried along -----------------------
+    fused_residual = True        # class-level switch (tests compare both formulations)
+
+    def fused_ok(self, src) -> bool:
+        from .fused import ln_fusable
+        return (self.fused_residual and src.dtype == torch.float32 and _amp_bf16(src) and ln_fusable(src, self.norm1) and
+                ln_fusable(src, self.norm2) and self.activation is F.relu)
+
+    def forward_fused(self, src32, src16, q16, pos16, reference_points, spatial_shapes, level_start_index,
+                      padding_mask, last: bool):
+        """One encoder layer under bf16 autocast.  The residual stream stays float32 (``src32``); every consumer that
+        computes in bf16 gets a bf16 view written by the kernel that produced the float32 one: ``src16`` feeds the
+        value projection, ``q16`` = bf16(src + pos) the offset / weight projections.  Their gradients come back into
+        the fused LayerNorm backward, which adds them to the residual gradient in registers -- no cast, add or
+        gradient-accumulation kernels in between.  Returns (src32, src16, q16) of the next layer."""
+        from .fused import add_dropout_layer_norm
+        attended = self.self_attn(q16, reference_points, src16, spatial_shapes, level_start_index, padding_mask)
+        y32, y16, _ = add_dropout_layer_norm(src32, attended, self.norm1, self.dropout1.p, self.training,
+                                             want=(True, True, False))
+        h = self.dropout2(big_linear(y16, self.linear1, relu=True))
+        z = big_linear(h, self.linear2)
+        return add_dropout_layer_norm(y32, z, self.norm2, self.dropout3.p, self.training, pos=pos16,
+                                      want=(True, True, not last))
 
 
 class DeformableTransformerEncoder(nn.Module):
@@ -123,6 +160,14 @@ class DeformableTransformerEncoder(nn.Module):
         ref = self.get_reference_points(spatial_shapes, valid_ratios, device=src.device)
         ref = ref.unsqueeze(1).expand(-1, n_frame, -1, -1, -1)  # same grid for every frame
         out = src
+        if pos is not None and all(hasattr(l, "fused_ok") and l.fused_ok(src) for l in self.layers):
+            pos16 = pos.to(torch.bfloat16)                      # gradients of the 6 uses accumulate in bf16
+            out16, q16 = out.to(torch.bfloat16), (out + pos).to(torch.bfloat16)
+            for i, layer in enumerate(self.layers):
+                out, out16, q16 = layer.forward_fused(out, out16, q16, pos16, ref, spatial_shapes, level_start_index,
+                                                      padding_mask, last=i + 1 == len(self.layers))
+            out._snipper_bf16 = out16                           # big_linear picks the bf16 twin up (decoder memory)
+            return out
         for layer in self.layers:
             out = layer(out, pos, ref, spatial_shapes, level_start_index, padding_mask)
         return out
@@ -184,12 +229,12 @@ class DeformableTransformerDecoderLayer(nn.Module, _FFNMixin):
         flat = tgt.reshape(bs, t * lq, c)
         qk = self.with_pos_embed(flat, query_pos.reshape(bs, t * lq, c)).transpose(0, 1)
         mixed = self.self_attn(qk, qk, flat.transpose(0, 1), need_weights=False)[0].transpose(0, 1)
-        tgt = self.norm2(flat + self.dropout2(mixed)).view(bs, t, lq, c)
+        tgt = _residual_norm(flat, mixed, self.norm2, self.dropout2).view(bs, t, lq, c)
         # deformable cross-attention into the encoder memory (reference :290-295)
         attended, atten_data = self._cross(amp_dtype, self.with_pos_embed(tgt, query_pos.view(bs, t, lq, c)),
                                            reference_points, src, src_spatial_shapes,
                                            level_start_index, src_padding_mask)
-        tgt = self.norm1(tgt + self.dropout1(attended))
+        tgt = _residual_norm(tgt, attended, self.norm1, self.dropout1)
         return self.forward_ffn(tgt), atten_data
 
 

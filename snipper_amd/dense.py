@@ -147,6 +147,9 @@ def big_linear(x: torch.Tensor, lin: torch.nn.Linear, relu: bool = False) -> tor
     """``lin(x)`` (followed by ReLU if ``relu``), routed to the hand-written kernels when ``x`` is a CUDA tensor with
     at least BIG_LINEAR_MIN_ROWS rows that is computed in bf16 (bf16 input, or autocast to bf16); plain PyTorch
     otherwise, with identical semantics."""
+    twin = getattr(x, "_snipper_bf16", None)      # a bf16 copy written by the kernel that produced x (same graph)
+    if twin is not None and twin.shape == x.shape and twin.device == x.device:
+        x = twin
     rows = x.numel() // max(1, x.shape[-1])
     in_bf16 = x.dtype == torch.bfloat16 or (torch.is_autocast_enabled('cuda') and
                                              torch.get_autocast_dtype('cuda') == torch.bfloat16)

@@ -102,3 +102,39 @@ def test_snipper_geometry_forward_backward_runs_d48_kernels():
     for a, c in zip(g_hip, g_ref):
         s = max(float(c.abs().max()), 1.0)
         torch.testing.assert_close(a / s, c / s, rtol=1e-3, atol=2e-4)
+
+
+def test_transformer_bf16_fused_residual_path_matches_plain_path(golden_dir):
+    """Under bf16 autocast the encoder carries bf16 twins of its float32 residual stream through the fused
+    residual + LayerNorm kernels; the result must agree with the plain per-op formulation (same autocast, same
+    weights, dropout off) to bf16 accuracy, outputs and parameter gradients, and with the float64 golden output."""
+    from snipper_amd.deformable_transformer import DeformableTransformerEncoderLayer as EncLayer
+    b = torch.load(os.path.join(golden_dir, "g4_transformer.pt"))
+    tr = DeformableTransformer(return_intermediate_dec=True, use_pytroch_deform=False, activation="relu", **b["cfg"])
+    tr.load_state_dict(b["state_dict"], strict=True)
+    tr = tr.to(DEV).float().eval()
+    args = (_to(b["srcs"], dtype=torch.float32), _to(b["masks"]), _to(b["pos"], dtype=torch.float32),
+            _to(b["query_embed"], dtype=torch.float32))
+    res = {}
+    for fused in (True, False):
+        EncLayer.fused_residual = fused
+        try:
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                hs = tr(*args)[0]
+            w = torch.linspace(-1, 1, hs.numel(), device=DEV).view_as(hs)
+            grads = torch.autograd.grad((hs.float() * w).sum(), list(tr.parameters()), allow_unused=True)
+        finally:
+            EncLayer.fused_residual = True
+        res[fused] = (hs.float(), grads)
+    rel = lambda a, c: ((a.double() - c.double()).norm() / c.double().norm().clamp_min(1e-20)).item()
+    gold = b["hs"].to(DEV)
+    e_fused, e_plain = rel(res[True][0], gold), rel(res[False][0], gold)
+    assert e_fused < 3e-2 and e_fused < 2.0 * e_plain + 1e-3, (e_fused, e_plain)
+    names = [k for k, _ in tr.named_parameters()]
+    for k, gf, gp in zip(names, res[True][1], res[False][1]):
+        ref = b["param_grads"][k]
+        if ref is None or gf is None:
+            continue
+        ref = ref.to(DEV)
+        ef, ep = rel(gf, ref), rel(gp, ref)
+        assert ef < 2.0 * ep + 3e-2, (k, ef, ep)
