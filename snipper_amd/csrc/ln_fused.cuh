@@ -214,20 +214,25 @@ __global__ __launch_bounds__(kLnThreads) void ln_fused_bwd_kernel(LnBwdArgs a) {
   }
 }
 
-// dgamma[c] = sum_b part[b][0][c], dbeta[c] = sum_b part[b][1][c]: 64 channels x 4 slices of b per workgroup
+// dgamma[c] = sum_b part[b][0][c], dbeta[c] = sum_b part[b][1][c]: 16 channels x 16 slices of b per workgroup
+// (the 16 lanes of a slice read 64 contiguous bytes; the slices meet in LDS), summed in a fixed order
 __global__ __launch_bounds__(256) void ln_param_grad_kernel(const float *part, int nparts, int C, float *dgamma, float *dbeta) {
-  __shared__ float red[4][64];
-  const int ci = threadIdx.x & 63, slice = threadIdx.x >> 6;
-  const int e = blockIdx.x * 64 + ci;                  // over 2*C
+  __shared__ float red[16][17];
+  const int ci = threadIdx.x & 15, slice = threadIdx.x >> 4;
+  const int e = blockIdx.x * 16 + ci;                  // over 2*C
   float sum = 0.f;
   if (e < 2 * C) {
     const int which = e >= C, c = which ? e - C : e;
-    for (int b = slice; b < nparts; b += 4) sum += part[((long long)b * 2 + which) * C + c];
+    const float *p = part + (long long)which * C + c;
+#pragma unroll 4
+    for (int b = slice; b < nparts; b += 16) sum += p[(long long)b * 2 * C];
   }
   red[slice][ci] = sum;
   __syncthreads();
   if (slice == 0 && e < 2 * C) {
-    sum = (red[0][ci] + red[1][ci]) + (red[2][ci] + red[3][ci]);
+    sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) sum += red[k][ci];
     if (e >= C) dbeta[e - C] = sum; else dgamma[e] = sum;
   }
 }

@@ -32,6 +32,7 @@ std::atomic<float> g_near_radius{6.0f};
 std::atomic<int> g_owner_debug{0};
 std::atomic<int> g_owner_chunk{64};
 std::atomic<int> g_wgrad_wgs{512};
+std::atomic<int> g_ln_bwd_blocks{2048};
 std::atomic<int> g_owner_enable{1};   // owner-computes backward for the encoder shape
 std::atomic<int> g_tile_edge[3] = {{16}, {8}, {4}};   // level area > 4096 px / > 1024 px / smaller
 
@@ -281,6 +282,9 @@ int snipper_msda_set_param(const char *name, double v) {
   } else if (k == "owner_chunk") {
     if (v != 64 && v != 128) return SNIPPER_E_SHAPE;
     g_owner_chunk.store((int)v);
+  } else if (k == "ln_bwd_blocks") {
+    if (!(v >= 1 && v <= 65536)) return SNIPPER_E_SHAPE;
+    g_ln_bwd_blocks.store((int)v);
   } else if (k == "wgrad_wgs") {
     if (!(v >= 1 && v <= 65536)) return SNIPPER_E_SHAPE;
     g_wgrad_wgs.store((int)v);
@@ -447,7 +451,7 @@ int snipper_wgrad_bf16(void *stream, const uint16_t *G, long long ldg, const uin
 }
 
 namespace {
-inline int ln_bwd_blocks(int rows) { return std::max(1, std::min((rows + 3) / 4, 1024)); }
+inline int ln_bwd_blocks(int rows) { return std::max(1, std::min((rows + 3) / 4, g_ln_bwd_blocks.load(std::memory_order_relaxed))); }
 inline bool ln_dt_ok(int dt) { return dt == 0 || dt == 1; }
 }  // namespace
 
@@ -486,7 +490,7 @@ int snipper_add_dropout_layernorm_backward(void *stream, const float *g32, const
   const LnBwdArgs a{g32, g16, gq16, s_save, mean, rstd, gamma, p > 0.f ? keep : nullptr, dx, dx_dt, dz, dz_dt,
                     (float *)workspace, rows, C, p};
   hipLaunchKernelGGL(ln_fused_bwd_kernel, dim3(blocks), dim3(kLnThreads), 0, (hipStream_t)stream, a);
-  hipLaunchKernelGGL(ln_param_grad_kernel, dim3((2 * C + 63) / 64), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(ln_param_grad_kernel, dim3((2 * C + 15) / 16), dim3(256), 0, (hipStream_t)stream,
                      (const float *)workspace, blocks, C, dgamma, dbeta);
   return launch_status();
 }
