@@ -232,6 +232,9 @@ def main():
     ap.add_argument("--master-weights", type=int, default=0,
                     help="bf16 only: 1 = bf16 parameters + fp32 master copy in the optimizer; 0 = fp32 parameters under autocast")
     ap.add_argument("--graph", type=int, default=0, help="1 = capture the step in a hipGraph (measured: no gain on ROCm 7.2, 73 vs 71 ms; off by default)")
+    ap.add_argument("--ddp", choices=["flat", "torch"], default="flat",
+                    help="N>1 gradient averaging: flat = one flat buffer + a few large all-reduces after backward "
+                         "(snipper_amd/grad_sync.py); torch = DistributedDataParallel (host-bound: +15 ms/step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip roofline/msda extras (profiling runs)")
     a = ap.parse_args()
@@ -287,11 +290,17 @@ def main():
         opt = build_optimizer(master_named, capturable=bool(a.graph))
     else:
         opt = build_optimizer(list(model.named_parameters()), capturable=bool(a.graph))
-    net = model
-    if use_ddp:
+    net, gsync = model, None
+    if use_ddp and a.ddp == "torch":
         net = torch.nn.parallel.DistributedDataParallel(
             model, device_ids=[local_rank], broadcast_buffers=False, gradient_as_bucket_view=True,
             bucket_cap_mb=50, static_graph=True)
+    elif use_ddp:
+        # the same semantics (rank 0's initial weights everywhere; mean of the ranks' gradients after backward)
+        # without a reducer hook per parameter: see snipper_amd/grad_sync.py
+        from snipper_amd.grad_sync import FlatGradSync
+        gsync = FlatGradSync(model.parameters())
+        gsync.broadcast_parameters(list(model.parameters()) + list(model.buffers()))
     batches = make_batches(a, device, 2, seed=1000 + rank)
 
     criterion = None
@@ -310,6 +319,8 @@ def main():
         if masters is None:
             opt.zero_grad(set_to_none=True)
             loss.backward()
+            if gsync is not None:
+                gsync.sync()
             torch.nn.utils.clip_grad_norm_(model.parameters(), 0.1)
             opt.step()
         else:

@@ -111,7 +111,7 @@ class _PointwiseConvBN(torch.autograd.Function):
         w_eff = (weight.reshape(cout, cin).float() * scale[:, None]).to(torch.bfloat16)
         y = linear_bf16(x2, w_eff, shift, res2, relu)
         ctx.relu, ctx.has_res = relu, res2 is not None
-        ctx.wshape, ctx.wdtype = weight.shape, weight.dtype
+        ctx.wshape, ctx.wdtype, ctx.wstride = weight.shape, weight.dtype, weight.stride()
         ctx.save_for_backward(x2, w_eff, scale, y if relu else None)
         return y
 
@@ -127,7 +127,8 @@ class _PointwiseConvBN(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             from .dense import wgrad_bf16
             dw, _ = wgrad_bf16(g, x2, want_bias=False, scale=scale)     # BN scale folded into the reduction kernel
-            dw = dw.reshape(ctx.wshape).to(ctx.wdtype)
+            # same memory, the parameter's own strides (NHWC weights: DDP aliases its bucket only when they match)
+            dw = dw.to(ctx.wdtype).as_strided(ctx.wshape, ctx.wstride)
         return dx, dw, None, None, (g if ctx.has_res else None), None
 
 

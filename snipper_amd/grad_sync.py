@@ -1,0 +1,80 @@
+"""Data-parallel gradient synchronisation for the training step: one flat buffer, a few large all-reduces.
+
+The reference trains with ``torch.nn.parallel.DistributedDataParallel`` (main.py:193-196).  DDP's reducer hooks every
+parameter's gradient accumulator; with the ~330 parameter tensors of this model that is ~15 ms of host work per step
+(measured on MI355X: the step goes from GPU-bound, 49 ms, to host-bound, 57 ms).  The semantics the path needs are
+just "after backward every rank holds the mean of the ranks' gradients", so this module does exactly that:
+
+  * all parameters that require grad own a slice of ONE flat float32 buffer;
+  * after ``loss.backward()`` (grads produced with ``zero_grad(set_to_none=True)``, so autograd hands its buffers
+    over without an accumulation kernel per parameter), ``sync()`` packs the gradients into the flat buffer with
+    multi-tensor copies, all-reduces it in a few large chunks (RCCL rings over xGMI are per-link bound: few, large
+    messages), scales by 1/world and re-points every ``p.grad`` at its slice -- views with the parameter's own
+    strides (NHWC convolution weights stay NHWC);
+  * ``broadcast_parameters()`` makes rank 0's initial weights everybody's, as DDP's constructor does.
+
+Parameters that took no part in the step (``grad is None``) contribute zeros, like DDP with static_graph.
+"""
+from __future__ import annotations
+
+from typing import Iterable, List
+
+import torch
+import torch.distributed as dist
+
+
+def _dense_view(flat: torch.Tensor, offset: int, like: torch.Tensor) -> torch.Tensor:
+    """A view of ``flat[offset : offset + like.numel()]`` with ``like``'s shape and strides (``like`` must be dense and
+    non-overlapping, which every parameter is)."""
+    return flat.as_strided(like.shape, like.stride(), offset)
+
+
+class FlatGradSync:
+    def __init__(self, params: Iterable[torch.nn.Parameter], group=None, chunks: int = 4):
+        self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
+        assert self.params, "no trainable parameters"
+        dev, dt = self.params[0].device, torch.float32
+        assert all(p.device == dev and p.dtype == dt for p in self.params), "float32 parameters on one device expected"
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        total = sum(p.numel() for p in self.params)
+        self.flat = torch.zeros(total, dtype=dt, device=dev)
+        self.views, off = [], 0
+        for p in self.params:
+            self.views.append(_dense_view(self.flat, off, p))
+            off += p.numel()
+        # chunk boundaries on parameter boundaries: contiguous slices of the flat buffer
+        self.chunks, start, acc, target = [], 0, 0, (total + chunks - 1) // max(1, chunks)
+        for p in self.params:
+            acc += p.numel()
+            if acc - start >= target:
+                self.chunks.append((start, acc))
+                start = acc
+        if start < total:
+            self.chunks.append((start, total))
+
+    @torch.no_grad()
+    def broadcast_parameters(self, modules_or_tensors: Iterable[torch.Tensor], src: int = 0) -> None:
+        if self.world == 1:
+            return
+        tensors = list(modules_or_tensors)
+        for t in tensors:
+            dist.broadcast(t.data if isinstance(t, torch.nn.Parameter) else t, src, group=self.group)
+
+    @torch.no_grad()
+    def sync(self) -> None:
+        """Mean of the ranks' gradients into every ``p.grad`` (collective: every rank must call it)."""
+        have = [(v, p.grad) for v, p in zip(self.views, self.params) if p.grad is not None and p.grad is not v]
+        missing = [v for v, p in zip(self.views, self.params) if p.grad is None]
+        if missing:
+            torch._foreach_zero_(missing)
+        if have:
+            torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
+        if self.world > 1:
+            works = [dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                     for a, b in self.chunks]
+            for w in works:
+                w.wait()
+            self.flat.mul_(1.0 / self.world)
+        for v, p in zip(self.views, self.params):
+            p.grad = v

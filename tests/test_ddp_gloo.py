@@ -29,14 +29,14 @@ ARGS = SimpleNamespace(hidden_dim=192, enc_layers=1, dec_layers=2, frames=2, fut
                        use_pytorch_deform=1, batch=1, height=64, width=96)
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, mode):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.set_num_threads(2)
     b = _bench()
     from snipper_amd.model import build_model
-    torch.manual_seed(0)
+    torch.manual_seed(0 if mode == "torch" else rank)      # flat: ranks start different, the broadcast must fix it
     model = build_model(b.model_args(ARGS))
     model.train()
     for mod in model.modules():          # dropout off: the single-process reference below must match
@@ -44,8 +44,15 @@ def _worker(rank, world, port, out_dir):
             mod.p = 0.0
         if isinstance(mod, torch.nn.MultiheadAttention):
             mod.dropout = 0.0
-    ddp = torch.nn.parallel.DistributedDataParallel(model, broadcast_buffers=False, gradient_as_bucket_view=True,
-                                                    bucket_cap_mb=50, static_graph=True)
+    gsync = None
+    if mode == "torch":
+        ddp = torch.nn.parallel.DistributedDataParallel(model, broadcast_buffers=False, gradient_as_bucket_view=True,
+                                                        bucket_cap_mb=50, static_graph=True)
+    else:                                # bench.py's default for N > 1
+        from snipper_amd.grad_sync import FlatGradSync
+        ddp = model
+        gsync = FlatGradSync(model.parameters(), chunks=3)
+        gsync.broadcast_parameters(list(model.parameters()) + list(model.buffers()))
     from snipper_amd.criterion import build_criterion
     crit = build_criterion(b.criterion_args(ARGS))
     opt = b.build_optimizer(list(model.named_parameters()))
@@ -56,6 +63,8 @@ def _worker(rank, world, port, out_dir):
         loss = crit.weighted_sum(losses)
         opt.zero_grad(set_to_none=True)
         loss.backward()
+        if gsync is not None:
+            gsync.sync()
         if it == 0:
             grads = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
         torch.nn.utils.clip_grad_norm_(model.parameters(), 0.1)
@@ -66,11 +75,12 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_two_rank_gloo_step_matches_single_process(tmp_path):
+@pytest.mark.parametrize("mode", ["flat", "torch"])
+def test_two_rank_gloo_step_matches_single_process(tmp_path, mode):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, str(tmp_path), mode), nprocs=2, join=True)
     r0, r1 = (torch.load(tmp_path / f"rank{r}.pt") for r in (0, 1))
     # (1) replicas stay identical
     for k in r0["params"]:
