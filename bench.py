@@ -306,7 +306,10 @@ def main():
         # the same semantics (rank 0's initial weights everywhere; mean of the ranks' gradients after backward)
         # without a reducer hook per parameter: see snipper_amd/grad_sync.py
         from snipper_amd.grad_sync import FlatGradSync
-        gsync = FlatGradSync(model.parameters())
+        # everything but the backbone is "early": its gradients are complete when the input projections' are
+        early = [p for n, p in model.named_parameters() if not n.startswith("backbone.")]
+        trigger = list(model.input_proj.parameters())
+        gsync = FlatGradSync(model.parameters(), early=early, trigger=trigger)
         gsync.broadcast_parameters(list(model.parameters()) + list(model.buffers()))
     batches = make_batches(a, device, 2, seed=1000 + rank)
 

@@ -14,6 +14,13 @@ just "after backward every rank holds the mean of the ranks' gradients", so this
   * ``broadcast_parameters()`` makes rank 0's initial weights everybody's, as DDP's constructor does.
 
 Parameters that took no part in the step (``grad is None``) contribute zeros, like DDP with static_graph.
+
+Overlap: backward reaches the backbone last (~1/4 of the step's GPU time, >half of the gradient bytes still to come).
+If ``early`` names the parameters whose gradients are complete before that (everything but the backbone) and
+``trigger`` the ones whose gradients arrive last among them (the 1x1 input projections between backbone and
+encoder), a post-accumulate hook on the trigger parameters packs and all-reduces the early slice while the backbone's
+backward is still running; ``sync()`` then only has the backbone's slice left.  The early launch is taken only when
+every early gradient is present at that moment -- otherwise ``sync()`` does everything, as without overlap.
 """
 from __future__ import annotations
 
@@ -30,8 +37,14 @@ def _dense_view(flat: torch.Tensor, offset: int, like: torch.Tensor) -> torch.Te
 
 
 class FlatGradSync:
-    def __init__(self, params: Iterable[torch.nn.Parameter], group=None, chunks: int = 4):
-        self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
+    def __init__(self, params: Iterable[torch.nn.Parameter], group=None, chunks: int = 4,
+                 early: Iterable[torch.nn.Parameter] = (), trigger: Iterable[torch.nn.Parameter] = ()):
+        params = [p for p in params if p.requires_grad]
+        early_ids = {id(p) for p in early if p.requires_grad}
+        # flat layout: [early | rest]
+        self.params: List[torch.nn.Parameter] = [p for p in params if id(p) in early_ids] + \
+                                                [p for p in params if id(p) not in early_ids]
+        self.n_early = sum(1 for p in params if id(p) in early_ids)
         assert self.params, "no trainable parameters"
         dev, dt = self.params[0].device, torch.float32
         assert all(p.device == dev and p.dtype == dt for p in self.params), "float32 parameters on one device expected"
@@ -52,6 +65,41 @@ class FlatGradSync:
                 start = acc
         if start < total:
             self.chunks.append((start, total))
+        self.early_elems = sum(p.numel() for p in self.params[:self.n_early])
+        self._early_works, self._early_done = [], False
+        self._trigger = [p for p in trigger if p.requires_grad]
+        self._pending = len(self._trigger)
+        if self.n_early and self._trigger and self.world > 1:
+            for p in self._trigger:
+                p.register_post_accumulate_grad_hook(self._on_trigger)
+
+    def _pack(self, lo: int, hi: int) -> None:
+        have = [(v, p.grad) for v, p in zip(self.views[lo:hi], self.params[lo:hi])
+                if p.grad is not None and p.grad is not v]
+        missing = [v for v, p in zip(self.views[lo:hi], self.params[lo:hi]) if p.grad is None]
+        if missing:
+            torch._foreach_zero_(missing)
+        if have:
+            torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
+
+    def _reduce(self, lo_elem: int, hi_elem: int):
+        works = []
+        for a, b in self.chunks:
+            a, b = max(a, lo_elem), min(b, hi_elem)
+            if a < b:
+                works.append(dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        return works
+
+    @torch.no_grad()
+    def _on_trigger(self, _param) -> None:
+        """Runs on the autograd thread when one trigger parameter's gradient is complete."""
+        self._pending -= 1
+        if self._pending > 0 or self._early_done:
+            return
+        if all(p.grad is not None for p in self.params[:self.n_early]):
+            self._pack(0, self.n_early)
+            self._early_works = self._reduce(0, self.early_elems)
+            self._early_done = True
 
     @torch.no_grad()
     def broadcast_parameters(self, modules_or_tensors: Iterable[torch.Tensor], src: int = 0) -> None:
@@ -64,17 +112,13 @@ class FlatGradSync:
     @torch.no_grad()
     def sync(self) -> None:
         """Mean of the ranks' gradients into every ``p.grad`` (collective: every rank must call it)."""
-        have = [(v, p.grad) for v, p in zip(self.views, self.params) if p.grad is not None and p.grad is not v]
-        missing = [v for v, p in zip(self.views, self.params) if p.grad is None]
-        if missing:
-            torch._foreach_zero_(missing)
-        if have:
-            torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
+        first = self.n_early if self._early_done else 0
+        self._pack(first, len(self.params))
         if self.world > 1:
-            works = [dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-                     for a, b in self.chunks]
+            works = self._early_works + self._reduce(self.early_elems if self._early_done else 0, self.flat.numel())
             for w in works:
                 w.wait()
             self.flat.mul_(1.0 / self.world)
         for v, p in zip(self.views, self.params):
             p.grad = v
+        self._early_works, self._early_done, self._pending = [], False, len(self._trigger)

@@ -51,7 +51,8 @@ def _worker(rank, world, port, out_dir, mode):
     else:                                # bench.py's default for N > 1
         from snipper_amd.grad_sync import FlatGradSync
         ddp = model
-        gsync = FlatGradSync(model.parameters(), chunks=3)
+        early = [p for n, p in model.named_parameters() if not n.startswith("backbone.")]
+        gsync = FlatGradSync(model.parameters(), chunks=3, early=early, trigger=list(model.input_proj.parameters()))
         gsync.broadcast_parameters(list(model.parameters()) + list(model.buffers()))
     from snipper_amd.criterion import build_criterion
     crit = build_criterion(b.criterion_args(ARGS))
@@ -64,6 +65,7 @@ def _worker(rank, world, port, out_dir, mode):
         opt.zero_grad(set_to_none=True)
         loss.backward()
         if gsync is not None:
+            assert gsync._early_done, "the early slice must have been launched from the hook"
             gsync.sync()
         if it == 0:
             grads = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
