@@ -85,14 +85,19 @@ int snipper_temporal_mix(void *stream, const void *in, int in_dtype, const unsig
 /* snipper_msda_prologue_forward: rows = N*T*Lq*M, one row = the L*P samples of a (query, head) (L*P <= 16, L <= 8)
  *   loc[row, l, p, :] = ref[row / M, l, :] + off[row, l, p, :] * (inv_w[l], inv_h[l])       (ms_deform_attn.py:164-165)
  *   prob[row, :]      = softmax(logit[row, :])                                               (:149, tied weights)
- *   off / logit: `dtype`;  ref, loc, prob: float32;  inv_w / inv_h: HOST arrays of L floats.
- * snipper_msda_prologue_backward: the adjoint; grad_ref may be NULL; otherwise M must be a power of two <= 64. */
-int snipper_msda_prologue_forward(void *stream, const void *off, const void *logit, int dtype, const float *ref,
-                                  const float *inv_w, const float *inv_h, long long rows, int M, int L, int P,
-                                  float *loc, float *prob);
+ *   off / logit: `dtype`, addressed per query with leading dimensions in elements -- row (q, m) reads
+ *   off + q * off_ld + m * 2*L*P and logit + q * logit_ld + m * L*P (off_ld = M*L*P*2, logit_ld = M*L*P for separate
+ *   contiguous arrays; both may be column slices of one merged projection output);
+ *   ref, loc, prob: float32 contiguous;  inv_w / inv_h: HOST arrays of L floats.
+ * snipper_msda_prologue_backward: the adjoint, grad_off / grad_logit with the same addressing; grad_ref may be NULL;
+ * otherwise M must be a power of two <= 64. */
+int snipper_msda_prologue_forward(void *stream, const void *off, long long off_ld, const void *logit, long long logit_ld,
+                                  int dtype, const float *ref, const float *inv_w, const float *inv_h, long long rows,
+                                  int M, int L, int P, float *loc, float *prob);
 int snipper_msda_prologue_backward(void *stream, const float *grad_loc, const float *grad_prob, const float *prob,
                                    const float *inv_w, const float *inv_h, long long rows, int M, int L, int P,
-                                   void *grad_off, void *grad_logit, int dtype, float *grad_ref);
+                                   void *grad_off, long long grad_off_ld, void *grad_logit, long long grad_logit_ld,
+                                   int dtype, float *grad_ref);
 
 /* ---- Hungarian matching on the device (csrc/lsap.cuh) ---------------------------------------------------
  * Replaces the host round trip of models/matcher.py:132 (`linear_sum_assignment(cost.cpu())`).

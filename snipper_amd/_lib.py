@@ -32,10 +32,11 @@ EXPORTS = {
     "snipper_msda_backward_bf16": (_BWD_ARGS, c_int),
     "snipper_temporal_mix": ([c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int,
                               ctypes.c_longlong, c_int, c_void_p, c_int], c_int),
-    "snipper_msda_prologue_forward": ([c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
-                                       ctypes.c_longlong, c_int, c_int, c_int, c_void_p, c_void_p], c_int),
-    "snipper_msda_prologue_backward": ([c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_longlong,
-                                        c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p], c_int),
+    "snipper_msda_prologue_forward": ([c_void_p, c_void_p, c_longlong, c_void_p, c_longlong, c_int, c_void_p, c_void_p,
+                                       c_void_p, c_longlong, c_int, c_int, c_int, c_void_p, c_void_p], c_int),
+    "snipper_msda_prologue_backward": ([c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong,
+                                        c_int, c_int, c_int, c_void_p, c_longlong, c_void_p, c_longlong, c_int,
+                                        c_void_p], c_int),
     "snipper_wgrad_workspace_bytes": ([c_int] * 3, c_size_t),
     "snipper_wgrad_bf16": ([c_void_p, c_void_p, c_longlong, c_void_p, c_longlong, c_int, c_int, c_int, c_void_p,
                             c_void_p, c_longlong, c_void_p, c_int, c_void_p, c_size_t], c_int),

@@ -547,40 +547,70 @@ static int make_level_scale(const float *inv_w, const float *inv_h, int L, Level
   return SNIPPER_OK;
 }
 
-int snipper_msda_prologue_forward(void *stream, const void *off, const void *logit, int dtype, const float *ref,
-                                  const float *inv_w, const float *inv_h, long long rows, int M, int L, int P,
-                                  float *loc, float *prob) {
+namespace {
+// 4-element vector accesses need LP % 4 == 0 and slices that start and advance on 4-element boundaries
+inline bool prologue_vec_ok(const void *a, long long a_ld, const void *b, long long b_ld, int LP, int dtype) {
+  const uintptr_t align = dtype == 0 ? 16 : 8;
+  return LP % 4 == 0 && a_ld % 4 == 0 && b_ld % 4 == 0 && ((uintptr_t)a % align) == 0 && ((uintptr_t)b % align) == 0;
+}
+}  // namespace
+
+int snipper_msda_prologue_forward(void *stream, const void *off, long long off_ld, const void *logit, long long logit_ld,
+                                  int dtype, const float *ref, const float *inv_w, const float *inv_h, long long rows,
+                                  int M, int L, int P, float *loc, float *prob) {
   if (!off || !logit || !ref || !loc || !prob) return SNIPPER_E_NULL;
   if (rows <= 0 || M <= 0 || L <= 0 || P <= 0 || L > kPrologueMaxL || L * P > kPrologueMaxLP) return SNIPPER_E_SHAPE;
+  if (off_ld < (long long)M * L * P * 2 || logit_ld < (long long)M * L * P) return SNIPPER_E_SHAPE;
   LevelScale sc{};
   if (int rc = make_level_scale(inv_w, inv_h, L, &sc)) return rc;
   const dim3 grid((unsigned)((rows + 255) / 256));
-  if (dtype == 0)
-    hipLaunchKernelGGL(prologue_fwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float *)off,
-                       (const float *)logit, ref, sc, rows, M, L, P, loc, prob);
-  else if (dtype == 1)
-    hipLaunchKernelGGL(prologue_fwd_kernel<uint16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t *)off,
-                       (const uint16_t *)logit, ref, sc, rows, M, L, P, loc, prob);
+  const bool vec = prologue_vec_ok(off, off_ld, logit, logit_ld, L * P, dtype) && ((uintptr_t)loc % 16) == 0 &&
+                   ((uintptr_t)prob % 16) == 0;
+#define SNIPPER_PROLOGUE_FWD(T, V, CL, CP)                                                                      \
+  hipLaunchKernelGGL((prologue_fwd_kernel<T, V, CL, CP>), grid, dim3(256), 0, (hipStream_t)stream, (const T *)off, \
+                     off_ld, (const T *)logit, logit_ld, ref, sc, rows, M, L, P, loc, prob)
+#define SNIPPER_PROLOGUE_FWD_T(T)                                            \
+  do {                                                                       \
+    if (vec && L == 3 && P == 4) SNIPPER_PROLOGUE_FWD(T, true, 3, 4);        \
+    else if (vec && L == 4 && P == 4) SNIPPER_PROLOGUE_FWD(T, true, 4, 4);   \
+    else SNIPPER_PROLOGUE_FWD(T, false, 0, 0);                               \
+  } while (0)
+  if (dtype == 0) SNIPPER_PROLOGUE_FWD_T(float);
+  else if (dtype == 1) SNIPPER_PROLOGUE_FWD_T(uint16_t);
   else return SNIPPER_E_UNSUPPORTED;
+#undef SNIPPER_PROLOGUE_FWD_T
+#undef SNIPPER_PROLOGUE_FWD
   return launch_status();
 }
 
 int snipper_msda_prologue_backward(void *stream, const float *grad_loc, const float *grad_prob, const float *prob,
                                    const float *inv_w, const float *inv_h, long long rows, int M, int L, int P,
-                                   void *grad_off, void *grad_logit, int dtype, float *grad_ref) {
+                                   void *grad_off, long long grad_off_ld, void *grad_logit, long long grad_logit_ld,
+                                   int dtype, float *grad_ref) {
   if (!grad_loc || !grad_prob || !prob || !grad_off || !grad_logit) return SNIPPER_E_NULL;
   if (rows <= 0 || M <= 0 || L <= 0 || P <= 0 || L > kPrologueMaxL || L * P > kPrologueMaxLP) return SNIPPER_E_SHAPE;
+  if (grad_off_ld < (long long)M * L * P * 2 || grad_logit_ld < (long long)M * L * P) return SNIPPER_E_SHAPE;
   if (grad_ref && (M > 64 || (M & (M - 1)))) return SNIPPER_E_SHAPE;
   LevelScale sc{};
   if (int rc = make_level_scale(inv_w, inv_h, L, &sc)) return rc;
   const dim3 grid((unsigned)((rows + 255) / 256));
-  if (dtype == 0)
-    hipLaunchKernelGGL(prologue_bwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, grad_loc, grad_prob, prob,
-                       sc, rows, M, L, P, (float *)grad_off, (float *)grad_logit, grad_ref);
-  else if (dtype == 1)
-    hipLaunchKernelGGL(prologue_bwd_kernel<uint16_t>, grid, dim3(256), 0, (hipStream_t)stream, grad_loc, grad_prob, prob,
-                       sc, rows, M, L, P, (uint16_t *)grad_off, (uint16_t *)grad_logit, grad_ref);
+  const bool vec = prologue_vec_ok(grad_off, grad_off_ld, grad_logit, grad_logit_ld, L * P, dtype) &&
+                   (((uintptr_t)grad_loc | (uintptr_t)grad_prob | (uintptr_t)prob) % 16) == 0;
+#define SNIPPER_PROLOGUE_BWD(T, V, CL, CP)                                                                        \
+  hipLaunchKernelGGL((prologue_bwd_kernel<T, V, CL, CP>), grid, dim3(256), 0, (hipStream_t)stream, grad_loc,       \
+                     grad_prob, prob, sc, rows, M, L, P, (T *)grad_off, grad_off_ld, (T *)grad_logit, grad_logit_ld, \
+                     grad_ref)
+#define SNIPPER_PROLOGUE_BWD_T(T)                                            \
+  do {                                                                       \
+    if (vec && L == 3 && P == 4) SNIPPER_PROLOGUE_BWD(T, true, 3, 4);        \
+    else if (vec && L == 4 && P == 4) SNIPPER_PROLOGUE_BWD(T, true, 4, 4);   \
+    else SNIPPER_PROLOGUE_BWD(T, false, 0, 0);                               \
+  } while (0)
+  if (dtype == 0) SNIPPER_PROLOGUE_BWD_T(float);
+  else if (dtype == 1) SNIPPER_PROLOGUE_BWD_T(uint16_t);
   else return SNIPPER_E_UNSUPPORTED;
+#undef SNIPPER_PROLOGUE_BWD_T
+#undef SNIPPER_PROLOGUE_BWD
   return launch_status();
 }
 

@@ -91,29 +91,46 @@ template <typename T> __device__ __forceinline__ void st_scalar(T *p, float v);
 template <> __device__ __forceinline__ void st_scalar<float>(float *p, float v) { *p = v; }
 template <> __device__ __forceinline__ void st_scalar<uint16_t>(uint16_t *p, float v) { *p = f32_to_bf16_bits(v); }
 
-// one thread per row (n, t, q, m):  loc = ref + off * (1/W_l, 1/H_l),  prob = softmax(logits)
-template <typename TI>
-__global__ __launch_bounds__(256) void prologue_fwd_kernel(const TI *__restrict__ off, const TI *__restrict__ logit,
+// One thread per row (n, t, q, m):  loc = ref + off * (1/W_l, 1/H_l),  prob = softmax(logits).
+// off / logit are addressed per QUERY with leading dimensions (elements): row (q, m) reads off + q * off_ld + m * 2LP
+// and logit + q * logit_ld + m * LP, so both may be column slices of one merged projection output.  VEC: 4-element
+// vector accesses (LP % 4 == 0 and 4-element aligned slices); otherwise scalar.
+// CL / CP > 0 fix L and P at compile time (every loop bound and level index folds: registers only, no scratch);
+// CL = 0 takes them from the arguments.
+template <typename TI, bool VEC, int CL, int CP>
+__global__ __launch_bounds__(256) void prologue_fwd_kernel(const TI *__restrict__ off, long long off_ld,
+                                                           const TI *__restrict__ logit, long long logit_ld,
                                                            const float *__restrict__ ref, LevelScale sc,
-                                                           long long rows, int M, int L, int P,
+                                                           long long rows, int M, int L_rt, int P_rt,
                                                            float *__restrict__ loc, float *__restrict__ prob) {
   const long long row = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (row >= rows) return;
+  const int L = CL > 0 ? CL : L_rt, P = CL > 0 ? CP : P_rt;
   const int LP = L * P;
-  const TI *o = off + row * LP * 2;
-  const TI *g = logit + row * LP;
-  const float *r = ref + (row / M) * L * 2;
+  const long long q = row / M;
+  const int m = (int)(row - q * M);
+  const TI *o = off + q * off_ld + (long long)m * LP * 2;
+  const TI *g = logit + q * logit_ld + (long long)m * LP;
+  const float *r = ref + q * L * 2;
   float *lo = loc + row * LP * 2;
   float *pr = prob + row * LP;
-  float z[kPrologueMaxLP];
+  float z[kPrologueMaxLP], ov[2 * kPrologueMaxLP];
+  if (VEC) {
+#pragma unroll
+    for (int i = 0; i < kPrologueMaxLP / 4; ++i)
+      if (i * 4 < LP) { float t[4]; Vec4IO<TI>::ld(g + i * 4, t); z[4 * i] = t[0]; z[4 * i + 1] = t[1]; z[4 * i + 2] = t[2]; z[4 * i + 3] = t[3]; }
+#pragma unroll
+    for (int i = 0; i < kPrologueMaxLP / 2; ++i)
+      if (i * 4 < 2 * LP) { float t[4]; Vec4IO<TI>::ld(o + i * 4, t); ov[4 * i] = t[0]; ov[4 * i + 1] = t[1]; ov[4 * i + 2] = t[2]; ov[4 * i + 3] = t[3]; }
+  } else {
+#pragma unroll
+    for (int i = 0; i < kPrologueMaxLP; ++i)
+      if (i < LP) { z[i] = ld_scalar<TI>(g + i); ov[2 * i] = ld_scalar<TI>(o + 2 * i); ov[2 * i + 1] = ld_scalar<TI>(o + 2 * i + 1); }
+  }
   float zmax = -INFINITY;
 #pragma unroll
-  for (int i = 0; i < kPrologueMaxLP; ++i) {
-    if (i < LP) {
-      z[i] = ld_scalar<TI>(g + i);
-      zmax = fmaxf(zmax, z[i]);
-    }
-  }
+  for (int i = 0; i < kPrologueMaxLP; ++i)
+    if (i < LP) zmax = fmaxf(zmax, z[i]);
   float sum = 0.f;
 #pragma unroll
   for (int i = 0; i < kPrologueMaxLP; ++i) {
@@ -127,36 +144,71 @@ __global__ __launch_bounds__(256) void prologue_fwd_kernel(const TI *__restrict_
   for (int i = 0; i < kPrologueMaxLP; ++i) {
     if (i < LP) {
       const int l = i / P;
-      pr[i] = z[i] * inv;
-      lo[2 * i] = fmaf(ld_scalar<TI>(o + 2 * i), sc.inv_w[l], r[2 * l]);
-      lo[2 * i + 1] = fmaf(ld_scalar<TI>(o + 2 * i + 1), sc.inv_h[l], r[2 * l + 1]);
+      z[i] *= inv;
+      ov[2 * i] = fmaf(ov[2 * i], sc.inv_w[l], r[2 * l]);
+      ov[2 * i + 1] = fmaf(ov[2 * i + 1], sc.inv_h[l], r[2 * l + 1]);
     }
+  }
+  if (VEC) {
+#pragma unroll
+    for (int i = 0; i < kPrologueMaxLP / 4; ++i)
+      if (i * 4 < LP) *reinterpret_cast<float4 *>(pr + 4 * i) = make_float4(z[4 * i], z[4 * i + 1], z[4 * i + 2], z[4 * i + 3]);
+#pragma unroll
+    for (int i = 0; i < kPrologueMaxLP / 2; ++i)
+      if (i * 4 < 2 * LP) *reinterpret_cast<float4 *>(lo + 4 * i) = make_float4(ov[4 * i], ov[4 * i + 1], ov[4 * i + 2], ov[4 * i + 3]);
+  } else {
+#pragma unroll
+    for (int i = 0; i < kPrologueMaxLP; ++i)
+      if (i < LP) { pr[i] = z[i]; lo[2 * i] = ov[2 * i]; lo[2 * i + 1] = ov[2 * i + 1]; }
   }
 }
 
 // grad_off = grad_loc * (1/W, 1/H);  grad_logit = prob * (grad_prob - <prob, grad_prob>);
-// grad_ref[n,t,q,l,:] = sum over heads and points of grad_loc   (M a power of two <= 64, rows of a query adjacent)
-template <typename TI>
+// grad_ref[n,t,q,l,:] = sum over heads and points of grad_loc   (M a power of two <= 64, rows of a query adjacent).
+// goff / glogit use the same per-query leading dimensions as the forward's inputs.
+template <typename TI, bool VEC, int CL, int CP>
 __global__ __launch_bounds__(256) void prologue_bwd_kernel(const float *__restrict__ gloc, const float *__restrict__ gprob,
                                                            const float *__restrict__ prob, LevelScale sc,
-                                                           long long rows, int M, int L, int P,
-                                                           TI *__restrict__ goff, TI *__restrict__ glogit,
+                                                           long long rows, int M, int L_rt, int P_rt,
+                                                           TI *__restrict__ goff, long long goff_ld,
+                                                           TI *__restrict__ glogit, long long glogit_ld,
                                                            float *__restrict__ gref /* or nullptr */) {
   const long long row = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = row < rows;
   const long long rr = live ? row : 0;
+  const int L = CL > 0 ? CL : L_rt, P = CL > 0 ? CP : P_rt;
   const int LP = L * P;
+  const long long q = rr / M;
+  const int m = (int)(rr - q * M);
   const float *gl = gloc + rr * LP * 2, *gp = gprob + rr * LP, *pr = prob + rr * LP;
-  float dotp = 0.f;
-  float p[kPrologueMaxLP], g[kPrologueMaxLP];
+  TI *go = goff + q * goff_ld + (long long)m * LP * 2;
+  TI *gg = glogit + q * glogit_ld + (long long)m * LP;
+  float p[kPrologueMaxLP], g[kPrologueMaxLP], gx[2 * kPrologueMaxLP];
+  if (VEC) {
 #pragma unroll
-  for (int i = 0; i < kPrologueMaxLP; ++i) {
-    if (i < LP) {
-      p[i] = pr[i];
-      g[i] = gp[i];
-      dotp = fmaf(p[i], g[i], dotp);
+    for (int i = 0; i < kPrologueMaxLP / 4; ++i) {
+      if (i * 4 < LP) {
+        const float4 a = *reinterpret_cast<const float4 *>(pr + 4 * i), b = *reinterpret_cast<const float4 *>(gp + 4 * i);
+        p[4 * i] = a.x; p[4 * i + 1] = a.y; p[4 * i + 2] = a.z; p[4 * i + 3] = a.w;
+        g[4 * i] = b.x; g[4 * i + 1] = b.y; g[4 * i + 2] = b.z; g[4 * i + 3] = b.w;
+      }
     }
+#pragma unroll
+    for (int i = 0; i < kPrologueMaxLP / 2; ++i) {
+      if (i * 4 < 2 * LP) {
+        const float4 a = *reinterpret_cast<const float4 *>(gl + 4 * i);
+        gx[4 * i] = a.x; gx[4 * i + 1] = a.y; gx[4 * i + 2] = a.z; gx[4 * i + 3] = a.w;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < kPrologueMaxLP; ++i)
+      if (i < LP) { p[i] = pr[i]; g[i] = gp[i]; gx[2 * i] = gl[2 * i]; gx[2 * i + 1] = gl[2 * i + 1]; }
   }
+  float dotp = 0.f;
+#pragma unroll
+  for (int i = 0; i < kPrologueMaxLP; ++i)
+    if (i < LP) dotp = fmaf(p[i], g[i], dotp);
   float rx[kPrologueMaxL], ry[kPrologueMaxL];
 #pragma unroll
   for (int l = 0; l < kPrologueMaxL; ++l) rx[l] = ry[l] = 0.f;
@@ -164,16 +216,27 @@ __global__ __launch_bounds__(256) void prologue_bwd_kernel(const float *__restri
   for (int i = 0; i < kPrologueMaxLP; ++i) {
     if (i < LP) {
       const int l = i / P;
-      const float gx = gl[2 * i], gy = gl[2 * i + 1];
-      if (live) {
-        st_scalar<TI>(glogit + rr * LP + i, p[i] * (g[i] - dotp));
-        st_scalar<TI>(goff + rr * LP * 2 + 2 * i, gx * sc.inv_w[l]);
-        st_scalar<TI>(goff + rr * LP * 2 + 2 * i + 1, gy * sc.inv_h[l]);
-      }
 #pragma unroll
       for (int ll = 0; ll < kPrologueMaxL; ++ll) {
-        if (ll == l) { rx[ll] += live ? gx : 0.f; ry[ll] += live ? gy : 0.f; }
+        if (ll == l) { rx[ll] += live ? gx[2 * i] : 0.f; ry[ll] += live ? gx[2 * i + 1] : 0.f; }
       }
+      g[i] = p[i] * (g[i] - dotp);
+      gx[2 * i] *= sc.inv_w[l];
+      gx[2 * i + 1] *= sc.inv_h[l];
+    }
+  }
+  if (live) {
+    if (VEC) {
+#pragma unroll
+      for (int i = 0; i < kPrologueMaxLP / 4; ++i)
+        if (i * 4 < LP) { const float t[4] = {g[4 * i], g[4 * i + 1], g[4 * i + 2], g[4 * i + 3]}; Vec4IO<TI>::st(gg + 4 * i, t); }
+#pragma unroll
+      for (int i = 0; i < kPrologueMaxLP / 2; ++i)
+        if (i * 4 < 2 * LP) { const float t[4] = {gx[4 * i], gx[4 * i + 1], gx[4 * i + 2], gx[4 * i + 3]}; Vec4IO<TI>::st(go + 4 * i, t); }
+    } else {
+#pragma unroll
+      for (int i = 0; i < kPrologueMaxLP; ++i)
+        if (i < LP) { st_scalar<TI>(gg + i, g[i]); st_scalar<TI>(go + 2 * i, gx[2 * i]); st_scalar<TI>(go + 2 * i + 1, gx[2 * i + 1]); }
     }
   }
   if (gref) {
@@ -185,9 +248,9 @@ __global__ __launch_bounds__(256) void prologue_bwd_kernel(const float *__restri
           ax += __shfl_xor(ax, o, 64);
           ay += __shfl_xor(ay, o, 64);
         }
-        if (live && (row % M) == 0) {
-          gref[(row / M) * L * 2 + 2 * l] = ax;
-          gref[(row / M) * L * 2 + 2 * l + 1] = ay;
+        if (live && m == 0) {
+          gref[q * L * 2 + 2 * l] = ax;
+          gref[q * L * 2 + 2 * l + 1] = ay;
         }
       }
     }

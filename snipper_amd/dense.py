@@ -158,3 +158,23 @@ def big_linear(x: torch.Tensor, lin: torch.nn.Linear, relu: bool = False) -> tor
         return _BigLinear.apply(x, lin.weight, lin.bias, relu)
     y = lin(x)
     return torch.relu(y) if relu else y
+
+
+def big_linear_merged(x: torch.Tensor, lins) -> Optional[torch.Tensor]:
+    """``cat([lin(x) for lin in lins], -1)`` as ONE projection (x is read once, one data-gradient GEMM, one
+    weight-gradient launch) when the conditions of ``big_linear`` hold; ``None`` otherwise (the caller then evaluates
+    the Linears one by one)."""
+    twin = getattr(x, "_snipper_bf16", None)
+    if twin is not None and twin.shape == x.shape and twin.device == x.device:
+        x = twin
+    rows = x.numel() // max(1, x.shape[-1])
+    in_bf16 = x.dtype == torch.bfloat16 or (torch.is_autocast_enabled('cuda') and
+                                             torch.get_autocast_dtype('cuda') == torch.bfloat16)
+    k = lins[0].in_features
+    if not (x.is_cuda and in_bf16 and rows >= BIG_LINEAR_MIN_ROWS and k % 64 == 0 and
+            x.dtype in (torch.bfloat16, torch.float32) and
+            all(l.in_features == k and l.out_features % 8 == 0 and l.bias is not None for l in lins)):
+        return None
+    weight = torch.cat([l.weight for l in lins], 0)
+    bias = torch.cat([l.bias for l in lins], 0)
+    return _BigLinear.apply(x, weight, bias, False)

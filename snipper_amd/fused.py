@@ -65,49 +65,75 @@ class TemporalMix(Function):
         return g, None, None
 
 
+def _query_rows(t: torch.Tensor, width: int):
+    """``t`` [..., width] as (tensor, leading dimension in elements): a view whose rows are evenly strided and whose
+    last dim is contiguous is taken as is (e.g. a column slice of a merged projection); anything else is copied."""
+    t2 = t.reshape(-1, width) if t.dim() != 2 else t
+    if t2.stride(1) != 1 or (t2.shape[0] > 1 and t2.stride(0) < width):
+        t2 = t2.contiguous()
+    return t2, (t2.stride(0) if t2.shape[0] > 1 else width)
+
+
 class MSDAPrologue(Function):
     """(raw offsets, raw logits, reference points) -> (sampling locations, attention probabilities).
 
-    off [..., M*L*P*2], logit [..., M*L*P] (f32 / bf16), ref [..., L, 2] float32 (leading dims = those of
-    off), hw: host list of (H, W).  Returns loc [rows, L, P, 2] and prob [rows, L, P] as float32 with
-    rows = prod(leading dims) * M."""
+    off [..., M*L*P*2], logit [..., M*L*P] (f32 / bf16), ref [..., L, 2] float32 (leading dims = those of off), hw:
+    host list of (H, W).  Returns loc [rows, L, P, 2] and prob [rows, L, P] as float32 with rows = prod(leading dims)
+    * M.  With ``logit=None``, ``off`` is the output [..., M*L*P*3] of ONE merged projection (offset columns first,
+    then logits): the kernels address both halves in place and the backward returns one dense gradient for it."""
 
     @staticmethod
     def forward(ctx, off, logit, ref, hw, M, L, P):
-        off, logit = off.contiguous(), logit.contiguous()
+        if logit is None:                       # merged input: [..., M*L*P*2 | M*L*P] in one tensor
+            both, ld = _query_rows(off, M * L * P * 3)
+            off2, logit2, off_ld, logit_ld = both[:, :M * L * P * 2], both[:, M * L * P * 2:], ld, ld
+            off_shape, logit_shape = off.shape, None
+        else:
+            off_shape, logit_shape = off.shape, logit.shape
+            off2, off_ld = _query_rows(off, M * L * P * 2)
+            logit2, logit_ld = _query_rows(logit, M * L * P)
         ref = ref.contiguous().float()
-        rows = off.numel() // (L * P * 2)
+        rows = off2.shape[0] * M
         loc = torch.empty((rows, L, P, 2), dtype=torch.float32, device=off.device)
         prob = torch.empty((rows, L, P), dtype=torch.float32, device=off.device)
         inv_w, inv_h = _farray([1.0 / w for h, w in hw]), _farray([1.0 / h for h, w in hw])
         with torch.cuda.device(off.device):
             rc = _lib.load().snipper_msda_prologue_forward(
-                _stream(off.device), off.data_ptr(), logit.data_ptr(), _DT[off.dtype], ref.data_ptr(),
-                ctypes.cast(inv_w, ctypes.c_void_p), ctypes.cast(inv_h, ctypes.c_void_p), rows, M, L, P,
+                _stream(off.device), off2.data_ptr(), off_ld, logit2.data_ptr(), logit_ld, _DT[off.dtype],
+                ref.data_ptr(), ctypes.cast(inv_w, ctypes.c_void_p), ctypes.cast(inv_h, ctypes.c_void_p), rows, M, L, P,
                 loc.data_ptr(), prob.data_ptr())
         _lib.check(rc, "snipper_msda_prologue_forward")
         ctx.save_for_backward(prob)
-        ctx.meta = (hw, M, L, P, off.dtype, off.shape, logit.shape, ref.shape, ctx.needs_input_grad[2])
+        merged = logit is None
+        ctx.meta = (hw, M, L, P, off.dtype, off_shape, logit_shape, ref.shape, ctx.needs_input_grad[2], merged)
         return loc, prob
 
     @staticmethod
     def backward(ctx, grad_loc, grad_prob):
         (prob,) = ctx.saved_tensors
-        hw, M, L, P, dtype, off_shape, logit_shape, ref_shape, need_ref = ctx.meta
+        hw, M, L, P, dtype, off_shape, logit_shape, ref_shape, need_ref, merged = ctx.meta
         rows = prob.shape[0]
+        nq, w_off, w_logit = rows // M, M * L * P * 2, M * L * P
         grad_loc = grad_loc.contiguous().float() if grad_loc is not None else torch.zeros(rows, L, P, 2, device=prob.device)
         grad_prob = grad_prob.contiguous().float() if grad_prob is not None else torch.zeros_like(prob)
-        g_off = torch.empty(off_shape, dtype=dtype, device=prob.device)
-        g_logit = torch.empty(logit_shape, dtype=dtype, device=prob.device)
+        if merged:
+            buf = torch.empty((nq, w_off + w_logit), dtype=dtype, device=prob.device)
+            g_off, g_logit, ld_o, ld_l = buf[:, :w_off], buf[:, w_off:], w_off + w_logit, w_off + w_logit
+        else:
+            g_off = torch.empty((nq, w_off), dtype=dtype, device=prob.device)
+            g_logit = torch.empty((nq, w_logit), dtype=dtype, device=prob.device)
+            ld_o, ld_l = w_off, w_logit
         g_ref = torch.empty(ref_shape, dtype=torch.float32, device=prob.device) if need_ref else None
         inv_w, inv_h = _farray([1.0 / w for h, w in hw]), _farray([1.0 / h for h, w in hw])
         with torch.cuda.device(prob.device):
             rc = _lib.load().snipper_msda_prologue_backward(
                 _stream(prob.device), grad_loc.data_ptr(), grad_prob.data_ptr(), prob.data_ptr(),
                 ctypes.cast(inv_w, ctypes.c_void_p), ctypes.cast(inv_h, ctypes.c_void_p), rows, M, L, P,
-                g_off.data_ptr(), g_logit.data_ptr(), _DT[dtype], g_ref.data_ptr() if g_ref is not None else None)
+                g_off.data_ptr(), ld_o, g_logit.data_ptr(), ld_l, _DT[dtype], g_ref.data_ptr() if g_ref is not None else None)
         _lib.check(rc, "snipper_msda_prologue_backward")
-        return g_off, g_logit, g_ref, None, None, None, None
+        if merged:
+            return buf.view(off_shape), None, g_ref, None, None, None, None
+        return g_off.view(off_shape), g_logit.view(logit_shape), g_ref, None, None, None, None
 
 
 _dropout_calls = 0

@@ -32,7 +32,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from .dense import big_linear
+from .dense import big_linear, big_linear_merged
 from .ms_deform_attn_func import MSDeformAttnFunction, ms_deform_attn_core_pytorch
 
 
@@ -171,12 +171,19 @@ class MSDeformAttn(nn.Module):
         N, T1, Lq, C = query.shape
         T2, S = value.shape[1], value.shape[2]
         M, L, P = self.n_heads, self.n_levels, self.n_points
-        off_raw = big_linear(query, self.sampling_offsets[0])                       # [N,T1,Lq, M*L*P*2]
-        logit_raw = big_linear(query, self.attention_weights[0])                    # [N,T1,Lq, M*L*P]
         fuse = hw is not None and self._fusable(query, ref, mask)
+        # offsets and logits are two Linears of the same query: one merged projection when the fused prologue (which
+        # reads both halves in place) follows
+        raw = big_linear_merged(query, [self.sampling_offsets[0], self.attention_weights[0]]) if fuse else None
+        if raw is None:
+            off_raw = big_linear(query, self.sampling_offsets[0])                   # [N,T1,Lq, M*L*P*2]
+            logit_raw = big_linear(query, self.attention_weights[0])                # [N,T1,Lq, M*L*P]
         if fuse:
             from .fused import MSDAPrologue, TemporalMix
-            loc, prob = MSDAPrologue.apply(off_raw, logit_raw, ref.expand(N, T1, Lq, L, 2), hw, M, L, P)
+            if raw is not None:
+                loc, prob = MSDAPrologue.apply(raw, None, ref.expand(N, T1, Lq, L, 2), hw, M, L, P)
+            else:
+                loc, prob = MSDAPrologue.apply(off_raw, logit_raw, ref.expand(N, T1, Lq, L, 2), hw, M, L, P)
             loc, prob = loc.view(N, T1, Lq, M, L, P, 2), prob.view(N, T1, Lq, M, L, P)
         else:
             off = off_raw.view(N, T1, Lq, M, L, P, 2)

@@ -154,3 +154,24 @@ def test_add_dropout_layernorm_eval_matches_layer_norm():
     assert torch.allclose(y, norm(x + z), atol=2e-5, rtol=1e-5)
     y = add_dropout_layer_norm(x, None, norm, 0.1, True)[0]
     assert torch.allclose(y, norm(x), atol=2e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_prologue_merged_input_matches_separate(dtype):
+    """The merged-projection form (one tensor, offsets then logits) gives the same locations / probabilities and,
+    in the backward, one dense gradient equal to the concatenation of the separate ones."""
+    g = torch.Generator().manual_seed(11)
+    M, L, P, nq = 8, 3, 4, 777
+    hw = [(19, 25), (10, 13), (5, 7)]
+    raw = torch.randn(nq, M * L * P * 3, generator=g).to(DEV).to(dtype).requires_grad_(True)
+    ref = torch.rand(nq, L, 2, generator=g).to(DEV).requires_grad_(True)
+    loc, prob = MSDAPrologue.apply(raw, None, ref, hw, M, L, P)
+    off = raw.detach()[:, :M * L * P * 2].contiguous().requires_grad_(True)
+    logit = raw.detach()[:, M * L * P * 2:].contiguous().requires_grad_(True)
+    ref2 = ref.detach().clone().requires_grad_(True)
+    loc2, prob2 = MSDAPrologue.apply(off, logit, ref2, hw, M, L, P)
+    assert torch.equal(loc, loc2) and torch.equal(prob, prob2)
+    gl, gp = torch.randn(loc.shape, generator=g).to(DEV), torch.randn(prob.shape, generator=g).to(DEV)
+    graw, gref = torch.autograd.grad((loc, prob), (raw, ref), (gl, gp))
+    goff, glogit, gref2 = torch.autograd.grad((loc2, prob2), (off, logit, ref2), (gl, gp))
+    assert torch.equal(graw, torch.cat([goff, glogit], 1)) and torch.equal(gref, gref2)
