@@ -24,10 +24,19 @@ extern "C" {
  * X, W, R, Y: bfloat16 bits (uint16_t); bias: float32 or NULL; R: NULL for no residual.
  * ldx / ldr / ldy: row strides in ELEMENTS (>= K / N / N).  Requirements: K % 64 == 0, N % 4 == 0,
  * X/W rows 16-byte aligned (ldx % 8 == 0), Y/R rows 8-byte aligned (ldy, ldr % 4 == 0).
- * Accumulation in float32, one rounding to bf16 at the end. */
+ * Accumulation in float32, one rounding to bf16 at the end.
+ * dropout_p > 0 applies inverted dropout AFTER the activation in the same epilogue (the FFN's
+ * ``dropout(relu(linear1(x)))``, models/deformable_transformer.py:196): element (m, n) is kept iff a counter-based
+ * hash of (seed, m * N + n) is >= p * 2^32; kept values are scaled by 1 / (1 - p).  M * N < 2^32 then. */
 int snipper_linear_bf16(void *stream, const uint16_t *X, long long ldx, const uint16_t *W,
                         const float *bias, const uint16_t *R, long long ldr, uint16_t *Y, long long ldy,
-                        int M, int N, int K, int relu);
+                        int M, int N, int K, int relu, float dropout_p, uint64_t seed);
+
+/* Backward of the (ReLU -> dropout) epilogue above from the layer's OUTPUT alone: a kept, active element has y > 0,
+ * a dropped or inactive one y == 0, so grad_pre = y > 0 ? grad_y / (1 - p) : 0 (p = 0: plain ReLU backward).
+ * bf16 bits, n % 8 == 0, 16-byte aligned. */
+int snipper_relu_dropout_backward_bf16(void *stream, const uint16_t *grad_y, const uint16_t *y, uint16_t *grad_pre,
+                                       long long n, float dropout_p);
 
 /* Weight and bias gradient of the same layers (csrc/wgrad_bf16.cuh):
  *   dW[N,Kc] (+)= scale[n] * sum_m G[m,n] * X[m,kc]      db[N] (+)= sum_m G[m,n]

@@ -49,7 +49,9 @@ EXPORTS = {
     "snipper_conv3x3_bf16": ([c_void_p] * 5 + [c_int] * 7, c_int),
     "snipper_lsap_f32": ([c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p], c_int),
     "snipper_linear_bf16": ([c_void_p, c_void_p, ctypes.c_longlong, c_void_p, c_void_p, c_void_p, ctypes.c_longlong,
-                             c_void_p, ctypes.c_longlong, c_int, c_int, c_int, c_int], c_int),
+                             c_void_p, ctypes.c_longlong, c_int, c_int, c_int, c_int, ctypes.c_float,
+                             ctypes.c_uint64], c_int),
+    "snipper_relu_dropout_backward_bf16": ([c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, ctypes.c_float], c_int),
 }
 
 ABI_VERSION = 1

@@ -36,7 +36,18 @@ struct GemmArgs {
   const uint16_t *R; long long ldr;      // [M][N] residual or nullptr
   uint16_t *Y; long long ldy;            // [M][N]
   int M, N, K;
+  float drop_p;                          // dropout after the activation (0 = none); element index m * N + n
+  uint32_t seed_lo, seed_hi;
 };
+
+// counter-based hash RNG shared with csrc/ln_fused.cuh (same constants): keep iff rand >= p * 2^32
+__device__ __forceinline__ uint32_t gemm_hash(uint32_t v) {
+  v ^= v >> 16; v *= 0x7feb352du; v ^= v >> 15; v *= 0x846ca68bu; v ^= v >> 16;
+  return v;
+}
+__device__ __forceinline__ uint32_t gemm_rand(uint32_t idx, uint32_t seed_lo, uint32_t seed_hi) {
+  return gemm_hash(gemm_hash(idx + seed_lo * 0x9e3779b9u) ^ seed_hi);
+}
 
 __device__ __forceinline__ float gemm_bf16_to_f32(uint16_t b) { return __uint_as_float((unsigned)b << 16); }
 __device__ __forceinline__ unsigned gemm_pack2(float a, float b) {
@@ -107,6 +118,9 @@ __global__ __launch_bounds__(kGemmThreads) void linear_bf16_kernel(GemmArgs g) {
   }
 
   // epilogue: lane holds n = nb + 4*(lane>>4) + r (r = 0..3) of output row m = mb + (lane & 15)
+  const bool drop = g.drop_p > 0.f;
+  const float keep_scale = drop ? 1.f / (1.f - g.drop_p) : 1.f;
+  const uint32_t thresh = (uint32_t)fminf(g.drop_p * 4294967296.f, 4294967040.f);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int n = n0 + wn * 64 + i * 16 + (lane >> 4) * 4;
@@ -124,12 +138,38 @@ __global__ __launch_bounds__(kGemmThreads) void linear_bf16_kernel(GemmArgs g) {
         v.z += __uint_as_float(r.y << 16); v.w += __uint_as_float(r.y & 0xffff0000u);
       }
       if (RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      if (drop) {
+        const uint32_t e = (uint32_t)m * (uint32_t)g.N + (uint32_t)n;
+        v.x = gemm_rand(e, g.seed_lo, g.seed_hi) >= thresh ? v.x * keep_scale : 0.f;
+        v.y = gemm_rand(e + 1, g.seed_lo, g.seed_hi) >= thresh ? v.y * keep_scale : 0.f;
+        v.z = gemm_rand(e + 2, g.seed_lo, g.seed_hi) >= thresh ? v.z * keep_scale : 0.f;
+        v.w = gemm_rand(e + 3, g.seed_lo, g.seed_hi) >= thresh ? v.w * keep_scale : 0.f;
+      }
       uint2 o;
       o.x = gemm_pack2(v.x, v.y);
       o.y = gemm_pack2(v.z, v.w);
       *reinterpret_cast<uint2 *>(g.Y + (long long)m * g.ldy + n) = o;
     }
   }
+}
+
+// Backward of (ReLU -> dropout) given only the layer's OUTPUT y: a kept, active element has y > 0, a dropped or
+// inactive one y == 0, so  dL/dpre = y > 0 ? g * scale : 0  (scale = 1 / (1 - p); p = 0: plain ReLU backward).
+// bf16 in / out, 8 elements per thread.
+__global__ __launch_bounds__(256) void relu_dropout_bwd_kernel(const uint16_t *__restrict__ gy, const uint16_t *__restrict__ y,
+                                                               uint16_t *__restrict__ out, long long n8, float scale) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n8) return;
+  const gemm_u32x4 a = reinterpret_cast<const gemm_u32x4 *>(gy)[i], b = reinterpret_cast<const gemm_u32x4 *>(y)[i];
+  const unsigned av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w};
+  unsigned o[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float g0 = __uint_as_float(av[k] << 16) * scale, g1 = __uint_as_float(av[k] & 0xffff0000u) * scale;
+    const float y0 = __uint_as_float(bv[k] << 16), y1 = __uint_as_float(bv[k] & 0xffff0000u);
+    o[k] = gemm_pack2(y0 > 0.f ? g0 : 0.f, y1 > 0.f ? g1 : 0.f);
+  }
+  reinterpret_cast<gemm_u32x4 *>(out)[i] = gemm_u32x4{o[0], o[1], o[2], o[3]};
 }
 
 // ---- 3x3 convolution, NHWC, as an implicit GEMM on the same tile machinery --------------------------------

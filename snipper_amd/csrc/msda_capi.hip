@@ -394,17 +394,29 @@ int snipper_msda_backward_bf16(void *stream, const uint16_t *grad_out, const uin
 
 int snipper_linear_bf16(void *stream, const uint16_t *X, long long ldx, const uint16_t *W,
                         const float *bias, const uint16_t *R, long long ldr, uint16_t *Y, long long ldy,
-                        int M, int N, int K, int relu) {
+                        int M, int N, int K, int relu, float dropout_p, uint64_t seed) {
   if (!X || !W || !Y) return SNIPPER_E_NULL;
   if (M <= 0 || N <= 0 || K <= 0 || K % kGemmBK || N % 4 || ldx % 8 || ldy % 4 || ldx < K || ldy < N ||
-      (R && (ldr % 4 || ldr < N)))
+      (R && (ldr % 4 || ldr < N)) || !(dropout_p >= 0.f && dropout_p < 1.f) ||
+      (dropout_p > 0.f && (long long)M * N >= (1LL << 32)))
     return SNIPPER_E_SHAPE;
-  const GemmArgs g{X, ldx, W, bias, R, ldr, Y, ldy, M, N, K};
+  const GemmArgs g{X, ldx, W, bias, R, ldr, Y, ldy, M, N, K, dropout_p, (uint32_t)seed, (uint32_t)(seed >> 32)};
   const dim3 grid((M + kGemmBM - 1) / kGemmBM, (N + kGemmBN - 1) / kGemmBN);
   if (relu)
     hipLaunchKernelGGL(linear_bf16_kernel<true>, grid, dim3(kGemmThreads), 0, (hipStream_t)stream, g);
   else
     hipLaunchKernelGGL(linear_bf16_kernel<false>, grid, dim3(kGemmThreads), 0, (hipStream_t)stream, g);
+  return launch_status();
+}
+
+int snipper_relu_dropout_backward_bf16(void *stream, const uint16_t *grad_y, const uint16_t *y, uint16_t *grad_pre,
+                                       long long n, float dropout_p) {
+  if (!grad_y || !y || !grad_pre) return SNIPPER_E_NULL;
+  if (n <= 0 || n % 8 || !(dropout_p >= 0.f && dropout_p < 1.f)) return SNIPPER_E_SHAPE;
+  if (((uintptr_t)grad_y | (uintptr_t)y | (uintptr_t)grad_pre) & 15) return SNIPPER_E_SHAPE;
+  const long long n8 = n / 8;
+  hipLaunchKernelGGL(relu_dropout_bwd_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     grad_y, y, grad_pre, n8, 1.f / (1.f - dropout_p));
   return launch_status();
 }
 

@@ -76,10 +76,10 @@ class _FFNMixin:
 
     def _ffn(self, x, drop_a, drop_b, norm):
         if self.activation is F.relu:
-            h = big_linear(x, self.linear1, relu=True)          # ReLU in the kernel's epilogue when it applies
+            h = big_linear(x, self.linear1, relu=True, dropout=drop_a)   # ReLU + dropout in the kernel's epilogue
         else:
-            h = self.activation(big_linear(x, self.linear1))
-        y = big_linear(drop_a(h), self.linear2)
+            h = drop_a(self.activation(big_linear(x, self.linear1)))
+        y = big_linear(h, self.linear2)
         return _residual_norm(x, y, norm, drop_b)
 
 
@@ -129,7 +129,7 @@ class DeformableTransformerEncoderLayer(nn.Module, _FFNMixin):
         attended = self.self_attn(q16, reference_points, src16, spatial_shapes, level_start_index, padding_mask)
         y32, y16, _ = add_dropout_layer_norm(src32, attended, self.norm1, self.dropout1.p, self.training,
                                              want=(True, True, False))
-        h = self.dropout2(big_linear(y16, self.linear1, relu=True))
+        h = big_linear(y16, self.linear1, relu=True, dropout=self.dropout2)
         z = big_linear(h, self.linear2)
         return add_dropout_layer_norm(y32, z, self.norm2, self.dropout3.p, self.training, pos=pos16,
                                       want=(True, True, not last))

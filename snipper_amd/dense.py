@@ -9,8 +9,9 @@ from . import _lib
 
 
 def linear_bf16(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
-                residual: Optional[torch.Tensor] = None, relu: bool = False) -> torch.Tensor:
-    """act(x @ weight.T + bias + residual) on the HIP kernel.
+                residual: Optional[torch.Tensor] = None, relu: bool = False, dropout_p: float = 0.0,
+                seed: int = 0) -> torch.Tensor:
+    """dropout(act(x @ weight.T + bias + residual)) on the HIP kernel (dropout_p = 0: no dropout).
 
     x [..., K] bf16 (last dim contiguous, rows evenly strided), weight [N, K] bf16 contiguous,
     bias [N] float32 or None, residual like the output (bf16) or None  ->  [..., N] bf16.
@@ -36,7 +37,8 @@ def linear_bf16(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tens
         rc = lib.snipper_linear_bf16(
             torch.cuda.current_stream(x.device).cuda_stream, x2.data_ptr(), x2.stride(0), weight.data_ptr(),
             bias.data_ptr() if bias is not None else None, r2.data_ptr() if r2 is not None else None,
-            r2.stride(0) if r2 is not None else 0, out.data_ptr(), out.stride(0), M, N, K, int(relu))
+            r2.stride(0) if r2 is not None else 0, out.data_ptr(), out.stride(0), M, N, K, int(relu),
+            float(dropout_p), int(seed))
     _lib.check(rc, "snipper_linear_bf16")
     return out.view(*x.shape[:-1], N)
 
@@ -108,12 +110,20 @@ class _BigLinear(torch.autograd.Function):
     encoder layer's FFN (models/deformable_transformer.py:180-198)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, relu):
+    def forward(ctx, x, weight, bias, relu, dropout_p=0.0):
+        """``dropout_p`` > 0 (only together with ``relu``): inverted dropout in the same epilogue; the backward needs
+        no mask -- a kept, active element of the output is > 0, everything else is 0."""
         n_out, k_in = weight.shape
         x2 = x.reshape(-1, k_in)
         xb = x2 if x2.dtype == torch.bfloat16 else x2.to(torch.bfloat16)
         wb = weight if weight.dtype == torch.bfloat16 else weight.to(torch.bfloat16)
-        y = linear_bf16(xb, wb, None if bias is None else bias.float(), None, relu)
+        assert dropout_p == 0.0 or relu, "epilogue dropout is implemented for the ReLU layer only"
+        seed = 0
+        if dropout_p > 0.0:
+            from .fused import _next_seed
+            seed = _next_seed()
+        y = linear_bf16(xb, wb, None if bias is None else bias.float(), None, relu, dropout_p, seed)
+        ctx.drop_p = float(dropout_p)
         ctx.relu, ctx.has_bias = relu, bias is not None
         ctx.x_shape, ctx.w_dtype = x.shape, weight.dtype
         ctx.b_dtype = None if bias is None else bias.dtype
@@ -128,7 +138,7 @@ class _BigLinear(torch.autograd.Function):
             g = g.to(torch.bfloat16)
         g = g.contiguous()
         if ctx.relu:
-            g = torch.ops.aten.threshold_backward(g, y, 0)
+            g = _relu_dropout_backward(g, y, ctx.drop_p)
         dx = torch.mm(g, wb).view(ctx.x_shape) if ctx.needs_input_grad[0] else None
         dW = db = None
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
@@ -137,16 +147,31 @@ class _BigLinear(torch.autograd.Function):
                 dW = dW.to(ctx.w_dtype)
             if db is not None and db.dtype != ctx.b_dtype:
                 db = db.to(ctx.b_dtype)
-        return dx, dW, db, None
+        return dx, dW, db, None, None
+
+
+def _relu_dropout_backward(g: torch.Tensor, y: torch.Tensor, p: float) -> torch.Tensor:
+    """y > 0 ? g / (1 - p) : 0 in one pass (bf16, contiguous)."""
+    if p == 0.0 or g.numel() % 8:
+        out = torch.ops.aten.threshold_backward(g, y, 0)
+        return out if p == 0.0 else out * (1.0 / (1.0 - p))
+    out = torch.empty_like(g)
+    with torch.cuda.device(g.device):
+        rc = _lib.load().snipper_relu_dropout_backward_bf16(
+            torch.cuda.current_stream(g.device).cuda_stream, g.data_ptr(), y.data_ptr(), out.data_ptr(), g.numel(), p)
+    _lib.check(rc, "snipper_relu_dropout_backward_bf16")
+    return out
 
 
 BIG_LINEAR_MIN_ROWS = 4096
 
 
-def big_linear(x: torch.Tensor, lin: torch.nn.Linear, relu: bool = False) -> torch.Tensor:
-    """``lin(x)`` (followed by ReLU if ``relu``), routed to the hand-written kernels when ``x`` is a CUDA tensor with
-    at least BIG_LINEAR_MIN_ROWS rows that is computed in bf16 (bf16 input, or autocast to bf16); plain PyTorch
-    otherwise, with identical semantics."""
+def big_linear(x: torch.Tensor, lin: torch.nn.Linear, relu: bool = False, dropout: Optional[torch.nn.Dropout] = None
+               ) -> torch.Tensor:
+    """``dropout(relu(lin(x)))`` (each optional; dropout only with relu), routed to the hand-written kernels when
+    ``x`` is a CUDA tensor with at least BIG_LINEAR_MIN_ROWS rows that is computed in bf16 (bf16 input, or autocast to
+    bf16); plain PyTorch otherwise, with identical semantics (the random stream differs: a counter-based hash instead
+    of Philox)."""
     twin = getattr(x, "_snipper_bf16", None)      # a bf16 copy written by the kernel that produced x (same graph)
     if twin is not None and twin.shape == x.shape and twin.device == x.device:
         x = twin
@@ -155,9 +180,14 @@ def big_linear(x: torch.Tensor, lin: torch.nn.Linear, relu: bool = False) -> tor
                                              torch.get_autocast_dtype('cuda') == torch.bfloat16)
     if (x.is_cuda and in_bf16 and rows >= BIG_LINEAR_MIN_ROWS and lin.in_features % 64 == 0 and
             lin.out_features % 8 == 0 and x.dtype in (torch.bfloat16, torch.float32)):
-        return _BigLinear.apply(x, lin.weight, lin.bias, relu)
+        p = dropout.p if (dropout is not None and dropout.training and relu) else 0.0
+        if x.numel() // x.shape[-1] * lin.out_features >= 2 ** 32:
+            p = 0.0
+        y = _BigLinear.apply(x, lin.weight, lin.bias, relu, p)
+        return dropout(y) if (dropout is not None and p == 0.0) else y
     y = lin(x)
-    return torch.relu(y) if relu else y
+    y = torch.relu(y) if relu else y
+    return dropout(y) if dropout is not None else y
 
 
 def big_linear_merged(x: torch.Tensor, lins) -> Optional[torch.Tensor]:
@@ -177,4 +207,4 @@ def big_linear_merged(x: torch.Tensor, lins) -> Optional[torch.Tensor]:
         return None
     weight = torch.cat([l.weight for l in lins], 0)
     bias = torch.cat([l.bias for l in lins], 0)
-    return _BigLinear.apply(x, weight, bias, False)
+    return _BigLinear.apply(x, weight, bias, False, 0.0)

@@ -180,3 +180,31 @@ def test_big_linear_small_inputs_use_pytorch():
     with torch.autocast("cuda", dtype=torch.bfloat16):
         assert torch.equal(big_linear(x, lin), lin(x))
     assert torch.equal(big_linear(x, lin), lin(x))          # no autocast: float32 module semantics
+
+
+def test_linear_dropout_epilogue_and_backward():
+    """ReLU + dropout in the GEMM epilogue: kept elements equal the plain result / (1 - p), the kept fraction is
+    1 - p, the mask depends on the seed only, and the mask-free backward equals the explicit one."""
+    from snipper_amd.dense import _relu_dropout_backward
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(3000, 128, generator=g).to(DEV).bfloat16()
+    w = (torch.randn(256, 128, generator=g) / 11).to(DEV).bfloat16()
+    b = torch.randn(256, generator=g).to(DEV)
+    p = 0.1
+    plain = linear_bf16(x, w, b, None, True).float()
+    y1 = linear_bf16(x, w, b, None, True, p, 77).float()
+    y2 = linear_bf16(x, w, b, None, True, p, 77).float()
+    y3 = linear_bf16(x, w, b, None, True, p, 78).float()
+    assert torch.equal(y1, y2) and not torch.equal(y1, y3)
+    active = plain > 0
+    kept = (y1 > 0) & active
+    frac = kept.sum().item() / active.sum().item()
+    assert abs(frac - (1 - p)) < 0.01
+    assert torch.all(y1[~kept] == 0)
+    ref = plain / (1 - p)
+    assert torch.allclose(y1[kept], ref[kept], rtol=2e-2, atol=1e-3)      # one extra bf16 rounding
+    gy = torch.randn(3000, 256, generator=g).to(DEV).bfloat16()
+    got = _relu_dropout_backward(gy, y1.bfloat16(), p).float()
+    want = torch.where(y1 > 0, gy.float() / (1 - p), torch.zeros_like(y1))
+    assert torch.allclose(got, want, rtol=1e-2, atol=1e-3)
+    assert torch.equal(_relu_dropout_backward(gy, plain.bfloat16(), 0.0), torch.ops.aten.threshold_backward(gy, plain.bfloat16(), 0))
