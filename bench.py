@@ -412,6 +412,15 @@ def main():
         torch.cuda.synchronize()
         pr.disable()
         pstats.Stats(pr, stream=sys.stderr).sort_stats("tottime").print_stats(45)
+    if os.environ.get("SNIPPER_TORCH_PROFILE"):   # op-level GPU time with input shapes (development aid)
+        from torch.profiler import profile, ProfilerActivity
+        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
+            for i in range(2):
+                step(i)
+            torch.cuda.synchronize()
+        print(prof.key_averages(group_by_input_shape=True).table(sort_by="cuda_time_total", row_limit=400,
+                                                                   max_name_column_width=40, max_shapes_column_width=70),
+              file=sys.stderr)
     if os.environ.get("SNIPPER_ISSUE_TIME"):      # is the host or the GPU the limiter?  (development aid)
         # host time to ISSUE three steps (no synchronisation) against the time until the GPU has retired them
         torch.cuda.synchronize()

@@ -292,18 +292,42 @@ class SetCriterion(nn.Module):
         td = torch.cat([t["depth"][tgt[:, a:b]] for t, a, b in zip(targets, offsets[:-1], offsets[1:])], 1)
         per_layer = self._all_losses(logits, sk, sd, tk, td, src, batch, targets[0]["max_depth"], num_traj)
 
+        names = list(per_layer)
+        stacked = torch.stack([per_layer[n] for n in names])     # [n_names, n_dec]
         losses = {}
-        for name, v in per_layer.items():
-            losses[name] = v[-1]                                 # main output = last decoder layer
+        for j, name in enumerate(names):                          # entries are (differentiable) views of `stacked`
+            losses[name] = stacked[j, -1]                        # main output = last decoder layer
             for i in range(n_dec - 1):
-                losses[f"{name}_{i}"] = v[i]
+                losses[f"{name}_{i}"] = stacked[j, i]
+        heat = None
         if "heatmap" in self.losses:
-            losses["loss_heatmap"] = self.loss_heatmap(outputs, targets)
+            heat = losses["loss_heatmap"] = self.loss_heatmap(outputs, targets)
+        self._fast = (losses, names, stacked, heat)              # lets weighted_sum() skip ~130 scalar kernels
         indices = [(src[-1, a:b], tgt[-1, a:b]) for a, b in zip(offsets[:-1], offsets[1:])]
         return losses, indices
 
+    def _weight_matrix(self, names, n_dec, device) -> torch.Tensor:
+        """W[j, i] = weight of loss `names[j]` at decoder layer i (last row index = the main output), 0 if unweighted."""
+        key = (tuple(names), n_dec, str(device))
+        cached = getattr(self, "_wm_cache", None)
+        if cached is None or cached[0] != key:
+            rows = [[self.weight_dict.get(f"{n}_{i}", 0.0) for i in range(n_dec - 1)] + [self.weight_dict.get(n, 0.0)]
+                    for n in names]
+            cached = (key, torch.tensor(rows, dtype=torch.float32, device=device))
+            self._wm_cache = cached
+        return cached[1]
+
     def weighted_sum(self, losses: Dict[str, torch.Tensor]) -> torch.Tensor:
-        """engine.py:56: sum(loss_dict[k] * weight_dict[k] for k in loss_dict if k in weight_dict)."""
+        """engine.py:56: sum(loss_dict[k] * weight_dict[k] for k in loss_dict if k in weight_dict).  For the dictionary
+        this criterion has just returned, the same sum is one product with a cached weight matrix instead of a
+        multiply and an add per entry (66 entries with 6 decoder layers, each also a backward kernel)."""
+        fast = getattr(self, "_fast", None)
+        if fast is not None and fast[0] is losses:
+            _, names, stacked, heat = fast
+            total = (stacked * self._weight_matrix(names, stacked.shape[1], stacked.device)).sum()
+            if heat is not None and "loss_heatmap" in self.weight_dict:
+                total = total + heat * self.weight_dict["loss_heatmap"]
+            return total
         return sum(losses[k] * self.weight_dict[k] for k in losses if k in self.weight_dict)
 
 
