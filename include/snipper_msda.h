@@ -105,6 +105,24 @@ int snipper_msda_backward_f32(void *stream, const float *grad_out, const float *
  * for ANY locations; only the speed depends on how local they are.  Whenever the shape, the knobs or
  * the workspace do not qualify, the call is exactly snipper_msda_backward_f32.
  * snipper_msda_backward_workspace_bytes returns 0 when the fast path would not be taken. */
+/* bfloat16 rows at the op's two activation interfaces, float32 everything else (value, loc, attn, all gradients,
+ * all arithmetic).  Under bf16 autocast the producer of grad_out (the data gradient of the output projection) and the
+ * consumer of out (the output projection itself) hold bf16 anyway; taking / writing bf16 here is exact with respect
+ * to that pipeline and saves two cast passes and half of the row traffic.  D == 48 kernels only: any other shape
+ * returns SNIPPER_E_UNSUPPORTED (the caller casts and uses the float32 entry points).
+ *   snipper_msda_forward_f32_bf16out    : as snipper_msda_forward_f32, out [N,Lq,M*D] bfloat16
+ *   snipper_msda_backward_ws_f32_bf16in : as snipper_msda_backward_ws_f32, grad_out [N,Lq,M*D] bfloat16
+ *                                         (host_shapes / workspace may be NULL / 0: atomic kernel) */
+int snipper_msda_forward_f32_bf16out(void *stream, const float *value, const int64_t *shapes,
+                                     const int64_t *level_start, const float *loc, const float *attn,
+                                     int N, int S, int M, int D, int L, int Lq, int P, uint16_t *out);
+int snipper_msda_backward_ws_f32_bf16in(void *stream, const uint16_t *grad_out, const float *value,
+                                        const int64_t *shapes, const int64_t *level_start,
+                                        const int64_t *host_shapes, void *workspace, long long workspace_bytes,
+                                        const float *loc, const float *attn,
+                                        int N, int S, int M, int D, int L, int Lq, int P,
+                                        float *grad_value, float *grad_loc, float *grad_attn);
+
 long long snipper_msda_backward_workspace_bytes(int N, int S, int M, int D, int L, int Lq, int P,
                                                 const int64_t *host_shapes);
 int snipper_msda_backward_ws_f32(void *stream, const float *grad_out, const float *value,

@@ -106,8 +106,11 @@ class _Timed:
 
 def ms_deform_attn_forward(value: torch.Tensor, spatial_shapes: torch.Tensor,
                            level_start_index: torch.Tensor, sampling_loc: torch.Tensor,
-                           attn_weight: torch.Tensor, im2col_step: int) -> torch.Tensor:
-    """-> Tensor[N, Lq, M*D]   (ms_deform_attn_cuda.cu:20-80)"""
+                           attn_weight: torch.Tensor, im2col_step: int, out_bf16: bool = False) -> torch.Tensor:
+    """-> Tensor[N, Lq, M*D]   (ms_deform_attn_cuda.cu:20-80)
+
+    ``out_bf16`` (extension): float32 ``value``, output rows written as bfloat16 by the kernel (exactly the float32
+    result rounded once); shapes without a bf16-row kernel get the float32 result cast here."""
     _check_common([("value", value), ("spatial_shapes", spatial_shapes),
                    ("level_start_index", level_start_index), ("sampling_loc", sampling_loc),
                    ("attn_weight", attn_weight)], value, spatial_shapes, level_start_index, im2col_step)
@@ -115,16 +118,25 @@ def ms_deform_attn_forward(value: torch.Tensor, spatial_shapes: torch.Tensor,
     _require(sampling_loc.dtype == cd and attn_weight.dtype == cd,
              f"sampling_loc/attn_weight must be {cd} for {value.dtype} value")
     N, S, M, D, L, Lq, P = _dims(value, spatial_shapes, sampling_loc, attn_weight)
-    out = torch.empty((N, Lq, M * D), dtype=value.dtype, device=value.device)
     lib = _lib.load()
-    fn = getattr(lib, "snipper_msda_forward_" + _SUFFIX[value.dtype])
     dims = dict(N=N, S=S, M=M, D=D, L=L, Lq=Lq, P=P, esize=value.element_size())
+    if out_bf16 and value.dtype == torch.float32:
+        out = torch.empty((N, Lq, M * D), dtype=torch.bfloat16, device=value.device)
+        with torch.cuda.device(value.device), _Timed("fwd", dims, value.device):
+            rc = lib.snipper_msda_forward_f32_bf16out(
+                _stream(value.device), value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
+                sampling_loc.data_ptr(), attn_weight.data_ptr(), N, S, M, D, L, Lq, P, out.data_ptr())
+        if rc != _lib.E_UNSUPPORTED:
+            _lib.check(rc, "ms_deform_attn_forward")
+            return out
+    out = torch.empty((N, Lq, M * D), dtype=value.dtype, device=value.device)
+    fn = getattr(lib, "snipper_msda_forward_" + _SUFFIX[value.dtype])
     with torch.cuda.device(value.device), _Timed("fwd", dims, value.device):
         rc = fn(_stream(value.device), value.data_ptr(), spatial_shapes.data_ptr(),
                 level_start_index.data_ptr(), sampling_loc.data_ptr(), attn_weight.data_ptr(),
                 N, S, M, D, L, Lq, P, out.data_ptr())
     _lib.check(rc, "ms_deform_attn_forward")
-    return out
+    return out.to(torch.bfloat16) if (out_bf16 and value.dtype == torch.float32) else out
 
 
 def ms_deform_attn_backward(value: torch.Tensor, spatial_shapes: torch.Tensor,
@@ -145,7 +157,8 @@ def ms_deform_attn_backward(value: torch.Tensor, spatial_shapes: torch.Tensor,
     cd = _coord_dtype(value)
     _require(sampling_loc.dtype == cd and attn_weight.dtype == cd,
              f"sampling_loc/attn_weight must be {cd} for {value.dtype} value")
-    _require(grad_output.dtype == value.dtype, "grad_output dtype must match value")
+    go_bf16 = grad_output.dtype == torch.bfloat16 and value.dtype == torch.float32      # extension: bf16 rows in
+    _require(grad_output.dtype == value.dtype or go_bf16, "grad_output dtype must match value")
     N, S, M, D, L, Lq, P = _dims(value, spatial_shapes, sampling_loc, attn_weight)
     _require(grad_output.numel() == N * Lq * M * D, "grad_output shape mismatch")
     acc_dtype = torch.float32 if value.dtype == torch.bfloat16 else value.dtype
@@ -156,12 +169,23 @@ def ms_deform_attn_backward(value: torch.Tensor, spatial_shapes: torch.Tensor,
     lib = _lib.load()
     dims = dict(N=N, S=S, M=M, D=D, L=L, Lq=Lq, P=P, esize=value.element_size())
     with torch.cuda.device(value.device), _Timed("bwd", dims, value.device):
-        ws_bytes = 0
+        ws_bytes, hs_p, rc = 0, None, None
         if host_shapes is not None and value.dtype == torch.float32 and len(host_shapes) == L:
             hs = (ctypes.c_int64 * (2 * L))(*[int(v) for hw in host_shapes for v in hw])
             hs_p = ctypes.cast(hs, ctypes.c_void_p)
             ws_bytes = lib.snipper_msda_backward_workspace_bytes(N, S, M, D, L, Lq, P, hs_p)
-        if ws_bytes > 0:
+        if go_bf16:
+            workspace = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=value.device)
+            rc = lib.snipper_msda_backward_ws_f32_bf16in(
+                _stream(value.device), grad_output.data_ptr(), value.data_ptr(), spatial_shapes.data_ptr(),
+                level_start_index.data_ptr(), hs_p if ws_bytes > 0 else None, workspace.data_ptr(), ws_bytes,
+                sampling_loc.data_ptr(), attn_weight.data_ptr(), N, S, M, D, L, Lq, P,
+                grad_value.data_ptr(), grad_loc.data_ptr(), grad_attn.data_ptr())
+            if rc == _lib.E_UNSUPPORTED:                 # no bf16-row kernel for this shape: widen and go on
+                grad_output, rc = grad_output.float(), None
+        if rc is not None:
+            pass
+        elif ws_bytes > 0:
             workspace = torch.empty(ws_bytes, dtype=torch.uint8, device=value.device)
             rc = lib.snipper_msda_backward_ws_f32(
                 _stream(value.device), grad_output.data_ptr(), value.data_ptr(), spatial_shapes.data_ptr(),

@@ -24,6 +24,8 @@ EXPORTS = {
     "snipper_msda_set_param": ([c_char_p, ctypes.c_double], c_int),
     "snipper_msda_backward_workspace_bytes": ([c_int] * 7 + [c_void_p], ctypes.c_longlong),
     "snipper_msda_backward_ws_f32": ([c_void_p] * 7 + [ctypes.c_longlong] + [c_void_p] * 2 + [c_int] * 7 + [c_void_p] * 3, c_int),
+    "snipper_msda_backward_ws_f32_bf16in": ([c_void_p] * 7 + [ctypes.c_longlong] + [c_void_p] * 2 + [c_int] * 7 + [c_void_p] * 3, c_int),
+    "snipper_msda_forward_f32_bf16out": (_FWD_ARGS, c_int),
     "snipper_msda_forward_f32": (_FWD_ARGS, c_int),
     "snipper_msda_forward_f64": (_FWD_ARGS, c_int),
     "snipper_msda_forward_bf16": (_FWD_ARGS, c_int),
@@ -94,6 +96,9 @@ def load():
         raise SnipperLibraryError(f"ABI mismatch: library {got}, binding {ABI_VERSION}")
     _lib = lib
     return lib
+
+
+E_UNSUPPORTED = -3      # include/snipper_msda.h
 
 
 def check(code: int, what: str) -> None:

@@ -115,7 +115,7 @@ template <typename VT> bool d48_eligible(const CoreDims &d) {
 
 template <typename VT>
 int forward_d48(hipStream_t st, const VT *value, const int64_t *shapes, const int64_t *lsi,
-                const float *loc, const float *attn, CoreDims d, VT *out) {
+                const float *loc, const float *attn, CoreDims d, VT *out, int out_bf16 = 0) {
   constexpr int kRows = kD48Block / D48Fwd<VT>::G;
   const long long rows = (long long)d.N * d.Lq * d.M;
   const int LP = d.L * d.P;
@@ -124,17 +124,17 @@ int forward_d48(hipStream_t st, const VT *value, const int64_t *shapes, const in
   const size_t lds = (size_t)kRows * (LP * sizeof(FwdRecord) + 16);
   if (LP == 12 && d.P == 4) {
     g_last_variant = "d48_lp12";
-    hipLaunchKernelGGL((msda_fwd_d48_kernel<VT, 12>), dim3(nblk_padded), dim3(kD48Block), lds, st, value, shapes, lsi, loc, attn, d, out, nblk_padded);
+    hipLaunchKernelGGL((msda_fwd_d48_kernel<VT, 12>), dim3(nblk_padded), dim3(kD48Block), lds, st, value, shapes, lsi, loc, attn, d, out, nblk_padded, out_bf16);
   } else {
     g_last_variant = "d48";
-    hipLaunchKernelGGL((msda_fwd_d48_kernel<VT, 0>), dim3(nblk_padded), dim3(kD48Block), lds, st, value, shapes, lsi, loc, attn, d, out, nblk_padded);
+    hipLaunchKernelGGL((msda_fwd_d48_kernel<VT, 0>), dim3(nblk_padded), dim3(kD48Block), lds, st, value, shapes, lsi, loc, attn, d, out, nblk_padded, out_bf16);
   }
   return launch_status();
 }
 
 int backward_d48_f32(hipStream_t st, const float *grad_out, const float *value, const int64_t *shapes,
                      const int64_t *lsi, const float *loc, const float *attn, CoreDims d,
-                     float *grad_value, float *grad_loc, float *grad_attn) {
+                     float *grad_value, float *grad_loc, float *grad_attn, int go_bf16 = 0) {
   constexpr int kRows = kD48Block / 16;
   const long long rows = (long long)d.N * d.Lq * d.M;
   const int LP = d.L * d.P;
@@ -143,10 +143,10 @@ int backward_d48_f32(hipStream_t st, const float *grad_out, const float *value, 
   const size_t lds = (size_t)kRows * (LP * sizeof(BwdRecord) + 16);
   if (LP == 12 && d.P == 4) {
     g_last_variant = "d48_lp12";
-    hipLaunchKernelGGL((msda_bwd_d48_f32_kernel<12>), dim3(nblk_padded), dim3(kD48Block), lds, st, grad_out, value, shapes, lsi, loc, attn, d, grad_value, grad_loc, grad_attn, nblk_padded);
+    hipLaunchKernelGGL((msda_bwd_d48_f32_kernel<12>), dim3(nblk_padded), dim3(kD48Block), lds, st, grad_out, value, shapes, lsi, loc, attn, d, grad_value, grad_loc, grad_attn, nblk_padded, go_bf16);
   } else {
     g_last_variant = "d48";
-    hipLaunchKernelGGL((msda_bwd_d48_f32_kernel<0>), dim3(nblk_padded), dim3(kD48Block), lds, st, grad_out, value, shapes, lsi, loc, attn, d, grad_value, grad_loc, grad_attn, nblk_padded);
+    hipLaunchKernelGGL((msda_bwd_d48_f32_kernel<0>), dim3(nblk_padded), dim3(kD48Block), lds, st, grad_out, value, shapes, lsi, loc, attn, d, grad_value, grad_loc, grad_attn, nblk_padded, go_bf16);
   }
   return launch_status();
 }
@@ -210,7 +210,7 @@ OwnerPlan make_owner_plan(const CoreDims &d, const int64_t *hs) {
 
 int backward_d48_owner_f32(hipStream_t st, const float *grad_out, const float *value, const float *loc,
                            const float *attn, CoreDims d, OwnerPlan plan, void *workspace,
-                           float *grad_value, float *grad_loc, float *grad_attn) {
+                           float *grad_value, float *grad_loc, float *grad_attn, int go_bf16 = 0) {
   const long long nm = (long long)d.N * d.M;
   plan.bitmap = reinterpret_cast<unsigned char *>(workspace);
   hipError_t e = hipMemsetAsync(plan.bitmap, 0, (size_t)(nm * plan.bytes_per_nm), st);
@@ -223,17 +223,17 @@ int backward_d48_owner_f32(hipStream_t st, const float *grad_out, const float *v
   const int nblk_padded = (nblk + 7) & ~7;
   const size_t lds = (size_t)kRows * (LP * sizeof(BinRecord) + 16);
   hipLaunchKernelGGL(msda_bwd_d48_bin_kernel, dim3(nblk_padded), dim3(kD48Block), lds, st, grad_out, value, loc,
-                     attn, d, plan, grad_value, grad_loc, grad_attn, nblk_padded);
+                     attn, d, plan, grad_value, grad_loc, grad_attn, nblk_padded, go_bf16);
   if (int rc = launch_status()) return rc;
   // 2) every tile adds what it owns
   const long long nblk_tiles = nm * plan.total_tiles;
   if (nblk_tiles >= (1LL << 31)) return SNIPPER_E_SHAPE;
   if (g_owner_chunk.load(std::memory_order_relaxed) == 128)
     hipLaunchKernelGGL(msda_bwd_d48_tile_kernel<128>, dim3((unsigned)nblk_tiles), dim3(kOwnerBlock), 0, st, grad_out,
-                       loc, attn, d, plan, grad_value);
+                       loc, attn, d, plan, grad_value, go_bf16);
   else
     hipLaunchKernelGGL(msda_bwd_d48_tile_kernel<64>, dim3((unsigned)nblk_tiles), dim3(kOwnerBlock), 0, st, grad_out,
-                       loc, attn, d, plan, grad_value);
+                       loc, attn, d, plan, grad_value, go_bf16);
   g_last_variant = "d48_owner";
   return launch_status();
 }
@@ -310,6 +310,14 @@ int snipper_msda_forward_f32(void *stream, const float *value, const int64_t *sh
   return forward_generic<float, float>(st, value, shapes, level_start, loc, attn, d, out);
 }
 
+int snipper_msda_forward_f32_bf16out(void *stream, const float *value, const int64_t *shapes,
+                                     const int64_t *level_start, const float *loc, const float *attn,
+                                     int N, int S, int M, int D, int L, int Lq, int P, uint16_t *out) {
+  SNIPPER_CHECK_FWD();
+  if (!d48_eligible<float>(d)) return SNIPPER_E_UNSUPPORTED;
+  return forward_d48<float>(st, value, shapes, level_start, loc, attn, d, reinterpret_cast<float *>(out), 1);
+}
+
 int snipper_msda_forward_f64(void *stream, const double *value, const int64_t *shapes,
                              const int64_t *level_start, const double *loc, const double *attn,
                              int N, int S, int M, int D, int L, int Lq, int P, double *out) {
@@ -370,6 +378,23 @@ int snipper_msda_backward_ws_f32(void *stream, const float *grad_out, const floa
   }
   return snipper_msda_backward_f32(stream, grad_out, value, shapes, level_start, loc, attn, N, S, M, D, L, Lq, P,
                                    grad_value, grad_loc, grad_attn);
+}
+
+int snipper_msda_backward_ws_f32_bf16in(void *stream, const uint16_t *grad_out, const float *value,
+                                        const int64_t *shapes, const int64_t *level_start,
+                                        const int64_t *host_shapes, void *workspace, long long workspace_bytes,
+                                        const float *loc, const float *attn,
+                                        int N, int S, int M, int D, int L, int Lq, int P,
+                                        float *grad_value, float *grad_loc, float *grad_attn) {
+  SNIPPER_CHECK_BWD();
+  if (!d48_eligible<float>(d)) return SNIPPER_E_UNSUPPORTED;
+  const float *go = reinterpret_cast<const float *>(grad_out);
+  if (int rc = zero_grad_value(st, grad_value, d)) return rc;
+  const long long need = host_shapes ? snipper_msda_backward_workspace_bytes(N, S, M, D, L, Lq, P, host_shapes) : 0;
+  if (need > 0 && workspace && workspace_bytes >= need)
+    return backward_d48_owner_f32(st, go, value, loc, attn, d, make_owner_plan(d, host_shapes), workspace,
+                                  grad_value, grad_loc, grad_attn, 1);
+  return backward_d48_f32(st, go, value, shapes, level_start, loc, attn, d, grad_value, grad_loc, grad_attn, 1);
 }
 
 int snipper_msda_backward_f64(void *stream, const double *grad_out, const double *value,

@@ -104,7 +104,9 @@ template <typename VT, int LP_T>
 __global__ __launch_bounds__(kD48Block) void msda_fwd_d48_kernel(
     const VT *__restrict__ value, const int64_t *__restrict__ shapes,
     const int64_t *__restrict__ level_start, const float *__restrict__ loc,
-    const float *__restrict__ attn, CoreDims d, VT *__restrict__ out, int nblk_padded) {
+    const float *__restrict__ attn, CoreDims d, VT *__restrict__ out, int nblk_padded, int out_bf16) {
+  // out_bf16 (float kernel only): `out` holds bfloat16 rows -- the consumer (the output projection) rounds to bf16
+  // anyway, so writing it here saves the cast pass and half the store traffic without changing any result
   using TR = D48Fwd<VT>;
   constexpr int G = TR::G, CPL = TR::CPL, kRows = kD48Block / G;
   __shared__ LevelTable lv;
@@ -172,9 +174,21 @@ __global__ __launch_bounds__(kD48Block) void msda_fwd_d48_kernel(
     TR::fma_tap(acc, r.w.z, v2);
     TR::fma_tap(acc, r.w.w, v3);
   }
+  if constexpr (sizeof(VT) == 4) {
+    if (out_bf16) {
+      uint16_t *o16 = reinterpret_cast<uint16_t *>(out) + (size_t)row * kD48 + lane * 3;
+      o16[0] = f32_to_bf16_bits(acc[0]); o16[1] = f32_to_bf16_bits(acc[1]); o16[2] = f32_to_bf16_bits(acc[2]);
+      return;
+    }
+  }
   const u32x3 packed = TR::pack(acc);
   unsigned char *o = reinterpret_cast<unsigned char *>(out) + (size_t)row * kD48 * sizeof(VT) + lane_off;
   *reinterpret_cast<u32x3 *>(o) = packed;
+}
+
+// one element of a grad_out row that is stored as float32 or (go_bf16) bfloat16
+__device__ __forceinline__ float ld_go(const float *grad_out, size_t idx, int go_bf16) {
+  return go_bf16 ? bf16_bits_to_f32(reinterpret_cast<const uint16_t *>(grad_out)[idx]) : grad_out[idx];
 }
 
 // ---- backward, f32 ------------------------------------------------------------------------
@@ -221,7 +235,7 @@ __global__ __launch_bounds__(kD48Block) void msda_bwd_d48_f32_kernel(
     const int64_t *__restrict__ shapes, const int64_t *__restrict__ level_start,
     const float *__restrict__ loc, const float *__restrict__ attn, CoreDims d,
     float *__restrict__ grad_value, float *__restrict__ grad_loc, float *__restrict__ grad_attn,
-    int nblk_padded) {
+    int nblk_padded, int go_bf16) {
   constexpr int G = 16, kRows = kD48Block / G;
   __shared__ LevelTable lv;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -273,8 +287,8 @@ __global__ __launch_bounds__(kD48Block) void msda_bwd_d48_f32_kernel(
   const auto vsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(value), 0, (int)value_bytes, 0x00020000);
   const auto gsrc = __builtin_amdgcn_make_buffer_rsrc(grad_value, 0, (int)value_bytes, 0x00020000);
   const unsigned lane_off = (unsigned)lane * 4u;
-  const float *gp = grad_out + (size_t)row * kD48 + lane;
-  const float g0 = gp[0], g1 = gp[16], g2 = gp[32];
+  const size_t gi = (size_t)row * kD48 + lane;
+  const float g0 = ld_go(grad_out, gi, go_bf16), g1 = ld_go(grad_out, gi + 16, go_bf16), g2 = ld_go(grad_out, gi + 32, go_bf16);
 
   float keep_a = 0.f, keep_x = 0.f, keep_y = 0.f;
 #pragma unroll(LP_T ? 2 : 1)

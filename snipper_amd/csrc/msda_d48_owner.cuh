@@ -108,7 +108,7 @@ __global__ __launch_bounds__(kD48Block) void msda_bwd_d48_bin_kernel(
     const float *__restrict__ grad_out, const float *__restrict__ value,
     const float *__restrict__ loc, const float *__restrict__ attn, CoreDims d, OwnerPlan plan,
     float *__restrict__ grad_value, float *__restrict__ grad_loc, float *__restrict__ grad_attn,
-    int nblk_padded) {
+    int nblk_padded, int go_bf16) {
   constexpr int G = 16, kRows = kD48Block / G;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int LP = d.L * kOwnerP;
@@ -204,8 +204,8 @@ __global__ __launch_bounds__(kD48Block) void msda_bwd_d48_bin_kernel(
   const auto vsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(value), 0, (int)value_bytes, 0x00020000);
   const auto gsrc = __builtin_amdgcn_make_buffer_rsrc(grad_value, 0, (int)value_bytes, 0x00020000);
   const unsigned lane_off = (unsigned)lane * 12u;
-  const float *gp = grad_out + (size_t)row * kD48 + lane * 3;
-  const float g0 = gp[0], g1 = gp[1], g2 = gp[2];
+  const size_t gi = (size_t)row * kD48 + lane * 3;
+  const float g0 = ld_go(grad_out, gi, go_bf16), g1 = ld_go(grad_out, gi + 1, go_bf16), g2 = ld_go(grad_out, gi + 2, go_bf16);
 
   float keep_a = 0.f, keep_x = 0.f, keep_y = 0.f;
 #pragma unroll 2
@@ -275,7 +275,7 @@ template <int kOwnerChunk> struct TileLds {   // kOwnerChunk = list entries (que
 template <int kOwnerChunk>
 __global__ __launch_bounds__(kOwnerBlock) void msda_bwd_d48_tile_kernel(
     const float *__restrict__ grad_out, const float *__restrict__ loc, const float *__restrict__ attn,
-    CoreDims d, OwnerPlan plan, float *__restrict__ grad_value) {
+    CoreDims d, OwnerPlan plan, float *__restrict__ grad_value, int go_bf16) {
   __shared__ TileLds<kOwnerChunk> S;
   // ---- which tile am I? ----
   const int tiles = plan.total_tiles;
@@ -328,6 +328,20 @@ __global__ __launch_bounds__(kOwnerBlock) void msda_bwd_d48_tile_kernel(
     for (int i = tid; i < tpx; i += kOwnerBlock) S.cnt[i] = 0;
     __syncthreads();
     // ---- stage the grad_out rows of the chunk (16 B per lane, coalesced) ----
+    if (go_bf16) {                                      // bf16 rows: 16 B = 8 channels per lane, widened into LDS
+      for (int i = tid; i < (plan.debug == 6 ? 0 : nh * (kD48 / 8)); i += kOwnerBlock) {
+        const int h = i / (kD48 / 8), c8 = i % (kD48 / 8);
+        const u32x4 v = *reinterpret_cast<const u32x4 *>(reinterpret_cast<const uint16_t *>(grad_out) +
+                                                         ((row_base + S.ent[h]) * d.M + m) * kD48 + c8 * 8);
+        f32x4 lo, hi;
+        lo.x = __uint_as_float(v.x << 16); lo.y = __uint_as_float(v.x & 0xffff0000u);
+        lo.z = __uint_as_float(v.y << 16); lo.w = __uint_as_float(v.y & 0xffff0000u);
+        hi.x = __uint_as_float(v.z << 16); hi.y = __uint_as_float(v.z & 0xffff0000u);
+        hi.z = __uint_as_float(v.w << 16); hi.w = __uint_as_float(v.w & 0xffff0000u);
+        *reinterpret_cast<f32x4 *>(S.gbuf + h * kD48 + c8 * 8) = lo;
+        *reinterpret_cast<f32x4 *>(S.gbuf + h * kD48 + c8 * 8 + 4) = hi;
+      }
+    } else
     for (int i = tid; i < (plan.debug == 6 ? 0 : nh * (kD48 / 4)); i += kOwnerBlock) {
       const int h = i / (kD48 / 4), c4 = i % (kD48 / 4);
       const f32x4 v = *reinterpret_cast<const f32x4 *>(grad_out + ((row_base + S.ent[h]) * d.M + m) * kD48 + c4 * 4);

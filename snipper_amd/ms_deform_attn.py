@@ -115,8 +115,12 @@ class MSDeformAttn(nn.Module):
             # under bf16 autocast the sampling itself stays in fp32: its f32 backward has the
             # owner-computes kernels (3x faster than the atomic one), which dwarfs the bf16 forward's gain
             value, loc, attn = value.float(), loc.float(), attn.float()
+        # under bf16 autocast the output projection that follows (and its data gradient that comes back) compute in
+        # bf16: let the kernels write / read bf16 rows instead of casting around them
+        rows_bf16 = (value.is_cuda and value.dtype == torch.float32 and torch.is_autocast_enabled('cuda') and
+                     torch.get_autocast_dtype('cuda') == torch.bfloat16)
         return MSDeformAttnFunction.apply(value.contiguous(), shapes, lsi, loc.contiguous(),
-                                          attn.contiguous(), self.im2col_step)
+                                          attn.contiguous(), self.im2col_step, rows_bf16)
 
     def forward(self, query, reference_points, input_flatten, input_spatial_shapes,
                 input_level_start_index, input_padding_mask=None):

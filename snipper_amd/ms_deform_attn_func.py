@@ -21,19 +21,28 @@ from . import MultiScaleDeformableAttention as MSDA
 
 
 class MSDeformAttnFunction(Function):
-    """apply(value, spatial_shapes, level_start_index, sampling_locations, attention_weights, im2col_step)"""
+    """apply(value, spatial_shapes, level_start_index, sampling_locations, attention_weights, im2col_step
+             [, rows_bf16=False])
+
+    ``rows_bf16`` (extension, float32 ``value`` only): the output is produced, and its gradient consumed, as bfloat16
+    rows by the kernels themselves -- for callers whose neighbouring projections compute in bf16."""
 
     @staticmethod
     def forward(ctx, value, value_spatial_shapes, value_level_start_index,
-                sampling_locations, attention_weights, im2col_step):
+                sampling_locations, attention_weights, im2col_step, rows_bf16=False):
         ctx.im2col_step = im2col_step
+        ctx.rows_bf16 = bool(rows_bf16) and value.dtype == torch.float32
         # host copy of the level shapes, when our transformer attached one (spares a device sync)
         ctx.host_shapes = getattr(value_spatial_shapes, "_snipper_host", None)
         if value.dtype == torch.bfloat16:   # coordinates and weights stay fp32 beside bf16 values
             sampling_locations = sampling_locations.float()
             attention_weights = attention_weights.float()
-        out = MSDA.ms_deform_attn_forward(value, value_spatial_shapes, value_level_start_index,
-                                          sampling_locations, attention_weights, im2col_step)
+        if ctx.rows_bf16:
+            out = MSDA.ms_deform_attn_forward(value, value_spatial_shapes, value_level_start_index,
+                                              sampling_locations, attention_weights, im2col_step, out_bf16=True)
+        else:
+            out = MSDA.ms_deform_attn_forward(value, value_spatial_shapes, value_level_start_index,
+                                              sampling_locations, attention_weights, im2col_step)
         ctx.save_for_backward(value, value_spatial_shapes, value_level_start_index,
                               sampling_locations, attention_weights)
         return out
@@ -42,10 +51,12 @@ class MSDeformAttnFunction(Function):
     @once_differentiable
     def backward(ctx, grad_output):
         value, shapes, lsi, loc, attn = ctx.saved_tensors
+        grad_output = grad_output.contiguous()
+        if grad_output.dtype != value.dtype and not (ctx.rows_bf16 and grad_output.dtype == torch.bfloat16):
+            grad_output = grad_output.to(value.dtype)
         grad_value, grad_loc, grad_attn = MSDA.ms_deform_attn_backward(
-            value, shapes, lsi, loc, attn, grad_output.contiguous(), ctx.im2col_step,
-            host_shapes=ctx.host_shapes)
-        return grad_value, None, None, grad_loc, grad_attn, None   # reference :42
+            value, shapes, lsi, loc, attn, grad_output, ctx.im2col_step, host_shapes=ctx.host_shapes)
+        return grad_value, None, None, grad_loc, grad_attn, None, None   # reference :42
 
 
 def ms_deform_attn_core_pytorch(value, value_spatial_shapes, sampling_locations, attention_weights):

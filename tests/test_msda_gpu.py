@@ -304,3 +304,53 @@ def test_full_size_properties(local):
     np.testing.assert_allclose(sga.cpu().numpy(), rga, rtol=1e-3, atol=1e-4)
     s = float(np.abs(rgl).max())
     np.testing.assert_allclose(sgl.cpu().numpy() / s, rgl / s, rtol=1e-3, atol=1e-4)
+
+
+@pytest.mark.parametrize("Lq_is_S", [True, False])
+def test_bf16_rows_interface_matches_f32(Lq_is_S):
+    """bf16 rows at the op's activation interfaces (out written / grad_out read as bf16 by the kernels): the output is
+    the float32 result rounded once, and the gradients equal the float32 path fed the same bf16-valued grad_out --
+    for the owner-computes shape (Lq == S, host shapes known) and for the atomic kernel."""
+    from snipper_amd import MultiScaleDeformableAttention as MSDA
+    torch.manual_seed(5)
+    shapes = [(19, 25), (10, 13), (5, 7)]
+    S = sum(h * w for h, w in shapes)
+    N, M, D, L, P = 2, 8, 48, 3, 4
+    Lq = S if Lq_is_S else 77
+    sh = torch.tensor(shapes, device="cuda:0")
+    lsi = torch.cat((sh.new_zeros(1), sh.prod(1).cumsum(0)[:-1]))
+    value = torch.randn(N, S, M, D, device="cuda:0")
+    loc = torch.rand(N, Lq, M, L, P, 2, device="cuda:0")
+    attn = torch.softmax(torch.randn(N, Lq, M, L * P, device="cuda:0"), -1).view(N, Lq, M, L, P)
+    out32 = MSDA.ms_deform_attn_forward(value, sh, lsi, loc, attn, 64)
+    out16 = MSDA.ms_deform_attn_forward(value, sh, lsi, loc, attn, 64, out_bf16=True)
+    assert out16.dtype == torch.bfloat16 and torch.equal(out16, out32.to(torch.bfloat16))
+    go16 = torch.randn(N, Lq, M * D, device="cuda:0").bfloat16()
+    hs = shapes if Lq_is_S else None
+    a = MSDA.ms_deform_attn_backward(value, sh, lsi, loc, attn, go16, 64, host_shapes=hs)
+    b = MSDA.ms_deform_attn_backward(value, sh, lsi, loc, attn, go16.float(), 64, host_shapes=hs)
+    for x, y in zip(a, b):
+        scale = max(float(y.abs().max()), 1.0)
+        torch.testing.assert_close(x / scale, y / scale, rtol=1e-5, atol=2e-6)
+
+
+def test_bf16_rows_unsupported_shape_falls_back_to_cast():
+    """D != 48 has no bf16-row kernel: the wrapper casts around the float32 entry points instead."""
+    from snipper_amd import MultiScaleDeformableAttention as MSDA
+    torch.manual_seed(6)
+    shapes = [(6, 4), (3, 2)]
+    S = sum(h * w for h, w in shapes)
+    N, M, D, L, P, Lq = 1, 2, 16, 2, 2, 9
+    sh = torch.tensor(shapes, device="cuda:0")
+    lsi = torch.cat((sh.new_zeros(1), sh.prod(1).cumsum(0)[:-1]))
+    value = torch.randn(N, S, M, D, device="cuda:0")
+    loc = torch.rand(N, Lq, M, L, P, 2, device="cuda:0")
+    attn = torch.softmax(torch.randn(N, Lq, M, L * P, device="cuda:0"), -1).view(N, Lq, M, L, P)
+    out32 = MSDA.ms_deform_attn_forward(value, sh, lsi, loc, attn, 64)
+    out16 = MSDA.ms_deform_attn_forward(value, sh, lsi, loc, attn, 64, out_bf16=True)
+    assert torch.equal(out16, out32.to(torch.bfloat16))
+    go16 = torch.randn(N, Lq, M * D, device="cuda:0").bfloat16()
+    a = MSDA.ms_deform_attn_backward(value, sh, lsi, loc, attn, go16, 64)
+    b = MSDA.ms_deform_attn_backward(value, sh, lsi, loc, attn, go16.float(), 64)
+    for x, y in zip(a, b):
+        torch.testing.assert_close(x, y, rtol=1e-6, atol=1e-7)
