@@ -74,6 +74,27 @@ int snipper_add_dropout_layernorm_backward(void *stream, const float *g32, const
                                            void *dx, int dx_dt, void *dz, int dz_dt, float *dgamma, float *dbeta,
                                            void *workspace, size_t workspace_bytes);
 
+/* GroupNorm of the input projections on token rows (csrc/gn_tokens.cuh; reference models/model.py:62-84 followed by
+ * the flatten + concatenation of models/deformable_transformer.py:103-122).  x [n, hw, C] bfloat16 = the 1x1
+ * projection's output in NHWC (one row per pixel); statistics per (image, group) over hw x C/G values.  The result
+ * is written into rows (i * dst_rows_per_image + dst_row_offset + r) of [*, C] buffers -- the level's slice of the
+ * concatenated [b, t, S, C] token arrays: y32 float32, y16 bfloat16, yq16 = bfloat16(y + pos) with pos (dtype code
+ * 0 = f32 / 1 = bf16) addressed like the outputs; any non-empty subset.  stats [n, G, 2] (mean, rstd) is kept for
+ * the backward, whose g32 / g16 / gq16 (gradients of the three outputs, same addressing, summed) give dx [n, hw, C]
+ * bfloat16 and dgamma / dbeta [C] (overwritten, summed in a fixed order).
+ * Requirements: C % G == 0, (C / G) % 4 == 0, C <= 1024, G <= 64; workspace >= ..._workspace_bytes(n, hw, C, G). */
+size_t snipper_groupnorm_tokens_workspace_bytes(int n, int hw, int C, int G);
+int snipper_groupnorm_tokens_forward(void *stream, const uint16_t *x, const float *gamma, const float *beta,
+                                     int n, int hw, int C, int G, float eps,
+                                     long long dst_rows_per_image, long long dst_row_offset,
+                                     const void *pos, int pos_dt, float *y32, uint16_t *y16, uint16_t *yq16,
+                                     float *stats, void *workspace, size_t workspace_bytes);
+int snipper_groupnorm_tokens_backward(void *stream, const uint16_t *x, const float *gamma, const float *stats,
+                                      const float *g32, const uint16_t *g16, const uint16_t *gq16,
+                                      int n, int hw, int C, int G,
+                                      long long dst_rows_per_image, long long dst_row_offset,
+                                      uint16_t *dx, float *dgamma, float *dbeta, void *workspace, size_t workspace_bytes);
+
 /* 3x3 convolution, padding 1, stride 1 or 2, NHWC bf16, as an implicit GEMM on the same MFMA tiles:
  * Y[B,Ho,Wo,Cout] = act(conv(X[B,H,W,Cin], W[Cout,3,3,Cin]) + bias[Cout]), Ho = (H-1)/stride + 1 (same for Wo).
  * Requirements: Cin % 64 == 0, Cout % 4 == 0.  (ResNet bottleneck conv2 with the frozen BatchNorm folded in.) */

@@ -294,7 +294,11 @@ class PositionEmbeddingSine(nn.Module):
         self.scale = 2 * math.pi if scale is None else scale
 
     def forward(self, tensor_list: NestedTensor):
-        mask = tensor_list.mask
+        return self.channel_last(tensor_list.mask).permute(0, 1, 4, 2, 3)   # (z, y, x) blocks -> [b,t,3F,h,w]
+
+    def channel_last(self, mask):
+        """[b*t, h, w] padding mask -> [b, t, h, w, 3F]: the embedding as it is computed, before the reference's
+        permute to channel-first (position_encoding.py:62); the token-row path uses it as is."""
         n, h, w = mask.shape
         live = ~mask.reshape(n // self.frames, self.frames, h, w)
         axes = []
@@ -310,7 +314,7 @@ class PositionEmbeddingSine(nn.Module):
         for e in axes:
             ang = e[..., None] / freq                           # [b,t,h,w,F]
             parts.append(torch.stack((ang[..., 0::2].sin(), ang[..., 1::2].cos()), dim=5).flatten(4))
-        return torch.cat(parts, dim=4).permute(0, 1, 4, 2, 3)   # (z, y, x) blocks -> [b,t,3F,h,w]
+        return torch.cat(parts, dim=4)
 
 
 class Joiner(nn.Sequential):

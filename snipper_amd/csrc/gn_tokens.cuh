@@ -1,0 +1,194 @@
+// gn_tokens.cuh -- GroupNorm of the input projections, computed on token rows (gfx950).
+//
+// The model projects every backbone level with Conv2d(1x1) + GroupNorm(32, C) (reference models/model.py:62-84) and
+// the transformer then flattens each [b, c, t, h, w] map into token rows [b, t, h*w, c] and concatenates the levels
+// (models/deformable_transformer.py:103-122).  With NHWC activations the 1x1 convolution already IS a GEMM whose
+// output rows are those tokens; what is left is a GroupNorm whose statistics run over (h*w, C/G channels) of one
+// image.  These kernels do that on the [n, hw, C] bf16 rows and write the result straight into the level's slice of
+// the concatenated [b, t, S, C] buffers -- float32 (residual stream), bf16 (input of the value projection) and
+// bf16(y + pos) (query of the first encoder layer) -- so no layout copy, concatenation, cast or add kernel follows.
+//
+//   forward : gn_stats_kernel  -> per-workgroup partial (sum, sum of squares) per (image, group)   [deterministic]
+//             gn_apply_kernel  -> finishes the statistics, normalises, writes the three views + mean / rstd
+//   backward: gn_bwd_stats_kernel -> partial (sum g*gamma, sum g*gamma*xhat) per (image, group) and partial
+//                                    dgamma / dbeta per channel (summed by ln_param_grad_kernel)
+//             gn_bwd_apply_kernel -> dx = rstd * (g*gamma - (s1 + xhat*s2) / count), bf16
+//
+// Thread mapping (all four): a thread owns one 4-channel chunk (4 | C/G, so a chunk never straddles groups) and
+// every RPP-th row of its workgroup's row range; blockDim = (C/4) * RPP <= 256.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "ln_fused.cuh"
+
+namespace snipper {
+
+constexpr int kGnMaxGroups = 64;
+
+struct GnArgs {
+  const uint16_t *x;          // [n][hw][C] bf16 (the projection's output)
+  const float *gamma, *beta;  // [C]
+  float *part;                // [n][nblk][G][2] partial sums (forward) / partial (s1, s2) (backward)
+  float *stats;               // [n][G][2] mean, rstd
+  // forward outputs: rows of image i start at row (i * dst_rows_per_image + dst_row_offset) of [*, C] buffers
+  float *y32; uint16_t *y16; uint16_t *yq16;
+  const void *pos; int pos_dt;            // same row addressing as the outputs; only for yq16
+  // backward inputs (same row addressing) and outputs
+  const float *g32; const uint16_t *g16; const uint16_t *gq16;
+  uint16_t *dx;               // [n][hw][C] bf16
+  float *part_param;          // [n * nblk][2][C] partial dgamma / dbeta
+  long long dst_rows_per_image, dst_row_offset;
+  int n, hw, C, G, nblk, rpp;
+  float eps;
+};
+
+__device__ __forceinline__ void gn_block_group_reduce(float a, float b, int G, int chunks_per_group, int chunks, int rpp,
+                                                      float *lds /* [256][2] */, float *out /* [G][2] */) {
+  lds[2 * threadIdx.x] = a;
+  lds[2 * threadIdx.x + 1] = b;
+  __syncthreads();
+  if ((int)threadIdx.x < G) {
+    float sa = 0.f, sb = 0.f;
+    for (int r = 0; r < rpp; ++r)
+      for (int c = 0; c < chunks_per_group; ++c) {
+        const int t = r * chunks + threadIdx.x * chunks_per_group + c;
+        sa += lds[2 * t];
+        sb += lds[2 * t + 1];
+      }
+    out[2 * threadIdx.x] = sa;
+    out[2 * threadIdx.x + 1] = sb;
+  }
+}
+
+__global__ __launch_bounds__(256) void gn_stats_kernel(GnArgs a) {
+  __shared__ float lds[512];
+  const int chunks = a.C / 4, chunk = threadIdx.x % chunks, rsub = threadIdx.x / chunks;
+  const int img = blockIdx.y;
+  const uint16_t *x = a.x + (long long)img * a.hw * a.C + chunk * 4;
+  float s = 0.f, q = 0.f;
+  for (int r = blockIdx.x * a.rpp + rsub; r < a.hw; r += a.nblk * a.rpp) {
+    const float4 v = ln_load4(x, 1, (long long)r * a.C);
+    s += (v.x + v.y) + (v.z + v.w);
+    q += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+  }
+  gn_block_group_reduce(s, q, a.G, (a.C / a.G) / 4, chunks, a.rpp, lds,
+                        a.part + ((long long)img * a.nblk + blockIdx.x) * a.G * 2);
+}
+
+// finishes per-(image, group) sums from the partials: returns (A, B) for this thread's group via LDS
+__device__ __forceinline__ void gn_finish(const float *part, int img, int nblk, int G, float *lds_out /* [G][2] */) {
+  if ((int)threadIdx.x < G) {
+    float sa = 0.f, sb = 0.f;
+    const float *p = part + (long long)img * nblk * G * 2 + threadIdx.x * 2;
+    for (int b = 0; b < nblk; ++b) { sa += p[(long long)b * G * 2]; sb += p[(long long)b * G * 2 + 1]; }
+    lds_out[2 * threadIdx.x] = sa;
+    lds_out[2 * threadIdx.x + 1] = sb;
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void gn_apply_kernel(GnArgs a) {
+  __shared__ float grp[2 * kGnMaxGroups];
+  const int chunks = a.C / 4, chunk = threadIdx.x % chunks, rsub = threadIdx.x / chunks;
+  const int img = blockIdx.y, cpg = a.C / a.G, g = (chunk * 4) / cpg;
+  gn_finish(a.part, img, a.nblk, a.G, grp);
+  const float cnt = (float)a.hw * (float)cpg;
+  const float mean = grp[2 * g] / cnt;
+  const float var = fmaxf(grp[2 * g + 1] / cnt - mean * mean, 0.f);
+  const float rstd = rsqrtf(var + a.eps);
+  if (blockIdx.x == 0 && (int)threadIdx.x < a.G) {
+    const float m = grp[2 * threadIdx.x] / cnt;
+    const float v = fmaxf(grp[2 * threadIdx.x + 1] / cnt - m * m, 0.f);
+    a.stats[((long long)img * a.G + threadIdx.x) * 2] = m;
+    a.stats[((long long)img * a.G + threadIdx.x) * 2 + 1] = rsqrtf(v + a.eps);
+  }
+  const float4 gm = *reinterpret_cast<const float4 *>(a.gamma + chunk * 4), bt = *reinterpret_cast<const float4 *>(a.beta + chunk * 4);
+  const uint16_t *x = a.x + (long long)img * a.hw * a.C + chunk * 4;
+  const long long drow0 = (long long)img * a.dst_rows_per_image + a.dst_row_offset;
+  for (int r = blockIdx.x * a.rpp + rsub; r < a.hw; r += a.nblk * a.rpp) {
+    const float4 v = ln_load4(x, 1, (long long)r * a.C);
+    float4 y;
+    y.x = (v.x - mean) * rstd * gm.x + bt.x; y.y = (v.y - mean) * rstd * gm.y + bt.y;
+    y.z = (v.z - mean) * rstd * gm.z + bt.z; y.w = (v.w - mean) * rstd * gm.w + bt.w;
+    const long long e = (drow0 + r) * a.C + chunk * 4;
+    if (a.y32) *reinterpret_cast<float4 *>(a.y32 + e) = y;
+    if (a.y16) ln_store4(a.y16, 1, e, y);
+    if (a.yq16) {
+      const float4 ps = ln_load4(a.pos, a.pos_dt, e);
+      ln_store4(a.yq16, 1, e, make_float4(y.x + ps.x, y.y + ps.y, y.z + ps.z, y.w + ps.w));
+    }
+  }
+}
+
+__device__ __forceinline__ float4 gn_load_grad(const GnArgs &a, long long e) {
+  float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (a.g32) g = *reinterpret_cast<const float4 *>(a.g32 + e);
+  if (a.g16) { const float4 t = ln_load4(a.g16, 1, e); g.x += t.x; g.y += t.y; g.z += t.z; g.w += t.w; }
+  if (a.gq16) { const float4 t = ln_load4(a.gq16, 1, e); g.x += t.x; g.y += t.y; g.z += t.z; g.w += t.w; }
+  return g;
+}
+
+__global__ __launch_bounds__(256) void gn_bwd_stats_kernel(GnArgs a) {
+  __shared__ float lds[512];
+  __shared__ float pg[256 * 8];
+  const int chunks = a.C / 4, chunk = threadIdx.x % chunks, rsub = threadIdx.x / chunks;
+  const int img = blockIdx.y, cpg = a.C / a.G, g = (chunk * 4) / cpg;
+  const float mean = a.stats[((long long)img * a.G + g) * 2], rstd = a.stats[((long long)img * a.G + g) * 2 + 1];
+  const float4 gm = *reinterpret_cast<const float4 *>(a.gamma + chunk * 4);
+  const uint16_t *x = a.x + (long long)img * a.hw * a.C + chunk * 4;
+  const long long drow0 = (long long)img * a.dst_rows_per_image + a.dst_row_offset;
+  float s1 = 0.f, s2 = 0.f;
+  float4 dg = make_float4(0.f, 0.f, 0.f, 0.f), db = dg;
+  for (int r = blockIdx.x * a.rpp + rsub; r < a.hw; r += a.nblk * a.rpp) {
+    const float4 v = ln_load4(x, 1, (long long)r * a.C);
+    const float4 gr = gn_load_grad(a, (drow0 + r) * a.C + chunk * 4);
+    const float4 h = make_float4((v.x - mean) * rstd, (v.y - mean) * rstd, (v.z - mean) * rstd, (v.w - mean) * rstd);
+    dg.x += gr.x * h.x; dg.y += gr.y * h.y; dg.z += gr.z * h.z; dg.w += gr.w * h.w;
+    db.x += gr.x; db.y += gr.y; db.z += gr.z; db.w += gr.w;
+    const float4 gg = make_float4(gr.x * gm.x, gr.y * gm.y, gr.z * gm.z, gr.w * gm.w);
+    s1 += (gg.x + gg.y) + (gg.z + gg.w);
+    s2 += (gg.x * h.x + gg.y * h.y) + (gg.z * h.z + gg.w * h.w);
+  }
+  // per-channel partials: the rpp row-lanes of a chunk meet in LDS, lane 0 of each chunk writes
+  float *mine = pg + threadIdx.x * 8;
+  mine[0] = dg.x; mine[1] = dg.y; mine[2] = dg.z; mine[3] = dg.w; mine[4] = db.x; mine[5] = db.y; mine[6] = db.z; mine[7] = db.w;
+  gn_block_group_reduce(s1, s2, a.G, cpg / 4, chunks, a.rpp, lds, a.part + ((long long)img * a.nblk + blockIdx.x) * a.G * 2);
+  // (gn_block_group_reduce has synchronised the workgroup after the LDS writes above)
+  if (rsub == 0) {
+    float acc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+    for (int r = 0; r < a.rpp; ++r)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc[k] += pg[(r * chunks + chunk) * 8 + k];
+    float *pp = a.part_param + ((long long)img * a.nblk + blockIdx.x) * 2 * a.C;
+    *reinterpret_cast<float4 *>(pp + chunk * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    *reinterpret_cast<float4 *>(pp + a.C + chunk * 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+  }
+}
+
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(GnArgs a) {
+  __shared__ float grp[2 * kGnMaxGroups];
+  const int chunks = a.C / 4, chunk = threadIdx.x % chunks, rsub = threadIdx.x / chunks;
+  const int img = blockIdx.y, cpg = a.C / a.G, g = (chunk * 4) / cpg;
+  gn_finish(a.part, img, a.nblk, a.G, grp);
+  const float inv_cnt = 1.f / ((float)a.hw * (float)cpg);
+  const float m1 = grp[2 * g] * inv_cnt, m2 = grp[2 * g + 1] * inv_cnt;
+  const float mean = a.stats[((long long)img * a.G + g) * 2], rstd = a.stats[((long long)img * a.G + g) * 2 + 1];
+  const float4 gm = *reinterpret_cast<const float4 *>(a.gamma + chunk * 4);
+  const uint16_t *x = a.x + (long long)img * a.hw * a.C + chunk * 4;
+  uint16_t *dx = a.dx + (long long)img * a.hw * a.C + chunk * 4;
+  const long long drow0 = (long long)img * a.dst_rows_per_image + a.dst_row_offset;
+  for (int r = blockIdx.x * a.rpp + rsub; r < a.hw; r += a.nblk * a.rpp) {
+    const float4 v = ln_load4(x, 1, (long long)r * a.C);
+    const float4 gr = gn_load_grad(a, (drow0 + r) * a.C + chunk * 4);
+    float4 d;
+    d.x = rstd * (gr.x * gm.x - m1 - (v.x - mean) * rstd * m2);
+    d.y = rstd * (gr.y * gm.y - m1 - (v.y - mean) * rstd * m2);
+    d.z = rstd * (gr.z * gm.z - m1 - (v.z - mean) * rstd * m2);
+    d.w = rstd * (gr.w * gm.w - m1 - (v.w - mean) * rstd * m2);
+    ln_store4(dx, 1, (long long)r * a.C, d);
+  }
+}
+
+}  // namespace snipper

@@ -16,6 +16,7 @@
 #include "gemm_bf16.cuh"
 #include "wgrad_bf16.cuh"
 #include "ln_fused.cuh"
+#include "gn_tokens.cuh"
 #include "msda_prologue.cuh"
 #include "lsap.cuh"
 #include "msda_d48.cuh"
@@ -529,6 +530,70 @@ int snipper_add_dropout_layernorm_backward(void *stream, const float *g32, const
   hipLaunchKernelGGL(ln_fused_bwd_kernel, dim3(blocks), dim3(kLnThreads), 0, (hipStream_t)stream, a);
   hipLaunchKernelGGL(ln_param_grad_kernel, dim3((2 * C + 15) / 16), dim3(256), 0, (hipStream_t)stream,
                      (const float *)workspace, blocks, C, dgamma, dbeta);
+  return launch_status();
+}
+
+namespace {
+struct GnPlan { int rpp, nblk; };
+inline GnPlan gn_plan(int hw, int C) {
+  GnPlan p;
+  p.rpp = std::max(1, 256 / (C / 4));
+  p.nblk = std::max(1, std::min((hw + p.rpp * 8 - 1) / (p.rpp * 8), 128));
+  return p;
+}
+inline bool gn_shape_ok(int n, int hw, int C, int G) {
+  return n > 0 && hw > 0 && C > 0 && G > 0 && G <= kGnMaxGroups && C % G == 0 && (C / G) % 4 == 0 && C / 4 <= 256;
+}
+}  // namespace
+
+size_t snipper_groupnorm_tokens_workspace_bytes(int n, int hw, int C, int G) {
+  if (!gn_shape_ok(n, hw, C, G)) return 0;
+  const GnPlan p = gn_plan(hw, C);
+  return ((size_t)n * p.nblk * G * 2 + (size_t)n * p.nblk * 2 * C) * sizeof(float);
+}
+
+int snipper_groupnorm_tokens_forward(void *stream, const uint16_t *x, const float *gamma, const float *beta,
+                                     int n, int hw, int C, int G, float eps,
+                                     long long dst_rows_per_image, long long dst_row_offset,
+                                     const void *pos, int pos_dt, float *y32, uint16_t *y16, uint16_t *yq16,
+                                     float *stats, void *workspace, size_t workspace_bytes) {
+  if (!x || !gamma || !beta || !stats || !workspace || (!y32 && !y16 && !yq16) || (yq16 && !pos)) return SNIPPER_E_NULL;
+  if (!gn_shape_ok(n, hw, C, G) || !ln_dt_ok(pos_dt) || dst_rows_per_image < hw || dst_row_offset < 0 ||
+      workspace_bytes < snipper_groupnorm_tokens_workspace_bytes(n, hw, C, G))
+    return SNIPPER_E_SHAPE;
+  const GnPlan p = gn_plan(hw, C);
+  GnArgs a{};
+  a.x = x; a.gamma = gamma; a.beta = beta; a.part = (float *)workspace; a.stats = stats;
+  a.y32 = y32; a.y16 = y16; a.yq16 = yq16; a.pos = pos; a.pos_dt = pos_dt;
+  a.dst_rows_per_image = dst_rows_per_image; a.dst_row_offset = dst_row_offset;
+  a.n = n; a.hw = hw; a.C = C; a.G = G; a.nblk = p.nblk; a.rpp = p.rpp; a.eps = eps;
+  const dim3 grid(p.nblk, n), block((C / 4) * p.rpp);
+  hipLaunchKernelGGL(gn_stats_kernel, grid, block, 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(gn_apply_kernel, grid, block, 0, (hipStream_t)stream, a);
+  return launch_status();
+}
+
+int snipper_groupnorm_tokens_backward(void *stream, const uint16_t *x, const float *gamma, const float *stats,
+                                      const float *g32, const uint16_t *g16, const uint16_t *gq16,
+                                      int n, int hw, int C, int G,
+                                      long long dst_rows_per_image, long long dst_row_offset,
+                                      uint16_t *dx, float *dgamma, float *dbeta, void *workspace, size_t workspace_bytes) {
+  if (!x || !gamma || !stats || !dx || !dgamma || !dbeta || !workspace || (!g32 && !g16 && !gq16)) return SNIPPER_E_NULL;
+  if (!gn_shape_ok(n, hw, C, G) || dst_rows_per_image < hw || dst_row_offset < 0 ||
+      workspace_bytes < snipper_groupnorm_tokens_workspace_bytes(n, hw, C, G))
+    return SNIPPER_E_SHAPE;
+  const GnPlan p = gn_plan(hw, C);
+  GnArgs a{};
+  a.x = x; a.gamma = gamma; a.part = (float *)workspace; a.stats = const_cast<float *>(stats);
+  a.part_param = (float *)workspace + (size_t)n * p.nblk * G * 2;
+  a.g32 = g32; a.g16 = g16; a.gq16 = gq16; a.dx = dx;
+  a.dst_rows_per_image = dst_rows_per_image; a.dst_row_offset = dst_row_offset;
+  a.n = n; a.hw = hw; a.C = C; a.G = G; a.nblk = p.nblk; a.rpp = p.rpp;
+  const dim3 grid(p.nblk, n), block((C / 4) * p.rpp);
+  hipLaunchKernelGGL(gn_bwd_stats_kernel, grid, block, 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(gn_bwd_apply_kernel, grid, block, 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(ln_param_grad_kernel, dim3((2 * C + 15) / 16), dim3(256), 0, (hipStream_t)stream,
+                     (const float *)a.part_param, n * p.nblk, C, dgamma, dbeta);
   return launch_status();
 }
 

@@ -156,13 +156,22 @@ class DeformableTransformerEncoder(nn.Module):
         centres = torch.cat(per_level, 1)                       # [B, S, 2]
         return centres[:, :, None] * valid_ratios[:, None]      # [B, S, L, 2]
 
-    def forward(self, src, spatial_shapes, level_start_index, valid_ratios, pos=None, padding_mask=None, n_frame=1):
+    def fused_ok(self, src) -> bool:
+        return all(hasattr(l, "fused_ok") and l.fused_ok(src) for l in self.layers)
+
+    def forward(self, src, spatial_shapes, level_start_index, valid_ratios, pos=None, padding_mask=None, n_frame=1,
+                twins=None):
+        """``twins`` = (src16, q16, pos16): the bf16 companions of ``src`` / ``src + pos`` / ``pos`` when the caller
+        already has them (the token-row input projections write them); otherwise they are made here."""
         ref = self.get_reference_points(spatial_shapes, valid_ratios, device=src.device)
         ref = ref.unsqueeze(1).expand(-1, n_frame, -1, -1, -1)  # same grid for every frame
         out = src
-        if pos is not None and all(hasattr(l, "fused_ok") and l.fused_ok(src) for l in self.layers):
-            pos16 = pos.to(torch.bfloat16)                      # gradients of the 6 uses accumulate in bf16
-            out16, q16 = out.to(torch.bfloat16), (out + pos).to(torch.bfloat16)
+        if pos is not None and self.fused_ok(src):
+            if twins is not None:
+                out16, q16, pos16 = twins
+            else:
+                pos16 = pos.to(torch.bfloat16)                  # gradients of the 6 uses accumulate in bf16
+                out16, q16 = out.to(torch.bfloat16), (out + pos).to(torch.bfloat16)
             for i, layer in enumerate(self.layers):
                 out, out16, q16 = layer.forward_fused(out, out16, q16, pos16, ref, spatial_shapes, level_start_index,
                                                       padding_mask, last=i + 1 == len(self.layers))
@@ -339,7 +348,57 @@ class DeformableTransformer(nn.Module):
         valid_ratios = torch.stack([self.get_valid_ratio(m) for m in masks], 1)   # [bs, L, 2]
 
         memory = self.encoder(src, spatial_shapes, level_start_index, valid_ratios, pos, mask, self.n_frame)
+        return self._decode(memory, hw, sizes, spatial_shapes, level_start_index, valid_ratios, mask, query_embed)
 
+    def tokens_path_ok(self, feats, input_proj) -> bool:
+        """Can the input projections be evaluated as token rows (fused.InputProjTokens)?  bf16 NHWC feature maps under
+        bf16 autocast, one (1x1 Conv2d + GroupNorm) per level, shapes the kernels take, a fused encoder."""
+        if not (feats and feats[0].is_cuda and _amp_bf16(feats[0]) and len(feats) == len(input_proj)):
+            return False
+        C = self.d_model
+        for f, proj in zip(feats, input_proj):
+            if not (isinstance(proj, nn.Sequential) and len(proj) == 2 and isinstance(proj[0], nn.Conv2d) and
+                    isinstance(proj[1], nn.GroupNorm)):
+                return False
+            conv, gn = proj
+            if not (conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.padding == (0, 0) and
+                    conv.groups == 1 and conv.bias is not None and conv.in_channels % 64 == 0 and
+                    conv.out_channels == C and gn.affine and C % gn.num_groups == 0 and
+                    (C // gn.num_groups) % 4 == 0 and gn.num_groups <= 64 and C <= 1024 and C % 64 == 0 and
+                    gn.num_groups == input_proj[0][1].num_groups and gn.eps == input_proj[0][1].eps):
+                return False
+            if not (f.dtype == torch.bfloat16 and f.dim() == 4 and f.is_contiguous(memory_format=torch.channels_last)):
+                return False
+        probe = torch.empty(0, dtype=torch.float32, device=feats[0].device).view(0, C)
+        return self.encoder.fused_ok(probe)
+
+    def forward_from_features(self, feats, masks, pos_tokens, input_proj, query_embed):
+        """The same computation as ``forward(srcs, masks, pos_embeds, query_embed)`` starting one step earlier:
+        feats L x [b*T, Cin, h, w] (backbone maps, bf16 NHWC), masks L x [b*T, h, w] bool, pos_tokens L x
+        [b, T, h*w, C] float32 (position encoding, token-major), input_proj the model's projection modules.
+        Check ``tokens_path_ok`` first."""
+        from .fused import InputProjTokens
+        T, c = self.n_frame, self.d_model
+        b = feats[0].shape[0] // T
+        hw = [tuple(int(v) for v in f.shape[-2:]) for f in feats]
+        sizes = [h * w for h, w in hw]
+        pos = torch.cat([p + self.level_embed[lvl].view(1, 1, 1, -1) for lvl, p in enumerate(pos_tokens)], 2)
+        pos16 = pos.to(torch.bfloat16)
+        mask = torch.cat([m.reshape(b, T, -1) for m in masks], 2)[..., None].expand(-1, -1, -1, c)
+        ratios = []
+        for m, (h, w) in zip(masks, hw):                                  # get_valid_ratio on frame 0 of each sample
+            m0 = m.view(b, T, h, w)[:, 0]
+            ratios.append(torch.stack([(~m0[:, 0, :]).sum(1).float() / w, (~m0[:, :, 0]).sum(1).float() / h], -1))
+        valid_ratios = torch.stack(ratios, 1)                             # [bs, L, 2]
+        spatial_shapes, level_start_index = _level_tensors(tuple(hw), feats[0].device)
+        params = [t for proj in input_proj for t in (proj[0].weight, proj[0].bias, proj[1].weight, proj[1].bias)]
+        gn = input_proj[0][1]
+        src, src16, q16 = InputProjTokens.apply(T, gn.num_groups, gn.eps, pos16, (True, True), *feats, *params)
+        memory = self.encoder(src, spatial_shapes, level_start_index, valid_ratios, pos, mask, self.n_frame,
+                              twins=(src16, q16, pos16))
+        return self._decode(memory, hw, sizes, spatial_shapes, level_start_index, valid_ratios, mask, query_embed)
+
+    def _decode(self, memory, hw, sizes, spatial_shapes, level_start_index, valid_ratios, mask, query_embed):
         bs, _, _, c = memory.shape
         heatmaps = []   # first num_keypoints channels of every head, per level (views; reference :141-149)
         for chunk, (h, w) in zip(memory.split(sizes, dim=2), hw):

@@ -227,3 +227,95 @@ def ln_fusable(x: torch.Tensor, norm: torch.nn.LayerNorm) -> bool:
     return (x.is_cuda and x.dtype in _DT and isinstance(norm, torch.nn.LayerNorm) and norm.elementwise_affine and
             norm.bias is not None and tuple(norm.normalized_shape) == (C,) and C % 4 == 0 and C <= 1024 and
             x.numel() < 2 ** 32)
+
+
+class InputProjTokens(Function):
+    """All input projections of the model (1x1 convolution + GroupNorm per backbone level, reference
+    models/model.py:62-84) followed by the flatten + concatenation of models/deformable_transformer.py:103-122, written
+    directly as token rows:
+
+        feats[l] [n, Cin_l, h_l, w_l] bf16, channels_last   (n = b * T frames)
+        -> src32 [b, T, S, C] float32, src16 (bf16 copy), q16 = bf16(src + pos)       S = sum_l h_l * w_l
+
+    The convolution is ONE GEMM per level on the NHWC rows (dense.linear_bf16, bias fused), GroupNorm runs on those
+    rows and writes the level's slice of the three outputs (csrc/gn_tokens.cuh): no layout copy, concatenation, cast
+    or add kernel.  ``pos`` [b, T, S, C] (bf16 or float32) only feeds q16; ``want`` = (src16, q16) flags.
+    apply(T, groups, eps, pos, want, *feats, *(weight, bias, gamma, beta per level))"""
+
+    @staticmethod
+    def forward(ctx, T, groups, eps, pos, want, *tensors):
+        from .dense import linear_bf16
+        L = len(tensors) // 5
+        feats, params = tensors[:L], tensors[L:]
+        n, dev = feats[0].shape[0], feats[0].device
+        C = params[0].shape[0]
+        hws = [(int(f.shape[2]), int(f.shape[3])) for f in feats]
+        S = sum(h * w for h, w in hws)
+        b = n // T
+        src32 = torch.empty((b, T, S, C), dtype=torch.float32, device=dev)
+        src16 = torch.empty((b, T, S, C), dtype=torch.bfloat16, device=dev) if want[0] else None
+        q16 = torch.empty((b, T, S, C), dtype=torch.bfloat16, device=dev) if (want[1] and pos is not None) else None
+        pos = pos.contiguous() if pos is not None else None
+        lib = _lib.load()
+        ptr = lambda t: t.data_ptr() if t is not None else None
+        saved, off = [], 0
+        for l, f in enumerate(feats):
+            w, bias, gamma, beta = params[4 * l: 4 * l + 4]
+            h, wd = hws[l]
+            x2 = f.permute(0, 2, 3, 1).reshape(n * h * wd, f.shape[1])          # NHWC rows (a view)
+            wb = w.reshape(C, -1).to(torch.bfloat16)
+            y = linear_bf16(x2, wb, bias.float())                               # [n*hw, C] bf16
+            stats = torch.empty((n, groups, 2), dtype=torch.float32, device=dev)
+            nbytes = lib.snipper_groupnorm_tokens_workspace_bytes(n, h * wd, C, groups)
+            ws = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
+            g32, b32 = gamma.float(), beta.float()
+            with torch.cuda.device(dev):
+                rc = lib.snipper_groupnorm_tokens_forward(
+                    _stream(dev), y.data_ptr(), g32.data_ptr(), b32.data_ptr(), n, h * wd, C, groups, float(eps),
+                    S, off, ptr(pos) if q16 is not None else None, _DT[pos.dtype] if pos is not None else 0,
+                    src32.data_ptr(), ptr(src16), ptr(q16), stats.data_ptr(), ws.data_ptr(), nbytes)
+            _lib.check(rc, "snipper_groupnorm_tokens_forward")
+            saved += [x2, wb, y, stats, g32]
+            off += h * wd
+        ctx.save_for_backward(*saved)
+        ctx.meta = (L, T, groups, hws, S, C, [tuple(f.shape) for f in feats], [p.shape for p in params],
+                    [p.dtype for p in params], pos is not None and q16 is not None)
+        return src32, src16, q16
+
+    @staticmethod
+    def backward(ctx, g32, g16, gq):
+        from .dense import linear_bf16, wgrad_bf16
+        L, T, groups, hws, S, C, fshapes, pshapes, pdtypes, has_q = ctx.meta
+        saved = ctx.saved_tensors
+        dev = saved[0].device
+        g32 = g32.contiguous().float() if g32 is not None else None
+        g16 = g16.contiguous().to(torch.bfloat16) if g16 is not None else None
+        gq = gq.contiguous().to(torch.bfloat16) if gq is not None else None
+        lib = _lib.load()
+        ptr = lambda t: t.data_ptr() if t is not None else None
+        dfeats, dparams, off = [], [], 0
+        for l in range(L):
+            x2, wb, y, stats, gamma = saved[5 * l: 5 * l + 5]
+            h, wd = hws[l]
+            n = fshapes[l][0]
+            dy = torch.empty_like(y)
+            dgb = torch.empty((2, C), dtype=torch.float32, device=dev)
+            nbytes = lib.snipper_groupnorm_tokens_workspace_bytes(n, h * wd, C, groups)
+            ws = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
+            with torch.cuda.device(dev):
+                rc = lib.snipper_groupnorm_tokens_backward(
+                    _stream(dev), y.data_ptr(), gamma.data_ptr(), stats.data_ptr(), ptr(g32), ptr(g16), ptr(gq),
+                    n, h * wd, C, groups, S, off, dy.data_ptr(), dgb[0].data_ptr(), dgb[1].data_ptr(),
+                    ws.data_ptr(), nbytes)
+            _lib.check(rc, "snipper_groupnorm_tokens_backward")
+            dfeat = None
+            if ctx.needs_input_grad[5 + l]:
+                dx2 = linear_bf16(dy, wb.t().contiguous())                      # [n*hw, Cin]
+                dfeat = dx2.view(n, h, wd, -1).permute(0, 3, 1, 2)              # logical NCHW, NHWC memory
+            dW, db = wgrad_bf16(dy, x2, want_bias=True)
+            shapes, dts = pshapes[4 * l: 4 * l + 4], pdtypes[4 * l: 4 * l + 4]
+            dparams += [dW.view(shapes[0]).to(dts[0]), db.to(dts[1]), dgb[0].to(dts[2]), dgb[1].to(dts[3])]
+            dfeats.append(dfeat)
+            off += h * wd
+        dpos = gq if (has_q and ctx.needs_input_grad[3]) else None
+        return (None, None, None, dpos, None, *dfeats, *dparams)

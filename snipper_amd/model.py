@@ -79,6 +79,10 @@ class SnipperDeformable(nn.Module):
     def forward(self, samples):
         if not isinstance(samples, NestedTensor):
             samples = nested_tensor_from_tensor_list(samples)
+        fast = self._forward_tokens(samples)
+        if fast is not None:
+            hs, heatmaps, init_reference, inter_references, inter_att = fast
+            return self._heads_entry(hs, heatmaps, init_reference, inter_references, inter_att)
         features, pos = self.backbone(samples)
         srcs, masks = [], []
         for lvl, feat in enumerate(features):
@@ -101,6 +105,32 @@ class SnipperDeformable(nn.Module):
 
         hs, heatmaps, init_reference, inter_references, inter_att = \
             self.transformer(srcs, masks, pos, self.query_embed.weight)
+        return self._heads_entry(hs, heatmaps, init_reference, inter_references, inter_att)
+
+    token_rows = True        # class-level switch (tests compare both formulations)
+
+    def _forward_tokens(self, samples):
+        """Backbone maps -> transformer without the channel-first detour (models/model.py:128-159 builds [b,c,t,h,w]
+        tensors that the transformer immediately flattens back to token rows): the projections and the position
+        encoding are produced token-major.  Returns None when the conditions of the fused path do not hold."""
+        joiner = self.backbone
+        if not (self.token_rows and samples.tensors.is_cuda and hasattr(self.transformer, "forward_from_features") and
+                hasattr(joiner[1], "channel_last") and self.num_feature_levels == len(joiner.num_channels)):
+            return None
+        xs = joiner[0](samples)
+        feats = [x for _, x in sorted(xs.items())]
+        maps = [f.tensors for f in feats]
+        if not self.transformer.tokens_path_ok(maps, self.input_proj):
+            return None
+        T = self.num_frames
+        pos_tokens = []
+        for f in feats:
+            p = joiner[1].channel_last(f.mask)                        # [b, t, h, w, C] float32
+            pos_tokens.append(p.flatten(2, 3))
+        return self.transformer.forward_from_features(maps, [f.mask for f in feats], pos_tokens, self.input_proj,
+                                                      self.query_embed.weight)
+
+    def _heads_entry(self, hs, heatmaps, init_reference, inter_references, inter_att):
         n_dec, bs, t, _, c = hs.shape
         if hs.is_cuda and torch.is_autocast_enabled('cuda'):
             # the heads see [n_dec, bs, T, queries, C] (a few thousand rows): float32, no autocast casts (the same

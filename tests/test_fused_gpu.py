@@ -175,3 +175,50 @@ def test_prologue_merged_input_matches_separate(dtype):
     graw, gref = torch.autograd.grad((loc, prob), (raw, ref), (gl, gp))
     goff, glogit, gref2 = torch.autograd.grad((loc2, prob2), (off, logit, ref2), (gl, gp))
     assert torch.equal(graw, torch.cat([goff, glogit], 1)) and torch.equal(gref, gref2)
+
+
+def test_input_proj_tokens_matches_conv_groupnorm():
+    """fused.InputProjTokens (1x1 conv as a GEMM + GroupNorm on token rows, three output views) against
+    Conv2d + GroupNorm + flatten/permute/cat in float32 on the same bf16-rounded operands."""
+    from snipper_amd.fused import InputProjTokens
+    g = torch.Generator().manual_seed(21)
+    T, b, C, G = 2, 2, 128, 8
+    n = b * T
+    cfg = [(64, 9, 11), (128, 5, 6)]
+    feats, params, refs = [], [], []
+    for cin, h, w in cfg:
+        f = torch.randn(n, cin, h, w, generator=g).to(DEV).bfloat16().contiguous(memory_format=torch.channels_last)
+        feats.append(f.requires_grad_(True))
+        wt = (torch.randn(C, cin, 1, 1, generator=g) / cin ** 0.5).to(DEV).requires_grad_(True)
+        bs = torch.randn(C, generator=g).to(DEV).requires_grad_(True)
+        gm = (torch.rand(C, generator=g) + 0.5).to(DEV).requires_grad_(True)
+        bt = torch.randn(C, generator=g).to(DEV).requires_grad_(True)
+        params += [wt, bs, gm, bt]
+    S = sum(h * w for _, h, w in cfg)
+    pos = torch.randn(b, T, S, C, generator=g).to(DEV).bfloat16().requires_grad_(True)
+    s32, s16, q16 = InputProjTokens.apply(T, G, 1e-5, pos, (True, True), *feats, *params)
+    assert s32.shape == (b, T, S, C) and s16.dtype == torch.bfloat16 and q16.dtype == torch.bfloat16
+    g32 = torch.randn(b, T, S, C, generator=g).to(DEV)
+    g16 = torch.randn(b, T, S, C, generator=g).to(DEV).bfloat16()
+    gq = torch.randn(b, T, S, C, generator=g).to(DEV).bfloat16()
+    grads = torch.autograd.grad((s32, s16, q16), feats + params + [pos], (g32, g16, gq))
+    # reference
+    rfeats = [f.detach().float().requires_grad_(True) for f in feats]
+    rparams = [p.detach().clone().requires_grad_(True) for p in params]
+    rpos = pos.detach().float().requires_grad_(True)
+    toks = []
+    for l, (cin, h, w) in enumerate(cfg):
+        wt, bs, gm, bt = rparams[4 * l: 4 * l + 4]
+        y = F.conv2d(rfeats[l], wt.bfloat16().float(), bs)
+        y = y + (y.bfloat16().float() - y).detach()                # the kernel rounds the projection to bf16 once
+        y = F.group_norm(y, G, gm, bt, 1e-5)
+        toks.append(y.view(b, T, C, h * w).permute(0, 1, 3, 2))
+    ref = torch.cat(toks, 2)
+    tot = (ref * g32).sum() + (ref * g16.float()).sum() + ((ref + rpos) * gq.float()).sum()
+    rgrads = torch.autograd.grad(tot, rfeats + rparams + [rpos])
+    rel = lambda a, c: ((a.double() - c.double()).norm() / c.double().norm().clamp_min(1e-20)).item()
+    assert rel(s32, ref) < 2e-3 and rel(s16, ref) < 6e-3 and rel(q16, ref + rpos) < 6e-3
+    names = [f"feat{l}" for l in range(2)] + [f"{k}{l}" for l in range(2) for k in ("w", "b", "gamma", "beta")] + ["pos"]
+    for name, a, c in zip(names, grads, rgrads):
+        assert a.shape == c.shape, name
+        assert rel(a, c) < 2e-2, (name, rel(a, c))

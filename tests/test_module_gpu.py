@@ -138,3 +138,44 @@ def test_transformer_bf16_fused_residual_path_matches_plain_path(golden_dir):
         ref = ref.to(DEV)
         ef, ep = rel(gf, ref), rel(gp, ref)
         assert ef < 2.0 * ep + 3e-2, (k, ef, ep)
+
+
+def test_model_token_row_path_matches_channel_first_path():
+    """SnipperDeformable under bf16 autocast: projections + position encoding produced as token rows (the fused
+    path) against the reference's channel-first route through the same modules -- outputs and parameter gradients."""
+    import importlib.util
+    from types import SimpleNamespace
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    a = SimpleNamespace(hidden_dim=192, enc_layers=2, dec_layers=2, frames=2, future_frames=0, use_pytorch_deform=0,
+                        batch=1, height=96, width=128)
+    from snipper_amd.model import build_model, SnipperDeformable
+    torch.manual_seed(0)
+    model = build_model(b.model_args(a)).to(DEV).to(memory_format=torch.channels_last).eval()
+    imgs, _ = b.make_batches(a, DEV, 1, seed=3)[0]
+    res = {}
+    for fast in (True, False):
+        SnipperDeformable.token_rows = fast
+        try:
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                out, _ = model(list(imgs))
+            k = out["all_layers"]["pred_kpts"].float()
+            w = torch.linspace(-1, 1, k.numel(), device=DEV).view_as(k)
+            params = [p for p in model.parameters() if p.requires_grad]
+            grads = torch.autograd.grad((k * w).sum() + out["heatmaps"][0].float().sum(), params, allow_unused=True)
+        finally:
+            SnipperDeformable.token_rows = True
+        res[fast] = (k, out["pred_logits"].float(), grads)
+    rel = lambda x, y: ((x.double() - y.double()).norm() / y.double().norm().clamp_min(1e-20)).item()
+    assert rel(res[True][0], res[False][0]) < 3e-2 and rel(res[True][1], res[False][1]) < 3e-2
+    names = [n for n, p in model.named_parameters() if p.requires_grad]
+    bad = []
+    for n, gf, gs in zip(names, res[True][2], res[False][2]):
+        if gf is None or gs is None:
+            assert gf is None and gs is None, n
+            continue
+        if rel(gf, gs) > 0.15:
+            bad.append((n, rel(gf, gs)))
+    assert len(bad) <= len(names) // 20, bad[:10]
