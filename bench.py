@@ -136,15 +136,16 @@ def build_optimizer(named_params, capturable=False):
 def msda_alg_bytes(d, bwd):
     """Algorithmic HBM bytes of one core-op launch; coordinates/weights are fp32."""
     e = d["esize"]
+    re = d.get("row_esize", e)         # out / grad_out rows (bf16 under autocast: the kernels convert in place)
     rows = d["N"] * d["Lq"] * d["M"]
     v = d["N"] * d["S"] * d["M"] * d["D"]
     o = rows * d["D"]
     lp = rows * d["L"] * d["P"]
     ce = 4 if e == 2 else e
     if not bwd:
-        return e * (v + o) + ce * 3 * lp
+        return e * v + re * o + ce * 3 * lp
     ge = 4 if e == 2 else e            # grad_value accumulates in f32 for bf16 inputs
-    return e * (v + o) + ge * v + ce * 6 * lp
+    return e * v + re * o + ge * v + ce * 6 * lp
 
 
 def cpu_baseline(a, budget_s=40.0):

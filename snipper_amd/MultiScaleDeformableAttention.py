@@ -119,7 +119,8 @@ def ms_deform_attn_forward(value: torch.Tensor, spatial_shapes: torch.Tensor,
              f"sampling_loc/attn_weight must be {cd} for {value.dtype} value")
     N, S, M, D, L, Lq, P = _dims(value, spatial_shapes, sampling_loc, attn_weight)
     lib = _lib.load()
-    dims = dict(N=N, S=S, M=M, D=D, L=L, Lq=Lq, P=P, esize=value.element_size())
+    dims = dict(N=N, S=S, M=M, D=D, L=L, Lq=Lq, P=P, esize=value.element_size(),
+                row_esize=2 if (out_bf16 and value.dtype == torch.float32) else value.element_size())
     if out_bf16 and value.dtype == torch.float32:
         out = torch.empty((N, Lq, M * D), dtype=torch.bfloat16, device=value.device)
         with torch.cuda.device(value.device), _Timed("fwd", dims, value.device):
@@ -167,7 +168,8 @@ def ms_deform_attn_backward(value: torch.Tensor, spatial_shapes: torch.Tensor,
     grad_loc = torch.empty_like(sampling_loc)
     grad_attn = torch.empty_like(attn_weight)
     lib = _lib.load()
-    dims = dict(N=N, S=S, M=M, D=D, L=L, Lq=Lq, P=P, esize=value.element_size())
+    dims = dict(N=N, S=S, M=M, D=D, L=L, Lq=Lq, P=P, esize=value.element_size(),
+                row_esize=grad_output.element_size())
     with torch.cuda.device(value.device), _Timed("bwd", dims, value.device):
         ws_bytes, hs_p, rc = 0, None, None
         if host_shapes is not None and value.dtype == torch.float32 and len(host_shapes) == L:
