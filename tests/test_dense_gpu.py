@@ -173,13 +173,13 @@ def test_big_linear_matches_module(relu, xdtype):
     assert rel(db, dbd) <= max(2e-3, 1.5 * rel(dbr, dbd)), (rel(db, dbd), rel(dbr, dbd))
 
 
-def test_big_linear_small_inputs_use_pytorch():
+def test_big_linear_small_inputs_match_pytorch():
     from snipper_amd.dense import big_linear
     lin = torch.nn.Linear(384, 96).to(DEV)
     x = torch.randn(4, 60, 384, device=DEV)
     with torch.autocast("cuda", dtype=torch.bfloat16):
         assert torch.equal(big_linear(x, lin), lin(x))
-    assert torch.equal(big_linear(x, lin), lin(x))          # no autocast: float32 module semantics
+    torch.testing.assert_close(big_linear(x, lin), lin(x), rtol=1e-6, atol=1e-6)   # no autocast: float32 module semantics
 
 
 def test_linear_dropout_epilogue_and_backward():
@@ -208,3 +208,19 @@ def test_linear_dropout_epilogue_and_backward():
     want = torch.where(y1 > 0, gy.float() / (1 - p), torch.zeros_like(y1))
     assert torch.allclose(got, want, rtol=1e-2, atol=1e-3)
     assert torch.equal(_relu_dropout_backward(gy, plain.bfloat16(), 0.0), torch.ops.aten.threshold_backward(gy, plain.bfloat16(), 0))
+
+
+def test_small_linear_equals_module():
+    """The decoder-size float32 path of big_linear: same output and gradients as nn.Linear."""
+    from snipper_amd.dense import big_linear
+    torch.manual_seed(4)
+    lin = torch.nn.Linear(384, 1024).to(DEV)
+    x = torch.randn(2, 4, 60, 384, device=DEV, requires_grad=True)
+    gy = torch.randn(2, 4, 60, 1024, device=DEV)
+    y = big_linear(x, lin)
+    g1 = torch.autograd.grad(y, (x, lin.weight, lin.bias), gy)
+    yr = lin(x)
+    g2 = torch.autograd.grad(yr, (x, lin.weight, lin.bias), gy)
+    torch.testing.assert_close(y, yr, rtol=1e-5, atol=1e-5)
+    for a, b in zip(g1, g2):
+        torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-4)
