@@ -9,6 +9,7 @@ ap.add_argument("trace")
 ap.add_argument("--delim", default="FusedAdam")
 ap.add_argument("--steps", type=int, default=4)
 ap.add_argument("--top", type=int, default=25)
+ap.add_argument("--csv", default=None, help="write the last step's per-kernel totals here")
 ap.add_argument("--region", type=float, nargs=2, default=None, help="ms range of the last step to list kernels for")
 a = ap.parse_args()
 rows = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(open(a.trace))]
@@ -49,6 +50,11 @@ for si in range(max(1, len(ends) - a.steps), len(ends)):
         for s_, e_, k in seg:
             agg[k][0] += 1
             agg[k][1] += e_ - s_
+        if a.csv:
+            w = csv.writer(open(a.csv, "w"))
+            w.writerow(["kernel", "dispatches_per_step", "total_ns_per_step", "avg_ns", f"step_wall_ns={wall}", f"step_busy_ns={busy}"])
+            for k, (n, t) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+                w.writerow([k, n, t, round(t / n, 1)])
         print("kernels of the last step by time:")
         for k, (n, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:45]:
             print(f"   {t/1e6:6.2f} ms {n:5d} x {t/n/1e3:8.1f}us  {short(k)}")
