@@ -108,7 +108,12 @@ class _PointwiseConvBN(torch.autograd.Function):
     def forward(ctx, x2, weight, scale, shift, res2, relu):
         from .dense import linear_bf16
         cout, cin = weight.shape[0], weight.shape[1]
-        w_eff = (weight.reshape(cout, cin).float() * scale[:, None]).to(torch.bfloat16)
+        from . import shadow
+        w_eff = shadow.lookup(weight)                   # bf16(weight * scale), refreshed once per step for the model
+        if w_eff is not None:
+            w_eff = w_eff.view(cout, cin)
+        else:
+            w_eff = (weight.reshape(cout, cin).float() * scale[:, None]).to(torch.bfloat16)
         y = linear_bf16(x2, w_eff, shift, res2, relu)
         ctx.relu, ctx.has_res = relu, res2 is not None
         ctx.wshape, ctx.wdtype, ctx.wstride = weight.shape, weight.dtype, weight.stride()
@@ -149,7 +154,10 @@ class _Conv3x3BN(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, scale, shift, stride, relu):
         from .dense import conv3x3_bf16
-        w_eff = (weight.float() * scale.view(-1, 1, 1, 1)).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        from . import shadow
+        w_eff = shadow.lookup(weight)
+        if w_eff is None or not w_eff.is_contiguous(memory_format=torch.channels_last):
+            w_eff = (weight.float() * scale.view(-1, 1, 1, 1)).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
         y = conv3x3_bf16(x, w_eff, shift, stride, relu)
         ctx.stride, ctx.relu, ctx.wdtype = stride, relu, weight.dtype
         ctx.save_for_backward(x, w_eff, scale, y if relu else None)

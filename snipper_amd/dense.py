@@ -116,7 +116,10 @@ class _BigLinear(torch.autograd.Function):
         n_out, k_in = weight.shape
         x2 = x.reshape(-1, k_in)
         xb = x2 if x2.dtype == torch.bfloat16 else x2.to(torch.bfloat16)
-        wb = weight if weight.dtype == torch.bfloat16 else weight.to(torch.bfloat16)
+        from . import shadow
+        wb = weight if weight.dtype == torch.bfloat16 else shadow.lookup(weight)
+        if wb is None:
+            wb = weight.to(torch.bfloat16)
         assert dropout_p == 0.0 or relu, "epilogue dropout is implemented for the ReLU layer only"
         seed = 0
         if dropout_p > 0.0:
@@ -247,6 +250,46 @@ def big_linear_merged(x: torch.Tensor, lins) -> Optional[torch.Tensor]:
             x.dtype in (torch.bfloat16, torch.float32) and
             all(l.in_features == k and l.out_features % 8 == 0 and l.bias is not None for l in lins)):
         return None
+    if len(lins) == 2:
+        return _BigLinearPair.apply(x, lins[0].weight, lins[0].bias, lins[1].weight, lins[1].bias, lins[0], lins[1])
     weight = torch.cat([l.weight for l in lins], 0)
     bias = torch.cat([l.bias for l in lins], 0)
     return _BigLinear.apply(x, weight, bias, False, 0.0)
+
+
+class _BigLinearPair(torch.autograd.Function):
+    """cat([x @ Wa^T + ba, x @ Wb^T + bb], -1) as one projection (see big_linear_merged); the merged bf16 weight and
+    bias come from the per-step shadows when they are valid, and the gradients go back to the four parameters as
+    slices of one weight-gradient launch."""
+
+    @staticmethod
+    def forward(ctx, x, wa, ba, wb_, bb, lin_a, lin_b):
+        from . import shadow
+        k_in = wa.shape[1]
+        x2 = x.reshape(-1, k_in)
+        xb = x2 if x2.dtype == torch.bfloat16 else x2.to(torch.bfloat16)
+        m = shadow.lookup_merged(lin_a, lin_b)
+        if m is not None:
+            w16, bias = m
+        else:
+            w16 = torch.cat([wa, wb_], 0).to(torch.bfloat16)
+            bias = torch.cat([ba, bb], 0).float()
+        y = linear_bf16(xb, w16, bias)
+        ctx.na, ctx.x_shape = wa.shape[0], x.shape
+        ctx.dts = (wa.dtype, ba.dtype, wb_.dtype, bb.dtype)
+        ctx.save_for_backward(xb, w16)
+        return y.view(*x.shape[:-1], w16.shape[0])
+
+    @staticmethod
+    def backward(ctx, gy):
+        xb, w16 = ctx.saved_tensors
+        g = gy.reshape(-1, w16.shape[0])
+        if g.dtype != torch.bfloat16:
+            g = g.to(torch.bfloat16)
+        g = g.contiguous()
+        dx = torch.mm(g, w16).view(ctx.x_shape) if ctx.needs_input_grad[0] else None
+        dW, db = wgrad_bf16(g, xb, want_bias=True)
+        na = ctx.na
+        outs = [dW[:na], db[:na], dW[na:], db[na:]]
+        outs = [o if o.dtype == dt else o.to(dt) for o, dt in zip(outs, ctx.dts)]
+        return (dx, *outs, None, None)

@@ -263,7 +263,9 @@ class InputProjTokens(Function):
             w, bias, gamma, beta = params[4 * l: 4 * l + 4]
             h, wd = hws[l]
             x2 = f.permute(0, 2, 3, 1).reshape(n * h * wd, f.shape[1])          # NHWC rows (a view)
-            wb = w.reshape(C, -1).to(torch.bfloat16)
+            from . import shadow
+            wb = shadow.lookup(w)
+            wb = wb.view(C, -1) if wb is not None else w.reshape(C, -1).to(torch.bfloat16)
             y = linear_bf16(x2, wb, bias.float())                               # [n*hw, C] bf16
             stats = torch.empty((n, groups, 2), dtype=torch.float32, device=dev)
             nbytes = lib.snipper_groupnorm_tokens_workspace_bytes(n, h * wd, C, groups)

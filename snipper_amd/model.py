@@ -79,6 +79,13 @@ class SnipperDeformable(nn.Module):
     def forward(self, samples):
         if not isinstance(samples, NestedTensor):
             samples = nested_tensor_from_tensor_list(samples)
+        if samples.tensors.is_cuda and torch.is_grad_enabled() and torch.is_autocast_enabled('cuda'):
+            # bf16 working copies of the weights (BN scale folded in for the backbone): a few multi-tensor launches
+            # here instead of 2-3 tiny ones at every layer (snipper_amd/shadow.py)
+            from .shadow import WeightShadows
+            if getattr(self, "_shadows", None) is None:
+                object.__setattr__(self, "_shadows", WeightShadows(self))
+            self._shadows.refresh()
         fast = self._forward_tokens(samples)
         if fast is not None:
             hs, heatmaps, init_reference, inter_references, inter_att = fast

@@ -1,0 +1,138 @@
+"""bf16 working copies ("shadows") of the weights the hand-written kernels consume.
+
+The parameters stay float32 (the optimizer's master copy); every kernel that multiplies by a weight wants it in bf16,
+and the frozen-BatchNorm convolutions want it pre-multiplied by the BN scale (backbone.conv_frozen_bn).  Doing that
+where the weight is used costs 2-3 tiny launches per layer and step -- ~190 for the 52 convolutions and ~50 for the
+encoder's Linears.  ``WeightShadows.refresh()`` does it for the whole model with a handful of multi-tensor launches
+at the start of a forward pass:
+
+    conv + frozen BN :  shadow = bf16(weight * scale[:, None, None, None])      (same shape and strides as the weight)
+    Linear           :  shadow = bf16(weight)
+    merged Linears   :  shadow = bf16([W_a; W_b]) in one buffer, bias = [b_a; b_b] (the offset + logit projections)
+
+A shadow is valid while the parameter's version counter is unchanged (the optimizer's in-place update bumps it), so
+frozen layers are converted once.  Consumers call ``lookup(param)`` and fall back to converting on the spot when there
+is no valid shadow -- results are identical either way.
+"""
+from __future__ import annotations
+
+import weakref
+from typing import Dict, List, Optional, Tuple
+
+import torch
+from torch import nn
+
+_entries: Dict[int, "_Entry"] = {}
+_merged: Dict[Tuple[int, int], "_Merged"] = {}
+
+
+class _Entry:
+    __slots__ = ("ref", "dst", "scale", "version")
+
+    def __init__(self, param, dst, scale=None):
+        self.ref, self.dst, self.scale, self.version = weakref.ref(param), dst, scale, -1
+
+
+class _Merged:
+    __slots__ = ("refs", "w", "b", "versions")
+
+    def __init__(self, params, w, b):
+        self.refs, self.w, self.b, self.versions = [weakref.ref(p) for p in params], w, b, None
+
+
+def lookup(param: torch.Tensor) -> Optional[torch.Tensor]:
+    e = _entries.get(id(param))
+    if e is not None and e.ref() is param and e.version == param._version and e.dst.device == param.device:
+        return e.dst
+    return None
+
+
+def lookup_merged(lin_a: nn.Linear, lin_b: nn.Linear):
+    m = _merged.get((id(lin_a.weight), id(lin_b.weight)))
+    if m is None:
+        return None
+    ps = [lin_a.weight, lin_a.bias, lin_b.weight, lin_b.bias]
+    if all(r() is p for r, p in zip(m.refs, ps)) and m.versions == [p._version for p in ps] and m.w.device == ps[0].device:
+        return m.w, m.b
+    return None
+
+
+class WeightShadows:
+    def __init__(self, model: nn.Module):
+        from .backbone import Bottleneck
+        from .deformable_transformer import DeformableTransformerEncoderLayer
+        from .ms_deform_attn import MSDeformAttn
+        self.convs: List[Tuple[nn.Conv2d, nn.Module]] = []
+        self.linears: List[nn.Linear] = []
+        self.pairs: List[Tuple[nn.Linear, nn.Linear]] = []
+        for mod in model.modules():
+            if isinstance(mod, Bottleneck):
+                self.convs += [(mod.conv1, mod.bn1), (mod.conv2, mod.bn2), (mod.conv3, mod.bn3)]
+                if mod.downsample is not None:
+                    self.convs.append((mod.downsample[0], mod.downsample[1]))
+            elif isinstance(mod, MSDeformAttn):
+                self.linears += [mod.value_proj, mod.output_proj]
+                if mod.weights_are_tied():
+                    self.pairs.append((mod.sampling_offsets[0], mod.attention_weights[0]))
+            elif isinstance(mod, DeformableTransformerEncoderLayer):
+                self.linears += [mod.linear1, mod.linear2]
+        for proj in getattr(model, "input_proj", []):
+            if isinstance(proj, nn.Sequential) and isinstance(proj[0], nn.Conv2d):
+                self.linears.append(proj[0])                     # a 1x1 convolution's weight is used as [Cout, Cin]
+
+    @torch.no_grad()
+    def refresh(self) -> None:
+        """Bring every stale shadow up to date (multi-tensor launches; nothing to do for unchanged parameters)."""
+        mul_src, mul_scale, mul_dst, cp_src, cp_dst = [], [], [], [], []
+        for conv, bn in self.convs:
+            w = conv.weight
+            if not (w.is_cuda and w.dtype == torch.float32):
+                continue
+            e = _entries.get(id(w))
+            if e is None or e.ref() is not w or e.dst.device != w.device:
+                e = _entries[id(w)] = _Entry(w, torch.empty_like(w, dtype=torch.bfloat16), None)
+            scale = bn.scale_bias()[0]
+            if e.version != w._version or e.scale is not scale:
+                mul_src.append(w)
+                mul_scale.append(scale.view(-1, 1, 1, 1))
+                mul_dst.append(e)
+                e.scale = scale
+        for lin in self.linears:
+            w = lin.weight
+            if not (w.is_cuda and w.dtype == torch.float32):
+                continue
+            e = _entries.get(id(w))
+            if e is None or e.ref() is not w or e.dst.device != w.device:
+                e = _entries[id(w)] = _Entry(w, torch.empty_like(w, dtype=torch.bfloat16))
+            if e.version != w._version:
+                cp_src.append(w)
+                cp_dst.append(e)
+        fin = []
+        for a, b in self.pairs:
+            ps = [a.weight, a.bias, b.weight, b.bias]
+            if not all(p is not None and p.is_cuda and p.dtype == torch.float32 for p in ps):
+                continue
+            key = (id(a.weight), id(b.weight))
+            m = _merged.get(key)
+            if m is None or any(r() is not p for r, p in zip(m.refs, ps)) or m.w.device != ps[0].device:
+                na, nb, k = a.out_features, b.out_features, a.in_features
+                m = _merged[key] = _Merged(ps, torch.empty((na + nb, k), dtype=torch.bfloat16, device=ps[0].device),
+                                           torch.empty((na + nb,), dtype=torch.float32, device=ps[0].device))
+            vers = [p._version for p in ps]
+            if m.versions != vers:
+                na = a.out_features
+                cp_src += [a.weight, b.weight, a.bias, b.bias]
+                cp_dst += [m.w[:na], m.w[na:], m.b[:na], m.b[na:]]
+                fin.append((m, vers))
+        if mul_src:
+            tmp = torch._foreach_mul(mul_src, mul_scale)
+            torch._foreach_copy_([e.dst for e in mul_dst], tmp)
+            for e, w in zip(mul_dst, mul_src):
+                e.version = w._version
+        if cp_src:
+            torch._foreach_copy_([d.dst if isinstance(d, _Entry) else d for d in cp_dst], cp_src)
+            for d, w in zip(cp_dst, cp_src):
+                if isinstance(d, _Entry):
+                    d.version = w._version
+        for m, vers in fin:
+            m.versions = vers
