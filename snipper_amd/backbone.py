@@ -127,7 +127,8 @@ class _PointwiseConvBN(torch.autograd.Function):
         g = gy.contiguous()
         if ctx.relu:
             g = torch.ops.aten.threshold_backward(g, y, 0)
-        dx = linear_bf16(g, w_eff.t().contiguous()) if ctx.needs_input_grad[0] else None
+        from .dense import _dgrad
+        dx = _dgrad(g, w_eff) if ctx.needs_input_grad[0] else None
         dw = None
         if ctx.needs_input_grad[1]:
             from .dense import wgrad_bf16

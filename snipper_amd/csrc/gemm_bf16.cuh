@@ -153,6 +153,116 @@ __global__ __launch_bounds__(kGemmThreads) void linear_bf16_kernel(GemmArgs g) {
   }
 }
 
+// ---- data gradient: Y[M,N] = X[M,K] . W[K,N]  (W row-major with the REDUCTION index as its slow axis) ------------
+// dX = dY . W for a Linear / 1x1 convolution whose weight is stored [out, in] = [K, N]: the kernel above would need
+// W transposed.  Here the W tile is staged as it lies in memory ([k][n], 16-byte loads along n) and the MFMA operand
+// is read with ds_read_b64_tr_b16 (the transposing LDS read, see wgrad_bf16.cuh): lane group g receives k-rows
+// {4g..4g+3} and {16+4g..16+4g+3} of each 32-step; the X operand is read in the SAME k order (two 8-byte reads
+// instead of one 16-byte read), so the products pair up correctly.  No epilogue besides the bf16 rounding.
+typedef __attribute__((__vector_size__(4 * sizeof(__bf16)))) __bf16 gemm_bf16x4;
+constexpr int kGemmTrStride = 144;       // [64 k][128 n + 16]: 288-byte rows, conflict-free transposed reads
+
+struct GemmNNArgs {
+  const uint16_t *X; long long ldx;      // [M][K]
+  const uint16_t *W; long long ldw;      // [K][N]
+  uint16_t *Y; long long ldy;            // [M][N]
+  int M, N, K;
+};
+
+__device__ __forceinline__ gemm_bf16x8 gemm_tr_frag(const uint16_t *tile, int byte_off) {
+  typedef __attribute__((address_space(3))) gemm_bf16x4 lds_v4;
+  const char *base = reinterpret_cast<const char *>(tile) + byte_off;
+  const gemm_bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4 *)(base));
+  const gemm_bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4 *)(base + 16 * kGemmTrStride * 2));
+  return gemm_bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+__global__ __launch_bounds__(kGemmThreads) void linear_bf16_nn_kernel(GemmNNArgs g) {
+  __shared__ __attribute__((aligned(16))) uint16_t Xs[kGemmBM * kGemmPad];
+  __shared__ __attribute__((aligned(16))) uint16_t Ws[kGemmBK * kGemmTrStride];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave & 1, wn = wave >> 1;
+  const int m0 = blockIdx.x * kGemmBM, n0 = blockIdx.y * kGemmBN;
+
+  const uint16_t *xp[4], *wp[4];
+  int x_off[4], w_off[4];
+  bool w_ok[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int idx = tid + kGemmThreads * i;
+    const int row = idx >> 3, kc = idx & 7;                 // X: 128 rows x 8 chunks of 8 k
+    xp[i] = g.X + (long long)min(m0 + row, g.M - 1) * g.ldx + kc * 8;
+    x_off[i] = row * kGemmPad + kc * 8;
+    const int krow = idx >> 4, nc = idx & 15;               // W: 64 k-rows x 16 chunks of 8 n
+    w_ok[i] = n0 + nc * 8 < g.N;
+    wp[i] = g.W + (long long)krow * g.ldw + n0 + nc * 8;
+    w_off[i] = krow * kGemmTrStride + nc * 8;
+  }
+  const gemm_u32x4 zero4 = {0u, 0u, 0u, 0u};
+  gemm_u32x4 xr[4], wr[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    xr[i] = *reinterpret_cast<const gemm_u32x4 *>(xp[i]);
+    wr[i] = w_ok[i] ? *reinterpret_cast<const gemm_u32x4 *>(wp[i]) : zero4;
+  }
+  gemm_f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = gemm_f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int grp = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+  const int tr_base = ((grp * 4 + q) * kGemmTrStride + 4 * p) * 2;       // bytes (transposed W reads)
+  const int frag_row = lane & 15;
+  for (int k0 = 0; k0 < g.K; k0 += kGemmBK) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      *reinterpret_cast<gemm_u32x4 *>(Xs + x_off[i]) = xr[i];
+      *reinterpret_cast<gemm_u32x4 *>(Ws + w_off[i]) = wr[i];
+    }
+    __syncthreads();
+    if (k0 + kGemmBK < g.K) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        xr[i] = *reinterpret_cast<const gemm_u32x4 *>(xp[i] + k0 + kGemmBK);
+        wr[i] = w_ok[i] ? *reinterpret_cast<const gemm_u32x4 *>(wp[i] + (long long)(k0 + kGemmBK) * g.ldw) : zero4;
+      }
+    }
+#pragma unroll
+    for (int kk = 0; kk < kGemmBK; kk += 32) {
+      gemm_bf16x8 wf[4], xf[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        wf[i] = gemm_tr_frag(Ws, tr_base + (kk * kGemmTrStride + wn * 64 + i * 16) * 2);
+        const uint16_t *xrow = Xs + (wm * 64 + i * 16 + frag_row) * kGemmPad + kk + grp * 4;
+        const gemm_bf16x4 lo = *reinterpret_cast<const gemm_bf16x4 *>(xrow);
+        const gemm_bf16x4 hi = *reinterpret_cast<const gemm_bf16x4 *>(xrow + 16);
+        xf[i] = gemm_bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int n = n0 + wn * 64 + i * 16 + (lane >> 4) * 4;
+    if (n >= g.N) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int m = m0 + wm * 64 + j * 16 + (lane & 15);
+      if (m >= g.M) continue;
+      uint2 o;
+      o.x = gemm_pack2(acc[i][j].x, acc[i][j].y);
+      o.y = gemm_pack2(acc[i][j].z, acc[i][j].w);
+      *reinterpret_cast<uint2 *>(g.Y + (long long)m * g.ldy + n) = o;
+    }
+  }
+}
+
 // Backward of (ReLU -> dropout) given only the layer's OUTPUT y: a kept, active element has y > 0, a dropped or
 // inactive one y == 0, so  dL/dpre = y > 0 ? g * scale : 0  (scale = 1 / (1 - p); p = 0: plain ReLU backward).
 // bf16 in / out, 8 elements per thread.

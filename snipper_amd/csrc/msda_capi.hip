@@ -435,6 +435,18 @@ int snipper_linear_bf16(void *stream, const uint16_t *X, long long ldx, const ui
   return launch_status();
 }
 
+int snipper_linear_nn_bf16(void *stream, const uint16_t *X, long long ldx, const uint16_t *W, long long ldw,
+                           uint16_t *Y, long long ldy, int M, int N, int K) {
+  if (!X || !W || !Y) return SNIPPER_E_NULL;
+  if (M <= 0 || N <= 0 || K <= 0 || K % kGemmBK || N % 8 || ldx % 8 || ldw % 8 || ldy % 4 || ldx < K || ldw < N || ldy < N)
+    return SNIPPER_E_SHAPE;
+  if (((uintptr_t)X | (uintptr_t)W) & 15) return SNIPPER_E_SHAPE;
+  const GemmNNArgs g{X, ldx, W, ldw, Y, ldy, M, N, K};
+  const dim3 grid((M + kGemmBM - 1) / kGemmBM, (N + kGemmBN - 1) / kGemmBN);
+  hipLaunchKernelGGL(linear_bf16_nn_kernel, grid, dim3(kGemmThreads), 0, (hipStream_t)stream, g);
+  return launch_status();
+}
+
 int snipper_relu_dropout_backward_bf16(void *stream, const uint16_t *grad_y, const uint16_t *y, uint16_t *grad_pre,
                                        long long n, float dropout_p) {
   if (!grad_y || !y || !grad_pre) return SNIPPER_E_NULL;

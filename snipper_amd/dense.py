@@ -67,6 +67,33 @@ def conv3x3_bf16(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Ten
     return out
 
 
+def linear_nn_bf16(x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+    """x [M, K] @ w [K, N] (both bf16, row-major; w = a Linear's weight [out, in] used for the data gradient) on the
+    HIP kernel that reads the weight tile through the transposing LDS read -- no transposed copy of w."""
+    assert x.is_cuda and x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and x.dim() == 2 and w.dim() == 2
+    assert x.shape[1] == w.shape[0]
+    if x.stride(1) != 1 or x.stride(0) % 8 or x.data_ptr() % 16:
+        x = x.contiguous()
+    if w.stride(1) != 1 or w.stride(0) % 8 or w.data_ptr() % 16:
+        w = w.contiguous()
+    M, K = x.shape
+    N = w.shape[1]
+    out = torch.empty((M, N), dtype=torch.bfloat16, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = _lib.load().snipper_linear_nn_bf16(
+            torch.cuda.current_stream(x.device).cuda_stream, x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0),
+            out.data_ptr(), out.stride(0), M, N, K)
+    _lib.check(rc, "snipper_linear_nn_bf16")
+    return out
+
+
+def _dgrad(g: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+    """g [M, out] @ w [out, in]: own kernel when the shape allows (out % 64 == 0, in % 8 == 0), hipBLASLt otherwise."""
+    if w.shape[0] % 64 == 0 and w.shape[1] % 8 == 0 and g.shape[0] >= 256:
+        return linear_nn_bf16(g, w)
+    return torch.mm(g, w)
+
+
 def wgrad_bf16(g: torch.Tensor, x: torch.Tensor, want_bias: bool = True, scale: Optional[torch.Tensor] = None,
                out: Optional[torch.Tensor] = None, out_bias: Optional[torch.Tensor] = None, accumulate: bool = False):
     """Weight / bias gradient of ``y = x @ W^T + b`` on the split-reduction MFMA kernel (csrc/wgrad_bf16.cuh).
@@ -142,7 +169,7 @@ class _BigLinear(torch.autograd.Function):
         g = g.contiguous()
         if ctx.relu:
             g = _relu_dropout_backward(g, y, ctx.drop_p)
-        dx = torch.mm(g, wb).view(ctx.x_shape) if ctx.needs_input_grad[0] else None
+        dx = _dgrad(g, wb).view(ctx.x_shape) if ctx.needs_input_grad[0] else None
         dW = db = None
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             dW, db = wgrad_bf16(g, xb, want_bias=ctx.has_bias and ctx.needs_input_grad[2])
@@ -287,7 +314,7 @@ class _BigLinearPair(torch.autograd.Function):
         if g.dtype != torch.bfloat16:
             g = g.to(torch.bfloat16)
         g = g.contiguous()
-        dx = torch.mm(g, w16).view(ctx.x_shape) if ctx.needs_input_grad[0] else None
+        dx = _dgrad(g, w16).view(ctx.x_shape) if ctx.needs_input_grad[0] else None
         dW, db = wgrad_bf16(g, xb, want_bias=True)
         na = ctx.na
         outs = [dW[:na], db[:na], dW[na:], db[na:]]

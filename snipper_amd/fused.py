@@ -312,7 +312,8 @@ class InputProjTokens(Function):
             _lib.check(rc, "snipper_groupnorm_tokens_backward")
             dfeat = None
             if ctx.needs_input_grad[5 + l]:
-                dx2 = linear_bf16(dy, wb.t().contiguous())                      # [n*hw, Cin]
+                from .dense import _dgrad
+                dx2 = _dgrad(dy, wb)                                            # [n*hw, Cin]
                 dfeat = dx2.view(n, h, wd, -1).permute(0, 3, 1, 2)              # logical NCHW, NHWC memory
             dW, db = wgrad_bf16(dy, x2, want_bias=True)
             shapes, dts = pshapes[4 * l: 4 * l + 4], pdtypes[4 * l: 4 * l + 4]

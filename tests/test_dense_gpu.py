@@ -224,3 +224,18 @@ def test_small_linear_equals_module():
     torch.testing.assert_close(y, yr, rtol=1e-5, atol=1e-5)
     for a, b in zip(g1, g2):
         torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("M,K,N", [(79000, 384, 384), (79000, 1024, 384), (79000, 384, 1024), (79000, 320, 384),
+                                   (60000, 128, 512), (300, 64, 8), (129, 192, 136)])
+def test_linear_nn_kernel(M, K, N):
+    """Data-gradient GEMM (weight read through the transposing LDS read) against float64 on the same bf16 operands."""
+    from snipper_amd.dense import linear_nn_bf16
+    g = torch.Generator().manual_seed(M + K + N)
+    x = torch.randn(M, K, generator=g).to(DEV).bfloat16()
+    w = (torch.randn(K, N, generator=g) / K ** 0.5).to(DEV).bfloat16()
+    y = linear_nn_bf16(x, w)
+    ref = x.double() @ w.double()
+    err = (y.double() - ref).abs().max().item()
+    assert err <= 2e-2 * max(1.0, ref.abs().max().item()), err
+    assert ((y.double() - ref).norm() / ref.norm()).item() < 4e-3
