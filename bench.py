@@ -268,6 +268,9 @@ def main():
     from snipper_amd import _lib
     from snipper_amd.model import build_model
     _lib.load()                                                   # fail loudly if the HIP library is missing
+    for kv in filter(None, os.environ.get("SNIPPER_PARAMS", "").split(",")):   # tuning knobs (development aid)
+        k, v = kv.split("=")
+        _lib.set_param(k.strip(), float(v))
 
     torch.manual_seed(42 + rank)                                  # main.py:48,175
     margs = model_args(a)
