@@ -223,12 +223,8 @@ int backward_d48_owner_f32(hipStream_t st, const float *grad_out, const float *v
   const int nblk = (int)((rows + kRows - 1) / kRows);
   const int nblk_padded = (nblk + 7) & ~7;
   const size_t lds = (size_t)kRows * (LP * sizeof(BinRecord) + 16);
-  if (LP == 12)
-    hipLaunchKernelGGL(msda_bwd_d48_bin_kernel<12>, dim3(nblk_padded), dim3(kD48Block), lds, st, grad_out, value, loc,
-                       attn, d, plan, grad_value, grad_loc, grad_attn, nblk_padded, go_bf16);
-  else
-    hipLaunchKernelGGL(msda_bwd_d48_bin_kernel<0>, dim3(nblk_padded), dim3(kD48Block), lds, st, grad_out, value, loc,
-                       attn, d, plan, grad_value, grad_loc, grad_attn, nblk_padded, go_bf16);
+  hipLaunchKernelGGL(msda_bwd_d48_bin_kernel, dim3(nblk_padded), dim3(kD48Block), lds, st, grad_out, value, loc,
+                     attn, d, plan, grad_value, grad_loc, grad_attn, nblk_padded, go_bf16);
   if (int rc = launch_status()) return rc;
   // 2) every tile adds what it owns
   const long long nblk_tiles = nm * plan.total_tiles;

@@ -104,7 +104,6 @@ __device__ __forceinline__ int quad_max(int v) {
   return max(v, __shfl_xor(v, 2, 4));
 }
 
-template <int LP_T>     // L*P when known at compile time (12 for Snipper), 0 = runtime
 __global__ __launch_bounds__(kD48Block) void msda_bwd_d48_bin_kernel(
     const float *__restrict__ grad_out, const float *__restrict__ value,
     const float *__restrict__ loc, const float *__restrict__ attn, CoreDims d, OwnerPlan plan,
@@ -112,7 +111,7 @@ __global__ __launch_bounds__(kD48Block) void msda_bwd_d48_bin_kernel(
     int nblk_padded, int go_bf16) {
   constexpr int G = 16, kRows = kD48Block / G;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  const int LP = LP_T ? LP_T : d.L * kOwnerP;
+  const int LP = d.L * kOwnerP;     // runtime on purpose: see the unroll note below
   const int rec_stride = LP * (int)sizeof(BinRecord) + 16;
   const int grp = threadIdx.x / G, lane = threadIdx.x % G;
   const long long total_rows = (long long)d.N * d.Lq * d.M;
@@ -211,7 +210,8 @@ __global__ __launch_bounds__(kD48Block) void msda_bwd_d48_bin_kernel(
   float keep_a = 0.f, keep_x = 0.f, keep_y = 0.f;
   // Pass 1 (branch-free, so the loads of several samples overlap): grad_attn / grad_loc of every sample.
   unsigned any_need = 0u;
-#pragma unroll 4      // (full unrolling of the 12 samples: 139 VGPRs, 3 waves/SIMD, measured 20 % slower)
+#pragma unroll 4      // (a compile-time trip count makes the compiler unroll all 12 samples: 139 VGPRs, 3 waves/SIMD,
+                      //  measured 20 % slower than this 63-VGPR form)
   for (int s = 0; s < LP; ++s) {
     const BinRecord r = *reinterpret_cast<const BinRecord *>(my_recs + s * sizeof(BinRecord));
     const float lh = r.q0.x, lw = r.q0.y;
