@@ -23,6 +23,22 @@
 
 namespace snipper {
 
+// Workgroup -> (M tile, N tile) for a 1-D grid of tiles_m * tiles_n workgroups.  Consecutive workgroup ids go
+// round-robin over the 8 XCDs, each with its own L2; the N tiles of one M tile all read the same X rows, so they are
+// given to ONE XCD back to back: the first fetches the X tile from HBM, the others hit that XCD's L2.  (With the
+// plain (M tile, N tile) = (blockIdx.x, blockIdx.y) order X came from HBM once per N tile: 3x for N = 384.)
+// The grid has tiles_n * 8 * ceil(tiles_m / 8) workgroups; those whose M tile does not exist return at once.
+__device__ __forceinline__ void gemm_tile_of_block(int tiles_n, int &tm, int &tn) {
+  const int b = blockIdx.x;
+  const int xcd = b & 7, j = b >> 3;
+  tm = xcd + 8 * (j / tiles_n);
+  tn = j % tiles_n;
+}
+inline unsigned gemm_grid_size(long long M, int N) {
+  const long long tiles_m = (M + 127) / 128, tiles_n = (N + 127) / 128;
+  return (unsigned)(tiles_n * 8 * ((tiles_m + 7) / 8));
+}
+
 typedef __attribute__((ext_vector_type(8))) __bf16 gemm_bf16x8;
 typedef __attribute__((ext_vector_type(4))) float gemm_f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned int gemm_u32x4;
@@ -60,7 +76,10 @@ __global__ __launch_bounds__(kGemmThreads) void linear_bf16_kernel(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) uint16_t Ws[kGemmBN * kGemmPad];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave & 1, wn = wave >> 1;
-  const int m0 = blockIdx.x * kGemmBM, n0 = blockIdx.y * kGemmBN;
+  int tm, tn;
+  gemm_tile_of_block((g.N + kGemmBN - 1) / kGemmBN, tm, tn);
+  if ((long long)tm * kGemmBM >= g.M) return;             // padding workgroups of the XCD-major grid
+  const int m0 = tm * kGemmBM, n0 = tn * kGemmBN;
 
   // loader: 4 x 16 B per operand per thread and K-step; row = idx / 8, 8-element chunk = idx % 8
   const uint16_t *xp[4], *wp[4];
@@ -182,7 +201,10 @@ __global__ __launch_bounds__(kGemmThreads) void linear_bf16_nn_kernel(GemmNNArgs
   __shared__ __attribute__((aligned(16))) uint16_t Ws[kGemmBK * kGemmTrStride];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave & 1, wn = wave >> 1;
-  const int m0 = blockIdx.x * kGemmBM, n0 = blockIdx.y * kGemmBN;
+  int tm, tn;
+  gemm_tile_of_block((g.N + kGemmBN - 1) / kGemmBN, tm, tn);
+  if ((long long)tm * kGemmBM >= g.M) return;
+  const int m0 = tm * kGemmBM, n0 = tn * kGemmBN;
 
   const uint16_t *xp[4], *wp[4];
   int x_off[4], w_off[4];
@@ -302,7 +324,10 @@ __global__ __launch_bounds__(kGemmThreads) void conv3x3_bf16_kernel(Conv3x3Args 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave & 1, wn = wave >> 1;
   const int M = g.B * g.Ho * g.Wo;
-  const int m0 = blockIdx.x * kGemmBM, n0 = blockIdx.y * kGemmBN;
+  int tm, tn;
+  gemm_tile_of_block((g.Cout + kGemmBN - 1) / kGemmBN, tm, tn);
+  if ((long long)tm * kGemmBM >= M) return;
+  const int m0 = tm * kGemmBM, n0 = tn * kGemmBN;
   const int kslices = g.Cin / kGemmBK, steps = 9 * kslices;
 
   int pb[4], py[4], px[4], kc8[4], lds_off[4];

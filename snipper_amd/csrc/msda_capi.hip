@@ -427,7 +427,7 @@ int snipper_linear_bf16(void *stream, const uint16_t *X, long long ldx, const ui
       (dropout_p > 0.f && (long long)M * N >= (1LL << 32)))
     return SNIPPER_E_SHAPE;
   const GemmArgs g{X, ldx, W, bias, R, ldr, Y, ldy, M, N, K, dropout_p, (uint32_t)seed, (uint32_t)(seed >> 32)};
-  const dim3 grid((M + kGemmBM - 1) / kGemmBM, (N + kGemmBN - 1) / kGemmBN);
+  const dim3 grid(gemm_grid_size(M, N));
   if (relu)
     hipLaunchKernelGGL(linear_bf16_kernel<true>, grid, dim3(kGemmThreads), 0, (hipStream_t)stream, g);
   else
@@ -442,7 +442,7 @@ int snipper_linear_nn_bf16(void *stream, const uint16_t *X, long long ldx, const
     return SNIPPER_E_SHAPE;
   if (((uintptr_t)X | (uintptr_t)W) & 15) return SNIPPER_E_SHAPE;
   const GemmNNArgs g{X, ldx, W, ldw, Y, ldy, M, N, K};
-  const dim3 grid((M + kGemmBM - 1) / kGemmBM, (N + kGemmBN - 1) / kGemmBN);
+  const dim3 grid(gemm_grid_size(M, N));
   hipLaunchKernelGGL(linear_bf16_nn_kernel, grid, dim3(kGemmThreads), 0, (hipStream_t)stream, g);
   return launch_status();
 }
@@ -618,7 +618,7 @@ int snipper_conv3x3_bf16(void *stream, const uint16_t *X, const uint16_t *W, con
   const long long M = (long long)B * Ho * Wo;
   if (M >= (1LL << 31)) return SNIPPER_E_SHAPE;
   const Conv3x3Args g{X, W, bias, Y, B, H, Wd, Cin, Cout, Ho, Wo, stride};
-  const dim3 grid((unsigned)((M + kGemmBM - 1) / kGemmBM), (Cout + kGemmBN - 1) / kGemmBN);
+  const dim3 grid(gemm_grid_size(M, Cout));
   if (relu)
     hipLaunchKernelGGL(conv3x3_bf16_kernel<true>, grid, dim3(kGemmThreads), 0, (hipStream_t)stream, g);
   else
