@@ -39,6 +39,26 @@ inline unsigned gemm_grid_size(long long M, int N) {
   return (unsigned)(tiles_n * 8 * ((tiles_m + 7) / 8));
 }
 
+// Output staging: the MFMA accumulator layout gives a lane 4 consecutive n of ONE row, so a direct store writes
+// 8-byte pieces of 16 different rows per instruction (32-byte runs in memory).  The finished bf16 tile is therefore
+// parked in LDS ([128][136], the operand buffers are free by then) and written out as whole 256-byte row segments,
+// 16 bytes per lane.  Needs N % 8 == 0, ldy % 8 == 0 and a 16-byte aligned Y; otherwise the direct stores are used.
+constexpr int kGemmCtStride = 136;
+__device__ __forceinline__ bool gemm_wide_ok(const uint16_t *Y, long long ldy, int N) {
+  return (N % 8) == 0 && (ldy % 8) == 0 && ((uintptr_t)Y % 16) == 0;
+}
+__device__ __forceinline__ void gemm_flush_tile(const uint16_t *Ct, uint16_t *Y, long long ldy, int m0, int n0, long long M, int N) {
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int idx = threadIdx.x + 256 * i, row = idx >> 4, ch = idx & 15;
+    const long long m = (long long)m0 + row;
+    const int n = n0 + ch * 8;
+    if (m < M && n < N)
+      *reinterpret_cast<uint4 *>(Y + m * ldy + n) = *reinterpret_cast<const uint4 *>(Ct + row * kGemmCtStride + ch * 8);
+  }
+}
+
 typedef __attribute__((ext_vector_type(8))) __bf16 gemm_bf16x8;
 typedef __attribute__((ext_vector_type(4))) float gemm_f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned int gemm_u32x4;
@@ -72,8 +92,8 @@ __device__ __forceinline__ unsigned gemm_pack2(float a, float b) {
 
 template <bool RELU>
 __global__ __launch_bounds__(kGemmThreads) void linear_bf16_kernel(GemmArgs g) {
-  __shared__ __attribute__((aligned(16))) uint16_t Xs[kGemmBM * kGemmPad];
-  __shared__ __attribute__((aligned(16))) uint16_t Ws[kGemmBN * kGemmPad];
+  __shared__ __attribute__((aligned(16))) uint16_t smem[(kGemmBM + kGemmBN) * kGemmPad];
+  uint16_t *Xs = smem, *Ws = smem + kGemmBM * kGemmPad;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave & 1, wn = wave >> 1;
   int tm, tn;
@@ -137,6 +157,7 @@ __global__ __launch_bounds__(kGemmThreads) void linear_bf16_kernel(GemmArgs g) {
   }
 
   // epilogue: lane holds n = nb + 4*(lane>>4) + r (r = 0..3) of output row m = mb + (lane & 15)
+  const bool wide = gemm_wide_ok(g.Y, g.ldy, g.N);
   const bool drop = g.drop_p > 0.f;
   const float keep_scale = drop ? 1.f / (1.f - g.drop_p) : 1.f;
   const uint32_t thresh = (uint32_t)fminf(g.drop_p * 4294967296.f, 4294967040.f);
@@ -167,9 +188,11 @@ __global__ __launch_bounds__(kGemmThreads) void linear_bf16_kernel(GemmArgs g) {
       uint2 o;
       o.x = gemm_pack2(v.x, v.y);
       o.y = gemm_pack2(v.z, v.w);
-      *reinterpret_cast<uint2 *>(g.Y + (long long)m * g.ldy + n) = o;
+      if (wide) *reinterpret_cast<uint2 *>(smem + (m - m0) * kGemmCtStride + (n - n0)) = o;
+      else *reinterpret_cast<uint2 *>(g.Y + (long long)m * g.ldy + n) = o;
     }
   }
+  if (wide) gemm_flush_tile(smem, g.Y, g.ldy, m0, n0, g.M, g.N);
 }
 
 // ---- data gradient: Y[M,N] = X[M,K] . W[K,N]  (W row-major with the REDUCTION index as its slow axis) ------------
@@ -197,8 +220,9 @@ __device__ __forceinline__ gemm_bf16x8 gemm_tr_frag(const uint16_t *tile, int by
 }
 
 __global__ __launch_bounds__(kGemmThreads) void linear_bf16_nn_kernel(GemmNNArgs g) {
-  __shared__ __attribute__((aligned(16))) uint16_t Xs[kGemmBM * kGemmPad];
-  __shared__ __attribute__((aligned(16))) uint16_t Ws[kGemmBK * kGemmTrStride];
+  __shared__ __attribute__((aligned(16))) uint16_t smem[kGemmBM * kGemmPad + kGemmBK * kGemmTrStride];
+  uint16_t *Xs = smem, *Ws = smem + kGemmBM * kGemmPad;
+  const bool wide = gemm_wide_ok(g.Y, g.ldy, g.N);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave & 1, wn = wave >> 1;
   int tm, tn;
@@ -280,9 +304,11 @@ __global__ __launch_bounds__(kGemmThreads) void linear_bf16_nn_kernel(GemmNNArgs
       uint2 o;
       o.x = gemm_pack2(acc[i][j].x, acc[i][j].y);
       o.y = gemm_pack2(acc[i][j].z, acc[i][j].w);
-      *reinterpret_cast<uint2 *>(g.Y + (long long)m * g.ldy + n) = o;
+      if (wide) *reinterpret_cast<uint2 *>(smem + (m - m0) * kGemmCtStride + (n - n0)) = o;
+      else *reinterpret_cast<uint2 *>(g.Y + (long long)m * g.ldy + n) = o;
     }
   }
+  if (wide) gemm_flush_tile(smem, g.Y, g.ldy, m0, n0, g.M, g.N);
 }
 
 // Backward of (ReLU -> dropout) given only the layer's OUTPUT y: a kept, active element has y > 0, a dropped or
@@ -319,8 +345,9 @@ struct Conv3x3Args {
 
 template <bool RELU>
 __global__ __launch_bounds__(kGemmThreads) void conv3x3_bf16_kernel(Conv3x3Args g) {
-  __shared__ __attribute__((aligned(16))) uint16_t Xs[kGemmBM * kGemmPad];
-  __shared__ __attribute__((aligned(16))) uint16_t Ws[kGemmBN * kGemmPad];
+  __shared__ __attribute__((aligned(16))) uint16_t smem[(kGemmBM + kGemmBN) * kGemmPad];
+  uint16_t *Xs = smem, *Ws = smem + kGemmBM * kGemmPad;
+  const bool wide = gemm_wide_ok(g.Y, g.Cout, g.Cout);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave & 1, wn = wave >> 1;
   const int M = g.B * g.Ho * g.Wo;
@@ -404,9 +431,11 @@ __global__ __launch_bounds__(kGemmThreads) void conv3x3_bf16_kernel(Conv3x3Args 
       uint2 o;
       o.x = gemm_pack2(v.x, v.y);
       o.y = gemm_pack2(v.z, v.w);
-      *reinterpret_cast<uint2 *>(g.Y + (long long)m * g.Cout + n) = o;
+      if (wide) *reinterpret_cast<uint2 *>(smem + (m - m0) * kGemmCtStride + (n - n0)) = o;
+      else *reinterpret_cast<uint2 *>(g.Y + (long long)m * g.Cout + n) = o;
     }
   }
+  if (wide) gemm_flush_tile(smem, g.Y, g.Cout, m0, n0, M, g.Cout);
 }
 
 }  // namespace snipper
