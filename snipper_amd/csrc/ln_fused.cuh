@@ -144,21 +144,23 @@ __global__ __launch_bounds__(kLnThreads) void ln_fused_fwd_kernel(LnFwdArgs a) {
 }
 
 // grid-stride over rows: every wave keeps its lanes' dgamma / dbeta in registers; one partial row per workgroup
+// NIT = ceil(C / 256) register chunks per lane (C = 384 -> 2: 70 VGPRs instead of 130, twice the waves in flight).
+template <int NIT>
 __global__ __launch_bounds__(kLnThreads) void ln_fused_bwd_kernel(LnBwdArgs a) {
-  __shared__ float red[(kLnThreads / 64) * 2 * kLnMaxIter * 64 * 4];     // [wave][2][C <= 1024]
+  __shared__ float red[(kLnThreads / 64) * 2 * NIT * 256];               // [wave][2][NIT * 256 >= C]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const float keep_scale = a.p > 0.f ? 1.f / (1.f - a.p) : 1.f;
-  float4 dg[kLnMaxIter], db[kLnMaxIter];
+  float4 dg[NIT], db[NIT];
 #pragma unroll
-  for (int it = 0; it < kLnMaxIter; ++it) dg[it] = db[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int it = 0; it < NIT; ++it) dg[it] = db[it] = make_float4(0.f, 0.f, 0.f, 0.f);
   const float inv_c = 1.f / (float)a.C;
   for (int row = blockIdx.x * (kLnThreads / 64) + wave; row < a.rows; row += gridDim.x * (kLnThreads / 64)) {
     const long long base = (long long)row * a.C;
     const float mean = a.mean[row], rstd = a.rstd[row];
-    float4 gg[kLnMaxIter], xh[kLnMaxIter];
+    float4 gg[NIT], xh[NIT];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int it = 0; it < kLnMaxIter; ++it) {
+    for (int it = 0; it < NIT; ++it) {
       const int c = (lane + 64 * it) * 4;
       gg[it] = xh[it] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (c < a.C) {
@@ -179,7 +181,7 @@ __global__ __launch_bounds__(kLnThreads) void ln_fused_bwd_kernel(LnBwdArgs a) {
     }
     const float m1 = ln_wave_sum(s1) * inv_c, m2 = ln_wave_sum(s2) * inv_c;
 #pragma unroll
-    for (int it = 0; it < kLnMaxIter; ++it) {
+    for (int it = 0; it < NIT; ++it) {
       const int c = (lane + 64 * it) * 4;
       if (c < a.C) {
         float4 d;
@@ -198,18 +200,18 @@ __global__ __launch_bounds__(kLnThreads) void ln_fused_bwd_kernel(LnBwdArgs a) {
     }
   }
   // the 4 waves' partials meet in LDS; wave 0 writes the workgroup's row of the partial buffer
-  float *mine = red + wave * 2 * kLnMaxIter * 256;
+  float *mine = red + wave * 2 * NIT * 256;
 #pragma unroll
-  for (int it = 0; it < kLnMaxIter; ++it) {
+  for (int it = 0; it < NIT; ++it) {          // (channels >= C are never read back)
     *reinterpret_cast<float4 *>(mine + (lane + 64 * it) * 4) = dg[it];
-    *reinterpret_cast<float4 *>(mine + kLnMaxIter * 256 + (lane + 64 * it) * 4) = db[it];
+    *reinterpret_cast<float4 *>(mine + NIT * 256 + (lane + 64 * it) * 4) = db[it];
   }
   __syncthreads();
   for (int e = threadIdx.x; e < 2 * a.C; e += kLnThreads) {
     const int which = e >= a.C, c = which ? e - a.C : e;
     float sum = 0.f;
 #pragma unroll
-    for (int w = 0; w < kLnThreads / 64; ++w) sum += red[w * 2 * kLnMaxIter * 256 + which * kLnMaxIter * 256 + c];
+    for (int w = 0; w < kLnThreads / 64; ++w) sum += red[w * 2 * NIT * 256 + which * NIT * 256 + c];
     a.part[((long long)blockIdx.x * 2 + which) * a.C + c] = sum;
   }
 }

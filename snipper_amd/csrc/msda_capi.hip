@@ -33,7 +33,7 @@ std::atomic<float> g_near_radius{6.0f};
 std::atomic<int> g_owner_debug{0};
 std::atomic<int> g_owner_chunk{64};
 std::atomic<int> g_wgrad_wgs{512};
-std::atomic<int> g_ln_bwd_blocks{2048};
+std::atomic<int> g_ln_bwd_blocks{1024};
 std::atomic<int> g_owner_enable{1};   // owner-computes backward for the encoder shape
 std::atomic<int> g_tile_edge[3] = {{16}, {8}, {4}};   // level area > 4096 px / > 1024 px / smaller
 
@@ -539,7 +539,12 @@ int snipper_add_dropout_layernorm_backward(void *stream, const float *g32, const
   const int blocks = ln_bwd_blocks(rows);
   const LnBwdArgs a{g32, g16, gq16, s_save, mean, rstd, gamma, p > 0.f ? keep : nullptr, dx, dx_dt, dz, dz_dt,
                     (float *)workspace, rows, C, p};
-  hipLaunchKernelGGL(ln_fused_bwd_kernel, dim3(blocks), dim3(kLnThreads), 0, (hipStream_t)stream, a);
+  switch ((C + 255) / 256) {
+    case 1: hipLaunchKernelGGL(ln_fused_bwd_kernel<1>, dim3(blocks), dim3(kLnThreads), 0, (hipStream_t)stream, a); break;
+    case 2: hipLaunchKernelGGL(ln_fused_bwd_kernel<2>, dim3(blocks), dim3(kLnThreads), 0, (hipStream_t)stream, a); break;
+    case 3: hipLaunchKernelGGL(ln_fused_bwd_kernel<3>, dim3(blocks), dim3(kLnThreads), 0, (hipStream_t)stream, a); break;
+    default: hipLaunchKernelGGL(ln_fused_bwd_kernel<4>, dim3(blocks), dim3(kLnThreads), 0, (hipStream_t)stream, a); break;
+  }
   hipLaunchKernelGGL(ln_param_grad_kernel, dim3((2 * C + 15) / 16), dim3(256), 0, (hipStream_t)stream,
                      (const float *)workspace, blocks, C, dgamma, dbeta);
   return launch_status();
