@@ -71,6 +71,62 @@ def _residual_norm(x, z, norm, drop):
     return norm(x + drop(z))
 
 
+class _QKVProj(torch.autograd.Function):
+    """The packed input projection of nn.MultiheadAttention for "query is key, value differs" (the decoder's
+    self-attention: q = k = tgt + pos, v = tgt), batch-first: [q | k] = x_qk @ W[:2E]^T + b[:2E], v = x_v @ W[2E:]^T +
+    b[2E:].  Two GEMMs instead of three, and dW / db are assembled here -- the module's own path slices the packed
+    weight three ways, which autograd pays back with a zero-fill, a copy and an add per slice."""
+
+    @staticmethod
+    def forward(ctx, x_qk, x_v, weight, bias):
+        E = x_qk.shape[-1]
+        a, b = x_qk.reshape(-1, E), x_v.reshape(-1, E)
+        ctx.save_for_backward(a, b, weight)
+        qk = torch.addmm(bias[:2 * E], a, weight[:2 * E].t())
+        v = torch.addmm(bias[2 * E:], b, weight[2 * E:].t())
+        return qk.view(*x_qk.shape[:-1], 2 * E), v.view(*x_v.shape[:-1], E)
+
+    @staticmethod
+    def backward(ctx, gqk, gv):
+        from .dense import _ones_row
+        a, b, weight = ctx.saved_tensors
+        E = a.shape[1]
+        gqk2, gv2 = gqk.reshape(-1, 2 * E), gv.reshape(-1, E)
+        dxa = torch.mm(gqk2, weight[:2 * E]).view(*gqk.shape[:-1], E) if ctx.needs_input_grad[0] else None
+        dxb = torch.mm(gv2, weight[2 * E:]).view(*gv.shape[:-1], E) if ctx.needs_input_grad[1] else None
+        dW = db = None
+        if ctx.needs_input_grad[2]:
+            dW = torch.cat([torch.mm(gqk2.t(), a), torch.mm(gv2.t(), b)], 0)
+        if ctx.needs_input_grad[3]:
+            ones = _ones_row(gqk2.shape[0], gqk2.device, gqk2.dtype)
+            db = torch.cat([torch.mm(ones, gqk2).view(-1), torch.mm(ones, gv2).view(-1)], 0)
+        return dxa, dxb, dW, db
+
+
+def _self_attention(mha: nn.MultiheadAttention, x_qk, x_v):
+    """``mha(x_qk^T, x_qk^T, x_v^T, need_weights=False)[0]^T`` for batch-first inputs [bs, L, E] -- the decoder's dense
+    self-attention (reference models/deformable_transformer.py:282-287) without the module's layout round trips: it
+    wants [L, bs, E], so the reference transposes in and out and the module copies q, k, v and the result between the
+    layouts (~10 copy kernels per call and direction).  Same parameters, same arithmetic (scaled dot-product attention
+    with dropout on the probabilities, packed input projection, output projection)."""
+    E = x_qk.shape[-1]
+    ok = (x_qk.is_cuda and x_qk.dtype == torch.float32 and not torch.is_autocast_enabled('cuda') and
+          mha._qkv_same_embed_dim and mha.in_proj_bias is not None and mha.bias_k is None and not mha.add_zero_attn and
+          not mha.batch_first and mha.out_proj.bias is not None)
+    if not ok:
+        return mha(x_qk.transpose(0, 1), x_qk.transpose(0, 1), x_v.transpose(0, 1), need_weights=False)[0].transpose(0, 1)
+    from .dense import _SmallLinear
+    bs, L, _ = x_qk.shape
+    H = mha.num_heads
+    qk, v = _QKVProj.apply(x_qk, x_v, mha.in_proj_weight, mha.in_proj_bias)
+    q = qk[..., :E].view(bs, L, H, E // H).transpose(1, 2)               # [bs, H, L, hd] views
+    k = qk[..., E:].view(bs, L, H, E // H).transpose(1, 2)
+    vh = v.view(bs, L, H, E // H).transpose(1, 2)
+    att = F.scaled_dot_product_attention(q, k, vh, dropout_p=mha.dropout if mha.training else 0.0)
+    att = att.transpose(1, 2).reshape(bs, L, E)
+    return _SmallLinear.apply(att, mha.out_proj.weight, mha.out_proj.bias)
+
+
 class _FFNMixin:
     """Linear -> act -> dropout -> Linear, residual, LayerNorm (shared by both layer types)."""
 
@@ -236,8 +292,7 @@ class DeformableTransformerDecoderLayer(nn.Module, _FFNMixin):
         bs, t, lq, c = tgt.shape
         # dense self-attention over all (frame, query) tokens of a sample (reference :282-287)
         flat = tgt.reshape(bs, t * lq, c)
-        qk = self.with_pos_embed(flat, query_pos.reshape(bs, t * lq, c)).transpose(0, 1)
-        mixed = self.self_attn(qk, qk, flat.transpose(0, 1), need_weights=False)[0].transpose(0, 1)
+        mixed = _self_attention(self.self_attn, self.with_pos_embed(flat, query_pos.reshape(bs, t * lq, c)), flat)
         tgt = _residual_norm(flat, mixed, self.norm2, self.dropout2).view(bs, t, lq, c)
         # deformable cross-attention into the encoder memory (reference :290-295)
         attended, atten_data = self._cross(amp_dtype, self.with_pos_embed(tgt, query_pos.view(bs, t, lq, c)),

@@ -179,3 +179,22 @@ def test_model_token_row_path_matches_channel_first_path():
         if rel(gf, gs) > 0.15:
             bad.append((n, rel(gf, gs)))
     assert len(bad) <= len(names) // 20, bad[:10]
+
+
+def test_decoder_self_attention_matches_nn_multihead_attention():
+    """The batch-first evaluation of the decoder's self-attention against nn.MultiheadAttention itself (dropout off):
+    output and all gradients, float32."""
+    from snipper_amd.deformable_transformer import _self_attention
+    torch.manual_seed(2)
+    mha = torch.nn.MultiheadAttention(384, 8, dropout=0.1).to(DEV).eval()
+    x_qk = torch.randn(2, 240, 384, device=DEV, requires_grad=True)
+    x_v = torch.randn(2, 240, 384, device=DEV, requires_grad=True)
+    gy = torch.randn(2, 240, 384, device=DEV)
+    params = [mha.in_proj_weight, mha.in_proj_bias, mha.out_proj.weight, mha.out_proj.bias]
+    y = _self_attention(mha, x_qk, x_v)
+    g1 = torch.autograd.grad(y, [x_qk, x_v] + params, gy)
+    yr = mha(x_qk.transpose(0, 1), x_qk.transpose(0, 1), x_v.transpose(0, 1), need_weights=False)[0].transpose(0, 1)
+    g2 = torch.autograd.grad(yr, [x_qk, x_v] + params, gy)
+    torch.testing.assert_close(y, yr, rtol=1e-4, atol=1e-5)
+    for a, b in zip(g1, g2):
+        torch.testing.assert_close(a, b, rtol=1e-3, atol=1e-4)
