@@ -281,11 +281,14 @@ class DeformableTransformerDecoderLayer(nn.Module, _FFNMixin):
         return self._forward(tgt, query_pos, reference_points, src, src_spatial_shapes, level_start_index,
                              src_padding_mask, cross_amp_dtype)
 
-    def _cross(self, amp_dtype, *args):
-        if amp_dtype is None:
-            return self.cross_attn(*args)
+    def _cross(self, amp_dtype, query, reference_points, src, *rest):
+        # When the encoder memory carries the bf16 twin its last kernel wrote (big_linear picks it up for the value
+        # projection, the only large GEMM here), the module can stay outside autocast: its query-side Linears see
+        # 480 rows, where autocast only adds casts of inputs, weights, biases and their gradients (~18 per layer).
+        if amp_dtype is None or getattr(src, "_snipper_bf16", None) is not None:
+            return self.cross_attn(query, reference_points, src, *rest)
         with torch.autocast("cuda", dtype=amp_dtype):
-            return self.cross_attn(*args)
+            return self.cross_attn(query, reference_points, src, *rest)
 
     def _forward(self, tgt, query_pos, reference_points, src, src_spatial_shapes, level_start_index,
                  src_padding_mask, amp_dtype):

@@ -240,6 +240,7 @@ def big_linear(x: torch.Tensor, lin: torch.nn.Linear, relu: bool = False, dropou
     ``x`` is a CUDA tensor with at least BIG_LINEAR_MIN_ROWS rows that is computed in bf16 (bf16 input, or autocast to
     bf16); plain PyTorch otherwise, with identical semantics (the random stream differs: a counter-based hash instead
     of Philox)."""
+    x_in = x
     twin = getattr(x, "_snipper_bf16", None)      # a bf16 copy written by the kernel that produced x (same graph)
     if twin is not None and twin.shape == x.shape and twin.device == x.device:
         x = twin
@@ -253,6 +254,7 @@ def big_linear(x: torch.Tensor, lin: torch.nn.Linear, relu: bool = False, dropou
             p = 0.0
         y = _BigLinear.apply(x, lin.weight, lin.bias, relu, p)
         return dropout(y) if (dropout is not None and p == 0.0) else y
+    x = x_in                                      # the twin is only for the bf16 kernels
     if (x.is_cuda and x.dtype == torch.float32 and lin.weight.dtype == torch.float32 and lin.bias is not None and
             not torch.is_autocast_enabled('cuda') and 16 <= rows < BIG_LINEAR_MIN_ROWS and torch.is_grad_enabled()):
         y = _SmallLinear.apply(x, lin.weight, lin.bias)

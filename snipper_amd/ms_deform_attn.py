@@ -218,10 +218,13 @@ class MSDeformAttn(nn.Module):
         locs = wts = None
         if self.attention_vis:   # same lists as reference :228-233, built as views
             locs, wts = [], []
+            pd = prob.detach()
+            ks = sorted({len(g) for g in groups})
+            scaled = {k: pd / k for k in ks}                  # one division per distinct group size, not per frame
             for t1, g in enumerate(groups):
                 k = len(g)
                 locs.append(loc[:, t1].detach().unsqueeze(-2).expand(N, Lq, M, L, P, k, 2))
-                wts.append((prob[:, t1].detach() / k).unsqueeze(-1).expand(N, Lq, M, L, P, k))
+                wts.append(scaled[k][:, t1].unsqueeze(-1).expand(N, Lq, M, L, P, k))
         return out, locs, wts
 
     # -- the reference's per-pair evaluation, for untied Linears ------------------------------
