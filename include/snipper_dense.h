@@ -101,6 +101,14 @@ int snipper_groupnorm_tokens_backward(void *stream, const uint16_t *x, const flo
                                       long long dst_rows_per_image, long long dst_row_offset,
                                       uint16_t *dx, float *dgamma, float *dbeta, void *workspace, size_t workspace_bytes);
 
+/* Column sums of row segments: out[c] = sum_{i < n_images} sum_{r < rows_per_seg} x[i * image_stride + r * C + c],
+ * x bfloat16 (image_stride in elements), out [C] float32, summed in a fixed order.  The gradient of a per-level
+ * embedding broadcast over a level's tokens (reference models/deformable_transformer.py:118), taken directly from the
+ * level's slice of the [b, t, S, C] gradient.  C % 4 == 0, C <= 1024. */
+size_t snipper_colsum_workspace_bytes(int n_images, int rows_per_seg, int C);
+int snipper_colsum_segments_bf16(void *stream, const uint16_t *x, long long image_stride, int n_images,
+                                 int rows_per_seg, int C, float *out, void *workspace, size_t workspace_bytes);
+
 /* 3x3 convolution, padding 1, stride 1 or 2, NHWC bf16, as an implicit GEMM on the same MFMA tiles:
  * Y[B,Ho,Wo,Cout] = act(conv(X[B,H,W,Cin], W[Cout,3,3,Cin]) + bias[Cout]), Ho = (H-1)/stride + 1 (same for Wo).
  * Requirements: Cin % 64 == 0, Cout % 4 == 0.  (ResNet bottleneck conv2 with the frozen BatchNorm folded in.) */

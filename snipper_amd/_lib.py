@@ -53,6 +53,9 @@ EXPORTS = {
                                           c_void_p, c_int] + [c_void_p] * 5 + [c_size_t], c_int),
     "snipper_groupnorm_tokens_backward": ([c_void_p] * 7 + [c_int] * 4 + [c_longlong, c_longlong] + [c_void_p] * 4 +
                                            [c_size_t], c_int),
+    "snipper_colsum_workspace_bytes": ([c_int] * 3, c_size_t),
+    "snipper_colsum_segments_bf16": ([c_void_p, c_void_p, c_longlong, c_int, c_int, c_int, c_void_p, c_void_p,
+                                      c_size_t], c_int),
     "snipper_conv3x3_bf16": ([c_void_p] * 5 + [c_int] * 7, c_int),
     "snipper_lsap_f32": ([c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p], c_int),
     "snipper_linear_bf16": ([c_void_p, c_void_p, ctypes.c_longlong, c_void_p, c_void_p, c_void_p, ctypes.c_longlong,

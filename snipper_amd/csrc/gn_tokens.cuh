@@ -191,4 +191,47 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(GnArgs a) {
   }
 }
 
+// ---- column sums of row segments: out[c] = sum over images i and rows r < rows_per_seg of x[i * image_stride + r][c]
+// (the gradient of a per-level embedding that was broadcast over a level's tokens: reference
+// models/deformable_transformer.py:118 ``lvl_pos_embed = pos_embed + self.level_embed[lvl]``).  x bf16, out f32.
+// Stage 1: workgroup (blk, image) sums every nblk-th group of rows into part[image * nblk + blk][C]; stage 2 adds the
+// partials in a fixed order.
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const uint16_t *x, long long image_stride, int rows_per_seg,
+                                                             int C, int nblk, int rpp, float *part) {
+  __shared__ float lds[256 * 4];
+  const int chunks = C / 4, chunk = threadIdx.x % chunks, rsub = threadIdx.x / chunks;
+  const uint16_t *xi = x + (long long)blockIdx.y * image_stride + chunk * 4;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int r = blockIdx.x * rpp + rsub; r < rows_per_seg; r += nblk * rpp) {
+    const float4 v = ln_load4(xi, 1, (long long)r * C);
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  *reinterpret_cast<float4 *>(lds + threadIdx.x * 4) = s;
+  __syncthreads();
+  if (rsub == 0) {
+    for (int r = 1; r < rpp; ++r) {
+      const float4 t = *reinterpret_cast<const float4 *>(lds + (r * chunks + chunk) * 4);
+      s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+    }
+    *reinterpret_cast<float4 *>(part + ((long long)blockIdx.y * nblk + blockIdx.x) * C + chunk * 4) = s;
+  }
+}
+
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float *part, int nparts, int C, float *out) {
+  __shared__ float red[16][17];
+  const int ci = threadIdx.x & 15, slice = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + ci;
+  float sum = 0.f;
+  if (c < C)
+    for (int b = slice; b < nparts; b += 16) sum += part[(long long)b * C + c];
+  red[slice][ci] = sum;
+  __syncthreads();
+  if (slice == 0 && c < C) {
+    sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) sum += red[k][ci];
+    out[c] = sum;
+  }
+}
+
 }  // namespace snipper

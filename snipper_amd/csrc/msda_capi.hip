@@ -614,6 +614,26 @@ int snipper_groupnorm_tokens_backward(void *stream, const uint16_t *x, const flo
   return launch_status();
 }
 
+size_t snipper_colsum_workspace_bytes(int n_images, int rows_per_seg, int C) {
+  if (n_images <= 0 || rows_per_seg <= 0 || C <= 0 || C % 4 || C / 4 > 256) return 0;
+  const GnPlan p = gn_plan(rows_per_seg, C);
+  return (size_t)n_images * p.nblk * C * sizeof(float);
+}
+
+int snipper_colsum_segments_bf16(void *stream, const uint16_t *x, long long image_stride, int n_images,
+                                 int rows_per_seg, int C, float *out, void *workspace, size_t workspace_bytes) {
+  if (!x || !out || !workspace) return SNIPPER_E_NULL;
+  if (n_images <= 0 || rows_per_seg <= 0 || C <= 0 || C % 4 || C / 4 > 256 || image_stride < (long long)rows_per_seg * C ||
+      image_stride % 4 || ((uintptr_t)x % 8) || workspace_bytes < snipper_colsum_workspace_bytes(n_images, rows_per_seg, C))
+    return SNIPPER_E_SHAPE;
+  const GnPlan p = gn_plan(rows_per_seg, C);
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3(p.nblk, n_images), dim3((C / 4) * p.rpp), 0, (hipStream_t)stream, x,
+                     image_stride, rows_per_seg, C, p.nblk, p.rpp, (float *)workspace);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 15) / 16), dim3(256), 0, (hipStream_t)stream,
+                     (const float *)workspace, n_images * p.nblk, C, out);
+  return launch_status();
+}
+
 int snipper_conv3x3_bf16(void *stream, const uint16_t *X, const uint16_t *W, const float *bias, uint16_t *Y,
                          int B, int H, int Wd, int Cin, int Cout, int stride, int relu) {
   if (!X || !W || !Y) return SNIPPER_E_NULL;

@@ -435,13 +435,14 @@ class DeformableTransformer(nn.Module):
         feats L x [b*T, Cin, h, w] (backbone maps, bf16 NHWC), masks L x [b*T, h, w] bool, pos_tokens L x
         [b, T, h*w, C] float32 (position encoding, token-major), input_proj the model's projection modules.
         Check ``tokens_path_ok`` first."""
-        from .fused import InputProjTokens
+        from .fused import InputProjTokens, LevelPosTokens
         T, c = self.n_frame, self.d_model
         b = feats[0].shape[0] // T
         hw = [tuple(int(v) for v in f.shape[-2:]) for f in feats]
         sizes = [h * w for h, w in hw]
-        pos = torch.cat([p + self.level_embed[lvl].view(1, 1, 1, -1) for lvl, p in enumerate(pos_tokens)], 2)
-        pos16 = pos.to(torch.bfloat16)
+        # the fused encoder only ever reads the position encoding in bf16 (query = bf16(src + pos))
+        pos16 = LevelPosTokens.apply(self.level_embed[:len(pos_tokens)], *pos_tokens)
+        pos = pos16
         mask = torch.cat([m.reshape(b, T, -1) for m in masks], 2)[..., None].expand(-1, -1, -1, c)
         ratios = []
         for m, (h, w) in zip(masks, hw):                                  # get_valid_ratio on frame 0 of each sample

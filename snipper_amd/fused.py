@@ -322,3 +322,45 @@ class InputProjTokens(Function):
             off += h * wd
         dpos = gq if (has_q and ctx.needs_input_grad[3]) else None
         return (None, None, None, dpos, None, *dfeats, *dparams)
+
+
+class LevelPosTokens(Function):
+    """pos16[b, t, S, C] = bf16(cat_l(pos_tokens[l] + level_embed[l])): the position encoding of every level plus its
+    learned level embedding (reference models/deformable_transformer.py:118-121), written once in the dtype the
+    encoder's kernels read.  Backward: level_embed's gradient is the column sum of each level's slice of the incoming
+    bf16 gradient (csrc/gn_tokens.cuh colsum kernels) -- no float32 copy of the [b, t, S, C] gradient, no cat /
+    slice / broadcast-reduction chain.  The sine encoding itself carries no gradient.
+    apply(level_embed [L, C], *pos_tokens (L x [b, t, hw_l, C] float32))"""
+
+    @staticmethod
+    def forward(ctx, level_embed, *pos_tokens):
+        b, t, _, C = pos_tokens[0].shape
+        sizes = [int(p.shape[2]) for p in pos_tokens]
+        S = sum(sizes)
+        out = torch.empty((b, t, S, C), dtype=torch.bfloat16, device=level_embed.device)
+        off = 0
+        for l, p in enumerate(pos_tokens):
+            torch.add(p, level_embed[l].view(1, 1, 1, C), out=out[:, :, off:off + sizes[l]])
+            off += sizes[l]
+        ctx.sizes, ctx.shape, ctx.le_dtype = sizes, (b, t, S, C), level_embed.dtype
+        ctx.n_levels = level_embed.shape[0]
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        b, t, S, C = ctx.shape
+        g = g.contiguous()
+        if g.dtype != torch.bfloat16:
+            g = g.to(torch.bfloat16)
+        lib = _lib.load()
+        d = torch.zeros((ctx.n_levels, C), dtype=torch.float32, device=g.device)
+        off = 0
+        for l, hw in enumerate(ctx.sizes):
+            nbytes = lib.snipper_colsum_workspace_bytes(b * t, hw, C)
+            ws = torch.empty(nbytes // 4, dtype=torch.float32, device=g.device)
+            with torch.cuda.device(g.device):
+                rc = lib.snipper_colsum_segments_bf16(_stream(g.device), g.data_ptr() + off * C * 2, S * C, b * t, hw, C,
+                                                      d[l].data_ptr(), ws.data_ptr(), nbytes)
+            _lib.check(rc, "snipper_colsum_segments_bf16")
+            off += hw
+        return (d.to(ctx.le_dtype),) + (None,) * len(ctx.sizes)

@@ -222,3 +222,19 @@ def test_input_proj_tokens_matches_conv_groupnorm():
     for name, a, c in zip(names, grads, rgrads):
         assert a.shape == c.shape, name
         assert rel(a, c) < 2e-2, (name, rel(a, c))
+
+
+def test_level_pos_tokens_forward_backward():
+    from snipper_amd.fused import LevelPosTokens
+    g = torch.Generator().manual_seed(33)
+    b, t, C = 2, 2, 384
+    sizes = [300, 80, 21]
+    le = torch.randn(3, C, generator=g).to(DEV).requires_grad_(True)
+    toks = [torch.randn(b, t, hw, C, generator=g).to(DEV) for hw in sizes]
+    out = LevelPosTokens.apply(le, *toks)
+    ref = torch.cat([p + le[l].view(1, 1, 1, C) for l, p in enumerate(toks)], 2)
+    assert out.dtype == torch.bfloat16 and torch.equal(out, ref.to(torch.bfloat16))
+    gy = torch.randn(b, t, sum(sizes), C, generator=g).to(DEV).bfloat16()
+    (d,) = torch.autograd.grad(out, le, gy)
+    (dr,) = torch.autograd.grad(ref, le, gy.float())
+    torch.testing.assert_close(d, dr, rtol=1e-4, atol=1e-3)
