@@ -105,7 +105,9 @@ class _PointwiseConvBN(torch.autograd.Function):
     the largest single item of the step's CPU time."""
 
     @staticmethod
-    def forward(ctx, x2, weight, scale, shift, res2, relu):
+    def forward(ctx, x2, weight, scale, shift, res2, relu, fork=False):
+        """``fork``: also return ``x2`` itself (as a second output) for a skip connection; the gradient that comes
+        back over that output is then added inside the data-gradient kernel instead of by a separate add."""
         from .dense import linear_bf16
         cout, cin = weight.shape[0], weight.shape[1]
         from . import shadow
@@ -118,24 +120,27 @@ class _PointwiseConvBN(torch.autograd.Function):
         ctx.relu, ctx.has_res = relu, res2 is not None
         ctx.wshape, ctx.wdtype, ctx.wstride = weight.shape, weight.dtype, weight.stride()
         ctx.save_for_backward(x2, w_eff, scale, y if relu else None)
+        ctx.fork = fork
+        if fork:
+            return y, x2.view_as(x2)
         return y
 
     @staticmethod
-    def backward(ctx, gy):
+    def backward(ctx, gy, gskip=None):
         from .dense import linear_bf16
         x2, w_eff, scale, y = ctx.saved_tensors
         g = gy.contiguous()
         if ctx.relu:
             g = torch.ops.aten.threshold_backward(g, y, 0)
         from .dense import _dgrad
-        dx = _dgrad(g, w_eff) if ctx.needs_input_grad[0] else None
+        dx = _dgrad(g, w_eff, gskip if ctx.fork else None) if ctx.needs_input_grad[0] else None
         dw = None
         if ctx.needs_input_grad[1]:
             from .dense import wgrad_bf16
             dw, _ = wgrad_bf16(g, x2, want_bias=False, scale=scale)     # BN scale folded into the reduction kernel
             # same memory, the parameter's own strides (NHWC weights: DDP aliases its bucket only when they match)
             dw = dw.to(ctx.wdtype).as_strided(ctx.wshape, ctx.wstride)
-        return dx, dw, None, None, (g if ctx.has_res else None), None
+        return dx, dw, None, None, (g if ctx.has_res else None), None, None
 
 
 def _hip_conv3x3_ok(x, conv) -> bool:
@@ -201,6 +206,18 @@ def _hip_pointwise(x, conv, scale, shift, relu, residual):
     return y.view(b, h, wd, -1).permute(0, 3, 1, 2)                          # logical NCHW, channels_last memory
 
 
+def _hip_pointwise_fork(x, conv, bn):
+    """(relu(bn(conv1x1(x))), x) with both results coming out of ONE autograd node, so that the gradient of the skip
+    connection is added inside that node's data-gradient kernel.  None when the MFMA path does not apply."""
+    if not (conv.stride == (1, 1) and _hip_pointwise_ok(x, conv, None)):
+        return None
+    scale, shift = bn.scale_bias()
+    b, c, h, wd = x.shape
+    rows = x.permute(0, 2, 3, 1).reshape(b * h * wd, c)
+    y, skip = _PointwiseConvBN.apply(rows, conv.weight, scale.float(), shift.float(), None, True, True)
+    return y.view(b, h, wd, -1).permute(0, 3, 1, 2), skip.view(b, h, wd, c).permute(0, 3, 1, 2)
+
+
 class Bottleneck(nn.Module):
     expansion = 4
 
@@ -218,9 +235,15 @@ class Bottleneck(nn.Module):
                                             FrozenBatchNorm2d(width * 4))
 
     def forward(self, x):
-        y = conv_frozen_bn(x, self.conv1, self.bn1, relu=True)
+        fork = None
+        if self.downsample is None and x.requires_grad and torch.is_grad_enabled():
+            fork = _hip_pointwise_fork(x, self.conv1, self.bn1)      # identity skip: fold its gradient add away
+        if fork is not None:
+            y, skip = fork
+        else:
+            y = conv_frozen_bn(x, self.conv1, self.bn1, relu=True)
+            skip = x if self.downsample is None else conv_frozen_bn(x, self.downsample[0], self.downsample[1], relu=False)
         y = conv_frozen_bn(y, self.conv2, self.bn2, relu=True)
-        skip = x if self.downsample is None else conv_frozen_bn(x, self.downsample[0], self.downsample[1], relu=False)
         return conv_frozen_bn(y, self.conv3, self.bn3, relu=True, residual=skip)
 
 

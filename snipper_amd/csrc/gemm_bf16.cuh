@@ -209,6 +209,7 @@ struct GemmNNArgs {
   const uint16_t *W; long long ldw;      // [K][N]
   uint16_t *Y; long long ldy;            // [M][N]
   int M, N, K;
+  const uint16_t *R; long long ldr;      // [M][N] addend (e.g. the gradient arriving over a skip connection) or nullptr
 };
 
 __device__ __forceinline__ gemm_bf16x8 gemm_tr_frag(const uint16_t *tile, int byte_off) {
@@ -301,9 +302,15 @@ __global__ __launch_bounds__(kGemmThreads) void linear_bf16_nn_kernel(GemmNNArgs
     for (int j = 0; j < 4; ++j) {
       const int m = m0 + wm * 64 + j * 16 + (lane & 15);
       if (m >= g.M) continue;
+      gemm_f32x4 v = acc[i][j];
+      if (g.R) {
+        const uint2 r = *reinterpret_cast<const uint2 *>(g.R + (long long)m * g.ldr + n);
+        v.x += __uint_as_float(r.x << 16); v.y += __uint_as_float(r.x & 0xffff0000u);
+        v.z += __uint_as_float(r.y << 16); v.w += __uint_as_float(r.y & 0xffff0000u);
+      }
       uint2 o;
-      o.x = gemm_pack2(acc[i][j].x, acc[i][j].y);
-      o.y = gemm_pack2(acc[i][j].z, acc[i][j].w);
+      o.x = gemm_pack2(v.x, v.y);
+      o.y = gemm_pack2(v.z, v.w);
       if (wide) *reinterpret_cast<uint2 *>(smem + (m - m0) * kGemmCtStride + (n - n0)) = o;
       else *reinterpret_cast<uint2 *>(g.Y + (long long)m * g.ldy + n) = o;
     }

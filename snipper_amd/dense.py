@@ -67,9 +67,9 @@ def conv3x3_bf16(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Ten
     return out
 
 
-def linear_nn_bf16(x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
-    """x [M, K] @ w [K, N] (both bf16, row-major; w = a Linear's weight [out, in] used for the data gradient) on the
-    HIP kernel that reads the weight tile through the transposing LDS read -- no transposed copy of w."""
+def linear_nn_bf16(x: torch.Tensor, w: torch.Tensor, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x [M, K] @ w [K, N] (+ residual [M, N]) (all bf16, row-major; w = a Linear's weight [out, in] used for the data
+    gradient) on the HIP kernel that reads the weight tile through the transposing LDS read -- no transposed copy."""
     assert x.is_cuda and x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and x.dim() == 2 and w.dim() == 2
     assert x.shape[1] == w.shape[0]
     if x.stride(1) != 1 or x.stride(0) % 8 or x.data_ptr() % 16:
@@ -79,19 +79,27 @@ def linear_nn_bf16(x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
     M, K = x.shape
     N = w.shape[1]
     out = torch.empty((M, N), dtype=torch.bfloat16, device=x.device)
+    r2 = None
+    if residual is not None:
+        r2 = residual.reshape(M, N)
+        if r2.dtype != torch.bfloat16 or r2.stride(1) != 1 or r2.stride(0) % 4:
+            r2 = r2.to(torch.bfloat16).contiguous()
     with torch.cuda.device(x.device):
         rc = _lib.load().snipper_linear_nn_bf16(
             torch.cuda.current_stream(x.device).cuda_stream, x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0),
+            r2.data_ptr() if r2 is not None else None, r2.stride(0) if r2 is not None else 0,
             out.data_ptr(), out.stride(0), M, N, K)
     _lib.check(rc, "snipper_linear_nn_bf16")
     return out
 
 
-def _dgrad(g: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
-    """g [M, out] @ w [out, in]: own kernel when the shape allows (out % 64 == 0, in % 8 == 0), hipBLASLt otherwise."""
+def _dgrad(g: torch.Tensor, w: torch.Tensor, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """g [M, out] @ w [out, in] (+ residual): own kernel when the shape allows (out % 64 == 0, in % 8 == 0), hipBLASLt
+    otherwise."""
     if w.shape[0] % 64 == 0 and w.shape[1] % 8 == 0 and g.shape[0] >= 256:
-        return linear_nn_bf16(g, w)
-    return torch.mm(g, w)
+        return linear_nn_bf16(g, w, residual)
+    y = torch.mm(g, w)
+    return y if residual is None else y + residual.reshape(y.shape)
 
 
 def wgrad_bf16(g: torch.Tensor, x: torch.Tensor, want_bias: bool = True, scale: Optional[torch.Tensor] = None,
