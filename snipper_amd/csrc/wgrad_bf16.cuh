@@ -30,7 +30,8 @@ namespace snipper {
 
 typedef __attribute__((__vector_size__(4 * sizeof(__bf16)))) __bf16 wgrad_bf16x4;
 
-constexpr int kWgTile = 128, kWgRows = 64, kWgStride = 144, kWgThreads = 256;
+constexpr int kWgTile = 128, kWgRows = 64, kWgStride = 144, kWgThreads = 256;    // (128-row steps: 2 waves/SIMD, measured slower)
+constexpr int kWgLoads = kWgRows / 16;      // 16-byte loads per operand, thread and step
 
 struct WgradArgs {
   const uint16_t *G; long long ldg;   // [M][N]
@@ -77,9 +78,9 @@ __global__ __launch_bounds__(kWgThreads) void wgrad_bf16_kernel(WgradArgs g) {
   const bool g_col_ok = n0 + chunk * 8 < g.N, x_col_ok = k0 + chunk * 8 < g.Kc;
   const uint16_t *gp = g.G + n0 + chunk * 8, *xp = g.X + k0 + chunk * 8;
   const gemm_u32x4 zero4 = {0u, 0u, 0u, 0u};
-  auto load_step = [&](int m, gemm_u32x4 (&gr)[4], gemm_u32x4 (&xr)[4]) {
+  auto load_step = [&](int m, gemm_u32x4 (&gr)[kWgLoads], gemm_u32x4 (&xr)[kWgLoads]) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < kWgLoads; ++i) {
       const int r = m + row0 + 16 * i;
       const bool ok = r < m_end;
       const long long rr = ok ? r : m_begin;
@@ -87,7 +88,7 @@ __global__ __launch_bounds__(kWgThreads) void wgrad_bf16_kernel(WgradArgs g) {
       xr[i] = (ok && x_col_ok) ? *reinterpret_cast<const gemm_u32x4 *>(xp + rr * g.ldx) : zero4;
     }
   };
-  gemm_u32x4 gr[4], xr[4];
+  gemm_u32x4 gr[kWgLoads], xr[kWgLoads];
   if (m_begin < m_end) load_step(m_begin, gr, xr);
   gemm_f32x4 acc[4][4];
 #pragma unroll
@@ -102,14 +103,14 @@ __global__ __launch_bounds__(kWgThreads) void wgrad_bf16_kernel(WgradArgs g) {
 
   for (int m = m_begin; m < m_end; m += kWgRows) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < kWgLoads; ++i) {
       const int off = (row0 + 16 * i) * kWgStride + chunk * 8;
       *reinterpret_cast<gemm_u32x4 *>(Gs + off) = gr[i];
       *reinterpret_cast<gemm_u32x4 *>(Xs + off) = xr[i];
     }
     if (do_bias) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < kWgLoads; ++i) {
         const unsigned w[4] = {gr[i].x, gr[i].y, gr[i].z, gr[i].w};
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
