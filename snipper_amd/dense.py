@@ -93,10 +93,17 @@ def linear_nn_bf16(x: torch.Tensor, w: torch.Tensor, residual: Optional[torch.Te
     return out
 
 
+import os as _os
+# Reductions from this length up would go to hipBLASLt.  In isolation (tools/nnbench.py) the library is 15-25 % faster
+# from K = 512 up; inside the training step the A/B (tools/ab.sh, 40 steps, twice) showed no gain, so the own kernel
+# (which also carries the skip-connection addend) stays the default.
+_DGRAD_LIB_K = int(_os.environ.get("SNIPPER_DGRAD_LIB_K", "1000000"))
+
+
 def _dgrad(g: torch.Tensor, w: torch.Tensor, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
     """g [M, out] @ w [out, in] (+ residual): own kernel when the shape allows (out % 64 == 0, in % 8 == 0), hipBLASLt
     otherwise."""
-    if w.shape[0] % 64 == 0 and w.shape[1] % 8 == 0 and g.shape[0] >= 256:
+    if w.shape[0] % 64 == 0 and w.shape[1] % 8 == 0 and g.shape[0] >= 256 and (w.shape[0] < _DGRAD_LIB_K or residual is not None):
         return linear_nn_bf16(g, w, residual)
     y = torch.mm(g, w)
     return y if residual is None else y + residual.reshape(y.shape)
