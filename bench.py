@@ -148,6 +148,25 @@ def msda_alg_bytes(d, bwd):
     return e * v + re * o + ge * v + ce * 6 * lp
 
 
+def pmc_traffic(kernel_tags, path=os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
+                                              "r01_pmc_bench_step_v7.csv")):
+    """HBM-side bytes per launch of the given kernels from the committed rocprofv3 --pmc profile of this same command
+    (FETCH_SIZE + WRITE_SIZE, raw counters; see the file's footer for the gfx950 caveats).  None if absent."""
+    try:
+        total, seen = 0.0, set()
+        for line in open(path):
+            if line.startswith("#") or line.startswith("kernel,"):
+                continue
+            name, counter, _, kb = line.rsplit(",", 3)
+            for tag in kernel_tags:
+                if tag in name:
+                    total += float(kb) * 1024.0
+                    seen.add((tag, counter))
+        return int(total) if len(seen) == 2 * len(kernel_tags) else None
+    except OSError:
+        return None
+
+
 def cpu_baseline(a, budget_s=40.0):
     """Time the CPU oracle (use_pytorch_deform=1 formulation, per-pair spatiotemporal module) on the host."""
     from oracle import msda_oracle as O
@@ -498,8 +517,13 @@ def main():
             avg_ms = sum(times) / len(times)
             bts = msda_alg_bytes(d, dom[0] == "bwd")
             ach = bts / (avg_ms * 1e-3) / 1e9
+            traffic = pmc_traffic(["msda_bwd_d48_bin_kernel", "msda_bwd_d48_tile_kernel"]) \
+                if dom[1] == "d48_owner" and d["N"] == 8 and d["Lq"] == 9875 else None
             line["roofline"] = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                                "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": None,
+                                "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                                "traffic_source": ("profiles/r01_pmc_bench_step_v7.csv: rocprofv3 --pmc FETCH_SIZE + "
+                                                   "WRITE_SIZE (separate passes, raw counters) of this command, bin + "
+                                                   "tile kernel" if traffic else None),
                                 "kernel": f"msda_{dom[0]}_{dom[1]} N={d['N']} Lq={d['Lq']}",
                                 "avg_launch_ms": round(avg_ms, 4), "alg_bytes_per_launch": bts,
                                 "launches_timed": len(times)}
