@@ -227,7 +227,7 @@ int backward_d48_owner_f32(hipStream_t st, const float *grad_out, const float *v
                      attn, d, plan, grad_value, grad_loc, grad_attn, nblk_padded, go_bf16);
   if (int rc = launch_status()) return rc;
   // 2) every tile adds what it owns
-  const long long nblk_tiles = nm * plan.total_tiles;
+  const long long nblk_tiles = ((nm + 7) / 8) * 8 * plan.total_tiles;      // XCD-major grid (see the tile kernel)
   if (nblk_tiles >= (1LL << 31)) return SNIPPER_E_SHAPE;
   if (g_owner_chunk.load(std::memory_order_relaxed) == 128)
     hipLaunchKernelGGL(msda_bwd_d48_tile_kernel<128>, dim3((unsigned)nblk_tiles), dim3(kOwnerBlock), 0, st, grad_out,
