@@ -436,22 +436,27 @@ __global__ __launch_bounds__(kOwnerBlock) void msda_bwd_d48_tile_kernel(
     }
     __syncthreads();
     // ---- accumulate: group g owns pixels g, g+16, ...; lane i owns channels 3i..3i+2 ----
+    // The phase is a chain of dependent LDS reads (list bounds -> tap record -> staged row -> FMA) with ~4 taps per
+    // pixel and chunk, i.e. latency-bound: the tap loop handles two taps per trip (two row reads in flight, the next
+    // pair of records prefetched).  A tap beyond the list end is clamped to the last valid one and gets weight 0.
+    // (Fetching bounds and first taps of all 16 pixels up front was measured: 200 VGPRs, 2 waves/SIMD, 30 % slower.)
     if (plan.debug != 1) {
 #pragma unroll
       for (int u = 0; u < kMaxPxPerGroup; ++u) {
         if (u < px_per_group) {
           const int pix = grp + 16 * u;
-          const int beg = pix < tpx ? S.off[pix] : 0, num = pix < tpx ? S.cnt[pix] : 0;
-          int2 cur = num > 0 ? S.tap[beg] : make_int2(0, 0);
-          for (int e = 0; e < num; ++e) {
-            const int2 nxt = S.tap[beg + (e + 1 < num ? e + 1 : e)];      // prefetch: breaks the LDS chain
-            const float w = __int_as_float(cur.y);
-            const float *gr = S.gbuf + cur.x * kD48 + lane * 3;
-            const float ga = gr[0], gb = gr[1], gc = gr[2];
-            acc[u][0] = fmaf(w, ga, acc[u][0]);
-            acc[u][1] = fmaf(w, gb, acc[u][1]);
-            acc[u][2] = fmaf(w, gc, acc[u][2]);
-            cur = nxt;
+          const int b_u = pix < tpx ? S.off[pix] : 0, n_u = pix < tpx ? S.cnt[pix] : 0;
+          const int last = n_u - 1;
+          int2 a = S.tap[b_u], b = S.tap[b_u + (n_u > 1 ? 1 : 0)];
+          for (int e = 0; e < n_u; e += 2) {
+            const int2 na = S.tap[b_u + min(e + 2, last)], nb = S.tap[b_u + min(e + 3, last)];   // next pair
+            const float wa = __int_as_float(a.y), wb = e + 1 < n_u ? __int_as_float(b.y) : 0.f;
+            const float *ga = S.gbuf + a.x * kD48 + lane * 3, *gb = S.gbuf + b.x * kD48 + lane * 3;
+            const float a0 = ga[0], a1 = ga[1], a2 = ga[2], b0 = gb[0], b1 = gb[1], b2 = gb[2];
+            acc[u][0] = fmaf(wb, b0, fmaf(wa, a0, acc[u][0]));
+            acc[u][1] = fmaf(wb, b1, fmaf(wa, a1, acc[u][1]));
+            acc[u][2] = fmaf(wb, b2, fmaf(wa, a2, acc[u][2]));
+            a = na; b = nb;
           }
         }
       }
