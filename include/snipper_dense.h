@@ -32,12 +32,15 @@ int snipper_linear_bf16(void *stream, const uint16_t *X, long long ldx, const ui
                         const float *bias, const uint16_t *R, long long ldr, uint16_t *Y, long long ldy,
                         int M, int N, int K, int relu, float dropout_p, uint64_t seed);
 
-/* Data gradient of the same layers without a transposed weight copy: Y[M,N] = X[M,K] . W[K,N] (+ R[M,N]), W
+/* Data gradient of the same layers without a transposed weight copy: Y[M,N] = gate(X[M,K] . W[K,N] + R[M,N]), W
  * row-major with the reduction index as its SLOW axis (a Linear's / 1x1 convolution's weight [out, in] taken as
- * [K, N]); X, W, R, Y bf16; R = NULL or an addend (the gradient that reaches the same tensor over a skip connection).
- * Requirements: K % 64 == 0, N % 8 == 0, ldx / ldw % 8 == 0, ldy / ldr % 4 == 0, X / W 16-byte aligned. */
+ * [K, N]); X, W, R, A, Y bf16.  R = NULL or an addend (the gradient that reaches the same tensor over a skip
+ * connection).  A = NULL or the activation this gradient flows back through: gate(v) = A > 0 ? v * gate_scale : 0,
+ * the backward of ReLU (gate_scale 1) or of ReLU followed by dropout with rate p applied to A (gate_scale 1/(1-p)).
+ * Requirements: K % 64 == 0, N % 8 == 0, ldx / ldw % 8 == 0, ldy / ldr / lda % 4 == 0, X / W 16-byte aligned. */
 int snipper_linear_nn_bf16(void *stream, const uint16_t *X, long long ldx, const uint16_t *W, long long ldw,
-                           const uint16_t *R, long long ldr, uint16_t *Y, long long ldy, int M, int N, int K);
+                           const uint16_t *R, long long ldr, const uint16_t *A, long long lda, float gate_scale,
+                           uint16_t *Y, long long ldy, int M, int N, int K);
 
 /* Backward of the (ReLU -> dropout) epilogue above from the layer's OUTPUT alone: a kept, active element has y > 0,
  * a dropped or inactive one y == 0, so grad_pre = y > 0 ? grad_y / (1 - p) : 0 (p = 0: plain ReLU backward).

@@ -62,7 +62,7 @@ EXPORTS = {
                              c_void_p, ctypes.c_longlong, c_int, c_int, c_int, c_int, ctypes.c_float,
                              ctypes.c_uint64], c_int),
     "snipper_linear_nn_bf16": ([c_void_p, c_void_p, c_longlong, c_void_p, c_longlong, c_void_p, c_longlong, c_void_p,
-                                c_longlong, c_int, c_int, c_int], c_int),
+                                c_longlong, ctypes.c_float, c_void_p, c_longlong, c_int, c_int, c_int], c_int),
     "snipper_relu_dropout_backward_bf16": ([c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, ctypes.c_float], c_int),
 }
 

@@ -47,15 +47,30 @@ constexpr int kGemmCtStride = 136;
 __device__ __forceinline__ bool gemm_wide_ok(const uint16_t *Y, long long ldy, int N) {
   return (N % 8) == 0 && (ldy % 8) == 0 && ((uintptr_t)Y % 16) == 0;
 }
-__device__ __forceinline__ void gemm_flush_tile(const uint16_t *Ct, uint16_t *Y, long long ldy, int m0, int n0, long long M, int N) {
+// `gate` (optional, [M][N] bf16, 16-byte aligned rows): elements whose gate value is not > 0 are written as 0 -- the
+// sign test of a ReLU (+ dropout) backward, done here on whole 16-byte chunks instead of per accumulator fragment.
+__device__ __forceinline__ void gemm_flush_tile(const uint16_t *Ct, uint16_t *Y, long long ldy, int m0, int n0, long long M, int N,
+                                                const uint16_t *gate = nullptr, long long ldg = 0) {
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int idx = threadIdx.x + 256 * i, row = idx >> 4, ch = idx & 15;
     const long long m = (long long)m0 + row;
     const int n = n0 + ch * 8;
-    if (m < M && n < N)
-      *reinterpret_cast<uint4 *>(Y + m * ldy + n) = *reinterpret_cast<const uint4 *>(Ct + row * kGemmCtStride + ch * 8);
+    if (m < M && n < N) {
+      uint4 v = *reinterpret_cast<const uint4 *>(Ct + row * kGemmCtStride + ch * 8);
+      if (gate) {
+        const uint4 a = *reinterpret_cast<const uint4 *>(gate + m * ldg + n);
+        // a bf16 is > 0 iff its sign bit is clear and it is not +0 (NaN gates do not occur: the gate is a ReLU output)
+        auto keep = [](unsigned av, unsigned vv) {
+          const unsigned lo = ((av & 0x8000u) == 0u && (av & 0x7fffu) != 0u) ? 0x0000ffffu : 0u;
+          const unsigned hi = ((av & 0x80000000u) == 0u && (av & 0x7fff0000u) != 0u) ? 0xffff0000u : 0u;
+          return vv & (lo | hi);
+        };
+        v.x = keep(a.x, v.x); v.y = keep(a.y, v.y); v.z = keep(a.z, v.z); v.w = keep(a.w, v.w);
+      }
+      *reinterpret_cast<uint4 *>(Y + m * ldy + n) = v;
+    }
   }
 }
 
@@ -210,6 +225,8 @@ struct GemmNNArgs {
   uint16_t *Y; long long ldy;            // [M][N]
   int M, N, K;
   const uint16_t *R; long long ldr;      // [M][N] addend (e.g. the gradient arriving over a skip connection) or nullptr
+  const uint16_t *A; long long lda;      // [M][N] activation whose sign gates the result (ReLU / ReLU+dropout
+  float gate_scale;                      //   backward): Y = A > 0 ? Y * gate_scale : 0;  nullptr = no gate
 };
 
 __device__ __forceinline__ gemm_bf16x8 gemm_tr_frag(const uint16_t *tile, int byte_off) {
@@ -224,6 +241,7 @@ __global__ __launch_bounds__(kGemmThreads) void linear_bf16_nn_kernel(GemmNNArgs
   __shared__ __attribute__((aligned(16))) uint16_t smem[kGemmBM * kGemmPad + kGemmBK * kGemmTrStride];
   uint16_t *Xs = smem, *Ws = smem + kGemmBM * kGemmPad;
   const bool wide = gemm_wide_ok(g.Y, g.ldy, g.N);
+  const bool gate_in_flush = wide && g.A && (g.lda % 8) == 0 && ((uintptr_t)g.A % 16) == 0;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave & 1, wn = wave >> 1;
   int tm, tn;
@@ -308,6 +326,17 @@ __global__ __launch_bounds__(kGemmThreads) void linear_bf16_nn_kernel(GemmNNArgs
         v.x += __uint_as_float(r.x << 16); v.y += __uint_as_float(r.x & 0xffff0000u);
         v.z += __uint_as_float(r.y << 16); v.w += __uint_as_float(r.y & 0xffff0000u);
       }
+      if (g.A) {
+        const float s = g.gate_scale;
+        v.x *= s; v.y *= s; v.z *= s; v.w *= s;
+        if (!gate_in_flush) {      // narrow path: sign test here, per fragment
+          const uint2 a = *reinterpret_cast<const uint2 *>(g.A + (long long)m * g.lda + n);
+          v.x = __uint_as_float(a.x << 16) > 0.f ? v.x : 0.f;
+          v.y = __uint_as_float(a.x & 0xffff0000u) > 0.f ? v.y : 0.f;
+          v.z = __uint_as_float(a.y << 16) > 0.f ? v.z : 0.f;
+          v.w = __uint_as_float(a.y & 0xffff0000u) > 0.f ? v.w : 0.f;
+        }
+      }
       uint2 o;
       o.x = gemm_pack2(v.x, v.y);
       o.y = gemm_pack2(v.z, v.w);
@@ -315,7 +344,7 @@ __global__ __launch_bounds__(kGemmThreads) void linear_bf16_nn_kernel(GemmNNArgs
       else *reinterpret_cast<uint2 *>(g.Y + (long long)m * g.ldy + n) = o;
     }
   }
-  if (wide) gemm_flush_tile(smem, g.Y, g.ldy, m0, n0, g.M, g.N);
+  if (wide) gemm_flush_tile(smem, g.Y, g.ldy, m0, n0, g.M, g.N, gate_in_flush ? g.A : nullptr, g.lda);
 }
 
 // Backward of (ReLU -> dropout) given only the layer's OUTPUT y: a kept, active element has y > 0, a dropped or

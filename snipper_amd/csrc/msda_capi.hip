@@ -436,13 +436,14 @@ int snipper_linear_bf16(void *stream, const uint16_t *X, long long ldx, const ui
 }
 
 int snipper_linear_nn_bf16(void *stream, const uint16_t *X, long long ldx, const uint16_t *W, long long ldw,
-                           const uint16_t *R, long long ldr, uint16_t *Y, long long ldy, int M, int N, int K) {
+                           const uint16_t *R, long long ldr, const uint16_t *A, long long lda, float gate_scale,
+                           uint16_t *Y, long long ldy, int M, int N, int K) {
   if (!X || !W || !Y) return SNIPPER_E_NULL;
   if (M <= 0 || N <= 0 || K <= 0 || K % kGemmBK || N % 8 || ldx % 8 || ldw % 8 || ldy % 4 || ldx < K || ldw < N || ldy < N ||
-      (R && (ldr % 4 || ldr < N)))
+      (R && (ldr % 4 || ldr < N)) || (A && (lda % 4 || lda < N)))
     return SNIPPER_E_SHAPE;
   if (((uintptr_t)X | (uintptr_t)W) & 15) return SNIPPER_E_SHAPE;
-  const GemmNNArgs g{X, ldx, W, ldw, Y, ldy, M, N, K, R, ldr};
+  const GemmNNArgs g{X, ldx, W, ldw, Y, ldy, M, N, K, R, ldr, A, lda, gate_scale};
   const dim3 grid(gemm_grid_size(M, N));
   hipLaunchKernelGGL(linear_bf16_nn_kernel, grid, dim3(kGemmThreads), 0, (hipStream_t)stream, g);
   return launch_status();

@@ -17,7 +17,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from .dense import big_linear
+from .dense import big_ffn, big_linear
 from .ms_deform_attn import MSDeformAttn
 
 
@@ -132,6 +132,9 @@ class _FFNMixin:
 
     def _ffn(self, x, drop_a, drop_b, norm):
         if self.activation is F.relu:
+            y = big_ffn(x, self.linear1, self.linear2, drop_a)            # the whole block as one node when it applies
+            if y is not None:
+                return _residual_norm(x, y, norm, drop_b)
             h = big_linear(x, self.linear1, relu=True, dropout=drop_a)   # ReLU + dropout in the kernel's epilogue
         else:
             h = drop_a(self.activation(big_linear(x, self.linear1)))
@@ -185,8 +188,9 @@ class DeformableTransformerEncoderLayer(nn.Module, _FFNMixin):
         attended = self.self_attn(q16, reference_points, src16, spatial_shapes, level_start_index, padding_mask)
         y32, y16, _ = add_dropout_layer_norm(src32, attended, self.norm1, self.dropout1.p, self.training,
                                              want=(True, True, False))
-        h = big_linear(y16, self.linear1, relu=True, dropout=self.dropout2)
-        z = big_linear(h, self.linear2)
+        z = big_ffn(y16, self.linear1, self.linear2, self.dropout2)
+        if z is None:
+            z = big_linear(big_linear(y16, self.linear1, relu=True, dropout=self.dropout2), self.linear2)
         return add_dropout_layer_norm(y32, z, self.norm2, self.dropout3.p, self.training, pos=pos16,
                                       want=(True, True, not last))
 

@@ -67,9 +67,12 @@ def conv3x3_bf16(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Ten
     return out
 
 
-def linear_nn_bf16(x: torch.Tensor, w: torch.Tensor, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """x [M, K] @ w [K, N] (+ residual [M, N]) (all bf16, row-major; w = a Linear's weight [out, in] used for the data
-    gradient) on the HIP kernel that reads the weight tile through the transposing LDS read -- no transposed copy."""
+def linear_nn_bf16(x: torch.Tensor, w: torch.Tensor, residual: Optional[torch.Tensor] = None,
+                   gate: Optional[torch.Tensor] = None, gate_scale: float = 1.0) -> torch.Tensor:
+    """gate(x [M, K] @ w [K, N] + residual [M, N]) (all bf16, row-major; w = a Linear's weight [out, in] used for the
+    data gradient) on the HIP kernel that reads the weight tile through the transposing LDS read -- no transposed
+    copy.  ``gate`` [M, N]: the activation the gradient flows back through; result = gate > 0 ? result * gate_scale : 0
+    (ReLU, or ReLU + dropout, backward fused into the epilogue)."""
     assert x.is_cuda and x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and x.dim() == 2 and w.dim() == 2
     assert x.shape[1] == w.shape[0]
     if x.stride(1) != 1 or x.stride(0) % 8 or x.data_ptr() % 16:
@@ -84,10 +87,16 @@ def linear_nn_bf16(x: torch.Tensor, w: torch.Tensor, residual: Optional[torch.Te
         r2 = residual.reshape(M, N)
         if r2.dtype != torch.bfloat16 or r2.stride(1) != 1 or r2.stride(0) % 4:
             r2 = r2.to(torch.bfloat16).contiguous()
+    a2 = None
+    if gate is not None:
+        a2 = gate.reshape(M, N)
+        if a2.dtype != torch.bfloat16 or a2.stride(1) != 1 or a2.stride(0) % 4:
+            a2 = a2.to(torch.bfloat16).contiguous()
     with torch.cuda.device(x.device):
         rc = _lib.load().snipper_linear_nn_bf16(
             torch.cuda.current_stream(x.device).cuda_stream, x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0),
             r2.data_ptr() if r2 is not None else None, r2.stride(0) if r2 is not None else 0,
+            a2.data_ptr() if a2 is not None else None, a2.stride(0) if a2 is not None else 0, float(gate_scale),
             out.data_ptr(), out.stride(0), M, N, K)
     _lib.check(rc, "snipper_linear_nn_bf16")
     return out
@@ -193,6 +202,70 @@ class _BigLinear(torch.autograd.Function):
             if db is not None and db.dtype != ctx.b_dtype:
                 db = db.to(ctx.b_dtype)
         return dx, dW, db, None, None
+
+
+class _BigFFN(torch.autograd.Function):
+    """linear2(dropout(relu(linear1(x)))) -- the feed-forward block of a transformer layer on 79 000 token rows
+    (reference models/deformable_transformer.py:194-198) as one autograd node: the hidden activation is written once
+    (ReLU and dropout in linear1's epilogue) and, in the backward, the gradient with respect to it gets its
+    ReLU / dropout gate inside the data-gradient kernel of linear2 -- no separate pass over the [rows, d_ffn] matrix in
+    either direction."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, dropout_p):
+        from . import shadow
+        k_in = w1.shape[1]
+        x2 = x.reshape(-1, k_in)
+        xb = x2 if x2.dtype == torch.bfloat16 else x2.to(torch.bfloat16)
+        w1b = shadow.lookup(w1)
+        w1b = w1b if w1b is not None else w1.to(torch.bfloat16)
+        w2b = shadow.lookup(w2)
+        w2b = w2b if w2b is not None else w2.to(torch.bfloat16)
+        seed = 0
+        if dropout_p > 0.0:
+            from .fused import _next_seed
+            seed = _next_seed()
+        h = linear_bf16(xb, w1b, b1.float(), None, True, dropout_p, seed)
+        z = linear_bf16(h, w2b, b2.float())
+        ctx.p, ctx.x_shape = float(dropout_p), x.shape
+        ctx.dts = (w1.dtype, b1.dtype, w2.dtype, b2.dtype)
+        ctx.save_for_backward(xb, w1b, w2b, h)
+        return z.view(*x.shape[:-1], w2.shape[0])
+
+    @staticmethod
+    def backward(ctx, gz):
+        xb, w1b, w2b, h = ctx.saved_tensors
+        g = gz.reshape(-1, w2b.shape[0])
+        if g.dtype != torch.bfloat16:
+            g = g.to(torch.bfloat16)
+        g = g.contiguous()
+        gh = linear_nn_bf16(g, w2b, None, h, 1.0 / (1.0 - ctx.p))            # gradient w.r.t. linear1's pre-activation
+        dW2, db2 = wgrad_bf16(g, h)
+        dx = _dgrad(gh, w1b).view(ctx.x_shape) if ctx.needs_input_grad[0] else None
+        dW1, db1 = wgrad_bf16(gh, xb)
+        outs = [dW1, db1, dW2, db2]
+        outs = [o if o.dtype == dt else o.to(dt) for o, dt in zip(outs, ctx.dts)]
+        return (dx, *outs, None)
+
+
+def big_ffn(x: torch.Tensor, lin1: torch.nn.Linear, lin2: torch.nn.Linear, dropout: Optional[torch.nn.Dropout]
+            ) -> Optional[torch.Tensor]:
+    """``lin2(dropout(relu(lin1(x))))`` as one node on the hand-written kernels, or None when the conditions of
+    ``big_linear`` do not hold for both layers (the caller then composes it from ``big_linear`` calls)."""
+    twin = getattr(x, "_snipper_bf16", None)
+    if twin is not None and twin.shape == x.shape and twin.device == x.device:
+        x = twin
+    rows = x.numel() // max(1, x.shape[-1])
+    in_bf16 = x.dtype == torch.bfloat16 or (torch.is_autocast_enabled('cuda') and
+                                             torch.get_autocast_dtype('cuda') == torch.bfloat16)
+    ok = (x.is_cuda and in_bf16 and rows >= BIG_LINEAR_MIN_ROWS and x.dtype in (torch.bfloat16, torch.float32) and
+          lin1.in_features % 64 == 0 and lin1.out_features % 64 == 0 and lin2.in_features == lin1.out_features and
+          lin2.out_features % 8 == 0 and lin1.bias is not None and lin2.bias is not None and
+          rows * lin1.out_features < 2 ** 32)
+    if not ok:
+        return None
+    p = dropout.p if (dropout is not None and dropout.training) else 0.0
+    return _BigFFN.apply(x, lin1.weight, lin1.bias, lin2.weight, lin2.bias, p)
 
 
 def _relu_dropout_backward(g: torch.Tensor, y: torch.Tensor, p: float) -> torch.Tensor:

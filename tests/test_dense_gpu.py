@@ -239,3 +239,30 @@ def test_linear_nn_kernel(M, K, N):
     err = (y.double() - ref).abs().max().item()
     assert err <= 2e-2 * max(1.0, ref.abs().max().item()), err
     assert ((y.double() - ref).norm() / ref.norm()).item() < 4e-3
+
+
+def test_big_ffn_matches_two_big_linears():
+    """The one-node feed-forward block against its composition from big_linear calls (dropout off): output and all
+    gradients; plus the gated data-gradient epilogue against the explicit mask."""
+    from snipper_amd.dense import big_ffn, big_linear, linear_nn_bf16
+    torch.manual_seed(8)
+    l1, l2 = torch.nn.Linear(384, 1024).to(DEV), torch.nn.Linear(1024, 384).to(DEV)
+    x = torch.randn(2, 2500, 384, device=DEV, requires_grad=True)
+    gy = torch.randn(2, 2500, 384, device=DEV).bfloat16()
+    params = [l1.weight, l1.bias, l2.weight, l2.bias]
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y = big_ffn(x, l1, l2, None)
+        g1 = torch.autograd.grad(y, [x] + params, gy)
+        yr = big_linear(big_linear(x, l1, relu=True), l2)
+        g2 = torch.autograd.grad(yr, [x] + params, gy)
+    assert torch.equal(y, yr)
+    rel = lambda a, b: ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()
+    for a, b in zip(g1, g2):
+        assert rel(a, b) < 5e-3, rel(a, b)
+    # gate epilogue
+    g = torch.randn(3000, 384, device=DEV).bfloat16()
+    w = (torch.randn(384, 1024, device=DEV) / 20).bfloat16()
+    h = torch.randn(3000, 1024, device=DEV).relu().bfloat16()
+    out = linear_nn_bf16(g, w, None, h, 1.25).float()
+    ref = torch.where(h.float() > 0, (g.float() @ w.float()) * 1.25, torch.zeros(1, device=DEV))
+    assert rel(out, ref) < 5e-3 and torch.all(out[h == 0] == 0)
