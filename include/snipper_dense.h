@@ -15,6 +15,7 @@
 
 #include <stddef.h>
 #include <stdint.h>
+#include "snipper_msda.h"
 
 #ifdef __cplusplus
 extern "C" {
@@ -146,6 +147,35 @@ int snipper_msda_prologue_backward(void *stream, const float *grad_loc, const fl
                                    const float *inv_w, const float *inv_h, long long rows, int M, int L, int P,
                                    void *grad_off, long long grad_off_ld, void *grad_logit, long long grad_logit_ld,
                                    int dtype, float *grad_ref);
+
+/* ---- the tied spatiotemporal module core in one call ------------------------------------------------------
+ * What MSDeformAttn.forward does between its value projection and its output projection when the per-frame
+ * offset / weight Linears are one module (reference models/ops/modules/ms_deform_attn.py:130-233, see DESIGN.md
+ * section 4): out[n, t1] = core_op(mean_{t2 in g(t1)} masked value[n, t2], ref + offsets, softmax(logits)).
+ *   value [N,T2,S,M*D] (value_dtype 0 = f32 / 1 = bf16), mask [N,T2,S] bytes or NULL (non-zero = padding),
+ *   mix: HOST [T1*T2] floats, mix[t1*T2 + t2] = 1/|g(t1)| for t2 in g(t1) else 0 (the neighbour table);
+ *   off / logit (+ per-query leading dimensions, dtype ql_dtype) and ref [N*T1*Lq, L, 2] as for
+ *   snipper_msda_prologue_forward; inv_w / inv_h HOST [L]; shapes / level_start device int64.
+ *   Outputs: vbar [N*T1,S,M,D] f32, loc [N*T1,Lq,M,L,P,2] f32, prob [N*T1,Lq,M,L,P] f32 (kept by the caller for the
+ *   backward) and out [N*T1,Lq,M*D] (f32, or bf16 rows when out_bf16 != 0 and D == 48).
+ * Backward: grad_out (f32 or bf16 rows) -> grad_value [N,T2,S,M*D] (value_dtype), grad_off / grad_logit (ql_dtype,
+ * same addressing as off / logit), grad_ref [N*T1*Lq,L,2] or NULL.  host_shapes (HOST [L,2], may be NULL) enables the
+ * owner-computes kernels; workspace >= snipper_st_msda_backward_workspace_bytes(...). */
+int snipper_st_msda_forward(void *stream, const void *value, int value_dtype, const unsigned char *mask, const float *mix,
+                            const void *off, long long off_ld, const void *logit, long long logit_ld, int ql_dtype,
+                            const float *ref, const float *inv_w, const float *inv_h,
+                            const int64_t *shapes, const int64_t *level_start,
+                            int N, int T1, int T2, int S, int M, int D, int L, int Lq, int P,
+                            float *vbar, float *loc, float *prob, void *out, int out_bf16);
+size_t snipper_st_msda_backward_workspace_bytes(int N, int T1, int S, int M, int D, int L, int Lq, int P,
+                                                const int64_t *host_shapes);
+int snipper_st_msda_backward(void *stream, const void *grad_out, int grad_out_bf16, const float *vbar, const float *loc,
+                             const float *prob, const unsigned char *mask, const float *mix,
+                             const float *inv_w, const float *inv_h, const int64_t *shapes, const int64_t *level_start,
+                             const int64_t *host_shapes, int N, int T1, int T2, int S, int M, int D, int L, int Lq, int P,
+                             void *workspace, size_t workspace_bytes,
+                             void *grad_value, int value_dtype, void *grad_off, long long grad_off_ld,
+                             void *grad_logit, long long grad_logit_ld, int ql_dtype, float *grad_ref);
 
 /* ---- Hungarian matching on the device (csrc/lsap.cuh) ---------------------------------------------------
  * Replaces the host round trip of models/matcher.py:132 (`linear_sum_assignment(cost.cpu())`).

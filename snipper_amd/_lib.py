@@ -57,6 +57,12 @@ EXPORTS = {
     "snipper_colsum_segments_bf16": ([c_void_p, c_void_p, c_longlong, c_int, c_int, c_int, c_void_p, c_void_p,
                                       c_size_t], c_int),
     "snipper_conv3x3_bf16": ([c_void_p] * 5 + [c_int] * 7, c_int),
+    "snipper_st_msda_forward": ([c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_longlong, c_void_p, c_longlong,
+                                 c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 9 +
+                                [c_void_p] * 4 + [c_int], c_int),
+    "snipper_st_msda_backward_workspace_bytes": ([c_int] * 8 + [c_void_p], c_size_t),
+    "snipper_st_msda_backward": ([c_void_p, c_void_p, c_int] + [c_void_p] * 10 + [c_int] * 9 + [c_void_p, c_size_t,
+                                 c_void_p, c_int, c_void_p, c_longlong, c_void_p, c_longlong, c_int, c_void_p], c_int),
     "snipper_lsap_f32": ([c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p], c_int),
     "snipper_linear_bf16": ([c_void_p, c_void_p, ctypes.c_longlong, c_void_p, c_void_p, c_void_p, ctypes.c_longlong,
                              c_void_p, ctypes.c_longlong, c_int, c_int, c_int, c_int, ctypes.c_float,

@@ -755,6 +755,88 @@ int snipper_msda_prologue_backward(void *stream, const float *grad_loc, const fl
   return launch_status();
 }
 
+// ---- the whole tied spatiotemporal module core in one call ("the fused entry") ------------------
+// forward : temporal mean of the neighbouring value frames (+ padding mask) -> sampling locations / probabilities ->
+//           core op with the T1 query frames folded into the batch.
+// backward: core op backward -> adjoint of locations / softmax -> adjoint of the temporal mean.
+// Pure compositions of the entry points above on one stream; the caller keeps vbar / loc / prob between the two.
+namespace {
+inline bool st_dims_ok(int N, int T1, int T2, int S, int M, int D, int L, int Lq, int P) {
+  return N > 0 && T1 > 0 && T2 > 0 && T1 <= kMixMaxFrames && T2 <= kMixMaxFrames && S > 0 && M > 0 && D > 0 && L > 0 &&
+         Lq > 0 && P > 0 && (long long)N * T1 < (1LL << 31);
+}
+inline void st_transpose_mix(const float *mix, int T1, int T2, float *out) {
+  for (int a = 0; a < T1; ++a)
+    for (int b = 0; b < T2; ++b) out[b * T1 + a] = mix[a * T2 + b];
+}
+}  // namespace
+
+int snipper_st_msda_forward(void *stream, const void *value, int value_dtype, const unsigned char *mask, const float *mix,
+                            const void *off, long long off_ld, const void *logit, long long logit_ld, int ql_dtype,
+                            const float *ref, const float *inv_w, const float *inv_h,
+                            const int64_t *shapes, const int64_t *level_start,
+                            int N, int T1, int T2, int S, int M, int D, int L, int Lq, int P,
+                            float *vbar, float *loc, float *prob, void *out, int out_bf16) {
+  if (!value || !mix || !off || !logit || !ref || !shapes || !level_start || !vbar || !loc || !prob || !out)
+    return SNIPPER_E_NULL;
+  if (!st_dims_ok(N, T1, T2, S, M, D, L, Lq, P)) return SNIPPER_E_SHAPE;
+  if (int rc = snipper_temporal_mix(stream, value, value_dtype, mask, 1, mix, N, T2, T1, S, M * D, vbar, 0)) return rc;
+  const long long rows = (long long)N * T1 * Lq * M;
+  if (int rc = snipper_msda_prologue_forward(stream, off, off_ld, logit, logit_ld, ql_dtype, ref, inv_w, inv_h, rows, M, L,
+                                             P, loc, prob))
+    return rc;
+  if (out_bf16)
+    return snipper_msda_forward_f32_bf16out(stream, vbar, shapes, level_start, loc, prob, N * T1, S, M, D, L, Lq, P,
+                                            (uint16_t *)out);
+  return snipper_msda_forward_f32(stream, vbar, shapes, level_start, loc, prob, N * T1, S, M, D, L, Lq, P, (float *)out);
+}
+
+size_t snipper_st_msda_backward_workspace_bytes(int N, int T1, int S, int M, int D, int L, int Lq, int P,
+                                                const int64_t *host_shapes) {
+  const size_t gv = (size_t)N * T1 * S * M * D * sizeof(float);
+  const size_t gl = (size_t)N * T1 * Lq * M * L * P * 3 * sizeof(float);
+  const long long owner = host_shapes ? snipper_msda_backward_workspace_bytes(N * T1, S, M, D, L, Lq, P, host_shapes) : 0;
+  return gv + gl + (size_t)((owner + 15) / 16 * 16);
+}
+
+int snipper_st_msda_backward(void *stream, const void *grad_out, int grad_out_bf16, const float *vbar, const float *loc,
+                             const float *prob, const unsigned char *mask, const float *mix,
+                             const float *inv_w, const float *inv_h, const int64_t *shapes, const int64_t *level_start,
+                             const int64_t *host_shapes, int N, int T1, int T2, int S, int M, int D, int L, int Lq, int P,
+                             void *workspace, size_t workspace_bytes,
+                             void *grad_value, int value_dtype, void *grad_off, long long grad_off_ld,
+                             void *grad_logit, long long grad_logit_ld, int ql_dtype, float *grad_ref) {
+  if (!grad_out || !vbar || !loc || !prob || !mix || !shapes || !level_start || !workspace || !grad_value || !grad_off ||
+      !grad_logit)
+    return SNIPPER_E_NULL;
+  if (!st_dims_ok(N, T1, T2, S, M, D, L, Lq, P)) return SNIPPER_E_SHAPE;
+  if (workspace_bytes < snipper_st_msda_backward_workspace_bytes(N, T1, S, M, D, L, Lq, P, host_shapes)) return SNIPPER_E_SHAPE;
+  const size_t gv_bytes = (size_t)N * T1 * S * M * D * sizeof(float);
+  const size_t rows_lp = (size_t)N * T1 * Lq * M * L * P;
+  float *g_vbar = (float *)workspace;
+  float *g_loc = (float *)((char *)workspace + gv_bytes);
+  float *g_prob = g_loc + 2 * rows_lp;
+  void *owner_ws = (char *)workspace + gv_bytes + rows_lp * 3 * sizeof(float);
+  const long long owner_bytes = host_shapes ? snipper_msda_backward_workspace_bytes(N * T1, S, M, D, L, Lq, P, host_shapes) : 0;
+  int rc;
+  if (grad_out_bf16)
+    rc = snipper_msda_backward_ws_f32_bf16in(stream, (const uint16_t *)grad_out, vbar, shapes, level_start,
+                                             owner_bytes > 0 ? host_shapes : nullptr, owner_ws, owner_bytes, loc, prob,
+                                             N * T1, S, M, D, L, Lq, P, g_vbar, g_loc, g_prob);
+  else
+    rc = snipper_msda_backward_ws_f32(stream, (const float *)grad_out, vbar, shapes, level_start,
+                                      owner_bytes > 0 ? host_shapes : nullptr, owner_ws, owner_bytes, loc, prob,
+                                      N * T1, S, M, D, L, Lq, P, g_vbar, g_loc, g_prob);
+  if (rc) return rc;
+  const long long rows = (long long)N * T1 * Lq * M;
+  rc = snipper_msda_prologue_backward(stream, g_loc, g_prob, prob, inv_w, inv_h, rows, M, L, P, grad_off, grad_off_ld,
+                                      grad_logit, grad_logit_ld, ql_dtype, grad_ref);
+  if (rc) return rc;
+  float mix_t[kMixMaxFrames * kMixMaxFrames];
+  st_transpose_mix(mix, T1, T2, mix_t);
+  return snipper_temporal_mix(stream, g_vbar, 0, mask, 0, mix_t, N, T1, T2, S, M * D, grad_value, value_dtype);
+}
+
 int snipper_lsap_f32(void *stream, const float *cost, int P, int n, int m, long long *out_src, long long *out_tgt) {
   if (!cost || !out_src || !out_tgt) return SNIPPER_E_NULL;
   if (P <= 0 || m <= 0 || n < m || n > kLsapMaxCols || m > kLsapMaxRows) return SNIPPER_E_SHAPE;
