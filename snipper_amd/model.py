@@ -121,6 +121,8 @@ class SnipperDeformable(nn.Module):
         tensors that the transformer immediately flattens back to token rows): the projections and the position
         encoding are produced token-major.  Returns None when the conditions of the fused path do not hold."""
         joiner = self.backbone
+        if not (isinstance(joiner, nn.Sequential) and len(joiner) >= 2):
+            return None
         if not (self.token_rows and samples.tensors.is_cuda and hasattr(self.transformer, "forward_from_features") and
                 hasattr(joiner[1], "channel_last") and self.num_feature_levels == len(joiner.num_channels)):
             return None

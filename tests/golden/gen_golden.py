@@ -15,6 +15,7 @@ Fixtures:
   g2_core_d48.npz      D=48, M=8, L=3, P=4 core op with out-of-range locations; fp64.
   g3_module_*.pt       MSDeformAttn modules (encoder T=3, decoder T=3 and T=3+2) with randomised
                        tied Linears and a padding mask: outputs, input grads, param grads, vis lists.
+  g6_model.pt          the reference SnipperDeformable on a replayed backbone: outputs + state_dict schema + aliases
   g5_criterion.pt      SetCriterion + HungarianMatcher (reference classes, torchvision / cv2 stubbed) on random
                        3-layer outputs: every loss, the matching, gradients of the weighted sum.
   g4_transformer.pt    one DeformableTransformer forward (T=2+1, enc2/dec2) + its state_dict
@@ -320,6 +321,65 @@ def gen_g5():
     }, os.path.join(OUT, "g5_criterion.pt"))
 
 
+def gen_g6(DeformableTransformer):
+    """The reference SnipperDeformable (models/model.py:45-237) itself on top of a stand-in backbone that replays stored
+    feature maps / masks / position encodings: pins the model assembly -- input projections, the [b*t,c,h,w] ->
+    [b,c,t,h,w] reshapes, query embedding, the shared prediction heads incl. the reference-point offset of the root
+    joint, aux outputs -- and the full state_dict key schema with its aliases (class_embed.N, root_embed.N,
+    joint_embed.N.K and their transformer.decoder.* twins)."""
+    ref_model, _ = import_reference_criterion()
+    from util.misc import NestedTensor
+    torch.manual_seed(11)
+    g = torch.Generator().manual_seed(123)
+    d_model, nhead, L, T, Fu, nq, K = 96, 4, 3, 2, 1, 5, 15
+    hw, chans, bs = [(12, 16), (6, 8), (3, 4)], [16, 32, 64], 2
+
+    feats = [torch.randn(bs * T, c, h, w, generator=g) for c, (h, w) in zip(chans, hw)]
+    masks = []
+    for h, w in hw:
+        m = torch.zeros(bs * T, h, w, dtype=torch.bool)
+        m[T:, :, w - max(1, w // 4):] = True            # sample 1 is padded on the right / bottom
+        m[T:, h - max(1, h // 3):, :] = True
+        masks.append(m)
+    pos = [torch.randn(bs * T, d_model, h, w, generator=g) for h, w in hw]
+
+    class Replay(torch.nn.Module):
+        strides, num_channels = [8, 16, 32], chans
+
+        def forward(self, samples):
+            return [NestedTensor(f, m) for f, m in zip(feats, masks)], [p.clone() for p in pos]
+
+    tr = DeformableTransformer(d_model=d_model, nhead=nhead, num_encoder_layers=1, num_decoder_layers=2,
+                               dim_feedforward=64, dropout=0.0, activation="relu", return_intermediate_dec=True,
+                               num_feature_levels=L, dec_n_points=4, enc_n_points=4, n_frame=T, n_future_frame=Fu,
+                               use_pytroch_deform=True, num_keypoints=K)
+    model = ref_model.SnipperDeformable(Replay(), tr, num_queries=nq, num_feature_levels=L, num_frames=T,
+                                        num_future_frames=Fu, num_keypoints=K, aux_loss=True)
+    with torch.no_grad():
+        tr.temporal_embed.copy_(torch.randn(tr.temporal_embed.shape, generator=g))
+    randomise_(model, g)
+    model.eval()
+    samples = NestedTensor(torch.zeros(bs * T, 3, 96, 128), torch.zeros(bs * T, 96, 128, dtype=torch.bool))
+    out, (init_ref, inter_refs, _) = model(samples)
+    sd = model.state_dict()
+    ptr = {}
+    for k, v in sd.items():
+        ptr.setdefault(v.data_ptr(), []).append(k)
+    torch.save({
+        "cfg": dict(d_model=d_model, nhead=nhead, num_encoder_layers=1, num_decoder_layers=2, dim_feedforward=64,
+                    dropout=0.0, num_feature_levels=L, dec_n_points=4, enc_n_points=4, n_frame=T, n_future_frame=Fu,
+                    num_keypoints=K),
+        "num_queries": nq, "chans": chans, "hw": hw, "bs": bs,
+        "feats": feats, "masks": masks, "pos": pos,
+        "state_dict": {k: v.detach().clone() for k, v in sd.items()},
+        "aliases": sorted(sorted(v) for v in ptr.values() if len(v) > 1),
+        "pred_logits": out["pred_logits"].detach(), "pred_kpts2d": out["pred_kpts2d"].detach(),
+        "pred_depth": out["pred_depth"].detach(), "heatmaps": [h.detach().clone() for h in out["heatmaps"]],
+        "aux": [{k: v.detach() for k, v in a.items()} for a in out["aux_outputs"]],
+        "init_ref": init_ref.detach(), "inter_refs": inter_refs.detach(),
+    }, os.path.join(OUT, "g6_model.pt"))
+
+
 if __name__ == "__main__":
     core, MSDeformAttn, DeformableTransformer = import_reference()
     gen_g1(core)
@@ -327,5 +387,6 @@ if __name__ == "__main__":
     gen_g3(MSDeformAttn)
     gen_g4(DeformableTransformer)
     gen_g5()
+    gen_g6(DeformableTransformer)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -136,3 +136,51 @@ def test_core_op_has_no_cpu_fallback():
     lsi = torch.tensor([0])
     with pytest.raises(RuntimeError, match="Not implemented on the CPU"):
         MSDeformAttnFunction.apply(v, shapes, lsi, torch.zeros(1, 1, 1, 1, 1, 2), torch.zeros(1, 1, 1, 1, 1), 64)
+
+
+def test_model_assembly_matches_reference_on_replayed_backbone(golden_dir):
+    """SnipperDeformable (snipper_amd/model.py) against the reference model itself (golden g6: models/model.py:45-237 run
+    on a stand-in backbone that replays stored feature maps): state_dict key schema incl. the aliases of the shared
+    heads, strict loading of the reference's weights, and every output of the forward pass."""
+    import os
+    import torch
+    from snipper_amd.deformable_transformer import DeformableTransformer
+    from snipper_amd.misc import NestedTensor
+    from snipper_amd.model import SnipperDeformable
+    b = torch.load(os.path.join(golden_dir, "g6_model.pt"))
+
+    class Replay(torch.nn.Module):
+        strides, num_channels = [8, 16, 32], b["chans"]
+
+        def forward(self, samples):
+            return [NestedTensor(f, m) for f, m in zip(b["feats"], b["masks"])], [p.clone() for p in b["pos"]]
+
+    tr = DeformableTransformer(return_intermediate_dec=True, use_pytroch_deform=True, activation="relu", **b["cfg"])
+    model = SnipperDeformable(Replay(), tr, num_queries=b["num_queries"], num_feature_levels=len(b["hw"]),
+                              num_frames=b["cfg"]["n_frame"], num_future_frames=b["cfg"]["n_future_frame"],
+                              num_keypoints=b["cfg"]["num_keypoints"], aux_loss=True)
+    sd = model.state_dict()
+    assert sorted(sd.keys()) == sorted(b["state_dict"].keys())
+    for k, v in sd.items():
+        assert tuple(v.shape) == tuple(b["state_dict"][k].shape), k
+    ptr = {}
+    for k, v in sd.items():
+        ptr.setdefault(v.data_ptr(), []).append(k)
+    assert sorted(sorted(v) for v in ptr.values() if len(v) > 1) == b["aliases"]
+    model.load_state_dict(b["state_dict"], strict=True)
+    model.eval()
+    T = b["cfg"]["n_frame"]
+    samples = NestedTensor(torch.zeros(b["bs"] * T, 3, 96, 128), torch.zeros(b["bs"] * T, 96, 128, dtype=torch.bool))
+    with torch.no_grad():
+        out, (init_ref, inter_refs, _) = model(samples)
+    tol = dict(rtol=1e-4, atol=1e-5)
+    for k in ("pred_logits", "pred_kpts2d", "pred_depth"):
+        torch.testing.assert_close(out[k], b[k], **tol)
+    for h, hr in zip(out["heatmaps"], b["heatmaps"]):
+        torch.testing.assert_close(h, hr, **tol)
+    assert len(out["aux_outputs"]) == len(b["aux"])
+    for a, ar in zip(out["aux_outputs"], b["aux"]):
+        for k in ar:
+            torch.testing.assert_close(a[k], ar[k], **tol)
+    torch.testing.assert_close(init_ref, b["init_ref"], **tol)
+    torch.testing.assert_close(inter_refs, b["inter_refs"], **tol)

@@ -198,3 +198,36 @@ def test_decoder_self_attention_matches_nn_multihead_attention():
     torch.testing.assert_close(y, yr, rtol=1e-4, atol=1e-5)
     for a, b in zip(g1, g2):
         torch.testing.assert_close(a, b, rtol=1e-3, atol=1e-4)
+
+
+def test_model_on_hip_matches_reference_model(golden_dir):
+    """Golden g6 (the reference SnipperDeformable on a replayed backbone) through the HIP kernels in float32."""
+    from snipper_amd.misc import NestedTensor
+    from snipper_amd.model import SnipperDeformable
+    b = torch.load(os.path.join(golden_dir, "g6_model.pt"))
+
+    class Replay(torch.nn.Module):
+        strides, num_channels = [8, 16, 32], b["chans"]
+
+        def forward(self, samples):
+            return ([NestedTensor(f.to(DEV), m.to(DEV)) for f, m in zip(b["feats"], b["masks"])],
+                    [p.to(DEV) for p in b["pos"]])
+
+    tr = DeformableTransformer(return_intermediate_dec=True, use_pytroch_deform=False, activation="relu", **b["cfg"])
+    model = SnipperDeformable(Replay(), tr, num_queries=b["num_queries"], num_feature_levels=len(b["hw"]),
+                              num_frames=b["cfg"]["n_frame"], num_future_frames=b["cfg"]["n_future_frame"],
+                              num_keypoints=b["cfg"]["num_keypoints"], aux_loss=True)
+    model.load_state_dict(b["state_dict"], strict=True)
+    model = model.to(DEV).eval()
+    T = b["cfg"]["n_frame"]
+    samples = NestedTensor(torch.zeros(b["bs"] * T, 3, 96, 128, device=DEV),
+                           torch.zeros(b["bs"] * T, 96, 128, dtype=torch.bool, device=DEV))
+    with torch.no_grad():
+        out, (init_ref, inter_refs, _) = model(samples)
+    tol = dict(rtol=1e-3, atol=1e-4)
+    for k in ("pred_logits", "pred_kpts2d", "pred_depth"):
+        torch.testing.assert_close(out[k].cpu(), b[k], **tol)
+    for a, ar in zip(out["aux_outputs"], b["aux"]):
+        for k in ar:
+            torch.testing.assert_close(a[k].cpu(), ar[k], **tol)
+    torch.testing.assert_close(inter_refs.cpu(), b["inter_refs"], **tol)
