@@ -184,3 +184,21 @@ def test_model_assembly_matches_reference_on_replayed_backbone(golden_dir):
             torch.testing.assert_close(a[k], ar[k], **tol)
     torch.testing.assert_close(init_ref, b["init_ref"], **tol)
     torch.testing.assert_close(inter_refs, b["inter_refs"], **tol)
+
+
+def test_nested_tensor_from_ragged_snippets():
+    """util/misc.py:310-330: every snippet [T*3, H, W] is split into T images, all images are zero-padded to the
+    largest H and W of the batch, the mask is True exactly on the padding; equal-sized inputs take the stack path."""
+    import torch
+    from snipper_amd.misc import nested_tensor_from_tensor_list
+    g = torch.Generator().manual_seed(0)
+    a, b = torch.rand(6, 5, 7, generator=g), torch.rand(6, 4, 9, generator=g)        # T = 2 frames each
+    nt = nested_tensor_from_tensor_list([a, b])
+    x, m = nt.decompose()
+    assert x.shape == (4, 3, 5, 9) and m.shape == (4, 5, 9) and m.dtype == torch.bool
+    assert torch.equal(x[0, :, :5, :7], a[:3]) and torch.equal(x[1, :, :5, :7], a[3:])
+    assert torch.equal(x[2, :, :4, :9], b[:3]) and torch.equal(x[3, :, :4, :9], b[3:])
+    assert float(x[0, :, :, 7:].abs().sum()) == 0 and float(x[2, :, 4:, :].abs().sum()) == 0
+    assert not m[0, :5, :7].any() and m[0, :, 7:].all() and not m[2, :4, :].any() and m[2, 4:, :].all()
+    same = nested_tensor_from_tensor_list([a, a.clone()])
+    assert same.tensors.shape == (4, 3, 5, 7) and not same.mask.any()
