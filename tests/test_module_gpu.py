@@ -231,3 +231,32 @@ def test_model_on_hip_matches_reference_model(golden_dir):
         for k in ar:
             torch.testing.assert_close(a[k].cpu(), ar[k], **tol)
     torch.testing.assert_close(inter_refs.cpu(), b["inter_refs"], **tol)
+
+
+def test_model_token_row_path_with_padded_inputs():
+    """Two snippets of different sizes (zero padding, masks True on it, valid ratios != 1): the token-row path against
+    the channel-first route, bf16 autocast, eval mode."""
+    import importlib.util
+    from types import SimpleNamespace
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    a = SimpleNamespace(hidden_dim=192, enc_layers=1, dec_layers=1, frames=2, future_frames=0, use_pytorch_deform=0,
+                        batch=2, height=96, width=128)
+    from snipper_amd.model import build_model, SnipperDeformable
+    torch.manual_seed(1)
+    model = build_model(b.model_args(a)).to(DEV).to(memory_format=torch.channels_last).eval()
+    g = torch.Generator().manual_seed(4)
+    imgs = [torch.rand(6, 96, 128, generator=g).to(DEV), torch.rand(6, 80, 104, generator=g).to(DEV)]
+    res = {}
+    for fast in (True, False):
+        SnipperDeformable.token_rows = fast
+        try:
+            with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+                out, _ = model(imgs)
+        finally:
+            SnipperDeformable.token_rows = True
+        res[fast] = (out["pred_kpts2d"].float(), out["pred_logits"].float())
+    rel = lambda x, y: ((x.double() - y.double()).norm() / y.double().norm().clamp_min(1e-20)).item()
+    assert rel(res[True][0], res[False][0]) < 3e-2 and rel(res[True][1], res[False][1]) < 3e-2
