@@ -19,8 +19,9 @@ Overlap: backward reaches the backbone last (~1/4 of the step's GPU time, >half 
 If ``early`` names the parameters whose gradients are complete before that (everything but the backbone) and
 ``trigger`` the ones whose gradients arrive last among them (the 1x1 input projections between backbone and
 encoder), a post-accumulate hook on the trigger parameters packs and all-reduces the early slice while the backbone's
-backward is still running; ``sync()`` then only has the backbone's slice left.  The early launch is taken only when
-every early gradient is present at that moment -- otherwise ``sync()`` does everything, as without overlap.
+backward is still running; ``sync()`` then only has the backbone's slice left.  The early launch happens as soon as the
+last trigger gradient is complete, on every rank alike (the same collectives in the same order); autograd's ordering
+guarantees that the early parameters are complete by then (their nodes were created after the projections').
 """
 from __future__ import annotations
 
@@ -96,10 +97,11 @@ class FlatGradSync:
         self._pending -= 1
         if self._pending > 0 or self._early_done:
             return
-        if all(p.grad is not None for p in self.params[:self.n_early]):
-            self._pack(0, self.n_early)
-            self._early_works = self._reduce(0, self.early_elems)
-            self._early_done = True
+        # Taken unconditionally once the last trigger has fired, so that every rank issues the same collectives in the
+        # same order whatever its batch looked like; an early parameter without a gradient contributes zeros.
+        self._pack(0, self.n_early)
+        self._early_works = self._reduce(0, self.early_elems)
+        self._early_done = True
 
     @torch.no_grad()
     def broadcast_parameters(self, modules_or_tensors: Iterable[torch.Tensor], src: int = 0) -> None:
