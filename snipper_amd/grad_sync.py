@@ -21,7 +21,9 @@ If ``early`` names the parameters whose gradients are complete before that (ever
 encoder), a post-accumulate hook on the trigger parameters packs and all-reduces the early slice while the backbone's
 backward is still running; ``sync()`` then only has the backbone's slice left.  The early launch happens as soon as the
 last trigger gradient is complete, on every rank alike (the same collectives in the same order); autograd's ordering
-guarantees that the early parameters are complete by then (their nodes were created after the projections').
+makes most early parameters complete by then (their nodes were created after the projections'); one that is completed
+later (e.g. ``level_embed`` on the token-row path, whose gradient also collects the projections' own contribution) is
+detected in ``sync()`` -- its gradient object differs from what was packed -- and reduced there.
 """
 from __future__ import annotations
 
@@ -67,7 +69,7 @@ class FlatGradSync:
         if start < total:
             self.chunks.append((start, total))
         self.early_elems = sum(p.numel() for p in self.params[:self.n_early])
-        self._early_works, self._early_done = [], False
+        self._early_works, self._early_done, self._early_seen = [], False, []
         self._trigger = [p for p in trigger if p.requires_grad]
         self._pending = len(self._trigger)
         if self.n_early and self._trigger and self.world > 1:
@@ -99,6 +101,7 @@ class FlatGradSync:
             return
         # Taken unconditionally once the last trigger has fired, so that every rank issues the same collectives in the
         # same order whatever its batch looked like; an early parameter without a gradient contributes zeros.
+        self._early_seen = [p.grad for p in self.params[:self.n_early]]      # what was packed (None = zeros)
         self._pack(0, self.n_early)
         self._early_works = self._reduce(0, self.early_elems)
         self._early_done = True
@@ -116,8 +119,21 @@ class FlatGradSync:
         """Mean of the ranks' gradients into every ``p.grad`` (collective: every rank must call it)."""
         first = self.n_early if self._early_done else 0
         self._pack(first, len(self.params))
+        late = []
+        if self._early_done:
+            # an "early" gradient that was completed (or replaced) after the early launch -- a property of the graph,
+            # hence the same on every rank: its slice is packed and reduced now
+            off = 0
+            for i, p in enumerate(self.params[:self.n_early]):
+                if p.grad is not None and p.grad is not self._early_seen[i] and p.grad is not self.views[i]:
+                    self.views[i].copy_(p.grad)
+                    late.append((off, off + p.numel()))
+                off += p.numel()
+            self._early_seen = []
         if self.world > 1:
             works = self._early_works + self._reduce(self.early_elems if self._early_done else 0, self.flat.numel())
+            works += [dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                      for a, b in late]
             for w in works:
                 w.wait()
             self.flat.mul_(1.0 / self.world)

@@ -52,7 +52,10 @@ def _worker(rank, world, port, out_dir, mode):
         from snipper_amd.grad_sync import FlatGradSync
         ddp = model
         early = [p for n, p in model.named_parameters() if not n.startswith("backbone.")]
-        gsync = FlatGradSync(model.parameters(), chunks=3, early=early, trigger=list(model.input_proj.parameters()))
+        # "flat_late": the trigger fires at the very start of backward, so nearly every early gradient is completed
+        # AFTER the early launch -- exercises the late-arrival path of sync()
+        trig = list(model.input_proj.parameters()) if mode == "flat" else list(model.class_embed[0].parameters())
+        gsync = FlatGradSync(model.parameters(), chunks=3, early=early, trigger=trig)
         gsync.broadcast_parameters(list(model.parameters()) + list(model.buffers()))
     from snipper_amd.criterion import build_criterion
     crit = build_criterion(b.criterion_args(ARGS))
@@ -77,7 +80,7 @@ def _worker(rank, world, port, out_dir, mode):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["flat", "torch"])
+@pytest.mark.parametrize("mode", ["flat", "flat_late", "torch"])
 def test_two_rank_gloo_step_matches_single_process(tmp_path, mode):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
