@@ -239,6 +239,11 @@ def time_msda_modules(a, device):
 
 
 def main():
+    # Native libraries write to the process's stdout too (RCCL prints a version banner when its first communicator comes
+    # up): keep the real stdout for the ONE JSON line and send everything else that goes to fd 1 to stderr.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
@@ -532,7 +537,8 @@ def main():
             line["msda"] = time_msda_modules(a, device)
         if world == 1 and not a.no_cpu_baseline and not a.no_extras:
             line["cpu_baseline"] = cpu_baseline(a)
-        print(json.dumps(line), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
     if use_ddp:
         dist.barrier()
         dist.destroy_process_group()

@@ -27,6 +27,7 @@ detected in ``sync()`` -- its gradient object differs from what was packed -- an
 """
 from __future__ import annotations
 
+import os
 from typing import Iterable, List
 
 import torch
@@ -53,6 +54,8 @@ class FlatGradSync:
         assert all(p.device == dev and p.dtype == dt for p in self.params), "float32 parameters on one device expected"
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # SNIPPER_SYNC_FORCE=1: run hooks and collectives even in a 1-rank group (exercises the path on a single GPU)
+        self.collective = self.world > 1 or (dist.is_initialized() and os.environ.get("SNIPPER_SYNC_FORCE") == "1")
         total = sum(p.numel() for p in self.params)
         self.flat = torch.zeros(total, dtype=dt, device=dev)
         self.views, off = [], 0
@@ -72,7 +75,7 @@ class FlatGradSync:
         self._early_works, self._early_done, self._early_seen = [], False, []
         self._trigger = [p for p in trigger if p.requires_grad]
         self._pending = len(self._trigger)
-        if self.n_early and self._trigger and self.world > 1:
+        if self.n_early and self._trigger and self.collective:
             for p in self._trigger:
                 p.register_post_accumulate_grad_hook(self._on_trigger)
 
@@ -130,7 +133,7 @@ class FlatGradSync:
                     late.append((off, off + p.numel()))
                 off += p.numel()
             self._early_seen = []
-        if self.world > 1:
+        if self.collective:
             works = self._early_works + self._reduce(self.early_elems if self._early_done else 0, self.flat.numel())
             works += [dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
                       for a, b in late]
