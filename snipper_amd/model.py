@@ -4,9 +4,8 @@ transformer -> prediction heads.
 API mirror of ``SnipperDeformable`` in /root/reference/models/model.py:45-237 (constructor
 arguments, parameter names -- ``input_proj.N.{0,1}``, ``query_embed``, ``class_embed.N``,
 ``root_embed.N.layers.0``, ``joint_embed.N.K.layers.0`` with the same tying across decoder layers --
-and the output dictionary).  The criterion / Hungarian matcher (model.py:240-545, matcher.py) are
-outside this round's scope; ``bench.py`` trains against a
-fixed-assignment surrogate loss and says so in its JSON line.
+and the output dictionary); pinned against the reference class itself by golden g6 (tests/test_host.py).  The
+criterion / Hungarian matcher (model.py:240-545, matcher.py) live in ``snipper_amd/criterion.py``.
 """
 from __future__ import annotations
 
