@@ -238,3 +238,28 @@ def test_level_pos_tokens_forward_backward():
     (d,) = torch.autograd.grad(out, le, gy)
     (dr,) = torch.autograd.grad(ref, le, gy.float())
     torch.testing.assert_close(d, dr, rtol=1e-4, atol=1e-3)
+
+
+def test_full_size_layernorm_and_groupnorm_tokens():
+    """The fused LayerNorm (79 000 x 384, the encoder's token matrix) and the GroupNorm-on-tokens kernels (8 images x
+    7500 pixels x 384 channels, level 0 of the 600x800 geometry) at BASELINE's full sizes against PyTorch in float32."""
+    from snipper_amd.fused import AddDropoutLayerNorm, InputProjTokens
+    g = torch.Generator().manual_seed(1)
+    rows, C = 79000, 384
+    x = torch.randn(rows, C, generator=g).to(DEV)
+    z = torch.randn(rows, C, generator=g).to(DEV).bfloat16()
+    gamma, beta = (torch.rand(C, generator=g) + 0.5).to(DEV), torch.randn(C, generator=g).to(DEV)
+    y32, y16, _ = AddDropoutLayerNorm.apply(x, z, None, gamma, beta, 0.0, 1e-5, (True, True, False), 1)
+    ref = F.layer_norm(x + z.float(), (C,), gamma, beta, 1e-5)
+    assert (y32 - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
+    assert torch.equal(y16, y32.to(torch.bfloat16))
+    # GroupNorm on token rows: one level, identity projection (Cin = C, W = I, b = 0) so that the kernel is isolated
+    n, h, w, G = 8, 75, 100, 32
+    f = torch.randn(n, C, h, w, generator=g).to(DEV).bfloat16().contiguous(memory_format=torch.channels_last)
+    eye = torch.eye(C, device=DEV).view(C, C, 1, 1)
+    gm, bt = (torch.rand(C, generator=g) + 0.5).to(DEV), torch.randn(C, generator=g).to(DEV)
+    s32, s16, _ = InputProjTokens.apply(4, G, 1e-5, None, (True, False), f, eye, torch.zeros(C, device=DEV), gm, bt)
+    refg = F.group_norm(f.float(), G, gm, bt, 1e-5).view(2, 4, C, h * w).permute(0, 1, 3, 2)
+    assert s32.shape == (2, 4, h * w, C)
+    assert (s32 - refg).abs().max().item() < 1e-4 * max(1.0, refg.abs().max().item())
+    assert torch.equal(s16, s32.to(torch.bfloat16))
