@@ -203,7 +203,10 @@ def cpu_baseline(a, budget_s=40.0):
 
 
 def time_msda_modules(a, device):
-    """MSDeformAttn module fwd+bwd ms at the bench geometry (encoder Lq=S, decoder Lq=60)."""
+    """MSDeformAttn module fwd+bwd ms at the bench geometry (encoder Lq=S, decoder Lq=60): the HIP path, and the
+    reference's own formulation of the module (``use_pytorch_deform=1``: per-pair grid_sample core op, PyTorch
+    everything) on the same GPU -- the denominator of BASELINE.json's ">= 3x the PyTorch-reference MSDeformAttn
+    throughput"."""
     from snipper_amd.ms_deform_attn import MSDeformAttn
     shapes = [(-(-a.height // s), -(-a.width // s)) for s in (8, 16, 32)]
     S = sum(h * w for h, w in shapes)
@@ -211,8 +214,9 @@ def time_msda_modules(a, device):
     sh._snipper_host = shapes
     lsi = torch.cat((sh.new_zeros(1), sh.prod(1).cumsum(0)[:-1]))
     res = {}
-    for mode, Lq, T1 in (("encoder", S, a.frames), ("decoder", 60, a.frames + a.future_frames)):
-        mod = MSDeformAttn(a.hidden_dim, 3, 8, 4, a.frames, mode, False, mode == "decoder").to(device)
+    for mode, Lq, T1, torch_path in (("encoder", S, a.frames, False), ("decoder", 60, a.frames + a.future_frames, False),
+                                     ("encoder", S, a.frames, True), ("decoder", 60, a.frames + a.future_frames, True)):
+        mod = MSDeformAttn(a.hidden_dim, 3, 8, 4, a.frames, mode, torch_path, mode == "decoder").to(device)
         q = torch.randn(a.batch, T1, Lq, a.hidden_dim, device=device, requires_grad=True)
         src = torch.randn(a.batch, a.frames, S, a.hidden_dim, device=device, requires_grad=True)
         if mode == "encoder":   # the encoder's reference points are the pixel centres of the maps
@@ -222,19 +226,34 @@ def time_msda_modules(a, device):
         else:
             ref = torch.rand(a.batch, T1, Lq, 3, 2, device=device)
 
+        amp = a.precision == "bf16"
+
         def run():
-            o = mod(q, ref, src, sh, lsi, None)
+            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):      # the step's precision
+                o = mod(q, ref, src, sh, lsi, None)
             o = o[0] if isinstance(o, tuple) else o
-            o.sum().backward()
-        for _ in range(2):
-            run()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        n = 5
-        for _ in range(n):
-            run()
-        torch.cuda.synchronize()
-        res[f"{mode}_module_fwd_bwd_ms"] = round((time.perf_counter() - t0) / n * 1e3, 3)
+            o.float().sum().backward()
+        try:
+            for _ in range(2):
+                run()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            n = 5
+            for _ in range(n):
+                run()
+            torch.cuda.synchronize()
+            key = f"{mode}_module_fwd_bwd_ms" if not torch_path else f"{mode}_module_pytorch_reference_fwd_bwd_ms"
+            res[key] = round((time.perf_counter() - t0) / n * 1e3, 3)
+        except RuntimeError as e:              # (the grid_sample formulation needs several GB at the encoder shape)
+            if not torch_path:
+                raise
+            res[f"{mode}_module_pytorch_reference_error"] = str(e)[:80]
+        del mod, q, src
+        torch.cuda.empty_cache()
+    for mode in ("encoder", "decoder"):
+        a_, b_ = res.get(f"{mode}_module_fwd_bwd_ms"), res.get(f"{mode}_module_pytorch_reference_fwd_bwd_ms")
+        if a_ and b_:
+            res[f"{mode}_speedup_vs_pytorch_reference"] = round(b_ / a_, 2)
     return res
 
 
