@@ -115,7 +115,8 @@ class FlatGradSync:
             return
         tensors = list(modules_or_tensors)
         for t in tensors:
-            dist.broadcast(t.data if isinstance(t, torch.nn.Parameter) else t, src, group=self.group)
+            # (detach() shares the parameter's version counter, .data does not: shadow.py keys its bf16 copies on it)
+            dist.broadcast(t.detach() if isinstance(t, torch.nn.Parameter) else t, src, group=self.group)
 
     @torch.no_grad()
     def sync(self) -> None:
