@@ -417,7 +417,7 @@ def main():
     if a.graph:
         try:
             static_imgs = torch.empty_like(batches[0][0])
-            static_tgt = {k: torch.empty_like(v) for k, v in batches[0][1].items()}
+            static_tgt = {k: torch.empty_like(v) for k, v in batches[0][1].items() if torch.is_tensor(v)}
 
             def load(i):
                 imgs, tgt = batches[i % len(batches)]
