@@ -177,6 +177,22 @@ int snipper_st_msda_backward(void *stream, const void *grad_out, int grad_out_bf
                              void *grad_value, int value_dtype, void *grad_off, long long grad_off_ld,
                              void *grad_logit, long long grad_logit_ld, int ql_dtype, float *grad_ref);
 
+/* ---- the keypoint / depth / continuity loss terms of SetCriterion (csrc/pair_losses.cuh) ---------------------------
+ * Reference models/model.py:289-427 (loss_root, loss_joint, loss_joint_disp, loss_joint_cont) for all matched
+ * (prediction, target) pairs of all decoder layers at once.  P = n_layers * pairs rows, layer-major:
+ *   sk [P,T,K,3] predicted (x, y, vis), sd [P,T,K,1] predicted depth, tk [P,T,K,3] target (x, y, vis),
+ *   td [P,T,K,2] target (depth, valid), cont_w [K], max_depth: DEVICE scalar, eps: the reference's 10e-6.
+ *   out [P,9] per-pair terms in the order root, root_depth, root_vis, joint_disp, joint_depth_disp, joint, joint_depth,
+ *   joint_vis, cont (the caller sums over the pairs of a layer and divides by the number of trajectories).
+ * Backward: grad_terms [P, 9] = dL/d(out) -> grad_sk, grad_sd.
+ * T * K <= 128, float32. */
+int snipper_pair_losses_forward(void *stream, const float *sk, const float *sd, const float *tk, const float *td,
+                                const float *cont_w, const float *max_depth, int n_layers, int pairs, int T, int K,
+                                float eps, float *out);
+int snipper_pair_losses_backward(void *stream, const float *sk, const float *sd, const float *tk, const float *td,
+                                 const float *cont_w, const float *max_depth, const float *grad_terms,
+                                 int n_layers, int pairs, int T, int K, float eps, float *grad_sk, float *grad_sd);
+
 /* ---- Hungarian matching on the device (csrc/lsap.cuh) ---------------------------------------------------
  * Replaces the host round trip of models/matcher.py:132 (`linear_sum_assignment(cost.cpu())`).
  * cost [P, n, m] float32 (P independent problems, n predictions, m targets, 1 <= m <= n <= 64), device memory.

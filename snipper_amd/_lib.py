@@ -63,6 +63,8 @@ EXPORTS = {
     "snipper_st_msda_backward_workspace_bytes": ([c_int] * 8 + [c_void_p], c_size_t),
     "snipper_st_msda_backward": ([c_void_p, c_void_p, c_int] + [c_void_p] * 10 + [c_int] * 9 + [c_void_p, c_size_t,
                                  c_void_p, c_int, c_void_p, c_longlong, c_void_p, c_longlong, c_int, c_void_p], c_int),
+    "snipper_pair_losses_forward": ([c_void_p] * 7 + [c_int] * 4 + [ctypes.c_float, c_void_p], c_int),
+    "snipper_pair_losses_backward": ([c_void_p] * 8 + [c_int] * 4 + [ctypes.c_float, c_void_p, c_void_p], c_int),
     "snipper_lsap_f32": ([c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p], c_int),
     "snipper_linear_bf16": ([c_void_p, c_void_p, ctypes.c_longlong, c_void_p, c_void_p, c_void_p, ctypes.c_longlong,
                              c_void_p, ctypes.c_longlong, c_int, c_int, c_int, c_int, ctypes.c_float,

@@ -169,6 +169,48 @@ def gaussian_blur(img: torch.Tensor, kernel_size: int) -> torch.Tensor:
     return F.conv2d(flat, k2).reshape(shape)
 
 
+_PAIR_TERMS = ("loss_root", "loss_root_depth", "loss_root_vis", "loss_joint_disp", "loss_joint_depth_disp",
+               "loss_joint", "loss_joint_depth", "loss_joint_vis", "loss_cont")
+
+
+class PairLosses(torch.autograd.Function):
+    """The nine keypoint / depth / continuity terms of every matched pair of every decoder layer in one launch each way
+    (csrc/pair_losses.cuh; the PyTorch formulation below it in ``_all_losses`` is the specification and the CPU path).
+    sk / sd / tk / td as in ``_all_losses``; -> [n_dec, Msum, 9] per-pair terms in ``_PAIR_TERMS`` order."""
+
+    @staticmethod
+    def forward(ctx, sk, sd, tk, td, cont_w, max_depth, eps):
+        from . import _lib
+        sk, sd, tk, td = (t.contiguous().float() for t in (sk, sd, tk, td))
+        n_dec, ms, T, K = sk.shape[:4]
+        out = torch.zeros((n_dec, ms, len(_PAIR_TERMS)), dtype=torch.float32, device=sk.device)
+        cw = cont_w.reshape(-1).contiguous().float()
+        md = max_depth.reshape(-1)[:1].to(device=sk.device, dtype=torch.float32).contiguous()
+        with torch.cuda.device(sk.device):
+            rc = _lib.load().snipper_pair_losses_forward(
+                torch.cuda.current_stream(sk.device).cuda_stream, sk.data_ptr(), sd.data_ptr(), tk.data_ptr(),
+                td.data_ptr(), cw.data_ptr(), md.data_ptr(), n_dec, ms, T, K, float(eps), out.data_ptr())
+        _lib.check(rc, "snipper_pair_losses_forward")
+        ctx.save_for_backward(sk, sd, tk, td, cw, md)
+        ctx.eps = float(eps)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import _lib
+        sk, sd, tk, td, cw, md = ctx.saved_tensors
+        n_dec, ms, T, K = sk.shape[:4]
+        gl = g.contiguous().float()                               # [n_dec, Msum, 9]
+        dsk, dsd = torch.zeros_like(sk), torch.zeros_like(sd)
+        with torch.cuda.device(sk.device):
+            rc = _lib.load().snipper_pair_losses_backward(
+                torch.cuda.current_stream(sk.device).cuda_stream, sk.data_ptr(), sd.data_ptr(), tk.data_ptr(),
+                td.data_ptr(), cw.data_ptr(), md.data_ptr(), gl.data_ptr(), n_dec, ms, T, K, ctx.eps,
+                dsk.data_ptr(), dsd.data_ptr())
+        _lib.check(rc, "snipper_pair_losses_backward")
+        return dsk, dsd, None, None, None, None, None
+
+
 class SetCriterion(nn.Module):
     def __init__(self, matcher, losses, eos_coef, weight_dict, cont_weights=None):
         super().__init__()
@@ -180,6 +222,7 @@ class SetCriterion(nn.Module):
         if cont_weights is None:
             cont_weights = torch.tensor(ROOTJOINTCONT).float()[None, None, :, None]
         self.register_buffer("cont_weights", cont_weights)          # [1, 1, K, 1]
+        self.fused_pair_losses = True                                # HIP kernel for the pair terms on CUDA (else PyTorch)
 
     # ---- the losses, over [n_dec, Msum, ...] gathered pairs ------------------------------------------
     def _all_losses(self, logits, sk, sd, tk, td, src, batch, max_depth, num_traj) -> Dict[str, torch.Tensor]:
@@ -196,6 +239,14 @@ class SetCriterion(nn.Module):
             classes[lidx, batch[None].expand_as(src), src] = tgt_vis
             ce = F.cross_entropy(logits.reshape(-1, 2).float(), classes.reshape(-1), self.empty_weight, reduction="none")
             out["loss_is_human"] = ce.view(n_dec, -1).mean(-1)
+
+        if (self.fused_pair_losses and sk.is_cuda and sk.dtype == torch.float32 and sk.shape[2] * sk.shape[3] <= 128 and
+                all(k in self.losses for k in ("root", "joint", "joint_disp", "joint_cont")) and torch.is_tensor(max_depth)):
+            # all nine terms in one kernel; the sum over pairs and the division by the trajectory count stay here
+            terms = PairLosses.apply(sk, sd, tk, td, self.cont_weights, max_depth, eps).sum(1) / num_traj   # [n_dec, 9]
+            for i, name in enumerate(_PAIR_TERMS):
+                out[name] = terms[:, i]
+            return out
 
         t_root_vis = tk[..., :1, 2:3]
         if "root" in self.losses:                                                   # model.py:289-324

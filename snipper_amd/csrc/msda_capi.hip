@@ -17,6 +17,7 @@
 #include "wgrad_bf16.cuh"
 #include "ln_fused.cuh"
 #include "gn_tokens.cuh"
+#include "pair_losses.cuh"
 #include "msda_prologue.cuh"
 #include "lsap.cuh"
 #include "msda_d48.cuh"
@@ -835,6 +836,33 @@ int snipper_st_msda_backward(void *stream, const void *grad_out, int grad_out_bf
   float mix_t[kMixMaxFrames * kMixMaxFrames];
   st_transpose_mix(mix, T1, T2, mix_t);
   return snipper_temporal_mix(stream, g_vbar, 0, mask, 0, mix_t, N, T1, T2, S, M * D, grad_value, value_dtype);
+}
+
+int snipper_pair_losses_forward(void *stream, const float *sk, const float *sd, const float *tk, const float *td,
+                                const float *cont_w, const float *max_depth, int n_layers, int pairs, int T, int K,
+                                float eps, float *out) {
+  if (!sk || !sd || !tk || !td || !cont_w || !max_depth || !out) return SNIPPER_E_NULL;
+  if (n_layers <= 0 || pairs < 0 || T <= 0 || K <= 0 || T * K > kPairMaxTK) return SNIPPER_E_SHAPE;
+  if (pairs == 0) return SNIPPER_OK;
+  PairLossArgs a{};
+  a.sk = sk; a.sd = sd; a.tk = tk; a.td = td; a.cont_w = cont_w; a.max_depth = max_depth; a.out = out;
+  a.P = n_layers * pairs; a.T = T; a.K = K; a.pairs_per_layer = pairs; a.eps = eps;
+  hipLaunchKernelGGL(pair_losses_fwd_kernel, dim3((a.P + 3) / 4), dim3(256), 0, (hipStream_t)stream, a);
+  return launch_status();
+}
+
+int snipper_pair_losses_backward(void *stream, const float *sk, const float *sd, const float *tk, const float *td,
+                                 const float *cont_w, const float *max_depth, const float *grad_terms,
+                                 int n_layers, int pairs, int T, int K, float eps, float *grad_sk, float *grad_sd) {
+  if (!sk || !sd || !tk || !td || !cont_w || !max_depth || !grad_terms || !grad_sk || !grad_sd) return SNIPPER_E_NULL;
+  if (n_layers <= 0 || pairs < 0 || T <= 0 || K <= 0 || T * K > kPairMaxTK) return SNIPPER_E_SHAPE;
+  if (pairs == 0) return SNIPPER_OK;
+  PairLossArgs a{};
+  a.sk = sk; a.sd = sd; a.tk = tk; a.td = td; a.cont_w = cont_w; a.max_depth = max_depth; a.gw = grad_terms;
+  a.dsk = grad_sk; a.dsd = grad_sd;
+  a.P = n_layers * pairs; a.T = T; a.K = K; a.pairs_per_layer = pairs; a.eps = eps;
+  hipLaunchKernelGGL(pair_losses_bwd_kernel, dim3((a.P + 3) / 4), dim3(256), 0, (hipStream_t)stream, a);
+  return launch_status();
 }
 
 int snipper_lsap_f32(void *stream, const float *cost, int P, int n, int m, long long *out_src, long long *out_tgt) {
