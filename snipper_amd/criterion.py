@@ -335,10 +335,20 @@ class SetCriterion(nn.Module):
             world = torch.distributed.get_world_size()
         num_traj = torch.clamp(num_traj / world, min=1)
 
-        lidx = torch.arange(n_dec, device=logits.device)[:, None].expand_as(src)
-        bidx = batch[None].expand_as(src)
-        sk = kpts2d[lidx, bidx, src].float()                     # [n_dec, Msum, T, K, 3]
-        sd = depth[lidx, bidx, src].float()
+        # matched predictions, gathered with ONE flat index: the backward of index_select is a single index_add
+        # kernel, that of three-tensor advanced indexing the sort-based accumulate path (~40 launches per gather)
+        bs, nq = logits.shape[1], logits.shape[2]
+        lidx = torch.arange(n_dec, device=logits.device)[:, None]
+        lin = ((lidx * bs + batch[None]) * nq + src).reshape(-1)                    # [n_dec * Msum]
+        al = outputs.get("all_layers")
+        if al is not None:                                       # (x, y, vis, depth) live in one tensor: one gather
+            kd = al["pred_kpts"].reshape(n_dec * bs * nq, *al["pred_kpts"].shape[3:]).index_select(0, lin).float()
+            kd = kd.view(n_dec, -1, *kd.shape[1:])
+            sk, sd = kd[..., 0:3], kd[..., 3:4]                  # [n_dec, Msum, T, K, 3] / [.., 1]
+        else:
+            pick = lambda t: t.reshape(n_dec * bs * nq, *t.shape[3:]).index_select(0, lin).float().view(
+                n_dec, -1, *t.shape[3:])
+            sk, sd = pick(kpts2d), pick(depth)
         tk = torch.cat([t["kpts2d"][tgt[:, a:b]] for t, a, b in zip(targets, offsets[:-1], offsets[1:])], 1)
         td = torch.cat([t["depth"][tgt[:, a:b]] for t, a, b in zip(targets, offsets[:-1], offsets[1:])], 1)
         per_layer = self._all_losses(logits, sk, sd, tk, td, src, batch, targets[0]["max_depth"], num_traj)
