@@ -151,17 +151,23 @@ class HungarianMatcher(nn.Module):
         return [(src[0, a:b], tgt[0, a:b]) for a, b in zip(offsets[:-1], offsets[1:])]
 
 
+_blur_kernels: Dict = {}
+
+
 def gaussian_blur(img: torch.Tensor, kernel_size: int) -> torch.Tensor:
     """torchvision.transforms.functional.gaussian_blur(img, [k, k]) restated (sigma = 0.3*((k-1)*0.5-1)+0.8,
     reflect padding, separable kernel).  torchvision is not vendored by the reference: parity unpinned."""
     if kernel_size <= 1:
         return img
-    sigma = 0.3 * ((kernel_size - 1) * 0.5 - 1) + 0.8
-    half = (kernel_size - 1) * 0.5
-    x = torch.linspace(-half, half, kernel_size, device=img.device, dtype=img.dtype)
-    k1 = torch.exp(-0.5 * (x / sigma) ** 2)
-    k1 = k1 / k1.sum()
-    k2 = (k1[:, None] * k1[None, :])[None, None]
+    key = (kernel_size, str(img.device), img.dtype)
+    k2 = _blur_kernels.get(key)
+    if k2 is None:                                  # a constant of (size, device, dtype): built once
+        sigma = 0.3 * ((kernel_size - 1) * 0.5 - 1) + 0.8
+        half = (kernel_size - 1) * 0.5
+        x = torch.linspace(-half, half, kernel_size, device=img.device, dtype=img.dtype)
+        k1 = torch.exp(-0.5 * (x / sigma) ** 2)
+        k1 = k1 / k1.sum()
+        k2 = _blur_kernels[key] = (k1[:, None] * k1[None, :])[None, None]
     shape = img.shape
     flat = img.reshape(-1, 1, shape[-2], shape[-1])
     pad = kernel_size // 2
@@ -292,19 +298,27 @@ class SetCriterion(nn.Module):
         bs = len(targets)
         counts = [int(tgt["kpts2d"].shape[0]) for tgt in targets]
         sample = torch.cat([torch.full((n,), i, dtype=torch.long, device=device) for i, n in enumerate(counts)])
-        for (t, h, w) in spatial:
+        t_all = max(t for t, _, _ in spatial)
+        k_all = torch.cat([tgt["kpts2d"][:, :t_all] for tgt in targets], 0)         # [Nsum, t, K, 3]
+        K = k_all.shape[2]
+        # pixel coordinates and validity for ALL levels in one set of launches: [levels, Nsum, t, K]
+        whs = torch.tensor([[w, h] for _, h, w in spatial], dtype=k_all.dtype).to(device, non_blocking=True) \
+            if getattr(self, "_wh_key", None) != tuple(spatial) else self._wh
+        self._wh_key, self._wh = tuple(spatial), whs
+        xy = (k_all[None, ..., 0:2] * whs[:, None, None, None, :]).long()
+        lim = whs.long()[:, None, None, None, :]
+        ok_all = (k_all[None, ..., 2] > 0) & ((xy >= 0) & (xy < lim)).all(-1)
+        xy = torch.minimum(xy.clamp(min=0), lim - 1)
+        ti = torch.arange(t_all, device=device)[None, :, None]
+        ki = torch.arange(K, device=device)[None, None, :]
+        for lvl, (t, h, w) in enumerate(spatial):
             ksize = max(h // 10 + h // 10 % 2 - 1, w // 10 + w // 10 % 2 - 1)
-            k = torch.cat([tgt["kpts2d"][:, :t] for tgt in targets], 0)             # [Nsum, t, K, 3]
-            K = k.shape[2]
-            x, y = (k[..., 0] * w).long(), (k[..., 1] * h).long()
-            ok = (k[..., 2] > 0) & (x >= 0) & (x < w) & (y >= 0) & (y < h)
-            ti = torch.arange(t, device=device)[None, :, None]
-            ki = torch.arange(K, device=device)[None, None, :]
+            x, y, ok = xy[lvl, :, :t, :, 0], xy[lvl, :, :t, :, 1], ok_all[lvl, :, :t]
             # One scatter-add over the flattened [bs, K, t, h, w] map for all samples.  No boolean-mask indexing (it
             # would read the count back to the host) and no multi-index index_put_ (its accumulate path range-checks
             # every index tensor with separate reductions and sorts: ~50 launches per call): invalid joints add 0 at
             # a clamped position, valid ones add 1, several on one pixel still give 1.
-            lin = (((sample[:, None, None] * K + ki) * t + ti) * h + y.clamp(0, h - 1)) * w + x.clamp(0, w - 1)
+            lin = (((sample[:, None, None] * K + ki) * t + ti[:, :t]) * h + y) * w + x
             hm = torch.zeros(bs * K * t * h * w, device=device)
             hm.index_add_(0, lin.reshape(-1), ok.reshape(-1).to(hm.dtype))
             hm = hm.clamp_(max=1).view(bs, K, t, h, w)
