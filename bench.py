@@ -474,15 +474,18 @@ def main():
                                                                    max_name_column_width=40, max_shapes_column_width=70),
               file=sys.stderr)
     if os.environ.get("SNIPPER_ISSUE_TIME"):      # is the host or the GPU the limiter?  (development aid)
-        # host time to ISSUE three steps (no synchronisation) against the time until the GPU has retired them
+        # host time to ISSUE a few steps (no synchronisation) against the time until the GPU has retired them
+        n_issue = int(os.environ.get("SNIPPER_ISSUE_TIME", "3")) if os.environ.get("SNIPPER_ISSUE_TIME", "1").isdigit() else 3
+        n_issue = max(n_issue, 3)
         torch.cuda.synchronize()
         h0 = time.perf_counter()
-        for i in range(3):
+        for i in range(n_issue):
             step(i)
         h1 = time.perf_counter()
         torch.cuda.synchronize()
         h2 = time.perf_counter()
-        print(f"[bench] issue {1e3 * (h1 - h0) / 3:.2f} ms/step, retire {1e3 * (h2 - h0) / 3:.2f} ms/step", file=sys.stderr)
+        print(f"[bench] issue {1e3 * (h1 - h0) / n_issue:.2f} ms/step, retire {1e3 * (h2 - h0) / n_issue:.2f} ms/step "
+              f"({n_issue} steps)", file=sys.stderr)
     t0 = time.perf_counter()
     for i in range(a.steps):
         loss = step(a.warmup + i)

@@ -63,7 +63,7 @@ def _coord_dtype(value):
 
 
 def _stream(device) -> int:
-    return torch.cuda.current_stream(device).cuda_stream
+    return _lib.raw_stream(device)
 
 
 # ---- optional launch timing (bench.py) --------------------------------------------------------
@@ -123,7 +123,7 @@ def ms_deform_attn_forward(value: torch.Tensor, spatial_shapes: torch.Tensor,
                 row_esize=2 if (out_bf16 and value.dtype == torch.float32) else value.element_size())
     if out_bf16 and value.dtype == torch.float32:
         out = torch.empty((N, Lq, M * D), dtype=torch.bfloat16, device=value.device)
-        with torch.cuda.device(value.device), _Timed("fwd", dims, value.device):
+        with _lib.device_guard(value.device), _Timed("fwd", dims, value.device):
             rc = lib.snipper_msda_forward_f32_bf16out(
                 _stream(value.device), value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
                 sampling_loc.data_ptr(), attn_weight.data_ptr(), N, S, M, D, L, Lq, P, out.data_ptr())
@@ -132,7 +132,7 @@ def ms_deform_attn_forward(value: torch.Tensor, spatial_shapes: torch.Tensor,
             return out
     out = torch.empty((N, Lq, M * D), dtype=value.dtype, device=value.device)
     fn = getattr(lib, "snipper_msda_forward_" + _SUFFIX[value.dtype])
-    with torch.cuda.device(value.device), _Timed("fwd", dims, value.device):
+    with _lib.device_guard(value.device), _Timed("fwd", dims, value.device):
         rc = fn(_stream(value.device), value.data_ptr(), spatial_shapes.data_ptr(),
                 level_start_index.data_ptr(), sampling_loc.data_ptr(), attn_weight.data_ptr(),
                 N, S, M, D, L, Lq, P, out.data_ptr())
@@ -170,7 +170,7 @@ def ms_deform_attn_backward(value: torch.Tensor, spatial_shapes: torch.Tensor,
     lib = _lib.load()
     dims = dict(N=N, S=S, M=M, D=D, L=L, Lq=Lq, P=P, esize=value.element_size(),
                 row_esize=grad_output.element_size())
-    with torch.cuda.device(value.device), _Timed("bwd", dims, value.device):
+    with _lib.device_guard(value.device), _Timed("bwd", dims, value.device):
         ws_bytes, hs_p, rc = 0, None, None
         if host_shapes is not None and value.dtype == torch.float32 and len(host_shapes) == L:
             hs = (ctypes.c_int64 * (2 * L))(*[int(v) for hw in host_shapes for v in hw])

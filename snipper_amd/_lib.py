@@ -119,6 +119,34 @@ def load():
 E_UNSUPPORTED = -3      # include/snipper_msda.h
 
 
+class _NoGuard:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_GUARD = _NoGuard()
+
+
+def device_guard(device):
+    """``torch.cuda.device(device)`` when that would change the current device, a no-op context otherwise (the usual
+    case: the guard object, its index parsing and two device exchanges cost ~6 us per kernel wrapper call)."""
+    import torch
+    idx = device.index
+    if idx is None or idx == torch.cuda.current_device():
+        return _NO_GUARD
+    return torch.cuda.device(device)
+
+
+def raw_stream(device) -> int:
+    """The current stream of ``device`` as a raw handle, without building a ``torch.cuda.Stream`` object."""
+    import torch
+    idx = device.index
+    return torch._C._cuda_getCurrentRawStream(torch.cuda.current_device() if idx is None else idx)
+
+
 def check(code: int, what: str) -> None:
     if code != 0:
         msg = load().snipper_msda_strerror(code).decode()

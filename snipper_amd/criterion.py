@@ -133,8 +133,8 @@ class HungarianMatcher(nn.Module):
             t = torch.empty((n_dec, m), dtype=torch.long, device=dev)
             if m:
                 c = c.contiguous()
-                with torch.cuda.device(dev):
-                    rc = lib.snipper_lsap_f32(torch.cuda.current_stream(dev).cuda_stream, c.data_ptr(), n_dec, nq, m,
+                with _lib.device_guard(dev):
+                    rc = lib.snipper_lsap_f32(_lib.raw_stream(dev), c.data_ptr(), n_dec, nq, m,
                                               s.data_ptr(), t.data_ptr())
                 _lib.check(rc, "snipper_lsap_f32")
             srcs.append(s)
@@ -192,9 +192,9 @@ class PairLosses(torch.autograd.Function):
         out = torch.zeros((n_dec, ms, len(_PAIR_TERMS)), dtype=torch.float32, device=sk.device)
         cw = cont_w.reshape(-1).contiguous().float()
         md = max_depth.reshape(-1)[:1].to(device=sk.device, dtype=torch.float32).contiguous()
-        with torch.cuda.device(sk.device):
+        with _lib.device_guard(sk.device):
             rc = _lib.load().snipper_pair_losses_forward(
-                torch.cuda.current_stream(sk.device).cuda_stream, sk.data_ptr(), sd.data_ptr(), tk.data_ptr(),
+                _lib.raw_stream(sk.device), sk.data_ptr(), sd.data_ptr(), tk.data_ptr(),
                 td.data_ptr(), cw.data_ptr(), md.data_ptr(), n_dec, ms, T, K, float(eps), out.data_ptr())
         _lib.check(rc, "snipper_pair_losses_forward")
         ctx.save_for_backward(sk, sd, tk, td, cw, md)
@@ -208,9 +208,9 @@ class PairLosses(torch.autograd.Function):
         n_dec, ms, T, K = sk.shape[:4]
         gl = g.contiguous().float()                               # [n_dec, Msum, 9]
         dsk, dsd = torch.zeros_like(sk), torch.zeros_like(sd)
-        with torch.cuda.device(sk.device):
+        with _lib.device_guard(sk.device):
             rc = _lib.load().snipper_pair_losses_backward(
-                torch.cuda.current_stream(sk.device).cuda_stream, sk.data_ptr(), sd.data_ptr(), tk.data_ptr(),
+                _lib.raw_stream(sk.device), sk.data_ptr(), sd.data_ptr(), tk.data_ptr(),
                 td.data_ptr(), cw.data_ptr(), md.data_ptr(), gl.data_ptr(), n_dec, ms, T, K, ctx.eps,
                 dsk.data_ptr(), dsd.data_ptr())
         _lib.check(rc, "snipper_pair_losses_backward")

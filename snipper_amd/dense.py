@@ -33,9 +33,9 @@ def linear_bf16(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tens
     if bias is not None and bias.dtype != torch.float32:
         bias = bias.float()
     lib = _lib.load()
-    with torch.cuda.device(x.device):
+    with _lib.device_guard(x.device):
         rc = lib.snipper_linear_bf16(
-            torch.cuda.current_stream(x.device).cuda_stream, x2.data_ptr(), x2.stride(0), weight.data_ptr(),
+            _lib.raw_stream(x.device), x2.data_ptr(), x2.stride(0), weight.data_ptr(),
             bias.data_ptr() if bias is not None else None, r2.data_ptr() if r2 is not None else None,
             r2.stride(0) if r2 is not None else 0, out.data_ptr(), out.stride(0), M, N, K, int(relu),
             float(dropout_p), int(seed))
@@ -59,9 +59,9 @@ def conv3x3_bf16(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Ten
     out = torch.empty((B, Cout, Ho, Wo), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
     if bias is not None and bias.dtype != torch.float32:
         bias = bias.float()
-    with torch.cuda.device(x.device):
+    with _lib.device_guard(x.device):
         rc = _lib.load().snipper_conv3x3_bf16(
-            torch.cuda.current_stream(x.device).cuda_stream, x.data_ptr(), weight.data_ptr(),
+            _lib.raw_stream(x.device), x.data_ptr(), weight.data_ptr(),
             bias.data_ptr() if bias is not None else None, out.data_ptr(), B, H, W, Cin, Cout, int(stride), int(relu))
     _lib.check(rc, "snipper_conv3x3_bf16")
     return out
@@ -92,9 +92,9 @@ def linear_nn_bf16(x: torch.Tensor, w: torch.Tensor, residual: Optional[torch.Te
         a2 = gate.reshape(M, N)
         if a2.dtype != torch.bfloat16 or a2.stride(1) != 1 or a2.stride(0) % 4:
             a2 = a2.to(torch.bfloat16).contiguous()
-    with torch.cuda.device(x.device):
+    with _lib.device_guard(x.device):
         rc = _lib.load().snipper_linear_nn_bf16(
-            torch.cuda.current_stream(x.device).cuda_stream, x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0),
+            _lib.raw_stream(x.device), x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0),
             r2.data_ptr() if r2 is not None else None, r2.stride(0) if r2 is not None else 0,
             a2.data_ptr() if a2 is not None else None, a2.stride(0) if a2 is not None else 0, float(gate_scale),
             out.data_ptr(), out.stride(0), M, N, K)
@@ -144,9 +144,9 @@ def wgrad_bf16(g: torch.Tensor, x: torch.Tensor, want_bias: bool = True, scale: 
     ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=g.device)
     if scale is not None and scale.dtype != torch.float32:
         scale = scale.float()
-    with torch.cuda.device(g.device):
+    with _lib.device_guard(g.device):
         rc = lib.snipper_wgrad_bf16(
-            torch.cuda.current_stream(g.device).cuda_stream, g.data_ptr(), g.stride(0), x.data_ptr(), x.stride(0),
+            _lib.raw_stream(g.device), g.data_ptr(), g.stride(0), x.data_ptr(), x.stride(0),
             M, N, Kc, scale.data_ptr() if scale is not None else None, dW.data_ptr(), dW.stride(0),
             db.data_ptr() if db is not None else None, int(accumulate), ws.data_ptr(), nbytes)
     _lib.check(rc, "snipper_wgrad_bf16")
@@ -274,9 +274,9 @@ def _relu_dropout_backward(g: torch.Tensor, y: torch.Tensor, p: float) -> torch.
         out = torch.ops.aten.threshold_backward(g, y, 0)
         return out if p == 0.0 else out * (1.0 / (1.0 - p))
     out = torch.empty_like(g)
-    with torch.cuda.device(g.device):
+    with _lib.device_guard(g.device):
         rc = _lib.load().snipper_relu_dropout_backward_bf16(
-            torch.cuda.current_stream(g.device).cuda_stream, g.data_ptr(), y.data_ptr(), out.data_ptr(), g.numel(), p)
+            _lib.raw_stream(g.device), g.data_ptr(), y.data_ptr(), out.data_ptr(), g.numel(), p)
     _lib.check(rc, "snipper_relu_dropout_backward_bf16")
     return out
 

@@ -15,7 +15,7 @@ _DT = {torch.float32: 0, torch.bfloat16: 1}
 
 
 def _stream(dev):
-    return torch.cuda.current_stream(dev).cuda_stream
+    return _lib.raw_stream(dev)
 
 
 def _farray(vals: Sequence[float]):
@@ -31,7 +31,7 @@ def _mix_launch(x, mask, mask_on_input, mix_rows: List[List[float]], out_dtype):
     To = len(mix_rows)
     out = torch.empty((N, To, S, C), dtype=out_dtype, device=x.device)
     flat = _farray([w for row in mix_rows for w in row])
-    with torch.cuda.device(x.device):
+    with _lib.device_guard(x.device):
         rc = _lib.load().snipper_temporal_mix(
             _stream(x.device), x.data_ptr(), _DT[x.dtype], mask.data_ptr() if mask is not None else None,
             int(mask_on_input), ctypes.cast(flat, ctypes.c_void_p), N, Ti, To, S, C, out.data_ptr(), _DT[out_dtype])
@@ -97,7 +97,7 @@ class MSDAPrologue(Function):
         loc = torch.empty((rows, L, P, 2), dtype=torch.float32, device=off.device)
         prob = torch.empty((rows, L, P), dtype=torch.float32, device=off.device)
         inv_w, inv_h = _farray([1.0 / w for h, w in hw]), _farray([1.0 / h for h, w in hw])
-        with torch.cuda.device(off.device):
+        with _lib.device_guard(off.device):
             rc = _lib.load().snipper_msda_prologue_forward(
                 _stream(off.device), off2.data_ptr(), off_ld, logit2.data_ptr(), logit_ld, _DT[off.dtype],
                 ref.data_ptr(), ctypes.cast(inv_w, ctypes.c_void_p), ctypes.cast(inv_h, ctypes.c_void_p), rows, M, L, P,
@@ -125,7 +125,7 @@ class MSDAPrologue(Function):
             ld_o, ld_l = w_off, w_logit
         g_ref = torch.empty(ref_shape, dtype=torch.float32, device=prob.device) if need_ref else None
         inv_w, inv_h = _farray([1.0 / w for h, w in hw]), _farray([1.0 / h for h, w in hw])
-        with torch.cuda.device(prob.device):
+        with _lib.device_guard(prob.device):
             rc = _lib.load().snipper_msda_prologue_backward(
                 _stream(prob.device), grad_loc.data_ptr(), grad_prob.data_ptr(), prob.data_ptr(),
                 ctypes.cast(inv_w, ctypes.c_void_p), ctypes.cast(inv_h, ctypes.c_void_p), rows, M, L, P,
@@ -172,7 +172,7 @@ class AddDropoutLayerNorm(Function):
         yq = torch.empty(x.shape, dtype=torch.bfloat16, device=dev) if want[2] else None
         g32, b32 = gamma.float(), beta.float()
         ptr = lambda t: t.data_ptr() if t is not None else None
-        with torch.cuda.device(dev):
+        with _lib.device_guard(dev):
             rc = _lib.load().snipper_add_dropout_layernorm_forward(
                 _stream(dev), x.data_ptr(), _DT[x.dtype], ptr(z), _DT[z.dtype] if z is not None else 0,
                 ptr(pos), _DT[pos.dtype] if pos is not None else 0, g32.data_ptr(), b32.data_ptr(), rows, C,
@@ -203,7 +203,7 @@ class AddDropoutLayerNorm(Function):
         nbytes = lib.snipper_add_dropout_layernorm_workspace_bytes(rows, C)
         ws = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
         ptr = lambda t: t.data_ptr() if t is not None else None
-        with torch.cuda.device(dev):
+        with _lib.device_guard(dev):
             rc = lib.snipper_add_dropout_layernorm_backward(
                 _stream(dev), ptr(g32), ptr(g16), ptr(gq), s_save.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(),
                 gamma.data_ptr(), ptr(keep), rows, C, p, ptr(dx), _DT[x_dt] if dx is not None else 0,
@@ -271,7 +271,7 @@ class InputProjTokens(Function):
             nbytes = lib.snipper_groupnorm_tokens_workspace_bytes(n, h * wd, C, groups)
             ws = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
             g32, b32 = gamma.float(), beta.float()
-            with torch.cuda.device(dev):
+            with _lib.device_guard(dev):
                 rc = lib.snipper_groupnorm_tokens_forward(
                     _stream(dev), y.data_ptr(), g32.data_ptr(), b32.data_ptr(), n, h * wd, C, groups, float(eps),
                     S, off, ptr(pos) if q16 is not None else None, _DT[pos.dtype] if pos is not None else 0,
@@ -304,7 +304,7 @@ class InputProjTokens(Function):
             dgb = torch.empty((2, C), dtype=torch.float32, device=dev)
             nbytes = lib.snipper_groupnorm_tokens_workspace_bytes(n, h * wd, C, groups)
             ws = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
-            with torch.cuda.device(dev):
+            with _lib.device_guard(dev):
                 rc = lib.snipper_groupnorm_tokens_backward(
                     _stream(dev), y.data_ptr(), gamma.data_ptr(), stats.data_ptr(), ptr(g32), ptr(g16), ptr(gq),
                     n, h * wd, C, groups, S, off, dy.data_ptr(), dgb[0].data_ptr(), dgb[1].data_ptr(),
@@ -358,7 +358,7 @@ class LevelPosTokens(Function):
         for l, hw in enumerate(ctx.sizes):
             nbytes = lib.snipper_colsum_workspace_bytes(b * t, hw, C)
             ws = torch.empty(nbytes // 4, dtype=torch.float32, device=g.device)
-            with torch.cuda.device(g.device):
+            with _lib.device_guard(g.device):
                 rc = lib.snipper_colsum_segments_bf16(_stream(g.device), g.data_ptr() + off * C * 2, S * C, b * t, hw, C,
                                                       d[l].data_ptr(), ws.data_ptr(), nbytes)
             _lib.check(rc, "snipper_colsum_segments_bf16")
