@@ -315,6 +315,8 @@ def main():
         k, v = kv.split("=")
         _lib.set_param(k.strip(), float(v))
 
+    if os.environ.get("SNIPPER_BLAS"):                            # "cublas" = rocBLAS, "cublaslt" = hipBLASLt (aid)
+        torch.backends.cuda.preferred_blas_library(os.environ["SNIPPER_BLAS"])
     torch.manual_seed(42 + rank)                                  # main.py:48,175
     margs = model_args(a)
     model = build_model(margs).to(device)
@@ -365,21 +367,45 @@ def main():
         from snipper_amd.criterion import build_criterion
         criterion = build_criterion(criterion_args(a)).to(device)
 
+    clip_params = [p for p in model.parameters() if p.requires_grad]   # walked once, not once per step
+
+    host_ms = {}                          # SNIPPER_HOST_REGIONS: host time per region of the step (development aid)
+    region_on = [False]
+
+    def mark(name, t0):
+        if region_on[0]:
+            host_ms[name] = host_ms.get(name, 0.0) + 1e3 * (time.perf_counter() - t0)
+        return time.perf_counter()
+
+    if os.environ.get("SNIPPER_HOST_REGIONS"):
+        def timed(mod, name):
+            mod.register_forward_pre_hook(lambda m, a: setattr(m, "_t0", time.perf_counter()))
+            mod.register_forward_hook(lambda m, a, o: (mark(name, m._t0), None)[1])
+        timed(model.backbone, "fwd.backbone")
+        timed(model.transformer.encoder, "fwd.encoder")
+        timed(model.transformer.decoder, "fwd.decoder")
+
     def train_step(imgs, tgt):
+        t = time.perf_counter()
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
             out, _ = net(list(imgs))
+        t = mark("fwd.model(total)", t)
         if criterion is not None:        # Hungarian matching + the six loss families (models/model.py:240-545)
             losses, _ = criterion(out, tgt["targets"])
             loss = criterion.weighted_sum(losses)
         else:
             loss = surrogate_loss(out, tgt)
+        t = mark("criterion", t)
         if masters is None:
             opt.zero_grad(set_to_none=True)
             loss.backward()
+            t = mark("backward", t)
             if gsync is not None:
                 gsync.sync()
-            torch.nn.utils.clip_grad_norm_(model.parameters(), 0.1)
+            torch.nn.utils.clip_grad_norm_(clip_params, 0.1)
+            t = mark("clip", t)
             opt.step()
+            t = mark("optimizer", t)
         else:
             mp, pp = masters
             for p in pp:
@@ -463,7 +489,7 @@ def main():
             step(i)
         torch.cuda.synchronize()
         pr.disable()
-        pstats.Stats(pr, stream=sys.stderr).sort_stats("tottime").print_stats(45)
+        pstats.Stats(pr, stream=sys.stderr).sort_stats(os.environ.get("SNIPPER_CPROFILE_SORT", "tottime")).print_stats(int(os.environ.get("SNIPPER_CPROFILE_N", "45")))
     if os.environ.get("SNIPPER_TORCH_PROFILE"):   # op-level GPU time with input shapes (development aid)
         from torch.profiler import profile, ProfilerActivity
         with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
@@ -472,6 +498,14 @@ def main():
             torch.cuda.synchronize()
         print(prof.key_averages(group_by_input_shape=True).table(sort_by="cuda_time_total", row_limit=400,
                                                                    max_name_column_width=40, max_shapes_column_width=70),
+              file=sys.stderr)
+    if os.environ.get("SNIPPER_TORCH_PROFILE_CPU"):   # host time per operator, both threads (development aid)
+        from torch.profiler import profile, ProfilerActivity
+        with profile(activities=[ProfilerActivity.CPU]) as prof:
+            for i in range(3):
+                step(i)
+            torch.cuda.synchronize()
+        print(prof.key_averages().table(sort_by="self_cpu_time_total", row_limit=70, max_name_column_width=60),
               file=sys.stderr)
     if os.environ.get("SNIPPER_ISSUE_TIME"):      # is the host or the GPU the limiter?  (development aid)
         # host time to ISSUE a few steps (no synchronisation) against the time until the GPU has retired them
@@ -486,6 +520,15 @@ def main():
         h2 = time.perf_counter()
         print(f"[bench] issue {1e3 * (h1 - h0) / n_issue:.2f} ms/step, retire {1e3 * (h2 - h0) / n_issue:.2f} ms/step "
               f"({n_issue} steps)", file=sys.stderr)
+    if os.environ.get("SNIPPER_HOST_REGIONS"):
+        torch.cuda.synchronize()
+        region_on[0] = True
+        for i in range(10):
+            step(i)
+        region_on[0] = False
+        torch.cuda.synchronize()
+        print("[bench] host ms per step by region: " +
+              ", ".join(f"{k} {v / 10:.2f}" for k, v in host_ms.items()), file=sys.stderr)
     t0 = time.perf_counter()
     for i in range(a.steps):
         loss = step(a.warmup + i)

@@ -264,6 +264,7 @@ class ResNet50Body(nn.Module):
             layers += [Bottleneck(inplanes, width) for _ in range(blocks - 1)]
             setattr(self, f"layer{i + 1}", nn.Sequential(*layers))
         self.return_interm_layers = return_interm_layers
+        self._stem_frozen = None      # decided at the first forward; reset it after changing layer1's requires_grad
         for m in self.modules():
             if isinstance(m, nn.Conv2d):
                 nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
@@ -272,7 +273,9 @@ class ResNet50Body(nn.Module):
         x = x.contiguous(memory_format=torch.channels_last)     # NHWC end to end: no layout shuffles around MIOpen
         x = conv_frozen_bn(x, self.conv1, self.bn1, relu=True)
         x = F.max_pool2d(x, 3, stride=2, padding=1)
-        if not any(p.requires_grad for p in self.layer1.parameters()):
+        if self._stem_frozen is None:                             # walked once (Backbone.__init__ freezes before use)
+            self._stem_frozen = not any(p.requires_grad for p in self.layer1.parameters())
+        if self._stem_frozen:
             with torch.no_grad():                                 # conv1 + layer1 are frozen: nothing to save
                 c2 = self.layer1(x)
         else:

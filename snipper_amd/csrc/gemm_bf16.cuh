@@ -106,7 +106,7 @@ __device__ __forceinline__ unsigned gemm_pack2(float a, float b) {
 }
 
 template <bool RELU>
-__global__ __launch_bounds__(kGemmThreads) void linear_bf16_kernel(GemmArgs g) {
+__global__ __launch_bounds__(kGemmThreads) __attribute__((amdgpu_waves_per_eu(3, 3))) void linear_bf16_kernel(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) uint16_t smem[(kGemmBM + kGemmBN) * kGemmPad];
   uint16_t *Xs = smem, *Ws = smem + kGemmBM * kGemmPad;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -237,7 +237,7 @@ __device__ __forceinline__ gemm_bf16x8 gemm_tr_frag(const uint16_t *tile, int by
   return gemm_bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 
-__global__ __launch_bounds__(kGemmThreads) void linear_bf16_nn_kernel(GemmNNArgs g) {
+__global__ __launch_bounds__(kGemmThreads) __attribute__((amdgpu_waves_per_eu(3, 3))) void linear_bf16_nn_kernel(GemmNNArgs g) {
   __shared__ __attribute__((aligned(16))) uint16_t smem[kGemmBM * kGemmPad + kGemmBK * kGemmTrStride];
   uint16_t *Xs = smem, *Ws = smem + kGemmBM * kGemmPad;
   const bool wide = gemm_wide_ok(g.Y, g.ldy, g.N);
@@ -380,7 +380,7 @@ struct Conv3x3Args {
 };
 
 template <bool RELU>
-__global__ __launch_bounds__(kGemmThreads) void conv3x3_bf16_kernel(Conv3x3Args g) {
+__global__ __launch_bounds__(kGemmThreads) __attribute__((amdgpu_waves_per_eu(3, 3))) void conv3x3_bf16_kernel(Conv3x3Args g) {
   __shared__ __attribute__((aligned(16))) uint16_t smem[(kGemmBM + kGemmBN) * kGemmPad];
   uint16_t *Xs = smem, *Ws = smem + kGemmBM * kGemmPad;
   const bool wide = gemm_wide_ok(g.Y, g.Cout, g.Cout);
