@@ -28,7 +28,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from .misc import NestedTensor
+from .misc import NestedTensor, is_no_padding, no_padding_mask
 
 
 class FrozenBatchNorm2d(nn.Module):
@@ -311,9 +311,15 @@ class Backbone(nn.Module):
         for name, x in feats.items():
             m = tensor_list.mask
             assert m is not None
-            mask = F.interpolate(m[None].float(), size=x.shape[-2:]).to(torch.bool)[0]    # nearest (:93)
+            if is_no_padding(m):                       # nearest-resizing an all-False mask: all False, known here
+                mask = no_padding_mask(m.shape[0], x.shape[-2], x.shape[-1], m.device)
+            else:
+                mask = F.interpolate(m[None].float(), size=x.shape[-2:]).to(torch.bool)[0]    # nearest (:93)
             out[name] = NestedTensor(x, mask)
         return out
+
+
+_POS_CACHE: Dict = {}
 
 
 class PositionEmbeddingSine(nn.Module):
@@ -334,6 +340,16 @@ class PositionEmbeddingSine(nn.Module):
     def channel_last(self, mask):
         """[b*t, h, w] padding mask -> [b, t, h, w, 3F]: the embedding as it is computed, before the reference's
         permute to channel-first (position_encoding.py:62); the token-row path uses it as is."""
+        n, h, w = mask.shape
+        if is_no_padding(mask) and not torch.is_inference_mode_enabled():   # a constant of the shapes: built once
+            key = (n, h, w, self.frames, self.num_pos_feats, self.temperature, self.normalize, self.scale, str(mask.device))
+            got = _POS_CACHE.get(key)
+            if got is None:
+                got = _POS_CACHE[key] = self._channel_last(mask)
+            return got
+        return self._channel_last(mask)
+
+    def _channel_last(self, mask):
         n, h, w = mask.shape
         live = ~mask.reshape(n // self.frames, self.frames, h, w)
         axes = []

@@ -18,6 +18,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from .dense import big_ffn, big_linear
+from .misc import is_no_padding
 from .ms_deform_attn import MSDeformAttn
 
 
@@ -206,6 +207,16 @@ class DeformableTransformerEncoder(nn.Module):
         """Pixel centres of every level, normalised by the valid extent, then re-expressed in each
         level's padded frame: [B, S, L, 2] (reference :220-232)."""
         hw = getattr(spatial_shapes, "_snipper_host", None) or spatial_shapes.tolist()
+        if getattr(valid_ratios, "_snipper_ones", False) and not torch.is_inference_mode_enabled():   # a constant grid
+            key = ("ref", valid_ratios.shape[0], tuple(tuple(x) for x in hw), str(device))
+            got = _LEVEL_CACHE.get(key)
+            if got is None:
+                got = _LEVEL_CACHE[key] = DeformableTransformerEncoder._reference_points(hw, valid_ratios, device)
+            return got
+        return DeformableTransformerEncoder._reference_points(hw, valid_ratios, device)
+
+    @staticmethod
+    def _reference_points(hw, valid_ratios, device):
         per_level = []
         for lvl, (H, W) in enumerate(hw):
             ys = torch.arange(H, dtype=torch.float32, device=device) + 0.5
@@ -447,12 +458,23 @@ class DeformableTransformer(nn.Module):
         # the fused encoder only ever reads the position encoding in bf16 (query = bf16(src + pos))
         pos16 = LevelPosTokens.apply(self.level_embed[:len(pos_tokens)], *pos_tokens)
         pos = pos16
-        mask = torch.cat([m.reshape(b, T, -1) for m in masks], 2)[..., None].expand(-1, -1, -1, c)
-        ratios = []
-        for m, (h, w) in zip(masks, hw):                                  # get_valid_ratio on frame 0 of each sample
-            m0 = m.view(b, T, h, w)[:, 0]
-            ratios.append(torch.stack([(~m0[:, 0, :]).sum(1).float() / w, (~m0[:, :, 0]).sum(1).float() / h], -1))
-        valid_ratios = torch.stack(ratios, 1)                             # [bs, L, 2]
+        if all(is_no_padding(m) for m in masks) and not torch.is_inference_mode_enabled():
+            # no padding anywhere (known on the host): the flattened mask and the valid ratios are constants of the shapes
+            key = ("no_pad", b, T, tuple(hw), str(feats[0].device))
+            got = _LEVEL_CACHE.get(key)
+            if got is None:
+                flat = torch.zeros((b, T, sum(sizes), 1), dtype=torch.bool, device=feats[0].device)
+                ones = torch.ones((b, len(hw), 2), dtype=torch.float32, device=feats[0].device)
+                ones._snipper_ones = True
+                got = _LEVEL_CACHE[key] = (flat, ones)
+            mask, valid_ratios = got[0].expand(-1, -1, -1, c), got[1]
+        else:
+            mask = torch.cat([m.reshape(b, T, -1) for m in masks], 2)[..., None].expand(-1, -1, -1, c)
+            ratios = []
+            for m, (h, w) in zip(masks, hw):                              # get_valid_ratio on frame 0 of each sample
+                m0 = m.view(b, T, h, w)[:, 0]
+                ratios.append(torch.stack([(~m0[:, 0, :]).sum(1).float() / w, (~m0[:, :, 0]).sum(1).float() / h], -1))
+            valid_ratios = torch.stack(ratios, 1)                         # [bs, L, 2]
         spatial_shapes, level_start_index = _level_tensors(tuple(hw), feats[0].device)
         params = [t for proj in input_proj for t in (proj[0].weight, proj[0].bias, proj[1].weight, proj[1].bias)]
         gn = input_proj[0][1]

@@ -24,6 +24,29 @@ class NestedTensor(object):
         return str(self.tensors)
 
 
+_NO_PAD_MASKS = {}
+
+
+def no_padding_mask(n: int, h: int, w: int, device) -> Tensor:
+    """An all-False [n, h, w] padding mask that says so on the host (attribute ``_snipper_all_false``): everything that
+    is a function of the mask alone -- the resized masks, the position encoding, the valid ratios, the encoder's
+    reference grid -- is then a constant of the shapes and is built once instead of ~150 small launches per step.
+    Shared and read-only; a copy (``.to``, ``.clone``) drops the attribute and with it the shortcut."""
+    if torch.is_inference_mode_enabled():            # inference tensors must not end up in a cache that training reads
+        return torch.zeros((n, h, w), dtype=torch.bool, device=device)
+    key = (n, h, w, str(device))
+    m = _NO_PAD_MASKS.get(key)
+    if m is None:
+        m = torch.zeros((n, h, w), dtype=torch.bool, device=device)
+        m._snipper_all_false = True
+        _NO_PAD_MASKS[key] = m
+    return m
+
+
+def is_no_padding(mask) -> bool:
+    return getattr(mask, "_snipper_all_false", False)
+
+
 def nested_tensor_from_tensor_list(tensor_list: List[Tensor], split=True) -> NestedTensor:
     """Each snippet arrives as [T*3, H, W]; it is split into T images of [3, H, W], all images are
     zero-padded to the largest H, W in the batch, and the mask is True on padding."""
@@ -36,7 +59,7 @@ def nested_tensor_from_tensor_list(tensor_list: List[Tensor], split=True) -> Nes
     w = max(t.shape[2] for t in tensor_list)
     if all(tuple(t.shape) == (c, h, w) for t in tensor_list):     # the training case: nothing to pad
         batch = torch.stack(list(tensor_list))
-        return NestedTensor(batch, torch.zeros((len(tensor_list), h, w), dtype=torch.bool, device=batch.device))
+        return NestedTensor(batch, no_padding_mask(len(tensor_list), h, w, batch.device))
     ref = tensor_list[0]
     batch = torch.zeros((len(tensor_list), c, h, w), dtype=ref.dtype, device=ref.device)
     mask = torch.ones((len(tensor_list), h, w), dtype=torch.bool, device=ref.device)

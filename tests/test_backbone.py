@@ -94,3 +94,23 @@ def test_position_embedding_shapes_and_symmetry():
     torch.testing.assert_close(pos[:, 0, 32:, 1, :], pos[:, 1, 32:, 4, :])
     # first valid cell: cumsum = 1 -> angle = 2*pi/(n_valid + eps) / dim_t[0]
     assert abs(float(pos[0, 0, 32, 0, 0]) - float(torch.sin(torch.tensor(2 * torch.pi / (5 + 1e-6))))) < 1e-5
+
+
+def test_no_padding_shortcuts_equal_the_general_path():
+    """A mask marked "no padding" on the host takes cached constants for the position encoding, the resized masks, the
+    valid ratios and the encoder's reference grid; an unmarked copy of the same mask takes the arithmetic."""
+    from snipper_amd.backbone import PositionEmbeddingSine
+    from snipper_amd.deformable_transformer import DeformableTransformerEncoder
+    from snipper_amd.misc import is_no_padding, no_padding_mask
+    m = no_padding_mask(8, 5, 7, "cpu")
+    assert is_no_padding(m) and not is_no_padding(m.clone()) and not m.any()
+    pe = PositionEmbeddingSine(32, num_frames=4, normalize=True)
+    a, b = pe.channel_last(m), pe.channel_last(m.clone())
+    assert a is pe.channel_last(m) and torch.equal(a, b)
+    shapes = torch.tensor([[5, 7], [3, 4]])
+    ones = torch.ones(2, 2, 2)
+    marked = torch.ones(2, 2, 2)
+    marked._snipper_ones = True
+    ra = DeformableTransformerEncoder.get_reference_points(shapes, marked, "cpu")
+    rb = DeformableTransformerEncoder.get_reference_points(shapes, ones, "cpu")
+    assert torch.equal(ra, rb) and ra is DeformableTransformerEncoder.get_reference_points(shapes, marked, "cpu")
