@@ -45,7 +45,7 @@ template <> struct Vec4IO<uint16_t> {
 // (MASK_IN: the mask belongs to the input frames -- forward) or being written as 0 (the mask belongs to
 // the output frames -- backward, where `in` is the gradient of the mixed frames).
 template <typename TI, typename TO, bool MASK_IN>
-__global__ __launch_bounds__(256) void temporal_mix_kernel(const TI *__restrict__ in, const unsigned char *__restrict__ mask,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void temporal_mix_kernel(const TI *__restrict__ in, const unsigned char *__restrict__ mask,
                                                            MixMatrix mix, int N, int Ti, int To, long long S, int C,
                                                            TO *__restrict__ out) {
   const long long X4 = S * C / 4;                       // vectors of 4 channels per frame
