@@ -193,6 +193,19 @@ int snipper_pair_losses_backward(void *stream, const float *sk, const float *sd,
                                  const float *cont_w, const float *max_depth, const float *grad_terms,
                                  int n_layers, int pairs, int T, int K, float eps, float *grad_sk, float *grad_sd);
 
+/* ---- the matcher's cost matrix (csrc/match_cost.cuh) ------------------------------------------------------
+ * Replaces the ~60 broadcast / reduction launches per sample of models/matcher.py:60-127.  One entry per (layer l,
+ * query q, target m): out[l][q][m] = w0 class + w1 root + w2 root_vis + w3 root_depth + w4 joint + w5 joint_vis +
+ * w6 joint_depth (weights7 is a HOST array in that order; the terms as defined in the file header).
+ * kpts [L][*][Q][T][K][3], depth [L][*][Q][T][K][1], logits [L][*][Q][T][2] float32 device memory, addressed through
+ * the layer / query strides and the keypoint stride kp_sk / d_sk (elements; 3 / 1 when dense, 4 / 4 for slices of one
+ * [..., K, 4] head output) so that a per-sample slice of the [L, bs, Q, ...] tensors needs no copy;
+ * tgt_kpts [M][T][K][3], tgt_depth [M][T][K][2] contiguous; max_depth a device scalar; out [L][Q][M]. */
+int snipper_match_cost_f32(void *stream, const float *kpts, long long kp_sl, long long kp_sq, int kp_sk, const float *depth,
+                           long long d_sl, long long d_sq, int d_sk, const float *logits, long long lg_sl, long long lg_sq,
+                           const float *tgt_kpts, const float *tgt_depth, const float *max_depth,
+                           int L, int Q, int M, int T, int K, const float *weights7, float eps, float *out);
+
 /* ---- Hungarian matching on the device (csrc/lsap.cuh) ---------------------------------------------------
  * Replaces the host round trip of models/matcher.py:132 (`linear_sum_assignment(cost.cpu())`).
  * cost [P, n, m] float32 (P independent problems, n predictions, m targets, 1 <= m <= n <= 64), device memory.

@@ -65,6 +65,9 @@ EXPORTS = {
                                  c_void_p, c_int, c_void_p, c_longlong, c_void_p, c_longlong, c_int, c_void_p], c_int),
     "snipper_pair_losses_forward": ([c_void_p] * 7 + [c_int] * 4 + [ctypes.c_float, c_void_p], c_int),
     "snipper_pair_losses_backward": ([c_void_p] * 8 + [c_int] * 4 + [ctypes.c_float, c_void_p, c_void_p], c_int),
+    "snipper_match_cost_f32": ([c_void_p, c_void_p, c_longlong, c_longlong, c_int, c_void_p, c_longlong, c_longlong, c_int, c_void_p,
+                                c_longlong, c_longlong, c_void_p, c_void_p, c_void_p] + [c_int] * 5 + [c_void_p, ctypes.c_float,
+                                                                                                     c_void_p], c_int),
     "snipper_lsap_f32": ([c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p], c_int),
     "snipper_linear_bf16": ([c_void_p, c_void_p, ctypes.c_longlong, c_void_p, c_void_p, c_void_p, ctypes.c_longlong,
                              c_void_p, ctypes.c_longlong, c_int, c_int, c_int, c_int, ctypes.c_float,

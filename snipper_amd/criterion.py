@@ -53,10 +53,15 @@ class HungarianMatcher(nn.Module):
         self.cost_joint_depth, self.cost_root_depth = cost_joint_depth, cost_root_depth
         self.eps = _EPS
         self.device_lsap = True     # HIP assignment kernel for CUDA inputs (n_query <= 64); SciPy otherwise
+        self.device_cost = True     # HIP cost-matrix kernel for CUDA inputs; the PyTorch formulation otherwise
 
     @torch.no_grad()
     def cost_matrices(self, logits, kpts2d, depth, targets) -> List[torch.Tensor]:
         """Per sample i: cost [n_dec, n_query, m_i] (the seven terms of matcher.py:86-130)."""
+        if logits.is_cuda and self.device_cost and all(t["kpts2d"].shape[0] > 0 for t in targets):
+            got = self._cost_matrices_device(logits, kpts2d, depth, targets)
+            if got is not None:
+                return got
         costs = []
         for i, tgt in enumerate(targets):
             tk = tgt["kpts2d"][None, None]                       # 1 x 1 x m x T x K x 3
@@ -89,6 +94,49 @@ class HungarianMatcher(nn.Module):
             costs.append(self.cost_is_human * c_class + self.cost_root * c_root + self.cost_root_vis * c_root_vis +
                          self.cost_root_depth * c_root_depth + self.cost_joint * c_joint +
                          self.cost_joint_vis * c_joint_vis + self.cost_joint_depth * c_joint_depth)
+        return costs
+
+    def _cost_matrices_device(self, logits, kpts2d, depth, targets):
+        """The same matrices from csrc/match_cost.cuh: one launch per sample instead of ~60.  None when the layouts are
+        not the ones the kernel addresses (then the formulation above runs)."""
+        import ctypes
+        from . import _lib
+        n_dec, bs, nq, T, K = kpts2d.shape[:5]
+
+        def rows(t, width):          # [n_dec, bs, nq, T, K, width] float32 with dense-compatible (T, K, width) axes
+            if t.dtype != torch.float32 or t.stride(-1) != 1:
+                t = t.float().contiguous()
+            sk = t.stride(-2)
+            if t.stride(-3) != K * sk or sk < width:
+                t = t.contiguous()
+                sk = t.stride(-2)
+            return t, sk
+
+        kp, kp_sk = rows(kpts2d, 3)
+        dp, d_sk = rows(depth, 1)
+        lg = logits if (logits.dtype == torch.float32 and logits[0, 0].is_contiguous()) else logits.float().contiguous()
+        if kp.stride(-4) != T * K * kp_sk or dp.stride(-4) != T * K * d_sk:
+            return None
+        w7 = (ctypes.c_float * 7)(self.cost_is_human, self.cost_root, self.cost_root_vis, self.cost_root_depth,
+                                  self.cost_joint, self.cost_joint_vis, self.cost_joint_depth)
+        lib, dev, costs = _lib.load(), logits.device, []
+        for i, tgt in enumerate(targets):
+            tk, td, md = tgt["kpts2d"], tgt["depth"], tgt["max_depth"]
+            if not (torch.is_tensor(md) and md.is_cuda):          # a host scalar would cost a blocking copy per call
+                return None
+            tk = tk.float().contiguous()
+            td = td.float().contiguous()
+            md = md.reshape(-1)[:1].float().contiguous()
+            m = tk.shape[0]
+            out = torch.empty((n_dec, nq, m), dtype=torch.float32, device=dev)
+            ki, di, li = kp[:, i], dp[:, i], lg[:, i]
+            with _lib.device_guard(dev):
+                rc = lib.snipper_match_cost_f32(
+                    _lib.raw_stream(dev), ki.data_ptr(), ki.stride(0), ki.stride(1), kp_sk, di.data_ptr(), di.stride(0),
+                    di.stride(1), d_sk, li.data_ptr(), li.stride(0), li.stride(1), tk.data_ptr(), td.data_ptr(),
+                    md.data_ptr(), n_dec, nq, m, T, K, ctypes.cast(w7, ctypes.c_void_p), float(self.eps), out.data_ptr())
+            _lib.check(rc, "snipper_match_cost_f32")
+            costs.append(out)
         return costs
 
     @torch.no_grad()

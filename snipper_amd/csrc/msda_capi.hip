@@ -15,6 +15,7 @@
 #include "../../include/snipper_dense.h"
 #include "gemm_bf16.cuh"
 #include "wgrad_bf16.cuh"
+#include "match_cost.cuh"
 #include "ln_fused.cuh"
 #include "gn_tokens.cuh"
 #include "pair_losses.cuh"
@@ -862,6 +863,20 @@ int snipper_pair_losses_backward(void *stream, const float *sk, const float *sd,
   a.dsk = grad_sk; a.dsd = grad_sd;
   a.P = n_layers * pairs; a.T = T; a.K = K; a.pairs_per_layer = pairs; a.eps = eps;
   hipLaunchKernelGGL(pair_losses_bwd_kernel, dim3((a.P + 3) / 4), dim3(256), 0, (hipStream_t)stream, a);
+  return launch_status();
+}
+
+int snipper_match_cost_f32(void *stream, const float *kpts, long long kp_sl, long long kp_sq, int kp_sk, const float *depth,
+                           long long d_sl, long long d_sq, int d_sk, const float *logits, long long lg_sl, long long lg_sq,
+                           const float *tgt_kpts, const float *tgt_depth, const float *max_depth,
+                           int L, int Q, int M, int T, int K, const float *weights7, float eps, float *out) {
+  if (!kpts || !depth || !logits || !tgt_kpts || !tgt_depth || !max_depth || !weights7 || !out) return SNIPPER_E_NULL;
+  if (L <= 0 || Q <= 0 || M <= 0 || T <= 0 || K < 2 || kp_sk < 3 || d_sk < 1) return SNIPPER_E_SHAPE;
+  const MatchCostArgs a{kpts, kp_sl, kp_sq, kp_sk, depth, d_sl, d_sq, d_sk, logits, lg_sl, lg_sq, tgt_kpts, tgt_depth, max_depth,
+                        L, Q, M, T, K, weights7[0], weights7[1], weights7[2], weights7[3], weights7[4], weights7[5],
+                        weights7[6], eps, out};
+  const long long total = (long long)L * Q * M;
+  hipLaunchKernelGGL(match_cost_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
   return launch_status();
 }
 

@@ -72,3 +72,41 @@ def test_criterion_golden_on_gpu(golden_dir):
         else:
             s = max(float(gr.abs().max()), 1e-6)
             torch.testing.assert_close(g.cpu() / s, gr / s, rtol=1e-3, atol=2e-5)
+
+
+@pytest.mark.parametrize("n_dec,bs,nq,T,K,packed", [(6, 2, 60, 4, 15, True), (1, 1, 7, 1, 15, False), (3, 2, 20, 6, 15, True),
+                                                     (2, 1, 5, 2, 2, False)])
+def test_match_cost_kernel_equals_pytorch_formulation(n_dec, bs, nq, T, K, packed):
+    """csrc/match_cost.cuh against the broadcast formulation of the same class (matcher.py:60-127): dense inputs and
+    slices of one [..., K, 4] head output (keypoint stride 4), targets with invisible joints and whole invisible
+    frames, uneven target counts; the assignments computed from both matrices agree."""
+    from snipper_amd.criterion import HungarianMatcher
+    g = torch.Generator().manual_seed(n_dec * 1000 + nq)
+    matcher = HungarianMatcher(cost_is_human=1.0, cost_root=5.0, cost_root_vis=0.1, cost_joint=5.0, cost_joint_vis=0.1,
+                               cost_joint_depth=5.0, cost_root_depth=5.0)
+    logits = torch.randn(n_dec, bs, nq, T, 2, generator=g).to(DEV)
+    if packed:
+        head = torch.rand(n_dec, bs, nq, T, K, 4, generator=g).to(DEV)
+        kpts2d, depth = head[..., 0:3], head[..., 3:4]
+    else:
+        kpts2d = torch.rand(n_dec, bs, nq, T, K, 3, generator=g).to(DEV)
+        depth = torch.rand(n_dec, bs, nq, T, K, 1, generator=g).to(DEV)
+    targets = []
+    for i in range(bs):
+        m = 3 + 4 * i
+        tk = torch.rand(m, T, K, 3, generator=g)
+        tk[..., 2] = (torch.rand(m, T, K, generator=g) < 0.7).float()
+        tk[0, 0, :, 2] = 0.0                                  # a frame with nothing visible
+        td = torch.rand(m, T, K, 2, generator=g)
+        td[..., 1] = (torch.rand(m, T, K, generator=g) < 0.6).float()
+        targets.append({"kpts2d": tk.to(DEV), "depth": td.to(DEV), "max_depth": torch.tensor(15.0, device=DEV)})
+    res = {}
+    for on in (True, False):
+        matcher.device_cost = on
+        res[on] = (matcher.cost_matrices(logits, kpts2d, depth, targets),
+                   matcher.match_all_layers(logits, kpts2d, depth, targets))
+    for a, b in zip(res[True][0], res[False][0]):
+        assert a.shape == b.shape
+        torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6)
+    for a, b in zip(res[True][1][:3], res[False][1][:3]):
+        assert torch.equal(a, b)
