@@ -300,6 +300,10 @@ class SetCriterion(nn.Module):
             terms = PairLosses.apply(sk, sd, tk, td, self.cont_weights, max_depth, eps).sum(1) / num_traj   # [n_dec, 9]
             for i, name in enumerate(_PAIR_TERMS):
                 out[name] = terms[:, i]
+            # forward() stacks the entries as [n_names, n_dec]; this is the same tensor built with one cat instead of nine
+            # selects + a stack (whose backward is a fill, a copy and an add per name)
+            head = [out[k][None] for k in out if k not in _PAIR_TERMS]
+            self._stacked_hint = (list(out), torch.cat(head + [terms.t()], 0))
             return out
 
         t_root_vis = tk[..., :1, 2:3]
@@ -413,10 +417,15 @@ class SetCriterion(nn.Module):
             sk, sd = pick(kpts2d), pick(depth)
         tk = torch.cat([t["kpts2d"][tgt[:, a:b]] for t, a, b in zip(targets, offsets[:-1], offsets[1:])], 1)
         td = torch.cat([t["depth"][tgt[:, a:b]] for t, a, b in zip(targets, offsets[:-1], offsets[1:])], 1)
+        self._stacked_hint = None
         per_layer = self._all_losses(logits, sk, sd, tk, td, src, batch, targets[0]["max_depth"], num_traj)
 
         names = list(per_layer)
-        stacked = torch.stack([per_layer[n] for n in names])     # [n_names, n_dec]
+        hint, self._stacked_hint = getattr(self, "_stacked_hint", None), None
+        if hint is not None and hint[0] == names:
+            stacked = hint[1]
+        else:
+            stacked = torch.stack([per_layer[n] for n in names])     # [n_names, n_dec]
         losses = {}
         for j, name in enumerate(names):                          # entries are (differentiable) views of `stacked`
             losses[name] = stacked[j, -1]                        # main output = last decoder layer
