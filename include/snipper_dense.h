@@ -206,6 +206,16 @@ int snipper_match_cost_f32(void *stream, const float *kpts, long long kp_sl, lon
                            const float *tgt_kpts, const float *tgt_depth, const float *max_depth,
                            int L, int Q, int M, int T, int K, const float *weights7, float eps, float *out);
 
+/* ---- decoder reference-point refinement (csrc/match_cost.cuh) ---------------------------------------------
+ * models/deformable_transformer.py:329-333 + util/misc.py:481-485 + :319-321 in one launch:
+ *   new_ref[row] = sigmoid(delta[row, 0:2] + inverse_sigmoid(ref[row]))     (clamps as the reference, eps = 1e-5)
+ *   ref_in[row, l] = new_ref[row] * valid_ratios[row / rows_per_batch, l]
+ * delta: float32 rows with leading dimension ld_delta (>= 2; e.g. the [.., 4] output of the root head); ref, new_ref
+ * [rows, 2]; valid_ratios [rows / rows_per_batch, L, 2]; ref_in [rows, L, 2].  Forward only: the reference detaches. */
+int snipper_refine_reference_f32(void *stream, const float *delta, long long ld_delta, const float *ref,
+                                 const float *valid_ratios, int rows, int rows_per_batch, int L, float eps,
+                                 float *new_ref, float *ref_in);
+
 /* ---- Hungarian matching on the device (csrc/lsap.cuh) ---------------------------------------------------
  * Replaces the host round trip of models/matcher.py:132 (`linear_sum_assignment(cost.cpu())`).
  * cost [P, n, m] float32 (P independent problems, n predictions, m targets, 1 <= m <= n <= 64), device memory.

@@ -91,4 +91,25 @@ __global__ __launch_bounds__(256) void match_cost_kernel(MatchCostArgs a) {
   a.out[idx] = cost;
 }
 
+// ---- iterative refinement of the decoder's reference points (reference models/deformable_transformer.py:329-333 with
+// util/misc.py:481-485): new_ref = sigmoid(delta + inverse_sigmoid(ref)), detached, and the next layer's
+// ref_in[row][l] = new_ref[row] * valid_ratios[batch(row)][l] (:319-321).  Eight element-wise launches on a few hundred
+// values per decoder layer in PyTorch; one here.  No gradient flows through it (the reference detaches the result).
+__global__ __launch_bounds__(256) void refine_reference_kernel(const float *__restrict__ delta, long long ld_delta,
+                                                               const float *__restrict__ ref,
+                                                               const float *__restrict__ valid_ratios, int rows,
+                                                               int rows_per_batch, int L, float eps,
+                                                               float *__restrict__ new_ref, float *__restrict__ ref_in) {
+  const int i = blockIdx.x * 256 + threadIdx.x;          // one thread per (row, coordinate)
+  if (i >= rows * 2) return;
+  const int row = i >> 1, c = i & 1;
+  float x = fminf(fmaxf(ref[i], 0.f), 1.f);
+  const float x1 = fmaxf(x, eps), x2 = fmaxf(1.f - x, eps);
+  const float z = delta[(long long)row * ld_delta + c] + logf(x1 / x2);
+  const float r = 1.f / (1.f + expf(-z));
+  new_ref[i] = r;
+  const float *vr = valid_ratios + (long long)(row / rows_per_batch) * L * 2 + c;
+  for (int l = 0; l < L; ++l) ref_in[((long long)row * L + l) * 2 + c] = r * vr[2 * l];
+}
+
 }  // namespace snipper

@@ -880,6 +880,16 @@ int snipper_match_cost_f32(void *stream, const float *kpts, long long kp_sl, lon
   return launch_status();
 }
 
+int snipper_refine_reference_f32(void *stream, const float *delta, long long ld_delta, const float *ref,
+                                 const float *valid_ratios, int rows, int rows_per_batch, int L, float eps,
+                                 float *new_ref, float *ref_in) {
+  if (!delta || !ref || !valid_ratios || !new_ref || !ref_in) return SNIPPER_E_NULL;
+  if (rows <= 0 || rows_per_batch <= 0 || rows % rows_per_batch || L <= 0 || ld_delta < 2) return SNIPPER_E_SHAPE;
+  hipLaunchKernelGGL(refine_reference_kernel, dim3((unsigned)((rows * 2 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     delta, ld_delta, ref, valid_ratios, rows, rows_per_batch, L, eps, new_ref, ref_in);
+  return launch_status();
+}
+
 int snipper_lsap_f32(void *stream, const float *cost, int P, int n, int m, long long *out_src, long long *out_tgt) {
   if (!cost || !out_src || !out_tgt) return SNIPPER_E_NULL;
   if (P <= 0 || m <= 0 || n < m || n > kLsapMaxCols || m > kLsapMaxRows) return SNIPPER_E_SHAPE;

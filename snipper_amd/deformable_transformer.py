@@ -28,6 +28,33 @@ def inverse_sigmoid(x, eps=1e-5):
     return torch.log(x.clamp(min=eps) / (1 - x).clamp(min=eps))
 
 
+def _refine_reference(head, out, reference_points, valid_ratios):
+    """(sigmoid(head(out)[..., :2] + inverse_sigmoid(ref)).detach(), that times the valid ratios) from one launch of
+    csrc/match_cost.cuh's refine kernel after the head's own GEMMs -- the result carries no gradient (the reference
+    detaches it, :333), so the head runs without a graph here.  None when the float32 CUDA layout does not apply."""
+    if not (out.is_cuda and out.dtype == torch.float32 and reference_points.dtype == torch.float32 and
+            reference_points.dim() == 4 and reference_points.shape[-1] == 2 and valid_ratios.dtype == torch.float32 and
+            not torch.is_autocast_enabled('cuda')):
+        return None
+    from . import _lib
+    with torch.no_grad():
+        tmp = head(out)
+        bs, t, lq = reference_points.shape[:3]
+        if tmp.dtype != torch.float32 or tmp.shape[:3] != (bs, t, lq) or tmp.stride(-1) != 1 or not tmp.is_contiguous():
+            return None
+        L = valid_ratios.shape[1]
+        ref = reference_points.contiguous()
+        vr = valid_ratios.contiguous()
+        new_ref = torch.empty_like(ref)
+        ref_in = torch.empty((bs, t, lq, L, 2), dtype=torch.float32, device=out.device)
+        with _lib.device_guard(out.device):
+            rc = _lib.load().snipper_refine_reference_f32(_lib.raw_stream(out.device), tmp.data_ptr(), tmp.shape[-1],
+                                                          ref.data_ptr(), vr.data_ptr(), bs * t * lq, t * lq, L, 1e-5,
+                                                          new_ref.data_ptr(), ref_in.data_ptr())
+        _lib.check(rc, "snipper_refine_reference_f32")
+    return new_ref, ref_in
+
+
 _LEVEL_CACHE = {}
 
 
@@ -347,13 +374,20 @@ class DeformableTransformerDecoder(nn.Module):
                  src_valid_ratios, query_pos, src_padding_mask, amp_dtype):
         out = query_obj
         inter, inter_ref, inter_att = [], [], []
+        ref_in = None
         for lid, layer in enumerate(self.layers):
-            ref_in = reference_points[:, :, :, None, :] * src_valid_ratios[:, None, None, :, :]
+            if ref_in is None:
+                ref_in = reference_points[:, :, :, None, :] * src_valid_ratios[:, None, None, :, :]
             out, atten_data = layer(out, query_pos, ref_in, src, src_spatial_shapes,
                                     src_level_start_index, src_padding_mask, cross_amp_dtype=amp_dtype)
+            ref_in = None
             if self.root_embed is not None:   # iterative refinement of the reference points (:329-333)
-                delta = self.root_embed[lid](out)[..., 0:2]
-                reference_points = (delta + inverse_sigmoid(reference_points)).sigmoid().detach()
+                fused = _refine_reference(self.root_embed[lid], out, reference_points, src_valid_ratios)
+                if fused is not None:
+                    reference_points, ref_in = fused
+                else:
+                    delta = self.root_embed[lid](out)[..., 0:2]
+                    reference_points = (delta + inverse_sigmoid(reference_points)).sigmoid().detach()
             if self.return_intermediate:
                 inter.append(out)
                 inter_ref.append(reference_points)

@@ -295,3 +295,24 @@ def test_no_padding_constants_leave_the_outputs_unchanged():
         # not bit-equal even between two identical calls: the decoder's float32 GEMMs (hipBLASLt) and the bf16 encoder
         # do not fix the summation order; the shortcut must stay inside that run-to-run noise
         assert d02 <= max(4 * d01, 2e-3 * outs[0][k].float().abs().max().item())
+
+
+def test_refine_reference_kernel_equals_the_reference_chain():
+    """sigmoid(head(out)[..., :2] + inverse_sigmoid(ref)) and its product with the valid ratios from one launch
+    (deformable_transformer.py:319-333 of the reference) against the PyTorch chain, incl. ref = 0, 1 and below eps."""
+    from snipper_amd.deformable_transformer import _refine_reference, inverse_sigmoid
+    g = torch.Generator().manual_seed(3)
+    head = torch.nn.Sequential(torch.nn.Linear(32, 16), torch.nn.ReLU(), torch.nn.Linear(16, 4)).to(DEV)
+    out = torch.randn(2, 3, 5, 32, generator=g).to(DEV)
+    ref = torch.rand(2, 3, 5, 2, generator=g)
+    ref[0, 0, 0] = torch.tensor([0.0, 1.0])
+    ref[0, 0, 1] = torch.tensor([1e-7, 1 - 1e-7])
+    ref = ref.to(DEV)
+    vr = (0.5 + 0.5 * torch.rand(2, 4, 2, generator=g)).to(DEV)
+    got = _refine_reference(head, out, ref, vr)
+    assert got is not None
+    new_ref, ref_in = got
+    want = (head(out)[..., 0:2] + inverse_sigmoid(ref)).sigmoid().detach()
+    torch.testing.assert_close(new_ref, want, rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(ref_in, want[:, :, :, None, :] * vr[:, None, None, :, :], rtol=1e-6, atol=1e-7)
+    assert not new_ref.requires_grad and not ref_in.requires_grad
