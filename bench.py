@@ -118,18 +118,30 @@ def criterion_args(a):
         aux_loss=True, dec_layers=a.dec_layers)
 
 
-def build_optimizer(named_params, capturable=False):
-    """AdamW with the reference's three groups (main.py:201-221) over (name, parameter) pairs."""
+def optimizer_groups(named_params):
+    """The reference's three groups (main.py:201-221) over (name, parameter) pairs: (main, backbone, slow) lists."""
     def named(pred):
         return [p for n, p in named_params if p.requires_grad and pred(n)]
     slow = lambda n: ("reference_points" in n or "sampling_offsets" in n) and "backbone" not in n
+    return (named(lambda n: "backbone" not in n and not slow(n)), named(lambda n: "backbone" in n), named(slow))
+
+
+def build_optimizer(named_params, capturable=False, flat=None):
+    """AdamW with the reference's three groups (main.py:201-221).  ``flat``: a FlatParameters over (main, slow,
+    backbone) -- then each group is its one flat leaf."""
+    main, backbone, slow = optimizer_groups(named_params)
+    if flat is not None:
+        main, slow, backbone = ([flat.leaf_of_group(i)] if flat.leaf_of_group(i) is not None else [] for i in range(3))
     groups = [
-        {"params": named(lambda n: "backbone" not in n and not slow(n)), "lr": 1e-4},
-        {"params": named(lambda n: "backbone" in n), "lr": 1e-5},
-        {"params": named(slow), "lr": 1e-5},
+        {"params": main, "lr": 1e-4},
+        {"params": backbone, "lr": 1e-5},
+        {"params": slow, "lr": 1e-5},
     ]
+    groups = [g for g in groups if g["params"]]
     # fused = one multi-tensor kernel per group instead of a Python loop over ~250 parameters
     fused = all(p.is_cuda for g in groups for p in g["params"])
+    if os.environ.get("SNIPPER_OPT_PLAIN"):               # single-tensor reference implementation (debugging only)
+        return torch.optim.AdamW(groups, lr=1e-4, weight_decay=1e-4, foreach=False, fused=False)
     return torch.optim.AdamW(groups, lr=1e-4, weight_decay=1e-4, capturable=capturable, fused=fused)
 
 
@@ -286,6 +298,9 @@ def main():
     ap.add_argument("--ddp", choices=["flat", "torch"], default="flat",
                     help="N>1 gradient averaging: flat = one flat buffer + a few large all-reduces after backward "
                          "(snipper_amd/grad_sync.py); torch = DistributedDataParallel (host-bound: +15 ms/step)")
+    ap.add_argument("--flat-params", type=int, default=1,
+                    help="1 = one flat tensor per optimizer group (snipper_amd/flat_params.py): the same AdamW + clipping on "
+                         "3 tensors instead of ~330; 0 = per-parameter form")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip roofline/msda extras (profiling runs)")
     a = ap.parse_args()
@@ -344,9 +359,8 @@ def main():
             mp.grad = torch.zeros_like(mp)
         masters = ([mp for _, mp in master_named], [p for _, p in named])
         opt = build_optimizer(master_named, capturable=bool(a.graph))
-    else:
-        opt = build_optimizer(list(model.named_parameters()), capturable=bool(a.graph))
-    net, gsync = model, None
+    net, gsync, flatp = model, None, None
+    use_flat = bool(a.flat_params) and masters is None and not a.graph and not (use_ddp and a.ddp == "torch")
     if use_ddp and a.ddp == "torch":
         net = torch.nn.parallel.DistributedDataParallel(
             model, device_ids=[local_rank], broadcast_buffers=False, gradient_as_bucket_view=True,
@@ -358,8 +372,19 @@ def main():
         # everything but the backbone is "early": its gradients are complete when the input projections' are
         early = [p for n, p in model.named_parameters() if not n.startswith("backbone.")]
         trigger = list(model.input_proj.parameters())
-        gsync = FlatGradSync(model.parameters(), early=early, trigger=trigger)
+        g_main, g_backbone, g_slow = optimizer_groups(list(model.named_parameters()))
+        # flat layout [main | slow | backbone]: early slice first, and group by group so that the optimizer's flat leaves
+        # (flat_params.py) line up with it
+        gsync = FlatGradSync(g_main + g_slow + g_backbone, early=early, trigger=trigger)
         gsync.broadcast_parameters(list(model.parameters()) + list(model.buffers()))
+    if masters is None:
+        if use_flat:
+            from snipper_amd.flat_params import FlatParameters
+            g_main, g_backbone, g_slow = optimizer_groups(list(model.named_parameters()))
+            if gsync is not None:
+                assert [id(p) for p in gsync.params] == [id(p) for p in g_main + g_slow + g_backbone]
+            flatp = FlatParameters([g_main, g_slow, g_backbone], grad_flat=gsync.flat if gsync is not None else None)
+        opt = build_optimizer(list(model.named_parameters()), capturable=bool(a.graph), flat=flatp)
     batches = make_batches(a, device, 2, seed=1000 + rank)
 
     criterion = None
@@ -397,14 +422,23 @@ def main():
             loss = surrogate_loss(out, tgt)
         t = mark("criterion", t)
         if masters is None:
-            opt.zero_grad(set_to_none=True)
+            if flatp is not None:
+                flatp.drop_param_grads()
+            else:
+                opt.zero_grad(set_to_none=True)
             loss.backward()
             t = mark("backward", t)
             if gsync is not None:
                 gsync.sync()
-            torch.nn.utils.clip_grad_norm_(clip_params, 0.1)
+            if flatp is not None:
+                flatp.pack()                 # (after sync() the gradients already live in the shared flat buffer)
+                torch.nn.utils.clip_grad_norm_(flatp.leaves, 0.1)
+            else:
+                torch.nn.utils.clip_grad_norm_(clip_params, 0.1)
             t = mark("clip", t)
             opt.step()
+            if flatp is not None:
+                flatp.after_step()
             t = mark("optimizer", t)
         else:
             mp, pp = masters
@@ -420,7 +454,20 @@ def main():
         return loss
 
     def step(i):
-        return train_step(*batches[i % len(batches)])
+        loss = train_step(*batches[i % len(batches)])
+        if os.environ.get("SNIPPER_PRINT_LOSS"):          # per-step loss (synchronises: debugging only)
+            with torch.no_grad():
+                prev = getattr(step, "prev", None)
+                cur = [q.detach().clone() for q in clip_params]
+                extra = ""
+                if prev is not None:
+                    d = [(c - q) for c, q in zip(cur, prev)]
+                    extra = (f" |dp| {float(torch.stack([x.norm() for x in d]).norm()):.5f}"
+                             f" max {max(float(x.abs().max()) for x in d):.6f}"
+                             f" n_changed {sum(int((x != 0).any()) for x in d)}/{len(d)}")
+                step.prev = cur
+            print(f"[bench] step loss {float(loss.detach()):.4f}{extra}", file=sys.stderr)
+        return loss
 
     def fence():
         if use_ddp:
@@ -578,7 +625,10 @@ def main():
                        "msda_path": "pytorch grid_sample" if a.use_pytorch_deform else "snipper_amd HIP (tied single-launch)",
                        "launch": graph_note,
                        "weights": ("bf16 parameters + fp32 master weights" if masters is not None else
-                                   "fp32 parameters" + (" under bf16 autocast" if amp else ""))},
+                                   "fp32 parameters" + (" under bf16 autocast" if amp else "")),
+                       "optimizer": ("torch.optim.AdamW (fused) + clip_grad_norm_ on one flat tensor per group "
+                                     "(snipper_amd/flat_params.py)" if flatp is not None else
+                                     "torch.optim.AdamW (fused) + clip_grad_norm_ per parameter")},
             "final_loss": round(loss_val, 5),
         }
         if launches:

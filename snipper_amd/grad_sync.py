@@ -34,6 +34,19 @@ import torch
 import torch.distributed as dist
 
 
+FLAT_ALIGN = 64       # elements (256 B): every tensor's slice of a flat buffer starts on a cache-line boundary
+
+
+def flat_offsets(params, align: int = FLAT_ALIGN):
+    """Start offset (elements) of every tensor in a flat buffer and the buffer's size; slices are padded to ``align``
+    (an unaligned weight pointer takes the slow path of vectorised kernels and of the BLAS library's heuristics)."""
+    offs, off = [], 0
+    for p in params:
+        offs.append(off)
+        off += (p.numel() + align - 1) // align * align
+    return offs, off
+
+
 def _dense_view(flat: torch.Tensor, offset: int, like: torch.Tensor) -> torch.Tensor:
     """A view of ``flat[offset : offset + like.numel()]`` with ``like``'s shape and strides (``like`` must be dense and
     non-overlapping, which every parameter is)."""
@@ -56,22 +69,19 @@ class FlatGradSync:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         # SNIPPER_SYNC_FORCE=1: run hooks and collectives even in a 1-rank group (exercises the path on a single GPU)
         self.collective = self.world > 1 or (dist.is_initialized() and os.environ.get("SNIPPER_SYNC_FORCE") == "1")
-        total = sum(p.numel() for p in self.params)
+        self.offsets, total = flat_offsets(self.params)
         self.flat = torch.zeros(total, dtype=dt, device=dev)
-        self.views, off = [], 0
-        for p in self.params:
-            self.views.append(_dense_view(self.flat, off, p))
-            off += p.numel()
+        self.views = [_dense_view(self.flat, off, p) for off, p in zip(self.offsets, self.params)]
+        ends = self.offsets[1:] + [total]                      # (padded) end of every parameter's slice
         # chunk boundaries on parameter boundaries: contiguous slices of the flat buffer
-        self.chunks, start, acc, target = [], 0, 0, (total + chunks - 1) // max(1, chunks)
-        for p in self.params:
-            acc += p.numel()
-            if acc - start >= target:
-                self.chunks.append((start, acc))
-                start = acc
+        self.chunks, start, target = [], 0, (total + chunks - 1) // max(1, chunks)
+        for end in ends:
+            if end - start >= target:
+                self.chunks.append((start, end))
+                start = end
         if start < total:
             self.chunks.append((start, total))
-        self.early_elems = sum(p.numel() for p in self.params[:self.n_early])
+        self.early_elems = self.offsets[self.n_early] if self.n_early < len(self.params) else total
         self._early_works, self._early_done, self._early_seen = [], False, []
         self._trigger = [p for p in trigger if p.requires_grad]
         self._pending = len(self._trigger)
@@ -127,12 +137,10 @@ class FlatGradSync:
         if self._early_done:
             # an "early" gradient that was completed (or replaced) after the early launch -- a property of the graph,
             # hence the same on every rank: its slice is packed and reduced now
-            off = 0
             for i, p in enumerate(self.params[:self.n_early]):
                 if p.grad is not None and p.grad is not self._early_seen[i] and p.grad is not self.views[i]:
                     self.views[i].copy_(p.grad)
-                    late.append((off, off + p.numel()))
-                off += p.numel()
+                    late.append((self.offsets[i], self.offsets[i] + p.numel()))
             self._early_seen = []
         if self.collective:
             works = self._early_works + self._reduce(self.early_elems if self._early_done else 0, self.flat.numel())

@@ -10,9 +10,14 @@ at the start of a forward pass:
     Linear           :  shadow = bf16(weight)
     merged Linears   :  shadow = bf16([W_a; W_b]) in one buffer, bias = [b_a; b_b] (the offset + logit projections)
 
-A shadow is valid while the parameter's version counter is unchanged (the optimizer's in-place update bumps it), so
-frozen layers are converted once.  Consumers call ``lookup(param)`` and fall back to converting on the spot when there
-is no valid shadow -- results are identical either way.
+A shadow is valid while the parameter's version counter is unchanged, so frozen layers are converted once.  An
+optimizer's in-place update bumps the counter in the single-tensor and foreach implementations, but NOT in the fused
+one (``torch.optim.AdamW(fused=True)`` leaves ``p._version`` alone: measured, PyTorch 2.10) -- a training loop with the
+fused optimizer would keep multiplying by the weights of step 0 in every shadowed layer.  ``WeightShadows`` therefore
+installs a global optimizer post-step hook (once) that bumps the version counter of every parameter the optimizer
+owns; updates made through other tensors (flat_params.py) bump the counters themselves.  Consumers call
+``lookup(param)`` and fall back to converting on the spot when there is no valid shadow -- results are identical
+either way.
 """
 from __future__ import annotations
 
@@ -57,8 +62,27 @@ def lookup_merged(lin_a: nn.Linear, lin_b: nn.Linear):
     return None
 
 
+_hook_installed = False
+
+
+def _after_optimizer_step(optimizer, args, kwargs) -> None:
+    ps = [p for g in optimizer.param_groups for p in g["params"] if isinstance(p, torch.Tensor)]
+    if ps:
+        torch.autograd.graph.increment_version(ps)
+
+
+def install_optimizer_hook() -> None:
+    """Every optimizer step from now on bumps its parameters' version counters (see the module docstring)."""
+    global _hook_installed
+    if not _hook_installed:
+        from torch.optim.optimizer import register_optimizer_step_post_hook
+        register_optimizer_step_post_hook(_after_optimizer_step)
+        _hook_installed = True
+
+
 class WeightShadows:
     def __init__(self, model: nn.Module):
+        install_optimizer_hook()
         from .backbone import Bottleneck
         from .deformable_transformer import DeformableTransformerEncoderLayer
         from .ms_deform_attn import MSDeformAttn

@@ -54,33 +54,47 @@ def _worker(rank, world, port, out_dir, mode):
         early = [p for n, p in model.named_parameters() if not n.startswith("backbone.")]
         # "flat_late": the trigger fires at the very start of backward, so nearly every early gradient is completed
         # AFTER the early launch -- exercises the late-arrival path of sync()
-        trig = list(model.input_proj.parameters()) if mode == "flat" else list(model.class_embed[0].parameters())
-        gsync = FlatGradSync(model.parameters(), chunks=3, early=early, trigger=trig)
+        trig = list(model.class_embed[0].parameters()) if mode == "flat_late" else list(model.input_proj.parameters())
+        g_main, g_backbone, g_slow = b.optimizer_groups(list(model.named_parameters()))
+        gsync = FlatGradSync(g_main + g_slow + g_backbone, chunks=3, early=early, trigger=trig)   # bench.py's order
         gsync.broadcast_parameters(list(model.parameters()) + list(model.buffers()))
+    flatp = None
+    if mode == "flat_params":            # bench.py's default: the optimizer sees one flat leaf per group
+        from snipper_amd.flat_params import FlatParameters
+        flatp = FlatParameters([g_main, g_slow, g_backbone], grad_flat=gsync.flat)
     from snipper_amd.criterion import build_criterion
     crit = build_criterion(b.criterion_args(ARGS))
-    opt = b.build_optimizer(list(model.named_parameters()))
+    opt = b.build_optimizer(list(model.named_parameters()), flat=flatp)
     imgs, tgt = b.make_batches(ARGS, "cpu", 1, seed=1000 + rank)[0]
     for it in range(2):
         out, _ = ddp(list(imgs))
         losses, _ = crit(out, tgt["targets"])
         loss = crit.weighted_sum(losses)
-        opt.zero_grad(set_to_none=True)
+        if flatp is not None:
+            flatp.drop_param_grads()
+        else:
+            opt.zero_grad(set_to_none=True)
         loss.backward()
         if gsync is not None:
             assert gsync._early_done, "the early slice must have been launched from the hook"
             gsync.sync()
         if it == 0:
             grads = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
-        torch.nn.utils.clip_grad_norm_(model.parameters(), 0.1)
+        if flatp is not None:
+            flatp.pack()
+            torch.nn.utils.clip_grad_norm_(flatp.leaves, 0.1)
+        else:
+            torch.nn.utils.clip_grad_norm_(model.parameters(), 0.1)
         opt.step()
+        if flatp is not None:
+            flatp.after_step()
     torch.save({"grads": grads, "params": {k: p.detach().clone() for k, p in model.named_parameters()},
                 "loss": float(loss)}, os.path.join(out_dir, f"rank{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["flat", "flat_late", "torch"])
+@pytest.mark.parametrize("mode", ["flat", "flat_late", "flat_params", "torch"])
 def test_two_rank_gloo_step_matches_single_process(tmp_path, mode):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
