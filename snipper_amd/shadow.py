@@ -32,10 +32,11 @@ _merged: Dict[Tuple[int, int], "_Merged"] = {}
 
 
 class _Entry:
-    __slots__ = ("ref", "dst", "scale", "version")
+    __slots__ = ("ref", "dst", "scale", "scale_full", "version")
 
     def __init__(self, param, dst, scale=None):
         self.ref, self.dst, self.scale, self.version = weakref.ref(param), dst, scale, -1
+        self.scale_full = None     # the BN scale expanded to the weight's shape AND strides (multi-tensor fast path)
 
 
 class _Merged:
@@ -117,8 +118,12 @@ class WeightShadows:
                 e = _entries[id(w)] = _Entry(w, torch.empty_like(w, dtype=torch.bfloat16), None)
             scale = bn.scale_bias()[0]
             if e.version != w._version or e.scale is not scale:
+                if e.scale is not scale or e.scale_full is None:
+                    # frozen BatchNorm: built once.  A broadcast operand sends _foreach_mul down its one-kernel-per-tensor
+                    # path (42 launches per step here); a full-size one with the weight's strides keeps it multi-tensor.
+                    e.scale_full = torch.empty_like(w).copy_(scale.view(-1, 1, 1, 1).expand_as(w))
                 mul_src.append(w)
-                mul_scale.append(scale.view(-1, 1, 1, 1))
+                mul_scale.append(e.scale_full)
                 mul_dst.append(e)
                 e.scale = scale
         for lin in self.linears:
