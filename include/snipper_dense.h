@@ -106,6 +106,13 @@ int snipper_groupnorm_tokens_backward(void *stream, const uint16_t *x, const flo
                                       long long dst_rows_per_image, long long dst_row_offset,
                                       uint16_t *dx, float *dgamma, float *dbeta, void *workspace, size_t workspace_bytes);
 
+/* ---- ResNet stem tail (csrc/gn_tokens.cuh) ------------------------------------------------------------------
+ * out[n, oh, ow, c] = relu(max over the 3x3 / stride 2 / pad 1 window of y[n, :, :, c] + shift[c]): the frozen-BN
+ * shift (models/backbone.py:54-64), the ReLU and torchvision's MaxPool2d(3, 2, 1) after conv1 in one pass.
+ * y [N, H, W, C] bf16 NHWC = conv1 with the BN scale folded into its weight and NO bias; shift [C] float32;
+ * out [N, (H-1)/2+1, (W-1)/2+1, C] bf16 NHWC.  C % 8 == 0, 16-byte aligned pointers.  Forward only (the stem is frozen). */
+int snipper_stem_pool_bf16(void *stream, const uint16_t *y, const float *shift, int N, int H, int W, int C, uint16_t *out);
+
 /* Column sums of row segments: out[c] = sum_{i < n_images} sum_{r < rows_per_seg} x[i * image_stride + r * C + c],
  * x bfloat16 (image_stride in elements), out [C] float32, summed in a fixed order.  The gradient of a per-level
  * embedding broadcast over a level's tokens (reference models/deformable_transformer.py:118), taken directly from the

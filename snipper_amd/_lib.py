@@ -70,6 +70,7 @@ EXPORTS = {
                                                                                                      c_void_p], c_int),
     "snipper_refine_reference_f32": ([c_void_p, c_void_p, c_longlong, c_void_p, c_void_p, c_int, c_int, c_int, ctypes.c_float,
                                       c_void_p, c_void_p], c_int),
+    "snipper_stem_pool_bf16": ([c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p], c_int),
     "snipper_lsap_f32": ([c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p], c_int),
     "snipper_linear_bf16": ([c_void_p, c_void_p, ctypes.c_longlong, c_void_p, c_void_p, c_void_p, ctypes.c_longlong,
                              c_void_p, ctypes.c_longlong, c_int, c_int, c_int, c_int, ctypes.c_float,

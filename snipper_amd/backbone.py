@@ -288,10 +288,39 @@ class ResNet50Body(nn.Module):
             if isinstance(m, nn.Conv2d):
                 nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
 
+    def _stem(self, x):
+        """relu(bn1(conv1(x))) -> MaxPool2d(3, 2, 1).  Frozen stem on bf16 NHWC: the convolution runs with the BN scale
+        folded in and no bias, and shift + ReLU + pooling are one kernel (csrc/gn_tokens.cuh stem_pool_kernel)."""
+        conv, bn = self.conv1, self.bn1
+        if (x.is_cuda and torch.is_autocast_enabled('cuda') and torch.get_autocast_dtype('cuda') == torch.bfloat16 and
+                not conv.weight.requires_grad and not (torch.is_grad_enabled() and x.requires_grad) and
+                conv.out_channels % 8 == 0 and conv.bias is None):
+            from . import _lib
+            scale, shift = bn.scale_bias()
+            with torch.no_grad():
+                key = (conv.weight._version, id(scale), conv.weight.data_ptr())
+                cached = getattr(self, "_stem_w", None)
+                if cached is None or cached[0] != key:           # frozen: folded and cast once
+                    w = (conv.weight * scale.view(-1, 1, 1, 1).to(conv.weight.dtype)).to(torch.bfloat16)
+                    cached = (key, w.contiguous(memory_format=torch.channels_last))
+                    object.__setattr__(self, "_stem_w", cached)
+                y = F.conv2d(x.to(torch.bfloat16), cached[1], None, conv.stride, conv.padding, conv.dilation, conv.groups)
+                if y.dtype == torch.bfloat16 and y.is_contiguous(memory_format=torch.channels_last):
+                    n, c, h, wd = y.shape
+                    out = torch.empty((n, c, (h - 1) // 2 + 1, (wd - 1) // 2 + 1), dtype=torch.bfloat16, device=y.device,
+                                      memory_format=torch.channels_last)
+                    sh = shift.float().contiguous()
+                    with _lib.device_guard(y.device):
+                        rc = _lib.load().snipper_stem_pool_bf16(_lib.raw_stream(y.device), y.data_ptr(), sh.data_ptr(),
+                                                                n, h, wd, c, out.data_ptr())
+                    _lib.check(rc, "snipper_stem_pool_bf16")
+                    return out
+        x = conv_frozen_bn(x, conv, bn, relu=True)
+        return F.max_pool2d(x, 3, stride=2, padding=1)
+
     def forward(self, x) -> Dict[str, torch.Tensor]:
         x = x.contiguous(memory_format=torch.channels_last)     # NHWC end to end: no layout shuffles around MIOpen
-        x = conv_frozen_bn(x, self.conv1, self.bn1, relu=True)
-        x = F.max_pool2d(x, 3, stride=2, padding=1)
+        x = self._stem(x)
         if self._stem_frozen is None:                             # walked once (Backbone.__init__ freezes before use)
             self._stem_frozen = not any(p.requires_grad for p in self.layer1.parameters())
         if self._stem_frozen:

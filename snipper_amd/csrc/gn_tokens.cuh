@@ -234,4 +234,56 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float *part, in
   }
 }
 
+// ---- ResNet stem tail: frozen-BN shift + ReLU + 3x3 / stride 2 / pad 1 max-pool in one pass (NHWC bf16) -------------
+// reference models/backbone.py:27-64 (FrozenBatchNorm2d after conv1) + torchvision's stem (ReLU, MaxPool2d(3, 2, 1)).
+// y = conv1(x, w * scale) [N, H, W, C] without the shift; out[n, oh, ow, c] = relu(max_{3x3 window}(y) + shift[c]) --
+// adding a per-channel constant and clamping at 0 are monotone, so they commute with the max.  PyTorch runs this as
+// an add (48 us), a clamp (37 us) and the pooling kernel (72 us) over the 123 MB stem output; here the output is read
+// once (window overlap through the caches) and only the pooled quarter is written.  One thread = 8 channels of one
+// output pixel (16-byte accesses); padding cells take no part (as -inf does in the reference).
+__global__ __launch_bounds__(256) void stem_pool_kernel(const uint16_t *__restrict__ y, const float *__restrict__ shift,
+                                                        int N, int H, int W, int C, int OH, int OW,
+                                                        uint16_t *__restrict__ out) {
+  const int c8 = C >> 3;
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long total = (long long)N * OH * OW * c8;
+  if (idx >= total) return;
+  const int cc = (int)(idx % c8);
+  const int ow = (int)((idx / c8) % OW);
+  const int oh = (int)((idx / ((long long)c8 * OW)) % OH);
+  const int n = (int)(idx / ((long long)c8 * OW * OH));
+  float m[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) m[i] = -3.0e38f;
+  const uint16_t *img = y + (long long)n * H * W * C + cc * 8;
+#pragma unroll
+  for (int dy = 0; dy < 3; ++dy) {
+    const int ih = oh * 2 - 1 + dy;
+    if (ih < 0 || ih >= H) continue;
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+      const int iw = ow * 2 - 1 + dx;
+      if (iw < 0 || iw >= W) continue;
+      const uint4 v = *reinterpret_cast<const uint4 *>(img + ((long long)ih * W + iw) * C);
+      const unsigned w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        m[2 * i] = fmaxf(m[2 * i], __uint_as_float(w4[i] << 16));
+        m[2 * i + 1] = fmaxf(m[2 * i + 1], __uint_as_float(w4[i] & 0xffff0000u));
+      }
+    }
+  }
+  const float4 s0 = *reinterpret_cast<const float4 *>(shift + cc * 8), s1 = *reinterpret_cast<const float4 *>(shift + cc * 8 + 4);
+  const float sh[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+  unsigned o[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    // (the convolution output arrives rounded to bf16 WITHOUT the shift, so conv + shift is rounded twice here where a
+    //  biased convolution rounds once: within one bf16 ulp of it)
+    const float a = fmaxf(m[2 * i] + sh[2 * i], 0.f), b = fmaxf(m[2 * i + 1] + sh[2 * i + 1], 0.f);
+    o[i] = (unsigned)__builtin_bit_cast(uint16_t, (__bf16)a) | ((unsigned)__builtin_bit_cast(uint16_t, (__bf16)b) << 16);
+  }
+  *reinterpret_cast<uint4 *>(out + (((long long)n * OH + oh) * OW + ow) * C + cc * 8) = make_uint4(o[0], o[1], o[2], o[3]);
+}
+
 }  // namespace snipper

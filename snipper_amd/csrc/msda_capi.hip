@@ -624,6 +624,16 @@ size_t snipper_colsum_workspace_bytes(int n_images, int rows_per_seg, int C) {
   return (size_t)n_images * p.nblk * C * sizeof(float);
 }
 
+int snipper_stem_pool_bf16(void *stream, const uint16_t *y, const float *shift, int N, int H, int W, int C, uint16_t *out) {
+  if (!y || !shift || !out) return SNIPPER_E_NULL;
+  if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 8 || (((uintptr_t)y | (uintptr_t)out | (uintptr_t)shift) & 15)) return SNIPPER_E_SHAPE;
+  const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;          // floor((H + 2 - 3) / 2) + 1
+  const long long total = (long long)N * OH * OW * (C / 8);
+  hipLaunchKernelGGL(stem_pool_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, y, shift,
+                     N, H, W, C, OH, OW, out);
+  return launch_status();
+}
+
 int snipper_colsum_segments_bf16(void *stream, const uint16_t *x, long long image_stride, int n_images,
                                  int rows_per_seg, int C, float *out, void *workspace, size_t workspace_bytes) {
   if (!x || !out || !workspace) return SNIPPER_E_NULL;

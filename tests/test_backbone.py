@@ -1,5 +1,6 @@
 """ResNet-50 restatement: layer-by-layer against plain F.conv2d + the reference's FrozenBatchNorm2d
 formula (reference models/backbone.py:54-64).  Parity with torchvision itself is unpinned (absent here)."""
+import pytest
 import torch
 import torch.nn.functional as F
 
@@ -114,3 +115,24 @@ def test_no_padding_shortcuts_equal_the_general_path():
     ra = DeformableTransformerEncoder.get_reference_points(shapes, marked, "cpu")
     rb = DeformableTransformerEncoder.get_reference_points(shapes, ones, "cpu")
     assert torch.equal(ra, rb) and ra is DeformableTransformerEncoder.get_reference_points(shapes, marked, "cpu")
+
+
+@pytest.mark.gpu
+def test_fused_stem_tail_matches_the_composition():
+    """conv1 (BN scale folded, no bias) + stem_pool_kernel against conv1 + frozen BN + ReLU + MaxPool2d(3, 2, 1) in
+    float32: odd sizes (the last window is cut by the border), negative shifts, bf16 tolerance."""
+    from snipper_amd.backbone import ResNet50Body
+    torch.manual_seed(0)
+    body = ResNet50Body(True, False).cuda().eval()
+    for p in body.parameters():
+        p.requires_grad_(False)
+    body.bn1.bias.copy_(torch.randn(64))
+    body.bn1.running_mean.copy_(torch.randn(64) * 0.1)
+    x = torch.rand(2, 3, 77, 101, device="cuda").contiguous(memory_format=torch.channels_last)
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        got = body._stem(x)
+    scale, shift = body.bn1.scale_bias()
+    ref = F.conv2d(x, body.conv1.weight, None, 2, 3) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    ref = F.max_pool2d(F.relu(ref), 3, 2, 1)
+    assert got.dtype == torch.bfloat16 and got.shape == ref.shape and got.is_contiguous(memory_format=torch.channels_last)
+    torch.testing.assert_close(got.float(), ref, rtol=2 ** -6, atol=2e-2)
