@@ -208,18 +208,24 @@ def gaussian_blur(img: torch.Tensor, kernel_size: int) -> torch.Tensor:
     if kernel_size <= 1:
         return img
     key = (kernel_size, str(img.device), img.dtype)
-    k2 = _blur_kernels.get(key)
-    if k2 is None:                                  # a constant of (size, device, dtype): built once
+    ks = _blur_kernels.get(key)
+    if ks is None:                                  # constants of (size, device, dtype): built once
         sigma = 0.3 * ((kernel_size - 1) * 0.5 - 1) + 0.8
         half = (kernel_size - 1) * 0.5
         x = torch.linspace(-half, half, kernel_size, device=img.device, dtype=img.dtype)
         k1 = torch.exp(-0.5 * (x / sigma) ** 2)
         k1 = k1 / k1.sum()
-        k2 = _blur_kernels[key] = (k1[:, None] * k1[None, :])[None, None]
+        ks = _blur_kernels[key] = ((k1[:, None] * k1[None, :])[None, None], k1.view(1, 1, -1, 1).contiguous(),
+                                   k1.view(1, 1, 1, -1).contiguous())
+    k2, kv, kh = ks
     shape = img.shape
     flat = img.reshape(-1, 1, shape[-2], shape[-1])
     pad = kernel_size // 2
     flat = F.pad(flat, [pad, pad, pad, pad], mode="reflect")
+    if img.is_cuda:
+        # the kernel is the outer product k1 k1^T: two 1-D passes (2k taps instead of k^2; the k x k float32 convolution
+        # was 88 us of MIOpen time on the finest level) -- equal to the 2-D form up to float32 rounding of the products
+        return F.conv2d(F.conv2d(flat, kv), kh).reshape(shape)
     return F.conv2d(flat, k2).reshape(shape)
 
 
