@@ -161,7 +161,7 @@ def msda_alg_bytes(d, bwd):
 
 
 def pmc_traffic(kernel_tags, path=os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
-                                              "r01_pmc_bench_step_v7.csv")):
+                                              "r01_pmc_bench_step_v17.csv")):
     """HBM-side bytes per launch of the given kernels from the committed rocprofv3 --pmc profile of this same command
     (FETCH_SIZE + WRITE_SIZE, raw counters; see the file's footer for the gfx950 caveats).  None if absent."""
     try:
@@ -646,7 +646,7 @@ def main():
                 if dom[1] == "d48_owner" and d["N"] == 8 and d["Lq"] == 9875 else None
             line["roofline"] = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                 "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                                "traffic_source": ("profiles/r01_pmc_bench_step_v7.csv: rocprofv3 --pmc FETCH_SIZE + "
+                                "traffic_source": ("profiles/r01_pmc_bench_step_v17.csv: rocprofv3 --pmc FETCH_SIZE + "
                                                    "WRITE_SIZE (separate passes, raw counters) of this command, bin + "
                                                    "tile kernel" if traffic else None),
                                 "kernel": f"msda_{dom[0]}_{dom[1]} N={d['N']} Lq={d['Lq']}",
