@@ -146,7 +146,7 @@ __global__ __launch_bounds__(kLnThreads) void ln_fused_fwd_kernel(LnFwdArgs a) {
 // grid-stride over rows: every wave keeps its lanes' dgamma / dbeta in registers; one partial row per workgroup
 // NIT = ceil(C / 256) register chunks per lane (C = 384 -> 2: 70 VGPRs instead of 130, twice the waves in flight).
 template <int NIT>
-__global__ __launch_bounds__(kLnThreads) __attribute__((amdgpu_waves_per_eu(6, 8))) void ln_fused_bwd_kernel(LnBwdArgs a) {
+__global__ __launch_bounds__(kLnThreads) __attribute__((amdgpu_waves_per_eu(NIT <= 2 ? 6 : 1, 8))) void ln_fused_bwd_kernel(LnBwdArgs a) {
   __shared__ float red[(kLnThreads / 64) * 2 * NIT * 256];               // [wave][2][NIT * 256 >= C]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const float keep_scale = a.p > 0.f ? 1.f / (1.f - a.p) : 1.f;

@@ -287,7 +287,7 @@ template <int kOwnerChunk> struct TileLds {   // kOwnerChunk = list entries (que
 // 5 waves per SIMD (96 VGPRs, 4 dwords spilled outside the chunk loop): the kernel is a chain of dependent LDS reads and
 // barriers, so residency is what hides them -- 123 VGPRs / 4 waves measured 617 us per launch in the step (rocprofv3), this 575.
 template <int kOwnerChunk>
-__global__ __launch_bounds__(kOwnerBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) void msda_bwd_d48_tile_kernel(
+__global__ __launch_bounds__(kOwnerBlock) __attribute__((amdgpu_waves_per_eu(kOwnerChunk <= 64 ? 5 : 1, kOwnerChunk <= 64 ? 5 : 8))) void msda_bwd_d48_tile_kernel(
     const float *__restrict__ grad_out, const float *__restrict__ loc, const float *__restrict__ attn,
     CoreDims d, OwnerPlan plan, float *__restrict__ grad_value, int go_bf16) {
   __shared__ TileLds<kOwnerChunk> S;
