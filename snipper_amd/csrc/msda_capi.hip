@@ -35,7 +35,7 @@ std::atomic<float> g_near_radius{6.0f};
 std::atomic<int> g_owner_debug{0};
 std::atomic<int> g_owner_chunk{64};
 std::atomic<int> g_wgrad_wgs{512};
-std::atomic<int> g_ln_bwd_blocks{1024};
+std::atomic<int> g_ln_bwd_blocks{1536};   // 6 workgroups per CU x 256 CUs: one full residency wave at 6 waves/SIMD (1024: +0.2 ms per step)
 std::atomic<int> g_owner_enable{1};   // owner-computes backward for the encoder shape
 std::atomic<int> g_tile_edge[3] = {{16}, {8}, {4}};   // level area > 4096 px / > 1024 px / smaller
 
