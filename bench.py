@@ -301,6 +301,9 @@ def main():
     ap.add_argument("--flat-params", type=int, default=1,
                     help="1 = one flat tensor per optimizer group (snipper_amd/flat_params.py): the same AdamW + clipping on "
                          "3 tensors instead of ~330; 0 = per-parameter form")
+    ap.add_argument("--gc-every", type=int, default=10,
+                    help="collect garbage by hand every N steps and keep the automatic collector off in between (its "
+                         "generation-0/1 passes cost the issuing thread ~1 ms per step); 0 = leave the collector alone")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip roofline/msda extras (profiling runs)")
     a = ap.parse_args()
@@ -455,6 +458,10 @@ def main():
 
     def step(i):
         loss = train_step(*batches[i % len(batches)])
+        ge = a.gc_every
+        if ge and i % ge == ge - 1:
+            import gc
+            gc.collect(1)
         if os.environ.get("SNIPPER_PRINT_LOSS"):          # per-step loss (synchronises: debugging only)
             with torch.no_grad():
                 prev = getattr(step, "prev", None)
@@ -477,6 +484,13 @@ def main():
     for i in range(a.warmup):
         step(i)
     fence()
+    gc_every = a.gc_every
+    if gc_every:
+        # the collector's generation-0/1 passes run on the thread that issues the step (a few hundred autograd / tensor
+        # objects per step trigger them constantly): collect by hand every N steps instead, as training loops commonly do
+        import gc
+        gc.collect()
+        gc.disable()
 
     # ---- hipGraph: the step is ~3000 launches of mostly short kernels and the host cannot issue them as fast
     #      as the GPU retires them; all shapes are static, so the whole step (forward, loss, backward, RCCL
@@ -581,6 +595,9 @@ def main():
         loss = step(a.warmup + i)
     fence()
     elapsed = time.perf_counter() - t0
+    if gc_every:
+        import gc
+        gc.enable()
     loss_val = float(loss.detach())
     if use_ddp:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
@@ -626,6 +643,7 @@ def main():
                        "launch": graph_note,
                        "weights": ("bf16 parameters + fp32 master weights" if masters is not None else
                                    "fp32 parameters" + (" under bf16 autocast" if amp else "")),
+                       "host": f"gc.collect every {a.gc_every} steps, automatic collector off" if a.gc_every else "default gc",
                        "optimizer": ("torch.optim.AdamW (fused) + clip_grad_norm_ on one flat tensor per group "
                                      "(snipper_amd/flat_params.py)" if flatp is not None else
                                      "torch.optim.AdamW (fused) + clip_grad_norm_ per parameter")},
