@@ -136,3 +136,24 @@ def test_fused_stem_tail_matches_the_composition():
     ref = F.max_pool2d(F.relu(ref), 3, 2, 1)
     assert got.dtype == torch.bfloat16 and got.shape == ref.shape and got.is_contiguous(memory_format=torch.channels_last)
     torch.testing.assert_close(got.float(), ref, rtol=2 ** -6, atol=2e-2)
+
+
+def test_subsample_node_equals_strided_slicing():
+    """The stride-2 sub-sampling in front of a downsample convolution as one autograd node: same values, same
+    gradient, channels-last both ways (autograd's own slice backward produces a contiguous gradient, which the
+    add that follows then handles with the slow strided kernel on the GPU)."""
+    from snipper_amd.backbone import _Subsample
+    x = torch.randn(2, 8, 7, 9, requires_grad=True)
+    y, r = _Subsample.apply(x, 2, 2), x[:, :, ::2, ::2]
+    assert torch.equal(y, r) and y.is_contiguous(memory_format=torch.channels_last)
+    g = torch.randn_like(y)
+    (gx,), (gr,) = torch.autograd.grad(y, x, g), torch.autograd.grad(r, x, g)
+    assert torch.equal(gx, gr) and gx.is_contiguous(memory_format=torch.channels_last)
+
+
+def test_no_padding_mask_is_not_cached_in_inference_mode():
+    from snipper_amd.misc import is_no_padding, no_padding_mask
+    with torch.inference_mode():
+        m = no_padding_mask(3, 4, 5, "cpu")
+    assert not is_no_padding(m) and not m.any() and m.shape == (3, 4, 5)
+    assert is_no_padding(no_padding_mask(3, 4, 5, "cpu"))
