@@ -18,6 +18,9 @@ Fixtures:
   g6_model.pt          the reference SnipperDeformable on a replayed backbone: outputs + state_dict schema + aliases
   g5_criterion.pt      SetCriterion + HungarianMatcher (reference classes, torchvision / cv2 stubbed) on random
                        3-layer outputs: every loss, the matching, gradients of the weighted sum.
+  g3_module_*_d48.pt   the same module at Snipper's real head geometry (d_model 384, 8 heads -> D = 48, the width the tuned
+                       HIP kernels are specialised for), float32 storage of a float64 evaluation.
+  g7_posenc.npz        PositionEmbeddingSine (models/position_encoding.py:20-63) on padded and unpadded masks.
   g4_transformer.pt    one DeformableTransformer forward (T=2+1, enc2/dec2) + its state_dict
                        (pins the key schema) + gradients of a scalar loss.
 """
@@ -179,6 +182,80 @@ def gen_g3(MSDeformAttn):
             blob["vis_loc"] = [t.clone() for t in vis[0]]
             blob["vis_w"] = [t.clone() for t in vis[1]]
         torch.save(blob, os.path.join(OUT, f"g3_module_{name}.pt"))
+
+
+def gen_g3_d48(MSDeformAttn):
+    """MSDeformAttn at d_model=384 / 8 heads (D=48): encoder (Lq == S, T=2) and decoder (Lq=6, T=2+1).  Everything is
+    drawn in float32 and evaluated by the reference in float64; results are stored as float32 (the consumers are the
+    float32 D=48 kernels, compared at 2e-4), which keeps the two files at a few MB."""
+    d_model, M, L, P = 384, 8, 3, 4
+    shapes = torch.as_tensor([(12, 16), (6, 8), (3, 4)], dtype=torch.long)
+    S = int(shapes.prod(1).sum())
+    lsi = lsi_of(shapes)
+    cases = {"enc_d48": ("encoder", 2, 2, S, 201), "dec_d48": ("decoder", 2, 3, 6, 202)}
+    for name, (mode, n_frame, T1, Lq, seed) in cases.items():
+        g = torch.Generator().manual_seed(seed)
+        torch.manual_seed(13)
+        mod = MSDeformAttn(d_model, L, M, P, n_frame, mode, True, mode == "decoder")
+        randomise_(mod, g, scale=0.5)
+        sd32 = {k: v.detach().clone() for k, v in mod.state_dict().items()}
+        mod = mod.double()
+        N, T2 = 1, n_frame
+        query32 = torch.randn(N, T1, Lq, d_model, generator=g)
+        if mode == "encoder":     # encoder-like reference points: the query's own pixel centre on every level
+            refs = []
+            for h, w in shapes.tolist():
+                ys, xs = torch.meshgrid(torch.arange(h) + 0.5, torch.arange(w) + 0.5, indexing="ij")
+                refs.append(torch.stack([xs.reshape(-1) / w, ys.reshape(-1) / h], -1))
+            ref32 = torch.cat(refs)[None, None, :, None, :].expand(N, T1, S, L, 2).contiguous()
+        else:
+            ref32 = torch.rand(N, T1, Lq, L, 2, generator=g) * 1.1 - 0.05
+        src32 = torch.randn(N, T2, S, d_model, generator=g)
+        query, ref, src = (t.double().requires_grad_(True) for t in (query32, ref32, src32))
+        mask = torch.zeros(N, T2, S, dtype=torch.bool)
+        mask[0, :, 7] = True
+        mask[0, 1, -2:] = True
+        mask_c = mask[..., None].expand(-1, -1, -1, d_model).contiguous()
+        res = mod(query, ref, src, shapes, lsi, mask_c)
+        vis = None
+        if isinstance(res, tuple):
+            res, vis = res
+        go32 = torch.randn(res.shape, generator=g)
+        params = dict(mod.named_parameters())
+        grads = torch.autograd.grad(res, [query, ref, src] + list(params.values()), go32.double())
+        blob = {
+            "cfg": dict(d_model=d_model, n_levels=L, n_heads=M, n_points=P, n_frame=n_frame, mode=mode),
+            "state_dict": sd32, "shapes": shapes, "lsi": lsi, "query": query32, "ref": ref32, "src": src32,
+            "mask": mask, "out": res.detach().float(), "grad_out": go32,
+            "grad_query": grads[0].float(), "grad_ref": grads[1].float(), "grad_src": grads[2].float(),
+            "param_grads": {k: g_.float() for k, g_ in zip(params.keys(), grads[3:])},
+        }
+        if vis is not None:
+            blob["vis_w"] = [t.float().clone() for t in vis[1]]
+        torch.save(blob, os.path.join(OUT, f"g3_module_{name}.pt"))
+
+
+def gen_g7():
+    """PositionEmbeddingSine of the reference (models/position_encoding.py:20-63) with build_position_encoding's
+    arguments (:93-99: hidden_dim // 3 features, normalize=True) on an unpadded and on a padded batch."""
+    import_reference()
+    from models.position_encoding import PositionEmbeddingSine
+    from util.misc import NestedTensor
+    out = {}
+    for name, (feats, frames, b, h, w) in {"t4_f128": (128, 4, 2, 7, 9), "t2_f16": (16, 2, 3, 5, 6)}.items():
+        pe = PositionEmbeddingSine(feats, num_frames=frames, normalize=True)
+        clean = torch.zeros(b * frames, h, w, dtype=torch.bool)
+        padded = clean.clone()
+        padded[frames:, :, w - 2:] = True           # sample 1: two padded columns, one padded row
+        padded[frames:, h - 1:, :] = True
+        if b > 2:
+            padded[2 * frames:, :, w - 1:] = True
+        for tag, mask in (("clean", clean), ("padded", padded)):
+            pos = pe(NestedTensor(torch.zeros(b * frames, 3, h, w), mask))
+            out[f"{name}_{tag}_mask"] = mask.numpy()
+            out[f"{name}_{tag}_pos"] = pos.numpy()
+        out[f"{name}_cfg"] = np.array([feats, frames])
+    np.savez_compressed(os.path.join(OUT, "g7_posenc.npz"), **out)
 
 
 def gen_g4(DeformableTransformer):
@@ -382,11 +459,12 @@ def gen_g6(DeformableTransformer):
 
 if __name__ == "__main__":
     core, MSDeformAttn, DeformableTransformer = import_reference()
-    gen_g1(core)
-    gen_g2(core)
-    gen_g3(MSDeformAttn)
-    gen_g4(DeformableTransformer)
-    gen_g5()
-    gen_g6(DeformableTransformer)
+    only = set(sys.argv[1:])          # e.g. `gen_golden.py g3d48 g7` regenerates just those
+    todo = [("g1", lambda: gen_g1(core)), ("g2", lambda: gen_g2(core)), ("g3", lambda: gen_g3(MSDeformAttn)),
+            ("g3d48", lambda: gen_g3_d48(MSDeformAttn)), ("g4", lambda: gen_g4(DeformableTransformer)),
+            ("g7", gen_g7), ("g5", gen_g5), ("g6", lambda: gen_g6(DeformableTransformer))]
+    for tag, fn in todo:
+        if not only or tag in only:
+            fn()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

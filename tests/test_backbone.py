@@ -1,5 +1,7 @@
 """ResNet-50 restatement: layer-by-layer against plain F.conv2d + the reference's FrozenBatchNorm2d
 formula (reference models/backbone.py:54-64).  Parity with torchvision itself is unpinned (absent here)."""
+import os
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -95,6 +97,28 @@ def test_position_embedding_shapes_and_symmetry():
     torch.testing.assert_close(pos[:, 0, 32:, 1, :], pos[:, 1, 32:, 4, :])
     # first valid cell: cumsum = 1 -> angle = 2*pi/(n_valid + eps) / dim_t[0]
     assert abs(float(pos[0, 0, 32, 0, 0]) - float(torch.sin(torch.tensor(2 * torch.pi / (5 + 1e-6))))) < 1e-5
+
+
+@pytest.mark.parametrize("name", ["t4_f128", "t2_f16"])
+def test_position_embedding_matches_reference_golden(golden_dir, name):
+    """g7: outputs of the reference's PositionEmbeddingSine (models/position_encoding.py:20-63) with
+    build_position_encoding's arguments, on an unpadded and a padded batch; channel-first and channel-last views."""
+    import numpy as np
+    g = np.load(os.path.join(golden_dir, "g7_posenc.npz"))
+    feats, frames = (int(v) for v in g[f"{name}_cfg"])
+    pe = PositionEmbeddingSine(feats, num_frames=frames, normalize=True)
+    for tag in ("clean", "padded"):
+        mask = torch.from_numpy(g[f"{name}_{tag}_mask"])
+        want = torch.from_numpy(g[f"{name}_{tag}_pos"])
+        n, h, w = mask.shape
+        got = pe(NestedTensor(torch.zeros(n, 3, h, w), mask))
+        assert got.shape == want.shape
+        torch.testing.assert_close(got, want, rtol=0, atol=2e-6)
+        torch.testing.assert_close(pe.channel_last(mask).permute(0, 1, 4, 2, 3), want, rtol=0, atol=2e-6)
+        if tag == "clean":        # the cached no-padding constant is the same tensor
+            from snipper_amd.misc import no_padding_mask
+            m2 = no_padding_mask(n, h, w, "cpu")
+            torch.testing.assert_close(pe(NestedTensor(torch.zeros(n, 3, h, w), m2)), want, rtol=0, atol=2e-6)
 
 
 def test_no_padding_shortcuts_equal_the_general_path():

@@ -49,3 +49,24 @@ def test_install_registers_reference_module_name():
     import MultiScaleDeformableAttention as MSDA
     assert hasattr(MSDA, "ms_deform_attn_forward") and hasattr(MSDA, "ms_deform_attn_backward")
     assert sys.modules["MultiScaleDeformableAttention"] is MSDA
+
+
+def test_reference_import_line_binds_without_install():
+    """``import MultiScaleDeformableAttention as MSDA`` (reference ms_deform_attn_func.py:18-21) resolves through the
+    repository-root alias in a fresh interpreter that never calls ``snipper_amd.install()``; and, where the reference
+    tree is present (build container only), the reference's own unmodified function file ends up with that module."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import MultiScaleDeformableAttention as MSDA\n"
+            "assert MSDA.ms_deform_attn_forward.__module__ == 'snipper_amd.MultiScaleDeformableAttention'\n"
+            "import os\n"
+            "if os.path.isdir('/root/reference/models/ops/functions'):\n"
+            "    sys.dont_write_bytecode = True\n"
+            "    sys.path.insert(0, '/root/reference/models/ops')\n"
+            "    from functions import ms_deform_attn_func as F\n"
+            "    assert F.MSDA is MSDA\n"
+            "print('ok')\n") % ROOT
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd="/tmp",
+                         env=dict(os.environ, PYTHONDONTWRITEBYTECODE="1"))
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-2000:]

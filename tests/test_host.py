@@ -47,6 +47,29 @@ def test_module_tied_path_matches_reference(golden_dir, name):
         torch.testing.assert_close(g, b["param_grads"][k], rtol=1e-9, atol=1e-10, msg=lambda m: f"{k}: {m}")
 
 
+@pytest.mark.parametrize("name", ["enc_d48", "dec_d48"])
+def test_module_d48_goldens_on_the_pytorch_path(golden_dir, name):
+    """The d_model=384 / 8-head goldens (float32 storage of the reference's float64 evaluation) through this package's
+    module in float64 with the reference's own ``use_pytorch_deform`` switch: pins the fixtures themselves on CPU; the GPU
+    suite runs the same fixtures through the D=48 kernels (tests/test_module_gpu.py)."""
+    b = torch.load(os.path.join(golden_dir, f"g3_module_{name}.pt"))
+    mod = _module_from(b)
+    q, r, s = (b[k].double().clone().requires_grad_(True) for k in ("query", "ref", "src"))
+    mask_c = b["mask"][..., None].expand(-1, -1, -1, b["cfg"]["d_model"])
+    res = mod(q, r, s, b["shapes"], b["lsi"], mask_c)
+    if mod.attention_vis:
+        res, (locs, wts) = res
+        for x, y in zip(wts, b["vis_w"]):
+            torch.testing.assert_close(x.float(), y, rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(res.float(), b["out"], rtol=1e-6, atol=1e-6)
+    params = dict(mod.named_parameters())
+    grads = torch.autograd.grad(res, [q, r, s] + list(params.values()), b["grad_out"].double())
+    for got, key in zip(grads[:3], ("grad_query", "grad_ref", "grad_src")):
+        torch.testing.assert_close(got.float(), b[key], rtol=1e-5, atol=1e-5)
+    for (k, _), g in zip(params.items(), grads[3:]):
+        torch.testing.assert_close(g.float(), b["param_grads"][k], rtol=1e-5, atol=1e-4, msg=lambda m: f"{k}: {m}")
+
+
 @pytest.mark.parametrize("name", ["enc_t3", "dec_t3f2"])
 def test_module_untied_path_matches_reference(golden_dir, name):
     """Untie the Linears (same values): the per-pair path must give the same answer."""

@@ -78,6 +78,9 @@ def test_st_entry_matches_composition(encoder, vdt):
                                       gv2.data_ptr(), vd, goff2.data_ptr(), M * L * P * 2, glogit2.data_ptr(), M * L * P,
                                       0, gref2.data_ptr())
     _lib.check(rc, "snipper_st_msda_backward")
+    # the encoder shape must run the owner-computes kernels (the ones the training step runs), the decoder shape the
+    # atomic D=48 kernel
+    assert _lib.last_variant() == ("d48_owner" if encoder else "d48_lp12"), _lib.last_variant()
     # (float atomics of the far taps are unordered: float32 sums differ in the last bits, a bf16 result by one ulp)
     rtol = 1e-5 if vdt == torch.float32 else 2 ** -7
     for a, b in ((gv2, g_value), (goff2, g_off), (glogit2, g_logit), (gref2, g_ref)):

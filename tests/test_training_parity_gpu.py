@@ -1,0 +1,91 @@
+"""End-to-end training parity on the GPU (``-m gpu``): K optimisation steps of a reduced Snipper model
+
+    arm "bf16"      the bench configuration: bf16 autocast, HIP kernels, bf16 weight shadows (snipper_amd/shadow.py),
+                    flat parameters + fused AdamW (snipper_amd/flat_params.py)
+    arm "hip_fp32"  float32, HIP kernels, flat parameters
+    arm "ref"       float32, the reference's ``use_pytorch_deform=1`` formulation, per-parameter AdamW, no autocast
+
+from the same initial weights on the same batches must follow the same loss trajectory.  This is the test that would
+have caught the stale-weight-shadow bug of round 1 (fused AdamW does not bump ``p._version``: every shadowed layer kept
+multiplying by the weights of step 0, and nothing compared a trained trajectory with the float32 path).
+"""
+import os
+import sys
+from types import SimpleNamespace
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+STEPS = 6
+
+
+def _args(use_pytorch_deform):
+    return SimpleNamespace(hidden_dim=384, enc_layers=2, dec_layers=2, frames=2, future_frames=0, batch=2,
+                           height=192, width=256, use_pytorch_deform=int(use_pytorch_deform))
+
+
+def _train(arm):
+    import bench
+    from snipper_amd.criterion import build_criterion
+    from snipper_amd.model import build_model
+    a = _args(arm == "ref")
+    margs = bench.model_args(a)
+    margs.dropout = 0.0                         # the arms must not differ by their random streams
+    torch.manual_seed(42)
+    model = build_model(margs).to(DEV).to(memory_format=torch.channels_last)
+    model.train()
+    amp = arm == "bf16"
+    flatp = None
+    if arm != "ref":
+        from snipper_amd.flat_params import FlatParameters
+        g_main, g_backbone, g_slow = bench.optimizer_groups(list(model.named_parameters()))
+        flatp = FlatParameters([g_main, g_slow, g_backbone])
+    opt = bench.build_optimizer(list(model.named_parameters()), flat=flatp)
+    criterion = build_criterion(bench.criterion_args(a)).to(DEV)
+    batches = bench.make_batches(a, torch.device(DEV), 2, seed=1000)
+    params = [p for p in model.parameters() if p.requires_grad]
+    losses = []
+    for i in range(STEPS):
+        imgs, tgt = batches[i % 2]
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+            out, _ = model(list(imgs))
+        ls, _ = criterion(out, tgt["targets"])
+        loss = criterion.weighted_sum(ls)
+        if flatp is not None:
+            flatp.drop_param_grads()
+        else:
+            opt.zero_grad(set_to_none=True)
+        loss.backward()
+        if flatp is not None:
+            flatp.pack()
+            torch.nn.utils.clip_grad_norm_(flatp.leaves, 0.1)
+        else:
+            torch.nn.utils.clip_grad_norm_(params, 0.1)
+        opt.step()
+        if flatp is not None:
+            flatp.after_step()
+        losses.append(float(loss.detach()))
+    first_conv = float(model.backbone[0].body.layer2[0].conv1.weight.detach().float().norm())
+    return losses, first_conv
+
+
+def test_loss_trajectories_agree():
+    res = {arm: _train(arm) for arm in ("ref", "hip_fp32", "bf16")}
+    for arm, (ls, _) in res.items():
+        print(f"[training parity] {arm:9s} " + " ".join(f"{v:.3f}" for v in ls))
+    ref = res["ref"][0]
+    assert all(torch.isfinite(torch.tensor(v)) for v in ref)
+    assert min(ref[2:]) < ref[0], "the float32 reference trajectory does not descend: the test would prove nothing"
+    for v, r in zip(res["hip_fp32"][0], ref):        # float32 kernels: same trajectory (Hungarian ties aside)
+        assert abs(v - r) <= 0.01 * abs(r), (res["hip_fp32"][0], ref)
+    for v, r in zip(res["bf16"][0], ref):            # bf16 dense layers + shadows: within bf16 accuracy of it
+        assert abs(v - r) <= 0.08 * abs(r), (res["bf16"][0], ref)
+    # the trained weights moved by the same amount (a stale shadow shows up here as well)
+    for arm in ("hip_fp32", "bf16"):
+        assert abs(res[arm][1] - res["ref"][1]) <= 1e-3 * res["ref"][1]
