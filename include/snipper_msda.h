@@ -14,7 +14,9 @@
  * and exposes them to Python as MultiScaleDeformableAttention.ms_deform_attn_forward /
  * ms_deform_attn_backward (models/ops/src/vision.cpp:13-16, ms_deform_attn.h:20-62).
  * snipper_msda_forward_* / snipper_msda_backward_* replace those two launchers
- * one for one (same pointers, same sizes, same order; the stream comes first).
+ * one for one (same pointers, same sizes, same order; the stream comes first);
+ * snipper_msda_forward_ex / _backward_ex are the same calls with the dtype as an
+ * argument plus two optional inputs (a host copy of the level shapes, a config).
  *
  * Conventions
  *   - every data pointer is a DEVICE pointer to a contiguous row-major array;
@@ -49,7 +51,7 @@
 extern "C" {
 #endif
 
-#define SNIPPER_MSDA_ABI_VERSION 1
+#define SNIPPER_MSDA_ABI_VERSION 2
 
 enum {
   SNIPPER_OK = 0,
@@ -62,17 +64,46 @@ enum {
 int snipper_msda_abi_version(void);
 /* Human-readable text for a code returned by any entry point (static storage). */
 const char *snipper_msda_strerror(int code);
-/* Name of the kernel variant the last forward / backward call on this thread
- * dispatched to ("generic", "d48", ...); for tests and profiles. */
+/* Name of the kernel variant the last forward / backward call of this process dispatched to ("generic", "d48_lp12",
+ * "d48_patch", "d48_owner", ...): a diagnostic for tests and profiles, never an input of any computation. */
 const char *snipper_msda_last_variant(void);
-/* Kernel-variant policy for tests and benchmarks: 0 = auto (tuned kernels where eligible),
- * 1 = generic kernels only.  Process-wide; returns 0 or SNIPPER_E_UNSUPPORTED. */
-int snipper_msda_set_policy(int policy);   /* 2 = tuned kernels but never the owner-computes backward */
-/* Tuning knobs (tests / benchmarks): "owner_enable" (0/1, default 1: owner-computes backward when
- * a host copy of the shapes and a workspace are supplied), "near_radius" (pixels,
- * default 6), "owner_tile_edge_big" / "_mid" / "_small" (tile edge, a power of two <= 16, for levels of > 4096 /
- * > 1024 / fewer pixels; default 16 / 8 / 4), "owner_debug" (timing ablations; wrong results when != 0). */
-int snipper_msda_set_param(const char *name, double value);
+
+/* The library keeps NO tuning state: everything that can change which kernels run travels in this struct, passed by the
+ * caller with every call of the *_ex entry points (NULL = the defaults).  Safe under concurrent callers (DDP's reducer
+ * thread, the autograd engine's thread). */
+typedef struct snipper_msda_config {
+  int32_t struct_bytes;   /* sizeof(snipper_msda_config), checked                                                    */
+  int32_t policy;         /* 0 auto; 1 generic kernels only; 2 tuned D=48 kernels but never the encoder-shape ones     */
+  float near_radius;      /* owner-computes backward: a sample within this many pixels of its anchor is "near" (6)     */
+  float window_halo;      /* LDS-staged window = a query block's anchor range +- this many pixels (5)                  */
+  int32_t tile_edge[3];   /* grad_value tile edge (power of two <= 16) for levels of > 4096 / > 1024 / fewer pixels    */
+  int32_t reserved[5];    /* must be 0 ([0] != 0 selects timing ablations of the encoder-shape kernels: WRONG results)  */
+} snipper_msda_config;
+void snipper_msda_config_init(snipper_msda_config *cfg);     /* fills in the defaults */
+
+/* General entry points.  dtype codes: 0 = float32, 1 = bfloat16 (raw bits), 2 = float64.
+ *   value_dtype 0: loc / attn float32; out_dtype 0, or 1 = bfloat16 ROWS written by the kernel (D == 48 only, else
+ *                  SNIPPER_E_UNSUPPORTED: the caller casts) -- under bf16 autocast the consumer of `out` (the output
+ *                  projection) and the producer of grad_out hold bf16 anyway; every other array and all arithmetic stay f32;
+ *   value_dtype 1: loc / attn float32, out bfloat16, gradients float32;   value_dtype 2: everything float64.
+ *   host_shapes  : the SAME [L,2] (H,W) values as `shapes`, readable by the HOST, or NULL when unknown.  With D == 48,
+ *                  P == 4, L <= 4 and Lq == S == sum(H*W) -- the encoder's self-attention, whose queries are the pixels of
+ *                  the L maps in level-major raster order -- they enable the encoder-shape kernels
+ *                  (csrc/msda_d48_patch.cuh): value neighbourhoods staged in LDS for the gathers, grad_value summed per
+ *                  tile by owner workgroups instead of per tap by HBM float atomics.  The result is the same function of
+ *                  the inputs for ANY locations; only the speed depends on how local they are.
+ *   workspace    : backward only; device scratch of at least snipper_msda_backward_ex_workspace_bytes(...) bytes (0 when
+ *                  the encoder-shape path would not be taken: then NULL is fine).  The library never allocates. */
+int snipper_msda_forward_ex(void *stream, const snipper_msda_config *cfg, const int64_t *host_shapes, const void *value,
+                            int value_dtype, const int64_t *shapes, const int64_t *level_start, const void *loc,
+                            const void *attn, int N, int S, int M, int D, int L, int Lq, int P, void *out, int out_dtype);
+long long snipper_msda_backward_ex_workspace_bytes(const snipper_msda_config *cfg, const int64_t *host_shapes,
+                                                   int value_dtype, int N, int S, int M, int D, int L, int Lq, int P);
+int snipper_msda_backward_ex(void *stream, const snipper_msda_config *cfg, const int64_t *host_shapes, void *workspace,
+                             long long workspace_bytes, const void *grad_out, int grad_out_dtype, const void *value,
+                             int value_dtype, const int64_t *shapes, const int64_t *level_start, const void *loc,
+                             const void *attn, int N, int S, int M, int D, int L, int Lq, int P, void *grad_value,
+                             void *grad_loc, void *grad_attn);
 
 /* ---- core op: replaces ms_deformable_im2col_cuda (.cuh:923-954) ------------------ */
 int snipper_msda_forward_f32(void *stream, const float *value, const int64_t *shapes,
@@ -94,43 +125,6 @@ int snipper_msda_backward_f32(void *stream, const float *grad_out, const float *
                               const float *loc, const float *attn,
                               int N, int S, int M, int D, int L, int Lq, int P,
                               float *grad_value, float *grad_loc, float *grad_attn);
-/* Owner-computes backward (csrc/msda_d48_owner.cuh); "owner_enable" = 0 switches it off.
- * Same contract as snipper_msda_backward_f32 plus
- *   host_shapes : the SAME [L,2] (H,W) values as `shapes`, readable by the host (NULL = unknown);
- *   workspace   : device scratch of at least snipper_msda_backward_workspace_bytes(...) bytes
- *                 (the library never allocates); contents are overwritten.
- * With D == 48, P == 4, L <= 4 and Lq == S == sum(H*W) -- the encoder's self-attention, whose queries
- * are the pixels of the L maps in level-major raster order -- grad_value is summed per tile by owner
- * workgroups instead of per tap by HBM float atomics.  The result is the same function of the inputs
- * for ANY locations; only the speed depends on how local they are.  Whenever the shape, the knobs or
- * the workspace do not qualify, the call is exactly snipper_msda_backward_f32.
- * snipper_msda_backward_workspace_bytes returns 0 when the fast path would not be taken. */
-/* bfloat16 rows at the op's two activation interfaces, float32 everything else (value, loc, attn, all gradients,
- * all arithmetic).  Under bf16 autocast the producer of grad_out (the data gradient of the output projection) and the
- * consumer of out (the output projection itself) hold bf16 anyway; taking / writing bf16 here is exact with respect
- * to that pipeline and saves two cast passes and half of the row traffic.  D == 48 kernels only: any other shape
- * returns SNIPPER_E_UNSUPPORTED (the caller casts and uses the float32 entry points).
- *   snipper_msda_forward_f32_bf16out    : as snipper_msda_forward_f32, out [N,Lq,M*D] bfloat16
- *   snipper_msda_backward_ws_f32_bf16in : as snipper_msda_backward_ws_f32, grad_out [N,Lq,M*D] bfloat16
- *                                         (host_shapes / workspace may be NULL / 0: atomic kernel) */
-int snipper_msda_forward_f32_bf16out(void *stream, const float *value, const int64_t *shapes,
-                                     const int64_t *level_start, const float *loc, const float *attn,
-                                     int N, int S, int M, int D, int L, int Lq, int P, uint16_t *out);
-int snipper_msda_backward_ws_f32_bf16in(void *stream, const uint16_t *grad_out, const float *value,
-                                        const int64_t *shapes, const int64_t *level_start,
-                                        const int64_t *host_shapes, void *workspace, long long workspace_bytes,
-                                        const float *loc, const float *attn,
-                                        int N, int S, int M, int D, int L, int Lq, int P,
-                                        float *grad_value, float *grad_loc, float *grad_attn);
-
-long long snipper_msda_backward_workspace_bytes(int N, int S, int M, int D, int L, int Lq, int P,
-                                                const int64_t *host_shapes);
-int snipper_msda_backward_ws_f32(void *stream, const float *grad_out, const float *value,
-                                 const int64_t *shapes, const int64_t *level_start,
-                                 const int64_t *host_shapes, void *workspace, long long workspace_bytes,
-                                 const float *loc, const float *attn,
-                                 int N, int S, int M, int D, int L, int Lq, int P,
-                                 float *grad_value, float *grad_loc, float *grad_attn);
 int snipper_msda_backward_f64(void *stream, const double *grad_out, const double *value,
                               const int64_t *shapes, const int64_t *level_start,
                               const double *loc, const double *attn,

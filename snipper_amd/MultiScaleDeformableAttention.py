@@ -104,13 +104,31 @@ class _Timed:
         return False
 
 
+_DT = {torch.float32: 0, torch.bfloat16: 1, torch.float64: 2}
+
+
+def _cfg_ptr(config):
+    cfg = config if config is not None else _lib.active_config()
+    return ctypes.byref(cfg) if cfg is not None else None
+
+
+def _host_shapes_ptr(host_shapes, L):
+    if host_shapes is None or len(host_shapes) != L:
+        return None, None
+    hs = (ctypes.c_int64 * (2 * L))(*[int(v) for hw in host_shapes for v in hw])
+    return hs, ctypes.cast(hs, ctypes.c_void_p)
+
+
 def ms_deform_attn_forward(value: torch.Tensor, spatial_shapes: torch.Tensor,
                            level_start_index: torch.Tensor, sampling_loc: torch.Tensor,
-                           attn_weight: torch.Tensor, im2col_step: int, out_bf16: bool = False) -> torch.Tensor:
+                           attn_weight: torch.Tensor, im2col_step: int, out_bf16: bool = False,
+                           host_shapes=None, config=None) -> torch.Tensor:
     """-> Tensor[N, Lq, M*D]   (ms_deform_attn_cuda.cu:20-80)
 
-    ``out_bf16`` (extension): float32 ``value``, output rows written as bfloat16 by the kernel (exactly the float32
-    result rounded once); shapes without a bf16-row kernel get the float32 result cast here."""
+    Extensions (all optional): ``out_bf16`` -- float32 ``value``, output rows written as bfloat16 by the kernel (exactly
+    the float32 result rounded once; shapes without a bf16-row kernel get the float32 result cast here);
+    ``host_shapes`` -- the values of ``spatial_shapes`` as a host list [(H, W), ...], which lets the library run its
+    encoder-shape kernels (include/snipper_msda.h) without a device-to-host copy; ``config`` -- a ``_lib.Config``."""
     _check_common([("value", value), ("spatial_shapes", spatial_shapes),
                    ("level_start_index", level_start_index), ("sampling_loc", sampling_loc),
                    ("attn_weight", attn_weight)], value, spatial_shapes, level_start_index, im2col_step)
@@ -119,37 +137,33 @@ def ms_deform_attn_forward(value: torch.Tensor, spatial_shapes: torch.Tensor,
              f"sampling_loc/attn_weight must be {cd} for {value.dtype} value")
     N, S, M, D, L, Lq, P = _dims(value, spatial_shapes, sampling_loc, attn_weight)
     lib = _lib.load()
+    rows16 = out_bf16 and value.dtype == torch.float32
     dims = dict(N=N, S=S, M=M, D=D, L=L, Lq=Lq, P=P, esize=value.element_size(),
-                row_esize=2 if (out_bf16 and value.dtype == torch.float32) else value.element_size())
-    if out_bf16 and value.dtype == torch.float32:
-        out = torch.empty((N, Lq, M * D), dtype=torch.bfloat16, device=value.device)
+                row_esize=2 if rows16 else value.element_size())
+    _keep, hs_p = _host_shapes_ptr(host_shapes, L)
+    for out_dtype in ((torch.bfloat16, value.dtype) if rows16 else (value.dtype,)):
+        out = torch.empty((N, Lq, M * D), dtype=out_dtype, device=value.device)
         with _lib.device_guard(value.device), _Timed("fwd", dims, value.device):
-            rc = lib.snipper_msda_forward_f32_bf16out(
-                _stream(value.device), value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
-                sampling_loc.data_ptr(), attn_weight.data_ptr(), N, S, M, D, L, Lq, P, out.data_ptr())
-        if rc != _lib.E_UNSUPPORTED:
-            _lib.check(rc, "ms_deform_attn_forward")
-            return out
-    out = torch.empty((N, Lq, M * D), dtype=value.dtype, device=value.device)
-    fn = getattr(lib, "snipper_msda_forward_" + _SUFFIX[value.dtype])
-    with _lib.device_guard(value.device), _Timed("fwd", dims, value.device):
-        rc = fn(_stream(value.device), value.data_ptr(), spatial_shapes.data_ptr(),
-                level_start_index.data_ptr(), sampling_loc.data_ptr(), attn_weight.data_ptr(),
-                N, S, M, D, L, Lq, P, out.data_ptr())
-    _lib.check(rc, "ms_deform_attn_forward")
-    return out.to(torch.bfloat16) if (out_bf16 and value.dtype == torch.float32) else out
+            rc = lib.snipper_msda_forward_ex(
+                _stream(value.device), _cfg_ptr(config), hs_p, value.data_ptr(), _DT[value.dtype],
+                spatial_shapes.data_ptr(), level_start_index.data_ptr(), sampling_loc.data_ptr(), attn_weight.data_ptr(),
+                N, S, M, D, L, Lq, P, out.data_ptr(), _DT[out_dtype])
+        if rc == _lib.E_UNSUPPORTED and out_dtype != value.dtype:
+            continue                                      # no bf16-row kernel for this shape: float32, cast below
+        _lib.check(rc, "ms_deform_attn_forward")
+        break
+    return out.to(torch.bfloat16) if (rows16 and out.dtype != torch.bfloat16) else out
 
 
 def ms_deform_attn_backward(value: torch.Tensor, spatial_shapes: torch.Tensor,
                             level_start_index: torch.Tensor, sampling_loc: torch.Tensor,
                             attn_weight: torch.Tensor, grad_output: torch.Tensor,
-                            im2col_step: int, host_shapes=None) -> List[torch.Tensor]:
+                            im2col_step: int, host_shapes=None, config=None) -> List[torch.Tensor]:
     """-> [grad_value, grad_sampling_loc, grad_attn_weight]   (ms_deform_attn_cuda.cu:83-153)
 
-    For bfloat16 ``value`` the returned grad_value is bfloat16 (accumulated in float32).
-    ``host_shapes`` (extension, optional): the values of ``spatial_shapes`` as a host list
-    [(H, W), ...]; lets the library use its owner-computes kernels for the encoder shape
-    (include/snipper_msda.h, snipper_msda_backward_hs_f32) without a device-to-host copy.
+    For bfloat16 ``value`` the returned grad_value is bfloat16 (accumulated in float32).  ``grad_output`` may be bfloat16
+    beside float32 ``value`` (bf16 rows, D == 48).  ``host_shapes`` / ``config``: as for the forward; with the host
+    shapes the encoder shape (Lq == S) takes the owner-computes backward.
     """
     _check_common([("value", value), ("spatial_shapes", spatial_shapes),
                    ("level_start_index", level_start_index), ("sampling_loc", sampling_loc),
@@ -170,36 +184,22 @@ def ms_deform_attn_backward(value: torch.Tensor, spatial_shapes: torch.Tensor,
     lib = _lib.load()
     dims = dict(N=N, S=S, M=M, D=D, L=L, Lq=Lq, P=P, esize=value.element_size(),
                 row_esize=grad_output.element_size())
+    _keep, hs_p = _host_shapes_ptr(host_shapes, L)
+    cfg_p = _cfg_ptr(config)
     with _lib.device_guard(value.device), _Timed("bwd", dims, value.device):
-        ws_bytes, hs_p, rc = 0, None, None
-        if host_shapes is not None and value.dtype == torch.float32 and len(host_shapes) == L:
-            hs = (ctypes.c_int64 * (2 * L))(*[int(v) for hw in host_shapes for v in hw])
-            hs_p = ctypes.cast(hs, ctypes.c_void_p)
-            ws_bytes = lib.snipper_msda_backward_workspace_bytes(N, S, M, D, L, Lq, P, hs_p)
-        if go_bf16:
-            workspace = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=value.device)
-            rc = lib.snipper_msda_backward_ws_f32_bf16in(
-                _stream(value.device), grad_output.data_ptr(), value.data_ptr(), spatial_shapes.data_ptr(),
-                level_start_index.data_ptr(), hs_p if ws_bytes > 0 else None, workspace.data_ptr(), ws_bytes,
-                sampling_loc.data_ptr(), attn_weight.data_ptr(), N, S, M, D, L, Lq, P,
-                grad_value.data_ptr(), grad_loc.data_ptr(), grad_attn.data_ptr())
-            if rc == _lib.E_UNSUPPORTED:                 # no bf16-row kernel for this shape: widen and go on
-                grad_output, rc = grad_output.float(), None
-        if rc is not None:
-            pass
-        elif ws_bytes > 0:
-            workspace = torch.empty(ws_bytes, dtype=torch.uint8, device=value.device)
-            rc = lib.snipper_msda_backward_ws_f32(
-                _stream(value.device), grad_output.data_ptr(), value.data_ptr(), spatial_shapes.data_ptr(),
-                level_start_index.data_ptr(), hs_p, workspace.data_ptr(), ws_bytes, sampling_loc.data_ptr(),
-                attn_weight.data_ptr(), N, S, M, D, L, Lq, P,
-                grad_value.data_ptr(), grad_loc.data_ptr(), grad_attn.data_ptr())
-        else:
-            fn = getattr(lib, "snipper_msda_backward_" + _SUFFIX[value.dtype])
-            rc = fn(_stream(value.device), grad_output.data_ptr(), value.data_ptr(),
-                    spatial_shapes.data_ptr(), level_start_index.data_ptr(), sampling_loc.data_ptr(),
-                    attn_weight.data_ptr(), N, S, M, D, L, Lq, P,
-                    grad_value.data_ptr(), grad_loc.data_ptr(), grad_attn.data_ptr())
+        ws_bytes = lib.snipper_msda_backward_ex_workspace_bytes(cfg_p, hs_p, _DT[value.dtype], N, S, M, D, L, Lq, P) \
+            if hs_p is not None else 0
+        workspace = torch.empty(ws_bytes, dtype=torch.uint8, device=value.device) if ws_bytes > 0 else None
+        for _ in range(2):
+            rc = lib.snipper_msda_backward_ex(
+                _stream(value.device), cfg_p, hs_p, workspace.data_ptr() if workspace is not None else None, ws_bytes,
+                grad_output.data_ptr(), _DT[grad_output.dtype], value.data_ptr(), _DT[value.dtype],
+                spatial_shapes.data_ptr(), level_start_index.data_ptr(), sampling_loc.data_ptr(), attn_weight.data_ptr(),
+                N, S, M, D, L, Lq, P, grad_value.data_ptr(), grad_loc.data_ptr(), grad_attn.data_ptr())
+            if rc == _lib.E_UNSUPPORTED and go_bf16 and grad_output.dtype == torch.bfloat16:
+                grad_output = grad_output.float()        # no bf16-row kernel for this shape: widen and go on
+                continue
+            break
     _lib.check(rc, "ms_deform_attn_backward")
     if grad_value.dtype != value.dtype:
         grad_value = grad_value.to(value.dtype)

@@ -20,12 +20,11 @@ EXPORTS = {
     "snipper_msda_abi_version": ([], c_int),
     "snipper_msda_strerror": ([c_int], c_char_p),
     "snipper_msda_last_variant": ([], c_char_p),
-    "snipper_msda_set_policy": ([c_int], c_int),
-    "snipper_msda_set_param": ([c_char_p, ctypes.c_double], c_int),
-    "snipper_msda_backward_workspace_bytes": ([c_int] * 7 + [c_void_p], ctypes.c_longlong),
-    "snipper_msda_backward_ws_f32": ([c_void_p] * 7 + [ctypes.c_longlong] + [c_void_p] * 2 + [c_int] * 7 + [c_void_p] * 3, c_int),
-    "snipper_msda_backward_ws_f32_bf16in": ([c_void_p] * 7 + [ctypes.c_longlong] + [c_void_p] * 2 + [c_int] * 7 + [c_void_p] * 3, c_int),
-    "snipper_msda_forward_f32_bf16out": (_FWD_ARGS, c_int),
+    "snipper_msda_config_init": ([c_void_p], None),
+    "snipper_msda_forward_ex": ([c_void_p] * 4 + [c_int] + [c_void_p] * 4 + [c_int] * 7 + [c_void_p, c_int], c_int),
+    "snipper_msda_backward_ex_workspace_bytes": ([c_void_p, c_void_p] + [c_int] * 8, c_longlong),
+    "snipper_msda_backward_ex": ([c_void_p] * 4 + [c_longlong, c_void_p, c_int, c_void_p, c_int] + [c_void_p] * 4 +
+                                 [c_int] * 7 + [c_void_p] * 3, c_int),
     "snipper_msda_forward_f32": (_FWD_ARGS, c_int),
     "snipper_msda_forward_f64": (_FWD_ARGS, c_int),
     "snipper_msda_forward_bf16": (_FWD_ARGS, c_int),
@@ -58,7 +57,7 @@ EXPORTS = {
                                       c_size_t], c_int),
     "snipper_conv3x3_bf16": ([c_void_p] * 5 + [c_int] * 7, c_int),
     "snipper_st_msda_forward": ([c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_longlong, c_void_p, c_longlong,
-                                 c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 9 +
+                                 c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 9 +
                                 [c_void_p] * 4 + [c_int], c_int),
     "snipper_st_msda_backward_workspace_bytes": ([c_int] * 8 + [c_void_p], c_size_t),
     "snipper_st_msda_backward": ([c_void_p, c_void_p, c_int] + [c_void_p] * 10 + [c_int] * 9 + [c_void_p, c_size_t,
@@ -80,7 +79,7 @@ EXPORTS = {
     "snipper_relu_dropout_backward_bf16": ([c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, ctypes.c_float], c_int),
 }
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class SnipperLibraryError(RuntimeError):
@@ -163,9 +162,61 @@ def last_variant() -> str:
     return load().snipper_msda_last_variant().decode()
 
 
+class Config(ctypes.Structure):
+    """``snipper_msda_config`` (include/snipper_msda.h).  The library itself keeps no tuning state; the wrappers in
+    MultiScaleDeformableAttention.py pass the caller's Config -- or ``None`` (the library defaults) -- with every call."""
+    _fields_ = [("struct_bytes", ctypes.c_int32), ("policy", ctypes.c_int32), ("near_radius", ctypes.c_float),
+                ("window_halo", ctypes.c_float), ("tile_edge", ctypes.c_int32 * 3), ("reserved", ctypes.c_int32 * 5)]
+
+    @classmethod
+    def defaults(cls) -> "Config":
+        c = cls()
+        load().snipper_msda_config_init(ctypes.byref(c))
+        return c
+
+
+# Test / benchmark hook (Python side only): a Config the wrappers use when the caller passes none.  ``None`` = library
+# defaults, which is what every product path runs with.
+_test_config = None
+
+_KNOBS = {"near_radius": ("near_radius", float), "window_halo": ("window_halo", float),
+          "owner_tile_edge_big": (("tile_edge", 0), int), "owner_tile_edge_mid": (("tile_edge", 1), int),
+          "owner_tile_edge_small": (("tile_edge", 2), int), "debug": (("reserved", 0), int)}
+
+
+def active_config():
+    return _test_config
+
+
+def reset_config() -> None:
+    global _test_config
+    _test_config = None
+
+
+def _ensure_test_config() -> Config:
+    global _test_config
+    if _test_config is None:
+        _test_config = Config.defaults()
+    return _test_config
+
+
 def set_policy(policy: int) -> None:
-    check(load().snipper_msda_set_policy(int(policy)), "snipper_msda_set_policy")
+    """0 auto, 1 generic kernels only, 2 tuned D=48 kernels but never the encoder-shape ones (tests / benchmarks)."""
+    if int(policy) not in (0, 1, 2):
+        raise RuntimeError(f"snipper_msda policy {policy} not supported")
+    _ensure_test_config().policy = int(policy)
 
 
 def set_param(name: str, value: float) -> None:
-    check(load().snipper_msda_set_param(name.encode(), float(value)), f"snipper_msda_set_param({name})")
+    """Tests / benchmarks: change one field of the Python-side test Config ("owner_enable" 0 = policy 2)."""
+    c = _ensure_test_config()
+    if name == "owner_enable":
+        c.policy = 0 if value else 2
+        return
+    if name not in _KNOBS:
+        raise RuntimeError(f"snipper_msda_set_param({name}) failed: no such knob")
+    field, typ = _KNOBS[name]
+    if isinstance(field, tuple):
+        getattr(c, field[0])[field[1]] = typ(value)
+    else:
+        setattr(c, field, typ(value))

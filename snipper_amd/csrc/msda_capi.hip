@@ -22,22 +22,42 @@
 #include "msda_prologue.cuh"
 #include "lsap.cuh"
 #include "msda_d48.cuh"
-#include "msda_d48_owner.cuh"
+#include "msda_d48_patch.cuh"
 #include "msda_generic.cuh"
 
 using namespace snipper;
 
 namespace {
 
-thread_local const char *g_last_variant = "none";
-std::atomic<int> g_policy{0};  // 0 auto, 1 generic only, 2 no owner-computes path
-std::atomic<float> g_near_radius{6.0f};
-std::atomic<int> g_owner_debug{0};
-std::atomic<int> g_owner_chunk{64};
-std::atomic<int> g_wgrad_wgs{512};
-std::atomic<int> g_ln_bwd_blocks{1536};   // 6 workgroups per CU x 256 CUs: one full residency wave at 6 waves/SIMD (1024: +0.2 ms per step)
-std::atomic<int> g_owner_enable{1};   // owner-computes backward for the encoder shape
-std::atomic<int> g_tile_edge[3] = {{16}, {8}, {4}};   // level area > 4096 px / > 1024 px / smaller
+// name of the kernel variant the last core-op call dispatched to: a diagnostic for tests and profiles (the backward
+// runs on the autograd engine's thread, so it is process-wide rather than thread-local; it never influences a result)
+std::atomic<const char *> g_last_variant{"none"};
+
+constexpr int kWgradWgs = 512;          // workgroups of the split-reduction weight gradient (2 per CU; 384 .. 1024 measured)
+constexpr int kLnBwdBlocks = 1536;      // 6 workgroups per CU x 256 CUs: one residency wave of the LayerNorm backward
+
+// the library keeps no tuning state: every knob travels in the caller's snipper_msda_config (NULL = these defaults)
+snipper_msda_config default_config() {
+  snipper_msda_config c{};
+  c.struct_bytes = (int32_t)sizeof(snipper_msda_config);
+  c.policy = 0;
+  c.near_radius = 6.0f;
+  c.window_halo = 5.0f;
+  c.tile_edge[0] = 16; c.tile_edge[1] = 8; c.tile_edge[2] = 4;
+  return c;
+}
+bool config_ok(const snipper_msda_config *cfg) {
+  if (!cfg) return true;
+  if (cfg->struct_bytes != (int32_t)sizeof(snipper_msda_config)) return false;
+  if (cfg->policy < 0 || cfg->policy > 2) return false;
+  if (!(cfg->near_radius >= 0.f && cfg->near_radius <= 64.f) || !(cfg->window_halo >= 0.f && cfg->window_halo <= 64.f)) return false;
+  for (int i = 0; i < 3; ++i) {
+    const int e = cfg->tile_edge[i];
+    if (e < 1 || e > 16 || (e & (e - 1))) return false;
+  }
+  return true;
+}
+snipper_msda_config resolve(const snipper_msda_config *cfg) { return cfg ? *cfg : default_config(); }
 
 int check_dims(int N, int S, int M, int D, int L, int Lq, int P) {
   if (N <= 0 || S <= 0 || M <= 0 || D <= 0 || L <= 0 || Lq <= 0 || P <= 0) return SNIPPER_E_SHAPE;
@@ -109,8 +129,8 @@ int backward_generic(hipStream_t st, const VT *grad_out, const VT *value, const 
 }
 
 // The D=48 kernels address `value` through one raw-buffer descriptor with 32-bit byte offsets.
-template <typename VT> bool d48_eligible(const CoreDims &d) {
-  if (g_policy.load(std::memory_order_relaxed) == 1) return false;
+template <typename VT> bool d48_eligible(const CoreDims &d, int policy = 0) {
+  if (policy == 1) return false;
   if (d.D != kD48 || d.L > kMaxLevelsFast) return false;
   if ((long long)d.N * d.S * d.M * kD48 * (long long)sizeof(VT) >= (1LL << 31)) return false;
   return d.L * d.P <= 64;
@@ -154,9 +174,9 @@ int backward_d48_f32(hipStream_t st, const float *grad_out, const float *value, 
   return launch_status();
 }
 
-// ---- owner-computes path (msda_d48_owner.cuh): needs the level shapes on the HOST and a workspace ----
-bool owner_shape_ok(const CoreDims &d, const int64_t *hs) {
-  if (!hs || !d48_eligible<float>(d) || d.L > kOwnerMaxLevels || d.P != kOwnerP || d.Lq != d.S) return false;
+// ---- encoder-shape kernels (msda_d48_patch.cuh): need the level shapes on the HOST ----
+bool patch_shape_ok(const CoreDims &d, const int64_t *hs, int policy) {
+  if (policy != 0 || !hs || !d48_eligible<float>(d, policy) || d.L > kPatchMaxLevels || d.P != kPatchP || d.Lq != d.S) return false;
   long long sum = 0;
   for (int l = 0; l < d.L; ++l) {
     if (hs[2 * l] <= 0 || hs[2 * l + 1] <= 0) return false;
@@ -165,78 +185,103 @@ bool owner_shape_ok(const CoreDims &d, const int64_t *hs) {
   return sum == d.S && d.S < (1 << 24);
 }
 
-OwnerPlan make_owner_plan(const CoreDims &d, const int64_t *hs) {
-  OwnerPlan p{};
+// Returns false when the geometry does not fit the marks' bounds (then the plain D=48 kernels run).
+bool make_patch_plan(const CoreDims &d, const int64_t *hs, const snipper_msda_config &cfg, PatchPlan *out) {
+  PatchPlan p{};
   p.L = d.L;
-  p.radius = g_near_radius.load(std::memory_order_relaxed);
-  p.debug = g_owner_debug.load(std::memory_order_relaxed);
-  int start = 0, base = 0;
+  p.radius = cfg.near_radius;
+  p.halo = cfg.window_halo;
+  p.debug = cfg.reserved[0];
+  int start = 0, tbase = 0, bbase = 0;
   for (int l = 0; l < d.L; ++l) {
-    OwnerLevel &v = p.lv[l];
+    PatchLevel &v = p.lv[l];
     v.H = (int)hs[2 * l];
     v.W = (int)hs[2 * l + 1];
     v.start = start;
     start += v.H * v.W;
+    v.nbx = (v.W + kPatchB - 1) / kPatchB;
+    v.nby = (v.H + kPatchB - 1) / kPatchB;
+    v.blk_base = bbase;
+    bbase += v.nbx * v.nby;
     const int area = v.H * v.W;
-    const int e = g_tile_edge[area > 4096 ? 0 : (area > 1024 ? 1 : 2)].load(std::memory_order_relaxed);
+    const int e = cfg.tile_edge[area > 4096 ? 0 : (area > 1024 ? 1 : 2)];
     v.shift = e >= 16 ? 4 : (e >= 8 ? 3 : (e >= 4 ? 2 : (e >= 2 ? 1 : 0)));
     const int edge = 1 << v.shift;
     v.ntx = (v.W + edge - 1) / edge;
     v.nty = (v.H + edge - 1) / edge;
-    v.tile_base = base;
-    base += v.ntx * v.nty;
+    v.tile_base = tbase;
+    tbase += v.ntx * v.nty;
   }
-  p.total_tiles = base;
-  // byte-map geometry: bounds of the candidate rectangles (msda_d48_owner.cuh, anchor_range: the span
-  // (edge + 1 + 2R) pixels of level l rescaled to level lq, +2 cells of margin, +2 for rounding)
+  p.nblocks = bbase;
+  p.total_tiles = tbase;
+  // marks geometry: bounds of the candidate block rectangles (patch_tile_cand: the span (edge + 1 + 2R) pixels of
+  // level l rescaled to level lq, +2 cells of margin and +2 for rounding, in blocks of 8 queries, +2 for alignment)
   long long lvl_base = 0;
   for (int l = 0; l < d.L; ++l) {
     const int edge = 1 << p.lv[l].shift;
     int off = 0;
     for (int lq = 0; lq < d.L; ++lq) {
       const double span = (double)edge + 1.0 + 2.0 * p.radius;
-      int rw = (int)(span * p.lv[lq].W / p.lv[l].W) + 5, rh = (int)(span * p.lv[lq].H / p.lv[l].H) + 5;
-      if (rw > p.lv[lq].W) rw = p.lv[lq].W;
-      if (rh > p.lv[lq].H) rh = p.lv[lq].H;
-      p.rw[l][lq] = rw;
-      p.rh[l][lq] = rh;
+      int qw = (int)(span * p.lv[lq].W / p.lv[l].W) + 5, qh = (int)(span * p.lv[lq].H / p.lv[l].H) + 5;
+      int bw = qw / kPatchB + 2, bh = qh / kPatchB + 2;
+      if (bw > p.lv[lq].nbx) bw = p.lv[lq].nbx;
+      if (bh > p.lv[lq].nby) bh = p.lv[lq].nby;
+      p.cbw[l][lq] = bw;
+      p.cbh[l][lq] = bh;
       p.coff[l][lq] = off;
-      off += rw * rh;
+      off += bw * bh;
     }
-    p.tstride[l] = (off + 15) & ~15;
+    if (off > kPatchMaxCand) return false;
+    p.tstride[l] = off;
     p.lvl_base[l] = lvl_base;
-    lvl_base += (long long)p.lv[l].ntx * p.lv[l].nty * p.tstride[l];
+    lvl_base += (long long)p.lv[l].ntx * p.lv[l].nty * off;
   }
-  p.bytes_per_nm = lvl_base;
-  return p;
+  p.words_per_nm = lvl_base;
+  *out = p;
+  return true;
 }
 
-int backward_d48_owner_f32(hipStream_t st, const float *grad_out, const float *value, const float *loc,
-                           const float *attn, CoreDims d, OwnerPlan plan, void *workspace,
-                           float *grad_value, float *grad_loc, float *grad_attn, int go_bf16 = 0) {
-  const long long nm = (long long)d.N * d.M;
-  plan.bitmap = reinterpret_cast<unsigned char *>(workspace);
-  hipError_t e = hipMemsetAsync(plan.bitmap, 0, (size_t)(nm * plan.bytes_per_nm), st);
-  if (e != hipSuccess) return (int)e;
-  // 1) grad_loc / grad_attn, marking of the near samples, HBM atomics for everything not marked
-  constexpr int kRows = kD48Block / 16;
-  const long long rows = (long long)d.N * d.Lq * d.M;
-  const int LP = d.L * d.P;
-  const int nblk = (int)((rows + kRows - 1) / kRows);
-  const int nblk_padded = (nblk + 7) & ~7;
-  const size_t lds = (size_t)kRows * (LP * sizeof(BinRecord) + 16);
-  hipLaunchKernelGGL(msda_bwd_d48_bin_kernel, dim3(nblk_padded), dim3(kD48Block), lds, st, grad_out, value, loc,
-                     attn, d, plan, grad_value, grad_loc, grad_attn, nblk_padded, go_bf16);
-  if (int rc = launch_status()) return rc;
-  // 2) every tile adds what it owns
-  const long long nblk_tiles = ((nm + 7) / 8) * 8 * plan.total_tiles;      // XCD-major grid (see the tile kernel)
-  if (nblk_tiles >= (1LL << 31)) return SNIPPER_E_SHAPE;
-  if (g_owner_chunk.load(std::memory_order_relaxed) == 128)
-    hipLaunchKernelGGL(msda_bwd_d48_tile_kernel<128>, dim3((unsigned)nblk_tiles), dim3(kOwnerBlock), 0, st, grad_out,
-                       loc, attn, d, plan, grad_value, go_bf16);
+int forward_d48_patch(hipStream_t st, const float *value, const float *loc, const float *attn, CoreDims d,
+                      const PatchPlan &plan, void *out, int out_bf16) {
+  const long long nblk = (long long)d.N * plan.nblocks * d.M;
+  const long long nblk_padded = (nblk + 7) & ~7LL;
+  if (nblk_padded >= (1LL << 31)) return SNIPPER_E_SHAPE;
+  g_last_variant = "d48_patch";
+  if (out_bf16)
+    hipLaunchKernelGGL(msda_fwd_d48_patch_kernel<true>, dim3((unsigned)nblk_padded), dim3(kPatchThreads), 0, st, value, loc, attn,
+                       d, plan, out, (int)nblk_padded);
   else
-    hipLaunchKernelGGL(msda_bwd_d48_tile_kernel<64>, dim3((unsigned)nblk_tiles), dim3(kOwnerBlock), 0, st, grad_out,
-                       loc, attn, d, plan, grad_value, go_bf16);
+    hipLaunchKernelGGL(msda_fwd_d48_patch_kernel<false>, dim3((unsigned)nblk_padded), dim3(kPatchThreads), 0, st, value, loc, attn,
+                       d, plan, out, (int)nblk_padded);
+  return launch_status();
+}
+
+int backward_d48_patch(hipStream_t st, const void *grad_out, const float *value, const float *loc, const float *attn,
+                       CoreDims d, PatchPlan plan, void *workspace, float *grad_value, float *grad_loc,
+                       float *grad_attn, int go_bf16) {
+  const long long nm = (long long)d.N * d.M;
+  plan.marks = reinterpret_cast<unsigned long long *>(workspace);
+  hipError_t e = hipMemsetAsync(plan.marks, 0, (size_t)(nm * plan.words_per_nm) * 8, st);
+  if (e != hipSuccess) return (int)e;
+  // 1) query side: grad_loc / grad_attn, marks, HBM atomics for the taps no tile owns
+  const long long nblk = nm * plan.nblocks;
+  const long long nblk_padded = (nblk + 7) & ~7LL;
+  // 2) grad_value side: every tile adds what it owns (XCD-major grid, see the kernel)
+  const long long nblk_tiles = ((nm + 7) / 8) * 8 * plan.total_tiles;
+  if (nblk_padded >= (1LL << 31) || nblk_tiles >= (1LL << 31)) return SNIPPER_E_SHAPE;
+  if (go_bf16) {
+    hipLaunchKernelGGL(msda_bwd_d48_patchbin_kernel<true>, dim3((unsigned)nblk_padded), dim3(kPatchThreads), 0, st, grad_out,
+                       value, loc, attn, d, plan, grad_value, grad_loc, grad_attn, (int)nblk_padded);
+    if (int rc = launch_status()) return rc;
+    hipLaunchKernelGGL((msda_bwd_d48_tile2_kernel<128, true>), dim3((unsigned)nblk_tiles), dim3(kPatchThreads), 0, st, grad_out,
+                       loc, attn, d, plan, grad_value);
+  } else {
+    hipLaunchKernelGGL(msda_bwd_d48_patchbin_kernel<false>, dim3((unsigned)nblk_padded), dim3(kPatchThreads), 0, st, grad_out,
+                       value, loc, attn, d, plan, grad_value, grad_loc, grad_attn, (int)nblk_padded);
+    if (int rc = launch_status()) return rc;
+    hipLaunchKernelGGL((msda_bwd_d48_tile2_kernel<128, false>), dim3((unsigned)nblk_tiles), dim3(kPatchThreads), 0, st, grad_out,
+                       loc, attn, d, plan, grad_value);
+  }
   g_last_variant = "d48_owner";
   return launch_status();
 }
@@ -262,162 +307,138 @@ const char *snipper_msda_strerror(int code) {
   }
 }
 
-const char *snipper_msda_last_variant(void) { return g_last_variant; }
+const char *snipper_msda_last_variant(void) { return g_last_variant.load(); }
 
-int snipper_msda_set_policy(int policy) {
-  if (policy < 0 || policy > 2) return SNIPPER_E_UNSUPPORTED;
-  g_policy.store(policy, std::memory_order_relaxed);
-  return SNIPPER_OK;
+void snipper_msda_config_init(snipper_msda_config *cfg) {
+  if (cfg) *cfg = default_config();
 }
 
-int snipper_msda_set_param(const char *name, double v) {
-  if (!name) return SNIPPER_E_NULL;
-  const std::string_view k(name);
-  auto edge_ok = [&](int e) { return e >= 1 && e * e <= kOwnerMaxTilePx && (e & (e - 1)) == 0; };
-  if (k == "near_radius") {
-    if (!(v >= 0.0 && v <= 64.0)) return SNIPPER_E_SHAPE;
-    g_near_radius.store((float)v);
-  } else if (k == "owner_tile_edge_big" || k == "owner_tile_edge_mid" || k == "owner_tile_edge_small") {
-    if (!edge_ok((int)v)) return SNIPPER_E_SHAPE;
-    g_tile_edge[k == "owner_tile_edge_big" ? 0 : (k == "owner_tile_edge_mid" ? 1 : 2)].store((int)v);
-  } else if (k == "owner_debug") {
-    g_owner_debug.store((int)v);
-  } else if (k == "owner_chunk") {
-    if (v != 64 && v != 128) return SNIPPER_E_SHAPE;
-    g_owner_chunk.store((int)v);
-  } else if (k == "ln_bwd_blocks") {
-    if (!(v >= 1 && v <= 65536)) return SNIPPER_E_SHAPE;
-    g_ln_bwd_blocks.store((int)v);
-  } else if (k == "wgrad_wgs") {
-    if (!(v >= 1 && v <= 65536)) return SNIPPER_E_SHAPE;
-    g_wgrad_wgs.store((int)v);
-  } else if (k == "owner_enable") {
-    g_owner_enable.store(v != 0.0);
-  } else {
-    return SNIPPER_E_UNSUPPORTED;
-  }
-  return SNIPPER_OK;
-}
-
-#define SNIPPER_CHECK_FWD()                                                              \
-  if (!value || !shapes || !level_start || !loc || !attn || !out) return SNIPPER_E_NULL; \
-  if (int rc = check_dims(N, S, M, D, L, Lq, P)) return rc;                              \
-  const CoreDims d{N, S, M, D, L, Lq, P};                                                \
+// ---- the general entry points: dtype codes 0 = float32, 1 = bfloat16, 2 = float64 ----
+int snipper_msda_forward_ex(void *stream, const snipper_msda_config *cfg, const int64_t *host_shapes, const void *value,
+                            int value_dtype, const int64_t *shapes, const int64_t *level_start, const void *loc,
+                            const void *attn, int N, int S, int M, int D, int L, int Lq, int P, void *out, int out_dtype) {
+  if (!value || !shapes || !level_start || !loc || !attn || !out) return SNIPPER_E_NULL;
+  if (int rc = check_dims(N, S, M, D, L, Lq, P)) return rc;
+  if (!config_ok(cfg)) return SNIPPER_E_SHAPE;
+  const snipper_msda_config c = resolve(cfg);
+  const CoreDims d{N, S, M, D, L, Lq, P};
   hipStream_t st = (hipStream_t)stream;
+  if (value_dtype == 2) {
+    if (out_dtype != 2) return SNIPPER_E_UNSUPPORTED;
+    return forward_generic<double, double>(st, (const double *)value, shapes, level_start, (const double *)loc,
+                                           (const double *)attn, d, (double *)out);
+  }
+  if (value_dtype == 1) {
+    if (out_dtype != 1) return SNIPPER_E_UNSUPPORTED;
+    if (d48_eligible<uint16_t>(d, c.policy))
+      return forward_d48<uint16_t>(st, (const uint16_t *)value, shapes, level_start, (const float *)loc, (const float *)attn, d,
+                                   (uint16_t *)out);
+    return forward_generic<uint16_t, float>(st, (const uint16_t *)value, shapes, level_start, (const float *)loc,
+                                            (const float *)attn, d, (uint16_t *)out);
+  }
+  if (value_dtype != 0 || (out_dtype != 0 && out_dtype != 1)) return SNIPPER_E_UNSUPPORTED;
+  const float *v = (const float *)value, *lo = (const float *)loc, *at = (const float *)attn;
+  if (patch_shape_ok(d, host_shapes, c.policy)) {
+    PatchPlan plan;
+    if (make_patch_plan(d, host_shapes, c, &plan)) return forward_d48_patch(st, v, lo, at, d, plan, out, out_dtype == 1);
+  }
+  if (d48_eligible<float>(d, c.policy)) return forward_d48<float>(st, v, shapes, level_start, lo, at, d, (float *)out, out_dtype == 1);
+  if (out_dtype == 1) return SNIPPER_E_UNSUPPORTED;       // bf16 rows: D = 48 kernels only (the caller casts)
+  return forward_generic<float, float>(st, v, shapes, level_start, lo, at, d, (float *)out);
+}
 
+long long snipper_msda_backward_ex_workspace_bytes(const snipper_msda_config *cfg, const int64_t *host_shapes,
+                                                   int value_dtype, int N, int S, int M, int D, int L, int Lq, int P) {
+  const CoreDims d{N, S, M, D, L, Lq, P};
+  if (check_dims(N, S, M, D, L, Lq, P) != SNIPPER_OK || !config_ok(cfg) || value_dtype != 0) return 0;
+  const snipper_msda_config c = resolve(cfg);
+  if (!patch_shape_ok(d, host_shapes, c.policy)) return 0;
+  PatchPlan plan;
+  if (!make_patch_plan(d, host_shapes, c, &plan)) return 0;
+  return (long long)N * M * plan.words_per_nm * 8;
+}
+
+int snipper_msda_backward_ex(void *stream, const snipper_msda_config *cfg, const int64_t *host_shapes, void *workspace,
+                             long long workspace_bytes, const void *grad_out, int grad_out_dtype, const void *value,
+                             int value_dtype, const int64_t *shapes, const int64_t *level_start, const void *loc,
+                             const void *attn, int N, int S, int M, int D, int L, int Lq, int P, void *grad_value,
+                             void *grad_loc, void *grad_attn) {
+  if (!grad_out || !value || !shapes || !level_start || !loc || !attn || !grad_value || !grad_loc || !grad_attn)
+    return SNIPPER_E_NULL;
+  if (int rc = check_dims(N, S, M, D, L, Lq, P)) return rc;
+  if (!config_ok(cfg)) return SNIPPER_E_SHAPE;
+  const snipper_msda_config c = resolve(cfg);
+  const CoreDims d{N, S, M, D, L, Lq, P};
+  hipStream_t st = (hipStream_t)stream;
+  if (value_dtype == 2) {
+    if (grad_out_dtype != 2) return SNIPPER_E_UNSUPPORTED;
+    if (int rc = zero_grad_value(st, (double *)grad_value, d)) return rc;
+    return backward_generic<double, double, double>(st, (const double *)grad_out, (const double *)value, shapes, level_start,
+                                                    (const double *)loc, (const double *)attn, d, (double *)grad_value,
+                                                    (double *)grad_loc, (double *)grad_attn);
+  }
+  if (value_dtype == 1) {        // bf16 value / grad_out, gradients accumulate in float32
+    if (grad_out_dtype != 1) return SNIPPER_E_UNSUPPORTED;
+    if (int rc = zero_grad_value(st, (float *)grad_value, d)) return rc;
+    return backward_generic<uint16_t, float, float>(st, (const uint16_t *)grad_out, (const uint16_t *)value, shapes,
+                                                    level_start, (const float *)loc, (const float *)attn, d,
+                                                    (float *)grad_value, (float *)grad_loc, (float *)grad_attn);
+  }
+  if (value_dtype != 0 || (grad_out_dtype != 0 && grad_out_dtype != 1)) return SNIPPER_E_UNSUPPORTED;
+  const float *v = (const float *)value, *lo = (const float *)loc, *at = (const float *)attn;
+  float *gv = (float *)grad_value, *gl = (float *)grad_loc, *ga = (float *)grad_attn;
+  const int go_bf16 = grad_out_dtype == 1;
+  if (go_bf16 && !d48_eligible<float>(d, c.policy)) return SNIPPER_E_UNSUPPORTED;   // bf16 rows: D = 48 kernels only
+  if (int rc = zero_grad_value(st, gv, d)) return rc;
+  if (workspace && patch_shape_ok(d, host_shapes, c.policy)) {
+    PatchPlan plan;
+    if (make_patch_plan(d, host_shapes, c, &plan) && workspace_bytes >= (long long)N * M * plan.words_per_nm * 8)
+      return backward_d48_patch(st, grad_out, v, lo, at, d, plan, workspace, gv, gl, ga, go_bf16);
+  }
+  if (d48_eligible<float>(d, c.policy))
+    return backward_d48_f32(st, (const float *)grad_out, v, shapes, level_start, lo, at, d, gv, gl, ga, go_bf16);
+  return backward_generic<float, float, float>(st, (const float *)grad_out, v, shapes, level_start, lo, at, d, gv, gl, ga);
+}
+
+// ---- the reference launchers' one-for-one replacements (default configuration, level shapes on the device only) ----
 int snipper_msda_forward_f32(void *stream, const float *value, const int64_t *shapes,
                              const int64_t *level_start, const float *loc, const float *attn,
                              int N, int S, int M, int D, int L, int Lq, int P, float *out) {
-  SNIPPER_CHECK_FWD();
-  if (d48_eligible<float>(d)) return forward_d48<float>(st, value, shapes, level_start, loc, attn, d, out);
-  return forward_generic<float, float>(st, value, shapes, level_start, loc, attn, d, out);
+  return snipper_msda_forward_ex(stream, nullptr, nullptr, value, 0, shapes, level_start, loc, attn, N, S, M, D, L, Lq, P, out, 0);
 }
-
-int snipper_msda_forward_f32_bf16out(void *stream, const float *value, const int64_t *shapes,
-                                     const int64_t *level_start, const float *loc, const float *attn,
-                                     int N, int S, int M, int D, int L, int Lq, int P, uint16_t *out) {
-  SNIPPER_CHECK_FWD();
-  if (!d48_eligible<float>(d)) return SNIPPER_E_UNSUPPORTED;
-  return forward_d48<float>(st, value, shapes, level_start, loc, attn, d, reinterpret_cast<float *>(out), 1);
-}
-
 int snipper_msda_forward_f64(void *stream, const double *value, const int64_t *shapes,
                              const int64_t *level_start, const double *loc, const double *attn,
                              int N, int S, int M, int D, int L, int Lq, int P, double *out) {
-  SNIPPER_CHECK_FWD();
-  return forward_generic<double, double>(st, value, shapes, level_start, loc, attn, d, out);
+  return snipper_msda_forward_ex(stream, nullptr, nullptr, value, 2, shapes, level_start, loc, attn, N, S, M, D, L, Lq, P, out, 2);
 }
-
 int snipper_msda_forward_bf16(void *stream, const uint16_t *value, const int64_t *shapes,
                               const int64_t *level_start, const float *loc, const float *attn,
                               int N, int S, int M, int D, int L, int Lq, int P, uint16_t *out) {
-  SNIPPER_CHECK_FWD();
-  if (d48_eligible<uint16_t>(d)) return forward_d48<uint16_t>(st, value, shapes, level_start, loc, attn, d, out);
-  return forward_generic<uint16_t, float>(st, value, shapes, level_start, loc, attn, d, out);
+  return snipper_msda_forward_ex(stream, nullptr, nullptr, value, 1, shapes, level_start, loc, attn, N, S, M, D, L, Lq, P, out, 1);
 }
-
-#define SNIPPER_CHECK_BWD()                                                                   \
-  if (!grad_out || !value || !shapes || !level_start || !loc || !attn || !grad_value ||      \
-      !grad_loc || !grad_attn)                                                                \
-    return SNIPPER_E_NULL;                                                                    \
-  if (int rc = check_dims(N, S, M, D, L, Lq, P)) return rc;                                   \
-  const CoreDims d{N, S, M, D, L, Lq, P};                                                     \
-  hipStream_t st = (hipStream_t)stream;
-
 int snipper_msda_backward_f32(void *stream, const float *grad_out, const float *value,
                               const int64_t *shapes, const int64_t *level_start,
                               const float *loc, const float *attn,
                               int N, int S, int M, int D, int L, int Lq, int P,
                               float *grad_value, float *grad_loc, float *grad_attn) {
-  SNIPPER_CHECK_BWD();
-  if (int rc = zero_grad_value(st, grad_value, d)) return rc;
-  if (d48_eligible<float>(d))
-    return backward_d48_f32(st, grad_out, value, shapes, level_start, loc, attn, d, grad_value, grad_loc, grad_attn);
-  return backward_generic<float, float, float>(st, grad_out, value, shapes, level_start, loc, attn, d, grad_value, grad_loc, grad_attn);
+  return snipper_msda_backward_ex(stream, nullptr, nullptr, nullptr, 0, grad_out, 0, value, 0, shapes, level_start, loc, attn,
+                                  N, S, M, D, L, Lq, P, grad_value, grad_loc, grad_attn);
 }
-
-long long snipper_msda_backward_workspace_bytes(int N, int S, int M, int D, int L, int Lq, int P,
-                                                const int64_t *host_shapes) {
-  const CoreDims d{N, S, M, D, L, Lq, P};
-  if (check_dims(N, S, M, D, L, Lq, P) != SNIPPER_OK) return 0;
-  if (g_policy.load(std::memory_order_relaxed) != 0 || !g_owner_enable.load(std::memory_order_relaxed)) return 0;
-  if (!owner_shape_ok(d, host_shapes)) return 0;
-  const OwnerPlan p = make_owner_plan(d, host_shapes);
-  return (long long)N * M * p.bytes_per_nm;
-}
-
-int snipper_msda_backward_ws_f32(void *stream, const float *grad_out, const float *value,
-                                 const int64_t *shapes, const int64_t *level_start,
-                                 const int64_t *host_shapes, void *workspace, long long workspace_bytes,
-                                 const float *loc, const float *attn,
-                                 int N, int S, int M, int D, int L, int Lq, int P,
-                                 float *grad_value, float *grad_loc, float *grad_attn) {
-  SNIPPER_CHECK_BWD();
-  const long long need = snipper_msda_backward_workspace_bytes(N, S, M, D, L, Lq, P, host_shapes);
-  if (need > 0 && workspace && workspace_bytes >= need) {
-    if (int rc = zero_grad_value(st, grad_value, d)) return rc;
-    return backward_d48_owner_f32(st, grad_out, value, loc, attn, d, make_owner_plan(d, host_shapes), workspace,
-                                  grad_value, grad_loc, grad_attn);
-  }
-  return snipper_msda_backward_f32(stream, grad_out, value, shapes, level_start, loc, attn, N, S, M, D, L, Lq, P,
-                                   grad_value, grad_loc, grad_attn);
-}
-
-int snipper_msda_backward_ws_f32_bf16in(void *stream, const uint16_t *grad_out, const float *value,
-                                        const int64_t *shapes, const int64_t *level_start,
-                                        const int64_t *host_shapes, void *workspace, long long workspace_bytes,
-                                        const float *loc, const float *attn,
-                                        int N, int S, int M, int D, int L, int Lq, int P,
-                                        float *grad_value, float *grad_loc, float *grad_attn) {
-  SNIPPER_CHECK_BWD();
-  if (!d48_eligible<float>(d)) return SNIPPER_E_UNSUPPORTED;
-  const float *go = reinterpret_cast<const float *>(grad_out);
-  if (int rc = zero_grad_value(st, grad_value, d)) return rc;
-  const long long need = host_shapes ? snipper_msda_backward_workspace_bytes(N, S, M, D, L, Lq, P, host_shapes) : 0;
-  if (need > 0 && workspace && workspace_bytes >= need)
-    return backward_d48_owner_f32(st, go, value, loc, attn, d, make_owner_plan(d, host_shapes), workspace,
-                                  grad_value, grad_loc, grad_attn, 1);
-  return backward_d48_f32(st, go, value, shapes, level_start, loc, attn, d, grad_value, grad_loc, grad_attn, 1);
-}
-
 int snipper_msda_backward_f64(void *stream, const double *grad_out, const double *value,
                               const int64_t *shapes, const int64_t *level_start,
                               const double *loc, const double *attn,
                               int N, int S, int M, int D, int L, int Lq, int P,
                               double *grad_value, double *grad_loc, double *grad_attn) {
-  SNIPPER_CHECK_BWD();
-  if (int rc = zero_grad_value(st, grad_value, d)) return rc;
-  return backward_generic<double, double, double>(st, grad_out, value, shapes, level_start, loc, attn, d, grad_value, grad_loc, grad_attn);
+  return snipper_msda_backward_ex(stream, nullptr, nullptr, nullptr, 0, grad_out, 2, value, 2, shapes, level_start, loc, attn,
+                                  N, S, M, D, L, Lq, P, grad_value, grad_loc, grad_attn);
 }
-
 int snipper_msda_backward_bf16(void *stream, const uint16_t *grad_out, const uint16_t *value,
                                const int64_t *shapes, const int64_t *level_start,
                                const float *loc, const float *attn,
                                int N, int S, int M, int D, int L, int Lq, int P,
                                float *grad_value, float *grad_loc, float *grad_attn) {
-  SNIPPER_CHECK_BWD();
-  if (int rc = zero_grad_value(st, grad_value, d)) return rc;
-  return backward_generic<uint16_t, float, float>(st, grad_out, value, shapes, level_start, loc, attn, d, grad_value, grad_loc, grad_attn);
+  return snipper_msda_backward_ex(stream, nullptr, nullptr, nullptr, 0, grad_out, 1, value, 1, shapes, level_start, loc, attn,
+                                  N, S, M, D, L, Lq, P, grad_value, grad_loc, grad_attn);
 }
 
 int snipper_linear_bf16(void *stream, const uint16_t *X, long long ldx, const uint16_t *W,
@@ -471,7 +492,7 @@ WgradPlan wgrad_plan(int M, int N, int Kc) {
   p.tiles_n = (N + kWgTile - 1) / kWgTile;
   p.tiles_k = (Kc + kWgTile - 1) / kWgTile;
   const int tiles = p.tiles_n * p.tiles_k;
-  int s0 = std::max(1, g_wgrad_wgs.load(std::memory_order_relaxed) / tiles);
+  int s0 = std::max(1, kWgradWgs / tiles);
   if (s0 >= 8) s0 = (s0 + 7) / 8 * 8;
   s0 = std::min(s0, std::max(1, M / kWgRows));
   p.rows = (M + s0 - 1) / s0;
@@ -505,7 +526,7 @@ int snipper_wgrad_bf16(void *stream, const uint16_t *G, long long ldg, const uin
 }
 
 namespace {
-inline int ln_bwd_blocks(int rows) { return std::max(1, std::min((rows + 3) / 4, g_ln_bwd_blocks.load(std::memory_order_relaxed))); }
+inline int ln_bwd_blocks(int rows) { return std::max(1, std::min((rows + 3) / 4, kLnBwdBlocks)); }
 inline bool ln_dt_ok(int dt) { return dt == 0 || dt == 1; }
 }  // namespace
 
@@ -786,7 +807,7 @@ inline void st_transpose_mix(const float *mix, int T1, int T2, float *out) {
 int snipper_st_msda_forward(void *stream, const void *value, int value_dtype, const unsigned char *mask, const float *mix,
                             const void *off, long long off_ld, const void *logit, long long logit_ld, int ql_dtype,
                             const float *ref, const float *inv_w, const float *inv_h,
-                            const int64_t *shapes, const int64_t *level_start,
+                            const int64_t *shapes, const int64_t *level_start, const int64_t *host_shapes,
                             int N, int T1, int T2, int S, int M, int D, int L, int Lq, int P,
                             float *vbar, float *loc, float *prob, void *out, int out_bf16) {
   if (!value || !mix || !off || !logit || !ref || !shapes || !level_start || !vbar || !loc || !prob || !out)
@@ -797,17 +818,15 @@ int snipper_st_msda_forward(void *stream, const void *value, int value_dtype, co
   if (int rc = snipper_msda_prologue_forward(stream, off, off_ld, logit, logit_ld, ql_dtype, ref, inv_w, inv_h, rows, M, L,
                                              P, loc, prob))
     return rc;
-  if (out_bf16)
-    return snipper_msda_forward_f32_bf16out(stream, vbar, shapes, level_start, loc, prob, N * T1, S, M, D, L, Lq, P,
-                                            (uint16_t *)out);
-  return snipper_msda_forward_f32(stream, vbar, shapes, level_start, loc, prob, N * T1, S, M, D, L, Lq, P, (float *)out);
+  return snipper_msda_forward_ex(stream, nullptr, host_shapes, vbar, 0, shapes, level_start, loc, prob, N * T1, S, M, D, L, Lq, P,
+                                 out, out_bf16 ? 1 : 0);
 }
 
 size_t snipper_st_msda_backward_workspace_bytes(int N, int T1, int S, int M, int D, int L, int Lq, int P,
                                                 const int64_t *host_shapes) {
   const size_t gv = (size_t)N * T1 * S * M * D * sizeof(float);
   const size_t gl = (size_t)N * T1 * Lq * M * L * P * 3 * sizeof(float);
-  const long long owner = host_shapes ? snipper_msda_backward_workspace_bytes(N * T1, S, M, D, L, Lq, P, host_shapes) : 0;
+  const long long owner = host_shapes ? snipper_msda_backward_ex_workspace_bytes(nullptr, host_shapes, 0, N * T1, S, M, D, L, Lq, P) : 0;
   return gv + gl + (size_t)((owner + 15) / 16 * 16);
 }
 
@@ -829,16 +848,10 @@ int snipper_st_msda_backward(void *stream, const void *grad_out, int grad_out_bf
   float *g_loc = (float *)((char *)workspace + gv_bytes);
   float *g_prob = g_loc + 2 * rows_lp;
   void *owner_ws = (char *)workspace + gv_bytes + rows_lp * 3 * sizeof(float);
-  const long long owner_bytes = host_shapes ? snipper_msda_backward_workspace_bytes(N * T1, S, M, D, L, Lq, P, host_shapes) : 0;
-  int rc;
-  if (grad_out_bf16)
-    rc = snipper_msda_backward_ws_f32_bf16in(stream, (const uint16_t *)grad_out, vbar, shapes, level_start,
-                                             owner_bytes > 0 ? host_shapes : nullptr, owner_ws, owner_bytes, loc, prob,
-                                             N * T1, S, M, D, L, Lq, P, g_vbar, g_loc, g_prob);
-  else
-    rc = snipper_msda_backward_ws_f32(stream, (const float *)grad_out, vbar, shapes, level_start,
-                                      owner_bytes > 0 ? host_shapes : nullptr, owner_ws, owner_bytes, loc, prob,
-                                      N * T1, S, M, D, L, Lq, P, g_vbar, g_loc, g_prob);
+  const long long owner_bytes = host_shapes ? snipper_msda_backward_ex_workspace_bytes(nullptr, host_shapes, 0, N * T1, S, M, D, L, Lq, P) : 0;
+  int rc = snipper_msda_backward_ex(stream, nullptr, owner_bytes > 0 ? host_shapes : nullptr, owner_bytes > 0 ? owner_ws : nullptr,
+                                    owner_bytes, grad_out, grad_out_bf16 ? 1 : 0, vbar, 0, shapes, level_start, loc, prob,
+                                    N * T1, S, M, D, L, Lq, P, g_vbar, g_loc, g_prob);
   if (rc) return rc;
   const long long rows = (long long)N * T1 * Lq * M;
   rc = snipper_msda_prologue_backward(stream, g_loc, g_prob, prob, inv_w, inv_h, rows, M, L, P, grad_off, grad_off_ld,

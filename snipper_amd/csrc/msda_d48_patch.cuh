@@ -1,0 +1,850 @@
+// msda_d48_patch.cuh -- encoder-shape kernels (D = 48, f32 value, P = 4, L <= 4, Lq == S, level shapes known on the
+// host) built around LDS-staged value neighbourhoods.  gfx950 only.
+//
+// Why: in the encoder the queries ARE the pixels of the L feature maps, and a query samples every level near its own
+// position rescaled to that level (the "anchor").  The query-per-lane-group kernels of msda_d48.cuh fetch every tap
+// row (192 B) through the texture path: 5.8 GB of tap rows per launch at N = 8, i.e. ~21 TB/s of L2->CU traffic for
+// 273 MB of algorithmic bytes -- bound by the 64 B/clk/CU vector-memory path, not by HBM (rocprof round 1: forward
+// 272 us, grad_loc/grad_attn kernel 414 us per launch).  Here one workgroup takes an 8 x 8 block of queries of one
+// level for one (batch, head); for each sampled level it stages the block's value neighbourhood (anchor range +- halo
+// pixels, <= 336 pixels x 192 B) in LDS once -- by LDS-DMA, no VGPR round trip -- and the 64 rows then read their
+// taps from LDS at 256 B/clk/CU (ds_read_b128 + ds_read_b64 per tap row).  Every staged byte is re-used ~3-6 times.
+// Taps outside the window ("far": large offsets, or (query level, sampled level) pairs whose neighbourhood does not
+// fit) keep the global path inside the same kernel, so results never depend on locality -- only speed does.
+// Semantics restated from /root/reference/models/ops/src/cuda/ms_deform_im2col_cuda.cuh:33-159, 237-299 (forward)
+// and :513-616 (backward, D = 48 branch); no code is shared with it.
+//
+// Three kernels:
+//   msda_fwd_d48_patch_kernel     forward.
+//   msda_bwd_d48_patchbin_kernel  backward, query side: grad_loc / grad_attn for every sample (same staged gather,
+//                                 dot products instead of sums), marks -- one 64-bit word per (grad_value tile, query
+//                                 block): which queries of the block have a near tap in the tile -- and HBM float atomics
+//                                 for the taps no tile owns.
+//   msda_bwd_d48_tile2_kernel     backward, grad_value side (owner computes): one workgroup per (n, m, tile) expands the
+//                                 marks of its candidate blocks into a hit list, re-decodes the hits' samples, sorts
+//                                 the owned taps by pixel (per-wave counters + a prefix: a fixed order, so grad_value is
+//                                 bit-reproducible), accumulates every pixel in registers reading the grad_out rows
+//                                 straight from L2, and adds the tile to grad_value with plain stores.
+// "near" and "owned" are pure functions of (query index, sample location, plan), evaluated with the pinned arithmetic
+// of msda_d48.cuh by both backward kernels: owned + unowned is a partition of the taps for ANY input.
+#pragma once
+#include "msda_d48.cuh"
+
+namespace snipper {
+
+constexpr int kPatchMaxLevels = 4;
+constexpr int kPatchP = 4;
+constexpr int kPatchB = 8;                       // query block edge
+constexpr int kPatchThreads = 256;               // = 64 rows x 4 points (decode) = 32 rows x 8 lanes (gather)
+constexpr int kPatchWinPx = 336;                 // LDS window capacity in pixels
+constexpr int kPatchRowBytes = kD48 * 4;         // 192
+constexpr int kPatchWinBytes = kPatchWinPx * kPatchRowBytes;
+constexpr int kPatchMaxTiles = 64;               // tiles one (block, level) may mark
+constexpr int kPatchMaxCand = 256;               // candidate blocks per tile (one per thread of the tile kernel)
+
+struct PatchLevel {
+  int H, W, start;          // level geometry
+  int nbx, nby, blk_base;   // 8 x 8 query blocks of this level, index of its first block
+  int shift, ntx, nty, tile_base;   // grad_value tiles (edge = 1 << shift)
+};
+
+struct PatchPlan {
+  PatchLevel lv[kPatchMaxLevels];
+  // marks: tile T of sampled level l has, for every query level lq, a rectangle of candidate blocks (the blocks holding
+  // queries whose near taps can reach T: a pure function of T, l, lq, radius).  Block (by, bx) of that rectangle owns the
+  // word  lvl_base[l] + T * tstride[l] + coff[l][lq] + (by - by0) * cbw[l][lq] + (bx - bx0)  of its (n, m) slab.
+  int cbw[kPatchMaxLevels][kPatchMaxLevels], cbh[kPatchMaxLevels][kPatchMaxLevels];
+  int coff[kPatchMaxLevels][kPatchMaxLevels];
+  int tstride[kPatchMaxLevels];
+  long long lvl_base[kPatchMaxLevels];
+  long long words_per_nm;
+  unsigned long long *marks;    // [N*M][words_per_nm], zeroed per backward call
+  int L, nblocks, total_tiles;
+  float halo;      // LDS window = anchor range of the block +- halo pixels
+  float radius;    // a sample is "near" when |pixel - anchor| <= radius on both axes
+  int debug;       // timing ablations (config.reserved[0]; results are WRONG when != 0): 1 no staging, 2 no gather /
+                   // accumulate, 4 no decode, 8 skeleton only
+};
+
+struct PatchBlock { int n, m, lq, qy0, qx0, bh, bw; };
+struct PatchWindow { int x0, y0, w, h; };            // w == 0: nothing staged for this (block, level)
+
+struct PatchRec {   // 48 B per (row, point) of the level in flight
+  f32x4 w;          // forward: bilinear x attention weight per tap.  backward: lh, lw, a, bits (far k | need k << 4)
+  u32x4 lds;        // byte offset of each tap's row inside the LDS window, or of the zero row
+  u32x4 g;          // byte offset of the tap's row in value / grad_value, or kOobOffset
+};
+
+__device__ __forceinline__ bool patch_block(const PatchPlan &p, const CoreDims &d, int nblk_padded, PatchBlock &b) {
+  const long long id = xcd_band_block(nblk_padded);          // (n, block, m), m fastest: the 8 heads of a block share lines
+  const long long total = (long long)d.N * p.nblocks * d.M;
+  if (id >= total) return false;
+  b.m = (int)(id % d.M);
+  const long long t = id / d.M;
+  const int blk = (int)(t % p.nblocks);
+  b.n = (int)(t / p.nblocks);
+  int lq = 0;
+  for (int i = 1; i < p.L; ++i) lq = (blk >= p.lv[i].blk_base) ? i : lq;
+  const int r = blk - p.lv[lq].blk_base;
+  const int by = r / p.lv[lq].nbx, bx = r - by * p.lv[lq].nbx;
+  b.lq = lq;
+  b.qy0 = by * kPatchB;
+  b.qx0 = bx * kPatchB;
+  b.bh = min(kPatchB, p.lv[lq].H - b.qy0);
+  b.bw = min(kPatchB, p.lv[lq].W - b.qx0);
+  return true;
+}
+
+__device__ __forceinline__ PatchWindow patch_window(const PatchPlan &p, const PatchBlock &b, int l) {
+  const PatchLevel &s = p.lv[l], &q = p.lv[b.lq];
+  const float ax0 = anchor_coord(b.qx0, s.W, q.W), ax1 = anchor_coord(b.qx0 + b.bw - 1, s.W, q.W);
+  const float ay0 = anchor_coord(b.qy0, s.H, q.H), ay1 = anchor_coord(b.qy0 + b.bh - 1, s.H, q.H);
+  const int x0 = max(0, (int)floorf(ax0 - p.halo)), x1 = min(s.W - 1, (int)ceilf(ax1 + p.halo));
+  const int y0 = max(0, (int)floorf(ay0 - p.halo)), y1 = min(s.H - 1, (int)ceilf(ay1 + p.halo));
+  PatchWindow w{x0, y0, x1 - x0 + 1, y1 - y0 + 1};
+  if (w.w <= 0 || w.h <= 0 || w.w * w.h > kPatchWinPx) w.w = w.h = 0;
+  return w;
+}
+
+// Stage the window's head rows into LDS in window order (pixel-major, 192 B each) with LDS-DMA: granule g (16 B) of
+// the image is piece g % 12 of pixel g / 12; one wave-instruction writes 64 consecutive granules (1 KiB), each lane
+// supplying its own source address.  Completion: the caller's __syncthreads() (hipcc puts vmcnt(0) in front of it).
+__device__ __forceinline__ void patch_stage(const float *value, const CoreDims &d, const PatchBlock &b,
+                                            const PatchLevel &s, const PatchWindow &w, unsigned char *win) {
+  const int G = w.w * w.h * (kPatchRowBytes / 16);
+  const unsigned px_stride = (unsigned)d.M * kPatchRowBytes;
+  const unsigned char *base = reinterpret_cast<const unsigned char *>(value) +
+                              ((size_t)b.n * d.S + s.start) * px_stride + (size_t)b.m * kPatchRowBytes;
+  const int tid = threadIdx.x;
+  for (int g0 = 0; g0 < G; g0 += kPatchThreads) {
+    const int g = g0 + tid;
+    if (g < G) {
+      const int px = g / 12, piece = g - px * 12;
+      const int wy = px / w.w, wx = px - wy * w.w;
+      const unsigned char *src = base + (size_t)((w.y0 + wy) * s.W + w.x0 + wx) * px_stride + piece * 16;
+      unsigned char *dst = win + (size_t)(g - (tid & 63)) * 16;      // wave-uniform; the hardware adds lane * 16
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                       (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+    }
+  }
+}
+
+// all-reduce over the 8 lanes of a row group (DPP: quad xor 1, quad xor 2, mirror within the half row)
+__device__ __forceinline__ float row8_sum(float v) {
+  v += dpp_f32<0xB1>(v);
+  v += dpp_f32<0x4E>(v);
+  v += dpp_f32<0x141>(v);
+  return v;
+}
+
+// lane j of an 8-lane row group owns channels 4j..4j+3 (one 16-B access) and 32+2j, 33+2j (one 8-B access)
+struct Row6 { f32x4 a; float2 b; };
+__device__ __forceinline__ Row6 lds_row(const unsigned char *win, unsigned off, int j) {
+  Row6 r;
+  r.a = *reinterpret_cast<const f32x4 *>(win + off + 16 * j);
+  r.b = *reinterpret_cast<const float2 *>(win + off + 128 + 8 * j);
+  return r;
+}
+__device__ __forceinline__ Row6 buf_row(__amdgpu_buffer_rsrc_t rsrc, unsigned off, int j) {
+  Row6 r;
+  const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 16u * j, 0, 0);
+  typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+  const u32x2 b = __builtin_amdgcn_raw_buffer_load_b64(rsrc, off + 128u + 8u * j, 0, 0);
+  r.a.x = __uint_as_float(a.x); r.a.y = __uint_as_float(a.y); r.a.z = __uint_as_float(a.z); r.a.w = __uint_as_float(a.w);
+  r.b.x = __uint_as_float(b.x); r.b.y = __uint_as_float(b.y);
+  return r;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Forward
+// ------------------------------------------------------------------------------------------------------------------
+template <bool OUT_BF16>
+__global__ __launch_bounds__(kPatchThreads) void msda_fwd_d48_patch_kernel(
+    const float *__restrict__ value, const float *__restrict__ loc, const float *__restrict__ attn, CoreDims d,
+    PatchPlan plan, void *__restrict__ out, int nblk_padded) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[kPatchWinBytes + kPatchRowBytes + kPatchThreads * sizeof(PatchRec)];
+  unsigned char *win = smem;                                   // window, then the zero row, then the records
+  PatchRec *recs = reinterpret_cast<PatchRec *>(smem + kPatchWinBytes + kPatchRowBytes);
+  PatchBlock b;
+  if (!patch_block(plan, d, nblk_padded, b)) return;
+  const int tid = threadIdx.x;
+  if (tid < kD48) reinterpret_cast<float *>(smem + kPatchWinBytes)[tid] = 0.f;
+  const PatchLevel lvq = plan.lv[b.lq];
+  const int LP = d.L * kPatchP;
+  // decode role: thread = (row r, point p)
+  const int rd = tid >> 2, pd = tid & 3;
+  const int rdy = rd >> 3, rdx = rd & 7;
+  const bool rd_ok = rdy < b.bh && rdx < b.bw;
+  const int qd = rd_ok ? lvq.start + (b.qy0 + rdy) * lvq.W + b.qx0 + rdx : lvq.start;
+  const long long rowd = ((long long)b.n * d.Lq + qd) * d.M + b.m;
+  const unsigned px_stride = (unsigned)d.M * kPatchRowBytes;
+  const unsigned gbase = (unsigned)(b.n * d.S) * px_stride + (unsigned)b.m * kPatchRowBytes;
+  // gather role: thread = (row rg + 32 * pass, lane j)
+  const int j = tid & 7, rg = tid >> 3;
+  const unsigned value_bytes = (unsigned)((size_t)d.N * d.S * d.M * kPatchRowBytes);
+  const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(value), 0, (int)value_bytes, 0x00020000);
+  float acc[2][6];
+#pragma unroll
+  for (int ps = 0; ps < 2; ++ps)
+#pragma unroll
+    for (int c = 0; c < 6; ++c) acc[ps][c] = 0.f;
+  // this thread's sample of EVERY level up front: one exposed HBM latency per workgroup instead of one per level
+  float2 xy_l[kPatchMaxLevels];
+  float a_l[kPatchMaxLevels];
+#pragma unroll
+  for (int l = 0; l < kPatchMaxLevels; ++l) {
+    xy_l[l] = make_float2(0.f, 0.f); a_l[l] = 0.f;
+    if (l < plan.L) {
+      const long long li = rowd * LP + l * kPatchP + pd;
+      xy_l[l] = *reinterpret_cast<const float2 *>(loc + 2 * li);
+      a_l[l] = attn[li];
+    }
+  }
+
+#pragma unroll
+  for (int l = 0; l < kPatchMaxLevels; ++l) {
+    if (l >= plan.L) break;
+    const PatchLevel lvl = plan.lv[l];
+    const PatchWindow w = patch_window(plan, b, l);
+    if (!(plan.debug & 1)) patch_stage(value, d, b, lvl, w, win);
+    {
+      const float2 xy = xy_l[l];
+      const float a_in = a_l[l];
+      const float y = xy.y * (float)lvl.H - 0.5f, x = xy.x * (float)lvl.W - 0.5f;
+      const bool inside = rd_ok && (y > -1.f) && (x > -1.f) && (y < (float)lvl.H) && (x < (float)lvl.W);
+      const float yf = floorf(y), xf = floorf(x);
+      const int y0 = (int)yf, x0 = (int)xf;
+      const float lh = inside ? y - yf : 0.f, lw = inside ? x - xf : 0.f;
+      const float hh = 1.f - lh, hw = 1.f - lw;
+      const float a = inside ? a_in : 0.f;
+      PatchRec r;
+      r.w.x = hh * hw * a; r.w.y = hh * lw * a; r.w.z = lh * hw * a; r.w.w = lh * lw * a;
+      unsigned lo[4], go[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int ty = y0 + (k >> 1), tx = x0 + (k & 1);
+        const bool in_map = inside && ty >= 0 && ty <= lvl.H - 1 && tx >= 0 && tx <= lvl.W - 1;
+        const int wy = ty - w.y0, wx = tx - w.x0;
+        const bool in_win = in_map && wy >= 0 && wy < w.h && wx >= 0 && wx < w.w;
+        lo[k] = in_win ? (unsigned)(wy * w.w + wx) * kPatchRowBytes : (unsigned)kPatchWinBytes;
+        go[k] = (in_map && !in_win) ? gbase + (unsigned)(lvl.start + ty * lvl.W + tx) * px_stride : kOobOffset;
+      }
+      r.lds.x = lo[0]; r.lds.y = lo[1]; r.lds.z = lo[2]; r.lds.w = lo[3];
+      r.g.x = go[0]; r.g.y = go[1]; r.g.z = go[2]; r.g.w = go[3];
+      recs[tid] = r;
+    }
+    __syncthreads();     // window landed (vmcnt(0) precedes the barrier), records visible
+    if (!(plan.debug & 2))
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+      const PatchRec *mine = recs + (ps * 32 + rg) * kPatchP;
+      unsigned far = 0u;
+#pragma unroll
+      for (int p = 0; p < kPatchP; ++p) {
+        const PatchRec r = mine[p];
+        const Row6 v0 = lds_row(win, r.lds.x, j), v1 = lds_row(win, r.lds.y, j);
+        const Row6 v2 = lds_row(win, r.lds.z, j), v3 = lds_row(win, r.lds.w, j);
+        far |= (min(min(r.g.x, r.g.y), min(r.g.z, r.g.w)) != kOobOffset) ? (1u << p) : 0u;
+#define SNIPPER_ACC_TAP(W_, V_)                                                                       \
+        acc[ps][0] = fmaf(W_, V_.a.x, acc[ps][0]); acc[ps][1] = fmaf(W_, V_.a.y, acc[ps][1]);        \
+        acc[ps][2] = fmaf(W_, V_.a.z, acc[ps][2]); acc[ps][3] = fmaf(W_, V_.a.w, acc[ps][3]);        \
+        acc[ps][4] = fmaf(W_, V_.b.x, acc[ps][4]); acc[ps][5] = fmaf(W_, V_.b.y, acc[ps][5]);
+        SNIPPER_ACC_TAP(r.w.x, v0) SNIPPER_ACC_TAP(r.w.y, v1) SNIPPER_ACC_TAP(r.w.z, v2) SNIPPER_ACC_TAP(r.w.w, v3)
+      }
+      if (__builtin_amdgcn_ballot_w64(far != 0u) != 0ull) {       // taps outside the window: global path
+#pragma unroll
+        for (int p = 0; p < kPatchP; ++p) {
+          if (__builtin_amdgcn_ballot_w64((far >> p) & 1u) == 0ull) continue;     // (wave-uniform)
+          const PatchRec r = mine[p];
+          const Row6 v0 = buf_row(rsrc, r.g.x, j), v1 = buf_row(rsrc, r.g.y, j);
+          const Row6 v2 = buf_row(rsrc, r.g.z, j), v3 = buf_row(rsrc, r.g.w, j);
+          SNIPPER_ACC_TAP(r.w.x, v0) SNIPPER_ACC_TAP(r.w.y, v1) SNIPPER_ACC_TAP(r.w.z, v2) SNIPPER_ACC_TAP(r.w.w, v3)
+        }
+      }
+    }
+    __syncthreads();     // before the window / the records are overwritten
+  }
+#pragma unroll
+  for (int ps = 0; ps < 2; ++ps) {
+    const int r = ps * 32 + rg, ry = r >> 3, rx = r & 7;
+    if (ry < b.bh && rx < b.bw) {
+      const int q = lvq.start + (b.qy0 + ry) * lvq.W + b.qx0 + rx;
+      const size_t row = ((size_t)b.n * d.Lq + q) * d.M + b.m;
+      if constexpr (OUT_BF16) {
+        uint16_t *o = reinterpret_cast<uint16_t *>(out) + row * kD48;
+        uint2 pa;
+        pa.x = (unsigned)f32_to_bf16_bits(acc[ps][0]) | ((unsigned)f32_to_bf16_bits(acc[ps][1]) << 16);
+        pa.y = (unsigned)f32_to_bf16_bits(acc[ps][2]) | ((unsigned)f32_to_bf16_bits(acc[ps][3]) << 16);
+        *reinterpret_cast<uint2 *>(o + 4 * j) = pa;
+        *reinterpret_cast<unsigned *>(o + 32 + 2 * j) =
+            (unsigned)f32_to_bf16_bits(acc[ps][4]) | ((unsigned)f32_to_bf16_bits(acc[ps][5]) << 16);
+      } else {
+        float *o = reinterpret_cast<float *>(out) + row * kD48;
+        f32x4 pa; pa.x = acc[ps][0]; pa.y = acc[ps][1]; pa.z = acc[ps][2]; pa.w = acc[ps][3];
+        *reinterpret_cast<f32x4 *>(o + 4 * j) = pa;
+        *reinterpret_cast<float2 *>(o + 32 + 2 * j) = make_float2(acc[ps][4], acc[ps][5]);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Marks geometry shared by the two backward kernels
+// ------------------------------------------------------------------------------------------------------------------
+// conservative index range of the queries of an axis with n_lq cells whose anchor, expressed in the sampled level
+// (n_l cells), can fall in [lo_px, hi_px]
+__device__ __forceinline__ void patch_anchor_range(float lo_px, float hi_px, int n_l, int n_lq, int &i0, int &i1) {
+  const float inv = __fdiv_rn((float)n_lq, (float)n_l);
+  i0 = (int)floorf(__fmaf_rn(lo_px + 0.5f, inv, -0.5f)) - 1;
+  i1 = (int)ceilf(__fmaf_rn(hi_px + 0.5f, inv, -0.5f)) + 1;
+  i0 = i0 < 0 ? 0 : i0;
+  i1 = i1 > n_lq - 1 ? n_lq - 1 : i1;
+}
+// candidate BLOCK rectangle of query level lq for the tile with origin (ty0, tx0), edge `edge`, of level l: a near tap
+// in the tile has |sample - anchor| <= R and tap in [sample - 1, sample + 1], so the anchor lies in [t0 - 1 - R, t0 + edge + R]
+__device__ __forceinline__ void patch_tile_cand(const PatchPlan &p, int l, int lq, int ty0, int tx0, int edge,
+                                                int &bx0, int &bx1, int &by0, int &by1) {
+  int qx0, qx1, qy0, qy1;
+  patch_anchor_range((float)(tx0 - 1) - p.radius, (float)(tx0 + edge) + p.radius, p.lv[l].W, p.lv[lq].W, qx0, qx1);
+  patch_anchor_range((float)(ty0 - 1) - p.radius, (float)(ty0 + edge) + p.radius, p.lv[l].H, p.lv[lq].H, qy0, qy1);
+  bx0 = qx0 >> 3; bx1 = qx1 >> 3; by0 = qy0 >> 3; by1 = qy1 >> 3;
+}
+// tiles of level l that near taps of block b can touch (anchor range +- (R + 1), clipped to the map)
+struct PatchTileBox { int tx0, ty0, ntx, nty; };
+__device__ __forceinline__ PatchTileBox patch_tile_box(const PatchPlan &p, const PatchBlock &b, int l) {
+  const PatchLevel &s = p.lv[l], &q = p.lv[b.lq];
+  const float ax0 = anchor_coord(b.qx0, s.W, q.W), ax1 = anchor_coord(b.qx0 + b.bw - 1, s.W, q.W);
+  const float ay0 = anchor_coord(b.qy0, s.H, q.H), ay1 = anchor_coord(b.qy0 + b.bh - 1, s.H, q.H);
+  const int x0 = max(0, (int)floorf(ax0 - p.radius) - 1), x1 = min(s.W - 1, (int)ceilf(ax1 + p.radius) + 1);
+  const int y0 = max(0, (int)floorf(ay0 - p.radius) - 1), y1 = min(s.H - 1, (int)ceilf(ay1 + p.radius) + 1);
+  PatchTileBox t;
+  t.tx0 = x0 >> s.shift; t.ty0 = y0 >> s.shift;
+  t.ntx = x1 >= x0 ? (x1 >> s.shift) - t.tx0 + 1 : 0;
+  t.nty = y1 >= y0 ? (y1 >> s.shift) - t.ty0 + 1 : 0;
+  return t;
+}
+// word of block b in the marks of tile (tyi, txi) of level l, or -1 when the block is not among the tile's candidates
+__device__ __forceinline__ long long patch_slot(const PatchPlan &p, const PatchBlock &b, int M, int l, int tyi, int txi) {
+  const PatchLevel &s = p.lv[l];
+  int bx0, bx1, by0, by1;
+  patch_tile_cand(p, l, b.lq, tyi << s.shift, txi << s.shift, 1 << s.shift, bx0, bx1, by0, by1);
+  const int bx = b.qx0 >> 3, by = b.qy0 >> 3;
+  const int dx = bx - bx0, dy = by - by0;
+  if (dx < 0 || dy < 0 || bx > bx1 || by > by1 || dx >= p.cbw[l][b.lq] || dy >= p.cbh[l][b.lq]) return -1;
+  return ((long long)b.n * M + b.m) * p.words_per_nm + p.lvl_base[l] + (long long)(tyi * s.ntx + txi) * p.tstride[l] +
+         p.coff[l][b.lq] + dy * p.cbw[l][b.lq] + dx;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Backward, query side
+// ------------------------------------------------------------------------------------------------------------------
+template <bool GO_BF16>
+__global__ __launch_bounds__(kPatchThreads) void msda_bwd_d48_patchbin_kernel(
+    const void *__restrict__ grad_out, const float *__restrict__ value, const float *__restrict__ loc,
+    const float *__restrict__ attn, CoreDims d, PatchPlan plan, float *__restrict__ grad_value,
+    float *__restrict__ grad_loc, float *__restrict__ grad_attn, int nblk_padded) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[kPatchWinBytes + kPatchRowBytes + kPatchThreads * sizeof(PatchRec) +
+                                                           2 * kPatchMaxTiles * 16];
+  unsigned char *win = smem;
+  PatchRec *recs = reinterpret_cast<PatchRec *>(smem + kPatchWinBytes + kPatchRowBytes);
+  unsigned long long *s_mask = reinterpret_cast<unsigned long long *>(recs + kPatchThreads);   // [2][kPatchMaxTiles]
+  long long *s_slot = reinterpret_cast<long long *>(s_mask + 2 * kPatchMaxTiles);              // [2][kPatchMaxTiles]
+  PatchBlock b;
+  if (!patch_block(plan, d, nblk_padded, b)) return;
+  const int tid = threadIdx.x;
+  if (tid < kD48) reinterpret_cast<float *>(smem + kPatchWinBytes)[tid] = 0.f;
+  const PatchLevel lvq = plan.lv[b.lq];
+  const int LP = d.L * kPatchP;
+  const int rd = tid >> 2, pd = tid & 3;
+  const int rdy = rd >> 3, rdx = rd & 7;
+  const bool rd_ok = rdy < b.bh && rdx < b.bw;
+  const int qd = rd_ok ? lvq.start + (b.qy0 + rdy) * lvq.W + b.qx0 + rdx : lvq.start;
+  const long long rowd = ((long long)b.n * d.Lq + qd) * d.M + b.m;
+  const unsigned px_stride = (unsigned)d.M * kPatchRowBytes;
+  const unsigned gbase = (unsigned)(b.n * d.S) * px_stride + (unsigned)b.m * kPatchRowBytes;
+  const int j = tid & 7, rg = tid >> 3;
+  const unsigned value_bytes = (unsigned)((size_t)d.N * d.S * d.M * kPatchRowBytes);
+  const auto vsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(value), 0, (int)value_bytes, 0x00020000);
+  const auto gsrc = __builtin_amdgcn_make_buffer_rsrc(grad_value, 0, (int)value_bytes, 0x00020000);
+
+  // this thread's slices of the two grad_out rows it gathers for (channels 4j..4j+3, 32+2j, 33+2j)
+  float g[2][6];
+  long long rowg[2];
+  bool rg_ok[2];
+#pragma unroll
+  for (int ps = 0; ps < 2; ++ps) {
+    const int r = ps * 32 + rg, ry = r >> 3, rx = r & 7;
+    rg_ok[ps] = ry < b.bh && rx < b.bw;
+    const int q = rg_ok[ps] ? lvq.start + (b.qy0 + ry) * lvq.W + b.qx0 + rx : lvq.start;
+    rowg[ps] = ((long long)b.n * d.Lq + q) * d.M + b.m;
+    if constexpr (GO_BF16) {
+      const uint16_t *gr = reinterpret_cast<const uint16_t *>(grad_out) + rowg[ps] * kD48;
+      const uint2 pa = *reinterpret_cast<const uint2 *>(gr + 4 * j);
+      const unsigned pb = *reinterpret_cast<const unsigned *>(gr + 32 + 2 * j);
+      g[ps][0] = __uint_as_float(pa.x << 16); g[ps][1] = __uint_as_float(pa.x & 0xffff0000u);
+      g[ps][2] = __uint_as_float(pa.y << 16); g[ps][3] = __uint_as_float(pa.y & 0xffff0000u);
+      g[ps][4] = __uint_as_float(pb << 16);   g[ps][5] = __uint_as_float(pb & 0xffff0000u);
+    } else {
+      const float *gr = reinterpret_cast<const float *>(grad_out) + rowg[ps] * kD48;
+      const f32x4 pa = *reinterpret_cast<const f32x4 *>(gr + 4 * j);
+      const float2 pb = *reinterpret_cast<const float2 *>(gr + 32 + 2 * j);
+      g[ps][0] = pa.x; g[ps][1] = pa.y; g[ps][2] = pa.z; g[ps][3] = pa.w; g[ps][4] = pb.x; g[ps][5] = pb.y;
+    }
+    if (!rg_ok[ps]) {
+#pragma unroll
+      for (int c = 0; c < 6; ++c) g[ps][c] = 0.f;
+    }
+  }
+
+  // slots of the first level (later levels: computed one level ahead, behind the gather of the current one)
+  auto fill_slots = [&](int l) {
+    const PatchTileBox tb = patch_tile_box(plan, b, l);
+    const int nt = min(tb.ntx * tb.nty, kPatchMaxTiles);
+    if (tid < kPatchMaxTiles) {
+      long long s = -1;
+      if (tid < nt) {
+        const int tiy = tid / tb.ntx, tix = tid - tiy * tb.ntx;
+        s = patch_slot(plan, b, d.M, l, tb.ty0 + tiy, tb.tx0 + tix);
+      }
+      s_slot[(l & 1) * kPatchMaxTiles + tid] = s;
+      s_mask[(l & 1) * kPatchMaxTiles + tid] = 0ull;
+    }
+  };
+  fill_slots(0);
+  float2 xy_l[kPatchMaxLevels];
+  float a_l[kPatchMaxLevels];
+#pragma unroll
+  for (int l = 0; l < kPatchMaxLevels; ++l) {
+    xy_l[l] = make_float2(0.f, 0.f); a_l[l] = 0.f;
+    if (l < plan.L) {
+      const long long li = rowd * LP + l * kPatchP + pd;
+      xy_l[l] = *reinterpret_cast<const float2 *>(loc + 2 * li);
+      a_l[l] = attn[li];
+    }
+  }
+  __syncthreads();
+
+#pragma unroll
+  for (int l = 0; l < kPatchMaxLevels; ++l) {
+    if (l >= plan.L) break;
+    const PatchLevel lvl = plan.lv[l];
+    const PatchWindow w = patch_window(plan, b, l);
+    const PatchTileBox tb = patch_tile_box(plan, b, l);
+    unsigned long long *mask_l = s_mask + (l & 1) * kPatchMaxTiles;
+    const long long *slot_l = s_slot + (l & 1) * kPatchMaxTiles;
+    if (!(plan.debug & 1)) patch_stage(value, d, b, lvl, w, win);
+    {
+      const float2 xy = xy_l[l];
+      const float a_in = a_l[l];
+      const float y = px_coord(xy.y, lvl.H), x = px_coord(xy.x, lvl.W);
+      const bool inside = rd_ok && (y > -1.f) && (x > -1.f) && (y < (float)lvl.H) && (x < (float)lvl.W);
+      const bool near = inside && near_anchor(x, y, anchor_coord(b.qx0 + rdx, lvl.W, lvq.W),
+                                              anchor_coord(b.qy0 + rdy, lvl.H, lvq.H), plan.radius);
+      const float yf = floorf(y), xf = floorf(x);
+      const int y0 = (int)yf, x0 = (int)xf;
+      PatchRec r;
+      r.w.x = inside ? y - yf : 0.f; r.w.y = inside ? x - xf : 0.f; r.w.z = inside ? a_in : 0.f;
+      unsigned lo[4], go[4], bits = 0u;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int ty = y0 + (k >> 1), tx = x0 + (k & 1);
+        const bool in_map = inside && ty >= 0 && ty <= lvl.H - 1 && tx >= 0 && tx <= lvl.W - 1;
+        const int wy = ty - w.y0, wx = tx - w.x0;
+        const bool in_win = in_map && wy >= 0 && wy < w.h && wx >= 0 && wx < w.w;
+        lo[k] = in_win ? (unsigned)(wy * w.w + wx) * kPatchRowBytes : (unsigned)kPatchWinBytes;
+        go[k] = in_map ? gbase + (unsigned)(lvl.start + ty * lvl.W + tx) * px_stride : kOobOffset;
+        bool owned = false;
+        if (near && in_map) {
+          const int tix = (tx >> lvl.shift) - tb.tx0, tiy = (ty >> lvl.shift) - tb.ty0;
+          if (tix >= 0 && tix < tb.ntx && tiy >= 0 && tiy < tb.nty) {
+            const int ti = tiy * tb.ntx + tix;
+            if (ti < kPatchMaxTiles && slot_l[ti] >= 0) {
+              owned = true;
+              atomicOr(&mask_l[ti], 1ull << rd);
+            }
+          }
+        }
+        bits |= (in_map && !in_win) ? (1u << k) : 0u;           // far: gather from global memory
+        bits |= (in_map && !owned) ? (16u << k) : 0u;           // need: no tile owns the tap -> HBM atomic here
+      }
+      r.w.w = __uint_as_float(bits);
+      r.lds.x = lo[0]; r.lds.y = lo[1]; r.lds.z = lo[2]; r.lds.w = lo[3];
+      r.g.x = go[0]; r.g.y = go[1]; r.g.z = go[2]; r.g.w = go[3];
+      recs[tid] = r;
+    }
+    __syncthreads();     // window landed, records and masks complete
+
+    if (tid < kPatchMaxTiles && slot_l[tid] >= 0 && mask_l[tid] != 0ull) plan.marks[slot_l[tid]] = mask_l[tid];
+    if (l + 1 < plan.L) fill_slots(l + 1);
+
+    if (!(plan.debug & 2))
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+      const PatchRec *mine = recs + (ps * 32 + rg) * kPatchP;
+      unsigned allbits = 0u;
+#pragma unroll
+      for (int p = 0; p < kPatchP; ++p) allbits |= __float_as_uint(mine[p].w.w);
+      const bool any_far = __builtin_amdgcn_ballot_w64((allbits & 15u) != 0u) != 0ull;
+      float keep_a = 0.f, keep_x = 0.f, keep_y = 0.f;
+#pragma unroll
+      for (int p = 0; p < kPatchP; ++p) {
+        const PatchRec r = mine[p];
+        const float lh = r.w.x, lw = r.w.y, a = r.w.z;
+        const unsigned bits = __float_as_uint(r.w.w);
+        const float hh = 1.f - lh, hw = 1.f - lw;
+        const unsigned lo[4] = {r.lds.x, r.lds.y, r.lds.z, r.lds.w};
+        const unsigned go[4] = {r.g.x, r.g.y, r.g.z, r.g.w};
+        float dot[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const Row6 v = lds_row(win, lo[k], j);
+          dot[k] = g[ps][0] * v.a.x + g[ps][1] * v.a.y + g[ps][2] * v.a.z + g[ps][3] * v.a.w + g[ps][4] * v.b.x +
+                   g[ps][5] * v.b.y;
+        }
+        if (any_far && __builtin_amdgcn_ballot_w64((bits & 15u) != 0u) != 0ull) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const Row6 v = buf_row(vsrc, ((bits >> k) & 1u) ? go[k] : kOobOffset, j);
+            dot[k] += g[ps][0] * v.a.x + g[ps][1] * v.a.y + g[ps][2] * v.a.z + g[ps][3] * v.a.w + g[ps][4] * v.b.x +
+                      g[ps][5] * v.b.y;
+          }
+        }
+        float pa = hh * hw * dot[0] + hh * lw * dot[1] + lh * hw * dot[2] + lh * lw * dot[3];
+        float px = hh * (dot[1] - dot[0]) + lh * (dot[3] - dot[2]);
+        float py = hw * (dot[2] - dot[0]) + lw * (dot[3] - dot[1]);
+        pa = row8_sum(pa);
+        px = row8_sum(px) * (a * (float)lvl.W);
+        py = row8_sum(py) * (a * (float)lvl.H);
+        if (j == p) { keep_a = pa; keep_x = px; keep_y = py; }
+      }
+      if (rg_ok[ps] && j < kPatchP) {
+        const long long li = rowg[ps] * LP + l * kPatchP + j;
+        grad_attn[li] = keep_a;
+        *reinterpret_cast<float2 *>(grad_loc + 2 * li) = make_float2(keep_x, keep_y);
+      }
+      // taps no tile owns (sample not near its anchor, or beyond the marks' capacity): the HBM float atomic of
+      // msda_d48.cuh, re-dealt so that the 8 lanes of a row add 32 contiguous bytes per instruction
+      if (__builtin_amdgcn_ballot_w64((allbits & 0xf0u) != 0u) != 0ull) {
+        float ga[6];
+#pragma unroll
+        for (int e = 0; e < 6; ++e) {
+          const int c = j + 8 * e;                                  // the channel this lane adds in step e
+          const int src = c < 32 ? (c >> 2) : ((c - 32) >> 1);      // lane (within the row group) that holds it
+          const int el = c < 32 ? (c & 3) : 4 + (c & 1);
+          float v = 0.f;
+#pragma unroll
+          for (int t = 0; t < 6; ++t) {
+            const float s = __shfl(g[ps][t], src, 8);
+            v = (el == t) ? s : v;
+          }
+          ga[e] = v;
+        }
+#pragma unroll
+        for (int p = 0; p < kPatchP; ++p) {
+          const PatchRec r = mine[p];
+          const unsigned bits = __float_as_uint(r.w.w) >> 4;
+          if (__builtin_amdgcn_ballot_w64(bits != 0u) == 0ull) continue;
+          const float lh = r.w.x, lw = r.w.y, a = r.w.z;
+          const float hh = 1.f - lh, hw = 1.f - lw;
+          const float wk[4] = {hh * hw * a, hh * lw * a, lh * hw * a, lh * lw * a};
+          const unsigned go[4] = {r.g.x, r.g.y, r.g.z, r.g.w};
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const unsigned o = ((bits >> k) & 1u) ? go[k] + 4u * j : kOobOffset;
+#pragma unroll
+            for (int e = 0; e < 6; ++e)
+              __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(wk[k] * ga[e], gsrc, o + 32u * e, 0, 0);
+          }
+        }
+      }
+    }
+    __syncthreads();     // before the window, the records and the other half of the slots are overwritten
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Backward, grad_value side: one workgroup per (n, m, tile)
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int kTile2MaxPx = 256;
+template <int HITCAP, bool GO_BF16> struct Tile2Lds {
+  static constexpr int kRowB = GO_BF16 ? 96 : 192;
+  __attribute__((aligned(16))) unsigned char rows[HITCAP * kRowB];   // grad_out rows of the round's hits (LDS-DMA)
+  int2 tap[HITCAP * 16];              // sorted taps of the round: (hit index, weight bits)
+  int hits[HITCAP];                   // queries of the round
+  int cntw[4][kTile2MaxPx];           // per wave and pixel: taps counted, then the wave's first position
+  int off[kTile2MaxPx + 1];           // exclusive prefix over pixels
+  int wsum[4];
+  int total_hits;
+};
+
+__device__ __forceinline__ int block_incl_scan(int v, int *wsum, int tid) {
+  int inc = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int up = __shfl_up(inc, o, 64);
+    inc += ((tid & 63) >= o) ? up : 0;
+  }
+  if ((tid & 63) == 63) wsum[tid >> 6] = inc;
+  __syncthreads();
+  int before = 0;
+  for (int w = 0; w < (tid >> 6); ++w) before += wsum[w];
+  return before + inc;
+}
+
+// one tap: acc += w * row, the row held in LDS as bf16 (96 B) or f32 (192 B); lane j owns channels 4j..4j+3, 32+2j, 33+2j
+template <bool GO_BF16>
+__device__ __forceinline__ void tile2_fma(float (&a6)[6], float w, const unsigned char *rows, int h, int j) {
+  if constexpr (GO_BF16) {
+    const uint2 pa = *reinterpret_cast<const uint2 *>(rows + h * 96 + 8 * j);
+    const unsigned pb = *reinterpret_cast<const unsigned *>(rows + h * 96 + 64 + 4 * j);
+    a6[0] = fmaf(w, __uint_as_float(pa.x << 16), a6[0]); a6[1] = fmaf(w, __uint_as_float(pa.x & 0xffff0000u), a6[1]);
+    a6[2] = fmaf(w, __uint_as_float(pa.y << 16), a6[2]); a6[3] = fmaf(w, __uint_as_float(pa.y & 0xffff0000u), a6[3]);
+    a6[4] = fmaf(w, __uint_as_float(pb << 16), a6[4]);   a6[5] = fmaf(w, __uint_as_float(pb & 0xffff0000u), a6[5]);
+  } else {
+    const Row6 v = lds_row(rows, (unsigned)h * 192u, j);
+    a6[0] = fmaf(w, v.a.x, a6[0]); a6[1] = fmaf(w, v.a.y, a6[1]); a6[2] = fmaf(w, v.a.z, a6[2]);
+    a6[3] = fmaf(w, v.a.w, a6[3]); a6[4] = fmaf(w, v.b.x, a6[4]); a6[5] = fmaf(w, v.b.y, a6[5]);
+  }
+}
+
+template <int HITCAP, bool GO_BF16>
+__global__ __launch_bounds__(kPatchThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void msda_bwd_d48_tile2_kernel(
+    const void *__restrict__ grad_out, const float *__restrict__ loc, const float *__restrict__ attn, CoreDims d,
+    PatchPlan plan, float *__restrict__ grad_value) {
+  __shared__ Tile2Lds<HITCAP, GO_BF16> S;
+  constexpr int kItems = HITCAP * kPatchP / kPatchThreads;
+  constexpr int kRowB = GO_BF16 ? 96 : 192;
+  // XCD-major: all tiles of one (n, m) go to ONE XCD back to back, so that (n, m)'s grad_out rows / locations (~1-2 MB),
+  // which every tile a query's samples touch reads again, stay in that XCD's L2
+  const int tiles = plan.total_tiles;
+  const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+  const int nm = xcd + 8 * (jb / tiles);
+  if (nm >= d.N * d.M) return;
+  const int tile_id = jb % tiles;
+  const int m = nm % d.M, n = nm / d.M;
+  int l = 0;
+  for (int i = 1; i < plan.L; ++i) l = (tile_id >= plan.lv[i].tile_base) ? i : l;
+  const PatchLevel me = plan.lv[l];
+  const int t = tile_id - me.tile_base;
+  const int edge = 1 << me.shift, tpx = edge * edge, tsh = 2 * me.shift;
+  const int tyi = t / me.ntx, txi = t - tyi * me.ntx;
+  const int ty0 = tyi << me.shift, tx0 = txi << me.shift;
+  const int tid = threadIdx.x, wave = tid >> 6;
+  const int LP = d.L * kPatchP;
+  const size_t row_base = (size_t)n * d.Lq;
+
+  // ---- A. this thread's candidate block: its mark word ----
+  unsigned long long mask = 0ull;
+  int c_lq = 0, c_by = 0, c_bx = 0;
+  {
+    int c = tid;
+    const unsigned long long *slab = plan.marks + ((long long)n * d.M + m) * plan.words_per_nm + plan.lvl_base[l] +
+                                     (long long)t * plan.tstride[l];
+    for (int lq = 0; lq < plan.L; ++lq) {
+      int bx0, bx1, by0, by1;
+      patch_tile_cand(plan, l, lq, ty0, tx0, edge, bx0, bx1, by0, by1);
+      const int cw = min(bx1 - bx0 + 1, plan.cbw[l][lq]), ch = min(by1 - by0 + 1, plan.cbh[l][lq]);
+      const int cnt = (cw > 0 && ch > 0) ? cw * ch : 0;
+      if (c >= 0 && c < cnt) {
+        const int dy = c / cw, dx = c - dy * cw;
+        mask = slab[plan.coff[l][lq] + dy * plan.cbw[l][lq] + dx];
+        c_lq = lq; c_by = by0 + dy; c_bx = bx0 + dx;
+      }
+      c -= cnt;          // (negative once this thread has found its block)
+    }
+  }
+  const int my_cnt = __popcll(mask);
+  const int my_excl = block_incl_scan(my_cnt, S.wsum, tid) - my_cnt;
+  if (tid == kPatchThreads - 1) S.total_hits = my_excl + my_cnt;
+  __syncthreads();
+  const int total_hits = (plan.debug & 8) ? 0 : S.total_hits;
+
+  // accumulators: 32 groups of 8 lanes own the tile's pixels
+  const int grp = tid >> 3, j = tid & 7;
+  constexpr int kMaxU = kTile2MaxPx / 32;
+  float acc[kMaxU][6];
+#pragma unroll
+  for (int u = 0; u < kMaxU; ++u)
+#pragma unroll
+    for (int c = 0; c < 6; ++c) acc[u][c] = 0.f;
+  const unsigned char *go_nm = reinterpret_cast<const unsigned char *>(grad_out) + (row_base * d.M + m) * kRowB;
+  const size_t q_stride = (size_t)d.M * kRowB;
+
+  for (int lo = 0; lo < total_hits; lo += HITCAP) {
+    const int hi = min(lo + HITCAP, total_hits), nh = hi - lo;
+    // ---- expand the marks into this round's hit list (order: candidate, then bit -- fixed) ----
+    if (my_cnt && my_excl < hi && my_excl + my_cnt > lo) {
+      unsigned long long mm = mask;
+      int gi = my_excl;
+      const PatchLevel &lq_ = plan.lv[c_lq];
+      while (mm) {
+        const int i = __builtin_ctzll(mm);
+        mm &= mm - 1;
+        if (gi >= lo && gi < hi) S.hits[gi - lo] = lq_.start + (c_by * kPatchB + (i >> 3)) * lq_.W + c_bx * kPatchB + (i & 7);
+        ++gi;
+      }
+    }
+    for (int i = tid; i < 4 * tpx; i += kPatchThreads) S.cntw[i / tpx][i % tpx] = 0;
+    __syncthreads();
+    // ---- the hits' grad_out rows -> LDS by LDS-DMA (lands behind the decode below) ----
+    if (!(plan.debug & 1)) {
+      constexpr int gpr = kRowB / 16;
+      const int G = nh * gpr;
+      for (int g0 = 0; g0 < G; g0 += kPatchThreads) {
+        const int g = g0 + tid;
+        if (g < G) {
+          const int h = g / gpr, piece = g - h * gpr;
+          const unsigned char *src = go_nm + (size_t)S.hits[h] * q_stride + piece * 16;
+          unsigned char *dst = S.rows + (size_t)(g - (tid & 63)) * 16;
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                           (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+        }
+      }
+    }
+    // ---- decode: item = (hit h, point p); rank every tap of this tile within its (wave, pixel) ----
+    unsigned t_pix[kItems], t_ok[kItems];   // 4 x 8 bits: pixel of each tap; bit k: tap k is in this tile
+    unsigned t_rank[kItems][2];        // 4 x 16 bits
+    float t_w[kItems][4];
+#pragma unroll
+    for (int it = 0; it < kItems; ++it) {
+      const int h = (tid + it * kPatchThreads) >> 2, p = tid & 3;
+      t_pix[it] = 0u; t_ok[it] = 0u; t_rank[it][0] = t_rank[it][1] = 0u;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) t_w[it][k] = 0.f;
+      if (h < nh && !(plan.debug & 4)) {
+        const int q = S.hits[h];
+        int lq = 0;
+        for (int i = 1; i < plan.L; ++i) lq = (q >= plan.lv[i].start) ? i : lq;
+        const int rq = q - plan.lv[lq].start;
+        const int qy = rq / plan.lv[lq].W, qx = rq - qy * plan.lv[lq].W;
+        const size_t li = ((row_base + q) * d.M + m) * LP + l * kPatchP + p;
+        const float2 xy = *reinterpret_cast<const float2 *>(loc + 2 * li);
+        const float x = px_coord(xy.x, me.W), y = px_coord(xy.y, me.H);
+        const bool inside = (y > -1.f) && (x > -1.f) && (y < (float)me.H) && (x < (float)me.W);
+        const bool near = inside && near_anchor(x, y, anchor_coord(qx, me.W, plan.lv[lq].W),
+                                                anchor_coord(qy, me.H, plan.lv[lq].H), plan.radius);
+        if (near) {
+          const float a = attn[li];
+          const float yf = floorf(y), xf = floorf(x);
+          const int y0 = (int)yf, x0 = (int)xf;
+          const float lh = y - yf, lw = x - xf, hh = 1.f - lh, hw = 1.f - lw;
+          const float w4[4] = {hh * hw * a, hh * lw * a, lh * hw * a, lh * lw * a};
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int ty = y0 + (k >> 1), tx = x0 + (k & 1);
+            const bool in_map = ty >= 0 && ty <= me.H - 1 && tx >= 0 && tx <= me.W - 1;
+            const bool mine = in_map && (ty >> me.shift) == tyi && (tx >> me.shift) == txi;
+            if (mine) {
+              const int pix = ((ty - ty0) << me.shift) + (tx - tx0);
+              const int rank = atomicAdd(&S.cntw[wave][pix], 1);
+              t_pix[it] |= (unsigned)pix << (8 * k);
+              t_ok[it] |= 1u << k;
+              t_rank[it][k >> 1] |= (unsigned)rank << (16 * (k & 1));
+              t_w[it][k] = w4[k];
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();     // ranks complete; (vmcnt(0) in front of the barrier: the rows have landed)
+    // ---- exclusive prefix over pixels; per wave the position of its first tap of every pixel ----
+    {
+      int c[4] = {0, 0, 0, 0};
+      if (tid < tpx) {
+#pragma unroll
+        for (int w = 0; w < 4; ++w) c[w] = S.cntw[w][tid];
+      }
+      const int tot = c[0] + c[1] + c[2] + c[3];
+      const int incl = block_incl_scan(tot, S.wsum, tid);
+      if (tid < tpx) {
+        int base = incl - tot;
+        S.off[tid] = base;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { S.cntw[w][tid] = base; base += c[w]; }
+      }
+      if (tid == kPatchThreads - 1) S.off[tpx] = incl;      // (threads >= tpx carry the total)
+    }
+    __syncthreads();
+    // ---- scatter the taps into pixel order ----
+#pragma unroll
+    for (int it = 0; it < kItems; ++it) {
+      const int h = (tid + it * kPatchThreads) >> 2;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if ((t_ok[it] >> k) & 1u) {
+          const unsigned pix = (t_pix[it] >> (8 * k)) & 0xffu;
+          const int pos = S.cntw[wave][pix] + (int)((t_rank[it][k >> 1] >> (16 * (k & 1))) & 0xffffu);
+          S.tap[pos] = make_int2(h, __float_as_int(t_w[it][k]));
+        }
+      }
+    }
+    __syncthreads();
+    // ---- accumulate: every pixel by one group (tiles of < 32 pixels: 32 / tpx groups share a pixel's taps) ----
+    if (!(plan.debug & 2)) {
+      auto run = [&](float (&a6)[6], int b0, int e0) {
+        const int last = e0 - 1;
+        for (int e = b0; e < e0; e += 4) {
+          const int2 r0 = S.tap[e], r1 = S.tap[min(e + 1, last)], r2 = S.tap[min(e + 2, last)], r3 = S.tap[min(e + 3, last)];
+          const float w0 = __int_as_float(r0.y), w1 = e + 1 < e0 ? __int_as_float(r1.y) : 0.f;
+          const float w2 = e + 2 < e0 ? __int_as_float(r2.y) : 0.f, w3 = e + 3 < e0 ? __int_as_float(r3.y) : 0.f;
+          tile2_fma<GO_BF16>(a6, w0, S.rows, r0.x, j);
+          tile2_fma<GO_BF16>(a6, w1, S.rows, r1.x, j);
+          tile2_fma<GO_BF16>(a6, w2, S.rows, r2.x, j);
+          tile2_fma<GO_BF16>(a6, w3, S.rows, r3.x, j);
+        }
+      };
+      if (tpx >= 32) {
+#pragma unroll
+        for (int u = 0; u < kMaxU; ++u) {
+          if (u < (tpx >> 5)) {
+            const int pix = grp + 32 * u;
+            run(acc[u], S.off[pix], S.off[pix + 1]);
+          }
+        }
+      } else {
+        const int pix = grp & (tpx - 1), s = grp >> tsh, gpp = 32 >> tsh;
+        const int b0 = S.off[pix], nt = S.off[pix + 1] - b0;
+        run(acc[0], b0 + (nt * s) / gpp, b0 + (nt * (s + 1)) / gpp);
+      }
+    }
+    __syncthreads();     // before the next round overwrites hits / rows / taps / counters
+  }
+
+  // ---- tiles of fewer than 32 pixels: add the groups' partial sums in a fixed order ----
+  if (tpx < 32) {
+    float *comb = reinterpret_cast<float *>(S.tap);               // [32 groups][8 lanes][6]
+    const int s = grp >> tsh, gpp = 32 >> tsh;
+    if (s > 0) {
+#pragma unroll
+      for (int c = 0; c < 6; ++c) comb[(grp * 8 + j) * 6 + c] = acc[0][c];
+    }
+    __syncthreads();
+    if (s == 0) {
+      for (int o = 1; o < gpp; ++o) {
+#pragma unroll
+        for (int c = 0; c < 6; ++c) acc[0][c] += comb[(((o << tsh) + grp) * 8 + j) * 6 + c];
+      }
+    }
+  }
+  // ---- add the tile to grad_value: plain read-modify-write (the query-side kernel has finished; tiles are disjoint) ----
+  const size_t img_base = ((size_t)n * d.S + me.start) * d.M;
+#pragma unroll
+  for (int u = 0; u < kMaxU; ++u) {
+    const bool on = tpx >= 32 ? (u < (tpx >> 5)) : (u == 0 && (grp >> tsh) == 0);
+    if (on) {
+      const int pix = tpx >= 32 ? grp + 32 * u : (grp & (tpx - 1));
+      const int ty = ty0 + (pix >> me.shift), tx = tx0 + (pix & (edge - 1));
+      if (ty < me.H && tx < me.W) {
+        float *dst = grad_value + (img_base + (size_t)(ty * me.W + tx) * d.M + m) * kD48;
+        f32x4 va = *reinterpret_cast<f32x4 *>(dst + 4 * j);
+        float2 vb = *reinterpret_cast<float2 *>(dst + 32 + 2 * j);
+        va.x += acc[u][0]; va.y += acc[u][1]; va.z += acc[u][2]; va.w += acc[u][3];
+        vb.x += acc[u][4]; vb.y += acc[u][5];
+        *reinterpret_cast<f32x4 *>(dst + 4 * j) = va;
+        *reinterpret_cast<float2 *>(dst + 32 + 2 * j) = vb;
+      }
+    }
+  }
+}
+
+}  // namespace snipper

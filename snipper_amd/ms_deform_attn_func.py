@@ -37,12 +37,9 @@ class MSDeformAttnFunction(Function):
         if value.dtype == torch.bfloat16:   # coordinates and weights stay fp32 beside bf16 values
             sampling_locations = sampling_locations.float()
             attention_weights = attention_weights.float()
-        if ctx.rows_bf16:
-            out = MSDA.ms_deform_attn_forward(value, value_spatial_shapes, value_level_start_index,
-                                              sampling_locations, attention_weights, im2col_step, out_bf16=True)
-        else:
-            out = MSDA.ms_deform_attn_forward(value, value_spatial_shapes, value_level_start_index,
-                                              sampling_locations, attention_weights, im2col_step)
+        out = MSDA.ms_deform_attn_forward(value, value_spatial_shapes, value_level_start_index, sampling_locations,
+                                          attention_weights, im2col_step, out_bf16=ctx.rows_bf16,
+                                          host_shapes=ctx.host_shapes)
         ctx.save_for_backward(value, value_spatial_shapes, value_level_start_index,
                               sampling_locations, attention_weights)
         return out

@@ -39,21 +39,13 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
-# Library knobs (csrc/msda_capi.hip) are process-wide: whatever a test changes is put back after EVERY test, so the order
-# in which files are collected cannot decide which kernels a later test exercises.
-_KNOB_DEFAULTS = {"near_radius": 6.0, "owner_tile_edge_big": 16, "owner_tile_edge_mid": 8, "owner_tile_edge_small": 4,
-                  "owner_debug": 0, "owner_chunk": 64, "ln_bwd_blocks": 1536, "wgrad_wgs": 512, "owner_enable": 1}
-
-
+# The library has no tuning state; tests change kernels through a Python-side test Config (snipper_amd/_lib.py) that is
+# dropped after EVERY test, so the order in which files are collected cannot decide which kernels a later test exercises.
 @pytest.fixture(autouse=True)
 def _library_defaults():
     yield
     try:
         from snipper_amd import _lib
-        if _lib._lib is None:          # never loaded by this test: nothing to restore
-            return
-        _lib.set_policy(0)
-        for k, v in _KNOB_DEFAULTS.items():
-            _lib.set_param(k, v)
+        _lib.reset_config()
     except Exception:
         pass

@@ -39,8 +39,11 @@ def test_library_loads_and_reports():
     one = ctypes.c_void_p(8)
     assert lib.snipper_msda_forward_f32(None, one, one, one, one, one, 0, 1, 1, 1, 1, 1, 1, one) == -2
     assert lib.snipper_msda_forward_f64(None, one, one, one, one, one, 1, 1 << 20, 64, 64, 1, 1, 1, one) == -2
-    assert lib.snipper_msda_set_policy(7) == -3
-    assert lib.snipper_msda_set_policy(0) == 0
+    cfg = _lib.Config.defaults()
+    assert cfg.struct_bytes == ctypes.sizeof(_lib.Config) and cfg.policy == 0 and cfg.near_radius == 6.0
+    assert list(cfg.tile_edge) == [16, 8, 4]
+    cfg.policy = 7      # a config the library rejects is an error, not a silent default
+    assert lib.snipper_msda_forward_ex(None, ctypes.byref(cfg), None, one, 0, one, one, one, one, 1, 1, 1, 1, 1, 1, 1, one, 0) == -2
 
 
 def test_install_registers_reference_module_name():

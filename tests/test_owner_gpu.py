@@ -73,6 +73,11 @@ def test_owner_backward_matches_oracle(name):
     ref = O.core_c_backward(f64(v), sh, lsi, f64(loc), f64(attn), f64(go), threads=4)
     (gv, gl, ga), variant = run_hip(v, sh, lsi, loc, attn, go, [tuple(x) for x in sh.tolist()])
     assert variant.startswith("d48_owner"), variant
+    t = lambda a: torch.from_numpy(a).to(DEV)
+    out = MSDA.ms_deform_attn_forward(t(v), t(sh), t(lsi), t(loc), t(attn), 64, host_shapes=[tuple(x) for x in sh.tolist()])
+    assert _lib.last_variant() == "d48_patch"
+    np.testing.assert_allclose(out.cpu().numpy(), O.core_c_forward(f64(v), sh, lsi, f64(loc), f64(attn), threads=4),
+                               rtol=1e-4, atol=2e-5)
     np.testing.assert_allclose(gv, ref[0], rtol=1e-4, atol=5e-5)
     s = float(np.abs(ref[1]).max())
     np.testing.assert_allclose(gl / s, ref[1] / s, rtol=1e-4, atol=2e-5)
@@ -156,10 +161,15 @@ def test_full_size_owner_backward_directly_against_oracle(geom, spread, far):
     np.testing.assert_allclose(ga, ref[2], rtol=1e-4, atol=1e-4)
     # forward of the same inputs
     t = lambda a: torch.from_numpy(a).to(DEV)
-    out = MSDA.ms_deform_attn_forward(t(v), t(sh), t(lsi), t(loc), t(attn), 64).cpu().numpy()
-    assert _lib.last_variant().startswith("d48")
     ref_out = O.core_c_forward(f64(v), sh, lsi, f64(loc), f64(attn), threads=32)
-    np.testing.assert_allclose(out, ref_out, rtol=1e-4, atol=2e-5)
+    for hs, want in ((shapes, "d48_patch"), (None, "d48_lp12")):      # LDS-staged encoder-shape kernel / plain D=48 kernel
+        out = MSDA.ms_deform_attn_forward(t(v), t(sh), t(lsi), t(loc), t(attn), 64, host_shapes=hs).cpu().numpy()
+        assert _lib.last_variant() == want, _lib.last_variant()
+        np.testing.assert_allclose(out, ref_out, rtol=1e-4, atol=2e-5)
+    out16 = MSDA.ms_deform_attn_forward(t(v), t(sh), t(lsi), t(loc), t(attn), 64, out_bf16=True, host_shapes=shapes)
+    assert out16.dtype == torch.bfloat16 and _lib.last_variant() == "d48_patch"
+    assert torch.equal(out16.cpu(), torch.from_numpy(out).to(torch.bfloat16)) or \
+        np.allclose(out16.float().cpu().numpy(), ref_out, rtol=2 ** -7, atol=1e-3)
     # the atomic kernel (no host shapes) at the same size
     (gv2, _, _), variant2 = run_hip(v, sh, lsi, loc, attn, go, None)
     assert "owner" not in variant2

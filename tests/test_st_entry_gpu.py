@@ -54,6 +54,7 @@ def test_st_entry_matches_composition(encoder, vdt):
     inv_w, inv_h = _f([1.0 / w for h, w in hw]), _f([1.0 / h for h, w in hw])
     mixf = _f([w for row in mix for w in row])
     cv = lambda a: ctypes.cast(a, ctypes.c_void_p)
+    hs = (ctypes.c_int64 * (2 * L))(*[int(v) for p in hw for v in p])
     vbar2 = torch.empty(N * T, S, M, D, device=DEV)
     loc2 = torch.empty(N * T, Lq, M, L, P, 2, device=DEV)
     prob2 = torch.empty(N * T, Lq, M, L, P, device=DEV)
@@ -62,12 +63,12 @@ def test_st_entry_matches_composition(encoder, vdt):
     v_in, off_in, logit_in, ref_in = value.detach(), off.detach(), logit.detach(), ref.detach().contiguous()
     rc = lib.snipper_st_msda_forward(st, v_in.data_ptr(), vd, m8.data_ptr(), cv(mixf), off_in.data_ptr(), M * L * P * 2,
                                      logit_in.data_ptr(), M * L * P, 0, ref_in.data_ptr(), cv(inv_w), cv(inv_h),
-                                     shapes.data_ptr(), lsi.data_ptr(), N, T, T, S, M, D, L, Lq, P,
+                                     shapes.data_ptr(), lsi.data_ptr(), cv(hs), N, T, T, S, M, D, L, Lq, P,
                                      vbar2.data_ptr(), loc2.data_ptr(), prob2.data_ptr(), out2.data_ptr(), 0)
     _lib.check(rc, "snipper_st_msda_forward")
+    assert _lib.last_variant() == ("d48_patch" if encoder else "d48_lp12"), _lib.last_variant()
     torch.testing.assert_close(out2, out.detach(), rtol=0, atol=0)
 
-    hs = (ctypes.c_int64 * (2 * L))(*[int(v) for p in hw for v in p])
     nbytes = lib.snipper_st_msda_backward_workspace_bytes(N, T, S, M, D, L, Lq, P, cv(hs))
     ws = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
     gv2 = torch.empty_like(v_in)

@@ -21,7 +21,7 @@ SHAPES = [(75, 100), (38, 50), (19, 25)]
 M, D, L, P = 8, 48, 3, 4
 
 
-def make(N, Lq, local, dtype, seed=0, dev="cuda:0"):
+def make(N, Lq, local, dtype, seed=0, dev="cuda:0", sigma=3.0, far=0.0):
     g = torch.Generator().manual_seed(seed)
     S = sum(h * w for h, w in SHAPES)
     value = torch.randn(N, S, M, D, generator=g)
@@ -32,7 +32,10 @@ def make(N, Lq, local, dtype, seed=0, dev="cuda:0"):
             refs.append(torch.stack([xs.reshape(-1) / w, ys.reshape(-1) / h], -1))
         ref = torch.cat(refs)[None, :, None, None, None, :]
         norm = torch.tensor([[w, h] for h, w in SHAPES], dtype=torch.float32)[None, None, None, :, None, :]
-        loc = ref + torch.randn(N, Lq, M, L, P, 2, generator=g) * 3.0 / norm
+        loc = ref + torch.randn(N, Lq, M, L, P, 2, generator=g) * sigma / norm
+        if far > 0:
+            pick = torch.rand(N, Lq, M, L, P, 1, generator=g) < far
+            loc = torch.where(pick, torch.rand(N, Lq, M, L, P, 2, generator=g) * 1.4 - 0.2, loc)
     else:
         loc = torch.rand(N, Lq, M, L, P, 2, generator=g)
     attn = torch.softmax(torch.randn(N, Lq, M, L * P, generator=g), -1).view(N, Lq, M, L, P)
@@ -67,21 +70,25 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--N", type=int, nargs="+", default=[1, 2, 8])
     ap.add_argument("--skip-torch", action="store_true")
-    ap.add_argument("--owner", type=int, default=0, help="pass host shapes (owner-computes backward)")
+    ap.add_argument("--owner", type=int, default=1, help="pass host shapes (encoder-shape kernels: LDS-staged forward, "
+                                                         "owner-computes backward)")
     ap.add_argument("--radius", type=float, default=None)
-    ap.add_argument("--owner-debug", type=int, default=0)
-    ap.add_argument("--owner-chunk", type=int, default=64)
+    ap.add_argument("--halo", type=float, default=None)
+    ap.add_argument("--debug", type=int, default=0, help="timing ablations of the encoder-shape kernels (wrong results)")
     ap.add_argument("--edges", type=int, nargs=3, default=None)
     ap.add_argument("--cases", nargs="+", default=["enc_local", "enc_uniform", "dec"])
     ap.add_argument("--dtypes", nargs="+", default=["float32", "bfloat16"])
+    ap.add_argument("--sigma", type=float, nargs="+", default=[3.0], help="enc_local: std of the offsets in pixels")
+    ap.add_argument("--far", type=float, nargs="+", default=[0.0], help="enc_local: fraction of samples placed anywhere")
+    ap.add_argument("--rows-bf16", type=int, default=0, help="1 = bf16 out / grad_out rows beside f32 value (the step's mode)")
     args = ap.parse_args()
     S = sum(h * w for h, w in SHAPES)
-    _lib.set_param("owner_enable", 1 if args.owner else 0)
-    _lib.set_param("owner_chunk", args.owner_chunk)
-    if args.owner_debug:
-        _lib.set_param("owner_debug", args.owner_debug)
     if args.radius is not None:
         _lib.set_param("near_radius", args.radius)
+    if args.debug:
+        _lib.set_param("debug", args.debug)
+    if args.halo is not None:
+        _lib.set_param("window_halo", args.halo)
     if args.edges:
         for k, e in zip(("big", "mid", "small"), args.edges):
             _lib.set_param(f"owner_tile_edge_{k}", e)
@@ -89,12 +96,19 @@ def main():
         for name, Lq, local in [("enc_local", S, True), ("enc_uniform", S, False), ("dec", 60, False)]:
             if name not in args.cases:
                 continue
+            sweeps = [(sg, fr) for sg in args.sigma for fr in args.far] if name == "enc_local" else [(3.0, 0.0)]
             for dtype in [getattr(torch, x) for x in args.dtypes]:
-                v, shapes, lsi, loc, attn, go = make(N, Lq, local, dtype)
-                for policy in ((0, 1) if dtype == torch.float32 else (0,)):
+              for sg, fr in sweeps:
+                v, shapes, lsi, loc, attn, go = make(N, Lq, local, dtype, sigma=sg, far=fr)
+                rows16 = bool(args.rows_bf16) and dtype == torch.float32
+                if rows16:
+                    go = go.to(torch.bfloat16)
+                for policy in ((0, 2, 1) if dtype == torch.float32 else (0,)):
+                    if policy == 1 and rows16:
+                        continue
                     _lib.set_policy(policy)
-                    f = lambda: MSDA.ms_deform_attn_forward(v, shapes, lsi, loc, attn, 64)
                     hs = SHAPES if (policy == 0 and args.owner) else None
+                    f = lambda: MSDA.ms_deform_attn_forward(v, shapes, lsi, loc, attn, 64, out_bf16=rows16, host_shapes=hs)
                     b = lambda: MSDA.ms_deform_attn_backward(v, shapes, lsi, loc, attn, go, 64, host_shapes=hs)
                     f(); var_f = _lib.last_variant()
                     b(); var_b = _lib.last_variant()
@@ -102,7 +116,8 @@ def main():
                     tb, tb0 = timeit(b, args.iters)
                     e = v.element_size()
                     print(json.dumps({
-                        "case": name, "N": N, "dtype": str(dtype).split(".")[-1], "fwd_variant": var_f,
+                        "case": name, "N": N, "sigma_px": sg, "far": fr, "rows_bf16": int(rows16),
+                        "dtype": str(dtype).split(".")[-1], "fwd_variant": var_f,
                         "bwd_variant": var_b, "fwd_ms": round(tf, 4), "fwd_min_ms": round(tf0, 4),
                         "bwd_ms": round(tb, 4), "bwd_min_ms": round(tb0, 4),
                         "fwd_alg_GBps": round(alg_bytes(N, Lq, S, e, False) / tf / 1e6, 1),
