@@ -126,6 +126,21 @@ def optimizer_groups(named_params):
     return (named(lambda n: "backbone" not in n and not slow(n)), named(lambda n: "backbone" in n), named(slow))
 
 
+def grad_sync_stages(model, non_backbone):
+    """Stages of the gradient all-reduce, in the order backward completes them: everything but the backbone (complete
+    when the 1x1 input projections' gradients are), then layer4, layer3, layer2 of the ResNet (each complete when its
+    FIRST block's gradients are: the blocks of a stage run backwards).  Each stage's slice is all-reduced over RCCL
+    while backward is still working on the next one."""
+    stages = [(non_backbone, list(model.input_proj.parameters()))]
+    body = model.backbone[0].body
+    for name in ("layer4", "layer3", "layer2"):
+        layer = getattr(body, name, None)
+        ps = [p for p in layer.parameters() if p.requires_grad] if layer is not None else []
+        if ps:
+            stages.append((ps, [p for p in layer[0].parameters() if p.requires_grad]))
+    return stages
+
+
 def build_optimizer(named_params, capturable=False, flat=None):
     """AdamW with the reference's three groups (main.py:201-221).  ``flat``: a FlatParameters over (main, slow,
     backbone) -- then each group is its one flat leaf."""
@@ -384,13 +399,10 @@ def main():
         # the same semantics (rank 0's initial weights everywhere; mean of the ranks' gradients after backward)
         # without a reducer hook per parameter: see snipper_amd/grad_sync.py
         from snipper_amd.grad_sync import FlatGradSync
-        # everything but the backbone is "early": its gradients are complete when the input projections' are
-        early = [p for n, p in model.named_parameters() if not n.startswith("backbone.")]
-        trigger = list(model.input_proj.parameters())
         g_main, g_backbone, g_slow = optimizer_groups(list(model.named_parameters()))
-        # flat layout [main | slow | backbone]: early slice first, and group by group so that the optimizer's flat leaves
-        # (flat_params.py) line up with it
-        gsync = FlatGradSync(g_main + g_slow + g_backbone, early=early, trigger=trigger)
+        # flat layout [main | slow | backbone]: group by group so that the optimizer's flat leaves (flat_params.py) line up
+        # with it, and in stages that backward completes one after the other (grad_sync_stages)
+        gsync = FlatGradSync(g_main + g_slow + g_backbone, stages=grad_sync_stages(model, g_main + g_slow))
         gsync.broadcast_parameters(list(model.parameters()) + list(model.buffers()))
     if masters is None:
         if use_flat:
@@ -656,7 +668,8 @@ def main():
                                           "7x7 stem, stride-2 dgrad and 3x3 wgrad"),
                        "grad_sync": ("none (1 GPU)" if not use_ddp else
                                      ("DistributedDataParallel" if a.ddp == "torch" else
-                                      "flat buffer + 4 RCCL all-reduces after backward (snipper_amd/grad_sync.py)")),
+                                      "flat buffer, 4 stages (transformer, layer4, layer3, layer2) all-reduced over RCCL "
+                                      "from autograd hooks while backward runs (snipper_amd/grad_sync.py)")),
                        "msda_path": "pytorch grid_sample" if a.use_pytorch_deform else "snipper_amd HIP (tied single-launch)",
                        "launch": graph_note,
                        "weights": ("bf16 parameters + fp32 master weights" if masters is not None else

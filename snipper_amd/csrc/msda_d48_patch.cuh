@@ -1,32 +1,36 @@
-// msda_d48_patch.cuh -- encoder-shape kernels (D = 48, f32 value, P = 4, L <= 4, Lq == S, level shapes known on the
-// host) built around LDS-staged value neighbourhoods.  gfx950 only.
+// msda_d48_patch.cuh -- the DETERMINISTIC owner-computes backward for the encoder shape (D = 48, f32 value, P = 4,
+// L <= 4, Lq == S, level shapes known on the host).  gfx950 only.
 //
-// Why: in the encoder the queries ARE the pixels of the L feature maps, and a query samples every level near its own
-// position rescaled to that level (the "anchor").  The query-per-lane-group kernels of msda_d48.cuh fetch every tap
-// row (192 B) through the texture path: 5.8 GB of tap rows per launch at N = 8, i.e. ~21 TB/s of L2->CU traffic for
-// 273 MB of algorithmic bytes -- bound by the 64 B/clk/CU vector-memory path, not by HBM (rocprof round 1: forward
-// 272 us, grad_loc/grad_attn kernel 414 us per launch).  Here one workgroup takes an 8 x 8 block of queries of one
-// level for one (batch, head); for each sampled level it stages the block's value neighbourhood (anchor range +- halo
-// pixels, <= 336 pixels x 192 B) in LDS once -- by LDS-DMA, no VGPR round trip -- and the 64 rows then read their
-// taps from LDS at 256 B/clk/CU (ds_read_b128 + ds_read_b64 per tap row).  Every staged byte is re-used ~3-6 times.
-// Taps outside the window ("far": large offsets, or (query level, sampled level) pairs whose neighbourhood does not
-// fit) keep the global path inside the same kernel, so results never depend on locality -- only speed does.
-// Semantics restated from /root/reference/models/ops/src/cuda/ms_deform_im2col_cuda.cuh:33-159, 237-299 (forward)
-// and :513-616 (backward, D = 48 branch); no code is shared with it.
+// Same idea as msda_d48_owner.cuh (grad_value is cut into tiles, every tile has ONE owner workgroup that sums the taps
+// landing in it and adds the tile with plain stores), two differences:
+//   * the query side works on 8 x 8 blocks of queries of one level for one (batch, head), so "which queries reach which
+//     tile" is ONE 64-bit word per (tile, query block) -- 4 MB of marks per launch at N = 8 instead of a 58 MB byte map,
+//     no scan of it on the tile side;
+//   * the tile side sorts the owned taps by pixel with per-wave counters and a prefix (no order-dependent LDS atomics
+//     decide a float summation order), so grad_value is BIT-REPRODUCIBLE from launch to launch for every tap the tiles
+//     own (far taps keep their HBM float atomics, as in every variant).
+// Selected by snipper_msda_config.deterministic; measured 7 % slower than the msda_d48_owner.cuh pair on MI355X
+// (profiles/r02_lds_staging_experiment_kernel_avgs.csv: 462 + 586 us against 414 + 562 us per launch at N = 8), which
+// is why it is an option and not the default.
 //
-// Three kernels:
-//   msda_fwd_d48_patch_kernel     forward.
-//   msda_bwd_d48_patchbin_kernel  backward, query side: grad_loc / grad_attn for every sample (same staged gather,
-//                                 dot products instead of sums), marks -- one 64-bit word per (grad_value tile, query
-//                                 block): which queries of the block have a near tap in the tile -- and HBM float atomics
-//                                 for the taps no tile owns.
-//   msda_bwd_d48_tile2_kernel     backward, grad_value side (owner computes): one workgroup per (n, m, tile) expands the
-//                                 marks of its candidate blocks into a hit list, re-decodes the hits' samples, sorts
-//                                 the owned taps by pixel (per-wave counters + a prefix: a fixed order, so grad_value is
-//                                 bit-reproducible), accumulates every pixel in registers reading the grad_out rows
-//                                 straight from L2, and adds the tile to grad_value with plain stores.
+// What is NOT here any more: round 2 built the forward and the query-side backward around LDS-staged value
+// neighbourhoods (a workgroup stages its block's anchor range +- 5 px of every level by LDS-DMA and gathers from LDS),
+// in a one-head-per-workgroup and in a software-pipelined all-heads-per-workgroup form.  Both were parity-green and
+// both were slower than the texture-path kernels of msda_d48.cuh (forward 311 / 395 us against 272 us): a 62 KB float32
+// window leaves two workgroups per CU, every phase becomes latency-bound, and LDS-DMA with per-lane addresses costs the
+// issuing wave as much as the register loads it replaces (skeleton + staging + gather times add up exactly in the
+// ablations of the profile above).  DESIGN.md section 3.4b has the numbers; the kernels were removed.
+//
+// Semantics restated from /root/reference/models/ops/src/cuda/ms_deform_im2col_cuda.cuh:87-159 (tap gradients) and
+// :513-616 (backward, D = 48 branch); no code is shared with it.
+//
+//   msda_bwd_d48_patchbin_kernel  query side: grad_loc / grad_attn for every sample, marks, HBM float atomics for the
+//                                 taps no tile owns.
+//   msda_bwd_d48_tile2_kernel     grad_value side: one workgroup per (n, m, tile) expands the marks of its candidate
+//                                 blocks into a hit list, re-decodes the hits' samples, sorts the owned taps by pixel,
+//                                 accumulates every pixel in registers from float32 rows staged in LDS and adds the tile.
 // "near" and "owned" are pure functions of (query index, sample location, plan), evaluated with the pinned arithmetic
-// of msda_d48.cuh by both backward kernels: owned + unowned is a partition of the taps for ANY input.
+// of msda_d48.cuh by both kernels: owned + unowned is a partition of the taps for ANY input.
 #pragma once
 #include "msda_d48.cuh"
 
@@ -36,9 +40,7 @@ constexpr int kPatchMaxLevels = 4;
 constexpr int kPatchP = 4;
 constexpr int kPatchB = 8;                       // query block edge
 constexpr int kPatchThreads = 256;               // = 64 rows x 4 points (decode) = 32 rows x 8 lanes (gather)
-constexpr int kPatchWinPx = 336;                 // LDS window capacity in pixels
 constexpr int kPatchRowBytes = kD48 * 4;         // 192
-constexpr int kPatchWinBytes = kPatchWinPx * kPatchRowBytes;
 constexpr int kPatchMaxTiles = 64;               // tiles one (block, level) may mark
 constexpr int kPatchMaxCand = 256;               // candidate blocks per tile (one per thread of the tile kernel)
 
@@ -60,19 +62,16 @@ struct PatchPlan {
   long long words_per_nm;
   unsigned long long *marks;    // [N*M][words_per_nm], zeroed per backward call
   int L, nblocks, total_tiles;
-  float halo;      // LDS window = anchor range of the block +- halo pixels
   float radius;    // a sample is "near" when |pixel - anchor| <= radius on both axes
-  int debug;       // timing ablations (config.reserved[0]; results are WRONG when != 0): 1 no staging, 2 no gather /
+  int debug;       // timing ablations (config.reserved[0]; results are WRONG when != 0): 1 no row staging, 2 no gather /
                    // accumulate, 4 no decode, 8 skeleton only
 };
 
 struct PatchBlock { int n, m, lq, qy0, qx0, bh, bw; };
-struct PatchWindow { int x0, y0, w, h; };            // w == 0: nothing staged for this (block, level)
 
-struct PatchRec {   // 48 B per (row, point) of the level in flight
-  f32x4 w;          // forward: bilinear x attention weight per tap.  backward: lh, lw, a, bits (far k | need k << 4)
-  u32x4 lds;        // byte offset of each tap's row inside the LDS window, or of the zero row
-  u32x4 g;          // byte offset of the tap's row in value / grad_value, or kOobOffset
+struct PatchRec {   // 32 B per (row, point) of the level in flight
+  f32x4 w;          // lh, lw, a, bits (bit 4 + k: no tile owns tap k -> HBM atomic here)
+  u32x4 g;          // byte offset of each tap's row in value / grad_value, or kOobOffset
 };
 
 __device__ __forceinline__ bool patch_block(const PatchPlan &p, const CoreDims &d, int nblk_padded, PatchBlock &b) {
@@ -95,39 +94,10 @@ __device__ __forceinline__ bool patch_block(const PatchPlan &p, const CoreDims &
   return true;
 }
 
-__device__ __forceinline__ PatchWindow patch_window(const PatchPlan &p, const PatchBlock &b, int l) {
-  const PatchLevel &s = p.lv[l], &q = p.lv[b.lq];
-  const float ax0 = anchor_coord(b.qx0, s.W, q.W), ax1 = anchor_coord(b.qx0 + b.bw - 1, s.W, q.W);
-  const float ay0 = anchor_coord(b.qy0, s.H, q.H), ay1 = anchor_coord(b.qy0 + b.bh - 1, s.H, q.H);
-  const int x0 = max(0, (int)floorf(ax0 - p.halo)), x1 = min(s.W - 1, (int)ceilf(ax1 + p.halo));
-  const int y0 = max(0, (int)floorf(ay0 - p.halo)), y1 = min(s.H - 1, (int)ceilf(ay1 + p.halo));
-  PatchWindow w{x0, y0, x1 - x0 + 1, y1 - y0 + 1};
-  if (w.w <= 0 || w.h <= 0 || w.w * w.h > kPatchWinPx) w.w = w.h = 0;
-  return w;
-}
-
-// Stage the window's head rows into LDS in window order (pixel-major, 192 B each) with LDS-DMA: granule g (16 B) of
-// the image is piece g % 12 of pixel g / 12; one wave-instruction writes 64 consecutive granules (1 KiB), each lane
-// supplying its own source address.  Completion: the caller's __syncthreads() (hipcc puts vmcnt(0) in front of it).
-__device__ __forceinline__ void patch_stage(const float *value, const CoreDims &d, const PatchBlock &b,
-                                            const PatchLevel &s, const PatchWindow &w, unsigned char *win) {
-  const int G = w.w * w.h * (kPatchRowBytes / 16);
-  const unsigned px_stride = (unsigned)d.M * kPatchRowBytes;
-  const unsigned char *base = reinterpret_cast<const unsigned char *>(value) +
-                              ((size_t)b.n * d.S + s.start) * px_stride + (size_t)b.m * kPatchRowBytes;
-  const int tid = threadIdx.x;
-  for (int g0 = 0; g0 < G; g0 += kPatchThreads) {
-    const int g = g0 + tid;
-    if (g < G) {
-      const int px = g / 12, piece = g - px * 12;
-      const int wy = px / w.w, wx = px - wy * w.w;
-      const unsigned char *src = base + (size_t)((w.y0 + wy) * s.W + w.x0 + wx) * px_stride + piece * 16;
-      unsigned char *dst = win + (size_t)(g - (tid & 63)) * 16;      // wave-uniform; the hardware adds lane * 16
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                       (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
-    }
-  }
-}
+// workgroup barrier that orders LDS traffic only: unlike __syncthreads() it does not drain the vector-memory counter, so
+// LDS-DMA transfers and prefetched global loads stay in flight across it
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ void vm_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // all-reduce over the 8 lanes of a row group (DPP: quad xor 1, quad xor 2, mirror within the half row)
 __device__ __forceinline__ float row8_sum(float v) {
@@ -153,139 +123,6 @@ __device__ __forceinline__ Row6 buf_row(__amdgpu_buffer_rsrc_t rsrc, unsigned of
   r.a.x = __uint_as_float(a.x); r.a.y = __uint_as_float(a.y); r.a.z = __uint_as_float(a.z); r.a.w = __uint_as_float(a.w);
   r.b.x = __uint_as_float(b.x); r.b.y = __uint_as_float(b.y);
   return r;
-}
-
-// ------------------------------------------------------------------------------------------------------------------
-// Forward
-// ------------------------------------------------------------------------------------------------------------------
-template <bool OUT_BF16>
-__global__ __launch_bounds__(kPatchThreads) void msda_fwd_d48_patch_kernel(
-    const float *__restrict__ value, const float *__restrict__ loc, const float *__restrict__ attn, CoreDims d,
-    PatchPlan plan, void *__restrict__ out, int nblk_padded) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[kPatchWinBytes + kPatchRowBytes + kPatchThreads * sizeof(PatchRec)];
-  unsigned char *win = smem;                                   // window, then the zero row, then the records
-  PatchRec *recs = reinterpret_cast<PatchRec *>(smem + kPatchWinBytes + kPatchRowBytes);
-  PatchBlock b;
-  if (!patch_block(plan, d, nblk_padded, b)) return;
-  const int tid = threadIdx.x;
-  if (tid < kD48) reinterpret_cast<float *>(smem + kPatchWinBytes)[tid] = 0.f;
-  const PatchLevel lvq = plan.lv[b.lq];
-  const int LP = d.L * kPatchP;
-  // decode role: thread = (row r, point p)
-  const int rd = tid >> 2, pd = tid & 3;
-  const int rdy = rd >> 3, rdx = rd & 7;
-  const bool rd_ok = rdy < b.bh && rdx < b.bw;
-  const int qd = rd_ok ? lvq.start + (b.qy0 + rdy) * lvq.W + b.qx0 + rdx : lvq.start;
-  const long long rowd = ((long long)b.n * d.Lq + qd) * d.M + b.m;
-  const unsigned px_stride = (unsigned)d.M * kPatchRowBytes;
-  const unsigned gbase = (unsigned)(b.n * d.S) * px_stride + (unsigned)b.m * kPatchRowBytes;
-  // gather role: thread = (row rg + 32 * pass, lane j)
-  const int j = tid & 7, rg = tid >> 3;
-  const unsigned value_bytes = (unsigned)((size_t)d.N * d.S * d.M * kPatchRowBytes);
-  const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(value), 0, (int)value_bytes, 0x00020000);
-  float acc[2][6];
-#pragma unroll
-  for (int ps = 0; ps < 2; ++ps)
-#pragma unroll
-    for (int c = 0; c < 6; ++c) acc[ps][c] = 0.f;
-  // this thread's sample of EVERY level up front: one exposed HBM latency per workgroup instead of one per level
-  float2 xy_l[kPatchMaxLevels];
-  float a_l[kPatchMaxLevels];
-#pragma unroll
-  for (int l = 0; l < kPatchMaxLevels; ++l) {
-    xy_l[l] = make_float2(0.f, 0.f); a_l[l] = 0.f;
-    if (l < plan.L) {
-      const long long li = rowd * LP + l * kPatchP + pd;
-      xy_l[l] = *reinterpret_cast<const float2 *>(loc + 2 * li);
-      a_l[l] = attn[li];
-    }
-  }
-
-#pragma unroll
-  for (int l = 0; l < kPatchMaxLevels; ++l) {
-    if (l >= plan.L) break;
-    const PatchLevel lvl = plan.lv[l];
-    const PatchWindow w = patch_window(plan, b, l);
-    if (!(plan.debug & 1)) patch_stage(value, d, b, lvl, w, win);
-    {
-      const float2 xy = xy_l[l];
-      const float a_in = a_l[l];
-      const float y = xy.y * (float)lvl.H - 0.5f, x = xy.x * (float)lvl.W - 0.5f;
-      const bool inside = rd_ok && (y > -1.f) && (x > -1.f) && (y < (float)lvl.H) && (x < (float)lvl.W);
-      const float yf = floorf(y), xf = floorf(x);
-      const int y0 = (int)yf, x0 = (int)xf;
-      const float lh = inside ? y - yf : 0.f, lw = inside ? x - xf : 0.f;
-      const float hh = 1.f - lh, hw = 1.f - lw;
-      const float a = inside ? a_in : 0.f;
-      PatchRec r;
-      r.w.x = hh * hw * a; r.w.y = hh * lw * a; r.w.z = lh * hw * a; r.w.w = lh * lw * a;
-      unsigned lo[4], go[4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int ty = y0 + (k >> 1), tx = x0 + (k & 1);
-        const bool in_map = inside && ty >= 0 && ty <= lvl.H - 1 && tx >= 0 && tx <= lvl.W - 1;
-        const int wy = ty - w.y0, wx = tx - w.x0;
-        const bool in_win = in_map && wy >= 0 && wy < w.h && wx >= 0 && wx < w.w;
-        lo[k] = in_win ? (unsigned)(wy * w.w + wx) * kPatchRowBytes : (unsigned)kPatchWinBytes;
-        go[k] = (in_map && !in_win) ? gbase + (unsigned)(lvl.start + ty * lvl.W + tx) * px_stride : kOobOffset;
-      }
-      r.lds.x = lo[0]; r.lds.y = lo[1]; r.lds.z = lo[2]; r.lds.w = lo[3];
-      r.g.x = go[0]; r.g.y = go[1]; r.g.z = go[2]; r.g.w = go[3];
-      recs[tid] = r;
-    }
-    __syncthreads();     // window landed (vmcnt(0) precedes the barrier), records visible
-    if (!(plan.debug & 2))
-#pragma unroll
-    for (int ps = 0; ps < 2; ++ps) {
-      const PatchRec *mine = recs + (ps * 32 + rg) * kPatchP;
-      unsigned far = 0u;
-#pragma unroll
-      for (int p = 0; p < kPatchP; ++p) {
-        const PatchRec r = mine[p];
-        const Row6 v0 = lds_row(win, r.lds.x, j), v1 = lds_row(win, r.lds.y, j);
-        const Row6 v2 = lds_row(win, r.lds.z, j), v3 = lds_row(win, r.lds.w, j);
-        far |= (min(min(r.g.x, r.g.y), min(r.g.z, r.g.w)) != kOobOffset) ? (1u << p) : 0u;
-#define SNIPPER_ACC_TAP(W_, V_)                                                                       \
-        acc[ps][0] = fmaf(W_, V_.a.x, acc[ps][0]); acc[ps][1] = fmaf(W_, V_.a.y, acc[ps][1]);        \
-        acc[ps][2] = fmaf(W_, V_.a.z, acc[ps][2]); acc[ps][3] = fmaf(W_, V_.a.w, acc[ps][3]);        \
-        acc[ps][4] = fmaf(W_, V_.b.x, acc[ps][4]); acc[ps][5] = fmaf(W_, V_.b.y, acc[ps][5]);
-        SNIPPER_ACC_TAP(r.w.x, v0) SNIPPER_ACC_TAP(r.w.y, v1) SNIPPER_ACC_TAP(r.w.z, v2) SNIPPER_ACC_TAP(r.w.w, v3)
-      }
-      if (__builtin_amdgcn_ballot_w64(far != 0u) != 0ull) {       // taps outside the window: global path
-#pragma unroll
-        for (int p = 0; p < kPatchP; ++p) {
-          if (__builtin_amdgcn_ballot_w64((far >> p) & 1u) == 0ull) continue;     // (wave-uniform)
-          const PatchRec r = mine[p];
-          const Row6 v0 = buf_row(rsrc, r.g.x, j), v1 = buf_row(rsrc, r.g.y, j);
-          const Row6 v2 = buf_row(rsrc, r.g.z, j), v3 = buf_row(rsrc, r.g.w, j);
-          SNIPPER_ACC_TAP(r.w.x, v0) SNIPPER_ACC_TAP(r.w.y, v1) SNIPPER_ACC_TAP(r.w.z, v2) SNIPPER_ACC_TAP(r.w.w, v3)
-        }
-      }
-    }
-    __syncthreads();     // before the window / the records are overwritten
-  }
-#pragma unroll
-  for (int ps = 0; ps < 2; ++ps) {
-    const int r = ps * 32 + rg, ry = r >> 3, rx = r & 7;
-    if (ry < b.bh && rx < b.bw) {
-      const int q = lvq.start + (b.qy0 + ry) * lvq.W + b.qx0 + rx;
-      const size_t row = ((size_t)b.n * d.Lq + q) * d.M + b.m;
-      if constexpr (OUT_BF16) {
-        uint16_t *o = reinterpret_cast<uint16_t *>(out) + row * kD48;
-        uint2 pa;
-        pa.x = (unsigned)f32_to_bf16_bits(acc[ps][0]) | ((unsigned)f32_to_bf16_bits(acc[ps][1]) << 16);
-        pa.y = (unsigned)f32_to_bf16_bits(acc[ps][2]) | ((unsigned)f32_to_bf16_bits(acc[ps][3]) << 16);
-        *reinterpret_cast<uint2 *>(o + 4 * j) = pa;
-        *reinterpret_cast<unsigned *>(o + 32 + 2 * j) =
-            (unsigned)f32_to_bf16_bits(acc[ps][4]) | ((unsigned)f32_to_bf16_bits(acc[ps][5]) << 16);
-      } else {
-        float *o = reinterpret_cast<float *>(out) + row * kD48;
-        f32x4 pa; pa.x = acc[ps][0]; pa.y = acc[ps][1]; pa.z = acc[ps][2]; pa.w = acc[ps][3];
-        *reinterpret_cast<f32x4 *>(o + 4 * j) = pa;
-        *reinterpret_cast<float2 *>(o + 32 + 2 * j) = make_float2(acc[ps][4], acc[ps][5]);
-      }
-    }
-  }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -343,16 +180,13 @@ __global__ __launch_bounds__(kPatchThreads) void msda_bwd_d48_patchbin_kernel(
     const void *__restrict__ grad_out, const float *__restrict__ value, const float *__restrict__ loc,
     const float *__restrict__ attn, CoreDims d, PatchPlan plan, float *__restrict__ grad_value,
     float *__restrict__ grad_loc, float *__restrict__ grad_attn, int nblk_padded) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[kPatchWinBytes + kPatchRowBytes + kPatchThreads * sizeof(PatchRec) +
-                                                           2 * kPatchMaxTiles * 16];
-  unsigned char *win = smem;
-  PatchRec *recs = reinterpret_cast<PatchRec *>(smem + kPatchWinBytes + kPatchRowBytes);
+  __shared__ __attribute__((aligned(16))) unsigned char smem[kPatchThreads * sizeof(PatchRec) + 2 * kPatchMaxTiles * 16];
+  PatchRec *recs = reinterpret_cast<PatchRec *>(smem);
   unsigned long long *s_mask = reinterpret_cast<unsigned long long *>(recs + kPatchThreads);   // [2][kPatchMaxTiles]
   long long *s_slot = reinterpret_cast<long long *>(s_mask + 2 * kPatchMaxTiles);              // [2][kPatchMaxTiles]
   PatchBlock b;
   if (!patch_block(plan, d, nblk_padded, b)) return;
   const int tid = threadIdx.x;
-  if (tid < kD48) reinterpret_cast<float *>(smem + kPatchWinBytes)[tid] = 0.f;
   const PatchLevel lvq = plan.lv[b.lq];
   const int LP = d.L * kPatchP;
   const int rd = tid >> 2, pd = tid & 3;
@@ -428,11 +262,9 @@ __global__ __launch_bounds__(kPatchThreads) void msda_bwd_d48_patchbin_kernel(
   for (int l = 0; l < kPatchMaxLevels; ++l) {
     if (l >= plan.L) break;
     const PatchLevel lvl = plan.lv[l];
-    const PatchWindow w = patch_window(plan, b, l);
     const PatchTileBox tb = patch_tile_box(plan, b, l);
     unsigned long long *mask_l = s_mask + (l & 1) * kPatchMaxTiles;
     const long long *slot_l = s_slot + (l & 1) * kPatchMaxTiles;
-    if (!(plan.debug & 1)) patch_stage(value, d, b, lvl, w, win);
     {
       const float2 xy = xy_l[l];
       const float a_in = a_l[l];
@@ -444,14 +276,11 @@ __global__ __launch_bounds__(kPatchThreads) void msda_bwd_d48_patchbin_kernel(
       const int y0 = (int)yf, x0 = (int)xf;
       PatchRec r;
       r.w.x = inside ? y - yf : 0.f; r.w.y = inside ? x - xf : 0.f; r.w.z = inside ? a_in : 0.f;
-      unsigned lo[4], go[4], bits = 0u;
+      unsigned go[4], bits = 0u;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const int ty = y0 + (k >> 1), tx = x0 + (k & 1);
         const bool in_map = inside && ty >= 0 && ty <= lvl.H - 1 && tx >= 0 && tx <= lvl.W - 1;
-        const int wy = ty - w.y0, wx = tx - w.x0;
-        const bool in_win = in_map && wy >= 0 && wy < w.h && wx >= 0 && wx < w.w;
-        lo[k] = in_win ? (unsigned)(wy * w.w + wx) * kPatchRowBytes : (unsigned)kPatchWinBytes;
         go[k] = in_map ? gbase + (unsigned)(lvl.start + ty * lvl.W + tx) * px_stride : kOobOffset;
         bool owned = false;
         if (near && in_map) {
@@ -464,15 +293,13 @@ __global__ __launch_bounds__(kPatchThreads) void msda_bwd_d48_patchbin_kernel(
             }
           }
         }
-        bits |= (in_map && !in_win) ? (1u << k) : 0u;           // far: gather from global memory
         bits |= (in_map && !owned) ? (16u << k) : 0u;           // need: no tile owns the tap -> HBM atomic here
       }
       r.w.w = __uint_as_float(bits);
-      r.lds.x = lo[0]; r.lds.y = lo[1]; r.lds.z = lo[2]; r.lds.w = lo[3];
       r.g.x = go[0]; r.g.y = go[1]; r.g.z = go[2]; r.g.w = go[3];
       recs[tid] = r;
     }
-    __syncthreads();     // window landed, records and masks complete
+    __syncthreads();     // records and masks complete
 
     if (tid < kPatchMaxTiles && slot_l[tid] >= 0 && mask_l[tid] != 0ull) plan.marks[slot_l[tid]] = mask_l[tid];
     if (l + 1 < plan.L) fill_slots(l + 1);
@@ -484,30 +311,19 @@ __global__ __launch_bounds__(kPatchThreads) void msda_bwd_d48_patchbin_kernel(
       unsigned allbits = 0u;
 #pragma unroll
       for (int p = 0; p < kPatchP; ++p) allbits |= __float_as_uint(mine[p].w.w);
-      const bool any_far = __builtin_amdgcn_ballot_w64((allbits & 15u) != 0u) != 0ull;
       float keep_a = 0.f, keep_x = 0.f, keep_y = 0.f;
 #pragma unroll
       for (int p = 0; p < kPatchP; ++p) {
         const PatchRec r = mine[p];
         const float lh = r.w.x, lw = r.w.y, a = r.w.z;
-        const unsigned bits = __float_as_uint(r.w.w);
         const float hh = 1.f - lh, hw = 1.f - lw;
-        const unsigned lo[4] = {r.lds.x, r.lds.y, r.lds.z, r.lds.w};
         const unsigned go[4] = {r.g.x, r.g.y, r.g.z, r.g.w};
         float dot[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const Row6 v = lds_row(win, lo[k], j);
+        for (int k = 0; k < 4; ++k) {          // (a tap outside the map has offset kOobOffset: the buffer load returns 0)
+          const Row6 v = buf_row(vsrc, go[k], j);
           dot[k] = g[ps][0] * v.a.x + g[ps][1] * v.a.y + g[ps][2] * v.a.z + g[ps][3] * v.a.w + g[ps][4] * v.b.x +
                    g[ps][5] * v.b.y;
-        }
-        if (any_far && __builtin_amdgcn_ballot_w64((bits & 15u) != 0u) != 0ull) {
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const Row6 v = buf_row(vsrc, ((bits >> k) & 1u) ? go[k] : kOobOffset, j);
-            dot[k] += g[ps][0] * v.a.x + g[ps][1] * v.a.y + g[ps][2] * v.a.z + g[ps][3] * v.a.w + g[ps][4] * v.b.x +
-                      g[ps][5] * v.b.y;
-          }
         }
         float pa = hh * hw * dot[0] + hh * lw * dot[1] + lh * hw * dot[2] + lh * lw * dot[3];
         float px = hh * (dot[1] - dot[0]) + lh * (dot[3] - dot[2]);
@@ -558,7 +374,7 @@ __global__ __launch_bounds__(kPatchThreads) void msda_bwd_d48_patchbin_kernel(
         }
       }
     }
-    __syncthreads();     // before the window, the records and the other half of the slots are overwritten
+    __syncthreads();     // before the records and the other half of the slots are overwritten
   }
 }
 
@@ -566,16 +382,19 @@ __global__ __launch_bounds__(kPatchThreads) void msda_bwd_d48_patchbin_kernel(
 // Backward, grad_value side: one workgroup per (n, m, tile)
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int kTile2MaxPx = 256;
+constexpr int kTile2HitList = 1536;   // hits expanded per pass over a tile (a tile of the 600x800 geometry has ~700)
 template <int HITCAP, bool GO_BF16> struct Tile2Lds {
-  static constexpr int kRowB = GO_BF16 ? 96 : 192;
-  __attribute__((aligned(16))) unsigned char rows[HITCAP * kRowB];   // grad_out rows of the round's hits (LDS-DMA)
-  int2 tap[HITCAP * 16];              // sorted taps of the round: (hit index, weight bits)
-  int hits[HITCAP];                   // queries of the round
+  // grad_out rows of the round's hits, float32 (bf16 rows are widened once while they are staged: 6 conversions per
+  // row and lane instead of 6 per tap)
+  __attribute__((aligned(16))) unsigned char rows[HITCAP * 192];
+  int2 tap[HITCAP * 16];              // sorted taps of the round: (hit index within the round, weight bits)
+  int hits[kTile2HitList];            // queries with a mark in this tile
   int cntw[4][kTile2MaxPx];           // per wave and pixel: taps counted, then the wave's first position
   int off[kTile2MaxPx + 1];           // exclusive prefix over pixels
   int wsum[4];
   int total_hits;
 };
+
 
 __device__ __forceinline__ int block_incl_scan(int v, int *wsum, int tid) {
   int inc = v;
@@ -585,7 +404,7 @@ __device__ __forceinline__ int block_incl_scan(int v, int *wsum, int tid) {
     inc += ((tid & 63) >= o) ? up : 0;
   }
   if ((tid & 63) == 63) wsum[tid >> 6] = inc;
-  __syncthreads();
+  lds_barrier();
   int before = 0;
   for (int w = 0; w < (tid >> 6); ++w) before += wsum[w];
   return before + inc;
@@ -594,21 +413,13 @@ __device__ __forceinline__ int block_incl_scan(int v, int *wsum, int tid) {
 // one tap: acc += w * row, the row held in LDS as bf16 (96 B) or f32 (192 B); lane j owns channels 4j..4j+3, 32+2j, 33+2j
 template <bool GO_BF16>
 __device__ __forceinline__ void tile2_fma(float (&a6)[6], float w, const unsigned char *rows, int h, int j) {
-  if constexpr (GO_BF16) {
-    const uint2 pa = *reinterpret_cast<const uint2 *>(rows + h * 96 + 8 * j);
-    const unsigned pb = *reinterpret_cast<const unsigned *>(rows + h * 96 + 64 + 4 * j);
-    a6[0] = fmaf(w, __uint_as_float(pa.x << 16), a6[0]); a6[1] = fmaf(w, __uint_as_float(pa.x & 0xffff0000u), a6[1]);
-    a6[2] = fmaf(w, __uint_as_float(pa.y << 16), a6[2]); a6[3] = fmaf(w, __uint_as_float(pa.y & 0xffff0000u), a6[3]);
-    a6[4] = fmaf(w, __uint_as_float(pb << 16), a6[4]);   a6[5] = fmaf(w, __uint_as_float(pb & 0xffff0000u), a6[5]);
-  } else {
-    const Row6 v = lds_row(rows, (unsigned)h * 192u, j);
-    a6[0] = fmaf(w, v.a.x, a6[0]); a6[1] = fmaf(w, v.a.y, a6[1]); a6[2] = fmaf(w, v.a.z, a6[2]);
-    a6[3] = fmaf(w, v.a.w, a6[3]); a6[4] = fmaf(w, v.b.x, a6[4]); a6[5] = fmaf(w, v.b.y, a6[5]);
-  }
+  const Row6 v = lds_row(rows, (unsigned)h * 192u, j);
+  a6[0] = fmaf(w, v.a.x, a6[0]); a6[1] = fmaf(w, v.a.y, a6[1]); a6[2] = fmaf(w, v.a.z, a6[2]);
+  a6[3] = fmaf(w, v.a.w, a6[3]); a6[4] = fmaf(w, v.b.x, a6[4]); a6[5] = fmaf(w, v.b.y, a6[5]);
 }
 
 template <int HITCAP, bool GO_BF16>
-__global__ __launch_bounds__(kPatchThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void msda_bwd_d48_tile2_kernel(
+__global__ __launch_bounds__(kPatchThreads) __attribute__((amdgpu_waves_per_eu(3, 3))) void msda_bwd_d48_tile2_kernel(
     const void *__restrict__ grad_out, const float *__restrict__ loc, const float *__restrict__ attn, CoreDims d,
     PatchPlan plan, float *__restrict__ grad_value) {
   __shared__ Tile2Lds<HITCAP, GO_BF16> S;
@@ -656,7 +467,8 @@ __global__ __launch_bounds__(kPatchThreads) __attribute__((amdgpu_waves_per_eu(4
   const int my_cnt = __popcll(mask);
   const int my_excl = block_incl_scan(my_cnt, S.wsum, tid) - my_cnt;
   if (tid == kPatchThreads - 1) S.total_hits = my_excl + my_cnt;
-  __syncthreads();
+  for (int i = tid; i < 4 * kTile2MaxPx; i += kPatchThreads) (&S.cntw[0][0])[i] = 0;
+  lds_barrier();
   const int total_hits = (plan.debug & 8) ? 0 : S.total_hits;
 
   // accumulators: 32 groups of 8 lanes own the tile's pixels
@@ -669,145 +481,192 @@ __global__ __launch_bounds__(kPatchThreads) __attribute__((amdgpu_waves_per_eu(4
     for (int c = 0; c < 6; ++c) acc[u][c] = 0.f;
   const unsigned char *go_nm = reinterpret_cast<const unsigned char *>(grad_out) + (row_base * d.M + m) * kRowB;
   const size_t q_stride = (size_t)d.M * kRowB;
+  const float *loc_nm = loc + ((row_base * d.M + m) * LP + l * kPatchP + (tid & 3)) * 2;
+  const float *attn_nm = attn + (row_base * d.M + m) * LP + l * kPatchP + (tid & 3);
+  const size_t s_stride = (size_t)d.M * LP;
 
-  for (int lo = 0; lo < total_hits; lo += HITCAP) {
-    const int hi = min(lo + HITCAP, total_hits), nh = hi - lo;
-    // ---- expand the marks into this round's hit list (order: candidate, then bit -- fixed) ----
-    if (my_cnt && my_excl < hi && my_excl + my_cnt > lo) {
+  for (int pass0 = 0; pass0 < total_hits; pass0 += kTile2HitList) {
+    const int pass1 = min(pass0 + kTile2HitList, total_hits), np = pass1 - pass0;
+    // ---- expand the marks into the hit list (order: candidate, then bit -- fixed) ----
+    if (my_cnt && my_excl < pass1 && my_excl + my_cnt > pass0) {
       unsigned long long mm = mask;
       int gi = my_excl;
       const PatchLevel &lq_ = plan.lv[c_lq];
       while (mm) {
         const int i = __builtin_ctzll(mm);
         mm &= mm - 1;
-        if (gi >= lo && gi < hi) S.hits[gi - lo] = lq_.start + (c_by * kPatchB + (i >> 3)) * lq_.W + c_bx * kPatchB + (i & 7);
+        if (gi >= pass0 && gi < pass1)
+          S.hits[gi - pass0] = lq_.start + (c_by * kPatchB + (i >> 3)) * lq_.W + c_bx * kPatchB + (i & 7);
         ++gi;
       }
     }
-    for (int i = tid; i < 4 * tpx; i += kPatchThreads) S.cntw[i / tpx][i % tpx] = 0;
-    __syncthreads();
-    // ---- the hits' grad_out rows -> LDS by LDS-DMA (lands behind the decode below) ----
-    if (!(plan.debug & 1)) {
-      constexpr int gpr = kRowB / 16;
-      const int G = nh * gpr;
-      for (int g0 = 0; g0 < G; g0 += kPatchThreads) {
-        const int g = g0 + tid;
-        if (g < G) {
-          const int h = g / gpr, piece = g - h * gpr;
-          const unsigned char *src = go_nm + (size_t)S.hits[h] * q_stride + piece * 16;
-          unsigned char *dst = S.rows + (size_t)(g - (tid & 63)) * 16;
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                           (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+    lds_barrier();
+    // this thread's samples of the first round (later rounds: fetched behind the previous round's accumulate phase)
+    float2 n_xy[kItems];
+    float n_a[kItems];
+    auto fetch = [&](int lo_, int nh_) {
+#pragma unroll
+      for (int it = 0; it < kItems; ++it) {
+        const int h = (tid + it * kPatchThreads) >> 2;
+        n_xy[it] = make_float2(-4.f, -4.f); n_a[it] = 0.f;      // (a location outside every map: decodes to "not near")
+        if (h < nh_ && !(plan.debug & 4)) {
+          const size_t so = (size_t)S.hits[lo_ + h] * s_stride;
+          n_xy[it] = *reinterpret_cast<const float2 *>(loc_nm + 2 * so);
+          n_a[it] = attn_nm[so];
         }
       }
-    }
-    // ---- decode: item = (hit h, point p); rank every tap of this tile within its (wave, pixel) ----
-    unsigned t_pix[kItems], t_ok[kItems];   // 4 x 8 bits: pixel of each tap; bit k: tap k is in this tile
-    unsigned t_rank[kItems][2];        // 4 x 16 bits
-    float t_w[kItems][4];
+    };
+    fetch(0, min(HITCAP, np));
+
+    for (int lo = 0; lo < np; lo += HITCAP) {
+      const int nh = min(HITCAP, np - lo);
+      // ---- the hits' grad_out rows -> LDS: float32 rows by LDS-DMA, bfloat16 rows through registers (issued here,
+      //      widened and written behind decode / prefix / scatter) ----
+      constexpr int kPieces = HITCAP * 6 / kPatchThreads;       // bf16: 16-B pieces (8 channels) per thread and round
+      u32x4 pc[kPieces];
+      if constexpr (GO_BF16) {
 #pragma unroll
-    for (int it = 0; it < kItems; ++it) {
-      const int h = (tid + it * kPatchThreads) >> 2, p = tid & 3;
-      t_pix[it] = 0u; t_ok[it] = 0u; t_rank[it][0] = t_rank[it][1] = 0u;
+        for (int i = 0; i < kPieces; ++i) {
+          const int g = tid + i * kPatchThreads, h = g / 6, piece = g - h * 6;
+          pc[i] = u32x4{0u, 0u, 0u, 0u};
+          if (h < nh && !(plan.debug & 1))
+            pc[i] = *reinterpret_cast<const u32x4 *>(go_nm + (size_t)S.hits[lo + h] * q_stride + piece * 16);
+        }
+      } else if (!(plan.debug & 1)) {
+        constexpr int gpr = kRowB / 16;
+        const int G = nh * gpr;
+        for (int g0 = 0; g0 < G; g0 += kPatchThreads) {
+          const int g = g0 + tid;
+          if (g < G) {
+            const int h = g / gpr, piece = g - h * gpr;
+            const unsigned char *src = go_nm + (size_t)S.hits[lo + h] * q_stride + piece * 16;
+            unsigned char *dst = S.rows + (size_t)(g - (tid & 63)) * 16;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+          }
+        }
+      }
+      // ---- decode: item = (hit h, point p); rank every tap of this tile within its (wave, pixel) ----
+      unsigned t_pix[kItems], t_ok[kItems];   // 4 x 8 bits: pixel of each tap; bit k: tap k is in this tile
+      unsigned t_rank[kItems][2];             // 4 x 16 bits
+      float t_w[kItems][4];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) t_w[it][k] = 0.f;
-      if (h < nh && !(plan.debug & 4)) {
-        const int q = S.hits[h];
-        int lq = 0;
-        for (int i = 1; i < plan.L; ++i) lq = (q >= plan.lv[i].start) ? i : lq;
-        const int rq = q - plan.lv[lq].start;
-        const int qy = rq / plan.lv[lq].W, qx = rq - qy * plan.lv[lq].W;
-        const size_t li = ((row_base + q) * d.M + m) * LP + l * kPatchP + p;
-        const float2 xy = *reinterpret_cast<const float2 *>(loc + 2 * li);
-        const float x = px_coord(xy.x, me.W), y = px_coord(xy.y, me.H);
-        const bool inside = (y > -1.f) && (x > -1.f) && (y < (float)me.H) && (x < (float)me.W);
-        const bool near = inside && near_anchor(x, y, anchor_coord(qx, me.W, plan.lv[lq].W),
-                                                anchor_coord(qy, me.H, plan.lv[lq].H), plan.radius);
-        if (near) {
-          const float a = attn[li];
-          const float yf = floorf(y), xf = floorf(x);
-          const int y0 = (int)yf, x0 = (int)xf;
-          const float lh = y - yf, lw = x - xf, hh = 1.f - lh, hw = 1.f - lw;
-          const float w4[4] = {hh * hw * a, hh * lw * a, lh * hw * a, lh * lw * a};
+      for (int it = 0; it < kItems; ++it) {
+        const int h = (tid + it * kPatchThreads) >> 2;
+        t_pix[it] = 0u; t_ok[it] = 0u; t_rank[it][0] = t_rank[it][1] = 0u;
 #pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const int ty = y0 + (k >> 1), tx = x0 + (k & 1);
-            const bool in_map = ty >= 0 && ty <= me.H - 1 && tx >= 0 && tx <= me.W - 1;
-            const bool mine = in_map && (ty >> me.shift) == tyi && (tx >> me.shift) == txi;
-            if (mine) {
-              const int pix = ((ty - ty0) << me.shift) + (tx - tx0);
-              const int rank = atomicAdd(&S.cntw[wave][pix], 1);
-              t_pix[it] |= (unsigned)pix << (8 * k);
-              t_ok[it] |= 1u << k;
-              t_rank[it][k >> 1] |= (unsigned)rank << (16 * (k & 1));
-              t_w[it][k] = w4[k];
+        for (int k = 0; k < 4; ++k) t_w[it][k] = 0.f;
+        const float x = px_coord(n_xy[it].x, me.W), y = px_coord(n_xy[it].y, me.H);
+        const bool inside = h < nh && (y > -1.f) && (x > -1.f) && (y < (float)me.H) && (x < (float)me.W);
+        if (inside) {
+          const int q = S.hits[lo + h];
+          int lq = 0;
+          for (int i = 1; i < plan.L; ++i) lq = (q >= plan.lv[i].start) ? i : lq;
+          const int rq = q - plan.lv[lq].start;
+          const int qy = rq / plan.lv[lq].W, qx = rq - qy * plan.lv[lq].W;
+          if (near_anchor(x, y, anchor_coord(qx, me.W, plan.lv[lq].W), anchor_coord(qy, me.H, plan.lv[lq].H), plan.radius)) {
+            const float a = n_a[it];
+            const float yf = floorf(y), xf = floorf(x);
+            const int y0 = (int)yf, x0 = (int)xf;
+            const float lh = y - yf, lw = x - xf, hh = 1.f - lh, hw = 1.f - lw;
+            const float w4[4] = {hh * hw * a, hh * lw * a, lh * hw * a, lh * lw * a};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const int ty = y0 + (k >> 1), tx = x0 + (k & 1);
+              const bool in_map = ty >= 0 && ty <= me.H - 1 && tx >= 0 && tx <= me.W - 1;
+              const bool mine = in_map && (ty >> me.shift) == tyi && (tx >> me.shift) == txi;
+              if (mine) {
+                const int pix = ((ty - ty0) << me.shift) + (tx - tx0);
+                const int rank = atomicAdd(&S.cntw[wave][pix], 1);
+                t_pix[it] |= (unsigned)pix << (8 * k);
+                t_ok[it] |= 1u << k;
+                t_rank[it][k >> 1] |= (unsigned)rank << (16 * (k & 1));
+                t_w[it][k] = w4[k];
+              }
             }
           }
         }
       }
-    }
-    __syncthreads();     // ranks complete; (vmcnt(0) in front of the barrier: the rows have landed)
-    // ---- exclusive prefix over pixels; per wave the position of its first tap of every pixel ----
-    {
-      int c[4] = {0, 0, 0, 0};
-      if (tid < tpx) {
+      lds_barrier();     // ranks complete
+      // ---- exclusive prefix over pixels; per wave the position of its first tap of every pixel ----
+      {
+        int c[4] = {0, 0, 0, 0};
+        if (tid < tpx) {
 #pragma unroll
-        for (int w = 0; w < 4; ++w) c[w] = S.cntw[w][tid];
+          for (int w = 0; w < 4; ++w) c[w] = S.cntw[w][tid];
+        }
+        const int tot = c[0] + c[1] + c[2] + c[3];
+        const int incl = block_incl_scan(tot, S.wsum, tid);
+        if (tid < tpx) {
+          int base = incl - tot;
+          S.off[tid] = base;
+#pragma unroll
+          for (int w = 0; w < 4; ++w) { S.cntw[w][tid] = base; base += c[w]; }
+        }
+        if (tid == kPatchThreads - 1) S.off[tpx] = incl;      // (threads >= tpx carry the total)
       }
-      const int tot = c[0] + c[1] + c[2] + c[3];
-      const int incl = block_incl_scan(tot, S.wsum, tid);
-      if (tid < tpx) {
-        int base = incl - tot;
-        S.off[tid] = base;
+      lds_barrier();
+      // ---- scatter the taps into pixel order ----
 #pragma unroll
-        for (int w = 0; w < 4; ++w) { S.cntw[w][tid] = base; base += c[w]; }
-      }
-      if (tid == kPatchThreads - 1) S.off[tpx] = incl;      // (threads >= tpx carry the total)
-    }
-    __syncthreads();
-    // ---- scatter the taps into pixel order ----
+      for (int it = 0; it < kItems; ++it) {
+        const int h = (tid + it * kPatchThreads) >> 2;
 #pragma unroll
-    for (int it = 0; it < kItems; ++it) {
-      const int h = (tid + it * kPatchThreads) >> 2;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        if ((t_ok[it] >> k) & 1u) {
-          const unsigned pix = (t_pix[it] >> (8 * k)) & 0xffu;
-          const int pos = S.cntw[wave][pix] + (int)((t_rank[it][k >> 1] >> (16 * (k & 1))) & 0xffffu);
-          S.tap[pos] = make_int2(h, __float_as_int(t_w[it][k]));
+        for (int k = 0; k < 4; ++k) {
+          if ((t_ok[it] >> k) & 1u) {
+            const unsigned pix = (t_pix[it] >> (8 * k)) & 0xffu;
+            const int pos = S.cntw[wave][pix] + (int)((t_rank[it][k >> 1] >> (16 * (k & 1))) & 0xffffu);
+            S.tap[pos] = make_int2(h, __float_as_int(t_w[it][k]));
+          }
         }
       }
-    }
-    __syncthreads();
-    // ---- accumulate: every pixel by one group (tiles of < 32 pixels: 32 / tpx groups share a pixel's taps) ----
-    if (!(plan.debug & 2)) {
-      auto run = [&](float (&a6)[6], int b0, int e0) {
-        const int last = e0 - 1;
-        for (int e = b0; e < e0; e += 4) {
-          const int2 r0 = S.tap[e], r1 = S.tap[min(e + 1, last)], r2 = S.tap[min(e + 2, last)], r3 = S.tap[min(e + 3, last)];
-          const float w0 = __int_as_float(r0.y), w1 = e + 1 < e0 ? __int_as_float(r1.y) : 0.f;
-          const float w2 = e + 2 < e0 ? __int_as_float(r2.y) : 0.f, w3 = e + 3 < e0 ? __int_as_float(r3.y) : 0.f;
-          tile2_fma<GO_BF16>(a6, w0, S.rows, r0.x, j);
-          tile2_fma<GO_BF16>(a6, w1, S.rows, r1.x, j);
-          tile2_fma<GO_BF16>(a6, w2, S.rows, r2.x, j);
-          tile2_fma<GO_BF16>(a6, w3, S.rows, r3.x, j);
-        }
-      };
-      if (tpx >= 32) {
+      if constexpr (GO_BF16) {
 #pragma unroll
-        for (int u = 0; u < kMaxU; ++u) {
-          if (u < (tpx >> 5)) {
-            const int pix = grp + 32 * u;
-            run(acc[u], S.off[pix], S.off[pix + 1]);
+        for (int i = 0; i < kPieces; ++i) {
+          const int g = tid + i * kPatchThreads, h = g / 6, piece = g - h * 6;
+          if (h < nh) {
+            f32x4 lo4, hi4;
+            lo4.x = __uint_as_float(pc[i].x << 16); lo4.y = __uint_as_float(pc[i].x & 0xffff0000u);
+            lo4.z = __uint_as_float(pc[i].y << 16); lo4.w = __uint_as_float(pc[i].y & 0xffff0000u);
+            hi4.x = __uint_as_float(pc[i].z << 16); hi4.y = __uint_as_float(pc[i].z & 0xffff0000u);
+            hi4.z = __uint_as_float(pc[i].w << 16); hi4.w = __uint_as_float(pc[i].w & 0xffff0000u);
+            *reinterpret_cast<f32x4 *>(S.rows + h * 192 + piece * 32) = lo4;
+            *reinterpret_cast<f32x4 *>(S.rows + h * 192 + piece * 32 + 16) = hi4;
           }
         }
       } else {
-        const int pix = grp & (tpx - 1), s = grp >> tsh, gpp = 32 >> tsh;
-        const int b0 = S.off[pix], nt = S.off[pix + 1] - b0;
-        run(acc[0], b0 + (nt * s) / gpp, b0 + (nt * (s + 1)) / gpp);
+        vm_drain();      // this wave's share of the rows has landed
       }
+      lds_barrier();     // taps sorted, every wave's rows in LDS
+      // the next round's samples: in flight while this round accumulates
+      if (lo + HITCAP < np) fetch(lo + HITCAP, min(HITCAP, np - lo - HITCAP));
+      for (int i = tid; i < 4 * tpx; i += kPatchThreads) S.cntw[i / tpx][i - (i / tpx) * tpx] = 0;   // for the next round
+      // ---- accumulate: every pixel by one group (tiles of < 32 pixels: 32 / tpx groups share a pixel's taps) ----
+      if (!(plan.debug & 2)) {       // pixels one after the other, 4 taps per trip
+        auto run = [&](float (&a6)[6], int b0, int e0) {
+          const int last = e0 - 1;
+          for (int e = b0; e < e0; e += 4) {
+            const int2 r0 = S.tap[e], r1 = S.tap[min(e + 1, last)], r2 = S.tap[min(e + 2, last)], r3 = S.tap[min(e + 3, last)];
+            const float w0 = __int_as_float(r0.y), w1 = e + 1 < e0 ? __int_as_float(r1.y) : 0.f;
+            const float w2 = e + 2 < e0 ? __int_as_float(r2.y) : 0.f, w3 = e + 3 < e0 ? __int_as_float(r3.y) : 0.f;
+            tile2_fma<GO_BF16>(a6, w0, S.rows, r0.x, j);
+            tile2_fma<GO_BF16>(a6, w1, S.rows, r1.x, j);
+            tile2_fma<GO_BF16>(a6, w2, S.rows, r2.x, j);
+            tile2_fma<GO_BF16>(a6, w3, S.rows, r3.x, j);
+          }
+        };
+        if (tpx >= 32) {
+#pragma unroll
+          for (int u = 0; u < kMaxU; ++u) {
+            if (u < (tpx >> 5)) run(acc[u], S.off[grp + 32 * u], S.off[grp + 32 * u + 1]);
+          }
+        } else {
+          const int pix = grp & (tpx - 1), s = grp >> tsh, gpp = 32 >> tsh;
+          const int pb = S.off[pix], nt = S.off[pix + 1] - pb;
+          run(acc[0], pb + (nt * s) / gpp, pb + (nt * (s + 1)) / gpp);
+        }
+      }
+      lds_barrier();     // before the next round overwrites rows / taps
     }
-    __syncthreads();     // before the next round overwrites hits / rows / taps / counters
   }
 
   // ---- tiles of fewer than 32 pixels: add the groups' partial sums in a fixed order ----
@@ -818,7 +677,7 @@ __global__ __launch_bounds__(kPatchThreads) __attribute__((amdgpu_waves_per_eu(4
 #pragma unroll
       for (int c = 0; c < 6; ++c) comb[(grp * 8 + j) * 6 + c] = acc[0][c];
     }
-    __syncthreads();
+    lds_barrier();
     if (s == 0) {
       for (int o = 1; o < gpp; ++o) {
 #pragma unroll

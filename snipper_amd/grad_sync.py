@@ -1,34 +1,39 @@
-"""Data-parallel gradient synchronisation for the training step: one flat buffer, a few large all-reduces.
+"""Data-parallel gradient synchronisation for the training step: one flat buffer, a few large all-reduces,
+launched stage by stage while backward is still running.
 
 The reference trains with ``torch.nn.parallel.DistributedDataParallel`` (main.py:193-196).  DDP's reducer hooks every
 parameter's gradient accumulator; with the ~330 parameter tensors of this model that is ~15 ms of host work per step
 (measured on MI355X: the step goes from GPU-bound, 49 ms, to host-bound, 57 ms).  The semantics the path needs are
 just "after backward every rank holds the mean of the ranks' gradients", so this module does exactly that:
 
-  * all parameters that require grad own a slice of ONE flat float32 buffer;
+  * all parameters that require grad own a slice of ONE flat float32 buffer, in the order they are given;
   * after ``loss.backward()`` (grads produced with ``zero_grad(set_to_none=True)``, so autograd hands its buffers
     over without an accumulation kernel per parameter), ``sync()`` packs the gradients into the flat buffer with
-    multi-tensor copies, all-reduces it in a few large chunks (RCCL rings over xGMI are per-link bound: few, large
-    messages), scales by 1/world and re-points every ``p.grad`` at its slice -- views with the parameter's own
-    strides (NHWC convolution weights stay NHWC);
+    multi-tensor copies, all-reduces what is still outstanding, scales by 1/world and re-points every ``p.grad`` at its
+    slice -- views with the parameter's own strides (NHWC convolution weights stay NHWC);
   * ``broadcast_parameters()`` makes rank 0's initial weights everybody's, as DDP's constructor does.
 
 Parameters that took no part in the step (``grad is None``) contribute zeros, like DDP with static_graph.
 
-Overlap: backward reaches the backbone last (~1/4 of the step's GPU time, >half of the gradient bytes still to come).
-If ``early`` names the parameters whose gradients are complete before that (everything but the backbone) and
-``trigger`` the ones whose gradients arrive last among them (the 1x1 input projections between backbone and
-encoder), a post-accumulate hook on the trigger parameters packs and all-reduces the early slice while the backbone's
-backward is still running; ``sync()`` then only has the backbone's slice left.  The early launch happens as soon as the
-last trigger gradient is complete, on every rank alike (the same collectives in the same order); autograd's ordering
-makes most early parameters complete by then (their nodes were created after the projections'); one that is completed
-later (e.g. ``level_embed`` on the token-row path, whose gradient also collects the projections' own contribution) is
-detected in ``sync()`` -- its gradient object differs from what was packed -- and reduced there.
+Overlap.  ``stages`` lists contiguous runs of the parameter list in the order backward completes them, each with its
+``trigger`` parameters -- the ones whose gradients arrive LAST within the stage (bench.py: everything but the backbone,
+triggered by the 1x1 input projections; then layer4 / layer3 / layer2 of the ResNet, each triggered by its first
+block).  A post-accumulate hook on the trigger parameters packs the stage's slice and launches its all-reduce as soon
+as the stage's last trigger gradient is complete, while backward goes on with the next stage.  The launch is taken
+unconditionally, on every rank alike (the same collectives in the same order whatever the batch looked like); a
+parameter of the stage whose gradient is completed or replaced AFTER the launch (e.g. ``level_embed`` on the token-row
+path, whose gradient also collects the projections' own contribution) is detected in ``sync()`` by object identity -- a
+property of the graph, hence the same on every rank -- and its slice is reduced again there, strictly after the first
+all-reduce of that slice has completed.
+
+Contract: ONE backward per ``sync()``, and gradients reset with ``set_to_none=True`` (or ``FlatParameters.
+drop_param_grads()``) in between.  A second backward before ``sync()`` or a gradient that still is last step's view of
+the flat buffer would silently corrupt a slice that is being all-reduced, so both raise.
 """
 from __future__ import annotations
 
 import os
-from typing import Iterable, List
+from typing import Iterable, List, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
@@ -53,15 +58,28 @@ def _dense_view(flat: torch.Tensor, offset: int, like: torch.Tensor) -> torch.Te
     return flat.as_strided(like.shape, like.stride(), offset)
 
 
+class _Stage:
+    __slots__ = ("lo", "hi", "lo_elem", "hi_elem", "triggers", "pending", "launched", "works", "seen")
+
+    def __init__(self, lo, hi, lo_elem, hi_elem, triggers):
+        self.lo, self.hi, self.lo_elem, self.hi_elem = lo, hi, lo_elem, hi_elem
+        self.triggers = triggers
+        self.pending, self.launched, self.works, self.seen = len(triggers), False, [], []
+
+
 class FlatGradSync:
     def __init__(self, params: Iterable[torch.nn.Parameter], group=None, chunks: int = 4,
-                 early: Iterable[torch.nn.Parameter] = (), trigger: Iterable[torch.nn.Parameter] = ()):
+                 early: Iterable[torch.nn.Parameter] = (), trigger: Iterable[torch.nn.Parameter] = (),
+                 stages: Optional[Sequence[Tuple[Sequence[torch.nn.Parameter], Sequence[torch.nn.Parameter]]]] = None):
+        """``stages``: [(parameters, trigger parameters), ...] in the order backward completes them; every stage must
+        be a contiguous run of ``params``.  ``early`` / ``trigger`` is the one-stage shorthand; for it alone the early
+        parameters are moved to the front of the flat layout."""
         params = [p for p in params if p.requires_grad]
-        early_ids = {id(p) for p in early if p.requires_grad}
-        # flat layout: [early | rest]
-        self.params: List[torch.nn.Parameter] = [p for p in params if id(p) in early_ids] + \
-                                                [p for p in params if id(p) not in early_ids]
-        self.n_early = sum(1 for p in params if id(p) in early_ids)
+        if stages is None:
+            early_ids = {id(p) for p in early if p.requires_grad}
+            params = [p for p in params if id(p) in early_ids] + [p for p in params if id(p) not in early_ids]
+            stages = [([p for p in params if id(p) in early_ids], list(trigger))] if early_ids else []
+        self.params: List[torch.nn.Parameter] = params
         assert self.params, "no trainable parameters"
         dev, dt = self.params[0].device, torch.float32
         assert all(p.device == dev and p.dtype == dt for p in self.params), "float32 parameters on one device expected"
@@ -72,26 +90,39 @@ class FlatGradSync:
         self.offsets, total = flat_offsets(self.params)
         self.flat = torch.zeros(total, dtype=dt, device=dev)
         self.views = [_dense_view(self.flat, off, p) for off, p in zip(self.offsets, self.params)]
-        ends = self.offsets[1:] + [total]                      # (padded) end of every parameter's slice
-        # chunk boundaries on parameter boundaries: contiguous slices of the flat buffer
-        self.chunks, start, target = [], 0, (total + chunks - 1) // max(1, chunks)
-        for end in ends:
-            if end - start >= target:
-                self.chunks.append((start, end))
-                start = end
-        if start < total:
-            self.chunks.append((start, total))
-        self.early_elems = self.offsets[self.n_early] if self.n_early < len(self.params) else total
-        self._early_works, self._early_done, self._early_seen = [], False, []
-        self._trigger = [p for p in trigger if p.requires_grad]
-        self._pending = len(self._trigger)
-        if self.n_early and self._trigger and self.collective:
-            for p in self._trigger:
-                p.register_post_accumulate_grad_hook(self._on_trigger)
+        self._view_ids = {id(v) for v in self.views}
+        self.max_chunk = (total + max(1, chunks) - 1) // max(1, chunks)
+        index = {id(p): i for i, p in enumerate(self.params)}
+        self.stages: List[_Stage] = []
+        covered = set()
+        for sp, trig in stages:
+            idx = sorted(index[id(p)] for p in sp if p.requires_grad)
+            if not idx:
+                continue
+            assert idx == list(range(idx[0], idx[-1] + 1)), "a stage must be a contiguous run of the parameter list"
+            assert not (covered & set(idx)), "stages overlap"
+            covered |= set(idx)
+            hi_elem = self.offsets[idx[-1] + 1] if idx[-1] + 1 < len(self.params) else total
+            trig = [p for p in trig if p.requires_grad]
+            assert all(id(p) in index for p in trig)
+            self.stages.append(_Stage(idx[0], idx[-1] + 1, self.offsets[idx[0]], hi_elem, trig))
+        # whatever no stage covers is reduced by sync()
+        self.rest = [(i, i + 1) for i in range(len(self.params)) if i not in covered]
+        self.n_early = self.stages[0].hi if self.stages and self.stages[0].lo == 0 else 0     # (kept for callers / tests)
+        self.early_elems = self.stages[0].hi_elem if self.n_early else 0
+        if self.collective:
+            for st in self.stages:
+                for p in st.triggers:
+                    p.register_post_accumulate_grad_hook(lambda _p, st=st: self._on_trigger(st))
 
+    # ------------------------------------------------------------------------------------------------------------
     def _pack(self, lo: int, hi: int) -> None:
-        have = [(v, p.grad) for v, p in zip(self.views[lo:hi], self.params[lo:hi])
-                if p.grad is not None and p.grad is not v]
+        stale = [i for i in range(lo, hi) if self.params[i].grad is not None and id(self.params[i].grad) in self._view_ids]
+        if stale:
+            raise RuntimeError(
+                "FlatGradSync: a parameter's .grad still is last step's view of the flat buffer (autograd accumulated into "
+                "it in place). Reset gradients with set_to_none=True / FlatParameters.drop_param_grads() before backward.")
+        have = [(v, p.grad) for v, p in zip(self.views[lo:hi], self.params[lo:hi]) if p.grad is not None]
         missing = [v for v, p in zip(self.views[lo:hi], self.params[lo:hi]) if p.grad is None]
         if missing:
             torch._foreach_zero_(missing)
@@ -99,25 +130,28 @@ class FlatGradSync:
             torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
 
     def _reduce(self, lo_elem: int, hi_elem: int):
-        works = []
-        for a, b in self.chunks:
-            a, b = max(a, lo_elem), min(b, hi_elem)
-            if a < b:
-                works.append(dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        works, a = [], lo_elem
+        while a < hi_elem:                       # few, large messages: RCCL rings over xGMI are per-link bound
+            b = min(hi_elem, a + self.max_chunk)
+            works.append(dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            a = b
         return works
 
     @torch.no_grad()
-    def _on_trigger(self, _param) -> None:
+    def _on_trigger(self, st: _Stage) -> None:
         """Runs on the autograd thread when one trigger parameter's gradient is complete."""
-        self._pending -= 1
-        if self._pending > 0 or self._early_done:
+        if st.launched:
+            raise RuntimeError("FlatGradSync: a second backward reached a stage whose all-reduce is already in flight; "
+                               "call sync() after every backward (no gradient accumulation across backwards)")
+        st.pending -= 1
+        if st.pending > 0:
             return
-        # Taken unconditionally once the last trigger has fired, so that every rank issues the same collectives in the
-        # same order whatever its batch looked like; an early parameter without a gradient contributes zeros.
-        self._early_seen = [p.grad for p in self.params[:self.n_early]]      # what was packed (None = zeros)
-        self._pack(0, self.n_early)
-        self._early_works = self._reduce(0, self.early_elems)
-        self._early_done = True
+        # Taken unconditionally once the stage's last trigger has fired, so that every rank issues the same collectives in
+        # the same order whatever its batch looked like; a parameter without a gradient contributes zeros.
+        st.seen = [p.grad for p in self.params[st.lo:st.hi]]          # what was packed (None = zeros)
+        self._pack(st.lo, st.hi)
+        st.works = self._reduce(st.lo_elem, st.hi_elem)
+        st.launched = True
 
     @torch.no_grad()
     def broadcast_parameters(self, modules_or_tensors: Iterable[torch.Tensor], src: int = 0) -> None:
@@ -131,24 +165,47 @@ class FlatGradSync:
     @torch.no_grad()
     def sync(self) -> None:
         """Mean of the ranks' gradients into every ``p.grad`` (collective: every rank must call it)."""
-        first = self.n_early if self._early_done else 0
-        self._pack(first, len(self.params))
+        works = []
+        # 1) everything that was not launched from a hook: pack and reduce now (stage by stage, then the uncovered rest)
+        for st in self.stages:
+            if not st.launched:
+                self._pack(st.lo, st.hi)
+                if self.collective:
+                    works += self._reduce(st.lo_elem, st.hi_elem)
+        for lo, hi in self.rest:
+            self._pack(lo, hi)
+            if self.collective:
+                hi_elem = self.offsets[hi] if hi < len(self.params) else self.flat.numel()
+                works += self._reduce(self.offsets[lo], hi_elem)
+        # 2) wait for EVERY in-flight all-reduce before touching a slice again: the collective runs on the process
+        #    group's own stream, so a late gradient copied into a slice that is still being reduced would race with it
+        for st in self.stages:
+            works += st.works
+        for w in works:
+            w.wait()
+        # 3) gradients completed (or replaced) after their stage's launch: their slices hold a reduced stale value; put the
+        #    complete local gradient there and reduce those slices again
         late = []
-        if self._early_done:
-            # an "early" gradient that was completed (or replaced) after the early launch -- a property of the graph,
-            # hence the same on every rank: its slice is packed and reduced now
-            for i, p in enumerate(self.params[:self.n_early]):
-                if p.grad is not None and p.grad is not self._early_seen[i] and p.grad is not self.views[i]:
-                    self.views[i].copy_(p.grad)
-                    late.append((self.offsets[i], self.offsets[i] + p.numel()))
-            self._early_seen = []
+        for st in self.stages:
+            if st.launched:
+                for i, p in zip(range(st.lo, st.hi), self.params[st.lo:st.hi]):
+                    g = p.grad
+                    if g is not None and g is not st.seen[i - st.lo]:
+                        if id(g) in self._view_ids:
+                            raise RuntimeError("FlatGradSync: .grad is a stale view of the flat buffer (see _pack)")
+                        self.views[i].copy_(g)
+                        late.append((self.offsets[i], self.offsets[i] + p.numel()))
         if self.collective:
-            works = self._early_works + self._reduce(self.early_elems if self._early_done else 0, self.flat.numel())
-            works += [dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-                      for a, b in late]
-            for w in works:
+            for w in [dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                      for a, b in late]:
                 w.wait()
             self.flat.mul_(1.0 / self.world)
         for v, p in zip(self.views, self.params):
             p.grad = v
-        self._early_works, self._early_done, self._pending = [], False, len(self._trigger)
+        for st in self.stages:
+            st.pending, st.launched, st.works, st.seen = len(st.triggers), False, [], []
+
+    # (tests look at this)
+    @property
+    def _early_done(self) -> bool:
+        return bool(self.stages) and self.stages[0].launched

@@ -29,6 +29,16 @@ ARGS = SimpleNamespace(hidden_dim=192, enc_layers=1, dec_layers=2, frames=2, fut
                        use_pytorch_deform=1, batch=1, height=64, width=96)
 
 
+def _batch(b, rank, mode):
+    """Rank ``rank``'s batch; mode "flat_stages" gives the ranks different numbers of persons (rank r drops r of them)."""
+    imgs, tgt = b.make_batches(ARGS, "cpu", 1, seed=1000 + rank)[0]
+    if mode == "flat_stages" and rank:
+        for t in tgt["targets"]:
+            for k in ("kpts2d", "depth", "traj_ids"):
+                t[k] = t[k][rank:]
+    return imgs, tgt
+
+
 def _worker(rank, world, port, out_dir, mode):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -56,16 +66,19 @@ def _worker(rank, world, port, out_dir, mode):
         # AFTER the early launch -- exercises the late-arrival path of sync()
         trig = list(model.class_embed[0].parameters()) if mode == "flat_late" else list(model.input_proj.parameters())
         g_main, g_backbone, g_slow = b.optimizer_groups(list(model.named_parameters()))
-        gsync = FlatGradSync(g_main + g_slow + g_backbone, chunks=3, early=early, trigger=trig)   # bench.py's order
+        if mode == "flat_stages":        # bench.py's default: transformer, layer4, layer3, layer2 launched from hooks
+            gsync = FlatGradSync(g_main + g_slow + g_backbone, stages=b.grad_sync_stages(model, g_main + g_slow))
+        else:
+            gsync = FlatGradSync(g_main + g_slow + g_backbone, chunks=3, early=early, trigger=trig)   # bench.py's order
         gsync.broadcast_parameters(list(model.parameters()) + list(model.buffers()))
     flatp = None
-    if mode == "flat_params":            # bench.py's default: the optimizer sees one flat leaf per group
+    if mode in ("flat_params", "flat_stages"):   # bench.py's default: the optimizer sees one flat leaf per group
         from snipper_amd.flat_params import FlatParameters
         flatp = FlatParameters([g_main, g_slow, g_backbone], grad_flat=gsync.flat)
     from snipper_amd.criterion import build_criterion
     crit = build_criterion(b.criterion_args(ARGS))
     opt = b.build_optimizer(list(model.named_parameters()), flat=flatp)
-    imgs, tgt = b.make_batches(ARGS, "cpu", 1, seed=1000 + rank)[0]
+    imgs, tgt = _batch(b, rank, mode)
     for it in range(2):
         out, _ = ddp(list(imgs))
         losses, _ = crit(out, tgt["targets"])
@@ -77,6 +90,8 @@ def _worker(rank, world, port, out_dir, mode):
         loss.backward()
         if gsync is not None:
             assert gsync._early_done, "the early slice must have been launched from the hook"
+            if mode == "flat_stages":
+                assert all(st.launched for st in gsync.stages) and len(gsync.stages) == 4
             gsync.sync()
         if it == 0:
             grads = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
@@ -94,16 +109,18 @@ def _worker(rank, world, port, out_dir, mode):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["flat", "flat_late", "flat_params", "torch"])
-def test_two_rank_gloo_step_matches_single_process(tmp_path, mode):
+@pytest.mark.parametrize("mode,world", [("flat", 2), ("flat_late", 2), ("flat_params", 2), ("torch", 2), ("flat_stages", 4)])
+def test_gloo_step_matches_single_process(tmp_path, mode, world):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    mp.spawn(_worker, args=(2, port, str(tmp_path), mode), nprocs=2, join=True)
-    r0, r1 = (torch.load(tmp_path / f"rank{r}.pt") for r in (0, 1))
+    mp.spawn(_worker, args=(world, port, str(tmp_path), mode), nprocs=world, join=True)
+    ranks = [torch.load(tmp_path / f"rank{r}.pt") for r in range(world)]
+    r0 = ranks[0]
     # (1) replicas stay identical
-    for k in r0["params"]:
-        torch.testing.assert_close(r0["params"][k], r1["params"][k], rtol=0, atol=0, msg=lambda m: f"{k}: {m}")
+    for r1 in ranks[1:]:
+        for k in r0["params"]:
+            torch.testing.assert_close(r0["params"][k], r1["params"][k], rtol=0, atol=0, msg=lambda m: f"{k}: {m}")
     # (2) the all-reduced gradient of step 0 is the mean of the two ranks' local gradients
     b = _bench()
     from snipper_amd.model import build_model
@@ -116,17 +133,44 @@ def test_two_rank_gloo_step_matches_single_process(tmp_path, mode):
         if isinstance(mod, torch.nn.MultiheadAttention):
             mod.dropout = 0.0
     acc = None
-    for rank in (0, 1):
-        imgs, tgt = b.make_batches(ARGS, "cpu", 1, seed=1000 + rank)[0]
+    from unittest import mock
+    # the criterion normalises by the persons per rank AVERAGED over the ranks (all-reduced, as models/model.py:521-526):
+    # give the single-process evaluation below the same normaliser
+    total_persons = float(sum(len(t["traj_ids"]) for r in range(world) for t in _batch(b, r, mode)[1]["targets"]))
+    for rank in range(world):
+        imgs, tgt = _batch(b, rank, mode)
         out, _ = model(list(imgs))
         model.zero_grad(set_to_none=True)
         from snipper_amd.criterion import build_criterion
         crit = build_criterion(b.criterion_args(ARGS))
-        crit.weighted_sum(crit(out, tgt["targets"])[0]).backward()
+        with mock.patch("torch.distributed.is_initialized", return_value=True), \
+                mock.patch("torch.distributed.all_reduce", side_effect=lambda t, *a, **k: t.fill_(total_persons)), \
+                mock.patch("torch.distributed.get_world_size", return_value=world):
+            loss = crit.weighted_sum(crit(out, tgt["targets"])[0])
+        loss.backward()
         g = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
         acc = g if acc is None else {k: acc[k] + g[k] for k in g}
     assert set(acc) == set(r0["grads"])
     for k, v in acc.items():
-        torch.testing.assert_close(r0["grads"][k], v / 2, rtol=2e-4, atol=2e-6, msg=lambda m: f"{k}: {m}")
+        torch.testing.assert_close(r0["grads"][k], v / world, rtol=2e-4, atol=2e-6, msg=lambda m: f"{k}: {m}")
     # frozen parts (conv1 + layer1) never receive gradients
     assert not any(k.startswith("backbone.0.body.layer1") or k.startswith("backbone.0.body.conv1") for k in acc)
+
+
+def test_flat_grad_sync_refuses_what_would_corrupt_a_slice():
+    """The contract of grad_sync.py: gradients reset with set_to_none between steps (a .grad that still is last step's
+    view of the flat buffer raises) -- single process, no collective needed."""
+    from snipper_amd.grad_sync import FlatGradSync
+    lin = torch.nn.Linear(4, 3)
+    gs = FlatGradSync(list(lin.parameters()))
+    lin(torch.ones(2, 4)).sum().backward()
+    gs.sync()
+    assert lin.weight.grad.data_ptr() == gs.flat.data_ptr()
+    lin(torch.ones(2, 4)).sum().backward()          # accumulates IN PLACE into the flat view: must be refused
+    with pytest.raises(RuntimeError, match="set_to_none"):
+        gs.sync()
+    for p in lin.parameters():
+        p.grad = None
+    lin(torch.ones(2, 4)).sum().backward()
+    gs.sync()
+    torch.testing.assert_close(lin.weight.grad, torch.full((3, 4), 2.0))

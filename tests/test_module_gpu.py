@@ -71,7 +71,7 @@ def test_module_d48_on_hip_matches_reference(golden_dir, name, mask_kind):
     m3 = _to(b["mask"])
     mask = {"expanded": m3[..., None].expand(-1, -1, -1, cfg["d_model"]), "3d": m3, "none": None}[mask_kind]
     res = mod(q, r, s, shapes, _to(b["lsi"]), mask)
-    assert _lib.last_variant() == ("d48_patch" if enc else "d48_lp12"), _lib.last_variant()
+    assert _lib.last_variant() == "d48_lp12", _lib.last_variant()
     if mask_kind == "none":          # the golden was made with the mask: only check that the path runs and differs
         res0 = res[0] if mod.attention_vis else res
         assert torch.isfinite(res0).all()

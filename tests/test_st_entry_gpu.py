@@ -66,7 +66,7 @@ def test_st_entry_matches_composition(encoder, vdt):
                                      shapes.data_ptr(), lsi.data_ptr(), cv(hs), N, T, T, S, M, D, L, Lq, P,
                                      vbar2.data_ptr(), loc2.data_ptr(), prob2.data_ptr(), out2.data_ptr(), 0)
     _lib.check(rc, "snipper_st_msda_forward")
-    assert _lib.last_variant() == ("d48_patch" if encoder else "d48_lp12"), _lib.last_variant()
+    assert _lib.last_variant() == "d48_lp12", _lib.last_variant()
     torch.testing.assert_close(out2, out.detach(), rtol=0, atol=0)
 
     nbytes = lib.snipper_st_msda_backward_workspace_bytes(N, T, S, M, D, L, Lq, P, cv(hs))
