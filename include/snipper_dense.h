@@ -124,6 +124,21 @@ int snipper_colsum_segments_bf16(void *stream, const uint16_t *x, long long imag
 /* 3x3 convolution, padding 1, stride 1 or 2, NHWC bf16, as an implicit GEMM on the same MFMA tiles:
  * Y[B,Ho,Wo,Cout] = act(conv(X[B,H,W,Cin], W[Cout,3,3,Cin]) + bias[Cout]), Ho = (H-1)/stride + 1 (same for Wo).
  * Requirements: Cin % 64 == 0, Cout % 4 == 0.  (ResNet bottleneck conv2 with the frozen BatchNorm folded in.) */
+/* Data gradient of the STRIDE-2 case: dX[B,Hx,Wx,Cx] = sum_taps G[B,Hg,Wg,Cg] . Wt, Hg = (Hx-1)/2 + 1, with
+ * Wt [Cx,3,3,Cg] = the convolution's weight with its channel roles swapped (NOT flipped).  Four launches of the same
+ * kernel, one per parity class of the input pixel: a class uses 1, 2, 2 or 4 of the nine taps, so no MFMA multiplies a
+ * structural zero (a zero-insertion formulation would waste 3/4 of them).  Cg % 64 == 0, Cx % 4 == 0; every pixel of
+ * dX is written.
+ * Weight gradient: dW[Cout,3,3,Cin] (+)= scale[co] * sum_{b,oy,ox} G[b,oy,ox,co] * X[b, oy*s+ky-1, ox*s+kx-1, ci] on the
+ * split-reduction kernel of snipper_wgrad_bf16 (taps = extra output columns, the input pixel under a tap gathered by
+ * the loader, zeros outside the image); float32 result in the channels_last layout of a convolution weight;
+ * deterministic.  Cin % 128 == 0, Cout % 8 == 0, stride 1 or 2. */
+int snipper_conv3x3_dgrad_s2_bf16(void *stream, const uint16_t *G, const uint16_t *Wt, uint16_t *dX,
+                                  int B, int Hx, int Wx, int Cx, int Cg);
+size_t snipper_wgrad_conv3x3_workspace_bytes(int B, int H, int W, int Cin, int Cout, int stride);
+int snipper_wgrad_conv3x3_bf16(void *stream, const uint16_t *G, const uint16_t *X, int B, int H, int W, int Cin, int Cout,
+                               int stride, const float *scale, float *dW, int accumulate, void *workspace,
+                               size_t workspace_bytes);
 int snipper_conv3x3_bf16(void *stream, const uint16_t *X, const uint16_t *W, const float *bias, uint16_t *Y,
                          int B, int H, int Wd, int Cin, int Cout, int stride, int relu);
 

@@ -154,8 +154,9 @@ def _hip_conv3x3_ok(x, conv) -> bool:
 
 class _Conv3x3BN(torch.autograd.Function):
     """relu?(conv3x3(x, W * scale) + shift): forward on this repository's implicit-GEMM kernel (one launch, BN and
-    ReLU in the epilogue); the stride-1 data gradient on the same kernel (taps reversed, channel roles swapped); the
-    stride-2 data gradient and every weight gradient through ``aten.convolution_backward`` (MIOpen) for now."""
+    ReLU in the epilogue); the stride-1 data gradient on the same kernel (taps reversed, channel roles swapped), the
+    stride-2 data gradient as four parity-class launches of it, the weight gradient on the split-reduction kernel
+    (csrc/wgrad_bf16.cuh, conv mode).  Nothing of a Snipper recipe's ResNet-50 goes through MIOpen."""
 
     @staticmethod
     def forward(ctx, x, weight, scale, shift, stride, relu):
@@ -175,19 +176,27 @@ class _Conv3x3BN(torch.autograd.Function):
         g = gy.contiguous(memory_format=torch.channels_last)
         if ctx.relu:
             g = torch.ops.aten.threshold_backward(g, y, 0)
-        from .dense import conv3x3_bf16
-        own_dgrad = ctx.needs_input_grad[0] and ctx.stride == 1 and w_eff.shape[0] % 64 == 0
-        need = [ctx.needs_input_grad[0] and not own_dgrad, ctx.needs_input_grad[1], False]
+        from .dense import conv3x3_bf16, conv3x3_dgrad_s2_bf16, wgrad_conv3x3_bf16
+        cout, cin = w_eff.shape[0], w_eff.shape[1]
+        own_dgrad = ctx.needs_input_grad[0] and cout % 64 == 0
+        own_wgrad = ctx.needs_input_grad[1] and cin % 128 == 0 and cout % 8 == 0
+        need = [ctx.needs_input_grad[0] and not own_dgrad, ctx.needs_input_grad[1] and not own_wgrad, False]
         dx, dw = None, None
-        if need[0] or need[1]:
+        if need[0] or need[1]:                     # shapes outside the kernels' requirements (no Snipper recipe has any)
             dx, dw, _ = torch.ops.aten.convolution_backward(
                 g, x, w_eff, None, [ctx.stride] * 2, [1, 1], [1, 1], False, [0, 0], 1, need)
-        if own_dgrad:
+            if dw is not None:
+                dw = (dw.float() * scale.view(-1, 1, 1, 1)).to(ctx.wdtype)
+        if own_dgrad and ctx.stride == 1:
             # stride 1: the data gradient is the same convolution with the taps reversed and the channel roles swapped
             w_t = w_eff.flip(2, 3).transpose(0, 1).contiguous(memory_format=torch.channels_last)
             dx = conv3x3_bf16(g, w_t, None, 1, False)
-        if dw is not None:
-            dw = (dw.float() * scale.view(-1, 1, 1, 1)).to(ctx.wdtype)
+        elif own_dgrad:
+            # stride 2: four parity classes of the input pixel, each with its 1 / 2 / 2 / 4 taps (csrc/gemm_bf16.cuh)
+            dx = conv3x3_dgrad_s2_bf16(g, w_eff.transpose(0, 1), x.shape[-2:])
+        if own_wgrad:
+            # split-reduction kernel, BN scale folded into its second pass; float32, channels_last like the parameter
+            dw = wgrad_conv3x3_bf16(g, x, ctx.stride, scale).to(ctx.wdtype)
         return dx, dw, None, None, None, None
 
 

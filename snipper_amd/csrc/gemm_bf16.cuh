@@ -377,13 +377,20 @@ struct Conv3x3Args {
   const float *bias;   // [Cout] or nullptr
   uint16_t *Y;         // [B][Ho][Wo][Cout]
   int B, H, Wd, Cin, Cout, Ho, Wo, stride;
+  // dgrad2 != 0: the data gradient of a STRIDE-2 convolution, one launch per parity class (cy, cx) of the input pixel
+  // (iy, ix) = (2a + cy, 2b + cx):  dX[n, iy, ix, :] = sum over the taps with (iy + 1 - ky) and (ix + 1 - kx) even of
+  // G[n, (iy + 1 - ky) / 2, (ix + 1 - kx) / 2, :] . W'[:, ky, kx, :]^T  -- 1, 2, 2 or 4 taps per class instead of 9, every
+  // MFMA useful.  Here X = G [B][H][W][Cin] (the output gradient, "Cin" = the convolution's Cout), W = W' [Cout'][3][3][Cin]
+  // (the weight with its channel roles swapped), Y = dX [B][Hy][Wy][Cout]; a row of the launch is (n, a, b) over the
+  // class's grid Ho x Wo and is stored at pixel (2a + cy, 2b + cx) of Y.
+  int dgrad2, cy, cx, Hy, Wy;
 };
 
 template <bool RELU>
 __global__ __launch_bounds__(kGemmThreads) __attribute__((amdgpu_waves_per_eu(3, 3))) void conv3x3_bf16_kernel(Conv3x3Args g) {
   __shared__ __attribute__((aligned(16))) uint16_t smem[(kGemmBM + kGemmBN) * kGemmPad];
   uint16_t *Xs = smem, *Ws = smem + kGemmBM * kGemmPad;
-  const bool wide = gemm_wide_ok(g.Y, g.Cout, g.Cout);
+  const bool wide = gemm_wide_ok(g.Y, g.Cout, g.Cout) && !g.dgrad2;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave & 1, wn = wave >> 1;
   const int M = g.B * g.Ho * g.Wo;
@@ -391,7 +398,9 @@ __global__ __launch_bounds__(kGemmThreads) __attribute__((amdgpu_waves_per_eu(3,
   gemm_tile_of_block((g.Cout + kGemmBN - 1) / kGemmBN, tm, tn);
   if ((long long)tm * kGemmBM >= M) return;
   const int m0 = tm * kGemmBM, n0 = tn * kGemmBN;
-  const int kslices = g.Cin / kGemmBK, steps = 9 * kslices;
+  // taps of this launch: all nine, or the parity class's (dgrad2): ky in {1} / {0, 2} for cy = 0 / 1, kx likewise
+  const int nty = g.dgrad2 ? (g.cy ? 2 : 1) : 3, ntx = g.dgrad2 ? (g.cx ? 2 : 1) : 3;
+  const int kslices = g.Cin / kGemmBK, steps = nty * ntx * kslices;
 
   int pb[4], py[4], px[4], kc8[4], lds_off[4];
   const uint16_t *wrow[4];
@@ -401,18 +410,23 @@ __global__ __launch_bounds__(kGemmThreads) __attribute__((amdgpu_waves_per_eu(3,
     const int m = min(m0 + row, M - 1);
     pb[i] = m / (g.Ho * g.Wo);
     const int r = m - pb[i] * (g.Ho * g.Wo);
-    py[i] = (r / g.Wo) * g.stride - 1;
-    px[i] = (r % g.Wo) * g.stride - 1;
+    py[i] = g.dgrad2 ? r / g.Wo : (r / g.Wo) * g.stride - 1;
+    px[i] = g.dgrad2 ? r % g.Wo : (r % g.Wo) * g.stride - 1;
     kc8[i] = kc * 8;
     wrow[i] = g.W + (long long)min(n0 + row, g.Cout - 1) * 9 * g.Cin + kc * 8;
     lds_off[i] = row * kGemmPad + kc * 8;
   }
   auto load_step = [&](int s, gemm_u32x4 (&xr)[4], gemm_u32x4 (&wr)[4]) {
-    const int tap = s / kslices, k0 = (s - tap * kslices) * kGemmBK;
-    const int ky = tap / 3, kx = tap - ky * 3;
+    const int t = s / kslices, k0 = (s - t * kslices) * kGemmBK;
+    const int ty = t / ntx, tx = t - ty * ntx;
+    // forward: tap (ky, kx) reads input pixel (oy * s - 1 + ky, ...); dgrad2: tap ky = cy ? 2 * ty : 1 reads gradient
+    // pixel a + (cy + 1 - ky) / 2
+    const int ky = g.dgrad2 ? (g.cy ? 2 * ty : 1) : ty, kx = g.dgrad2 ? (g.cx ? 2 * tx : 1) : tx;
+    const int dy = g.dgrad2 ? (g.cy + 1 - ky) / 2 : ky, dx = g.dgrad2 ? (g.cx + 1 - kx) / 2 : kx;
+    const int tap = ky * 3 + kx;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int iy = py[i] + ky, ix = px[i] + kx;
+      const int iy = py[i] + dy, ix = px[i] + dx;
       const bool ok = iy >= 0 && iy < g.H && ix >= 0 && ix < g.Wd;
       const uint16_t *xp = g.X + (((long long)pb[i] * g.H + (ok ? iy : 0)) * g.Wd + (ok ? ix : 0)) * g.Cin + k0 + kc8[i];
       const gemm_u32x4 v = *reinterpret_cast<const gemm_u32x4 *>(xp);
@@ -468,7 +482,14 @@ __global__ __launch_bounds__(kGemmThreads) __attribute__((amdgpu_waves_per_eu(3,
       o.x = gemm_pack2(v.x, v.y);
       o.y = gemm_pack2(v.z, v.w);
       if (wide) *reinterpret_cast<uint2 *>(smem + (m - m0) * kGemmCtStride + (n - n0)) = o;
-      else *reinterpret_cast<uint2 *>(g.Y + (long long)m * g.Cout + n) = o;
+      else {
+        long long row = m;
+        if (g.dgrad2) {
+          const int b = m / (g.Ho * g.Wo), r = m - b * (g.Ho * g.Wo);
+          row = ((long long)b * g.Hy + 2 * (r / g.Wo) + g.cy) * g.Wy + 2 * (r % g.Wo) + g.cx;
+        }
+        *reinterpret_cast<uint2 *>(g.Y + row * g.Cout + n) = o;
+      }
     }
   }
   if (wide) gemm_flush_tile(smem, g.Y, g.Cout, m0, n0, M, g.Cout);

@@ -580,10 +580,38 @@ int snipper_wgrad_bf16(void *stream, const uint16_t *G, long long ldg, const uin
   if (workspace_bytes < snipper_wgrad_workspace_bytes(M, N, Kc)) return SNIPPER_E_SHAPE;
   const WgradPlan p = wgrad_plan(M, N, Kc);
   float *P = (float *)workspace, *Pb = db ? P + (size_t)p.S * N * Kc : nullptr;
-  const WgradArgs a{G, ldg, X, ldx, P, Pb, M, N, Kc, p.S, p.rows, p.tiles_n, p.tiles_k};
+  const WgradArgs a{G, ldg, X, ldx, P, Pb, M, N, Kc, p.S, p.rows, p.tiles_n, p.tiles_k, 0, 0, 0, 0, 0, 0, 0};
   hipLaunchKernelGGL(wgrad_bf16_kernel, dim3(p.tiles_n * p.tiles_k * p.S), dim3(kWgThreads), 0, (hipStream_t)stream, a);
   const WgradReduceArgs r{P, Pb, dW, lddw, db, scale, N, Kc, p.S, accumulate};
   const long long quads = (long long)N * Kc / 4;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((quads + 63) / 64)), dim3(256), 0, (hipStream_t)stream, r);
+  return launch_status();
+}
+
+size_t snipper_wgrad_conv3x3_workspace_bytes(int B, int H, int Wd, int Cin, int Cout, int stride) {
+  if (B <= 0 || H <= 0 || Wd <= 0 || Cin <= 0 || Cout <= 0 || (stride != 1 && stride != 2)) return 0;
+  const int Ho = (H - 1) / stride + 1, Wo = (Wd - 1) / stride + 1;
+  return snipper_wgrad_workspace_bytes(B * Ho * Wo, Cout, 9 * Cin);
+}
+
+int snipper_wgrad_conv3x3_bf16(void *stream, const uint16_t *G, const uint16_t *X, int B, int H, int Wd, int Cin, int Cout,
+                               int stride, const float *scale, float *dW, int accumulate, void *workspace,
+                               size_t workspace_bytes) {
+  if (!G || !X || !dW || !workspace) return SNIPPER_E_NULL;
+  if (B <= 0 || H <= 0 || Wd <= 0 || Cin <= 0 || Cout <= 0 || Cin % kWgTile || Cout % 8 || (stride != 1 && stride != 2))
+    return SNIPPER_E_SHAPE;
+  if (((uintptr_t)G | (uintptr_t)X | (uintptr_t)dW | (uintptr_t)workspace) & 15) return SNIPPER_E_SHAPE;
+  const int Ho = (H - 1) / stride + 1, Wo = (Wd - 1) / stride + 1;
+  const long long M = (long long)B * Ho * Wo;
+  if (M >= (1LL << 31) || (long long)B * H * Wd >= (1LL << 31)) return SNIPPER_E_SHAPE;
+  const int Kc = 9 * Cin;
+  if (workspace_bytes < snipper_wgrad_workspace_bytes((int)M, Cout, Kc)) return SNIPPER_E_SHAPE;
+  const WgradPlan p = wgrad_plan((int)M, Cout, Kc);
+  float *P = (float *)workspace;
+  const WgradArgs a{G, Cout, X, Cin, P, nullptr, (int)M, Cout, Kc, p.S, p.rows, p.tiles_n, p.tiles_k, 1, H, Wd, Cin, Ho, Wo, stride};
+  hipLaunchKernelGGL(wgrad_bf16_kernel, dim3(p.tiles_n * p.tiles_k * p.S), dim3(kWgThreads), 0, (hipStream_t)stream, a);
+  const WgradReduceArgs r{P, nullptr, dW, Kc, nullptr, scale, Cout, Kc, p.S, accumulate};
+  const long long quads = (long long)Cout * Kc / 4;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((quads + 63) / 64)), dim3(256), 0, (hipStream_t)stream, r);
   return launch_status();
 }
@@ -740,12 +768,29 @@ int snipper_conv3x3_bf16(void *stream, const uint16_t *X, const uint16_t *W, con
   const int Ho = (H - 1) / stride + 1, Wo = (Wd - 1) / stride + 1;
   const long long M = (long long)B * Ho * Wo;
   if (M >= (1LL << 31)) return SNIPPER_E_SHAPE;
-  const Conv3x3Args g{X, W, bias, Y, B, H, Wd, Cin, Cout, Ho, Wo, stride};
+  const Conv3x3Args g{X, W, bias, Y, B, H, Wd, Cin, Cout, Ho, Wo, stride, 0, 0, 0, 0, 0};
   const dim3 grid(gemm_grid_size(M, Cout));
   if (relu)
     hipLaunchKernelGGL(conv3x3_bf16_kernel<true>, grid, dim3(kGemmThreads), 0, (hipStream_t)stream, g);
   else
     hipLaunchKernelGGL(conv3x3_bf16_kernel<false>, grid, dim3(kGemmThreads), 0, (hipStream_t)stream, g);
+  return launch_status();
+}
+
+int snipper_conv3x3_dgrad_s2_bf16(void *stream, const uint16_t *G, const uint16_t *Wt, uint16_t *dX,
+                                  int B, int Hx, int Wx, int Cx, int Cg) {
+  if (!G || !Wt || !dX) return SNIPPER_E_NULL;
+  if (B <= 0 || Hx <= 0 || Wx <= 0 || Cx <= 0 || Cg <= 0 || Cg % kGemmBK || Cx % 4) return SNIPPER_E_SHAPE;
+  const int Hg = (Hx - 1) / 2 + 1, Wg = (Wx - 1) / 2 + 1;          // the stride-2 convolution's output size
+  if ((long long)B * Hx * Wx >= (1LL << 31)) return SNIPPER_E_SHAPE;
+  for (int cy = 0; cy < 2; ++cy)
+    for (int cx = 0; cx < 2; ++cx) {
+      const int Hc = (Hx - cy + 1) / 2, Wc = (Wx - cx + 1) / 2;    // input pixels (2a + cy, 2b + cx) of this class
+      if (Hc <= 0 || Wc <= 0) continue;
+      const Conv3x3Args g{G, Wt, nullptr, dX, B, Hg, Wg, Cg, Cx, Hc, Wc, 1, 1, cy, cx, Hx, Wx};
+      hipLaunchKernelGGL(conv3x3_bf16_kernel<false>, dim3(gemm_grid_size((long long)B * Hc * Wc, Cx)), dim3(kGemmThreads), 0,
+                         (hipStream_t)stream, g);
+    }
   return launch_status();
 }
 

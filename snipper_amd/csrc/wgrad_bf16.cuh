@@ -39,6 +39,11 @@ struct WgradArgs {
   float *P;                           // [S][N][Kc] partial sums
   float *Pb;                          // [S][N] partial column sums of G, or nullptr
   int M, N, Kc, S, rows_per_split, tiles_n, tiles_k;
+  // 3x3-convolution mode (conv != 0): X is the convolution's INPUT [B][H][W][Cin] (NHWC), G its output gradient
+  // [B][Ho][Wo][N]; the reduction row m = (b, oy, ox) pairs G[m] with the input pixel under tap (ky, kx) of that output
+  // pixel (zeros outside the image), and column kc of dW is (tap, ci): dW = [N][3][3][Cin], the channels_last layout of a
+  // convolution weight.  Kc = 9 * Cin, Cin % 128 == 0 (a 128-column tile never straddles two taps).
+  int conv, H, Wd, Cin, Ho, Wo, stride;
 };
 
 __device__ __forceinline__ gemm_bf16x8 wgrad_frag(const uint16_t *tile, int byte_off) {
@@ -76,7 +81,8 @@ __global__ __launch_bounds__(kWgThreads) void wgrad_bf16_kernel(WgradArgs g) {
   // loader: 4 x 16 B per operand per thread and step; row = idx / 16, 8-column chunk = idx % 16 (fixed per thread)
   const int chunk = tid & 15, row0 = tid >> 4;
   const bool g_col_ok = n0 + chunk * 8 < g.N, x_col_ok = k0 + chunk * 8 < g.Kc;
-  const uint16_t *gp = g.G + n0 + chunk * 8, *xp = g.X + k0 + chunk * 8;
+  const int tap = g.conv ? k0 / g.Cin : 0, ky = tap / 3 - 1, kx = tap - (tap / 3) * 3 - 1;     // (conv mode)
+  const uint16_t *gp = g.G + n0 + chunk * 8, *xp = g.X + (g.conv ? k0 - tap * g.Cin : k0) + chunk * 8;
   const gemm_u32x4 zero4 = {0u, 0u, 0u, 0u};
   auto load_step = [&](int m, gemm_u32x4 (&gr)[kWgLoads], gemm_u32x4 (&xr)[kWgLoads]) {
 #pragma unroll
@@ -85,7 +91,17 @@ __global__ __launch_bounds__(kWgThreads) void wgrad_bf16_kernel(WgradArgs g) {
       const bool ok = r < m_end;
       const long long rr = ok ? r : m_begin;
       gr[i] = (ok && g_col_ok) ? *reinterpret_cast<const gemm_u32x4 *>(gp + rr * g.ldg) : zero4;
-      xr[i] = (ok && x_col_ok) ? *reinterpret_cast<const gemm_u32x4 *>(xp + rr * g.ldx) : zero4;
+      if (g.conv) {
+        const int b = (int)rr / (g.Ho * g.Wo), rem = (int)rr - b * (g.Ho * g.Wo);
+        const int oy = rem / g.Wo, ox = rem - oy * g.Wo;
+        const int iy = oy * g.stride + ky, ix = ox * g.stride + kx;
+        const bool in = ok && x_col_ok && iy >= 0 && iy < g.H && ix >= 0 && ix < g.Wd;
+        const long long px = in ? ((long long)b * g.H + iy) * g.Wd + ix : 0;
+        const gemm_u32x4 v = *reinterpret_cast<const gemm_u32x4 *>(xp + px * g.ldx);
+        xr[i] = in ? v : zero4;
+      } else {
+        xr[i] = (ok && x_col_ok) ? *reinterpret_cast<const gemm_u32x4 *>(xp + rr * g.ldx) : zero4;
+      }
     }
   };
   gemm_u32x4 gr[kWgLoads], xr[kWgLoads];

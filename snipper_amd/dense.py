@@ -67,6 +67,51 @@ def conv3x3_bf16(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Ten
     return out
 
 
+def conv3x3_dgrad_s2_bf16(g: torch.Tensor, weight_t: torch.Tensor, in_hw) -> torch.Tensor:
+    """Data gradient of a stride-2, padding-1 3x3 convolution on the implicit-GEMM kernel (four parity-class launches).
+
+    g [B, Cout, Ho, Wo] bf16 channels_last = dL/dy; weight_t [Cin, Cout, 3, 3] bf16 channels_last = the weight with its
+    channel roles swapped (``w.transpose(0, 1)``, not flipped); in_hw = (H, W) of the convolution's input
+    ->  dL/dx [B, Cin, H, W] bf16 channels_last."""
+    assert g.is_cuda and g.dtype == torch.bfloat16 and weight_t.dtype == torch.bfloat16
+    g = g.contiguous(memory_format=torch.channels_last)
+    weight_t = weight_t.contiguous(memory_format=torch.channels_last)
+    B, Cg, Hg, Wg = g.shape
+    Cx = weight_t.shape[0]
+    H, W = in_hw
+    assert weight_t.shape[1] == Cg and (H - 1) // 2 + 1 == Hg and (W - 1) // 2 + 1 == Wg
+    dx = torch.empty((B, Cx, H, W), dtype=torch.bfloat16, device=g.device, memory_format=torch.channels_last)
+    with _lib.device_guard(g.device):
+        rc = _lib.load().snipper_conv3x3_dgrad_s2_bf16(_lib.raw_stream(g.device), g.data_ptr(), weight_t.data_ptr(),
+                                                       dx.data_ptr(), B, H, W, Cx, Cg)
+    _lib.check(rc, "snipper_conv3x3_dgrad_s2_bf16")
+    return dx
+
+
+def wgrad_conv3x3_bf16(g: torch.Tensor, x: torch.Tensor, stride: int, scale: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Weight gradient of a padding-1 3x3 convolution (stride 1 or 2) on the split-reduction MFMA kernel.
+
+    g [B, Cout, Ho, Wo] = dL/dy and x [B, Cin, H, W] = the input, both bf16 channels_last; ``scale`` [Cout] float32
+    multiplies the rows (folded BatchNorm)  ->  dW [Cout, Cin, 3, 3] float32 in channels_last memory; deterministic."""
+    assert g.is_cuda and g.dtype == torch.bfloat16 and x.dtype == torch.bfloat16
+    g = g.contiguous(memory_format=torch.channels_last)
+    x = x.contiguous(memory_format=torch.channels_last)
+    B, Cin, H, W = x.shape
+    Cout = g.shape[1]
+    lib = _lib.load()
+    nbytes = lib.snipper_wgrad_conv3x3_workspace_bytes(B, H, W, Cin, Cout, int(stride))
+    ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=g.device)
+    dw = torch.empty((Cout, 3, 3, Cin), dtype=torch.float32, device=g.device)
+    if scale is not None and scale.dtype != torch.float32:
+        scale = scale.float()
+    with _lib.device_guard(g.device):
+        rc = lib.snipper_wgrad_conv3x3_bf16(_lib.raw_stream(g.device), g.data_ptr(), x.data_ptr(), B, H, W, Cin, Cout,
+                                            int(stride), scale.data_ptr() if scale is not None else None, dw.data_ptr(),
+                                            0, ws.data_ptr(), nbytes)
+    _lib.check(rc, "snipper_wgrad_conv3x3_bf16")
+    return dw.permute(0, 3, 1, 2)            # [Cout, Cin, 3, 3] logical, channels_last memory
+
+
 def linear_nn_bf16(x: torch.Tensor, w: torch.Tensor, residual: Optional[torch.Tensor] = None,
                    gate: Optional[torch.Tensor] = None, gate_scale: float = 1.0) -> torch.Tensor:
     """gate(x [M, K] @ w [K, N] + residual [M, N]) (all bf16, row-major; w = a Linear's weight [out, in] used for the
