@@ -22,8 +22,9 @@ One JSON line on stdout (rank 0).  Besides the contract's keys:
   roofline      the dominant hand-written kernel (deformable-attention backward, encoder shape),
                 timed live with events on the launch stream, against the 8 TB/s HBM peak with the
                 algorithmic bytes of SURVEY.md section 8(d) / DESIGN.md;
-  cpu_baseline  the CPU oracle's use_pytorch_deform=1 formulation of the encoder MSDeformAttn module
-                (fwd+bwd, 1 snippet) on the host cores, converted to an attention-only snippets/s bound;
+  cpu_baseline  the CPU oracle's use_pytorch_deform=1 formulation on the host's physical cores: one encoder core
+                call, one encoder MSDeformAttn module fwd+bwd (= `value`, ms) and BASELINE configs[0] (T=1 enc2/dec4
+                transformer forward); measured, nothing extrapolated;
   msda          MSDeformAttn fwd+bwd ms (encoder / decoder module), the second half of the metric.
 """
 from __future__ import annotations
@@ -175,112 +176,212 @@ def msda_alg_bytes(d, bwd):
     return e * v + re * o + ge * v + ce * 6 * lp
 
 
-def pmc_traffic(kernel_tags, path=os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
-                                              "r01_pmc_bench_step_v17.csv")):
-    """HBM-side bytes per launch of the given kernels from the committed rocprofv3 --pmc profile of this same command
-    (FETCH_SIZE + WRITE_SIZE, raw counters; see the file's footer for the gfx950 caveats).  None if absent."""
+PMC_PROFILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_bench_step.csv")
+
+
+def pmc_traffic(path=PMC_PROFILE):
+    """HBM-side bytes per launch of the owner-computes backward's two kernels from the committed rocprofv3 --pmc profile
+    of this same command (FETCH_SIZE and WRITE_SIZE in separate passes, tools/pmc_summary.py).  Returns (raw, corrected):
+    raw = the counters as they read; corrected = with the gfx950 rule of MI355X_MICROARCH.md "HBM" applied -- FETCH_SIZE
+    reports half the bytes of a 16-B-per-lane coalesced stream, which is how the tile kernel stages its grad_out rows, so
+    that kernel's FETCH is doubled (WRITE_SIZE and the bin kernel's 12-B-per-lane gathers are left as read).  (None, None)
+    if the profile is absent."""
     try:
-        total, seen = 0.0, set()
+        vals = {}
         for line in open(path):
             if line.startswith("#") or line.startswith("kernel,"):
                 continue
             name, counter, _, kb = line.rsplit(",", 3)
-            for tag in kernel_tags:
+            for tag in ("msda_bwd_d48_bin_kernel", "msda_bwd_d48_tile_kernel"):
                 if tag in name:
-                    total += float(kb) * 1024.0
-                    seen.add((tag, counter))
-        return int(total) if len(seen) == 2 * len(kernel_tags) else None
-    except OSError:
-        return None
+                    vals[(tag, counter.strip())] = float(kb) * 1024.0
+        if len(vals) != 4:
+            return None, None
+        raw = sum(vals.values())
+        corrected = raw + vals[("msda_bwd_d48_tile_kernel", "FETCH_SIZE")]
+        return int(raw), int(corrected)
+    except (OSError, ValueError):
+        return None, None
 
 
-def cpu_baseline(a, budget_s=40.0):
-    """Time the CPU oracle (use_pytorch_deform=1 formulation, per-pair spatiotemporal module) on the host."""
+def physical_cores():
+    """(physical cores, the lscpu lines that say so) of the host."""
+    import subprocess
+    try:
+        txt = subprocess.run(["lscpu"], capture_output=True, text=True, timeout=10).stdout
+        get = lambda k: next((l.split(":", 1)[1].strip() for l in txt.splitlines() if l.startswith(k)), None)
+        cps, sockets, model = get("Core(s) per socket"), get("Socket(s)"), get("Model name")
+        n = int(cps) * int(sockets)
+        return n, f"lscpu: {model}; {sockets} socket(s) x {cps} cores, {get('Thread(s) per core')} thread(s) per core"
+    except Exception:
+        n = os.cpu_count() or 1
+        return n, f"lscpu unavailable; os.cpu_count() = {n}"
+
+
+def cpu_baseline(a, budget_s=45.0):
+    """the CPU restatement of the reference's ``use_pytorch_deform=1`` path (oracle/, pinned to the
+    reference's own outputs) timed on this box's host cores -- threads = physical cores -- best of a few repetitions after
+    one warm-up, for (1) one encoder core call, (2) one encoder MSDeformAttn module forward + backward (1 snippet, T
+    frames), (3) BASELINE configs[0]: T=1, enc2/dec4 transformer forward at the 600x800 geometry.  ``value`` is (2), the
+    CPU counterpart of the metric's "MSDeformAttn fwd+bwd ms"; nothing is extrapolated to a whole training step."""
     from oracle import msda_oracle as O
+    from snipper_amd.deformable_transformer import DeformableTransformer
     shapes = [(-(-a.height // s), -(-a.width // s)) for s in (8, 16, 32)]
     S = sum(h * w for h, w in shapes)
     C, M, L, P, T = a.hidden_dim, 8, 3, 4, a.frames
-    cores = min(os.cpu_count() or 1, 32)      # more threads than this only slow torch's CPU grid_sample down
+    cores, lscpu = physical_cores()
     torch.set_num_threads(cores)
     g = torch.Generator().manual_seed(0)
     r = lambda *s: torch.randn(*s, generator=g)
+    t_start = time.perf_counter()
+
+    def best_of(fn, reps, share):
+        fn()                                                   # warm-up
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t0)
+            if time.perf_counter() - t_start > budget_s * share:
+                break
+        return min(ts), len(ts)
+
+    # (1) one encoder core call (N = 1): core_pytorch formulation
+    sh = torch.tensor(shapes)
+    value = r(1, S, M, C // M)
+    loc = torch.rand(1, S, M, L, P, 2, generator=g)
+    attn = torch.softmax(r(1, S, M, L * P), -1).view(1, S, M, L, P)
+    with torch.no_grad():
+        t_core, n_core = best_of(lambda: O.core_gridsample(value, sh, loc, attn), 5, 0.2)
+    # (2) one encoder module forward + backward (per-pair spatiotemporal formulation, explicit weights)
     q = r(1, T, S, C).requires_grad_(True)
     src = r(1, T, S, C).requires_grad_(True)
     ref = torch.rand(1, T, S, L, 2, generator=g)
     vw, vb, ow, ob = r(C, C) * 0.05, torch.zeros(C), r(C, C) * 0.05, torch.zeros(C)
     offw, offb = [r(M * L * P * 2, C) * 0.01] * T, [r(M * L * P * 2)] * T
     attw, attb = [r(M * L * P, C) * 0.05] * T, [torch.zeros(M * L * P)] * T
-    reps, t0 = 0, time.perf_counter()
-    while True:                                # a bounded sample: at least 12 s of CPU work, at most budget_s
+
+    def module_step():
         q.grad = src.grad = None
         out, _, _ = O.st_msdeform_attn(q, ref, src, shapes, None, vw, vb, offw, offb, attw, attb, ow, ob, M, L, P, T)
         out.sum().backward()
-        reps += 1
-        total = time.perf_counter() - t0
-        if total >= 12.0 or total + total / reps > budget_s:
-            break
-    dt = total / reps
-    per_snippet = dt * a.enc_layers            # encoder attention only; decoder/dense/backbone not counted
-    return {"value": round(1.0 / per_snippet, 5), "unit": "snippets/s", "cores": cores, "kind": "port",
-            "sample": (f"oracle use_pytorch_deform=1 formulation: one encoder MSDeformAttn module fwd+bwd, 1 snippet, "
-                       f"T={T}, {reps} repetitions in {total:.1f} s ({dt:.2f} s each) on {cores} host threads; value = "
-                       f"1/({a.enc_layers} encoder layers x that), i.e. attention-only upper bound of the CPU rate "
-                       "(dense layers, decoder, backbone excluded)"),
-            "module_fwd_bwd_s": round(dt, 3)}
+    t_mod, n_mod = best_of(module_step, 3, 0.65)
+    # (3) BASELINE configs[0]: T=1, enc2/dec4, hidden 384, 60 queries, transformer forward on 600x800 feature maps
+    torch.manual_seed(0)
+    tr = DeformableTransformer(d_model=C, nhead=M, num_encoder_layers=2, num_decoder_layers=4, dim_feedforward=1024,
+                               dropout=0.1, activation="relu", return_intermediate_dec=True, num_feature_levels=L,
+                               dec_n_points=P, enc_n_points=P, n_frame=1, n_future_frame=0, use_pytroch_deform=True,
+                               num_keypoints=15).eval()
+    srcs = [r(1, C, 1, h, w) for h, w in shapes]
+    masks = [torch.zeros(1, C, 1, h, w, dtype=torch.bool) for h, w in shapes]
+    pos = [r(1, C, 1, h, w) for h, w in shapes]
+    qe = r(60, 2 * C)
+    with torch.no_grad():
+        t_cfg1, n_cfg1 = best_of(lambda: tr(srcs, masks, pos, qe), 2, 1.0)
+    return {"value": round(t_mod * 1e3, 1), "unit": f"ms per encoder MSDeformAttn module fwd+bwd (1 snippet, T={T}, 600x800)",
+            "cores": cores, "kind": "port",
+            "sample": (f"oracle/ (use_pytorch_deform=1 formulation, pinned to the reference's outputs) on {cores} host threads "
+                       f"= physical cores [{lscpu}]; best of {n_mod} after 1 warm-up; no extrapolation"),
+            "timings_s": {"encoder_core_call_N1": round(t_core, 4), "encoder_module_fwd_bwd": round(t_mod, 4),
+                          "config1_T1_enc2_dec4_transformer_forward": round(t_cfg1, 4)},
+            "repetitions": {"core": n_core, "module": n_mod, "config1": n_cfg1},
+            "total_cpu_seconds": round(time.perf_counter() - t_start, 1)}
+
+
+def reference_module(mod, query, ref, src, hw, groups):
+    """The REFERENCE's formulation of the MSDeformAttn module (models/ops/modules/ms_deform_attn.py:99-243 with
+    ``use_pytorch_deform=1``) in plain PyTorch on the module's parameters: one value projection, then per (query frame,
+    value frame) pair its own offset / logit Linears, a joint softmax over levels x points x neighbour frames, one
+    grid_sample core op per pair, the sum of the pairs, the output projection.  nn.Linear everywhere (F.linear), float32:
+    the denominator of BASELINE.json's ">= 3x the PyTorch-reference MSDeformAttn throughput"."""
+    from snipper_amd.ms_deform_attn_func import ms_deform_attn_core_pytorch
+    N, T1, Lq, C = query.shape
+    T2, S = src.shape[1], src.shape[2]
+    M, L, P = mod.n_heads, mod.n_levels, mod.n_points
+    value = F.linear(src, mod.value_proj.weight, mod.value_proj.bias).view(N, T2, S, M, C // M)
+    scale = torch.tensor([[w, h] for h, w in hw], dtype=query.dtype, device=query.device)
+    outs = []
+    for t1, grp in enumerate(groups):
+        q = query[:, t1]
+        logits = torch.stack([F.linear(q, mod.attention_weights[t2].weight, mod.attention_weights[t2].bias)
+                              .view(N, Lq, M, L, P) for t2 in grp], -1)
+        prob = F.softmax(logits.flatten(-3), -1).view(N, Lq, M, L, P, len(grp))
+        acc = None
+        for k, t2 in enumerate(grp):
+            off = F.linear(q, mod.sampling_offsets[t2].weight, mod.sampling_offsets[t2].bias).view(N, Lq, M, L, P, 2)
+            loc = ref[:, t1, :, None, :, None, :] + off / scale[None, None, None, :, None, :]
+            o = ms_deform_attn_core_pytorch(value[:, t2], hw, loc, prob[..., k])
+            acc = o if acc is None else acc + o
+        outs.append(acc)
+    return F.linear(torch.stack(outs, 1), mod.output_proj.weight, mod.output_proj.bias)
 
 
 def time_msda_modules(a, device):
-    """MSDeformAttn module fwd+bwd ms at the bench geometry (encoder Lq=S, decoder Lq=60): the HIP path, and the
-    reference's own formulation of the module (``use_pytorch_deform=1``: per-pair grid_sample core op, PyTorch
-    everything) on the same GPU -- the denominator of BASELINE.json's ">= 3x the PyTorch-reference MSDeformAttn
-    throughput"."""
-    from snipper_amd.ms_deform_attn import MSDeformAttn
+    """MSDeformAttn module fwd+bwd ms at the bench geometry (encoder Lq=S, decoder Lq=60), three ways on the same GPU:
+
+      *_module_fwd_bwd_ms                       this package's HIP path in the step's precision;
+      *_module_reference_fp32_fwd_bwd_ms        the REFERENCE's formulation (``reference_module`` above: per-pair
+                                                grid_sample core op, per-pair Linears, joint softmax, F.linear
+                                                everywhere, float32 -- the reference has no AMP): the denominator of
+                                                BASELINE.json's ">= 3x the PyTorch-reference MSDeformAttn throughput";
+      *_module_package_pytorch_switch_fwd_bwd_ms  this package's own module with ``use_pytorch_deform=1`` under the step's
+                                                autocast: the tied single-grid_sample formulation plus this package's GEMM
+                                                kernels -- NOT the reference's cost, reported for continuity with round 1.
+    """
+    from snipper_amd.ms_deform_attn import MSDeformAttn, frame_neighbours
     shapes = [(-(-a.height // s), -(-a.width // s)) for s in (8, 16, 32)]
     S = sum(h * w for h, w in shapes)
     sh = torch.tensor(shapes, device=device)
     sh._snipper_host = shapes
     lsi = torch.cat((sh.new_zeros(1), sh.prod(1).cumsum(0)[:-1]))
     res = {}
-    for mode, Lq, T1, torch_path in (("encoder", S, a.frames, False), ("decoder", 60, a.frames + a.future_frames, False),
-                                     ("encoder", S, a.frames, True), ("decoder", 60, a.frames + a.future_frames, True)):
-        mod = MSDeformAttn(a.hidden_dim, 3, 8, 4, a.frames, mode, torch_path, mode == "decoder").to(device)
-        q = torch.randn(a.batch, T1, Lq, a.hidden_dim, device=device, requires_grad=True)
-        src = torch.randn(a.batch, a.frames, S, a.hidden_dim, device=device, requires_grad=True)
-        if mode == "encoder":   # the encoder's reference points are the pixel centres of the maps
-            from snipper_amd.deformable_transformer import DeformableTransformerEncoder
-            vr = torch.ones(a.batch, 3, 2, device=device)
-            ref = DeformableTransformerEncoder.get_reference_points(sh, vr, device)[:, None].expand(-1, T1, -1, -1, -1)
-        else:
-            ref = torch.rand(a.batch, T1, Lq, 3, 2, device=device)
+    amp = a.precision == "bf16"
+    for mode, Lq, T1 in (("encoder", S, a.frames), ("decoder", 60, a.frames + a.future_frames)):
+        for kind in ("hip", "reference_fp32", "package_pytorch_switch"):
+            mod = MSDeformAttn(a.hidden_dim, 3, 8, 4, a.frames, mode, kind == "package_pytorch_switch",
+                               mode == "decoder").to(device)
+            q = torch.randn(a.batch, T1, Lq, a.hidden_dim, device=device, requires_grad=True)
+            src = torch.randn(a.batch, a.frames, S, a.hidden_dim, device=device, requires_grad=True)
+            if mode == "encoder":   # the encoder's reference points are the pixel centres of the maps
+                from snipper_amd.deformable_transformer import DeformableTransformerEncoder
+                vr = torch.ones(a.batch, 3, 2, device=device)
+                ref = DeformableTransformerEncoder.get_reference_points(sh, vr, device)[:, None].expand(-1, T1, -1, -1, -1)
+            else:
+                ref = torch.rand(a.batch, T1, Lq, 3, 2, device=device)
+            groups = [frame_neighbours(t1, a.frames, a.frames) for t1 in range(T1)]
 
-        amp = a.precision == "bf16"
-
-        def run():
-            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):      # the step's precision
-                o = mod(q, ref, src, sh, lsi, None)
-            o = o[0] if isinstance(o, tuple) else o
-            o.float().sum().backward()
-        try:
-            for _ in range(2):
-                run()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            n = 5
-            for _ in range(n):
-                run()
-            torch.cuda.synchronize()
-            key = f"{mode}_module_fwd_bwd_ms" if not torch_path else f"{mode}_module_pytorch_reference_fwd_bwd_ms"
-            res[key] = round((time.perf_counter() - t0) / n * 1e3, 3)
-        except RuntimeError as e:              # (the grid_sample formulation needs several GB at the encoder shape)
-            if not torch_path:
-                raise
-            res[f"{mode}_module_pytorch_reference_error"] = str(e)[:80]
-        del mod, q, src
-        torch.cuda.empty_cache()
+            def run():
+                if kind == "reference_fp32":
+                    o = reference_module(mod, q, ref, src, shapes, groups)
+                else:
+                    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):      # the step's precision
+                        o = mod(q, ref, src, sh, lsi, None)
+                o = o[0] if isinstance(o, tuple) else o
+                o.float().sum().backward()
+            key = f"{mode}_module_fwd_bwd_ms" if kind == "hip" else f"{mode}_module_{kind}_fwd_bwd_ms"
+            try:
+                for _ in range(2):
+                    run()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                n = 5
+                for _ in range(n):
+                    run()
+                torch.cuda.synchronize()
+                res[key] = round((time.perf_counter() - t0) / n * 1e3, 3)
+            except RuntimeError as e:              # (the grid_sample formulation needs several GB at the encoder shape)
+                if kind == "hip":
+                    raise
+                res[key.replace("_fwd_bwd_ms", "_error")] = str(e)[:80]
+            del mod, q, src
+            torch.cuda.empty_cache()
     for mode in ("encoder", "decoder"):
-        a_, b_ = res.get(f"{mode}_module_fwd_bwd_ms"), res.get(f"{mode}_module_pytorch_reference_fwd_bwd_ms")
+        a_, b_ = res.get(f"{mode}_module_fwd_bwd_ms"), res.get(f"{mode}_module_reference_fp32_fwd_bwd_ms")
         if a_ and b_:
             res[f"{mode}_speedup_vs_pytorch_reference"] = round(b_ / a_, 2)
+        c_ = res.get(f"{mode}_module_package_pytorch_switch_fwd_bwd_ms")
+        if a_ and c_:
+            res[f"{mode}_speedup_vs_package_pytorch_switch"] = round(c_ / a_, 2)
     return res
 
 
@@ -356,9 +457,6 @@ def main():
     from snipper_amd import _lib
     from snipper_amd.model import build_model
     _lib.load()                                                   # fail loudly if the HIP library is missing
-    for kv in filter(None, os.environ.get("SNIPPER_PARAMS", "").split(",")):   # tuning knobs (development aid)
-        k, v = kv.split("=")
-        _lib.set_param(k.strip(), float(v))
 
     if os.environ.get("SNIPPER_BLAS"):                            # "cublas" = rocBLAS, "cublaslt" = hipBLASLt (aid)
         torch.backends.cuda.preferred_blas_library(os.environ["SNIPPER_BLAS"])
@@ -692,13 +790,14 @@ def main():
             avg_ms = sum(times) / len(times)
             bts = msda_alg_bytes(d, dom[0] == "bwd")
             ach = bts / (avg_ms * 1e-3) / 1e9
-            traffic = pmc_traffic(["msda_bwd_d48_bin_kernel", "msda_bwd_d48_tile_kernel"]) \
-                if dom[1] == "d48_owner" and d["N"] == 8 and d["Lq"] == 9875 else None
+            raw, corrected = pmc_traffic() if dom[1] == "d48_owner" and d["N"] == 8 and d["Lq"] == 9875 else (None, None)
             line["roofline"] = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                                "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                                "traffic_source": ("profiles/r01_pmc_bench_step_v17.csv: rocprofv3 --pmc FETCH_SIZE + "
-                                                   "WRITE_SIZE (separate passes, raw counters) of this command, bin + "
-                                                   "tile kernel" if traffic else None),
+                                "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": corrected, "traffic_raw_counters": raw,
+                                "traffic_source": ("profiles/r02_pmc_bench_step.csv: rocprofv3 --pmc FETCH_SIZE and "
+                                                   "WRITE_SIZE (separate passes) of this command, bin + tile kernel; "
+                                                   "`traffic` doubles the tile kernel's FETCH_SIZE (gfx950 counts half of a "
+                                                   "16-B-per-lane stream: MI355X_MICROARCH.md, HBM), `traffic_raw_counters` "
+                                                   "is what the counters read" if corrected else None),
                                 "kernel": f"msda_{dom[0]}_{dom[1]} N={d['N']} Lq={d['Lq']}",
                                 "avg_launch_ms": round(avg_ms, 4), "alg_bytes_per_launch": bts,
                                 "launches_timed": len(times)}

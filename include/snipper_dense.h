@@ -133,6 +133,11 @@ int snipper_colsum_segments_bf16(void *stream, const uint16_t *x, long long imag
  * split-reduction kernel of snipper_wgrad_bf16 (taps = extra output columns, the input pixel under a tap gathered by
  * the loader, zeros outside the image); float32 result in the channels_last layout of a convolution weight;
  * deterministic.  Cin % 128 == 0, Cout % 8 == 0, stride 1 or 2. */
+/* The ResNet stem: Y[B,Ho,Wo,64] = conv7x7(stride 2, padding 3) of X4[B,H,W,4] (the 3-channel image padded to 4 bf16 channels,
+ * NHWC) with Wp[64,256] = the weight (BN scale folded in) laid out as k = ky*32 + kx*4 + c, zero in the padding slots;
+ * Ho = (H-1)/2 + 1.  Forward only (the stem is frozen, reference backbone.py:71-73); bias / ReLU / pooling follow in
+ * snipper_stem_pool_bf16. */
+int snipper_stem7x7_bf16(void *stream, const uint16_t *X4, const uint16_t *Wp, uint16_t *Y, int B, int H, int W);
 int snipper_conv3x3_dgrad_s2_bf16(void *stream, const uint16_t *G, const uint16_t *Wt, uint16_t *dX,
                                   int B, int Hx, int Wx, int Cx, int Cg);
 size_t snipper_wgrad_conv3x3_workspace_bytes(int B, int H, int W, int Cin, int Cout, int stride);

@@ -311,9 +311,28 @@ class ResNet50Body(nn.Module):
                 cached = getattr(self, "_stem_w", None)
                 if cached is None or cached[0] != key:           # frozen: folded and cast once
                     w = (conv.weight * scale.view(-1, 1, 1, 1).to(conv.weight.dtype)).to(torch.bfloat16)
-                    cached = (key, w.contiguous(memory_format=torch.channels_last))
+                    wp = None
+                    if tuple(conv.weight.shape) == (64, 3, 7, 7) and conv.stride == (2, 2) and conv.padding == (3, 3):
+                        # the stem kernel's K order: k = ky*32 + kx*4 + c, zero in the padding slots (csrc/gemm_bf16.cuh)
+                        wp = torch.zeros(64, 8, 8, 4, dtype=torch.bfloat16, device=w.device)
+                        wp[:, :7, :7, :3] = w.permute(0, 2, 3, 1)
+                        wp = wp.view(64, 256)
+                    cached = (key, w.contiguous(memory_format=torch.channels_last), wp)
                     object.__setattr__(self, "_stem_w", cached)
-                y = F.conv2d(x.to(torch.bfloat16), cached[1], None, conv.stride, conv.padding, conv.dilation, conv.groups)
+                y = None
+                if cached[2] is not None and x.shape[1] == 3:
+                    n, _, h, wd = x.shape
+                    x4 = torch.zeros((n, h, wd, 4), dtype=torch.bfloat16, device=x.device)     # channels padded 3 -> 4
+                    x4[..., :3] = x.permute(0, 2, 3, 1)
+                    y = torch.empty((n, 64, (h - 1) // 2 + 1, (wd - 1) // 2 + 1), dtype=torch.bfloat16, device=x.device,
+                                    memory_format=torch.channels_last)
+                    with _lib.device_guard(x.device):
+                        rc = _lib.load().snipper_stem7x7_bf16(_lib.raw_stream(x.device), x4.data_ptr(), cached[2].data_ptr(),
+                                                              y.data_ptr(), n, h, wd)
+                    _lib.check(rc, "snipper_stem7x7_bf16")
+                if y is None:
+                    y = F.conv2d(x.to(torch.bfloat16), cached[1], None, conv.stride, conv.padding, conv.dilation,
+                                 conv.groups)
                 if y.dtype == torch.bfloat16 and y.is_contiguous(memory_format=torch.channels_last):
                     n, c, h, wd = y.shape
                     out = torch.empty((n, c, (h - 1) // 2 + 1, (wd - 1) // 2 + 1), dtype=torch.bfloat16, device=y.device,

@@ -495,4 +495,104 @@ __global__ __launch_bounds__(kGemmThreads) __attribute__((amdgpu_waves_per_eu(3,
   if (wide) gemm_flush_tile(smem, g.Y, g.Cout, m0, n0, M, g.Cout);
 }
 
+// ---- the ResNet stem: 7x7 convolution, stride 2, padding 3, 3 input channels -> 64, NHWC bf16 ----------------
+//   Y[b, oy, ox, :] = sum_{ky,kx,c} X4[b, 2*oy - 3 + ky, 2*ox - 3 + kx, c] * Wp[:, ky*32 + kx*4 + c]
+// X4 [B][H][W][4] bf16 = the image with its 3 channels padded to 4 (8 B per pixel, so a tap row of a pixel pair is one
+// aligned 16-byte piece), Wp [64][256] bf16 = the weight (BN scale folded in) in the matching K order, zero in the padding
+// slots (c = 3, kx = 7, ky = 7).  Implicit GEMM on the tile machinery above: 128 output pixels x 64 channels per
+// workgroup, K = 256 in four steps of two tap rows; each wave owns 32 pixels x 64 channels (2 x 4 MFMA tiles).
+// The stem is frozen in every Snipper recipe (reference backbone.py:71-73): forward only.
+struct StemArgs {
+  const uint16_t *X4;   // [B][H][W][4]
+  const uint16_t *Wp;   // [64][256]
+  uint16_t *Y;          // [B][Ho][Wo][64]
+  int B, H, Wd, Ho, Wo;
+};
+constexpr int kStemN = 64, kStemK = 256;
+
+__global__ __launch_bounds__(kGemmThreads) void stem7x7_bf16_kernel(StemArgs g) {
+  __shared__ __attribute__((aligned(16))) uint16_t smem[(kGemmBM + kStemN) * kGemmPad];
+  uint16_t *Xs = smem, *Ws = smem + kGemmBM * kGemmPad;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long long M = (long long)g.B * g.Ho * g.Wo;
+  const long long m0 = (long long)blockIdx.x * kGemmBM;
+  if (m0 >= M) return;
+  int pb[4], py[4], px[4], lds_off[4], kyl[4], kx0[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int idx = tid + kGemmThreads * i, row = idx >> 3, kc = idx & 7;
+    const long long m = min(m0 + row, M - 1);
+    pb[i] = (int)(m / (g.Ho * g.Wo));
+    const int r = (int)(m - (long long)pb[i] * (g.Ho * g.Wo));
+    py[i] = (r / g.Wo) * 2 - 3;
+    px[i] = (r % g.Wo) * 2 - 3;
+    kyl[i] = kc >> 2;               // tap row within the step (two per step)
+    kx0[i] = (kc & 3) * 2;          // first tap column of this 16-byte piece (a pixel pair)
+    lds_off[i] = row * kGemmPad + kc * 8;
+  }
+  const int wrow = tid >> 2, wkc = (tid & 3) * 2;        // weight tile: 64 rows x 8 pieces, two pieces per thread
+  typedef unsigned int stem_u32x2 __attribute__((ext_vector_type(2)));
+  auto load_step = [&](int s, gemm_u32x4 (&xr)[4], gemm_u32x4 (&wr)[2]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int ky = 2 * s + kyl[i];
+      const int iy = py[i] + ky, ix = px[i] + kx0[i];
+      const bool oky = ky < 7 && iy >= 0 && iy < g.H;
+      const bool ok0 = oky && ix >= 0 && ix < g.Wd, ok1 = oky && ix + 1 >= 0 && ix + 1 < g.Wd;
+      const uint16_t *base = g.X4 + (((long long)pb[i] * g.H + (oky ? iy : 0)) * g.Wd) * 4;
+      const stem_u32x2 a = *reinterpret_cast<const stem_u32x2 *>(base + (long long)(ok0 ? ix : 0) * 4);
+      const stem_u32x2 b = *reinterpret_cast<const stem_u32x2 *>(base + (long long)(ok1 ? ix + 1 : 0) * 4);
+      xr[i] = gemm_u32x4{ok0 ? a.x : 0u, ok0 ? a.y : 0u, ok1 ? b.x : 0u, ok1 ? b.y : 0u};
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      wr[i] = *reinterpret_cast<const gemm_u32x4 *>(g.Wp + (long long)wrow * kStemK + s * kGemmBK + (wkc + i) * 8);
+  };
+  gemm_u32x4 xr[4], wr[2];
+  load_step(0, xr, wr);
+  gemm_f32x4 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = gemm_f32x4{0.f, 0.f, 0.f, 0.f};
+  const int frag_row = lane & 15, frag_k = (lane >> 4) * 8;
+  for (int s = 0; s < kStemK / kGemmBK; ++s) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<gemm_u32x4 *>(Xs + lds_off[i]) = xr[i];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) *reinterpret_cast<gemm_u32x4 *>(Ws + wrow * kGemmPad + (wkc + i) * 8) = wr[i];
+    __syncthreads();
+    if (s + 1 < kStemK / kGemmBK) load_step(s + 1, xr, wr);
+#pragma unroll
+    for (int kk = 0; kk < kGemmBK; kk += 32) {
+      gemm_bf16x8 wf[4], xf[2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        wf[i] = *reinterpret_cast<const gemm_bf16x8 *>(Ws + (i * 16 + frag_row) * kGemmPad + kk + frag_k);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        xf[j] = *reinterpret_cast<const gemm_bf16x8 *>(Xs + (wave * 32 + j * 16 + frag_row) * kGemmPad + kk + frag_k);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int n = i * 16 + (lane >> 4) * 4;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const long long m = m0 + wave * 32 + j * 16 + (lane & 15);
+      if (m >= M) continue;
+      uint2 o;
+      o.x = gemm_pack2(acc[i][j].x, acc[i][j].y);
+      o.y = gemm_pack2(acc[i][j].z, acc[i][j].w);
+      *reinterpret_cast<uint2 *>(g.Y + m * kStemN + n) = o;
+    }
+  }
+}
+
 }  // namespace snipper

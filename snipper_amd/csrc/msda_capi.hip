@@ -777,6 +777,19 @@ int snipper_conv3x3_bf16(void *stream, const uint16_t *X, const uint16_t *W, con
   return launch_status();
 }
 
+int snipper_stem7x7_bf16(void *stream, const uint16_t *X4, const uint16_t *Wp, uint16_t *Y, int B, int H, int Wd) {
+  if (!X4 || !Wp || !Y) return SNIPPER_E_NULL;
+  if (B <= 0 || H <= 0 || Wd <= 0) return SNIPPER_E_SHAPE;
+  if (((uintptr_t)X4 | (uintptr_t)Wp | (uintptr_t)Y) & 15) return SNIPPER_E_SHAPE;
+  const int Ho = (H - 1) / 2 + 1, Wo = (Wd - 1) / 2 + 1;           // (H + 2*3 - 7) / 2 + 1
+  const long long M = (long long)B * Ho * Wo;
+  if (M >= (1LL << 31) * 64LL) return SNIPPER_E_SHAPE;
+  const StemArgs g{X4, Wp, Y, B, H, Wd, Ho, Wo};
+  hipLaunchKernelGGL(stem7x7_bf16_kernel, dim3((unsigned)((M + kGemmBM - 1) / kGemmBM)), dim3(kGemmThreads), 0,
+                     (hipStream_t)stream, g);
+  return launch_status();
+}
+
 int snipper_conv3x3_dgrad_s2_bf16(void *stream, const uint16_t *G, const uint16_t *Wt, uint16_t *dX,
                                   int B, int Hx, int Wx, int Cx, int Cg) {
   if (!G || !Wt || !dX) return SNIPPER_E_NULL;

@@ -374,3 +374,26 @@ def test_whole_backbone_at_600x800_matches_float32_composition():
     assert max(out_err) <= 2e-2, out_err
     for e, n in grad_err:
         assert e <= 1.25 * lib_grad[n] + 1e-2, (n, e, lib_grad[n])
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 600, 800), (1, 33, 47), (3, 8, 8), (1, 1, 1)])
+def test_stem7x7_kernel(B, H, W):
+    """The ResNet stem (7x7, stride 2, padding 3, 3 -> 64 channels) on the MFMA kernel against F.conv2d in float32 on the
+    same bf16-rounded operands."""
+    from snipper_amd import _lib
+    gen = torch.Generator().manual_seed(H + W)
+    x = torch.rand(B, 3, H, W, generator=gen).to(DEV).bfloat16()
+    w = (torch.randn(64, 3, 7, 7, generator=gen) / 12).to(DEV).bfloat16()
+    x4 = torch.zeros(B, H, W, 4, dtype=torch.bfloat16, device=DEV)
+    x4[..., :3] = x.permute(0, 2, 3, 1)
+    wp = torch.zeros(64, 8, 8, 4, dtype=torch.bfloat16, device=DEV)
+    wp[:, :7, :7, :3] = w.permute(0, 2, 3, 1)
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    y = torch.empty(B, Ho, Wo, 64, dtype=torch.bfloat16, device=DEV)
+    rc = _lib.load().snipper_stem7x7_bf16(_lib.raw_stream(torch.device(DEV)), x4.data_ptr(), wp.view(64, 256).data_ptr(),
+                                          y.data_ptr(), B, H, W)
+    _lib.check(rc, "snipper_stem7x7_bf16")
+    ref = F.conv2d(x.float(), w.float(), None, 2, 3).permute(0, 2, 3, 1)
+    assert ref.shape == y.shape
+    err = (y.float() - ref).abs().max().item()
+    assert err <= 2e-2 * max(1.0, ref.abs().max().item()), err
