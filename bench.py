@@ -761,9 +761,8 @@ def main():
                        "global_batch": a.batch * world, "per_gpu_batch": a.batch, "parallelism": f"dp{world}",
                        "loss": ("SetCriterion + Hungarian matcher (reference coefficients, 6+8 synthetic persons)"
                                 if a.loss == "criterion" else "fixed-assignment surrogate"),
-                       "backbone_convs": ("1x1 and 3x3 bottleneck convs on own bf16 MFMA kernels (BN/residual/ReLU "
-                                          "fused; 1x1 fwd+dgrad+wgrad, 3x3 fwd + stride-1 dgrad); MIOpen for the "
-                                          "7x7 stem, stride-2 dgrad and 3x3 wgrad"),
+                       "backbone_convs": ("every ResNet-50 convolution on own bf16 MFMA kernels (BN / residual / ReLU fused): 7x7 "
+                                          "stem, 1x1 and 3x3 forward, data and weight gradients; nothing in MIOpen"),
                        "grad_sync": ("none (1 GPU)" if not use_ddp else
                                      ("DistributedDataParallel" if a.ddp == "torch" else
                                       "flat buffer, 4 stages (transformer, layer4, layer3, layer2) all-reduced over RCCL "
