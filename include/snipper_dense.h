@@ -187,7 +187,7 @@ int snipper_msda_prologue_backward(void *stream, const float *grad_loc, const fl
  *   backward) and out [N*T1,Lq,M*D] (f32, or bf16 rows when out_bf16 != 0 and D == 48).
  * Backward: grad_out (f32 or bf16 rows) -> grad_value [N,T2,S,M*D] (value_dtype), grad_off / grad_logit (ql_dtype,
  * same addressing as off / logit), grad_ref [N*T1*Lq,L,2] or NULL.  host_shapes (HOST [L,2], may be NULL) enables the
- * owner-computes backward (csrc/msda_d48_owner.cuh); workspace >= snipper_st_msda_backward_workspace_bytes(...). */
+ * owner-computes backward (csrc/msda_d48_patch.cuh); workspace >= snipper_st_msda_backward_workspace_bytes(...). */
 int snipper_st_msda_forward(void *stream, const void *value, int value_dtype, const unsigned char *mask, const float *mix,
                             const void *off, long long off_ld, const void *logit, long long logit_ld, int ql_dtype,
                             const float *ref, const float *inv_w, const float *inv_h,

@@ -65,7 +65,7 @@ int snipper_msda_abi_version(void);
 /* Human-readable text for a code returned by any entry point (static storage). */
 const char *snipper_msda_strerror(int code);
 /* Name of the kernel variant the last forward / backward call of this process dispatched to ("generic", "d48_lp12",
- * "d48_owner", "d48_owner_det", ...): a diagnostic for tests and profiles, never an input of any computation. */
+ * "d48_owner", ...): a diagnostic for tests and profiles, never an input of any computation. */
 const char *snipper_msda_last_variant(void);
 
 /* The library keeps NO tuning state: everything that can change which kernels run travels in this struct, passed by the
@@ -75,9 +75,9 @@ typedef struct snipper_msda_config {
   int32_t struct_bytes;   /* sizeof(snipper_msda_config), checked                                                    */
   int32_t policy;         /* 0 auto; 1 generic kernels only; 2 tuned D=48 kernels but never the encoder-shape ones     */
   float near_radius;      /* owner-computes backward: a sample within this many pixels of its anchor is "near" (6)     */
-  int32_t deterministic;  /* 1: bit-reproducible owner-computes backward (marks + sorted taps; ~7 % slower), default 0  */
+  int32_t reserved0;      /* must be 0                                                                                 */
   int32_t tile_edge[3];   /* grad_value tile edge (power of two <= 16) for levels of > 4096 / > 1024 / fewer pixels    */
-  int32_t reserved[5];    /* must be 0 ([0] != 0 selects timing ablations of the deterministic backward: WRONG results)  */
+  int32_t reserved[5];    /* must be 0 ([0] != 0 selects timing ablations of the owner-computes backward: WRONG results)  */
 } snipper_msda_config;
 void snipper_msda_config_init(snipper_msda_config *cfg);     /* fills in the defaults */
 
@@ -89,8 +89,8 @@ void snipper_msda_config_init(snipper_msda_config *cfg);     /* fills in the def
  *   host_shapes  : the SAME [L,2] (H,W) values as `shapes`, readable by the HOST, or NULL when unknown.  With D == 48,
  *                  P == 4, L <= 4 and Lq == S == sum(H*W) -- the encoder's self-attention, whose queries are the pixels of
  *                  the L maps in level-major raster order -- they enable the owner-computes backward
- *                  (csrc/msda_d48_owner.cuh; csrc/msda_d48_patch.cuh when config.deterministic): grad_value summed per
- *                  tile by owner workgroups instead of per tap by HBM float atomics.  The result is the same function of
+ *                  (csrc/msda_d48_patch.cuh; float32 or bfloat16 value): grad_value summed per tile by owner workgroups
+ *                  -- in a fixed order, so bit-reproducible -- instead of per tap by HBM float atomics.  The result is the same function of
  *                  the inputs for ANY locations; only the speed depends on how local they are.
  *   workspace    : backward only; device scratch of at least snipper_msda_backward_ex_workspace_bytes(...) bytes (0 when
  *                  the encoder-shape path would not be taken: then NULL is fine).  The library never allocates. */

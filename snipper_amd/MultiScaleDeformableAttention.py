@@ -158,12 +158,14 @@ def ms_deform_attn_forward(value: torch.Tensor, spatial_shapes: torch.Tensor,
 def ms_deform_attn_backward(value: torch.Tensor, spatial_shapes: torch.Tensor,
                             level_start_index: torch.Tensor, sampling_loc: torch.Tensor,
                             attn_weight: torch.Tensor, grad_output: torch.Tensor,
-                            im2col_step: int, host_shapes=None, config=None) -> List[torch.Tensor]:
+                            im2col_step: int, host_shapes=None, config=None,
+                            grad_value_f32: bool = False) -> List[torch.Tensor]:
     """-> [grad_value, grad_sampling_loc, grad_attn_weight]   (ms_deform_attn_cuda.cu:83-153)
 
     For bfloat16 ``value`` the returned grad_value is bfloat16 (accumulated in float32).  ``grad_output`` may be bfloat16
     beside float32 ``value`` (bf16 rows, D == 48).  ``host_shapes`` / ``config``: as for the forward; with the host
-    shapes the encoder shape (Lq == S) takes the owner-computes backward.
+    shapes the encoder shape (Lq == S) takes the owner-computes backward.  ``grad_value_f32``: return the float32
+    accumulation buffer for bfloat16 ``value`` as it is (a caller that reduces it further spares two cast passes).
     """
     _check_common([("value", value), ("spatial_shapes", spatial_shapes),
                    ("level_start_index", level_start_index), ("sampling_loc", sampling_loc),
@@ -201,6 +203,6 @@ def ms_deform_attn_backward(value: torch.Tensor, spatial_shapes: torch.Tensor,
                 continue
             break
     _lib.check(rc, "ms_deform_attn_backward")
-    if grad_value.dtype != value.dtype:
+    if grad_value.dtype != value.dtype and not grad_value_f32:
         grad_value = grad_value.to(value.dtype)
     return [grad_value, grad_loc, grad_attn]

@@ -22,7 +22,6 @@
 #include "msda_prologue.cuh"
 #include "lsap.cuh"
 #include "msda_d48.cuh"
-#include "msda_d48_owner.cuh"
 #include "msda_d48_patch.cuh"
 #include "msda_generic.cuh"
 
@@ -43,7 +42,6 @@ snipper_msda_config default_config() {
   c.struct_bytes = (int32_t)sizeof(snipper_msda_config);
   c.policy = 0;
   c.near_radius = 6.0f;
-  c.deterministic = 0;
   c.tile_edge[0] = 16; c.tile_edge[1] = 8; c.tile_edge[2] = 4;
   return c;
 }
@@ -51,7 +49,7 @@ bool config_ok(const snipper_msda_config *cfg) {
   if (!cfg) return true;
   if (cfg->struct_bytes != (int32_t)sizeof(snipper_msda_config)) return false;
   if (cfg->policy < 0 || cfg->policy > 2) return false;
-  if (!(cfg->near_radius >= 0.f && cfg->near_radius <= 64.f) || cfg->deterministic < 0 || cfg->deterministic > 1) return false;
+  if (!(cfg->near_radius >= 0.f && cfg->near_radius <= 64.f)) return false;
   for (int i = 0; i < 3; ++i) {
     const int e = cfg->tile_edge[i];
     if (e < 1 || e > 16 || (e & (e - 1))) return false;
@@ -175,7 +173,7 @@ int backward_d48_f32(hipStream_t st, const float *grad_out, const float *value, 
   return launch_status();
 }
 
-// ---- deterministic owner-computes backward (msda_d48_patch.cuh) ----
+// ---- owner-computes backward for the encoder shape (msda_d48_patch.cuh): needs the level shapes on the HOST ----
 // Returns false when the geometry does not fit the marks' bounds (then the plain D=48 kernels run).
 bool make_patch_plan(const CoreDims &d, const int64_t *hs, const snipper_msda_config &cfg, PatchPlan *out) {
   PatchPlan p{};
@@ -231,7 +229,8 @@ bool make_patch_plan(const CoreDims &d, const int64_t *hs, const snipper_msda_co
   return true;
 }
 
-int backward_d48_patch(hipStream_t st, const void *grad_out, const float *value, const float *loc, const float *attn,
+template <typename VT>
+int backward_d48_patch(hipStream_t st, const void *grad_out, const VT *value, const float *loc, const float *attn,
                        CoreDims d, PatchPlan plan, void *workspace, float *grad_value, float *grad_loc,
                        float *grad_attn, int go_bf16) {
   const long long nm = (long long)d.N * d.M;
@@ -245,103 +244,30 @@ int backward_d48_patch(hipStream_t st, const void *grad_out, const float *value,
   const long long nblk_tiles = ((nm + 7) / 8) * 8 * plan.total_tiles;
   if (nblk_padded >= (1LL << 31) || nblk_tiles >= (1LL << 31)) return SNIPPER_E_SHAPE;
   if (go_bf16) {
-    hipLaunchKernelGGL((msda_bwd_d48_patchbin_kernel<true>), dim3((unsigned)nblk_padded), dim3(kPatchThreads), 0, st, grad_out,
+    hipLaunchKernelGGL((msda_bwd_d48_patchbin_kernel<VT, true>), dim3((unsigned)nblk_padded), dim3(kPatchThreads), 0, st, grad_out,
                        value, loc, attn, d, plan, grad_value, grad_loc, grad_attn, (int)nblk_padded);
     if (int rc = launch_status()) return rc;
     hipLaunchKernelGGL((msda_bwd_d48_tile2_kernel<128, true>), dim3((unsigned)nblk_tiles), dim3(kPatchThreads), 0, st, grad_out,
                        loc, attn, d, plan, grad_value);
   } else {
-    hipLaunchKernelGGL((msda_bwd_d48_patchbin_kernel<false>), dim3((unsigned)nblk_padded), dim3(kPatchThreads), 0, st, grad_out,
+    hipLaunchKernelGGL((msda_bwd_d48_patchbin_kernel<VT, false>), dim3((unsigned)nblk_padded), dim3(kPatchThreads), 0, st, grad_out,
                        value, loc, attn, d, plan, grad_value, grad_loc, grad_attn, (int)nblk_padded);
     if (int rc = launch_status()) return rc;
     hipLaunchKernelGGL((msda_bwd_d48_tile2_kernel<128, false>), dim3((unsigned)nblk_tiles), dim3(kPatchThreads), 0, st, grad_out,
                        loc, attn, d, plan, grad_value);
   }
-  g_last_variant = "d48_owner_det";
+  g_last_variant = "d48_owner";
   return launch_status();
 }
 
-// ---- owner-computes path (msda_d48_owner.cuh): needs the level shapes on the HOST and a workspace ----
 bool owner_shape_ok(const CoreDims &d, const int64_t *hs, int policy) {
-  if (policy != 0 || !hs || !d48_eligible<float>(d, policy) || d.L > kOwnerMaxLevels || d.P != kOwnerP || d.Lq != d.S) return false;
+  if (policy != 0 || !hs || !d48_eligible<float>(d, policy) || d.L > kPatchMaxLevels || d.P != kPatchP || d.Lq != d.S) return false;
   long long sum = 0;
   for (int l = 0; l < d.L; ++l) {
     if (hs[2 * l] <= 0 || hs[2 * l + 1] <= 0) return false;
     sum += hs[2 * l] * hs[2 * l + 1];
   }
   return sum == d.S && d.S < (1 << 24);
-}
-
-OwnerPlan make_owner_plan(const CoreDims &d, const int64_t *hs, const snipper_msda_config &cfg) {
-  OwnerPlan p{};
-  p.L = d.L;
-  p.radius = cfg.near_radius;
-  p.debug = 0;
-  int start = 0, base = 0;
-  for (int l = 0; l < d.L; ++l) {
-    OwnerLevel &v = p.lv[l];
-    v.H = (int)hs[2 * l];
-    v.W = (int)hs[2 * l + 1];
-    v.start = start;
-    start += v.H * v.W;
-    const int area = v.H * v.W;
-    const int e = cfg.tile_edge[area > 4096 ? 0 : (area > 1024 ? 1 : 2)];
-    v.shift = e >= 16 ? 4 : (e >= 8 ? 3 : (e >= 4 ? 2 : (e >= 2 ? 1 : 0)));
-    const int edge = 1 << v.shift;
-    v.ntx = (v.W + edge - 1) / edge;
-    v.nty = (v.H + edge - 1) / edge;
-    v.tile_base = base;
-    base += v.ntx * v.nty;
-  }
-  p.total_tiles = base;
-  // byte-map geometry: bounds of the candidate rectangles (msda_d48_owner.cuh, anchor_range: the span
-  // (edge + 1 + 2R) pixels of level l rescaled to level lq, +2 cells of margin, +2 for rounding)
-  long long lvl_base = 0;
-  for (int l = 0; l < d.L; ++l) {
-    const int edge = 1 << p.lv[l].shift;
-    int off = 0;
-    for (int lq = 0; lq < d.L; ++lq) {
-      const double span = (double)edge + 1.0 + 2.0 * p.radius;
-      int rw = (int)(span * p.lv[lq].W / p.lv[l].W) + 5, rh = (int)(span * p.lv[lq].H / p.lv[l].H) + 5;
-      if (rw > p.lv[lq].W) rw = p.lv[lq].W;
-      if (rh > p.lv[lq].H) rh = p.lv[lq].H;
-      p.rw[l][lq] = rw;
-      p.rh[l][lq] = rh;
-      p.coff[l][lq] = off;
-      off += rw * rh;
-    }
-    p.tstride[l] = (off + 15) & ~15;
-    p.lvl_base[l] = lvl_base;
-    lvl_base += (long long)p.lv[l].ntx * p.lv[l].nty * p.tstride[l];
-  }
-  p.bytes_per_nm = lvl_base;
-  return p;
-}
-
-int backward_d48_owner_f32(hipStream_t st, const float *grad_out, const float *value, const float *loc,
-                           const float *attn, CoreDims d, OwnerPlan plan, void *workspace,
-                           float *grad_value, float *grad_loc, float *grad_attn, int go_bf16 = 0) {
-  const long long nm = (long long)d.N * d.M;
-  plan.bitmap = reinterpret_cast<unsigned char *>(workspace);
-  hipError_t e = hipMemsetAsync(plan.bitmap, 0, (size_t)(nm * plan.bytes_per_nm), st);
-  if (e != hipSuccess) return (int)e;
-  // 1) grad_loc / grad_attn, marking of the near samples, HBM atomics for everything not marked
-  constexpr int kRows = kD48Block / 16;
-  const long long rows = (long long)d.N * d.Lq * d.M;
-  const int LP = d.L * d.P;
-  const int nblk = (int)((rows + kRows - 1) / kRows);
-  const int nblk_padded = (nblk + 7) & ~7;
-  const size_t lds = (size_t)kRows * (LP * sizeof(BinRecord) + 16);
-  hipLaunchKernelGGL(msda_bwd_d48_bin_kernel, dim3(nblk_padded), dim3(kD48Block), lds, st, grad_out, value, loc,
-                     attn, d, plan, grad_value, grad_loc, grad_attn, nblk_padded, go_bf16);
-  if (int rc = launch_status()) return rc;
-  // 2) every tile adds what it owns
-  const long long nblk_tiles = ((nm + 7) / 8) * 8 * plan.total_tiles;      // XCD-major grid (see the tile kernel)
-  if (nblk_tiles >= (1LL << 31)) return SNIPPER_E_SHAPE;
-  hipLaunchKernelGGL(msda_bwd_d48_tile_kernel<64>, dim3((unsigned)nblk_tiles), dim3(kOwnerBlock), 0, st, grad_out,
-                       loc, attn, d, plan, grad_value, go_bf16);
-  g_last_variant = "d48_owner";
-  return launch_status();
 }
 
 template <typename GVT> int zero_grad_value(hipStream_t st, GVT *gv, const CoreDims &d) {
@@ -405,14 +331,11 @@ int snipper_msda_forward_ex(void *stream, const snipper_msda_config *cfg, const 
 long long snipper_msda_backward_ex_workspace_bytes(const snipper_msda_config *cfg, const int64_t *host_shapes,
                                                    int value_dtype, int N, int S, int M, int D, int L, int Lq, int P) {
   const CoreDims d{N, S, M, D, L, Lq, P};
-  if (check_dims(N, S, M, D, L, Lq, P) != SNIPPER_OK || !config_ok(cfg) || value_dtype != 0) return 0;
+  if (check_dims(N, S, M, D, L, Lq, P) != SNIPPER_OK || !config_ok(cfg) || (value_dtype != 0 && value_dtype != 1)) return 0;
   const snipper_msda_config c = resolve(cfg);
   if (!owner_shape_ok(d, host_shapes, c.policy)) return 0;
-  if (c.deterministic) {
-    PatchPlan plan;
-    if (make_patch_plan(d, host_shapes, c, &plan)) return (long long)N * M * plan.words_per_nm * 8;
-  }
-  return (long long)N * M * make_owner_plan(d, host_shapes, c).bytes_per_nm;
+  PatchPlan plan;
+  return make_patch_plan(d, host_shapes, c, &plan) ? (long long)N * M * plan.words_per_nm * 8 : 0;
 }
 
 int snipper_msda_backward_ex(void *stream, const snipper_msda_config *cfg, const int64_t *host_shapes, void *workspace,
@@ -437,6 +360,12 @@ int snipper_msda_backward_ex(void *stream, const snipper_msda_config *cfg, const
   if (value_dtype == 1) {        // bf16 value / grad_out, gradients accumulate in float32
     if (grad_out_dtype != 1) return SNIPPER_E_UNSUPPORTED;
     if (int rc = zero_grad_value(st, (float *)grad_value, d)) return rc;
+    if (workspace && owner_shape_ok(d, host_shapes, c.policy)) {       // encoder shape: owner-computes (marks + sorted taps)
+      PatchPlan plan;
+      if (make_patch_plan(d, host_shapes, c, &plan) && workspace_bytes >= (long long)N * M * plan.words_per_nm * 8)
+        return backward_d48_patch<uint16_t>(st, grad_out, (const uint16_t *)value, (const float *)loc, (const float *)attn, d,
+                                            plan, workspace, (float *)grad_value, (float *)grad_loc, (float *)grad_attn, 1);
+    }
     return backward_generic<uint16_t, float, float>(st, (const uint16_t *)grad_out, (const uint16_t *)value, shapes,
                                                     level_start, (const float *)loc, (const float *)attn, d,
                                                     (float *)grad_value, (float *)grad_loc, (float *)grad_attn);
@@ -449,14 +378,8 @@ int snipper_msda_backward_ex(void *stream, const snipper_msda_config *cfg, const
   if (int rc = zero_grad_value(st, gv, d)) return rc;
   if (workspace && owner_shape_ok(d, host_shapes, c.policy)) {
     PatchPlan plan;
-    if (c.deterministic && make_patch_plan(d, host_shapes, c, &plan)) {
-      if (workspace_bytes >= (long long)N * M * plan.words_per_nm * 8)
-        return backward_d48_patch(st, grad_out, v, lo, at, d, plan, workspace, gv, gl, ga, go_bf16);
-    } else {
-      const OwnerPlan oplan = make_owner_plan(d, host_shapes, c);
-      if (workspace_bytes >= (long long)N * M * oplan.bytes_per_nm)
-        return backward_d48_owner_f32(st, (const float *)grad_out, v, lo, at, d, oplan, workspace, gv, gl, ga, go_bf16);
-    }
+    if (make_patch_plan(d, host_shapes, c, &plan) && workspace_bytes >= (long long)N * M * plan.words_per_nm * 8)
+      return backward_d48_patch<float>(st, grad_out, v, lo, at, d, plan, workspace, gv, gl, ga, go_bf16);
   }
   if (d48_eligible<float>(d, c.policy))
     return backward_d48_f32(st, (const float *)grad_out, v, shapes, level_start, lo, at, d, gv, gl, ga, go_bf16);

@@ -1,36 +1,45 @@
-// msda_d48_patch.cuh -- the DETERMINISTIC owner-computes backward for the encoder shape (D = 48, f32 value, P = 4,
+// msda_d48_patch.cuh -- "owner-computes" backward for the encoder shape (D = 48, float32 or bfloat16 value, P = 4,
 // L <= 4, Lq == S, level shapes known on the host).  gfx950 only.
 //
-// Same idea as msda_d48_owner.cuh (grad_value is cut into tiles, every tile has ONE owner workgroup that sums the taps
-// landing in it and adds the tile with plain stores), two differences:
-//   * the query side works on 8 x 8 blocks of queries of one level for one (batch, head), so "which queries reach which
-//     tile" is ONE 64-bit word per (tile, query block) -- 4 MB of marks per launch at N = 8 instead of a 58 MB byte map,
-//     no scan of it on the tile side;
-//   * the tile side sorts the owned taps by pixel with per-wave counters and a prefix (no order-dependent LDS atomics
-//     decide a float summation order), so grad_value is BIT-REPRODUCIBLE from launch to launch for every tap the tiles
-//     own (far taps keep their HBM float atomics, as in every variant).
-// Selected by snipper_msda_config.deterministic; measured 7 % slower than the msda_d48_owner.cuh pair on MI355X
-// (profiles/r02_lds_staging_experiment_kernel_avgs.csv: 462 + 586 us against 414 + 562 us per launch at N = 8), which
-// is why it is an option and not the default.
+// Why: the straightforward backward scatters every tap with a float atomic to HBM (the reference does exactly that,
+// /root/reference/models/ops/src/cuda/ms_deform_im2col_cuda.cuh:125-152).  On MI355X float atomics execute at the memory
+// side at ~1.3-1.9 TB/s chip-wide whatever the locality; an encoder launch adds N*S*M*L*P*4*D*4 B = 728 MB per sample:
+// 4.1 ms per launch at N = 8, 1.6 % of the HBM roofline, the largest kernel of the training step.
 //
-// What is NOT here any more: round 2 built the forward and the query-side backward around LDS-staged value
-// neighbourhoods (a workgroup stages its block's anchor range +- 5 px of every level by LDS-DMA and gathers from LDS),
-// in a one-head-per-workgroup and in a software-pipelined all-heads-per-workgroup form.  Both were parity-green and
-// both were slower than the texture-path kernels of msda_d48.cuh (forward 311 / 395 us against 272 us): a 62 KB float32
+// Idea: in the encoder the queries ARE the pixels of the L feature maps and a query samples each level near its own
+// position rescaled to that level (its "anchor").  grad_value is cut into tiles (one level, one (batch, head), 16 x 16 /
+// 8 x 8 / 4 x 4 pixels); every tile has ONE owner workgroup that sums the taps landing in it and adds the tile to HBM with
+// plain stores.  Two kernels:
+//   msda_bwd_d48_patchbin_kernel  query side, one workgroup per (batch, head, 8 x 8 block of queries of one level):
+//                                 grad_loc / grad_attn for every sample (64 rows x 4 points decoded by 256 threads, then
+//                                 32 rows x 8 lanes gather the tap rows -- lane j owns channels 4j..4j+3 and 32+2j, 33+2j
+//                                 -- with v_dot2c_f32_bf16 when value and grad_out are both bf16); "which queries of the
+//                                 block have a near tap in which tile" as ONE 64-bit word per (tile, block), OR-ed in LDS
+//                                 and stored once (4 MB of marks per launch at N = 8; round 1's byte map was 58 MB and
+//                                 had to be scanned); HBM float atomics for the taps no tile owns, re-dealt through LDS
+//                                 to 16 lanes per row so that every atomic instruction adds 64 contiguous bytes per row.
+//   msda_bwd_d48_tile2_kernel     grad_value side, one workgroup per (n, m, tile): expands the marks of its <= 256
+//                                 candidate blocks into a hit list (prefix over popcounts), re-decodes the hits' samples
+//                                 in rounds of 128 (the next round's locations prefetched behind the accumulate phase),
+//                                 ranks every owned tap within its (wave, pixel) counter and places it with a prefix over
+//                                 pixels, accumulates every pixel in registers from float32 rows staged in LDS, adds the
+//                                 tile.  No float sum depends on an arrival order: grad_value is BIT-REPRODUCIBLE from
+//                                 launch to launch for every tap the tiles own.
+// "near" = inside the map and |pixel - anchor| <= R on both axes, anchor a fixed function of the query INDEX; "owned" =
+// near, in the map, and the block is among the tile's candidates.  Both kernels evaluate them with the pinned arithmetic of
+// msda_d48.cuh, so owned + unowned is a partition of the taps for ANY input; locality only decides how many taps go the
+// fast way.  Measured against round 1's pair (byte map + LDS-atomic ranks, msda_d48_owner.cuh, removed): whole backward at
+// N = 8, bf16 rows, sigma 1.5 / 8 px: 1.07 / 2.33 ms against 1.15 / 2.40 ms; with a bfloat16 value 0.97 ms.
+//
+// What is NOT here: round 2 also built the forward and this query side around LDS-staged value neighbourhoods (anchor range
+// +- 5 px of every level staged by LDS-DMA, gathers from LDS), one-head-per-workgroup and software-pipelined.  Both were
+// parity-green and both were slower than the texture-path kernels (forward 311 / 395 us against 272 us): a 62 KB float32
 // window leaves two workgroups per CU, every phase becomes latency-bound, and LDS-DMA with per-lane addresses costs the
-// issuing wave as much as the register loads it replaces (skeleton + staging + gather times add up exactly in the
-// ablations of the profile above).  DESIGN.md section 3.4b has the numbers; the kernels were removed.
+// issuing wave as much as the register loads it replaces (profiles/r02_lds_staging_experiment_kernel_avgs.csv, DESIGN.md
+// section 3.4b); the kernels were removed.
 //
 // Semantics restated from /root/reference/models/ops/src/cuda/ms_deform_im2col_cuda.cuh:87-159 (tap gradients) and
 // :513-616 (backward, D = 48 branch); no code is shared with it.
-//
-//   msda_bwd_d48_patchbin_kernel  query side: grad_loc / grad_attn for every sample, marks, HBM float atomics for the
-//                                 taps no tile owns.
-//   msda_bwd_d48_tile2_kernel     grad_value side: one workgroup per (n, m, tile) expands the marks of its candidate
-//                                 blocks into a hit list, re-decodes the hits' samples, sorts the owned taps by pixel,
-//                                 accumulates every pixel in registers from float32 rows staged in LDS and adds the tile.
-// "near" and "owned" are pure functions of (query index, sample location, plan), evaluated with the pinned arithmetic
-// of msda_d48.cuh by both kernels: owned + unowned is a partition of the taps for ANY input.
 #pragma once
 #include "msda_d48.cuh"
 
@@ -39,7 +48,7 @@ namespace snipper {
 constexpr int kPatchMaxLevels = 4;
 constexpr int kPatchP = 4;
 constexpr int kPatchB = 8;                       // query block edge
-constexpr int kPatchThreads = 256;               // = 64 rows x 4 points (decode) = 32 rows x 8 lanes (gather)
+constexpr int kPatchThreads = 256;               // = 64 rows x 4 points (decode) = 32 rows x 8 lanes (gather) = 16 rows x 16 lanes (atomics)
 constexpr int kPatchRowBytes = kD48 * 4;         // 192
 constexpr int kPatchMaxTiles = 64;               // tiles one (block, level) may mark
 constexpr int kPatchMaxCand = 256;               // candidate blocks per tile (one per thread of the tile kernel)
@@ -173,17 +182,59 @@ __device__ __forceinline__ long long patch_slot(const PatchPlan &p, const PatchB
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// Backward, query side
+// Backward, query side.  VT = storage type of `value` (float, or uint16_t = bfloat16 bits: under bf16 autocast the
+// temporal mean of the projected memory can be kept in bf16, which halves the bytes of every tap row -- the gathers are
+// bound by the ~20 TB/s the texture path delivers, profiles/r02_lds_staging_experiment_kernel_avgs.csv); coordinates,
+// weights, all gradients and all sums stay float32.
 // ------------------------------------------------------------------------------------------------------------------
-template <bool GO_BF16>
+typedef __bf16 patch_bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int patch_u32x2 __attribute__((ext_vector_type(2)));
+
+// <grad_out slice, value tap row> over this lane's 6 channels (4j..4j+3, 32+2j, 33+2j)
+template <typename VT, bool GO_BF16> struct PatchDot;
+template <bool GO_BF16> struct PatchDot<float, GO_BF16> {
+  static constexpr unsigned kRowV = 192;
+  static __device__ __forceinline__ float dot(__amdgpu_buffer_rsrc_t vsrc, unsigned off, int j, const float (&g)[6],
+                                              const unsigned (&)[3]) {
+    const Row6 v = buf_row(vsrc, off, j);
+    return g[0] * v.a.x + g[1] * v.a.y + g[2] * v.a.z + g[3] * v.a.w + g[4] * v.b.x + g[5] * v.b.y;
+  }
+};
+template <bool GO_BF16> struct PatchDot<uint16_t, GO_BF16> {
+  static constexpr unsigned kRowV = 96;
+  static __device__ __forceinline__ float dot(__amdgpu_buffer_rsrc_t vsrc, unsigned off, int j, const float (&g)[6],
+                                              const unsigned (&gp)[3]) {
+    const patch_u32x2 a = __builtin_amdgcn_raw_buffer_load_b64(vsrc, off + 8u * j, 0, 0);
+    const unsigned b = __builtin_amdgcn_raw_buffer_load_b32(vsrc, off + 64u + 4u * j, 0, 0);
+    // (elements by INDEX: with `.x` / `.y` on the loaded pair, hipcc of ROCm 7.2 narrows the load to one dword and feeds
+    //  the first element to both products -- reproduced in isolation, round 2)
+    const unsigned ax = a[0], ay = a[1];
+    if constexpr (GO_BF16) {        // both operands are bf16 pairs: v_dot2c_f32_bf16, products exact, float32 sums
+      float acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(patch_bf16x2, ax), __builtin_bit_cast(patch_bf16x2, gp[0]), 0.f, false);
+      acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(patch_bf16x2, ay), __builtin_bit_cast(patch_bf16x2, gp[1]), acc, false);
+      return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(patch_bf16x2, b), __builtin_bit_cast(patch_bf16x2, gp[2]), acc, false);
+    } else {
+      return g[0] * __uint_as_float(ax << 16) + g[1] * __uint_as_float(ax & 0xffff0000u) +
+             g[2] * __uint_as_float(ay << 16) + g[3] * __uint_as_float(ay & 0xffff0000u) +
+             g[4] * __uint_as_float(b << 16) + g[5] * __uint_as_float(b & 0xffff0000u);
+    }
+  }
+};
+
+template <typename VT, bool GO_BF16>
 __global__ __launch_bounds__(kPatchThreads) void msda_bwd_d48_patchbin_kernel(
-    const void *__restrict__ grad_out, const float *__restrict__ value, const float *__restrict__ loc,
+    const void *__restrict__ grad_out, const VT *__restrict__ value, const float *__restrict__ loc,
     const float *__restrict__ attn, CoreDims d, PatchPlan plan, float *__restrict__ grad_value,
     float *__restrict__ grad_loc, float *__restrict__ grad_attn, int nblk_padded) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[kPatchThreads * sizeof(PatchRec) + 2 * kPatchMaxTiles * 16];
+  using DOT = PatchDot<VT, GO_BF16>;
+  constexpr unsigned kRowV = DOT::kRowV;                 // bytes of one head row of `value`
+  constexpr int kRows = kPatchB * kPatchB;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[kPatchThreads * sizeof(PatchRec) + 2 * kPatchMaxTiles * 16 +
+                                                           kRows * kPatchRowBytes];
   PatchRec *recs = reinterpret_cast<PatchRec *>(smem);
   unsigned long long *s_mask = reinterpret_cast<unsigned long long *>(recs + kPatchThreads);   // [2][kPatchMaxTiles]
   long long *s_slot = reinterpret_cast<long long *>(s_mask + 2 * kPatchMaxTiles);              // [2][kPatchMaxTiles]
+  float *s_g = reinterpret_cast<float *>(s_slot + 2 * kPatchMaxTiles);                         // [64 rows][48]: grad_out rows
   PatchBlock b;
   if (!patch_block(plan, d, nblk_padded, b)) return;
   const int tid = threadIdx.x;
@@ -194,15 +245,18 @@ __global__ __launch_bounds__(kPatchThreads) void msda_bwd_d48_patchbin_kernel(
   const bool rd_ok = rdy < b.bh && rdx < b.bw;
   const int qd = rd_ok ? lvq.start + (b.qy0 + rdy) * lvq.W + b.qx0 + rdx : lvq.start;
   const long long rowd = ((long long)b.n * d.Lq + qd) * d.M + b.m;
-  const unsigned px_stride = (unsigned)d.M * kPatchRowBytes;
-  const unsigned gbase = (unsigned)(b.n * d.S) * px_stride + (unsigned)b.m * kPatchRowBytes;
+  const unsigned px_stride = (unsigned)d.M * kRowV;
+  const unsigned gbase = (unsigned)(b.n * d.S) * px_stride + (unsigned)b.m * kRowV;
   const int j = tid & 7, rg = tid >> 3;
-  const unsigned value_bytes = (unsigned)((size_t)d.N * d.S * d.M * kPatchRowBytes);
-  const auto vsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(value), 0, (int)value_bytes, 0x00020000);
-  const auto gsrc = __builtin_amdgcn_make_buffer_rsrc(grad_value, 0, (int)value_bytes, 0x00020000);
+  const unsigned value_bytes = (unsigned)((size_t)d.N * d.S * d.M * kRowV);
+  const unsigned gv_bytes = (unsigned)((size_t)d.N * d.S * d.M * kPatchRowBytes);
+  const auto vsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<VT *>(value), 0, (int)value_bytes, 0x00020000);
+  const auto gsrc = __builtin_amdgcn_make_buffer_rsrc(grad_value, 0, (int)gv_bytes, 0x00020000);
 
-  // this thread's slices of the two grad_out rows it gathers for (channels 4j..4j+3, 32+2j, 33+2j)
+  // this thread's slices of the two grad_out rows it gathers for (channels 4j..4j+3, 32+2j, 33+2j); the rows also go to
+  // LDS for the atomic phase, which re-deals them over 16 lanes per row
   float g[2][6];
+  unsigned gp[2][3];
   long long rowg[2];
   bool rg_ok[2];
 #pragma unroll
@@ -211,10 +265,12 @@ __global__ __launch_bounds__(kPatchThreads) void msda_bwd_d48_patchbin_kernel(
     rg_ok[ps] = ry < b.bh && rx < b.bw;
     const int q = rg_ok[ps] ? lvq.start + (b.qy0 + ry) * lvq.W + b.qx0 + rx : lvq.start;
     rowg[ps] = ((long long)b.n * d.Lq + q) * d.M + b.m;
+    gp[ps][0] = gp[ps][1] = gp[ps][2] = 0u;
     if constexpr (GO_BF16) {
       const uint16_t *gr = reinterpret_cast<const uint16_t *>(grad_out) + rowg[ps] * kD48;
       const uint2 pa = *reinterpret_cast<const uint2 *>(gr + 4 * j);
       const unsigned pb = *reinterpret_cast<const unsigned *>(gr + 32 + 2 * j);
+      gp[ps][0] = pa.x; gp[ps][1] = pa.y; gp[ps][2] = pb;
       g[ps][0] = __uint_as_float(pa.x << 16); g[ps][1] = __uint_as_float(pa.x & 0xffff0000u);
       g[ps][2] = __uint_as_float(pa.y << 16); g[ps][3] = __uint_as_float(pa.y & 0xffff0000u);
       g[ps][4] = __uint_as_float(pb << 16);   g[ps][5] = __uint_as_float(pb & 0xffff0000u);
@@ -227,7 +283,11 @@ __global__ __launch_bounds__(kPatchThreads) void msda_bwd_d48_patchbin_kernel(
     if (!rg_ok[ps]) {
 #pragma unroll
       for (int c = 0; c < 6; ++c) g[ps][c] = 0.f;
+      gp[ps][0] = gp[ps][1] = gp[ps][2] = 0u;
     }
+    f32x4 ga4; ga4.x = g[ps][0]; ga4.y = g[ps][1]; ga4.z = g[ps][2]; ga4.w = g[ps][3];
+    *reinterpret_cast<f32x4 *>(s_g + r * kD48 + 4 * j) = ga4;
+    *reinterpret_cast<float2 *>(s_g + r * kD48 + 32 + 2 * j) = make_float2(g[ps][4], g[ps][5]);
   }
 
   // slots of the first level (later levels: computed one level ahead, behind the gather of the current one)
@@ -265,6 +325,7 @@ __global__ __launch_bounds__(kPatchThreads) void msda_bwd_d48_patchbin_kernel(
     const PatchTileBox tb = patch_tile_box(plan, b, l);
     unsigned long long *mask_l = s_mask + (l & 1) * kPatchMaxTiles;
     const long long *slot_l = s_slot + (l & 1) * kPatchMaxTiles;
+    unsigned my_bits = 0u;
     {
       const float2 xy = xy_l[l];
       const float a_in = a_l[l];
@@ -276,7 +337,7 @@ __global__ __launch_bounds__(kPatchThreads) void msda_bwd_d48_patchbin_kernel(
       const int y0 = (int)yf, x0 = (int)xf;
       PatchRec r;
       r.w.x = inside ? y - yf : 0.f; r.w.y = inside ? x - xf : 0.f; r.w.z = inside ? a_in : 0.f;
-      unsigned go[4], bits = 0u;
+      unsigned go[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const int ty = y0 + (k >> 1), tx = x0 + (k & 1);
@@ -293,13 +354,13 @@ __global__ __launch_bounds__(kPatchThreads) void msda_bwd_d48_patchbin_kernel(
             }
           }
         }
-        bits |= (in_map && !owned) ? (16u << k) : 0u;           // need: no tile owns the tap -> HBM atomic here
+        my_bits |= (in_map && !owned) ? (16u << k) : 0u;        // need: no tile owns the tap -> HBM atomic here
       }
-      r.w.w = __uint_as_float(bits);
+      r.w.w = __uint_as_float(my_bits);
       r.g.x = go[0]; r.g.y = go[1]; r.g.z = go[2]; r.g.w = go[3];
       recs[tid] = r;
     }
-    __syncthreads();     // records and masks complete
+    const int any_need = __syncthreads_or((int)my_bits);     // records and masks complete; does ANY tap need an atomic?
 
     if (tid < kPatchMaxTiles && slot_l[tid] >= 0 && mask_l[tid] != 0ull) plan.marks[slot_l[tid]] = mask_l[tid];
     if (l + 1 < plan.L) fill_slots(l + 1);
@@ -308,9 +369,6 @@ __global__ __launch_bounds__(kPatchThreads) void msda_bwd_d48_patchbin_kernel(
 #pragma unroll
     for (int ps = 0; ps < 2; ++ps) {
       const PatchRec *mine = recs + (ps * 32 + rg) * kPatchP;
-      unsigned allbits = 0u;
-#pragma unroll
-      for (int p = 0; p < kPatchP; ++p) allbits |= __float_as_uint(mine[p].w.w);
       float keep_a = 0.f, keep_x = 0.f, keep_y = 0.f;
 #pragma unroll
       for (int p = 0; p < kPatchP; ++p) {
@@ -320,11 +378,8 @@ __global__ __launch_bounds__(kPatchThreads) void msda_bwd_d48_patchbin_kernel(
         const unsigned go[4] = {r.g.x, r.g.y, r.g.z, r.g.w};
         float dot[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {          // (a tap outside the map has offset kOobOffset: the buffer load returns 0)
-          const Row6 v = buf_row(vsrc, go[k], j);
-          dot[k] = g[ps][0] * v.a.x + g[ps][1] * v.a.y + g[ps][2] * v.a.z + g[ps][3] * v.a.w + g[ps][4] * v.b.x +
-                   g[ps][5] * v.b.y;
-        }
+        for (int k = 0; k < 4; ++k)            // (a tap outside the map has offset kOobOffset: the buffer load returns 0)
+          dot[k] = DOT::dot(vsrc, go[k], j, g[ps], gp[ps]);
         float pa = hh * hw * dot[0] + hh * lw * dot[1] + lh * hw * dot[2] + lh * lw * dot[3];
         float px = hh * (dot[1] - dot[0]) + lh * (dot[3] - dot[2]);
         float py = hw * (dot[2] - dot[0]) + lw * (dot[3] - dot[1]);
@@ -338,38 +393,32 @@ __global__ __launch_bounds__(kPatchThreads) void msda_bwd_d48_patchbin_kernel(
         grad_attn[li] = keep_a;
         *reinterpret_cast<float2 *>(grad_loc + 2 * li) = make_float2(keep_x, keep_y);
       }
-      // taps no tile owns (sample not near its anchor, or beyond the marks' capacity): the HBM float atomic of
-      // msda_d48.cuh, re-dealt so that the 8 lanes of a row add 32 contiguous bytes per instruction
-      if (__builtin_amdgcn_ballot_w64((allbits & 0xf0u) != 0u) != 0ull) {
-        float ga[6];
-#pragma unroll
-        for (int e = 0; e < 6; ++e) {
-          const int c = j + 8 * e;                                  // the channel this lane adds in step e
-          const int src = c < 32 ? (c >> 2) : ((c - 32) >> 1);      // lane (within the row group) that holds it
-          const int el = c < 32 ? (c & 3) : 4 + (c & 1);
-          float v = 0.f;
-#pragma unroll
-          for (int t = 0; t < 6; ++t) {
-            const float s = __shfl(g[ps][t], src, 8);
-            v = (el == t) ? s : v;
-          }
-          ga[e] = v;
-        }
+    }
+    // taps no tile owns (sample not near its anchor, or beyond the marks' capacity): the HBM float atomic of
+    // msda_d48.cuh.  Re-dealt to 16 lanes per row, lane i adding channels {i, i+16, i+32}: every atomic instruction then
+    // adds 64 contiguous bytes per row (the shape the memory-side atomic units take at full rate).
+    if (any_need) {
+      const int ai = tid & 15, ar = tid >> 4;
+#pragma unroll 1
+      for (int pass = 0; pass < kRows / 16; ++pass) {
+        const int r = pass * 16 + ar;
+        const float g0 = s_g[r * kD48 + ai], g1 = s_g[r * kD48 + 16 + ai], g2 = s_g[r * kD48 + 32 + ai];
 #pragma unroll
         for (int p = 0; p < kPatchP; ++p) {
-          const PatchRec r = mine[p];
-          const unsigned bits = __float_as_uint(r.w.w) >> 4;
+          const PatchRec rc = recs[r * kPatchP + p];
+          const unsigned bits = __float_as_uint(rc.w.w) >> 4;
           if (__builtin_amdgcn_ballot_w64(bits != 0u) == 0ull) continue;
-          const float lh = r.w.x, lw = r.w.y, a = r.w.z;
+          const float lh = rc.w.x, lw = rc.w.y, a = rc.w.z;
           const float hh = 1.f - lh, hw = 1.f - lw;
           const float wk[4] = {hh * hw * a, hh * lw * a, lh * hw * a, lh * lw * a};
-          const unsigned go[4] = {r.g.x, r.g.y, r.g.z, r.g.w};
+          const unsigned go[4] = {rc.g.x, rc.g.y, rc.g.z, rc.g.w};
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
-            const unsigned o = ((bits >> k) & 1u) ? go[k] + 4u * j : kOobOffset;
-#pragma unroll
-            for (int e = 0; e < 6; ++e)
-              __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(wk[k] * ga[e], gsrc, o + 32u * e, 0, 0);
+            // value offsets are in rows of kRowV bytes, grad_value rows are 192 B
+            const unsigned o = ((bits >> k) & 1u) ? go[k] * (kPatchRowBytes / kRowV) + 4u * ai : kOobOffset;
+            __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(wk[k] * g0, gsrc, o, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(wk[k] * g1, gsrc, o + 64u, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(wk[k] * g2, gsrc, o + 128u, 0, 0);
           }
         }
       }

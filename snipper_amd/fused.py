@@ -8,6 +8,7 @@ from typing import List, Optional, Sequence
 
 import torch
 from torch.autograd import Function
+from torch.autograd.function import once_differentiable
 
 from . import _lib
 
@@ -63,6 +64,55 @@ class TemporalMix(Function):
         mix_t = [[mix[a][b] for a in range(len(mix))] for b in range(len(mix[0]))]
         g = _mix_launch(grad_out.contiguous().float(), m8, False, mix_t, ctx.in_dtype)
         return g, None, None
+
+
+class TiedSampler(Function):
+    """The tied module core as ONE autograd node: core_op(temporal mean of the neighbouring, padding-masked value frames,
+    loc, prob)  (reference models/ops/modules/ms_deform_attn.py:116, 130-226 with the per-frame Linears tied, DESIGN.md
+    section 4).  Fusing TemporalMix with the core op keeps the mean -- ``vbar`` -- internal to the node, which is what allows
+    it to be held in bfloat16 under bf16 autocast (``vbar_bf16``: the projected value is bf16 already; the tap rows of the
+    gathers, which are bound by the bytes the texture path moves, halve: forward 0.28 -> 0.17 ms, backward 1.15 -> 0.97 ms per
+    encoder launch at N = 8) while its float32 gradient goes straight into the transposed mix without a cast round trip.
+
+    value [N, T2, S, C] (f32 / bf16), mask [N, T2, S] or None, mix: host list [T1][T2], loc [N*T1, Lq, M, L, P, 2] and
+    prob [N*T1, Lq, M, L, P] float32  ->  [N*T1, Lq, C] (bf16 rows when ``rows_bf16`` or ``vbar_bf16``)."""
+
+    @staticmethod
+    def forward(ctx, value, mask, mix, loc, prob, shapes, lsi, M, im2col_step, rows_bf16, vbar_bf16):
+        from . import MultiScaleDeformableAttention as MSDA
+        value = value.contiguous()
+        N, T2, S, C = value.shape
+        m8 = None
+        if mask is not None:
+            m8 = mask.contiguous().view(torch.uint8) if mask.dtype == torch.bool else mask.contiguous()
+        host_shapes = getattr(shapes, "_snipper_host", None)
+        vbar = _mix_launch(value, m8, True, mix, torch.bfloat16 if vbar_bf16 else torch.float32)
+        v4 = vbar.view(N * len(mix), S, M, C // M)
+        out = MSDA.ms_deform_attn_forward(v4, shapes, lsi, loc, prob, im2col_step,
+                                          out_bf16=bool(rows_bf16) and not vbar_bf16, host_shapes=host_shapes)
+        ctx.mix, ctx.in_dtype, ctx.dims, ctx.host_shapes, ctx.step = mix, value.dtype, (N, len(mix), S, C), host_shapes, im2col_step
+        ctx.has_mask = m8 is not None
+        ctx.save_for_backward(v4, shapes, lsi, loc, prob, *([m8] if m8 is not None else []))
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_out):
+        from . import MultiScaleDeformableAttention as MSDA
+        v4, shapes, lsi, loc, prob = ctx.saved_tensors[:5]
+        m8 = ctx.saved_tensors[5] if ctx.has_mask else None
+        N, T1, S, C = ctx.dims
+        go = grad_out.contiguous()
+        if v4.dtype == torch.bfloat16 and go.dtype != torch.bfloat16:
+            go = go.to(torch.bfloat16)
+        elif v4.dtype == torch.float32 and go.dtype not in (torch.float32, torch.bfloat16):
+            go = go.float()
+        gv, gl, ga = MSDA.ms_deform_attn_backward(v4, shapes, lsi, loc, prob, go, ctx.step, host_shapes=ctx.host_shapes,
+                                                  grad_value_f32=True)
+        mix = ctx.mix
+        mix_t = [[mix[a][b] for a in range(len(mix))] for b in range(len(mix[0]))]
+        g_value = _mix_launch(gv.view(N, T1, S, C), m8, False, mix_t, ctx.in_dtype)
+        return g_value, None, None, gl, ga, None, None, None, None, None, None
 
 
 def _query_rows(t: torch.Tensor, width: int):

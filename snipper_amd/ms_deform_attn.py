@@ -72,6 +72,10 @@ class MSDeformAttn(nn.Module):
         self.attention_vis = attention_vis
         self.core_in_fp32 = True    # see _core
         self.fused_elementwise = True   # HIP kernels for mask / temporal mean / locations / softmax
+        # bf16 autocast, encoder (Lq == S): keep the temporal mean of the (bf16) projected value in bf16 for the sampling
+        # kernels -- halves the tap-row bytes that bound them; coordinates, weights, sums and all gradients stay float32
+        # (fused.TiedSampler).  False = float32 mean, as in round 1.
+        self.value_bf16 = True
 
         shared_offsets = nn.Linear(d_model, n_heads * n_levels * n_points * 2)
         shared_weights = nn.Linear(d_model, n_heads * n_levels * n_points)
@@ -199,6 +203,17 @@ class MSDeformAttn(nn.Module):
         if fuse and not (identity and mask is None and value.dtype == torch.float32):
             mix = [[(1.0 / len(g)) if t2 in g else 0.0 for t2 in range(T2)] for g in groups]
             m2 = None if mask is None else (mask if mask.dim() == 3 else mask[..., 0])
+            amp16 = (value.is_cuda and torch.is_autocast_enabled('cuda') and
+                     torch.get_autocast_dtype('cuda') == torch.bfloat16)
+            if value.is_cuda and value.dtype in (torch.float32, torch.bfloat16) and C // M == 48:
+                # mean + core op as one node (fused.TiedSampler); under bf16 autocast the encoder's mean stays bf16
+                from .fused import TiedSampler
+                vbar16 = bool(self.value_bf16 and amp16 and value.dtype == torch.bfloat16 and Lq == S and
+                              not self.attention_vis)
+                out = TiedSampler.apply(value.reshape(N, T2, S, C), m2, mix, loc.reshape(N * T1, Lq, M, L, P, 2).contiguous(),
+                                        prob.reshape(N * T1, Lq, M, L, P).contiguous(), shapes, lsi, M, self.im2col_step,
+                                        amp16, vbar16)
+                return out.view(N, T1, Lq, C), *self._vis_lists(loc, prob, groups, N, Lq, M, L, P)
             vbar = TemporalMix.apply(value.reshape(N, T2, S, C), m2, mix).view(N, T1, S, M, C // M)
         else:
             if mask is not None:
@@ -214,7 +229,9 @@ class MSDeformAttn(nn.Module):
         out = self._core(vbar.reshape(N * T1, S, M, C // M), shapes, lsi,
                          loc.reshape(N * T1, Lq, M, L, P, 2), prob.reshape(N * T1, Lq, M, L, P))
         out = out.view(N, T1, Lq, C)
+        return out, *self._vis_lists(loc, prob, groups, N, Lq, M, L, P)
 
+    def _vis_lists(self, loc, prob, groups, N, Lq, M, L, P):
         locs = wts = None
         if self.attention_vis:   # same lists as reference :228-233, built as views
             locs, wts = [], []
@@ -225,7 +242,7 @@ class MSDeformAttn(nn.Module):
                 k = len(g)
                 locs.append(loc[:, t1].detach().unsqueeze(-2).expand(N, Lq, M, L, P, k, 2))
                 wts.append(scaled[k][:, t1].unsqueeze(-1).expand(N, Lq, M, L, P, k))
-        return out, locs, wts
+        return locs, wts
 
     # -- the reference's per-pair evaluation, for untied Linears ------------------------------
     def _forward_pairs(self, query, ref, value, shapes, lsi, scale, groups):

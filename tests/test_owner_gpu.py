@@ -49,18 +49,10 @@ def grid_case(N, shapes, M, P, seed, spread_px, frac_far=0.0, dtype=np.float32):
     return value, shapes, O.level_start_index(shapes), loc, attn, go
 
 
-def run_hip(v, shapes, lsi, loc, attn, go, host_shapes, deterministic=False):
+def run_hip(v, shapes, lsi, loc, attn, go, host_shapes):
     t = lambda a: torch.from_numpy(a).to(DEV)
-    cfg = None
-    if deterministic:          # the bit-reproducible variant (csrc/msda_d48_patch.cuh), same knobs as the active test config
-        cfg = _lib.Config.defaults() if _lib.active_config() is None else _lib.Config.from_buffer_copy(_lib.active_config())
-        cfg.deterministic = 1
-    out = MSDA.ms_deform_attn_backward(t(v), t(shapes), t(lsi), t(loc), t(attn), t(go), 64, host_shapes=host_shapes,
-                                       config=cfg)
+    out = MSDA.ms_deform_attn_backward(t(v), t(shapes), t(lsi), t(loc), t(attn), t(go), 64, host_shapes=host_shapes)
     return [x.cpu().numpy() for x in out], _lib.last_variant()
-
-
-OWNER = {False: "d48_owner", True: "d48_owner_det"}
 
 
 CASES = {
@@ -73,15 +65,14 @@ CASES = {
 }
 
 
-@pytest.mark.parametrize("det", [False, True], ids=["fast", "deterministic"])
 @pytest.mark.parametrize("name", sorted(CASES))
-def test_owner_backward_matches_oracle(name, det):
+def test_owner_backward_matches_oracle(name):
     N, shapes, M, P, spread, far = CASES[name]
     v, sh, lsi, loc, attn, go = grid_case(N, shapes, M, P, seed=len(name), spread_px=spread, frac_far=far)
     f64 = lambda a: a.astype(np.float64)
     ref = O.core_c_backward(f64(v), sh, lsi, f64(loc), f64(attn), f64(go), threads=4)
-    (gv, gl, ga), variant = run_hip(v, sh, lsi, loc, attn, go, [tuple(x) for x in sh.tolist()], det)
-    assert variant == OWNER[det], variant
+    (gv, gl, ga), variant = run_hip(v, sh, lsi, loc, attn, go, [tuple(x) for x in sh.tolist()])
+    assert variant == "d48_owner", variant
     np.testing.assert_allclose(gv, ref[0], rtol=1e-4, atol=5e-5)
     s = float(np.abs(ref[1]).max())
     np.testing.assert_allclose(gl / s, ref[1] / s, rtol=1e-4, atol=2e-5)
@@ -94,10 +85,9 @@ def test_owner_backward_matches_oracle(name, det):
     np.testing.assert_allclose(ga, ga2, rtol=1e-4, atol=1e-5)
 
 
-@pytest.mark.parametrize("det", [False, True], ids=["fast", "deterministic"])
 @pytest.mark.parametrize("radius", [0.0, 0.75, 3.0, 40.0])
 @pytest.mark.parametrize("edges", [(16, 8, 4), (8, 8, 8), (4, 4, 2), (16, 16, 16), (1, 1, 1)])
-def test_partition_holds_for_any_radius_and_tiling(radius, edges, det):
+def test_partition_holds_for_any_radius_and_tiling(radius, edges):
     """Whatever the near radius / tile sizes, near + far must add up to the same gradient."""
     v, sh, lsi, loc, attn, go = grid_case(2, [(21, 26), (11, 13), (6, 7)], 4, 4, seed=5, spread_px=2.5, frac_far=0.1)
     f64 = lambda a: a.astype(np.float64)
@@ -106,10 +96,10 @@ def test_partition_holds_for_any_radius_and_tiling(radius, edges, det):
         _lib.set_param("near_radius", radius)
         for k, e in zip(("big", "mid", "small"), edges):
             _lib.set_param(f"owner_tile_edge_{k}", e)
-        (gv, _, _), variant = run_hip(v, sh, lsi, loc, attn, go, [tuple(x) for x in sh.tolist()], det)
+        (gv, _, _), variant = run_hip(v, sh, lsi, loc, attn, go, [tuple(x) for x in sh.tolist()])
     finally:
         _lib.reset_config()
-    assert variant == OWNER[det]
+    assert variant == "d48_owner"
     np.testing.assert_allclose(gv, ref, rtol=1e-4, atol=5e-5)
 
 
@@ -130,10 +120,6 @@ def test_full_size_encoder_backward_owner_vs_atomics():
     v, sh, lsi, loc, attn, go = grid_case(2, shapes, 8, 4, seed=3, spread_px=3.0, frac_far=0.01)
     (gv, gl, ga), variant = run_hip(v, sh, lsi, loc, attn, go, shapes)
     assert variant == "d48_owner"
-    (gv3, gl3, ga3), variant3 = run_hip(v, sh, lsi, loc, attn, go, shapes, True)
-    assert variant3 == "d48_owner_det"
-    np.testing.assert_allclose(gv, gv3, rtol=2e-4, atol=2e-4)
-    np.testing.assert_allclose(gl, gl3, rtol=1e-4, atol=1e-3)
     (gv2, gl2, ga2), _ = run_hip(v, sh, lsi, loc, attn, go, None)
     np.testing.assert_allclose(gv, gv2, rtol=2e-4, atol=2e-4)
     np.testing.assert_allclose(gl, gl2, rtol=1e-4, atol=1e-3)
@@ -151,24 +137,21 @@ GEOMETRIES = {
 }
 
 
-@pytest.mark.parametrize("det", [False, True], ids=["fast", "deterministic"])
 @pytest.mark.parametrize("geom", sorted(GEOMETRIES))
 @pytest.mark.parametrize("spread,far", [(2.0, 0.0), (3.0, 0.2), (8.0, 0.5)], ids=["local", "far20", "wide_far50"])
-def test_full_size_owner_backward_directly_against_oracle(geom, spread, far, det):
+def test_full_size_owner_backward_directly_against_oracle(geom, spread, far):
     """The dominant kernels of the training step (owner-computes backward, D=48 forward) at FULL map size, N=1,
     compared DIRECTLY with the C oracle (float64), not through the atomic kernel."""
     shapes = GEOMETRIES[geom]
     v, sh, lsi, loc, attn, go = grid_case(1, shapes, 8, 4, seed=11, spread_px=spread, frac_far=far)
     f64 = lambda a: a.astype(np.float64)
     ref = O.core_c_backward(f64(v), sh, lsi, f64(loc), f64(attn), f64(go), threads=32)
-    (gv, gl, ga), variant = run_hip(v, sh, lsi, loc, attn, go, shapes, det)
-    assert variant == OWNER[det]
+    (gv, gl, ga), variant = run_hip(v, sh, lsi, loc, attn, go, shapes)
+    assert variant == "d48_owner"
     np.testing.assert_allclose(gv, ref[0], rtol=1e-4, atol=2e-4)
     s = float(np.abs(ref[1]).max())
     np.testing.assert_allclose(gl / s, ref[1] / s, rtol=1e-4, atol=2e-5)
     np.testing.assert_allclose(ga, ref[2], rtol=1e-4, atol=1e-4)
-    if det:
-        return
     # forward of the same inputs
     t = lambda a: torch.from_numpy(a).to(DEV)
     ref_out = O.core_c_forward(f64(v), sh, lsi, f64(loc), f64(attn), threads=32)
@@ -184,20 +167,45 @@ def test_full_size_owner_backward_directly_against_oracle(geom, spread, far, det
     np.testing.assert_allclose(gv2, ref[0], rtol=1e-4, atol=2e-4)
 
 
-def test_deterministic_backward_is_bit_reproducible_for_near_samples():
-    """config.deterministic: all-near inputs (no far taps, hence no HBM float atomics) must give identical bits from
-    launch to launch, for float32 and for bfloat16 grad_out rows."""
+def test_owner_backward_is_bit_reproducible_for_near_samples():
+    """All-near inputs (no far taps, hence no HBM float atomics) must give identical bits from launch to launch, for
+    float32 and for bfloat16 grad_out rows: no float sum of the owner-computes kernels depends on an arrival order."""
     shapes = GEOMETRIES["600x800"]
     v, sh, lsi, loc, attn, go = grid_case(2, shapes, 8, 4, seed=4, spread_px=1.5, frac_far=0.0)
-    (a, _, _), variant = run_hip(v, sh, lsi, loc, attn, go, shapes, True)
-    assert variant == "d48_owner_det"
+    (a, _, _), variant = run_hip(v, sh, lsi, loc, attn, go, shapes)
+    assert variant == "d48_owner"
     for _ in range(3):
-        (b, _, _), _ = run_hip(v, sh, lsi, loc, attn, go, shapes, True)
+        (b, _, _), _ = run_hip(v, sh, lsi, loc, attn, go, shapes)
         assert np.array_equal(a, b)
-    cfg = _lib.Config.defaults()
-    cfg.deterministic = 1
     t = lambda x: torch.from_numpy(x).to(DEV)
     outs = [MSDA.ms_deform_attn_backward(t(v), t(sh), t(lsi), t(loc), t(attn), t(go).to(torch.bfloat16), 64,
-                                         host_shapes=shapes, config=cfg)[0] for _ in range(3)]
+                                         host_shapes=shapes)[0] for _ in range(3)]
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
     np.testing.assert_allclose(outs[0].cpu().numpy(), a, rtol=0.02, atol=0.05)      # bf16-rounded grad_out rows
+
+
+@pytest.mark.parametrize("geom", ["small", "600x800"])
+@pytest.mark.parametrize("spread,far", [(2.0, 0.0), (4.0, 0.3)], ids=["local", "far30"])
+def test_bf16_value_owner_backward_against_oracle(geom, spread, far):
+    """bfloat16 ``value`` (and grad_out rows) through the owner-computes kernels (v_dot2c_f32_bf16 dot products, float32
+    everything else) against the C oracle in float64 on the SAME bf16-rounded value / grad_out."""
+    shapes = GEOMETRIES[geom] if geom in GEOMETRIES else [(19, 25), (10, 13), (5, 7)]
+    v, sh, lsi, loc, attn, go = grid_case(1 if geom != "small" else 2, shapes, 8, 4, seed=21, spread_px=spread, frac_far=far)
+    t = lambda a: torch.from_numpy(a).to(DEV)
+    v16, go16 = t(v).to(torch.bfloat16), t(go).to(torch.bfloat16)
+    f64 = lambda a: a.astype(np.float64)
+    ref_out = O.core_c_forward(f64(v16.float().cpu().numpy()), sh, lsi, f64(loc), f64(attn), threads=32)
+    ref = O.core_c_backward(f64(v16.float().cpu().numpy()), sh, lsi, f64(loc), f64(attn), f64(go16.float().cpu().numpy()),
+                            threads=32)
+    out = MSDA.ms_deform_attn_forward(v16, t(sh), t(lsi), t(loc), t(attn), 64, host_shapes=shapes)
+    assert out.dtype == torch.bfloat16
+    np.testing.assert_allclose(out.float().cpu().numpy(), ref_out, rtol=2 ** -7, atol=2e-2)
+    gv, gl, ga = MSDA.ms_deform_attn_backward(v16, t(sh), t(lsi), t(loc), t(attn), go16, 64, host_shapes=shapes,
+                                              grad_value_f32=True)
+    assert _lib.last_variant() == "d48_owner" and gv.dtype == torch.float32
+    np.testing.assert_allclose(gv.cpu().numpy(), ref[0], rtol=1e-4, atol=2e-4)
+    s = float(np.abs(ref[1]).max())
+    np.testing.assert_allclose(gl.cpu().numpy() / s, ref[1] / s, rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(ga.cpu().numpy(), ref[2], rtol=1e-4, atol=1e-4)
+    gv2 = MSDA.ms_deform_attn_backward(v16, t(sh), t(lsi), t(loc), t(attn), go16, 64, host_shapes=shapes)[0]
+    assert gv2.dtype == torch.bfloat16

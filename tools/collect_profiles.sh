@@ -26,7 +26,7 @@ cd $GRAFT_REPO_ROOT
 } > $out/pmc_mfma_busy.csv
 python3 tools/copybench.py > $out/copybench.json 2> $out/copybench.err
 python3 tools/opbench.py --N 8 --cases enc_local --dtypes float32 --skip-torch --rows-bf16 1 --sigma 1 3 8 --far 0 0.1 0.5 --iters 10 > $out/opbench_locality.jsonl 2> $out/opbench.err
-python3 tools/opbench.py --N 8 --cases enc_local --dtypes float32 --skip-torch --rows-bf16 1 --sigma 1 3 8 --far 0 0.5 --iters 10 --deterministic 1 > $out/opbench_locality_deterministic.jsonl 2>> $out/opbench.err
+python3 tools/opbench.py --N 8 --cases enc_local --dtypes bfloat16 --skip-torch --sigma 1 3 8 --far 0 0.5 --iters 10 > $out/opbench_locality_bf16_value.jsonl 2>> $out/opbench.err
 python3 bench.py --steps 20 --warmup 5 --precision fp32 --no-cpu-baseline > $out/bench_fp32.json 2> $out/bench_fp32.err
 python3 bench.py --steps 20 --warmup 5 > $out/bench_bf16.json 2> $out/bench_bf16.err
 tail -c 600 $out/bench_bf16.json; cat $out/copybench.json; head -3 $out/pmc_mfma_busy.csv; grep -c case $out/opbench_locality.jsonl

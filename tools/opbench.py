@@ -72,7 +72,6 @@ def main():
     ap.add_argument("--skip-torch", action="store_true")
     ap.add_argument("--owner", type=int, default=1, help="pass host shapes (owner-computes backward)")
     ap.add_argument("--radius", type=float, default=None)
-    ap.add_argument("--deterministic", type=int, default=0, help="1 = bit-reproducible owner-computes backward")
     ap.add_argument("--debug", type=int, default=0, help="timing ablations of the encoder-shape kernels (wrong results)")
     ap.add_argument("--edges", type=int, nargs=3, default=None)
     ap.add_argument("--cases", nargs="+", default=["enc_local", "enc_uniform", "dec"])
@@ -86,8 +85,6 @@ def main():
         _lib.set_param("near_radius", args.radius)
     if args.debug:
         _lib.set_param("debug", args.debug)
-    if args.deterministic:
-        _lib.set_param("deterministic", 1)
     if args.edges:
         for k, e in zip(("big", "mid", "small"), args.edges):
             _lib.set_param(f"owner_tile_edge_{k}", e)
