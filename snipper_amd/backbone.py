@@ -111,7 +111,7 @@ class _PointwiseConvBN(torch.autograd.Function):
         from .dense import linear_bf16
         cout, cin = weight.shape[0], weight.shape[1]
         from . import shadow
-        w_eff = shadow.lookup(weight)                   # bf16(weight * scale), refreshed once per step for the model
+        w_eff = shadow.lookup(weight, scale)            # bf16(weight * scale), refreshed once per step for the model
         if w_eff is not None:
             w_eff = w_eff.view(cout, cin)
         else:
@@ -162,7 +162,7 @@ class _Conv3x3BN(torch.autograd.Function):
     def forward(ctx, x, weight, scale, shift, stride, relu):
         from .dense import conv3x3_bf16
         from . import shadow
-        w_eff = shadow.lookup(weight)
+        w_eff = shadow.lookup(weight, scale)
         if w_eff is None or not w_eff.is_contiguous(memory_format=torch.channels_last):
             w_eff = (weight.float() * scale.view(-1, 1, 1, 1)).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
         y = conv3x3_bf16(x, w_eff, shift, stride, relu)
@@ -395,7 +395,8 @@ class Backbone(nn.Module):
         return out
 
 
-_POS_CACHE: Dict = {}
+from .misc import BoundedCache  # noqa: E402
+_POS_CACHE = BoundedCache(16)
 
 
 class PositionEmbeddingSine(nn.Module):

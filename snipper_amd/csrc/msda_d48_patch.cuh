@@ -436,8 +436,9 @@ template <int HITCAP, bool GO_BF16> struct Tile2Lds {
   // grad_out rows of the round's hits, float32 (bf16 rows are widened once while they are staged: 6 conversions per
   // row and lane instead of 6 per tap)
   __attribute__((aligned(16))) unsigned char rows[HITCAP * 192];
-  int2 tap[HITCAP * 16];              // sorted taps of the round: (hit index within the round, weight bits)
-  int hits[kTile2HitList];            // queries with a mark in this tile
+  int2 tap[HITCAP * 16];              // sorted taps of the round: (byte offset of the hit's row in `rows`, weight bits)
+  unsigned hits[kTile2HitList];       // queries with a mark in this tile, packed (level << 30 | qy << 15 | qx): the decode of a
+                                      // sample needs the query's grid position, not only its index
   int cntw[4][kTile2MaxPx];           // per wave and pixel: taps counted, then the wave's first position
   int off[kTile2MaxPx + 1];           // exclusive prefix over pixels
   int wsum[4];
@@ -461,10 +462,23 @@ __device__ __forceinline__ int block_incl_scan(int v, int *wsum, int tid) {
 
 // one tap: acc += w * row, the row held in LDS as bf16 (96 B) or f32 (192 B); lane j owns channels 4j..4j+3, 32+2j, 33+2j
 template <bool GO_BF16>
-__device__ __forceinline__ void tile2_fma(float (&a6)[6], float w, const unsigned char *rows, int h, int j) {
-  const Row6 v = lds_row(rows, (unsigned)h * 192u, j);
+__device__ __forceinline__ void tile2_fma(float (&a6)[6], float w, const unsigned char *rows, int row_off, int j) {
+  const Row6 v = lds_row(rows, (unsigned)row_off, j);
   a6[0] = fmaf(w, v.a.x, a6[0]); a6[1] = fmaf(w, v.a.y, a6[1]); a6[2] = fmaf(w, v.a.z, a6[2]);
   a6[3] = fmaf(w, v.a.w, a6[3]); a6[4] = fmaf(w, v.b.x, a6[4]); a6[5] = fmaf(w, v.b.y, a6[5]);
+}
+
+// (level, qy, qx) of a packed hit -> query index; the level's start / width by a select chain (a run-time index into the
+// kernel argument would put a copy of the plan in scratch memory)
+__device__ __forceinline__ int hit_query(const PatchPlan &p, unsigned hit, int &lq, int &qy, int &qx, int &Wq, int &Hq) {
+  lq = (int)(hit >> 30); qy = (int)((hit >> 15) & 0x7fffu); qx = (int)(hit & 0x7fffu);
+  int start = p.lv[0].start;
+  Wq = p.lv[0].W; Hq = p.lv[0].H;
+#pragma unroll
+  for (int i = 1; i < kPatchMaxLevels; ++i) {
+    if (lq == i) { start = p.lv[i].start; Wq = p.lv[i].W; Hq = p.lv[i].H; }
+  }
+  return start + qy * Wq + qx;
 }
 
 template <int HITCAP, bool GO_BF16>
@@ -540,12 +554,12 @@ __global__ __launch_bounds__(kPatchThreads) __attribute__((amdgpu_waves_per_eu(3
     if (my_cnt && my_excl < pass1 && my_excl + my_cnt > pass0) {
       unsigned long long mm = mask;
       int gi = my_excl;
-      const PatchLevel &lq_ = plan.lv[c_lq];
       while (mm) {
         const int i = __builtin_ctzll(mm);
         mm &= mm - 1;
         if (gi >= pass0 && gi < pass1)
-          S.hits[gi - pass0] = lq_.start + (c_by * kPatchB + (i >> 3)) * lq_.W + c_bx * kPatchB + (i & 7);
+          S.hits[gi - pass0] = ((unsigned)c_lq << 30) | ((unsigned)(c_by * kPatchB + (i >> 3)) << 15) |
+                               (unsigned)(c_bx * kPatchB + (i & 7));
         ++gi;
       }
     }
@@ -559,7 +573,8 @@ __global__ __launch_bounds__(kPatchThreads) __attribute__((amdgpu_waves_per_eu(3
         const int h = (tid + it * kPatchThreads) >> 2;
         n_xy[it] = make_float2(-4.f, -4.f); n_a[it] = 0.f;      // (a location outside every map: decodes to "not near")
         if (h < nh_ && !(plan.debug & 4)) {
-          const size_t so = (size_t)S.hits[lo_ + h] * s_stride;
+          int lq_, qy_, qx_, wq_, hq_;
+          const size_t so = (size_t)hit_query(plan, S.hits[lo_ + h], lq_, qy_, qx_, wq_, hq_) * s_stride;
           n_xy[it] = *reinterpret_cast<const float2 *>(loc_nm + 2 * so);
           n_a[it] = attn_nm[so];
         }
@@ -578,8 +593,11 @@ __global__ __launch_bounds__(kPatchThreads) __attribute__((amdgpu_waves_per_eu(3
         for (int i = 0; i < kPieces; ++i) {
           const int g = tid + i * kPatchThreads, h = g / 6, piece = g - h * 6;
           pc[i] = u32x4{0u, 0u, 0u, 0u};
-          if (h < nh && !(plan.debug & 1))
-            pc[i] = *reinterpret_cast<const u32x4 *>(go_nm + (size_t)S.hits[lo + h] * q_stride + piece * 16);
+          if (h < nh && !(plan.debug & 1)) {
+            int lq_, qy_, qx_, wq_, hq_;
+            pc[i] = *reinterpret_cast<const u32x4 *>(go_nm + (size_t)hit_query(plan, S.hits[lo + h], lq_, qy_, qx_, wq_, hq_) *
+                                                     q_stride + piece * 16);
+          }
         }
       } else if (!(plan.debug & 1)) {
         constexpr int gpr = kRowB / 16;
@@ -588,7 +606,9 @@ __global__ __launch_bounds__(kPatchThreads) __attribute__((amdgpu_waves_per_eu(3
           const int g = g0 + tid;
           if (g < G) {
             const int h = g / gpr, piece = g - h * gpr;
-            const unsigned char *src = go_nm + (size_t)S.hits[lo + h] * q_stride + piece * 16;
+            int lq_, qy_, qx_, wq_, hq_;
+            const unsigned char *src = go_nm + (size_t)hit_query(plan, S.hits[lo + h], lq_, qy_, qx_, wq_, hq_) * q_stride +
+                                       piece * 16;
             unsigned char *dst = S.rows + (size_t)(g - (tid & 63)) * 16;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                              (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
@@ -608,12 +628,9 @@ __global__ __launch_bounds__(kPatchThreads) __attribute__((amdgpu_waves_per_eu(3
         const float x = px_coord(n_xy[it].x, me.W), y = px_coord(n_xy[it].y, me.H);
         const bool inside = h < nh && (y > -1.f) && (x > -1.f) && (y < (float)me.H) && (x < (float)me.W);
         if (inside) {
-          const int q = S.hits[lo + h];
-          int lq = 0;
-          for (int i = 1; i < plan.L; ++i) lq = (q >= plan.lv[i].start) ? i : lq;
-          const int rq = q - plan.lv[lq].start;
-          const int qy = rq / plan.lv[lq].W, qx = rq - qy * plan.lv[lq].W;
-          if (near_anchor(x, y, anchor_coord(qx, me.W, plan.lv[lq].W), anchor_coord(qy, me.H, plan.lv[lq].H), plan.radius)) {
+          int lq, qy, qx, Wq, Hq;
+          hit_query(plan, S.hits[lo + h], lq, qy, qx, Wq, Hq);
+          if (near_anchor(x, y, anchor_coord(qx, me.W, Wq), anchor_coord(qy, me.H, Hq), plan.radius)) {
             const float a = n_a[it];
             const float yf = floorf(y), xf = floorf(x);
             const int y0 = (int)yf, x0 = (int)xf;
@@ -664,7 +681,7 @@ __global__ __launch_bounds__(kPatchThreads) __attribute__((amdgpu_waves_per_eu(3
           if ((t_ok[it] >> k) & 1u) {
             const unsigned pix = (t_pix[it] >> (8 * k)) & 0xffu;
             const int pos = S.cntw[wave][pix] + (int)((t_rank[it][k >> 1] >> (16 * (k & 1))) & 0xffffu);
-            S.tap[pos] = make_int2(h, __float_as_int(t_w[it][k]));
+            S.tap[pos] = make_int2(h * kPatchRowBytes, __float_as_int(t_w[it][k]));
           }
         }
       }

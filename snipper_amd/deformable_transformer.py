@@ -55,7 +55,8 @@ def _refine_reference(head, out, reference_points, valid_ratios):
     return new_ref, ref_in
 
 
-_LEVEL_CACHE = {}
+from .misc import BoundedCache  # noqa: E402
+_LEVEL_CACHE = BoundedCache(32)
 
 
 def _level_tensors(hw, device):

@@ -193,6 +193,10 @@ def _next_seed() -> int:
     """A fresh 64-bit seed per call: torch's seed in the high half, a process-wide call counter in the low half
     (reproducible after ``torch.manual_seed`` for a fixed order of calls)."""
     global _dropout_calls
+    if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+        # the seed is a kernel scalar: a captured graph would replay the SAME dropout mask every step
+        raise RuntimeError("fused dropout (p > 0) cannot be captured into a hipGraph: its seed is a host-side scalar; "
+                           "run the step eagerly or with dropout 0")
     _dropout_calls += 1
     return ((torch.initial_seed() & 0xFFFFFFFF) << 32) | (_dropout_calls & 0xFFFFFFFF)
 
@@ -226,7 +230,7 @@ class AddDropoutLayerNorm(Function):
             rc = _lib.load().snipper_add_dropout_layernorm_forward(
                 _stream(dev), x.data_ptr(), _DT[x.dtype], ptr(z), _DT[z.dtype] if z is not None else 0,
                 ptr(pos), _DT[pos.dtype] if pos is not None else 0, g32.data_ptr(), b32.data_ptr(), rows, C,
-                p, float(eps), int(seed if seed is not None else _next_seed()), ptr(s_save),
+                p, float(eps), int(seed if seed is not None else (_next_seed() if p > 0 else 0)), ptr(s_save),
                 stats[0].data_ptr() if stats is not None else None, stats[1].data_ptr() if stats is not None else None,
                 ptr(keep), ptr(y32), ptr(y16), ptr(yq))
         _lib.check(rc, "snipper_add_dropout_layernorm_forward")

@@ -24,7 +24,31 @@ class NestedTensor(object):
         return str(self.tensors)
 
 
-_NO_PAD_MASKS = {}
+class BoundedCache(dict):
+    """A dict that keeps at most ``limit`` entries (least recently inserted / touched first out).  The geometry caches
+    (masks, position encodings, level tensors, reference grids) are keyed by shapes and batch size: with variable input
+    sizes -- multi-scale training, evaluation on differently sized videos -- an unbounded dict would pin device memory."""
+
+    def __init__(self, limit: int = 16):
+        super().__init__()
+        self.limit = limit
+
+    def get(self, key, default=None):
+        if key in self:
+            val = super().pop(key)
+            super().__setitem__(key, val)          # touched: most recent
+            return val
+        return default
+
+    def __setitem__(self, key, val):
+        if key in self:
+            super().pop(key)
+        super().__setitem__(key, val)
+        while len(self) > self.limit:
+            super().pop(next(iter(self)))
+
+
+_NO_PAD_MASKS = BoundedCache(16)
 
 
 def no_padding_mask(n: int, h: int, w: int, device) -> Tensor:

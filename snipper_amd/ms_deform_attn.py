@@ -43,7 +43,8 @@ def frame_neighbours(t1: int, n_frame: int, n_value_frames: int) -> List[int]:
     return list(range(n_value_frames))   # future (forecast) frame: every value frame
 
 
-_SCALE_CACHE = {}
+from .misc import BoundedCache  # noqa: E402
+_SCALE_CACHE = BoundedCache(16)
 
 
 def _level_scale(hw, dtype, device):

@@ -46,11 +46,30 @@ class _Merged:
         self.refs, self.w, self.b, self.versions = [weakref.ref(p) for p in params], w, b, None
 
 
-def lookup(param: torch.Tensor) -> Optional[torch.Tensor]:
+def lookup(param: torch.Tensor, scale: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+    """The valid bf16 shadow of ``param`` or None.  ``scale``: the BatchNorm scale the caller is about to fold -- a shadow
+    folded with a different scale tensor is not valid for it."""
     e = _entries.get(id(param))
-    if e is not None and e.ref() is param and e.version == param._version and e.dst.device == param.device:
+    if (e is not None and e.ref() is param and e.version == param._version and e.dst.device == param.device and
+            e.dst.data_ptr() != 0 and (scale is None or e.scale is None or e.scale is scale)):
         return e.dst
     return None
+
+
+def invalidate(params=None) -> None:
+    """Drop the shadows of ``params`` (an iterable of parameters), or all of them.  Validity is keyed on the parameter's
+    version counter; writes that do not bump it -- ``p.data.copy_()``, an EMA swap through ``.data``, reference-style
+    ``.data`` initialisers run after the first refresh -- must be followed by this call (or by ``torch.autograd.graph.
+    increment_version``)."""
+    if params is None:
+        _entries.clear()
+        _merged.clear()
+        return
+    ids = {id(p) for p in params}
+    for k in [k for k in _entries if k in ids]:
+        del _entries[k]
+    for k in [k for k in _merged if k[0] in ids or k[1] in ids]:
+        del _merged[k]
 
 
 def lookup_merged(lin_a: nn.Linear, lin_b: nn.Linear):
