@@ -435,7 +435,8 @@ int snipper_linear_bf16(void *stream, const uint16_t *X, long long ldx, const ui
       (R && (ldr % 4 || ldr < N)) || !(dropout_p >= 0.f && dropout_p < 1.f) ||
       (dropout_p > 0.f && (long long)M * N >= (1LL << 32)))
     return SNIPPER_E_SHAPE;
-  const GemmArgs g{X, ldx, W, bias, R, ldr, Y, ldy, M, N, K, dropout_p, (uint32_t)seed, (uint32_t)(seed >> 32)};
+  static const int dbg = getenv("SNIPPER_GEMM_DEBUG") ? atoi(getenv("SNIPPER_GEMM_DEBUG")) : 0;
+  const GemmArgs g{X, ldx, W, bias, R, ldr, Y, ldy, M, N, K, dropout_p, (uint32_t)seed, (uint32_t)(seed >> 32), dbg};
   const dim3 grid(gemm_grid_size(M, N));
   if (relu)
     hipLaunchKernelGGL(linear_bf16_kernel<true>, grid, dim3(kGemmThreads), 0, (hipStream_t)stream, g);
