@@ -139,13 +139,16 @@ int snipper_colsum_segments_bf16(void *stream, const uint16_t *x, long long imag
  * snipper_stem_pool_bf16. */
 int snipper_stem7x7_bf16(void *stream, const uint16_t *X4, const uint16_t *Wp, uint16_t *Y, int B, int H, int W);
 int snipper_conv3x3_dgrad_s2_bf16(void *stream, const uint16_t *G, const uint16_t *Wt, uint16_t *dX,
-                                  int B, int Hx, int Wx, int Cx, int Cg);
+                                  int B, int Hx, int Wx, int Cx, int Cg, const uint16_t *gate);
 size_t snipper_wgrad_conv3x3_workspace_bytes(int B, int H, int W, int Cin, int Cout, int stride);
 int snipper_wgrad_conv3x3_bf16(void *stream, const uint16_t *G, const uint16_t *X, int B, int H, int W, int Cin, int Cout,
                                int stride, const float *scale, float *dW, int accumulate, void *workspace,
                                size_t workspace_bytes);
+/* `gate` (optional, the layout of the result, 16-byte aligned, not together with relu): results whose gate value is not > 0
+ * are written as 0.  A data gradient is itself such a convolution; when the activation it differentiates came out of a
+ * ReLU, passing that activation as the gate does the ReLU's backward in the store phase (no separate pass). */
 int snipper_conv3x3_bf16(void *stream, const uint16_t *X, const uint16_t *W, const float *bias, uint16_t *Y,
-                         int B, int H, int Wd, int Cin, int Cout, int stride, int relu);
+                         int B, int H, int Wd, int Cin, int Cout, int stride, int relu, const uint16_t *gate);
 
 /* ---- element-wise fusions around the core op (csrc/msda_prologue.cuh) --------------------------------
  * dtype codes: 0 = float32, 1 = bfloat16 bits.

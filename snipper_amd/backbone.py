@@ -67,8 +67,38 @@ class FrozenBatchNorm2d(nn.Module):
         return x * scale.view(1, -1, 1, 1).to(x.dtype) + bias.view(1, -1, 1, 1).to(x.dtype)
 
 
-def conv_frozen_bn(x, conv: nn.Conv2d, bn: FrozenBatchNorm2d, relu: bool, residual=None):
+# Fold the backward of the bottleneck ReLUs into the data-gradient kernels' store phase (tests switch it off to compare)
+FOLD_RELU_BACKWARD = True
+
+
+class _ReluGate(torch.autograd.Function):
+    """Identity whose backward zeroes the gradient where ``x`` (a ReLU output) is 0: the explicit form of the ReLU
+    backward that the data-gradient kernels otherwise apply in their store phase (``gate_input`` below).  Only taken when
+    a consumer cannot do that itself (shapes outside the kernels' requirements)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        return torch.ops.aten.threshold_backward(g.contiguous(memory_format=torch.channels_last)
+                                                 if x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last)
+                                                 else g.contiguous(), x, 0)
+
+
+def conv_frozen_bn(x, conv: nn.Conv2d, bn: FrozenBatchNorm2d, relu: bool, residual=None, gate_input: bool = False,
+                   pregated: bool = False):
     """conv -> frozen BN (+ residual) (-> ReLU) with the BN folded into the convolution.
+
+    The backward of a ReLU between two of these nodes is folded into the store phase of the data-gradient kernel that
+    produces the gradient of the ReLU's output (its consumer knows the activation: it is its saved input):
+    ``gate_input`` -- ``x`` came out of a ReLU whose own node does NOT apply the ReLU backward; this node gates the
+    gradient it returns for ``x``.  ``pregated`` -- the gradient arriving for this node's output already is gated by its
+    consumer (which was given ``gate_input``); this node skips its own ReLU backward.  The two flags are always set as a
+    pair by the code that wires producer and consumer (Bottleneck.forward / ResNet50Body._run_layer).
 
     The BN is an affine map with constant coefficients (reference backbone.py:54-64), so
     ``bn(conv(x, w)) == conv(x, w * scale[:, None, None, None]) + shift``: one convolution with a bias
@@ -76,15 +106,35 @@ def conv_frozen_bn(x, conv: nn.Conv2d, bn: FrozenBatchNorm2d, relu: bool, residu
     the live weight every call (a few MB), so gradients reach ``conv.weight`` exactly as before.
     """
     scale, shift = bn.scale_bias()
+    assert relu or not pregated
     if _hip_pointwise_ok(x, conv, None):
-        return _hip_pointwise(x, conv, scale.float(), shift.float(), relu, residual)
+        return _hip_pointwise(x, conv, scale.float(), shift.float(), relu, residual, gate_input, pregated)
     if residual is None and _hip_conv3x3_ok(x, conv):
-        return _Conv3x3BN.apply(x, conv.weight, scale.float(), shift.float(), conv.stride[0], relu)
+        return _Conv3x3BN.apply(x, conv.weight, scale.float(), shift.float(), conv.stride[0], relu, gate_input, pregated)
+    if gate_input and x.requires_grad and torch.is_grad_enabled():
+        x = _ReluGate.apply(x)
     w = conv.weight * scale.view(-1, 1, 1, 1).to(conv.weight.dtype)
     y = F.conv2d(x, w, shift.to(w.dtype), conv.stride, conv.padding, conv.dilation, conv.groups)
     if residual is not None:
         y = y + residual
-    return F.relu(y, inplace=True) if relu else y
+    if not relu:
+        return y
+    if pregated:                                  # the consumer gates the gradient: a ReLU without a backward of its own
+        return _PregatedRelu.apply(y)
+    return F.relu(y, inplace=True)
+
+
+class _PregatedRelu(torch.autograd.Function):
+    """relu(y) whose gradient is passed through unchanged: the consumer of the result was told (``gate_input``) to zero
+    the gradient where the result is 0, which is exactly this ReLU's backward."""
+
+    @staticmethod
+    def forward(ctx, y):
+        return torch.relu(y)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
 
 
 def _hip_pointwise_ok(x, conv, w) -> bool:
@@ -105,9 +155,11 @@ class _PointwiseConvBN(torch.autograd.Function):
     the largest single item of the step's CPU time."""
 
     @staticmethod
-    def forward(ctx, x2, weight, scale, shift, res2, relu, fork=False):
+    def forward(ctx, x2, weight, scale, shift, res2, relu, fork=False, gate_input=False, pregated=False):
         """``fork``: also return ``x2`` itself (as a second output) for a skip connection; the gradient that comes
-        back over that output is then added inside the data-gradient kernel instead of by a separate add."""
+        back over that output is then added inside the data-gradient kernel instead of by a separate add.
+        ``gate_input`` / ``pregated``: see conv_frozen_bn (with ``fork`` the gate covers the sum of both gradients of
+        ``x2``, i.e. everything that flows back into the ReLU that produced it)."""
         from .dense import linear_bf16
         cout, cin = weight.shape[0], weight.shape[1]
         from . import shadow
@@ -117,10 +169,10 @@ class _PointwiseConvBN(torch.autograd.Function):
         else:
             w_eff = (weight.reshape(cout, cin).float() * scale[:, None]).to(torch.bfloat16)
         y = linear_bf16(x2, w_eff, shift, res2, relu)
-        ctx.relu, ctx.has_res = relu, res2 is not None
+        ctx.relu, ctx.has_res = relu and not pregated, res2 is not None
         ctx.wshape, ctx.wdtype, ctx.wstride = weight.shape, weight.dtype, weight.stride()
-        ctx.save_for_backward(x2, w_eff, scale, y if relu else None)
-        ctx.fork = fork
+        ctx.save_for_backward(x2, w_eff, scale, y if ctx.relu else None)
+        ctx.fork, ctx.gate_input = fork, gate_input
         if fork:
             return y, x2.view_as(x2)
         return y
@@ -133,14 +185,16 @@ class _PointwiseConvBN(torch.autograd.Function):
         if ctx.relu:
             g = torch.ops.aten.threshold_backward(g, y, 0)
         from .dense import _dgrad
-        dx = _dgrad(g, w_eff, gskip if ctx.fork else None) if ctx.needs_input_grad[0] else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = _dgrad(g, w_eff, gskip if ctx.fork else None, x2 if ctx.gate_input else None)
         dw = None
         if ctx.needs_input_grad[1]:
             from .dense import wgrad_bf16
             dw, _ = wgrad_bf16(g, x2, want_bias=False, scale=scale)     # BN scale folded into the reduction kernel
             # same memory, the parameter's own strides (NHWC weights: DDP aliases its bucket only when they match)
             dw = dw.to(ctx.wdtype).as_strided(ctx.wshape, ctx.wstride)
-        return dx, dw, None, None, (g if ctx.has_res else None), None, None
+        return dx, dw, None, None, (g if ctx.has_res else None), None, None, None, None
 
 
 def _hip_conv3x3_ok(x, conv) -> bool:
@@ -159,15 +213,15 @@ class _Conv3x3BN(torch.autograd.Function):
     (csrc/wgrad_bf16.cuh, conv mode).  Nothing of a Snipper recipe's ResNet-50 goes through MIOpen."""
 
     @staticmethod
-    def forward(ctx, x, weight, scale, shift, stride, relu):
+    def forward(ctx, x, weight, scale, shift, stride, relu, gate_input=False, pregated=False):
         from .dense import conv3x3_bf16
         from . import shadow
         w_eff = shadow.lookup(weight, scale)
         if w_eff is None or not w_eff.is_contiguous(memory_format=torch.channels_last):
             w_eff = (weight.float() * scale.view(-1, 1, 1, 1)).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
         y = conv3x3_bf16(x, w_eff, shift, stride, relu)
-        ctx.stride, ctx.relu, ctx.wdtype = stride, relu, weight.dtype
-        ctx.save_for_backward(x, w_eff, scale, y if relu else None)
+        ctx.stride, ctx.relu, ctx.wdtype, ctx.gate_input = stride, relu and not pregated, weight.dtype, gate_input
+        ctx.save_for_backward(x, w_eff, scale, y if ctx.relu else None)
         return y
 
     @staticmethod
@@ -187,17 +241,20 @@ class _Conv3x3BN(torch.autograd.Function):
                 g, x, w_eff, None, [ctx.stride] * 2, [1, 1], [1, 1], False, [0, 0], 1, need)
             if dw is not None:
                 dw = (dw.float() * scale.view(-1, 1, 1, 1)).to(ctx.wdtype)
+            if dx is not None and ctx.gate_input:
+                dx = torch.ops.aten.threshold_backward(dx, x, 0)
+        gate = x if ctx.gate_input else None      # x came out of a ReLU that left its backward to this node
         if own_dgrad and ctx.stride == 1:
             # stride 1: the data gradient is the same convolution with the taps reversed and the channel roles swapped
             w_t = w_eff.flip(2, 3).transpose(0, 1).contiguous(memory_format=torch.channels_last)
-            dx = conv3x3_bf16(g, w_t, None, 1, False)
+            dx = conv3x3_bf16(g, w_t, None, 1, False, gate)
         elif own_dgrad:
             # stride 2: four parity classes of the input pixel, each with its 1 / 2 / 2 / 4 taps (csrc/gemm_bf16.cuh)
-            dx = conv3x3_dgrad_s2_bf16(g, w_eff.transpose(0, 1), x.shape[-2:])
+            dx = conv3x3_dgrad_s2_bf16(g, w_eff.transpose(0, 1), x.shape[-2:], gate)
         if own_wgrad:
             # split-reduction kernel, BN scale folded into its second pass; float32, channels_last like the parameter
             dw = wgrad_conv3x3_bf16(g, x, ctx.stride, scale).to(ctx.wdtype)
-        return dx, dw, None, None, None, None
+        return dx, dw, None, None, None, None, None, None
 
 
 class _Subsample(torch.autograd.Function):
@@ -219,9 +276,11 @@ class _Subsample(torch.autograd.Function):
         return dx, None, None
 
 
-def _hip_pointwise(x, conv, scale, shift, relu, residual):
+def _hip_pointwise(x, conv, scale, shift, relu, residual, gate_input=False, pregated=False):
     """conv1x1 + folded BN (+ residual) (+ ReLU) as ONE launch of the MFMA kernel."""
     if conv.stride != (1, 1):
+        if gate_input and x.requires_grad and torch.is_grad_enabled():
+            x, gate_input = _ReluGate.apply(x), False          # (the gate has x's shape, not the sub-sampled one)
         x = _Subsample.apply(x, conv.stride[0], conv.stride[1])
     b, c, h, wd = x.shape
     rows = x.permute(0, 2, 3, 1).reshape(b * h * wd, c)                      # a view: NHWC is row-major [M, Cin]
@@ -230,11 +289,11 @@ def _hip_pointwise(x, conv, scale, shift, relu, residual):
         res = residual.permute(0, 2, 3, 1).reshape(b * h * wd, -1)
         if res.dtype != torch.bfloat16:
             res = res.to(torch.bfloat16)
-    y = _PointwiseConvBN.apply(rows, conv.weight, scale, shift.float(), res, relu)
+    y = _PointwiseConvBN.apply(rows, conv.weight, scale, shift.float(), res, relu, False, gate_input, pregated)
     return y.view(b, h, wd, -1).permute(0, 3, 1, 2)                          # logical NCHW, channels_last memory
 
 
-def _hip_pointwise_fork(x, conv, bn):
+def _hip_pointwise_fork(x, conv, bn, gate_input=False, pregated=False):
     """(relu(bn(conv1x1(x))), x) with both results coming out of ONE autograd node, so that the gradient of the skip
     connection is added inside that node's data-gradient kernel.  None when the MFMA path does not apply."""
     if not (conv.stride == (1, 1) and _hip_pointwise_ok(x, conv, None)):
@@ -242,7 +301,7 @@ def _hip_pointwise_fork(x, conv, bn):
     scale, shift = bn.scale_bias()
     b, c, h, wd = x.shape
     rows = x.permute(0, 2, 3, 1).reshape(b * h * wd, c)
-    y, skip = _PointwiseConvBN.apply(rows, conv.weight, scale.float(), shift.float(), None, True, True)
+    y, skip = _PointwiseConvBN.apply(rows, conv.weight, scale.float(), shift.float(), None, True, True, gate_input, pregated)
     return y.view(b, h, wd, -1).permute(0, 3, 1, 2), skip.view(b, h, wd, c).permute(0, 3, 1, 2)
 
 
@@ -262,17 +321,25 @@ class Bottleneck(nn.Module):
             self.downsample = nn.Sequential(nn.Conv2d(inplanes, width * 4, 1, stride=stride, bias=False),
                                             FrozenBatchNorm2d(width * 4))
 
-    def forward(self, x):
+    def forward(self, x, in_gated: bool = False, out_pregated: bool = False):
+        """``in_gated``: ``x`` is the previous block's output and that block left the backward of its final ReLU to this
+        one; ``out_pregated``: the next block does the same for this block's final ReLU (ResNet50Body._run_layer sets
+        both sides).  Inside the block the two inner ReLUs are always handled that way: conv2 gates the gradient of
+        conv1's output, conv3 that of conv2's."""
+        fold = torch.is_grad_enabled() and FOLD_RELU_BACKWARD
         fork = None
         if self.downsample is None and x.requires_grad and torch.is_grad_enabled():
-            fork = _hip_pointwise_fork(x, self.conv1, self.bn1)      # identity skip: fold its gradient add away
+            # identity skip: fold its gradient add away (and, if in_gated, the previous block's ReLU backward with it)
+            fork = _hip_pointwise_fork(x, self.conv1, self.bn1, gate_input=in_gated, pregated=fold)
         if fork is not None:
             y, skip = fork
         else:
-            y = conv_frozen_bn(x, self.conv1, self.bn1, relu=True)
+            if in_gated and x.requires_grad and torch.is_grad_enabled():
+                x = _ReluGate.apply(x)                  # several consumers of x below: gate once, explicitly
+            y = conv_frozen_bn(x, self.conv1, self.bn1, relu=True, pregated=fold)
             skip = x if self.downsample is None else conv_frozen_bn(x, self.downsample[0], self.downsample[1], relu=False)
-        y = conv_frozen_bn(y, self.conv2, self.bn2, relu=True)
-        return conv_frozen_bn(y, self.conv3, self.bn3, relu=True, residual=skip)
+        y = conv_frozen_bn(y, self.conv2, self.bn2, relu=True, gate_input=fold, pregated=fold)
+        return conv_frozen_bn(y, self.conv3, self.bn3, relu=True, residual=skip, gate_input=fold, pregated=out_pregated)
 
 
 class ResNet50Body(nn.Module):
@@ -346,6 +413,21 @@ class ResNet50Body(nn.Module):
         x = conv_frozen_bn(x, conv, bn, relu=True)
         return F.max_pool2d(x, 3, stride=2, padding=1)
 
+    @staticmethod
+    def _run_layer(layer, x):
+        """The layer's blocks in sequence; between two blocks of one layer (identity skip on the consumer's side) the
+        backward of the producer's final ReLU is left to the consumer's data-gradient kernel.  A layer's LAST output has
+        other consumers (next layer, input projections) and keeps its own ReLU backward."""
+        blocks = list(layer)
+        fold = torch.is_grad_enabled() and FOLD_RELU_BACKWARD
+        gated = False
+        for i, blk in enumerate(blocks):
+            nxt = blocks[i + 1] if i + 1 < len(blocks) else None
+            pre = bool(fold and nxt is not None and isinstance(nxt, Bottleneck) and nxt.downsample is None)
+            x = blk(x, gated, pre) if isinstance(blk, Bottleneck) else blk(x)
+            gated = pre
+        return x
+
     def forward(self, x) -> Dict[str, torch.Tensor]:
         x = x.contiguous(memory_format=torch.channels_last)     # NHWC end to end: no layout shuffles around MIOpen
         x = self._stem(x)
@@ -355,10 +437,10 @@ class ResNet50Body(nn.Module):
             with torch.no_grad():                                 # conv1 + layer1 are frozen: nothing to save
                 c2 = self.layer1(x)
         else:
-            c2 = self.layer1(x)
-        c3 = self.layer2(c2)
-        c4 = self.layer3(c3)
-        c5 = self.layer4(c4)
+            c2 = self._run_layer(self.layer1, x)
+        c3 = self._run_layer(self.layer2, c2)
+        c4 = self._run_layer(self.layer3, c3)
+        c5 = self._run_layer(self.layer4, c4)
         if self.return_interm_layers:
             return {"0": c3, "1": c4, "2": c5}
         return {"0": c5}

@@ -388,6 +388,9 @@ struct Conv3x3Args {
   // (the weight with its channel roles swapped), Y = dX [B][Hy][Wy][Cout]; a row of the launch is (n, a, b) over the
   // class's grid Ho x Wo and is stored at pixel (2a + cy, 2b + cx) of Y.
   int dgrad2, cy, cx, Hy, Wy;
+  // gate (optional, the layout of Y): outputs whose gate value is not > 0 are written as 0 -- when this launch is a data
+  // gradient and Y's activation came out of a ReLU, that ReLU's backward happens here, in the store phase
+  const uint16_t *gate;
 };
 
 template <bool RELU>
@@ -492,11 +495,16 @@ __global__ __launch_bounds__(kGemmThreads) __attribute__((amdgpu_waves_per_eu(3,
           const int b = m / (g.Ho * g.Wo), r = m - b * (g.Ho * g.Wo);
           row = ((long long)b * g.Hy + 2 * (r / g.Wo) + g.cy) * g.Wy + 2 * (r % g.Wo) + g.cx;
         }
+        if (g.gate) {
+          const uint2 a = *reinterpret_cast<const uint2 *>(g.gate + row * g.Cout + n);
+          o.x &= (__uint_as_float(a.x << 16) > 0.f ? 0x0000ffffu : 0u) | (__uint_as_float(a.x & 0xffff0000u) > 0.f ? 0xffff0000u : 0u);
+          o.y &= (__uint_as_float(a.y << 16) > 0.f ? 0x0000ffffu : 0u) | (__uint_as_float(a.y & 0xffff0000u) > 0.f ? 0xffff0000u : 0u);
+        }
         *reinterpret_cast<uint2 *>(g.Y + row * g.Cout + n) = o;
       }
     }
   }
-  if (wide) gemm_flush_tile(smem, g.Y, g.Cout, m0, n0, M, g.Cout);
+  if (wide) gemm_flush_tile(smem, g.Y, g.Cout, m0, n0, M, g.Cout, g.gate, g.Cout);
 }
 
 // ---- the ResNet stem: 7x7 convolution, stride 2, padding 3, 3 input channels -> 64, NHWC bf16 ----------------

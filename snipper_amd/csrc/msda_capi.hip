@@ -685,14 +685,15 @@ int snipper_colsum_segments_bf16(void *stream, const uint16_t *x, long long imag
 }
 
 int snipper_conv3x3_bf16(void *stream, const uint16_t *X, const uint16_t *W, const float *bias, uint16_t *Y,
-                         int B, int H, int Wd, int Cin, int Cout, int stride, int relu) {
+                         int B, int H, int Wd, int Cin, int Cout, int stride, int relu, const uint16_t *gate) {
   if (!X || !W || !Y) return SNIPPER_E_NULL;
+  if (gate && (((uintptr_t)gate & 15) || relu)) return SNIPPER_E_SHAPE;
   if (B <= 0 || H <= 0 || Wd <= 0 || Cin <= 0 || Cout <= 0 || Cin % kGemmBK || Cout % 4 || (stride != 1 && stride != 2))
     return SNIPPER_E_SHAPE;
   const int Ho = (H - 1) / stride + 1, Wo = (Wd - 1) / stride + 1;
   const long long M = (long long)B * Ho * Wo;
   if (M >= (1LL << 31)) return SNIPPER_E_SHAPE;
-  const Conv3x3Args g{X, W, bias, Y, B, H, Wd, Cin, Cout, Ho, Wo, stride, 0, 0, 0, 0, 0};
+  const Conv3x3Args g{X, W, bias, Y, B, H, Wd, Cin, Cout, Ho, Wo, stride, 0, 0, 0, 0, 0, gate};
   const dim3 grid(gemm_grid_size(M, Cout));
   if (relu)
     hipLaunchKernelGGL(conv3x3_bf16_kernel<true>, grid, dim3(kGemmThreads), 0, (hipStream_t)stream, g);
@@ -715,8 +716,9 @@ int snipper_stem7x7_bf16(void *stream, const uint16_t *X4, const uint16_t *Wp, u
 }
 
 int snipper_conv3x3_dgrad_s2_bf16(void *stream, const uint16_t *G, const uint16_t *Wt, uint16_t *dX,
-                                  int B, int Hx, int Wx, int Cx, int Cg) {
+                                  int B, int Hx, int Wx, int Cx, int Cg, const uint16_t *gate) {
   if (!G || !Wt || !dX) return SNIPPER_E_NULL;
+  if (gate && ((uintptr_t)gate & 15)) return SNIPPER_E_SHAPE;
   if (B <= 0 || Hx <= 0 || Wx <= 0 || Cx <= 0 || Cg <= 0 || Cg % kGemmBK || Cx % 4) return SNIPPER_E_SHAPE;
   const int Hg = (Hx - 1) / 2 + 1, Wg = (Wx - 1) / 2 + 1;          // the stride-2 convolution's output size
   if ((long long)B * Hx * Wx >= (1LL << 31)) return SNIPPER_E_SHAPE;
@@ -724,7 +726,7 @@ int snipper_conv3x3_dgrad_s2_bf16(void *stream, const uint16_t *G, const uint16_
     for (int cx = 0; cx < 2; ++cx) {
       const int Hc = (Hx - cy + 1) / 2, Wc = (Wx - cx + 1) / 2;    // input pixels (2a + cy, 2b + cx) of this class
       if (Hc <= 0 || Wc <= 0) continue;
-      const Conv3x3Args g{G, Wt, nullptr, dX, B, Hg, Wg, Cg, Cx, Hc, Wc, 1, 1, cy, cx, Hx, Wx};
+      const Conv3x3Args g{G, Wt, nullptr, dX, B, Hg, Wg, Cg, Cx, Hc, Wc, 1, 1, cy, cx, Hx, Wx, gate};
       hipLaunchKernelGGL(conv3x3_bf16_kernel<false>, dim3(gemm_grid_size((long long)B * Hc * Wc, Cx)), dim3(kGemmThreads), 0,
                          (hipStream_t)stream, g);
     }

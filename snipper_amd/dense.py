@@ -43,9 +43,20 @@ def linear_bf16(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tens
     return out.view(*x.shape[:-1], N)
 
 
+def _gate_ptr(gate: Optional[torch.Tensor], like: torch.Tensor):
+    """Data pointer of a ReLU gate laid out exactly like ``like`` (bf16, channels_last), or None."""
+    if gate is None:
+        return None, None
+    if gate.dtype != torch.bfloat16 or not gate.is_contiguous(memory_format=torch.channels_last):
+        gate = gate.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    assert gate.shape == like.shape
+    return gate.data_ptr(), gate          # (the tensor is returned so that it outlives the launch call)
+
+
 def conv3x3_bf16(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, stride: int = 1,
-                 relu: bool = False) -> torch.Tensor:
-    """act(conv2d(x, weight, padding=1, stride=stride) + bias) on the implicit-GEMM HIP kernel.
+                 relu: bool = False, gate: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """act(conv2d(x, weight, padding=1, stride=stride) + bias) on the implicit-GEMM HIP kernel.  ``gate`` (shape of the
+    result): results whose gate is not > 0 are written as 0 (a ReLU backward fused into a data gradient's store phase).
 
     x [B, Cin, H, W] bf16 in channels_last memory, weight [Cout, Cin, 3, 3] bf16 in channels_last memory (i.e.
     [Cout][3][3][Cin] contiguous), bias [Cout] float32 or None  ->  [B, Cout, Ho, Wo] bf16, channels_last."""
@@ -59,15 +70,16 @@ def conv3x3_bf16(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Ten
     out = torch.empty((B, Cout, Ho, Wo), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
     if bias is not None and bias.dtype != torch.float32:
         bias = bias.float()
+    gp, _keep = _gate_ptr(gate, out)
     with _lib.device_guard(x.device):
         rc = _lib.load().snipper_conv3x3_bf16(
             _lib.raw_stream(x.device), x.data_ptr(), weight.data_ptr(),
-            bias.data_ptr() if bias is not None else None, out.data_ptr(), B, H, W, Cin, Cout, int(stride), int(relu))
+            bias.data_ptr() if bias is not None else None, out.data_ptr(), B, H, W, Cin, Cout, int(stride), int(relu), gp)
     _lib.check(rc, "snipper_conv3x3_bf16")
     return out
 
 
-def conv3x3_dgrad_s2_bf16(g: torch.Tensor, weight_t: torch.Tensor, in_hw) -> torch.Tensor:
+def conv3x3_dgrad_s2_bf16(g: torch.Tensor, weight_t: torch.Tensor, in_hw, gate: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Data gradient of a stride-2, padding-1 3x3 convolution on the implicit-GEMM kernel (four parity-class launches).
 
     g [B, Cout, Ho, Wo] bf16 channels_last = dL/dy; weight_t [Cin, Cout, 3, 3] bf16 channels_last = the weight with its
@@ -81,9 +93,10 @@ def conv3x3_dgrad_s2_bf16(g: torch.Tensor, weight_t: torch.Tensor, in_hw) -> tor
     H, W = in_hw
     assert weight_t.shape[1] == Cg and (H - 1) // 2 + 1 == Hg and (W - 1) // 2 + 1 == Wg
     dx = torch.empty((B, Cx, H, W), dtype=torch.bfloat16, device=g.device, memory_format=torch.channels_last)
+    gp, _keep = _gate_ptr(gate, dx)
     with _lib.device_guard(g.device):
         rc = _lib.load().snipper_conv3x3_dgrad_s2_bf16(_lib.raw_stream(g.device), g.data_ptr(), weight_t.data_ptr(),
-                                                       dx.data_ptr(), B, H, W, Cx, Cg)
+                                                       dx.data_ptr(), B, H, W, Cx, Cg, gp)
     _lib.check(rc, "snipper_conv3x3_dgrad_s2_bf16")
     return dx
 
@@ -154,13 +167,17 @@ import os as _os
 _DGRAD_LIB_K = int(_os.environ.get("SNIPPER_DGRAD_LIB_K", "1000000"))
 
 
-def _dgrad(g: torch.Tensor, w: torch.Tensor, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """g [M, out] @ w [out, in] (+ residual): own kernel when the shape allows (out % 64 == 0, in % 8 == 0), hipBLASLt
-    otherwise."""
-    if w.shape[0] % 64 == 0 and w.shape[1] % 8 == 0 and g.shape[0] >= 256 and (w.shape[0] < _DGRAD_LIB_K or residual is not None):
-        return linear_nn_bf16(g, w, residual)
+def _dgrad(g: torch.Tensor, w: torch.Tensor, residual: Optional[torch.Tensor] = None,
+           gate: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """gate(g [M, out] @ w [out, in] (+ residual)): own kernel when the shape allows (out % 64 == 0, in % 8 == 0),
+    hipBLASLt otherwise.  ``gate`` [M, in]: the ReLU output the gradient flows back into (result zeroed where it is 0)."""
+    if w.shape[0] % 64 == 0 and w.shape[1] % 8 == 0 and g.shape[0] >= 256 and (
+            w.shape[0] < _DGRAD_LIB_K or residual is not None or gate is not None):
+        return linear_nn_bf16(g, w, residual, gate)
     y = torch.mm(g, w)
-    return y if residual is None else y + residual.reshape(y.shape)
+    if residual is not None:
+        y = y + residual.reshape(y.shape)
+    return y if gate is None else torch.ops.aten.threshold_backward(y, gate.reshape(y.shape), 0)
 
 
 def wgrad_bf16(g: torch.Tensor, x: torch.Tensor, want_bias: bool = True, scale: Optional[torch.Tensor] = None,

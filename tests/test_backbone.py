@@ -181,3 +181,33 @@ def test_no_padding_mask_is_not_cached_in_inference_mode():
         m = no_padding_mask(3, 4, 5, "cpu")
     assert not is_no_padding(m) and not m.any() and m.shape == (3, 4, 5)
     assert is_no_padding(no_padding_mask(3, 4, 5, "cpu"))
+
+
+def test_relu_backward_fold_protocol_gives_the_same_gradients():
+    """The bottleneck ReLUs' backward is left to the CONSUMER of each activation (gate_input / pregated flags, wired in
+    Bottleneck.forward and ResNet50Body._run_layer).  On the CPU the consumers take the explicit form of the gate
+    (_ReluGate / _PregatedRelu); gradients must equal the plain composition's exactly."""
+    import snipper_amd.backbone as bb
+    torch.manual_seed(0)
+    net = bb.Backbone("resnet50", True, True, False)
+    g = torch.Generator().manual_seed(1)
+    for m in net.modules():
+        if isinstance(m, bb.FrozenBatchNorm2d):
+            m.bias.copy_(torch.randn(m.bias.shape, generator=g) * 0.2)        # so that ReLUs do cut
+    imgs = torch.rand(2, 3, 64, 96, generator=g)
+    mask = torch.zeros(2, 64, 96, dtype=torch.bool)
+    params = [p for p in net.parameters() if p.requires_grad]
+    res = []
+    for fold in (True, False):
+        bb.FOLD_RELU_BACKWARD = fold
+        try:
+            feats = net(NestedTensor(imgs, mask))
+            outs = [feats[k].tensors for k in ("0", "1", "2")]
+            gos = [torch.randn(o.shape, generator=torch.Generator().manual_seed(2 + i)) for i, o in enumerate(outs)]
+            res.append(([o.detach() for o in outs], torch.autograd.grad(outs, params, gos)))
+        finally:
+            bb.FOLD_RELU_BACKWARD = True
+    for a, b in zip(res[0][0], res[1][0]):
+        assert torch.equal(a, b)
+    for a, b in zip(res[0][1], res[1][1]):
+        assert torch.equal(a, b)

@@ -397,3 +397,46 @@ def test_stem7x7_kernel(B, H, W):
     assert ref.shape == y.shape
     err = (y.float() - ref).abs().max().item()
     assert err <= 2e-2 * max(1.0, ref.abs().max().item()), err
+
+
+def test_relu_backward_folded_into_data_gradient_kernels_is_bit_identical():
+    """Backbone on the HIP kernels with the bottleneck ReLUs' backward done in the data-gradient kernels' store phase
+    (1x1 NN kernel gate, 3x3 stride-1 flush gate, 3x3 stride-2 per-fragment gate) against the same kernels followed by
+    separate threshold_backward passes: gating is exact, so outputs and every weight gradient must be bit-identical;
+    and the folded run must launch (almost) no threshold_backward."""
+    import snipper_amd.backbone as bb
+    from snipper_amd.misc import NestedTensor
+    from torch.profiler import ProfilerActivity, profile
+    torch.manual_seed(0)
+    net = bb.Backbone("resnet50", True, True, False).to(DEV).to(memory_format=torch.channels_last)
+    g = torch.Generator().manual_seed(1)
+    for m in net.modules():
+        if isinstance(m, bb.FrozenBatchNorm2d):
+            m.bias.copy_(torch.randn(m.bias.shape, generator=g) * 0.2)
+    imgs = torch.rand(2, 3, 270, 350, generator=g).to(DEV)            # odd map sizes on every level (135x175 -> 9x11)
+    mask = torch.zeros(2, 270, 350, dtype=torch.bool, device=DEV)
+    params = [p for p in net.parameters() if p.requires_grad]
+    res, counts = [], []
+    for fold in (True, False):
+        bb.FOLD_RELU_BACKWARD = fold
+        try:
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                feats = net(NestedTensor(imgs, mask))
+            outs = [feats[k].tensors for k in ("0", "1", "2")]
+            gos = [torch.randn(o.shape, generator=torch.Generator().manual_seed(2 + i)).to(DEV).to(o.dtype)
+                   for i, o in enumerate(outs)]
+            with profile(activities=[ProfilerActivity.CPU]) as prof:
+                grads = torch.autograd.grad(outs, params, gos)
+            counts.append(sum(e.count for e in prof.key_averages() if "threshold_backward" in e.key))
+            res.append(([o.detach().clone() for o in outs], [x.detach().clone() for x in grads]))
+        finally:
+            bb.FOLD_RELU_BACKWARD = True
+    for a, b in zip(res[0][0], res[1][0]):
+        assert torch.equal(a, b)
+    names = [n for n, p in net.named_parameters() if p.requires_grad]
+    for a, b, n in zip(res[0][1], res[1][1], names):
+        assert torch.equal(a, b), n
+    print("[relu fold] threshold_backward launches: folded", counts[0], "unfolded", counts[1])
+    # folded: the three layer outputs keep their own ReLU backward (other consumers); at THIS input size layer4's maps have
+    # 198 < 256 rows, so its five gated 1x1 data gradients take the library GEMM + explicit gate (dense._dgrad)
+    assert counts[1] >= 39 and counts[0] <= 8, counts
