@@ -435,8 +435,7 @@ int snipper_linear_bf16(void *stream, const uint16_t *X, long long ldx, const ui
       (R && (ldr % 4 || ldr < N)) || !(dropout_p >= 0.f && dropout_p < 1.f) ||
       (dropout_p > 0.f && (long long)M * N >= (1LL << 32)))
     return SNIPPER_E_SHAPE;
-  static const int dbg = getenv("SNIPPER_GEMM_DEBUG") ? atoi(getenv("SNIPPER_GEMM_DEBUG")) : 0;
-  const GemmArgs g{X, ldx, W, bias, R, ldr, Y, ldy, M, N, K, dropout_p, (uint32_t)seed, (uint32_t)(seed >> 32), dbg};
+  const GemmArgs g{X, ldx, W, bias, R, ldr, Y, ldy, M, N, K, dropout_p, (uint32_t)seed, (uint32_t)(seed >> 32)};
   const dim3 grid(gemm_grid_size(M, N));
   if (relu)
     hipLaunchKernelGGL(linear_bf16_kernel<true>, grid, dim3(kGemmThreads), 0, (hipStream_t)stream, g);
@@ -741,23 +740,33 @@ int snipper_temporal_mix(void *stream, const void *in, int in_dtype, const unsig
   MixMatrix m{};
   for (int a = 0; a < To; ++a)
     for (int b = 0; b < Ti; ++b) m.w[a][b] = mix[a * Ti + b];
-  const long long total = (long long)N * S * C / 4;
-  const int grid = (int)std::min<long long>((total + 255) / 256, 256LL * 32);
+  if ((long long)N * S * C / 4 >= (1LL << 31) || S >= (1LL << 31)) return SNIPPER_E_SHAPE;
+  const bool few = Ti <= 4 && To <= 4;      // (more frames: 4 channels per lane, or the registers would not hold them)
+  const bool wide = few && C % 8 == 0 && (((uintptr_t)in | (uintptr_t)out) & 15) == 0;
+  const long long total = (long long)N * S * C / (wide ? 8 : 4);
+  const unsigned grid = (unsigned)((total + 255) / 256);
   hipStream_t st = (hipStream_t)stream;
-#define SNIPPER_MIX(TI, TO)                                                                                      \
-  do {                                                                                                           \
-    if (mask_on_input)                                                                                           \
-      hipLaunchKernelGGL((temporal_mix_kernel<TI, TO, true>), dim3(grid), dim3(256), 0, st, (const TI *)in, mask, m, \
-                         N, Ti, To, S, C, (TO *)out);                                                            \
-    else                                                                                                         \
-      hipLaunchKernelGGL((temporal_mix_kernel<TI, TO, false>), dim3(grid), dim3(256), 0, st, (const TI *)in, mask, m, \
-                         N, Ti, To, S, C, (TO *)out);                                                            \
+#define SNIPPER_MIX_FW(TI, TO, MI, F, W)                                                                          \
+  hipLaunchKernelGGL((temporal_mix_kernel<TI, TO, MI, F, W>), dim3(grid), dim3(256), 0, st, (const TI *)in, mask, m, N, \
+                     Ti, To, (int)S, C, (TO *)out)
+#define SNIPPER_MIX_M(TI, TO, MI)                                                                                 \
+  do {                                                                                                            \
+    if (wide) SNIPPER_MIX_FW(TI, TO, MI, 4, 8);                                                                   \
+    else if (few) SNIPPER_MIX_FW(TI, TO, MI, 4, 4);                                                               \
+    else SNIPPER_MIX_FW(TI, TO, MI, 8, 4);                                                                        \
+  } while (0)
+#define SNIPPER_MIX(TI, TO)                                                                                       \
+  do {                                                                                                            \
+    if (mask_on_input) SNIPPER_MIX_M(TI, TO, true);                                                               \
+    else SNIPPER_MIX_M(TI, TO, false);                                                                            \
   } while (0)
   if (in_dtype == 0 && out_dtype == 0) SNIPPER_MIX(float, float);
   else if (in_dtype == 1 && out_dtype == 0) SNIPPER_MIX(uint16_t, float);
   else if (in_dtype == 0 && out_dtype == 1) SNIPPER_MIX(float, uint16_t);
   else if (in_dtype == 1 && out_dtype == 1) SNIPPER_MIX(uint16_t, uint16_t);
   else return SNIPPER_E_UNSUPPORTED;
+#undef SNIPPER_MIX_FW
+#undef SNIPPER_MIX_M
 #undef SNIPPER_MIX
   return launch_status();
 }

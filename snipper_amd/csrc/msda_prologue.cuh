@@ -41,41 +41,84 @@ template <> struct Vec4IO<uint16_t> {
   }
 };
 
+// W consecutive channels per lane: 4 (the types above) or 8 (two of them; bf16: ONE 16-byte access per lane)
+template <typename T, int W> struct VecIO {
+  static __device__ __forceinline__ void ld(const T *p, float (&v)[W]) {
+    if constexpr (W == 4) {
+      Vec4IO<T>::ld(p, v);
+    } else if constexpr (sizeof(T) == 2) {
+      const uint4 t = *reinterpret_cast<const uint4 *>(p);
+      v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
+      v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
+      v[4] = __uint_as_float(t.z << 16); v[5] = __uint_as_float(t.z & 0xffff0000u);
+      v[6] = __uint_as_float(t.w << 16); v[7] = __uint_as_float(t.w & 0xffff0000u);
+    } else {
+      const float4 a = reinterpret_cast<const float4 *>(p)[0], b = reinterpret_cast<const float4 *>(p)[1];
+      v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    }
+  }
+  static __device__ __forceinline__ void st(T *p, const float (&v)[W]) {
+    if constexpr (W == 4) {
+      Vec4IO<T>::st(p, v);
+    } else if constexpr (sizeof(T) == 2) {
+      uint4 t;
+      t.x = (unsigned)f32_to_bf16_bits(v[0]) | ((unsigned)f32_to_bf16_bits(v[1]) << 16);
+      t.y = (unsigned)f32_to_bf16_bits(v[2]) | ((unsigned)f32_to_bf16_bits(v[3]) << 16);
+      t.z = (unsigned)f32_to_bf16_bits(v[4]) | ((unsigned)f32_to_bf16_bits(v[5]) << 16);
+      t.w = (unsigned)f32_to_bf16_bits(v[6]) | ((unsigned)f32_to_bf16_bits(v[7]) << 16);
+      *reinterpret_cast<uint4 *>(p) = t;
+    } else {
+      reinterpret_cast<float4 *>(p)[0] = make_float4(v[0], v[1], v[2], v[3]);
+      reinterpret_cast<float4 *>(p)[1] = make_float4(v[4], v[5], v[6], v[7]);
+    }
+  }
+};
+
 // out[n, to, s, c] = sum_ti mix[to][ti] * in[n, ti, s, c], masked positions (mask[n, t, s] != 0) reading as 0
 // (MASK_IN: the mask belongs to the input frames -- forward) or being written as 0 (the mask belongs to
 // the output frames -- backward, where `in` is the gradient of the mixed frames).
-template <typename TI, typename TO, bool MASK_IN>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void temporal_mix_kernel(const TI *__restrict__ in, const unsigned char *__restrict__ mask,
-                                                           MixMatrix mix, int N, int Ti, int To, long long S, int C,
-                                                           TO *__restrict__ out) {
-  const long long X4 = S * C / 4;                       // vectors of 4 channels per frame
-  const long long total = (long long)N * X4;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const long long n = i / X4, x4 = i - n * X4;
-    const long long s = (x4 * 4) / C;
-    float v[kMixMaxFrames][4];
+// F = frames the instantiation holds in registers (4 or 8 >= Ti, To), W = channels per lane (8 when C % 8 == 0: a bf16
+// frame row then moves as 16 bytes per lane; measured 47 -> see DESIGN 3.5).  One position per thread: the grid covers
+// N * S * C / W exactly (< 2^31), so the index arithmetic is 32-bit.
+template <typename TI, typename TO, bool MASK_IN, int F, int W>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void temporal_mix_kernel(
+    const TI *__restrict__ in, const unsigned char *__restrict__ mask, MixMatrix mix, int N, int Ti, int To, int S, int C,
+    TO *__restrict__ out) {
+  const unsigned XW = (unsigned)S * (unsigned)C / W;    // vectors of W channels per frame
+  const unsigned i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= (unsigned)N * XW) return;
+  const unsigned n = i / XW, xw = i - n * XW;
+  const unsigned s = xw / ((unsigned)C / W);
+  float v[F][W];
 #pragma unroll
-    for (int ti = 0; ti < kMixMaxFrames; ++ti) {
-      if (ti < Ti) {
-        Vec4IO<TI>::ld(in + ((n * Ti + ti) * X4 + x4) * 4, v[ti]);
-        if (MASK_IN && mask && mask[(n * Ti + ti) * S + s]) v[ti][0] = v[ti][1] = v[ti][2] = v[ti][3] = 0.f;
+  for (int ti = 0; ti < F; ++ti) {
+    if (ti < Ti) {
+      VecIO<TI, W>::ld(in + ((size_t)(n * Ti + ti) * XW + xw) * W, v[ti]);
+      if (MASK_IN && mask && mask[(size_t)(n * Ti + ti) * S + s]) {
+#pragma unroll
+        for (int k = 0; k < W; ++k) v[ti][k] = 0.f;
       }
     }
+  }
 #pragma unroll
-    for (int to = 0; to < kMixMaxFrames; ++to) {
-      if (to < To) {
-        float o[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int to = 0; to < F; ++to) {
+    if (to < To) {
+      float o[W];
 #pragma unroll
-        for (int ti = 0; ti < kMixMaxFrames; ++ti) {
-          if (ti < Ti) {
-            const float w = mix.w[to][ti];
+      for (int k = 0; k < W; ++k) o[k] = 0.f;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) o[k] = fmaf(w, v[ti][k], o[k]);
-          }
+      for (int ti = 0; ti < F; ++ti) {
+        if (ti < Ti) {
+          const float w = mix.w[to][ti];
+#pragma unroll
+          for (int k = 0; k < W; ++k) o[k] = fmaf(w, v[ti][k], o[k]);
         }
-        if (!MASK_IN && mask && mask[(n * To + to) * S + s]) o[0] = o[1] = o[2] = o[3] = 0.f;
-        Vec4IO<TO>::st(out + ((n * To + to) * X4 + x4) * 4, o);
       }
+      if (!MASK_IN && mask && mask[(size_t)(n * To + to) * S + s]) {
+#pragma unroll
+        for (int k = 0; k < W; ++k) o[k] = 0.f;
+      }
+      VecIO<TO, W>::st(out + ((size_t)(n * To + to) * XW + xw) * W, o);
     }
   }
 }
