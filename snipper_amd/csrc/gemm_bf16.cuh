@@ -105,109 +105,132 @@ __device__ __forceinline__ unsigned gemm_pack2(float a, float b) {
   return (unsigned)__builtin_bit_cast(uint16_t, (__bf16)a) | ((unsigned)__builtin_bit_cast(uint16_t, (__bf16)b) << 16);
 }
 
+// The grid may be smaller than the tile count: workgroup (xcd, w) then walks the tiles j = w, w + W, w + 2W, ... of its
+// XCD's list (W = gridDim.x / 8 workgroups per XCD) with the first K-step of the NEXT tile in flight behind the epilogue
+// of the current one.  Measured with 3 workgroups per CU resident for the whole launch: no gain over one tile per
+// workgroup (79 000 x 384 x 384: 44.4 vs 44.6 us; x1024: 96 vs 92 us) -- the dispatcher already starts a new workgroup
+// while its two neighbours compute -- so the launcher uses gemm_grid_size() workgroups, one tile each.
 template <bool RELU>
 __global__ __launch_bounds__(kGemmThreads) __attribute__((amdgpu_waves_per_eu(3, 3))) void linear_bf16_kernel(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) uint16_t smem[(kGemmBM + kGemmBN) * kGemmPad];
   uint16_t *Xs = smem, *Ws = smem + kGemmBM * kGemmPad;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave & 1, wn = wave >> 1;
-  int tm, tn;
-  gemm_tile_of_block((g.N + kGemmBN - 1) / kGemmBN, tm, tn);
-  if ((long long)tm * kGemmBM >= g.M) return;             // padding workgroups of the XCD-major grid
-  const int m0 = tm * kGemmBM, n0 = tn * kGemmBN;
+  const int tiles_n = (g.N + kGemmBN - 1) / kGemmBN, tiles_m = (g.M + kGemmBM - 1) / kGemmBM;
+  const int xcd = blockIdx.x & 7, per_xcd = (int)(gridDim.x >> 3);
+  const int ntile = ((tiles_m - xcd + 7) >> 3) * tiles_n;        // tiles of this XCD (M tiles xcd, xcd + 8, ...)
+  int j = (int)(blockIdx.x >> 3);
+  if (j >= ntile) return;
 
-  // loader: 4 x 16 B per operand per thread and K-step; row = idx / 8, 8-element chunk = idx % 8
-  const uint16_t *xp[4], *wp[4];
+  // loader: 4 x 16 B per operand per thread and K-step; row = 32 * i + tid / 8, 8-element chunk = tid % 8.  Raw buffer
+  // loads: the descriptor covers the tile's rows only (base = the tile's first row, a uniform value), so a row past the
+  // end of the matrix reads as 0 without a clamp and the per-lane state is ONE 32-bit offset per operand for all tiles
+  // (+ a multiple of the row-group stride, added per load); the K-step goes into the scalar offset.  (The range check
+  // of a raw buffer looks at the vector offset only, which is why the row group must be part of it.)
+  const int lrow = tid >> 3, kc = tid & 7;
+  const unsigned x_voff = ((unsigned)lrow * (unsigned)g.ldx + kc * 8) * 2u, w_voff = ((unsigned)lrow * (unsigned)g.K + kc * 8) * 2u;
+  const unsigned x_step = 32u * (unsigned)g.ldx * 2u, w_step = 32u * (unsigned)g.K * 2u;      // bytes between row groups
   int lds_off[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int idx = tid + kGemmThreads * i, row = idx >> 3, kc = idx & 7;
-    const int mr = min(m0 + row, g.M - 1), nr = min(n0 + row, g.N - 1);     // clamp: edge rows are never stored
-    xp[i] = g.X + (long long)mr * g.ldx + kc * 8;
-    wp[i] = g.W + (long long)nr * g.K + kc * 8;
-    lds_off[i] = row * kGemmPad + kc * 8;
-  }
+  for (int i = 0; i < 4; ++i) lds_off[i] = (lrow + 32 * i) * kGemmPad + kc * 8;
   gemm_u32x4 xr[4], wr[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    xr[i] = *reinterpret_cast<const gemm_u32x4 *>(xp[i]);
-    wr[i] = *reinterpret_cast<const gemm_u32x4 *>(wp[i]);
-  }
-  gemm_f32x4 acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = gemm_f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const int frag_row = lane & 15, frag_k = (lane >> 4) * 8;
-  for (int k0 = 0; k0 < g.K; k0 += kGemmBK) {
+  __amdgpu_buffer_rsrc_t xsrc, wsrc;
+  auto load_step = [&](int k0) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      *reinterpret_cast<gemm_u32x4 *>(Xs + lds_off[i]) = xr[i];
-      *reinterpret_cast<gemm_u32x4 *>(Ws + lds_off[i]) = wr[i];
+      xr[i] = __builtin_amdgcn_raw_buffer_load_b128(xsrc, x_voff + i * x_step, (unsigned)k0 * 2u, 0);
+      wr[i] = __builtin_amdgcn_raw_buffer_load_b128(wsrc, w_voff + i * w_step, (unsigned)k0 * 2u, 0);
     }
-    __syncthreads();
-    if (k0 + kGemmBK < g.K) {     // next K-step in flight while this one is multiplied
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        xr[i] = *reinterpret_cast<const gemm_u32x4 *>(xp[i] + k0 + kGemmBK);
-        wr[i] = *reinterpret_cast<const gemm_u32x4 *>(wp[i] + k0 + kGemmBK);
-      }
-    }
-#pragma unroll
-    for (int kk = 0; kk < kGemmBK; kk += 32) {
-      gemm_bf16x8 wf[4], xf[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        wf[i] = *reinterpret_cast<const gemm_bf16x8 *>(Ws + (wn * 64 + i * 16 + frag_row) * kGemmPad + kk + frag_k);
-        xf[i] = *reinterpret_cast<const gemm_bf16x8 *>(Xs + (wm * 64 + i * 16 + frag_row) * kGemmPad + kk + frag_k);
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
-    }
-    __syncthreads();
-  }
-
-  // epilogue: lane holds n = nb + 4*(lane>>4) + r (r = 0..3) of output row m = mb + (lane & 15)
+  };
+  auto start_tile = [&](int jj) {          // descriptors of tile jj, its first K-step in flight
+    const int m0 = (xcd + 8 * (jj / tiles_n)) * kGemmBM, n0 = (jj % tiles_n) * kGemmBN;
+    const int mrows = min(kGemmBM, g.M - m0), nrows = min(kGemmBN, g.N - n0);
+    xsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(g.X + (long long)m0 * g.ldx), 0,
+                                             (int)(((long long)(mrows - 1) * g.ldx + g.K) * 2), 0x00020000);
+    wsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(g.W + (long long)n0 * g.K), 0,
+                                             (int)((long long)nrows * g.K * 2), 0x00020000);
+    load_step(0);
+  };
+  start_tile(j);
+  const int frag_row = lane & 15, frag_k = (lane >> 4) * 8;
   const bool wide = gemm_wide_ok(g.Y, g.ldy, g.N);
   const bool drop = g.drop_p > 0.f;
   const float keep_scale = drop ? 1.f / (1.f - g.drop_p) : 1.f;
   const uint32_t thresh = (uint32_t)fminf(g.drop_p * 4294967296.f, 4294967040.f);
+
+  for (;;) {
+    const int m0 = (xcd + 8 * (j / tiles_n)) * kGemmBM, n0 = (j % tiles_n) * kGemmBN;
+    gemm_f32x4 acc[4][4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int n = n0 + wn * 64 + i * 16 + (lane >> 4) * 4;
-    if (n >= g.N) continue;
-    gemm_f32x4 b = {0.f, 0.f, 0.f, 0.f};
-    if (g.bias) b = *reinterpret_cast<const gemm_f32x4 *>(g.bias + n);
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int m = m0 + wm * 64 + j * 16 + (lane & 15);
-      if (m >= g.M) continue;
-      gemm_f32x4 v = acc[i][j] + b;
-      if (g.R) {
-        const uint2 r = *reinterpret_cast<const uint2 *>(g.R + (long long)m * g.ldr + n);
-        v.x += __uint_as_float(r.x << 16); v.y += __uint_as_float(r.x & 0xffff0000u);
-        v.z += __uint_as_float(r.y << 16); v.w += __uint_as_float(r.y & 0xffff0000u);
+      for (int jj = 0; jj < 4; ++jj) acc[i][jj] = gemm_f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int k0 = 0; k0 < g.K; k0 += kGemmBK) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        *reinterpret_cast<gemm_u32x4 *>(Xs + lds_off[i]) = xr[i];
+        *reinterpret_cast<gemm_u32x4 *>(Ws + lds_off[i]) = wr[i];
       }
-      if (RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-      if (drop) {
-        const uint32_t e = (uint32_t)m * (uint32_t)g.N + (uint32_t)n;
-        v.x = gemm_rand(e, g.seed_lo, g.seed_hi) >= thresh ? v.x * keep_scale : 0.f;
-        v.y = gemm_rand(e + 1, g.seed_lo, g.seed_hi) >= thresh ? v.y * keep_scale : 0.f;
-        v.z = gemm_rand(e + 2, g.seed_lo, g.seed_hi) >= thresh ? v.z * keep_scale : 0.f;
-        v.w = gemm_rand(e + 3, g.seed_lo, g.seed_hi) >= thresh ? v.w * keep_scale : 0.f;
+      __syncthreads();
+      if (k0 + kGemmBK < g.K) load_step(k0 + kGemmBK);     // next K-step in flight while this one is multiplied
+#pragma unroll
+      for (int kk = 0; kk < kGemmBK; kk += 32) {
+        gemm_bf16x8 wf[4], xf[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          wf[i] = *reinterpret_cast<const gemm_bf16x8 *>(Ws + (wn * 64 + i * 16 + frag_row) * kGemmPad + kk + frag_k);
+          xf[i] = *reinterpret_cast<const gemm_bf16x8 *>(Xs + (wm * 64 + i * 16 + frag_row) * kGemmPad + kk + frag_k);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj)
+            acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[jj], acc[i][jj], 0, 0, 0);
       }
-      uint2 o;
-      o.x = gemm_pack2(v.x, v.y);
-      o.y = gemm_pack2(v.z, v.w);
-      if (wide) *reinterpret_cast<uint2 *>(smem + (m - m0) * kGemmCtStride + (n - n0)) = o;
-      else *reinterpret_cast<uint2 *>(g.Y + (long long)m * g.ldy + n) = o;
+      __syncthreads();
     }
+    const int jn = j + per_xcd;
+    const bool more = jn < ntile;
+    if (more) start_tile(jn);      // in flight behind this tile's epilogue
+
+    // epilogue: lane holds n = nb + 4*(lane>>4) + r (r = 0..3) of output row m = mb + (lane & 15)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int n = n0 + wn * 64 + i * 16 + (lane >> 4) * 4;
+      if (n >= g.N) continue;
+      gemm_f32x4 b = {0.f, 0.f, 0.f, 0.f};
+      if (g.bias) b = *reinterpret_cast<const gemm_f32x4 *>(g.bias + n);
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const int m = m0 + wm * 64 + jj * 16 + (lane & 15);
+        if (m >= g.M) continue;
+        gemm_f32x4 v = acc[i][jj] + b;
+        if (g.R) {
+          const uint2 r = *reinterpret_cast<const uint2 *>(g.R + (long long)m * g.ldr + n);
+          v.x += __uint_as_float(r.x << 16); v.y += __uint_as_float(r.x & 0xffff0000u);
+          v.z += __uint_as_float(r.y << 16); v.w += __uint_as_float(r.y & 0xffff0000u);
+        }
+        if (RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        if (drop) {
+          const uint32_t e = (uint32_t)m * (uint32_t)g.N + (uint32_t)n;
+          v.x = gemm_rand(e, g.seed_lo, g.seed_hi) >= thresh ? v.x * keep_scale : 0.f;
+          v.y = gemm_rand(e + 1, g.seed_lo, g.seed_hi) >= thresh ? v.y * keep_scale : 0.f;
+          v.z = gemm_rand(e + 2, g.seed_lo, g.seed_hi) >= thresh ? v.z * keep_scale : 0.f;
+          v.w = gemm_rand(e + 3, g.seed_lo, g.seed_hi) >= thresh ? v.w * keep_scale : 0.f;
+        }
+        uint2 o;
+        o.x = gemm_pack2(v.x, v.y);
+        o.y = gemm_pack2(v.z, v.w);
+        if (wide) *reinterpret_cast<uint2 *>(smem + (m - m0) * kGemmCtStride + (n - n0)) = o;
+        else *reinterpret_cast<uint2 *>(g.Y + (long long)m * g.ldy + n) = o;
+      }
+    }
+    if (wide) gemm_flush_tile(smem, g.Y, g.ldy, m0, n0, g.M, g.N);
+    if (!more) break;
+    j = jn;
+    __syncthreads();               // the staged tile has been read out before the next tile's operands overwrite it
   }
-  if (wide) gemm_flush_tile(smem, g.Y, g.ldy, m0, n0, g.M, g.N);
 }
 
 // ---- data gradient: Y[M,N] = X[M,K] . W[K,N]  (W row-major with the REDUCTION index as its slow axis) ------------
@@ -249,27 +272,33 @@ __global__ __launch_bounds__(kGemmThreads) __attribute__((amdgpu_waves_per_eu(3,
   if ((long long)tm * kGemmBM >= g.M) return;
   const int m0 = tm * kGemmBM, n0 = tn * kGemmBN;
 
-  const uint16_t *xp[4], *wp[4];
+  // loaders (raw buffer loads as in linear_bf16_kernel).  X: 128 rows x 8 chunks of 8 k, row = 32 * i + tid / 8; the
+  // descriptor covers the tile's rows, so rows past the end read as 0.  W: 64 k-rows x 16 chunks of 8 n, k-row =
+  // 16 * i + tid / 16; a lane whose columns lie past N gets an offset outside the descriptor (reads as 0).
+  const int lrow = tid >> 3, kc = tid & 7, krow = tid >> 4, nc = tid & 15;
+  const unsigned x_voff = ((unsigned)lrow * (unsigned)g.ldx + kc * 8) * 2u, x_step = 32u * (unsigned)g.ldx * 2u;
+  const unsigned w_step = 16u * (unsigned)g.ldw * 2u;
+  const unsigned w_voff = n0 + nc * 8 < g.N ? ((unsigned)krow * (unsigned)g.ldw + nc * 8) * 2u : 0x80000000u;
   int x_off[4], w_off[4];
-  bool w_ok[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int idx = tid + kGemmThreads * i;
-    const int row = idx >> 3, kc = idx & 7;                 // X: 128 rows x 8 chunks of 8 k
-    xp[i] = g.X + (long long)min(m0 + row, g.M - 1) * g.ldx + kc * 8;
-    x_off[i] = row * kGemmPad + kc * 8;
-    const int krow = idx >> 4, nc = idx & 15;               // W: 64 k-rows x 16 chunks of 8 n
-    w_ok[i] = n0 + nc * 8 < g.N;
-    wp[i] = g.W + (long long)krow * g.ldw + n0 + nc * 8;
-    w_off[i] = krow * kGemmTrStride + nc * 8;
+    x_off[i] = (lrow + 32 * i) * kGemmPad + kc * 8;
+    w_off[i] = (krow + 16 * i) * kGemmTrStride + nc * 8;
   }
-  const gemm_u32x4 zero4 = {0u, 0u, 0u, 0u};
+  const int mrows = min(kGemmBM, g.M - m0);
+  const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint16_t *>(g.X + (long long)m0 * g.ldx), 0, (int)(((long long)(mrows - 1) * g.ldx + g.K) * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint16_t *>(g.W + n0), 0, (int)(((long long)(g.K - 1) * g.ldw + (g.N - n0)) * 2), 0x00020000);
   gemm_u32x4 xr[4], wr[4];
+  auto load_step = [&](int k0) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    xr[i] = *reinterpret_cast<const gemm_u32x4 *>(xp[i]);
-    wr[i] = w_ok[i] ? *reinterpret_cast<const gemm_u32x4 *>(wp[i]) : zero4;
-  }
+    for (int i = 0; i < 4; ++i) {
+      xr[i] = __builtin_amdgcn_raw_buffer_load_b128(xsrc, x_voff + i * x_step, (unsigned)k0 * 2u, 0);
+      wr[i] = __builtin_amdgcn_raw_buffer_load_b128(wsrc, w_voff + i * w_step, (unsigned)k0 * (unsigned)g.ldw * 2u, 0);
+    }
+  };
+  load_step(0);
   gemm_f32x4 acc[4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -286,13 +315,7 @@ __global__ __launch_bounds__(kGemmThreads) __attribute__((amdgpu_waves_per_eu(3,
       *reinterpret_cast<gemm_u32x4 *>(Ws + w_off[i]) = wr[i];
     }
     __syncthreads();
-    if (k0 + kGemmBK < g.K) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        xr[i] = *reinterpret_cast<const gemm_u32x4 *>(xp[i] + k0 + kGemmBK);
-        wr[i] = w_ok[i] ? *reinterpret_cast<const gemm_u32x4 *>(wp[i] + (long long)(k0 + kGemmBK) * g.ldw) : zero4;
-      }
-    }
+    if (k0 + kGemmBK < g.K) load_step(k0 + kGemmBK);
 #pragma unroll
     for (int kk = 0; kk < kGemmBK; kk += 32) {
       gemm_bf16x8 wf[4], xf[4];
