@@ -428,20 +428,29 @@ __global__ __launch_bounds__(kGemmThreads) __attribute__((amdgpu_waves_per_eu(3,
   const int nty = g.dgrad2 ? (g.cy ? 2 : 1) : 3, ntx = g.dgrad2 ? (g.cx ? 2 : 1) : 3;
   const int kslices = g.Cin / kGemmBK, steps = nty * ntx * kslices;
 
-  int pb[4], py[4], px[4], kc8[4], lds_off[4];
-  const uint16_t *wrow[4];
+  // loader: rows 32 * i + tid / 8 of the tile, 8-element chunk tid % 8.  Raw buffer loads: the X descriptor covers the
+  // whole activation (< 2 GiB, checked by the launcher) and a tap that falls outside the image gets an offset outside the
+  // descriptor -- it reads as 0 without a select; the W descriptor covers the tile's Cout rows (rows past Cout read as
+  // 0), one lane offset for all taps, the tap / channel slice in the scalar offset.
+  const int lrow = tid >> 3, kc = tid & 7;
+  int py[4], px[4], pix[4], lds_off[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int idx = tid + kGemmThreads * i, row = idx >> 3, kc = idx & 7;
+    const int row = lrow + 32 * i;
     const int m = min(m0 + row, M - 1);
-    pb[i] = m / (g.Ho * g.Wo);
-    const int r = m - pb[i] * (g.Ho * g.Wo);
+    const int b = m / (g.Ho * g.Wo);
+    const int r = m - b * (g.Ho * g.Wo);
     py[i] = g.dgrad2 ? r / g.Wo : (r / g.Wo) * g.stride - 1;
     px[i] = g.dgrad2 ? r % g.Wo : (r % g.Wo) * g.stride - 1;
-    kc8[i] = kc * 8;
-    wrow[i] = g.W + (long long)min(n0 + row, g.Cout - 1) * 9 * g.Cin + kc * 8;
+    pix[i] = (b * g.H + py[i]) * g.Wd + px[i];           // (may be "negative" by up to a row + 1: only used when in range)
     lds_off[i] = row * kGemmPad + kc * 8;
   }
+  const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint16_t *>(g.X), 0, (int)((long long)g.B * g.H * g.Wd * g.Cin * 2), 0x00020000);
+  const int nrows = min(kGemmBN, g.Cout - n0);
+  const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint16_t *>(g.W + (long long)n0 * 9 * g.Cin), 0, (int)((long long)nrows * 9 * g.Cin * 2), 0x00020000);
+  const unsigned w_voff = ((unsigned)lrow * 9u * (unsigned)g.Cin + kc * 8) * 2u, w_step = 32u * 9u * (unsigned)g.Cin * 2u;
   auto load_step = [&](int s, gemm_u32x4 (&xr)[4], gemm_u32x4 (&wr)[4]) {
     const int t = s / kslices, k0 = (s - t * kslices) * kGemmBK;
     const int ty = t / ntx, tx = t - ty * ntx;
@@ -450,14 +459,14 @@ __global__ __launch_bounds__(kGemmThreads) __attribute__((amdgpu_waves_per_eu(3,
     const int ky = g.dgrad2 ? (g.cy ? 2 * ty : 1) : ty, kx = g.dgrad2 ? (g.cx ? 2 * tx : 1) : tx;
     const int dy = g.dgrad2 ? (g.cy + 1 - ky) / 2 : ky, dx = g.dgrad2 ? (g.cx + 1 - kx) / 2 : kx;
     const int tap = ky * 3 + kx;
+    const int dpix = dy * g.Wd + dx;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int iy = py[i] + dy, ix = px[i] + dx;
       const bool ok = iy >= 0 && iy < g.H && ix >= 0 && ix < g.Wd;
-      const uint16_t *xp = g.X + (((long long)pb[i] * g.H + (ok ? iy : 0)) * g.Wd + (ok ? ix : 0)) * g.Cin + k0 + kc8[i];
-      const gemm_u32x4 v = *reinterpret_cast<const gemm_u32x4 *>(xp);
-      xr[i] = ok ? v : gemm_u32x4{0u, 0u, 0u, 0u};
-      wr[i] = *reinterpret_cast<const gemm_u32x4 *>(wrow[i] + (long long)tap * g.Cin + k0);
+      const unsigned xoff = ok ? ((unsigned)(pix[i] + dpix) * (unsigned)g.Cin + (unsigned)(k0 + kc * 8)) * 2u : 0x80000000u;
+      xr[i] = __builtin_amdgcn_raw_buffer_load_b128(xsrc, xoff, 0, 0);
+      wr[i] = __builtin_amdgcn_raw_buffer_load_b128(wsrc, w_voff + i * w_step, (unsigned)(tap * g.Cin + k0) * 2u, 0);
     }
   };
   gemm_u32x4 xr[4], wr[4];

@@ -526,7 +526,7 @@ int snipper_wgrad_conv3x3_bf16(void *stream, const uint16_t *G, const uint16_t *
   if (((uintptr_t)G | (uintptr_t)X | (uintptr_t)dW | (uintptr_t)workspace) & 15) return SNIPPER_E_SHAPE;
   const int Ho = (H - 1) / stride + 1, Wo = (Wd - 1) / stride + 1;
   const long long M = (long long)B * Ho * Wo;
-  if (M >= (1LL << 31) || (long long)B * H * Wd >= (1LL << 31)) return SNIPPER_E_SHAPE;
+  if (M >= (1LL << 31) || (long long)B * H * Wd * Cin >= (1LL << 30)) return SNIPPER_E_SHAPE;      // (32-bit byte offsets)
   const int Kc = 9 * Cin;
   if (workspace_bytes < snipper_wgrad_workspace_bytes((int)M, Cout, Kc)) return SNIPPER_E_SHAPE;
   const WgradPlan p = wgrad_plan((int)M, Cout, Kc);
@@ -691,7 +691,7 @@ int snipper_conv3x3_bf16(void *stream, const uint16_t *X, const uint16_t *W, con
     return SNIPPER_E_SHAPE;
   const int Ho = (H - 1) / stride + 1, Wo = (Wd - 1) / stride + 1;
   const long long M = (long long)B * Ho * Wo;
-  if (M >= (1LL << 31)) return SNIPPER_E_SHAPE;
+  if (M >= (1LL << 31) || (long long)B * H * Wd * Cin >= (1LL << 30)) return SNIPPER_E_SHAPE;   // (32-bit byte offsets)
   const Conv3x3Args g{X, W, bias, Y, B, H, Wd, Cin, Cout, Ho, Wo, stride, 0, 0, 0, 0, 0, gate};
   const dim3 grid(gemm_grid_size(M, Cout));
   if (relu)
@@ -720,7 +720,7 @@ int snipper_conv3x3_dgrad_s2_bf16(void *stream, const uint16_t *G, const uint16_
   if (gate && ((uintptr_t)gate & 15)) return SNIPPER_E_SHAPE;
   if (B <= 0 || Hx <= 0 || Wx <= 0 || Cx <= 0 || Cg <= 0 || Cg % kGemmBK || Cx % 4) return SNIPPER_E_SHAPE;
   const int Hg = (Hx - 1) / 2 + 1, Wg = (Wx - 1) / 2 + 1;          // the stride-2 convolution's output size
-  if ((long long)B * Hx * Wx >= (1LL << 31)) return SNIPPER_E_SHAPE;
+  if ((long long)B * Hx * Wx >= (1LL << 31) || (long long)B * Hg * Wg * Cg >= (1LL << 30)) return SNIPPER_E_SHAPE;
   for (int cy = 0; cy < 2; ++cy)
     for (int cx = 0; cx < 2; ++cx) {
       const int Hc = (Hx - cy + 1) / 2, Wc = (Wx - cx + 1) / 2;    // input pixels (2a + cy, 2b + cx) of this class

@@ -82,8 +82,7 @@ __global__ __launch_bounds__(kWgThreads) void wgrad_bf16_kernel(WgradArgs g) {
   const int chunk = tid & 15, row0 = tid >> 4;
   const bool g_col_ok = n0 + chunk * 8 < g.N, x_col_ok = k0 + chunk * 8 < g.Kc;
   const int tap = g.conv ? k0 / g.Cin : 0, ky = tap / 3 - 1, kx = tap - (tap / 3) * 3 - 1;     // (conv mode)
-  const uint16_t *xp = g.X + (g.conv ? k0 - tap * g.Cin : k0) + chunk * 8;
-  const gemm_u32x4 zero4 = {0u, 0u, 0u, 0u};
+  const unsigned conv_col = (unsigned)((g.conv ? k0 - tap * g.Cin : k0) + chunk * 8);
   // G (and X outside conv mode) by raw buffer loads: the descriptor covers this workgroup's row range and column tile
   // (base = its first element, a uniform value), the per-lane offset is one 32-bit register per operand (+ the row
   // group and the step's row offset, added per load -- they must be part of the VECTOR offset, the only one the range
@@ -92,9 +91,12 @@ __global__ __launch_bounds__(kWgThreads) void wgrad_bf16_kernel(WgradArgs g) {
   const __amdgpu_buffer_rsrc_t gsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<uint16_t *>(g.G + (long long)m_begin * g.ldg + n0), 0,
       (int)(((long long)(nrows - 1) * g.ldg + (g.N - n0)) * 2), 0x00020000);
-  const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<uint16_t *>(g.X + (long long)m_begin * g.ldx + k0), 0,
-      (int)(((long long)(nrows - 1) * g.ldx + (g.Kc - k0)) * 2), 0x00020000);
+  // (conv mode: X is the [B][H][W][Cin] activation, < 2 GiB by the launcher's check; the descriptor covers all of it and a
+  //  tap outside the image gets an offset outside the descriptor)
+  const __amdgpu_buffer_rsrc_t xsrc = g.conv
+      ? __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(g.X), 0, (int)((long long)(g.M / (g.Ho * g.Wo)) * g.H * g.Wd * g.ldx * 2), 0x00020000)
+      : __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(g.X + (long long)m_begin * g.ldx + k0), 0,
+                                          (int)(((long long)(nrows - 1) * g.ldx + (g.Kc - k0)) * 2), 0x00020000);
   const unsigned g_voff = g_col_ok ? ((unsigned)row0 * (unsigned)g.ldg + chunk * 8) * 2u : 0x80000000u;
   const unsigned x_voff = x_col_ok ? ((unsigned)row0 * (unsigned)g.ldx + chunk * 8) * 2u : 0x80000000u;
   const unsigned g_grp = 16u * (unsigned)g.ldg * 2u, x_grp = 16u * (unsigned)g.ldx * 2u;
@@ -111,9 +113,8 @@ __global__ __launch_bounds__(kWgThreads) void wgrad_bf16_kernel(WgradArgs g) {
         const int oy = rem / g.Wo, ox = rem - oy * g.Wo;
         const int iy = oy * g.stride + ky, ix = ox * g.stride + kx;
         const bool in = ok && x_col_ok && iy >= 0 && iy < g.H && ix >= 0 && ix < g.Wd;
-        const long long px = in ? ((long long)b * g.H + iy) * g.Wd + ix : 0;
-        const gemm_u32x4 v = *reinterpret_cast<const gemm_u32x4 *>(xp + px * g.ldx);
-        xr[i] = in ? v : zero4;
+        const unsigned xo = in ? ((unsigned)((b * g.H + iy) * g.Wd + ix) * (unsigned)g.ldx + conv_col) * 2u : 0x80000000u;
+        xr[i] = __builtin_amdgcn_raw_buffer_load_b128(xsrc, xo, 0, 0);
       } else {
         xr[i] = __builtin_amdgcn_raw_buffer_load_b128(xsrc, x_voff + i * x_grp + mrel * (unsigned)g.ldx * 2u, 0, 0);
       }
