@@ -46,6 +46,13 @@ int snipper_linear_nn_bf16(void *stream, const uint16_t *X, long long ldx, const
 /* Backward of the (ReLU -> dropout) epilogue above from the layer's OUTPUT alone: a kept, active element has y > 0,
  * a dropped or inactive one y == 0, so grad_pre = y > 0 ? grad_y / (1 - p) : 0 (p = 0: plain ReLU backward).
  * bf16 bits, n % 8 == 0, 16-byte aligned. */
+/* Backward of y = x . W^T + b for a few hundred float32 rows (the decoder's Linears, reference
+ * models/deformable_transformer.py:244-343) in ONE launch: dX[M,K] = G[M,N] . W[N,K], dW[N,K] = G^T . X[M,K],
+ * db[N] = column sums of G -- each optional (NULL).  float32 in, float32 accumulate (v_mfma_f32_32x32x2_f32: bitwise an
+ * fmaf chain), fixed summation order.  N % 4 == 0, K % 4 == 0, leading dimensions % 4 == 0, 16-byte aligned inputs. */
+int snipper_small_linear_backward_f32(void *stream, const float *G, long long ldg, const float *X, long long ldx,
+                                      const float *W, long long ldw, int M, int N, int K, float *dX, long long lddx,
+                                      float *dW, long long lddw, float *db);
 int snipper_relu_dropout_backward_bf16(void *stream, const uint16_t *grad_y, const uint16_t *y, uint16_t *grad_pre,
                                        long long n, float dropout_p);
 

@@ -80,6 +80,8 @@ EXPORTS = {
                              ctypes.c_uint64], c_int),
     "snipper_linear_nn_bf16": ([c_void_p, c_void_p, c_longlong, c_void_p, c_longlong, c_void_p, c_longlong, c_void_p,
                                 c_longlong, ctypes.c_float, c_void_p, c_longlong, c_int, c_int, c_int], c_int),
+    "snipper_small_linear_backward_f32": ([c_void_p, c_void_p, c_longlong, c_void_p, c_longlong, c_void_p, c_longlong,
+                                           c_int, c_int, c_int, c_void_p, c_longlong, c_void_p, c_longlong, c_void_p], c_int),
     "snipper_relu_dropout_backward_bf16": ([c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, ctypes.c_float], c_int),
 }
 

@@ -15,6 +15,7 @@
 #include "../../include/snipper_dense.h"
 #include "gemm_bf16.cuh"
 #include "wgrad_bf16.cuh"
+#include "small_linear.cuh"
 #include "match_cost.cuh"
 #include "ln_fused.cuh"
 #include "gn_tokens.cuh"
@@ -455,6 +456,23 @@ int snipper_linear_nn_bf16(void *stream, const uint16_t *X, long long ldx, const
   const GemmNNArgs g{X, ldx, W, ldw, Y, ldy, M, N, K, R, ldr, A, lda, gate_scale};
   const dim3 grid(gemm_grid_size(M, N));
   hipLaunchKernelGGL(linear_bf16_nn_kernel, grid, dim3(kGemmThreads), 0, (hipStream_t)stream, g);
+  return launch_status();
+}
+
+int snipper_small_linear_backward_f32(void *stream, const float *G, long long ldg, const float *X, long long ldx,
+                                      const float *W, long long ldw, int M, int N, int K, float *dX, long long lddx,
+                                      float *dW, long long lddw, float *db) {
+  if (!G || (dX && !W) || ((dW || db) && !X)) return SNIPPER_E_NULL;
+  if (M <= 0 || N <= 0 || K <= 0 || N % 4 || K % 4 || ldg % 4 || ldg < N || (X && (ldx % 4 || ldx < K)) ||
+      (W && (ldw % 4 || ldw < K)) || (dX && lddx < K) || (dW && lddw < K))
+    return SNIPPER_E_SHAPE;
+  if (((uintptr_t)G | (uintptr_t)X | (uintptr_t)W) & 15) return SNIPPER_E_SHAPE;
+  const int tiles_k = (K + kSlTile - 1) / kSlTile;
+  const int tiles_dx = dX ? ((M + kSlTile - 1) / kSlTile) * tiles_k : 0;
+  const int tiles_dw = (dW || db) ? ((N + kSlTile - 1) / kSlTile) * tiles_k : 0;     // (db comes out of the dW tiles)
+  if (tiles_dx + tiles_dw == 0) return SNIPPER_OK;
+  const SmallLinearBwdArgs a{G, ldg, X, ldx, W, ldw, dX, lddx, dW, lddw, db, M, N, K, tiles_dx};
+  hipLaunchKernelGGL(small_linear_bwd_f32_kernel, dim3(tiles_dx + tiles_dw), dim3(kSlThreads), 0, (hipStream_t)stream, a);
   return launch_status();
 }
 

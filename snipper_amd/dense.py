@@ -359,6 +359,10 @@ class _SmallLinear(torch.autograd.Function):
     def backward(ctx, gy):
         x2, weight = ctx.saved_tensors
         g = gy.reshape(-1, weight.shape[0])
+        fused = small_linear_backward(g, x2, weight, *ctx.needs_input_grad)
+        if fused is not None:
+            dx, dW, db = fused
+            return (dx.view(ctx.x_shape) if dx is not None else None), dW, db
         dx = torch.mm(g, weight).view(ctx.x_shape) if ctx.needs_input_grad[0] else None
         dW = torch.mm(g.t(), x2) if ctx.needs_input_grad[1] else None
         db = None
@@ -366,6 +370,32 @@ class _SmallLinear(torch.autograd.Function):
             ones = _ones_row(g.shape[0], g.device, g.dtype)
             db = torch.mm(ones, g).view(-1)
         return dx, dW, db
+
+
+def small_linear_backward(g: torch.Tensor, x: torch.Tensor, w: torch.Tensor, need_dx=True, need_dw=True, need_db=True):
+    """(dX, dW, db) of ``y = x @ w.T + b`` from g = dL/dy in ONE launch (csrc/small_linear.cuh; float32, deterministic),
+    or None when the shapes are outside the kernel's requirements (the caller then takes the three library GEMMs)."""
+    M, N = g.shape
+    K = x.shape[1]
+    if not (g.is_cuda and g.dtype == torch.float32 and x.dtype == torch.float32 and w.dtype == torch.float32 and
+            N % 4 == 0 and K % 4 == 0 and M <= 8192 and w.shape == (N, K) and x.shape[0] == M):
+        return None
+    if g.stride(1) != 1 or g.stride(0) % 4 or g.data_ptr() % 16:
+        g = g.contiguous()
+    if x.stride(1) != 1 or x.stride(0) % 4 or x.data_ptr() % 16:
+        x = x.contiguous()
+    if w.stride(1) != 1 or w.stride(0) % 4 or w.data_ptr() % 16:
+        w = w.contiguous()
+    dx = torch.empty((M, K), dtype=torch.float32, device=g.device) if need_dx else None
+    dw = torch.empty((N, K), dtype=torch.float32, device=g.device) if need_dw else None
+    db = torch.empty((N,), dtype=torch.float32, device=g.device) if need_db else None
+    with _lib.device_guard(g.device):
+        rc = _lib.load().snipper_small_linear_backward_f32(
+            _lib.raw_stream(g.device), g.data_ptr(), g.stride(0), x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0),
+            M, N, K, dx.data_ptr() if dx is not None else None, K, dw.data_ptr() if dw is not None else None, K,
+            db.data_ptr() if db is not None else None)
+    _lib.check(rc, "snipper_small_linear_backward_f32")
+    return dx, dw, db
 
 
 _ones_cache = {}

@@ -440,3 +440,52 @@ def test_relu_backward_folded_into_data_gradient_kernels_is_bit_identical():
     # folded: the three layer outputs keep their own ReLU backward (other consumers); at THIS input size layer4's maps have
     # 198 < 256 rows, so its five gated 1x1 data gradients take the library GEMM + explicit gate (dense._dgrad)
     assert counts[1] >= 39 and counts[0] <= 8, counts
+
+
+@pytest.mark.parametrize("M,N,K", [(480, 384, 384), (480, 1024, 384), (480, 384, 1024), (240, 288, 384), (33, 36, 44),
+                                   (1, 4, 4), (720, 384, 384), (480, 96, 384), (2880, 384, 384)])
+def test_small_linear_backward_kernel(M, N, K):
+    """The decoder-size Linear backward as ONE launch (csrc/small_linear.cuh: dX, dW, db on float32 MFMA tiles) against a
+    float64 evaluation of the same three products; float32 results, so the error budget is accumulation order only.
+    Also: each output alone (the other pointers NULL) and run-to-run determinism."""
+    from snipper_amd.dense import small_linear_backward
+    g = torch.Generator().manual_seed(M * 7 + N)
+    G = torch.randn(M, N, generator=g).to(DEV)
+    X = torch.randn(M, K, generator=g).to(DEV)
+    W = torch.randn(N, K, generator=g).to(DEV)
+    dx, dw, db = small_linear_backward(G, X, W)
+    G64, X64, W64 = G.double(), X.double(), W.double()
+    for got, ref in ((dx, G64 @ W64), (dw, G64.t() @ X64), (db, G64.sum(0))):
+        scale = float(ref.abs().max().clamp_min(1.0))
+        assert float((got.double() - ref).abs().max()) <= 2e-6 * scale * max(M, N) ** 0.5, (M, N, K)
+    a = small_linear_backward(G, X, W, True, False, False)
+    b = small_linear_backward(G, X, W, False, True, False)
+    c = small_linear_backward(G, X, W, False, False, True)
+    assert a[1] is None and a[2] is None and torch.equal(a[0], dx)
+    assert b[0] is None and b[2] is None and torch.equal(b[1], dw)
+    assert c[0] is None and c[1] is None and torch.equal(c[2], db)
+    again = small_linear_backward(G, X, W)
+    assert all(torch.equal(u, v) for u, v in zip(again, (dx, dw, db)))
+    # strided (sliced) operands take the contiguous copy path
+    Gs = torch.randn(M, N + 8, generator=g).to(DEV)[:, 4:N + 4]
+    dx2, dw2, db2 = small_linear_backward(Gs, X, W)
+    assert torch.allclose(dx2, Gs.contiguous() @ W, rtol=1e-4, atol=1e-3 * max(1.0, float(dx2.abs().max())))
+
+
+def test_small_linear_backward_timing_against_three_gemms():
+    """Development aid kept as a test: prints the launch times (one fused launch vs the three library GEMMs)."""
+    from snipper_amd.dense import small_linear_backward, _ones_row
+    M, N, K = 480, 384, 384
+    G, X, W = (torch.randn(M, N, device=DEV), torch.randn(M, K, device=DEV), torch.randn(N, K, device=DEV))
+    def t(fn, n=50):
+        for _ in range(5): fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n): fn()
+        e1.record(); torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n * 1e3
+    ones = _ones_row(M, G.device, G.dtype)
+    fused = t(lambda: small_linear_backward(G, X, W))
+    lib = t(lambda: (torch.mm(G, W), torch.mm(G.t(), X), torch.mm(ones, G)))
+    print(f"[small linear backward 480x384x384] fused {fused:.1f} us, three library GEMMs {lib:.1f} us")
