@@ -46,10 +46,26 @@ int snipper_linear_nn_bf16(void *stream, const uint16_t *X, long long ldx, const
 /* Backward of the (ReLU -> dropout) epilogue above from the layer's OUTPUT alone: a kept, active element has y > 0,
  * a dropped or inactive one y == 0, so grad_pre = y > 0 ? grad_y / (1 - p) : 0 (p = 0: plain ReLU backward).
  * bf16 bits, n % 8 == 0, 16-byte aligned. */
-/* Backward of y = x . W^T + b for a few hundred float32 rows (the decoder's Linears, reference
- * models/deformable_transformer.py:244-343) in ONE launch: dX[M,K] = G[M,N] . W[N,K], dW[N,K] = G^T . X[M,K],
- * db[N] = column sums of G -- each optional (NULL).  float32 in, float32 accumulate (v_mfma_f32_32x32x2_f32: bitwise an
- * fmaf chain), fixed summation order.  N % 4 == 0, K % 4 == 0, leading dimensions % 4 == 0, 16-byte aligned inputs. */
+/* Float32 products of decoder size (a few hundred rows: the Linears of reference models/deformable_transformer.py:244-343),
+ * SEVERAL PER LAUNCH:  out[I,J] = opA(A)[I,R] . opB(B)[R,J] (+ bias[J]),  optionally colsum[I] = sum_r opA(A)[i,r].
+ * A is stored [I][R] (a_transposed = 0) or [R][I] (1); B is stored [R][J] (0) or [J][R] (1); out / colsum may be NULL
+ * (not both).  One launch is e.g. a Linear's forward (x . W^T + b: B transposed), its whole backward (dX = G . W and
+ * dW = G^T . X with db as the column sums), or a packed projection pair.  float32 in, float32 accumulate
+ * (v_mfma_f32_32x32x2_f32: bitwise an fmaf chain), fixed summation order.  Stored row lengths and leading dimensions
+ * % 4 == 0, 16-byte aligned operands, count <= 6. */
+typedef struct snipper_small_gemm {
+  const float *A; long long lda; int a_transposed;
+  const float *B; long long ldb; int b_transposed;
+  float *out; long long ldo;
+  const float *bias;
+  float *colsum;
+  int I, J, R;
+} snipper_small_gemm;
+int snipper_small_gemm_batch_f32(void *stream, const snipper_small_gemm *problems, int count);
+/* convenience: y[M,N] = x[M,K] . W[N,K]^T + b[N] (b may be NULL) */
+int snipper_small_linear_forward_f32(void *stream, const float *X, long long ldx, const float *W, long long ldw,
+                                     const float *bias, int M, int N, int K, float *Y, long long ldy);
+/* convenience: backward of y = x . W^T + b:  dX[M,K] = G[M,N] . W[N,K], dW[N,K] = G^T . X[M,K], db[N] (each optional) */
 int snipper_small_linear_backward_f32(void *stream, const float *G, long long ldg, const float *X, long long ldx,
                                       const float *W, long long ldw, int M, int N, int K, float *dX, long long lddx,
                                       float *dW, long long lddw, float *db);

@@ -80,6 +80,9 @@ EXPORTS = {
                              ctypes.c_uint64], c_int),
     "snipper_linear_nn_bf16": ([c_void_p, c_void_p, c_longlong, c_void_p, c_longlong, c_void_p, c_longlong, c_void_p,
                                 c_longlong, ctypes.c_float, c_void_p, c_longlong, c_int, c_int, c_int], c_int),
+    "snipper_small_gemm_batch_f32": ([c_void_p, c_void_p, c_int], c_int),
+    "snipper_small_linear_forward_f32": ([c_void_p, c_void_p, c_longlong, c_void_p, c_longlong, c_void_p, c_int, c_int, c_int,
+                                          c_void_p, c_longlong], c_int),
     "snipper_small_linear_backward_f32": ([c_void_p, c_void_p, c_longlong, c_void_p, c_longlong, c_void_p, c_longlong,
                                            c_int, c_int, c_int, c_void_p, c_longlong, c_void_p, c_longlong, c_void_p], c_int),
     "snipper_relu_dropout_backward_bf16": ([c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, ctypes.c_float], c_int),
@@ -166,6 +169,14 @@ def check(code: int, what: str) -> None:
 
 def last_variant() -> str:
     return load().snipper_msda_last_variant().decode()
+
+
+class SmallGemm(ctypes.Structure):
+    """include/snipper_dense.h: snipper_small_gemm (one product of a snipper_small_gemm_batch_f32 launch)."""
+    _fields_ = [("A", c_void_p), ("lda", c_longlong), ("a_transposed", c_int),
+                ("B", c_void_p), ("ldb", c_longlong), ("b_transposed", c_int),
+                ("out", c_void_p), ("ldo", c_longlong), ("bias", c_void_p), ("colsum", c_void_p),
+                ("I", c_int), ("J", c_int), ("R", c_int)]
 
 
 class Config(ctypes.Structure):

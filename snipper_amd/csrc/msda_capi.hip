@@ -459,21 +459,44 @@ int snipper_linear_nn_bf16(void *stream, const uint16_t *X, long long ldx, const
   return launch_status();
 }
 
+int snipper_small_gemm_batch_f32(void *stream, const snipper_small_gemm *problems, int count) {
+  if (!problems) return SNIPPER_E_NULL;
+  if (count <= 0 || count > kSgMaxProblems) return SNIPPER_E_SHAPE;
+  SmallGemmBatch batch{};
+  int tiles = 0;
+  for (int i = 0; i < count; ++i) {
+    const snipper_small_gemm &q = problems[i];
+    if (!q.A || !q.B || (!q.out && !q.colsum)) return SNIPPER_E_NULL;
+    const int a_cols = q.a_transposed ? q.I : q.R, b_cols = q.b_transposed ? q.R : q.J;
+    if (q.I <= 0 || q.J <= 0 || q.R <= 0 || a_cols % 4 || b_cols % 4 || q.lda % 4 || q.ldb % 4 || q.lda < a_cols ||
+        q.ldb < b_cols || (q.out && q.ldo < q.J))
+      return SNIPPER_E_SHAPE;
+    if (((uintptr_t)q.A | (uintptr_t)q.B) & 15) return SNIPPER_E_SHAPE;
+    tiles += ((q.I + kSgTile - 1) / kSgTile) * ((q.J + kSgTile - 1) / kSgTile);
+    batch.p[i] = SmallGemmProblem{q.A, q.lda, q.B, q.ldb, q.out, q.ldo, q.bias, q.colsum, q.I, q.J, q.R,
+                                  q.a_transposed ? 1 : 0, q.b_transposed ? 1 : 0, tiles};
+  }
+  batch.count = count;
+  hipLaunchKernelGGL(small_gemm_batch_f32_kernel, dim3(tiles), dim3(kSgThreads), 0, (hipStream_t)stream, batch);
+  return launch_status();
+}
+
+int snipper_small_linear_forward_f32(void *stream, const float *X, long long ldx, const float *W, long long ldw,
+                                     const float *bias, int M, int N, int K, float *Y, long long ldy) {
+  const snipper_small_gemm q{X, ldx, 0, W, ldw, 1, Y, ldy, bias, nullptr, M, N, K};            // X . W^T + b
+  return snipper_small_gemm_batch_f32(stream, &q, 1);
+}
+
 int snipper_small_linear_backward_f32(void *stream, const float *G, long long ldg, const float *X, long long ldx,
                                       const float *W, long long ldw, int M, int N, int K, float *dX, long long lddx,
                                       float *dW, long long lddw, float *db) {
   if (!G || (dX && !W) || ((dW || db) && !X)) return SNIPPER_E_NULL;
-  if (M <= 0 || N <= 0 || K <= 0 || N % 4 || K % 4 || ldg % 4 || ldg < N || (X && (ldx % 4 || ldx < K)) ||
-      (W && (ldw % 4 || ldw < K)) || (dX && lddx < K) || (dW && lddw < K))
-    return SNIPPER_E_SHAPE;
-  if (((uintptr_t)G | (uintptr_t)X | (uintptr_t)W) & 15) return SNIPPER_E_SHAPE;
-  const int tiles_k = (K + kSlTile - 1) / kSlTile;
-  const int tiles_dx = dX ? ((M + kSlTile - 1) / kSlTile) * tiles_k : 0;
-  const int tiles_dw = (dW || db) ? ((N + kSlTile - 1) / kSlTile) * tiles_k : 0;     // (db comes out of the dW tiles)
-  if (tiles_dx + tiles_dw == 0) return SNIPPER_OK;
-  const SmallLinearBwdArgs a{G, ldg, X, ldx, W, ldw, dX, lddx, dW, lddw, db, M, N, K, tiles_dx};
-  hipLaunchKernelGGL(small_linear_bwd_f32_kernel, dim3(tiles_dx + tiles_dw), dim3(kSlThreads), 0, (hipStream_t)stream, a);
-  return launch_status();
+  snipper_small_gemm q[2];
+  int n = 0;
+  if (dX) q[n++] = snipper_small_gemm{G, ldg, 0, W, ldw, 0, dX, lddx, nullptr, nullptr, M, K, N};          // G . W
+  if (dW || db) q[n++] = snipper_small_gemm{G, ldg, 1, X, ldx, 0, dW, lddw, nullptr, db, N, K, M};          // G^T . X, column sums
+  if (n == 0) return SNIPPER_OK;
+  return snipper_small_gemm_batch_f32(stream, q, n);
 }
 
 int snipper_relu_dropout_backward_bf16(void *stream, const uint16_t *grad_y, const uint16_t *y, uint16_t *grad_pre,

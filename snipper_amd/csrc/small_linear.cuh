@@ -1,97 +1,107 @@
-// small_linear.cuh -- backward of y = x . W^T + b for a few hundred float32 rows, ONE launch (gfx950).
+// small_linear.cuh -- float32 products of decoder size, several per launch (gfx950).
 //
 // The decoder's Linears (reference models/deformable_transformer.py:244-343: self-attention projections, the offset /
-// weight / output projections of the cross attention, the feed-forward block, 60 queries x T frames x batch = a few
-// hundred rows) each need three products in the backward pass
-//     dX[M,K] = G[M,N] . W[N,K]        dW[N,K] = G^T . X[M,K]        db[N] = sum_m G[m,:]
-// which PyTorch issues as three library GEMM launches of ~9 us each (the third one a [1,M] x [M,N] product) -- 36 such
-// triples per training step, all latency-bound.  Here the three are tiles of one grid: workgroup b owns one 32 x 32 tile
-// of dX or of dW; its four waves split the reduction axis (chunks of 32, interleaved), each accumulates the tile with
-// v_mfma_f32_32x32x2_f32 (float32 in, float32 accumulate: bitwise an fmaf chain, so the result is float32-exact like
-// the library's), and the four partial tiles meet in LDS in a fixed order.  db is the column sum of the G chunks that the
-// dW tiles of the first K column stage anyway.  Everything is deterministic.
+// weight / output projections of the cross attention, the feed-forward block; 60 queries x T frames x batch = a few
+// hundred rows) are latency-bound library GEMM launches in PyTorch: ~9 us of GPU time and 21-27 us of host time each,
+// and a Linear's backward needs three of them (dX = G . W, dW = G^T . X, db = column sums of G, the last one issued as
+// a [1, M] x [M, N] product).  Here a launch takes a LIST of up to kSgMaxProblems products
+//     out[I, J] = opA(A)[I, R] . opB(B)[R, J] (+ bias[J]),      optionally  colsum[I] = sum_r opA(A)[i, r]
+// with each operand read as stored or transposed (flags), so that one launch is a Linear's whole backward (dX, dW + db),
+// a packed q|k / v projection pair, or that pair's backward (two dX, two dW written into the row blocks of the packed
+// gradient, two db) -- no concatenations, no transposed copies.
+// Workgroup b owns one 32 x 32 tile of one product; its four waves split the reduction axis (chunks of 32, interleaved),
+// each accumulates the tile with v_mfma_f32_32x32x2_f32 (float32 in, float32 accumulate: bitwise an fmaf chain, so the
+// result is float32-exact like the library's), and the four partial tiles meet in LDS in a fixed order: deterministic.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 namespace snipper {
 
-typedef __attribute__((ext_vector_type(16))) float sl_f32x16;
+typedef __attribute__((ext_vector_type(16))) float sg_f32x16;
 
-struct SmallLinearBwdArgs {
-  const float *G; long long ldg;     // [M][N]   dL/dy
-  const float *X; long long ldx;     // [M][K]   the layer's input
-  const float *W; long long ldw;     // [N][K]   the weight
-  float *dX; long long lddx;         // [M][K] or nullptr
-  float *dW; long long lddw;         // [N][K] or nullptr
-  float *db;                         // [N] or nullptr
-  int M, N, K;
-  int tiles_dx;                      // workgroups [0, tiles_dx): dX tiles; the rest: dW tiles
+constexpr int kSgMaxProblems = 6;
+struct SmallGemmProblem {
+  const float *A; long long lda;     // a_tr == 0: [I][R]   a_tr == 1: [R][I]
+  const float *B; long long ldb;     // b_tr == 0: [R][J]   b_tr == 1: [J][R]
+  float *out; long long ldo;         // [I][J] or nullptr
+  const float *bias;                 // [J] added to every row, or nullptr
+  float *colsum;                     // [I] = sum over r of opA(A)[i][r], or nullptr (needs a_tr == 1 or 0 alike)
+  int I, J, R, a_tr, b_tr;
+  int tile_end;                      // workgroups [previous tile_end, tile_end) belong to this product
+};
+struct SmallGemmBatch {
+  SmallGemmProblem p[kSgMaxProblems];
+  int count;
 };
 
-constexpr int kSlTile = 32, kSlStride = 33, kSlThreads = 256;
+constexpr int kSgTile = 32, kSgStride = 33, kSgThreads = 256;
 
-// a 32 x 32 float32 tile, rows r0.., columns c0.. of a row-major matrix with `rows` x `cols` valid elements -> LDS
-// [32][33] (zeros outside); 64 lanes x 4 float4
-__device__ __forceinline__ void sl_load_tile(const float *__restrict__ A, long long ld, int rows, int cols, int r0, int c0,
+// a 32 x 32 float32 tile, rows r0.., columns c0.. of a row-major matrix with `rows` x `cols` valid elements (zeros
+// outside; cols % 4 == 0 and 16-byte aligned rows): 64 lanes x 4 float4
+__device__ __forceinline__ void sg_load_tile(const float *__restrict__ A, long long ld, int rows, int cols, int r0, int c0,
                                              float4 (&v)[4], int lane) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int r = r0 + (lane >> 3) + 8 * i, c = c0 + (lane & 7) * 4;
     v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (r < rows && c < cols) v[i] = *reinterpret_cast<const float4 *>(A + (long long)r * ld + c);     // (cols % 4 == 0)
+    if (r < rows && c < cols) v[i] = *reinterpret_cast<const float4 *>(A + (long long)r * ld + c);
   }
 }
-__device__ __forceinline__ void sl_store_tile(float *T, const float4 (&v)[4], int lane) {
+__device__ __forceinline__ void sg_store_tile(float *T, const float4 (&v)[4], int lane) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    float *p = T + ((lane >> 3) + 8 * i) * kSlStride + (lane & 7) * 4;
+    float *p = T + ((lane >> 3) + 8 * i) * kSgStride + (lane & 7) * 4;
     p[0] = v[i].x; p[1] = v[i].y; p[2] = v[i].z; p[3] = v[i].w;
   }
 }
 
-__global__ __launch_bounds__(kSlThreads) void small_linear_bwd_f32_kernel(SmallLinearBwdArgs g) {
-  __shared__ float At[4][kSlTile * kSlStride], Bt[4][kSlTile * kSlStride];      // per wave: its chunk's operand tiles
-  __shared__ float bsum[4][kSlTile];
+__global__ __launch_bounds__(kSgThreads) void small_gemm_batch_f32_kernel(SmallGemmBatch batch) {
+  __shared__ float At[4][kSgTile * kSgStride], Bt[4][kSgTile * kSgStride];      // per wave: its chunk's operand tiles
+  __shared__ float csum[4][kSgTile];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const bool is_dx = (int)blockIdx.x < g.tiles_dx;
-  const int tiles_k = (g.K + kSlTile - 1) / kSlTile;
-  const int t = is_dx ? (int)blockIdx.x : (int)blockIdx.x - g.tiles_dx;
-  const int tr = t / tiles_k, tk = t - tr * tiles_k;          // tile row (m for dX, n for dW), tile column (k)
-  const int r0 = tr * kSlTile, c0 = tk * kSlTile;
-  const int R = is_dx ? g.N : g.M;                            // reduction length
-  const int nchunk = (R + kSlTile - 1) / kSlTile, per_wave = (nchunk + 3) / 4;
-  const bool do_bias = !is_dx && g.db != nullptr && tk == 0;
+  // which product (a select chain: a run-time index into the kernel argument would copy it to scratch)
+  SmallGemmProblem g = batch.p[0];
+  int first = 0;
+#pragma unroll
+  for (int i = 1; i < kSgMaxProblems; ++i) {
+    if (i < batch.count && (int)blockIdx.x >= batch.p[i - 1].tile_end) { g = batch.p[i]; first = batch.p[i - 1].tile_end; }
+  }
+  const int tiles_j = (g.J + kSgTile - 1) / kSgTile;
+  const int t = (int)blockIdx.x - first;
+  const int ti = t / tiles_j, tj = t - ti * tiles_j;
+  const int r0 = ti * kSgTile, c0 = tj * kSgTile;
+  const int nchunk = (g.R + kSgTile - 1) / kSgTile, per_wave = (nchunk + 3) / 4;
+  const bool do_sum = g.colsum != nullptr && tj == 0;
+  const bool a_tr = g.a_tr != 0, b_tr = g.b_tr != 0;
 
-  sl_f32x16 acc;
+  sg_f32x16 acc;
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-  float bias_part = 0.f;
+  float sum_part = 0.f;
   float *A = At[wave], *B = Bt[wave];
   const int li = lane & 31, lk = lane >> 5;
   for (int it = 0; it < per_wave; ++it) {
-    const int q0 = (it * 4 + wave) * kSlTile;                 // this wave's chunk of the reduction axis (may lie past R: zeros)
+    const int q0 = (it * 4 + wave) * kSgTile;         // this wave's chunk of the reduction axis (past R: zeros)
     float4 va[4], vb[4];
-    if (is_dx) {
-      sl_load_tile(g.G, g.ldg, g.M, g.N, r0, q0, va, lane);    // A[i = m][k = n]: rows of G
-      sl_load_tile(g.W, g.ldw, g.N, g.K, q0, c0, vb, lane);    // B[k = n][j = kc]: rows of W
-    } else {
-      sl_load_tile(g.G, g.ldg, g.M, g.N, q0, r0, va, lane);    // stored [m][n]; read as A[i = n][k = m]
-      sl_load_tile(g.X, g.ldx, g.M, g.K, q0, c0, vb, lane);    // B[k = m][j = kc]: rows of X
-    }
-    __syncthreads();                                           // the previous chunk's reads are done
-    sl_store_tile(A, va, lane);
-    sl_store_tile(B, vb, lane);
+    if (a_tr) sg_load_tile(g.A, g.lda, g.R, g.I, q0, r0, va, lane);      // stored [r][i]
+    else sg_load_tile(g.A, g.lda, g.I, g.R, r0, q0, va, lane);           // stored [i][r]
+    if (b_tr) sg_load_tile(g.B, g.ldb, g.J, g.R, c0, q0, vb, lane);      // stored [j][r]
+    else sg_load_tile(g.B, g.ldb, g.R, g.J, q0, c0, vb, lane);           // stored [r][j]
+    __syncthreads();                                                      // the previous chunk's reads are done
+    sg_store_tile(A, va, lane);
+    sg_store_tile(B, vb, lane);
     __syncthreads();
+    // MFMA operands: lane l holds A[i = l & 31][k = l >> 5] and B[k = l >> 5][j = l & 31] of each 2-step
 #pragma unroll
-    for (int kk = 0; kk < kSlTile; kk += 2) {
-      const float a = is_dx ? A[li * kSlStride + kk + lk] : A[(kk + lk) * kSlStride + li];
-      const float b = B[(kk + lk) * kSlStride + li];
+    for (int kk = 0; kk < kSgTile; kk += 2) {
+      const float a = a_tr ? A[(kk + lk) * kSgStride + li] : A[li * kSgStride + kk + lk];
+      const float b = b_tr ? B[li * kSgStride + kk + lk] : B[(kk + lk) * kSgStride + li];
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
     }
-    if (do_bias && lane < kSlTile) {
+    if (do_sum && lane < kSgTile) {
 #pragma unroll 8
-      for (int m = 0; m < kSlTile; ++m) bias_part += A[m * kSlStride + lane];
+      for (int q = 0; q < kSgTile; ++q) sum_part += a_tr ? A[q * kSgStride + lane] : A[lane * kSgStride + q];
     }
   }
   __syncthreads();
@@ -101,24 +111,24 @@ __global__ __launch_bounds__(kSlThreads) void small_linear_bwd_f32_kernel(SmallL
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int row = (r & 3) + 8 * (r >> 2) + 4 * lk;
-    P[wave * kSlTile * kSlStride + row * kSlStride + li] = acc[r];
+    P[wave * kSgTile * kSgStride + row * kSgStride + li] = acc[r];
   }
-  if (do_bias && lane < kSlTile) bsum[wave][lane] = bias_part;
+  if (do_sum && lane < kSgTile) csum[wave][lane] = sum_part;
   __syncthreads();
-  float *out = is_dx ? g.dX : g.dW;
-  const long long ldo = is_dx ? g.lddx : g.lddw;
-  const int rows_out = is_dx ? g.M : g.N;
-  if (out) {
+  if (g.out) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int e = tid + kSlThreads * i, row = e >> 5, col = e & 31;
-      const int o = row * kSlStride + col;
-      const float s = (P[o] + P[kSlTile * kSlStride + o]) + (P[2 * kSlTile * kSlStride + o] + P[3 * kSlTile * kSlStride + o]);
-      if (r0 + row < rows_out && c0 + col < g.K) out[(long long)(r0 + row) * ldo + c0 + col] = s;
+      const int e = tid + kSgThreads * i, row = e >> 5, col = e & 31;
+      const int o = row * kSgStride + col;
+      float s = (P[o] + P[kSgTile * kSgStride + o]) + (P[2 * kSgTile * kSgStride + o] + P[3 * kSgTile * kSgStride + o]);
+      if (r0 + row < g.I && c0 + col < g.J) {
+        if (g.bias) s += g.bias[c0 + col];
+        g.out[(long long)(r0 + row) * g.ldo + c0 + col] = s;
+      }
     }
   }
-  if (do_bias && tid < kSlTile && r0 + tid < g.N)
-    g.db[r0 + tid] = (bsum[0][tid] + bsum[1][tid]) + (bsum[2][tid] + bsum[3][tid]);
+  if (do_sum && tid < kSgTile && r0 + tid < g.I)
+    g.colsum[r0 + tid] = (csum[0][tid] + csum[1][tid]) + (csum[2][tid] + csum[3][tid]);
 }
 
 }  // namespace snipper

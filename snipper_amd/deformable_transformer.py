@@ -111,8 +111,17 @@ class _QKVProj(torch.autograd.Function):
         E = x_qk.shape[-1]
         a, b = x_qk.reshape(-1, E), x_v.reshape(-1, E)
         ctx.save_for_backward(a, b, weight)
-        qk = torch.addmm(bias[:2 * E], a, weight[:2 * E].t())
-        v = torch.addmm(bias[2 * E:], b, weight[2 * E:].t())
+        from .dense import _sg_dense, _sg_ok, small_gemm_batch
+        a2, b2 = _sg_dense(a), _sg_dense(b)
+        if _sg_ok(a2, b2, weight) and bias.dtype == torch.float32 and bias.is_contiguous() and a2.shape[0] <= 8192:
+            # both projections in one launch of the small-GEMM kernel (csrc/small_linear.cuh)
+            qk = torch.empty((a2.shape[0], 2 * E), dtype=torch.float32, device=a.device)
+            v = torch.empty((b2.shape[0], E), dtype=torch.float32, device=a.device)
+            small_gemm_batch([(a2, False, weight[:2 * E], True, qk, bias[:2 * E], None),
+                              (b2, False, weight[2 * E:], True, v, bias[2 * E:], None)])
+        else:
+            qk = torch.addmm(bias[:2 * E], a, weight[:2 * E].t())
+            v = torch.addmm(bias[2 * E:], b, weight[2 * E:].t())
         return qk.view(*x_qk.shape[:-1], 2 * E), v.view(*x_v.shape[:-1], E)
 
     @staticmethod
@@ -121,6 +130,16 @@ class _QKVProj(torch.autograd.Function):
         a, b, weight = ctx.saved_tensors
         E = a.shape[1]
         gqk2, gv2 = gqk.reshape(-1, 2 * E), gv.reshape(-1, E)
+        from .dense import small_gemm_batch, small_linear_backward
+        if gqk2.is_cuda and all(ctx.needs_input_grad):
+            # the whole backward in one launch: two data gradients, the two row blocks of the packed dW and of db
+            dW = torch.empty_like(weight)
+            db = torch.empty((3 * E,), dtype=weight.dtype, device=weight.device)
+            r1 = small_linear_backward(gqk2, a, weight[:2 * E], dw_out=dW[:2 * E], db_out=db[:2 * E], launch=False)
+            r2 = small_linear_backward(gv2, b, weight[2 * E:], dw_out=dW[2 * E:], db_out=db[2 * E:], launch=False)
+            if r1 is not None and r2 is not None:
+                small_gemm_batch(r1[3] + r2[3])
+                return r1[0].view(*gqk.shape[:-1], E), r2[0].view(*gv.shape[:-1], E), dW, db
         dxa = torch.mm(gqk2, weight[:2 * E]).view(*gqk.shape[:-1], E) if ctx.needs_input_grad[0] else None
         dxb = torch.mm(gv2, weight[2 * E:]).view(*gv.shape[:-1], E) if ctx.needs_input_grad[1] else None
         dW = db = None

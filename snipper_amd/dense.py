@@ -353,7 +353,10 @@ class _SmallLinear(torch.autograd.Function):
         x2 = x.reshape(-1, x.shape[-1])
         ctx.save_for_backward(x2, weight)
         ctx.x_shape = x.shape
-        return torch.addmm(bias, x2, weight.t()).view(*x.shape[:-1], weight.shape[0])
+        y = small_linear_forward(x2, weight, bias)
+        if y is None:
+            y = torch.addmm(bias, x2, weight.t())
+        return y.view(*x.shape[:-1], weight.shape[0])
 
     @staticmethod
     def backward(ctx, gy):
@@ -372,29 +375,92 @@ class _SmallLinear(torch.autograd.Function):
         return dx, dW, db
 
 
-def small_linear_backward(g: torch.Tensor, x: torch.Tensor, w: torch.Tensor, need_dx=True, need_dw=True, need_db=True):
+def _sg_ok(*ts) -> bool:
+    """float32 CUDA matrices the small-GEMM kernel can read in place (unit inner stride, rows a multiple of 16 bytes)."""
+    return all(t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and t.stride(1) == 1 and t.stride(0) % 4 == 0 and
+               t.shape[1] % 4 == 0 and t.data_ptr() % 16 == 0 for t in ts)
+
+
+def small_gemm_batch(problems) -> None:
+    """One launch of csrc/small_linear.cuh for a list of float32 products (<= 6).  Each problem is a tuple
+    ``(A, a_transposed, B, b_transposed, out, bias, colsum)``:  out[I, J] = opA(A) . opB(B) (+ bias), colsum[I] =
+    row sums of opA(A); ``out`` (2-D, unit inner stride: may be a row block of a larger matrix), ``bias`` and ``colsum``
+    may be None (not both out and colsum).  Operands must satisfy ``_sg_ok``."""
+    from ._lib import SmallGemm
+    n = len(problems)
+    arr = (SmallGemm * n)()
+    dev = None
+    for q, (A, a_tr, B, b_tr, out, bias, colsum) in zip(arr, problems):
+        dev = A.device
+        I, R = (A.shape[1], A.shape[0]) if a_tr else (A.shape[0], A.shape[1])
+        J = B.shape[0] if b_tr else B.shape[1]
+        assert (B.shape[1] if b_tr else B.shape[0]) == R
+        if out is not None:
+            assert out.dtype == torch.float32 and out.shape == (I, J) and out.stride(1) == 1
+        q.A, q.lda, q.a_transposed = A.data_ptr(), A.stride(0), int(bool(a_tr))
+        q.B, q.ldb, q.b_transposed = B.data_ptr(), B.stride(0), int(bool(b_tr))
+        q.out, q.ldo = (out.data_ptr(), out.stride(0)) if out is not None else (None, 0)
+        q.bias = bias.data_ptr() if bias is not None else None
+        q.colsum = colsum.data_ptr() if colsum is not None else None
+        q.I, q.J, q.R = I, J, R
+    with _lib.device_guard(dev):
+        rc = _lib.load().snipper_small_gemm_batch_f32(_lib.raw_stream(dev), arr, n)
+    _lib.check(rc, "snipper_small_gemm_batch_f32")
+
+
+def _sg_dense(t: torch.Tensor) -> torch.Tensor:
+    return t if (t.stride(1) == 1 and t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0) else t.contiguous()
+
+
+def small_linear_forward(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor]):
+    """x [M, K] @ w [N, K]^T + b in one launch of the small-GEMM kernel, or None when it does not apply."""
+    if not (x.is_cuda and x.dtype == torch.float32 and w.dtype == torch.float32 and x.dim() == 2 and
+            x.shape[1] % 4 == 0 and x.shape[0] <= 8192 and (b is None or (b.dtype == torch.float32 and b.is_contiguous()))):
+        return None
+    x, w = _sg_dense(x), _sg_dense(w)
+    if not _sg_ok(x, w):
+        return None
+    y = torch.empty((x.shape[0], w.shape[0]), dtype=torch.float32, device=x.device)
+    with _lib.device_guard(x.device):
+        rc = _lib.load().snipper_small_linear_forward_f32(
+            _lib.raw_stream(x.device), x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0),
+            b.data_ptr() if b is not None else None, x.shape[0], w.shape[0], x.shape[1], y.data_ptr(), y.stride(0))
+    _lib.check(rc, "snipper_small_linear_forward_f32")
+    return y
+
+
+def small_linear_backward(g: torch.Tensor, x: torch.Tensor, w: torch.Tensor, need_dx=True, need_dw=True, need_db=True,
+                          dw_out: Optional[torch.Tensor] = None, db_out: Optional[torch.Tensor] = None, launch=True):
     """(dX, dW, db) of ``y = x @ w.T + b`` from g = dL/dy in ONE launch (csrc/small_linear.cuh; float32, deterministic),
-    or None when the shapes are outside the kernel's requirements (the caller then takes the three library GEMMs)."""
+    or None when the shapes are outside the kernel's requirements (the caller then takes the three library GEMMs).
+    ``dw_out`` / ``db_out``: where to write dW / db (e.g. a row block of a packed gradient).  ``launch=False`` returns
+    ``(dX, dW, db, problems)`` without launching, for batching several layers into one launch."""
     M, N = g.shape
     K = x.shape[1]
     if not (g.is_cuda and g.dtype == torch.float32 and x.dtype == torch.float32 and w.dtype == torch.float32 and
             N % 4 == 0 and K % 4 == 0 and M <= 8192 and w.shape == (N, K) and x.shape[0] == M):
         return None
-    if g.stride(1) != 1 or g.stride(0) % 4 or g.data_ptr() % 16:
-        g = g.contiguous()
-    if x.stride(1) != 1 or x.stride(0) % 4 or x.data_ptr() % 16:
-        x = x.contiguous()
-    if w.stride(1) != 1 or w.stride(0) % 4 or w.data_ptr() % 16:
-        w = w.contiguous()
+    g, x, w = _sg_dense(g), _sg_dense(x), _sg_dense(w)
+    if not _sg_ok(g, x, w):
+        return None
     dx = torch.empty((M, K), dtype=torch.float32, device=g.device) if need_dx else None
-    dw = torch.empty((N, K), dtype=torch.float32, device=g.device) if need_dw else None
-    db = torch.empty((N,), dtype=torch.float32, device=g.device) if need_db else None
-    with _lib.device_guard(g.device):
-        rc = _lib.load().snipper_small_linear_backward_f32(
-            _lib.raw_stream(g.device), g.data_ptr(), g.stride(0), x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0),
-            M, N, K, dx.data_ptr() if dx is not None else None, K, dw.data_ptr() if dw is not None else None, K,
-            db.data_ptr() if db is not None else None)
-    _lib.check(rc, "snipper_small_linear_backward_f32")
+    dw = (dw_out if dw_out is not None else torch.empty((N, K), dtype=torch.float32, device=g.device)) if need_dw else None
+    db = (db_out if db_out is not None else torch.empty((N,), dtype=torch.float32, device=g.device)) if need_db else None
+    problems = []
+    if need_dx:
+        problems.append((g, False, w, False, dx, None, None))                  # G . W
+    if need_dw or need_db:
+        problems.append((g, True, x, False, dw, None, db))                     # G^T . X, column sums of G
+    if not launch:
+        return dx, dw, db, problems
+    if problems:                       # (plain-argument entry point: cheaper on the host than building the problem list)
+        with _lib.device_guard(g.device):
+            rc = _lib.load().snipper_small_linear_backward_f32(
+                _lib.raw_stream(g.device), g.data_ptr(), g.stride(0), x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0),
+                M, N, K, dx.data_ptr() if dx is not None else None, K,
+                dw.data_ptr() if dw is not None else None, dw.stride(0) if dw is not None else K,
+                db.data_ptr() if db is not None else None)
+        _lib.check(rc, "snipper_small_linear_backward_f32")
     return dx, dw, db
 
 
