@@ -46,6 +46,26 @@ int snipper_linear_nn_bf16(void *stream, const uint16_t *X, long long ldx, const
 /* Backward of the (ReLU -> dropout) epilogue above from the layer's OUTPUT alone: a kept, active element has y > 0,
  * a dropped or inactive one y == 0, so grad_pre = y > 0 ? grad_y / (1 - p) : 0 (p = 0: plain ReLU backward).
  * bf16 bits, n % 8 == 0, 16-byte aligned. */
+/* The decoder's dense self-attention (reference models/deformable_transformer.py:282-287: nn.MultiheadAttention over the
+ * nq * T object queries of a sample) for L <= 256 queries and heads of 48 or 32 channels, one launch each way:
+ *   out[b,i,h,:] = sum_j dropout(softmax_j(scale * q[b,i,h,:] . k[b,j,h,:]))[j] * v[b,j,h,:]
+ * Element (b, i, h, e) of q / k / v / out / their gradients is at base + b * X_bs + i * X_ld + h * hd + e (so q and k
+ * may be the two halves of a packed projection output and the gradients may be written into the halves of its
+ * gradient).  P [bs,H,L,L] receives the probabilities before dropout (the backward reads it and the saved `out`).
+ * Dropout: counter-based hash of (seed, element index); the backward must be given the forward's seed.  float32
+ * throughout; leading dimensions % 4 == 0, 16-byte aligned pointers. */
+int snipper_small_attention_forward_f32(void *stream, const float *q, long long q_ld, long long q_bs, const float *k,
+                                        long long k_ld, long long k_bs, const float *v, long long v_ld, long long v_bs,
+                                        float *out, long long o_ld, long long o_bs, float *P, int bs, int H, int L, int hd,
+                                        float scale, float dropout_p, uint64_t seed);
+int snipper_small_attention_backward_f32(void *stream, const float *q, long long q_ld, long long q_bs, const float *k,
+                                         long long k_ld, long long k_bs, const float *v, long long v_ld, long long v_bs,
+                                         const float *out, long long o_ld, long long o_bs, const float *P,
+                                         const float *dout, long long do_ld, long long do_bs, float *dq, long long dq_ld,
+                                         long long dq_bs, float *dk, long long dk_ld, long long dk_bs, float *dv,
+                                         long long dv_ld, long long dv_bs, int bs, int H, int L, int hd, float scale,
+                                         float dropout_p, uint64_t seed);
+
 /* Float32 products of decoder size (a few hundred rows: the Linears of reference models/deformable_transformer.py:244-343),
  * SEVERAL PER LAUNCH:  out[I,J] = opA(A)[I,R] . opB(B)[R,J] (+ bias[J]),  optionally colsum[I] = sum_r opA(A)[i,r].
  * A is stored [I][R] (a_transposed = 0) or [R][I] (1); B is stored [R][J] (0) or [J][R] (1); out / colsum may be NULL

@@ -80,6 +80,11 @@ EXPORTS = {
                              ctypes.c_uint64], c_int),
     "snipper_linear_nn_bf16": ([c_void_p, c_void_p, c_longlong, c_void_p, c_longlong, c_void_p, c_longlong, c_void_p,
                                 c_longlong, ctypes.c_float, c_void_p, c_longlong, c_int, c_int, c_int], c_int),
+    "snipper_small_attention_forward_f32": ([c_void_p] + [c_void_p, c_longlong, c_longlong] * 4 + [c_void_p] + [c_int] * 4 +
+                                             [ctypes.c_float, ctypes.c_float, ctypes.c_uint64], c_int),
+    "snipper_small_attention_backward_f32": ([c_void_p] + [c_void_p, c_longlong, c_longlong] * 4 + [c_void_p] +
+                                              [c_void_p, c_longlong, c_longlong] * 4 + [c_int] * 4 +
+                                              [ctypes.c_float, ctypes.c_float, ctypes.c_uint64], c_int),
     "snipper_small_gemm_batch_f32": ([c_void_p, c_void_p, c_int], c_int),
     "snipper_small_linear_forward_f32": ([c_void_p, c_void_p, c_longlong, c_void_p, c_longlong, c_void_p, c_int, c_int, c_int,
                                           c_void_p, c_longlong], c_int),

@@ -16,6 +16,7 @@
 #include "gemm_bf16.cuh"
 #include "wgrad_bf16.cuh"
 #include "small_linear.cuh"
+#include "small_attention.cuh"
 #include "match_cost.cuh"
 #include "ln_fused.cuh"
 #include "gn_tokens.cuh"
@@ -456,6 +457,56 @@ int snipper_linear_nn_bf16(void *stream, const uint16_t *X, long long ldx, const
   const GemmNNArgs g{X, ldx, W, ldw, Y, ldy, M, N, K, R, ldr, A, lda, gate_scale};
   const dim3 grid(gemm_grid_size(M, N));
   hipLaunchKernelGGL(linear_bf16_nn_kernel, grid, dim3(kGemmThreads), 0, (hipStream_t)stream, g);
+  return launch_status();
+}
+
+namespace {
+int small_attn_check(const void *q, long long q_ld, const void *k, long long k_ld, const void *v, long long v_ld,
+                     const void *o, long long o_ld, const void *P, int bs, int H, int L, int hd, float p) {
+  if (!q || !k || !v || !o || !P) return SNIPPER_E_NULL;
+  if (bs <= 0 || H <= 0 || L <= 0 || L > kSaMaxL || (hd != 48 && hd != 32) || (q_ld | k_ld | v_ld | o_ld) % 4 ||
+      !(p >= 0.f && p < 1.f) || (long long)bs * H * L * L >= (1LL << 32))
+    return SNIPPER_E_SHAPE;
+  if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o) & 15) return SNIPPER_E_SHAPE;
+  return SNIPPER_OK;
+}
+}  // namespace
+
+int snipper_small_attention_forward_f32(void *stream, const float *q, long long q_ld, long long q_bs, const float *k,
+                                        long long k_ld, long long k_bs, const float *v, long long v_ld, long long v_bs,
+                                        float *out, long long o_ld, long long o_bs, float *P, int bs, int H, int L, int hd,
+                                        float scale, float dropout_p, uint64_t seed) {
+  if (int rc = small_attn_check(q, q_ld, k, k_ld, v, v_ld, out, o_ld, P, bs, H, L, hd, dropout_p)) return rc;
+  SmallAttnArgs a{};
+  a.q = q; a.q_ld = q_ld; a.q_bs = q_bs; a.k = k; a.k_ld = k_ld; a.k_bs = k_bs; a.v = v; a.v_ld = v_ld; a.v_bs = v_bs;
+  a.out = out; a.o_ld = o_ld; a.o_bs = o_bs; a.P = P; a.bs = bs; a.H = H; a.L = L; a.scale = scale; a.drop_p = dropout_p;
+  a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32);
+  const dim3 grid((unsigned)(bs * H * ((L + kSaRows - 1) / kSaRows)));
+  if (hd == 48) hipLaunchKernelGGL(small_attn_fwd_kernel<48>, grid, dim3(kSaThreads), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(small_attn_fwd_kernel<32>, grid, dim3(kSaThreads), 0, (hipStream_t)stream, a);
+  return launch_status();
+}
+
+int snipper_small_attention_backward_f32(void *stream, const float *q, long long q_ld, long long q_bs, const float *k,
+                                         long long k_ld, long long k_bs, const float *v, long long v_ld, long long v_bs,
+                                         const float *out, long long o_ld, long long o_bs, const float *P,
+                                         const float *dout, long long do_ld, long long do_bs, float *dq, long long dq_ld,
+                                         long long dq_bs, float *dk, long long dk_ld, long long dk_bs, float *dv,
+                                         long long dv_ld, long long dv_bs, int bs, int H, int L, int hd, float scale,
+                                         float dropout_p, uint64_t seed) {
+  if (int rc = small_attn_check(q, q_ld, k, k_ld, v, v_ld, out, o_ld, P, bs, H, L, hd, dropout_p)) return rc;
+  if (!dout || !dq || !dk || !dv) return SNIPPER_E_NULL;
+  if (do_ld % 4 || ((uintptr_t)dout & 15)) return SNIPPER_E_SHAPE;
+  SmallAttnArgs a{};
+  a.q = q; a.q_ld = q_ld; a.q_bs = q_bs; a.k = k; a.k_ld = k_ld; a.k_bs = k_bs; a.v = v; a.v_ld = v_ld; a.v_bs = v_bs;
+  a.out = const_cast<float *>(out); a.o_ld = o_ld; a.o_bs = o_bs; a.P = const_cast<float *>(P);
+  a.dout = dout; a.do_ld = do_ld; a.do_bs = do_bs; a.dq = dq; a.dq_ld = dq_ld; a.dq_bs = dq_bs;
+  a.dk = dk; a.dk_ld = dk_ld; a.dk_bs = dk_bs; a.dv = dv; a.dv_ld = dv_ld; a.dv_bs = dv_bs;
+  a.bs = bs; a.H = H; a.L = L; a.scale = scale; a.drop_p = dropout_p;
+  a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32);
+  const dim3 grid((unsigned)(bs * H * 2 * ((L + kSaRows - 1) / kSaRows)));
+  if (hd == 48) hipLaunchKernelGGL(small_attn_bwd_kernel<48>, grid, dim3(kSaThreads), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(small_attn_bwd_kernel<32>, grid, dim3(kSaThreads), 0, (hipStream_t)stream, a);
   return launch_status();
 }
 

@@ -151,6 +151,56 @@ class _QKVProj(torch.autograd.Function):
         return dxa, dxb, dW, db
 
 
+class _SmallAttention(torch.autograd.Function):
+    """softmax(q k^T / sqrt(hd)) with dropout, times v, for the decoder's few hundred queries: one launch forward, one
+    backward (csrc/small_attention.cuh).  ``qk`` [bs, L, 2E] is the packed q | k projection output, read in place; its
+    gradient comes back as one [bs, L, 2E] tensor (no concatenation)."""
+
+    @staticmethod
+    def forward(ctx, qk, v, H, p):
+        from . import _lib
+        bs, L, E2 = qk.shape
+        E = E2 // 2
+        hd = E // H
+        out = torch.empty((bs, L, E), dtype=torch.float32, device=qk.device)
+        P = torch.empty((bs, H, L, L), dtype=torch.float32, device=qk.device)
+        seed = 0
+        if p > 0.0:
+            from .fused import _next_seed
+            seed = _next_seed()
+        scale = hd ** -0.5
+        with _lib.device_guard(qk.device):
+            rc = _lib.load().snipper_small_attention_forward_f32(
+                _lib.raw_stream(qk.device), qk.data_ptr(), E2, L * E2, qk.data_ptr() + 4 * E, E2, L * E2,
+                v.data_ptr(), E, L * E, out.data_ptr(), E, L * E, P.data_ptr(), bs, H, L, hd, scale, float(p), seed)
+        _lib.check(rc, "snipper_small_attention_forward_f32")
+        ctx.save_for_backward(qk, v, out, P)
+        ctx.cfg = (H, float(p), seed, scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        from . import _lib
+        qk, v, out, P = ctx.saved_tensors
+        H, p, seed, scale = ctx.cfg
+        bs, L, E2 = qk.shape
+        E = E2 // 2
+        g = gout.contiguous()
+        dqk = torch.empty_like(qk)
+        dv = torch.empty_like(v)
+        with _lib.device_guard(qk.device):
+            rc = _lib.load().snipper_small_attention_backward_f32(
+                _lib.raw_stream(qk.device), qk.data_ptr(), E2, L * E2, qk.data_ptr() + 4 * E, E2, L * E2,
+                v.data_ptr(), E, L * E, out.data_ptr(), E, L * E, P.data_ptr(), g.data_ptr(), E, L * E,
+                dqk.data_ptr(), E2, L * E2, dqk.data_ptr() + 4 * E, E2, L * E2, dv.data_ptr(), E, L * E,
+                bs, H, L, E // H, scale, p, seed)
+        _lib.check(rc, "snipper_small_attention_backward_f32")
+        return dqk, dv, None, None
+
+
+SMALL_ATTENTION_MAX_L = 256       # csrc/small_attention.cuh: kSaMaxL
+
+
 def _self_attention(mha: nn.MultiheadAttention, x_qk, x_v):
     """``mha(x_qk^T, x_qk^T, x_v^T, need_weights=False)[0]^T`` for batch-first inputs [bs, L, E] -- the decoder's dense
     self-attention (reference models/deformable_transformer.py:282-287) without the module's layout round trips: it
@@ -167,6 +217,9 @@ def _self_attention(mha: nn.MultiheadAttention, x_qk, x_v):
     bs, L, _ = x_qk.shape
     H = mha.num_heads
     qk, v = _QKVProj.apply(x_qk, x_v, mha.in_proj_weight, mha.in_proj_bias)
+    if L <= SMALL_ATTENTION_MAX_L and E // H in (32, 48) and qk.is_contiguous() and v.is_contiguous():
+        att = _SmallAttention.apply(qk, v, H, mha.dropout if mha.training else 0.0)
+        return _SmallLinear.apply(att, mha.out_proj.weight, mha.out_proj.bias)
     q = qk[..., :E].view(bs, L, H, E // H).transpose(1, 2)               # [bs, H, L, hd] views
     k = qk[..., E:].view(bs, L, H, E // H).transpose(1, 2)
     vh = v.view(bs, L, H, E // H).transpose(1, 2)

@@ -395,3 +395,45 @@ def test_inference_style_padded_snippets_at_540x960():
     torch.testing.assert_close(inter_h, inter_r, rtol=2e-3, atol=2e-4)
     for a, b in zip(out_h["heatmaps"], out_r["heatmaps"]):
         torch.testing.assert_close(a, b, rtol=2e-3, atol=5e-4)
+
+
+@pytest.mark.parametrize("L,E,H,p", [(240, 384, 8, 0.1), (60, 384, 8, 0.0), (37, 256, 8, 0.25), (256, 384, 8, 0.1)])
+def test_small_attention_kernel_with_dropout_against_composition(L, E, H, p, monkeypatch):
+    """csrc/small_attention.cuh: forward and the one-launch backward against softmax(q k^T / sqrt(hd)) . v written out in
+    PyTorch WITH THE KERNEL'S OWN dropout mask.  The mask is recovered by linearity: for a fixed seed the output is
+    Pd . V, so probing with one-hot V blocks returns the dropped probabilities themselves."""
+    import snipper_amd.fused as fused
+    from snipper_amd.deformable_transformer import _SmallAttention
+    monkeypatch.setattr(fused, "_next_seed", lambda: 0x1234567 + L)
+    g = torch.Generator().manual_seed(L + H)
+    bs, hd = 2, E // H
+    qk = torch.randn(bs, L, 2 * E, generator=g).to(DEV).requires_grad_(True)
+    v = torch.randn(bs, L, E, generator=g).to(DEV).requires_grad_(True)
+    gy = torch.randn(bs, L, E, generator=g).to(DEV)
+    out = _SmallAttention.apply(qk, v, H, p)
+    # dropped probabilities by probing: V_probe[b, j, h*hd + e] = 1 if j == c * hd + e
+    Pd = torch.zeros(bs, H, L, L, device=DEV)
+    with torch.no_grad():
+        for c in range((L + hd - 1) // hd):
+            probe = torch.zeros(bs, L, H, hd, device=DEV)
+            n = min(hd, L - c * hd)
+            idx = torch.arange(n, device=DEV)
+            probe[:, c * hd + idx, :, idx] = 1.0
+            o = _SmallAttention.apply(qk.detach(), probe.view(bs, L, E), H, p).view(bs, L, H, hd)
+            Pd[:, :, :, c * hd:c * hd + n] = o.permute(0, 2, 1, 3)[..., :n]
+    q = qk[..., :E].view(bs, L, H, hd).transpose(1, 2)
+    k = qk[..., E:].view(bs, L, H, hd).transpose(1, 2)
+    P = torch.softmax(q @ k.transpose(-1, -2) * hd ** -0.5, -1)
+    keep = (Pd > 0).float()
+    if p == 0.0:
+        assert bool(keep.all())
+    else:
+        frac = float(keep.mean())
+        assert abs(frac - (1 - p)) < 0.01, frac
+    ref = ((P * keep / (1 - p)) @ v.view(bs, L, H, hd).transpose(1, 2)).transpose(1, 2).reshape(bs, L, E)
+    torch.testing.assert_close(Pd, (P * keep / (1 - p)).detach(), rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(out, ref, rtol=1e-4, atol=1e-5)
+    g1 = torch.autograd.grad(out, (qk, v), gy)
+    g2 = torch.autograd.grad(ref, (qk, v), gy)
+    for a, b in zip(g1, g2):
+        torch.testing.assert_close(a, b, rtol=1e-3, atol=2e-5 * float(b.abs().max()) + 1e-6)
