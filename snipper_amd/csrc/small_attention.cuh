@@ -6,9 +6,9 @@
 // launches, all latency.  Here:
 //   forward   workgroup = (batch, head, 16 queries) x 16 lanes per query: K (rows padded to hd + 4 floats: the 16 lanes of
 //             a query read 16 consecutive keys conflict-free) and V of the head in LDS; lane c scores keys c, c + 16, ...;
-//             row max / sum by DPP over the 16 lanes; probabilities (before dropout) are SAVED ([bs, H, L, L] float32,
-//             3.7 MB at the benchmark size -- cheaper than recomputing them) and parked in LDS; lane c then owns
-//             channels c, c + 16, c + 32 of the output row.
+//             row max / sum by lane shuffles over the 16 lanes; probabilities (before dropout) are SAVED ([bs, H, L, L]
+//             float32, 3.7 MB at the benchmark size -- cheaper than recomputing them) and parked in LDS; lanes
+//             0 .. HD/4 - 1 then own 4 channels each of the output row (16-byte row reads, 4 keys per trip).
 //   backward  ONE launch, two kinds of workgroups.  Row kind (16 queries): dS_ij = P_ij (dP_ij - delta_i) with
 //             dP = keep / (1 - p) * (dO_i . V_j) and delta_i = dO_i . O_i (which equals sum_j dP_ij P_ij, dropout
 //             included), then dQ_i = scale * sum_j dS_ij K_j.  Column kind (16 keys): the same dS_ij and the dropped
@@ -67,20 +67,49 @@ template <int HD> struct SaLds {
 };
 
 // rows [0, L) of a strided [L][HD] matrix -> LDS rows of kPad floats
+// (rows [L, round-up-to-4 of L) are zeroed: the combination loops below walk the rows four at a time)
 template <int HD>
 __device__ __forceinline__ void sa_stage(float *dst, const float *src, long long ld, int L, int tid) {
-  constexpr int kPad = HD + 4, kV = HD / 4;
-  for (int x = tid; x < L * kV; x += kSaThreads) {
+  constexpr int kPad = HD + 4, kV = HD / 4, kIter = (kSaMaxL * kV + kSaThreads - 1) / kSaThreads;
+  const int L4 = (L + 3) & ~3;
+  float4 t[kIter];
+#pragma unroll
+  for (int it = 0; it < kIter; ++it) {          // all loads in flight before the first LDS store (one workgroup per CU:
+    const int x = tid + it * kSaThreads;        // nothing else would hide their latency)
     const int r = x / kV, c = x - r * kV;
-    *reinterpret_cast<float4 *>(dst + r * kPad + 4 * c) = *reinterpret_cast<const float4 *>(src + (long long)r * ld + 4 * c);
+    t[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < L) t[it] = *reinterpret_cast<const float4 *>(src + (long long)r * ld + 4 * c);
+  }
+#pragma unroll
+  for (int it = 0; it < kIter; ++it) {
+    const int x = tid + it * kSaThreads;
+    const int r = x / kV, c = x - r * kV;
+    if (r < L4) *reinterpret_cast<float4 *>(dst + r * kPad + 4 * c) = t[it];
+  }
+}
+// acc[0..3] += sum_y coef[y] * rows[y][4c .. 4c+3] over y < L4 (coefficients four at a time, one 16-byte row read each)
+template <int HD>
+__device__ __forceinline__ void sa_combine(float (&acc)[4], const float *coef, const float *rows, int L4, int c) {
+  constexpr int kPad = HD + 4;
+  for (int y = 0; y < L4; y += 4) {
+    const float4 w = *reinterpret_cast<const float4 *>(coef + y);
+    const float4 r0 = *reinterpret_cast<const float4 *>(rows + (y + 0) * kPad + 4 * c);
+    const float4 r1 = *reinterpret_cast<const float4 *>(rows + (y + 1) * kPad + 4 * c);
+    const float4 r2 = *reinterpret_cast<const float4 *>(rows + (y + 2) * kPad + 4 * c);
+    const float4 r3 = *reinterpret_cast<const float4 *>(rows + (y + 3) * kPad + 4 * c);
+    acc[0] = fmaf(w.x, r0.x, acc[0]); acc[1] = fmaf(w.x, r0.y, acc[1]); acc[2] = fmaf(w.x, r0.z, acc[2]); acc[3] = fmaf(w.x, r0.w, acc[3]);
+    acc[0] = fmaf(w.y, r1.x, acc[0]); acc[1] = fmaf(w.y, r1.y, acc[1]); acc[2] = fmaf(w.y, r1.z, acc[2]); acc[3] = fmaf(w.y, r1.w, acc[3]);
+    acc[0] = fmaf(w.z, r2.x, acc[0]); acc[1] = fmaf(w.z, r2.y, acc[1]); acc[2] = fmaf(w.z, r2.z, acc[2]); acc[3] = fmaf(w.z, r2.w, acc[3]);
+    acc[0] = fmaf(w.w, r3.x, acc[0]); acc[1] = fmaf(w.w, r3.y, acc[1]); acc[2] = fmaf(w.w, r3.z, acc[2]); acc[3] = fmaf(w.w, r3.w, acc[3]);
   }
 }
 
 template <int HD>
 __global__ __launch_bounds__(kSaThreads) void small_attn_fwd_kernel(SmallAttnArgs g) {
   __shared__ SaLds<HD> S;
-  constexpr int kPad = HD + 4, kC = HD / 16;          // channels per lane in the output phase (lane c: c, c + 16, ...)
+  constexpr int kPad = HD + 4, kLanes = HD / 4;       // output phase: lanes 0 .. HD/4 - 1 of a group own 4 channels each
   const int tid = threadIdx.x, grp = tid >> 4, c = tid & 15;
+  const int L4 = (g.L + 3) & ~3;
   const int nblk = (g.L + kSaRows - 1) / kSaRows;
   const int blk = blockIdx.x % nblk, bh = blockIdx.x / nblk, h = bh % g.H, b = bh / g.H;
   const int i = blk * kSaRows + grp;
@@ -127,29 +156,21 @@ __global__ __launch_bounds__(kSaThreads) void small_attn_fwd_kernel(SmallAttnArg
     if (row_ok) Prow[j] = p;
     S.p[grp][j] = p * sa_keep(g, thresh, keep_scale, bh, i, j);
   }
-  __syncthreads();         // (the group's row is complete; a workgroup barrier because groups straddle no wave, but cheap)
-  float o[kC];
-#pragma unroll
-  for (int u = 0; u < kC; ++u) o[u] = 0.f;
-  for (int j = 0; j < g.L; ++j) {
-    const float p = S.p[grp][j];
-    const float *vr = S.b + j * kPad;
-#pragma unroll
-    for (int u = 0; u < kC; ++u) o[u] = fmaf(p, vr[c + 16 * u], o[u]);
-  }
-  if (row_ok) {
-    float *op = g.out + b * g.o_bs + (long long)i * g.o_ld + h * HD;
-#pragma unroll
-    for (int u = 0; u < kC; ++u) op[c + 16 * u] = o[u];
-  }
+  if (c < L4 - g.L) S.p[grp][g.L + c] = 0.f;
+  __syncthreads();         // (the group's row is complete; groups straddle no wave, but a workgroup barrier is cheap here)
+  float o[4] = {0.f, 0.f, 0.f, 0.f};
+  if (c < kLanes) sa_combine<HD>(o, S.p[grp], S.b, L4, c);
+  if (row_ok && c < kLanes)
+    *reinterpret_cast<float4 *>(g.out + b * g.o_bs + (long long)i * g.o_ld + h * HD + 4 * c) = make_float4(o[0], o[1], o[2], o[3]);
 }
 
 // backward: blocks [0, nblk) of a (b, h) are the row kind, [nblk, 2 nblk) the column kind
 template <int HD>
 __global__ __launch_bounds__(kSaThreads) void small_attn_bwd_kernel(SmallAttnArgs g) {
   __shared__ SaLds<HD> S;
-  constexpr int kPad = HD + 4, kC = HD / 16;
+  constexpr int kPad = HD + 4, kLanes = HD / 4;
   const int tid = threadIdx.x, grp = tid >> 4, c = tid & 15;
+  const int L4 = (g.L + 3) & ~3;
   const int nblk = (g.L + kSaRows - 1) / kSaRows;
   const int per_bh = 2 * nblk;
   const int bh = blockIdx.x / per_bh, r = blockIdx.x % per_bh, h = bh % g.H, b = bh / g.H;
@@ -192,57 +213,54 @@ __global__ __launch_bounds__(kSaThreads) void small_attn_bwd_kernel(SmallAttnArg
     }
   }
   __syncthreads();
-  // coefficients of this group's row (of dS) or column (of dS and of the dropped probabilities)
+  // coefficients of this group's row (of dS) or column (of dS and of the dropped probabilities).  The saved
+  // probabilities of the lane's <= 16 elements are fetched up front (a load inside the loop would expose its latency
+  // once per element: one workgroup per CU, nothing to switch to)
   const float *Pbh = g.P + (long long)bh * g.L * g.L;
-  for (int y = c; y < g.L; y += 16) {
+  constexpr int kPer = kSaMaxL / 16;
+  float pv[kPer];
+#pragma unroll
+  for (int t = 0; t < kPer; ++t) {
+    const int y = c + 16 * t;
+    const int i = col_kind ? y : x0, j = col_kind ? x0 : y;
+    pv[t] = (x_ok && y < g.L) ? Pbh[(long long)i * g.L + j] : 0.f;
+  }
+#pragma unroll
+  for (int t = 0; t < kPer; ++t) {
+    const int y = c + 16 * t;
+    if (y >= g.L) break;
     const float *yr = S.a + y * kPad;
     float dot = 0.f;
 #pragma unroll
     for (int e = 0; e < HD; e += 4) {
-      const float4 t = *reinterpret_cast<const float4 *>(yr + e);
-      dot = fmaf(xv[e], t.x, dot); dot = fmaf(xv[e + 1], t.y, dot); dot = fmaf(xv[e + 2], t.z, dot); dot = fmaf(xv[e + 3], t.w, dot);
+      const float4 v4 = *reinterpret_cast<const float4 *>(yr + e);
+      dot = fmaf(xv[e], v4.x, dot); dot = fmaf(xv[e + 1], v4.y, dot); dot = fmaf(xv[e + 2], v4.z, dot); dot = fmaf(xv[e + 3], v4.w, dot);
     }
     const int i = col_kind ? y : x0, j = col_kind ? x0 : y;
-    const float p = x_ok ? Pbh[(long long)i * g.L + j] : 0.f;
+    const float p = pv[t];
     const float ks = sa_keep(g, thresh, keep_scale, bh, i, j);
     const float ds = p * (ks * dot - S.delta[i]);
     S.p[grp][y] = ds * g.scale;
     if (col_kind) S.p2[grp][y] = p * ks;
   }
+  if (c < L4 - g.L) { S.p[grp][g.L + c] = 0.f; S.p2[grp][g.L + c] = 0.f; }
   __syncthreads();
+  if (c >= kLanes) return;
   if (!col_kind) {
-    float acc[kC];
-#pragma unroll
-    for (int u = 0; u < kC; ++u) acc[u] = 0.f;
-    for (int j = 0; j < g.L; ++j) {
-      const float w = S.p[grp][j];
-      const float *kr = S.b + j * kPad;
-#pragma unroll
-      for (int u = 0; u < kC; ++u) acc[u] = fmaf(w, kr[c + 16 * u], acc[u]);
-    }
-    if (x_ok) {
-      float *o = g.dq + b * g.dq_bs + (long long)x0 * g.dq_ld + h * HD;
-#pragma unroll
-      for (int u = 0; u < kC; ++u) o[c + 16 * u] = acc[u];
-    }
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    sa_combine<HD>(acc, S.p[grp], S.b, L4, c);                       // dQ_i = scale * sum_j dS_ij K_j
+    if (x_ok)
+      *reinterpret_cast<float4 *>(g.dq + b * g.dq_bs + (long long)x0 * g.dq_ld + h * HD + 4 * c) =
+          make_float4(acc[0], acc[1], acc[2], acc[3]);
   } else {
-    float ak[kC], av[kC];
-#pragma unroll
-    for (int u = 0; u < kC; ++u) { ak[u] = 0.f; av[u] = 0.f; }
-    for (int i = 0; i < g.L; ++i) {
-      const float w = S.p[grp][i], pd = S.p2[grp][i];
-      const float *qr = S.b + i * kPad, *gr = S.a + i * kPad;
-#pragma unroll
-      for (int u = 0; u < kC; ++u) {
-        ak[u] = fmaf(w, qr[c + 16 * u], ak[u]);
-        av[u] = fmaf(pd, gr[c + 16 * u], av[u]);
-      }
-    }
+    float ak[4] = {0.f, 0.f, 0.f, 0.f}, av[4] = {0.f, 0.f, 0.f, 0.f};
+    sa_combine<HD>(ak, S.p[grp], S.b, L4, c);                        // dK_j = scale * sum_i dS_ij Q_i
+    sa_combine<HD>(av, S.p2[grp], S.a, L4, c);                       // dV_j = sum_i Pd_ij dO_i
     if (x_ok) {
-      float *ok_ = g.dk + b * g.dk_bs + (long long)x0 * g.dk_ld + h * HD;
-      float *ov = g.dv + b * g.dv_bs + (long long)x0 * g.dv_ld + h * HD;
-#pragma unroll
-      for (int u = 0; u < kC; ++u) { ok_[c + 16 * u] = ak[u]; ov[c + 16 * u] = av[u]; }
+      *reinterpret_cast<float4 *>(g.dk + b * g.dk_bs + (long long)x0 * g.dk_ld + h * HD + 4 * c) =
+          make_float4(ak[0], ak[1], ak[2], ak[3]);
+      *reinterpret_cast<float4 *>(g.dv + b * g.dv_bs + (long long)x0 * g.dv_ld + h * HD + 4 * c) =
+          make_float4(av[0], av[1], av[2], av[3]);
     }
   }
 }
