@@ -74,6 +74,33 @@ __device__ __forceinline__ void gemm_flush_tile(const uint16_t *Ct, uint16_t *Y,
   }
 }
 
+// the same for a tile of BN columns staged with rows of BN + 8 elements
+template <int BN>
+__device__ __forceinline__ void gemm_flush_tile_n(const uint16_t *Ct, uint16_t *Y, long long ldy, int m0, int n0, long long M,
+                                                  int N, const uint16_t *gate = nullptr, long long ldg = 0) {
+  constexpr int CH = BN / 8, ITER = 128 * CH / 256, CTS = BN + 8;
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < ITER; ++i) {
+    const int idx = threadIdx.x + 256 * i, row = idx / CH, ch = idx % CH;
+    const long long m = (long long)m0 + row;
+    const int n = n0 + ch * 8;
+    if (m < M && n < N) {
+      uint4 v = *reinterpret_cast<const uint4 *>(Ct + row * CTS + ch * 8);
+      if (gate) {
+        const uint4 a = *reinterpret_cast<const uint4 *>(gate + m * ldg + n);
+        auto keep = [](unsigned av, unsigned vv) {
+          const unsigned lo = ((av & 0x8000u) == 0u && (av & 0x7fffu) != 0u) ? 0x0000ffffu : 0u;
+          const unsigned hi = ((av & 0x80000000u) == 0u && (av & 0x7fff0000u) != 0u) ? 0xffff0000u : 0u;
+          return vv & (lo | hi);
+        };
+        v.x = keep(a.x, v.x); v.y = keep(a.y, v.y); v.z = keep(a.z, v.z); v.w = keep(a.w, v.w);
+      }
+      *reinterpret_cast<uint4 *>(Y + m * ldy + n) = v;
+    }
+  }
+}
+
 typedef __attribute__((ext_vector_type(8))) __bf16 gemm_bf16x8;
 typedef __attribute__((ext_vector_type(4))) float gemm_f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned int gemm_u32x4;
@@ -233,6 +260,124 @@ __global__ __launch_bounds__(kGemmThreads) __attribute__((amdgpu_waves_per_eu(3,
   }
 }
 
+// ---- the same product on 128 x 64 tiles -----------------------------------------------------------------------------
+// Each wave owns 64 x 32: half the accumulators, 94 VGPRs, 27.6 KB of LDS -> FIVE workgroups per CU instead of three.
+// The phases of a short-K tile (first load, LDS writes, MFMA, store) do not overlap within a workgroup
+// (profiles/r02_gemm_phase_ablation.json), so residency is what hides them; the price is X read from L2 once per 64
+// instead of per 128 output columns.  Measured (tools/gemmbench.py, us, 128x128 -> 128x64): 240000x256x64 34 -> 27,
+// 240000x64x64 22 -> 16, 3800x2048x512 32 -> 24, 60000x128x512 28 -> 24, 79000x384x384 45 -> 45, but 79000x384x1024
+// 92 -> 102 and 79000x1024x384 84 -> 95: the launcher takes these tiles unless the product is both long and wide
+// (gemm_use_n64).
+constexpr int kGemmBN64 = 64, kGemmCt64 = 72;
+inline bool gemm_use_n64(long long M, int N, int K) { return !(M >= 32768 && (K >= 1024 || N >= 1024)); }
+template <bool RELU>
+__global__ __launch_bounds__(kGemmThreads) __attribute__((amdgpu_waves_per_eu(5, 5))) void linear_bf16_n64_kernel(GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) uint16_t smem[(kGemmBM + kGemmBN64) * kGemmPad];
+  uint16_t *Xs = smem, *Ws = smem + kGemmBM * kGemmPad;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave & 1, wn = wave >> 1;
+  const int tiles_n = (g.N + kGemmBN64 - 1) / kGemmBN64;
+  const int xcd = blockIdx.x & 7, j = (int)(blockIdx.x >> 3);
+  const int tm = xcd + 8 * (j / tiles_n), tn = j % tiles_n;
+  if ((long long)tm * kGemmBM >= g.M) return;
+  const int m0 = tm * kGemmBM, n0 = tn * kGemmBN64;
+  const int lrow = tid >> 3, kc = tid & 7;
+  const unsigned x_voff = ((unsigned)lrow * (unsigned)g.ldx + kc * 8) * 2u, w_voff = ((unsigned)lrow * (unsigned)g.K + kc * 8) * 2u;
+  const unsigned x_step = 32u * (unsigned)g.ldx * 2u, w_step = 32u * (unsigned)g.K * 2u;
+  int lds_off[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) lds_off[i] = (lrow + 32 * i) * kGemmPad + kc * 8;
+  const int mrows = min(kGemmBM, g.M - m0), nrows = min(kGemmBN64, g.N - n0);
+  const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint16_t *>(g.X + (long long)m0 * g.ldx), 0, (int)(((long long)(mrows - 1) * g.ldx + g.K) * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint16_t *>(g.W + (long long)n0 * g.K), 0, (int)((long long)nrows * g.K * 2), 0x00020000);
+  gemm_u32x4 xr[4], wr[2];
+  auto load_step = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) xr[i] = __builtin_amdgcn_raw_buffer_load_b128(xsrc, x_voff + i * x_step, (unsigned)k0 * 2u, 0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) wr[i] = __builtin_amdgcn_raw_buffer_load_b128(wsrc, w_voff + i * w_step, (unsigned)k0 * 2u, 0);
+  };
+  load_step(0);
+  gemm_f32x4 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) acc[i][jj] = gemm_f32x4{0.f, 0.f, 0.f, 0.f};
+  const int frag_row = lane & 15, frag_k = (lane >> 4) * 8;
+  for (int k0 = 0; k0 < g.K; k0 += kGemmBK) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<gemm_u32x4 *>(Xs + lds_off[i]) = xr[i];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) *reinterpret_cast<gemm_u32x4 *>(Ws + lds_off[i]) = wr[i];
+    __syncthreads();
+    if (k0 + kGemmBK < g.K) load_step(k0 + kGemmBK);
+#pragma unroll
+    for (int kk = 0; kk < kGemmBK; kk += 32) {
+      gemm_bf16x8 wf[2], xf[4];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        wf[i] = *reinterpret_cast<const gemm_bf16x8 *>(Ws + (wn * 32 + i * 16 + frag_row) * kGemmPad + kk + frag_k);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        xf[i] = *reinterpret_cast<const gemm_bf16x8 *>(Xs + (wm * 64 + i * 16 + frag_row) * kGemmPad + kk + frag_k);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+          acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[jj], acc[i][jj], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  const bool wide = gemm_wide_ok(g.Y, g.ldy, g.N);
+  const bool drop = g.drop_p > 0.f;
+  const float keep_scale = drop ? 1.f / (1.f - g.drop_p) : 1.f;
+  const uint32_t thresh = (uint32_t)fminf(g.drop_p * 4294967296.f, 4294967040.f);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int n = n0 + wn * 32 + i * 16 + (lane >> 4) * 4;
+    if (n >= g.N) continue;
+    gemm_f32x4 b = {0.f, 0.f, 0.f, 0.f};
+    if (g.bias) b = *reinterpret_cast<const gemm_f32x4 *>(g.bias + n);
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const int m = m0 + wm * 64 + jj * 16 + (lane & 15);
+      if (m >= g.M) continue;
+      gemm_f32x4 v = acc[i][jj] + b;
+      if (g.R) {
+        const uint2 r = *reinterpret_cast<const uint2 *>(g.R + (long long)m * g.ldr + n);
+        v.x += __uint_as_float(r.x << 16); v.y += __uint_as_float(r.x & 0xffff0000u);
+        v.z += __uint_as_float(r.y << 16); v.w += __uint_as_float(r.y & 0xffff0000u);
+      }
+      if (RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      if (drop) {
+        const uint32_t e = (uint32_t)m * (uint32_t)g.N + (uint32_t)n;
+        v.x = gemm_rand(e, g.seed_lo, g.seed_hi) >= thresh ? v.x * keep_scale : 0.f;
+        v.y = gemm_rand(e + 1, g.seed_lo, g.seed_hi) >= thresh ? v.y * keep_scale : 0.f;
+        v.z = gemm_rand(e + 2, g.seed_lo, g.seed_hi) >= thresh ? v.z * keep_scale : 0.f;
+        v.w = gemm_rand(e + 3, g.seed_lo, g.seed_hi) >= thresh ? v.w * keep_scale : 0.f;
+      }
+      uint2 o;
+      o.x = gemm_pack2(v.x, v.y);
+      o.y = gemm_pack2(v.z, v.w);
+      if (wide) *reinterpret_cast<uint2 *>(smem + (m - m0) * kGemmCt64 + (n - n0)) = o;
+      else *reinterpret_cast<uint2 *>(g.Y + (long long)m * g.ldy + n) = o;
+    }
+  }
+  if (wide) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = tid + 256 * i, row = idx >> 3, ch = idx & 7;
+      const long long m = (long long)m0 + row;
+      const int n = n0 + ch * 8;
+      if (m < g.M && n < g.N)
+        *reinterpret_cast<uint4 *>(g.Y + m * g.ldy + n) = *reinterpret_cast<const uint4 *>(smem + row * kGemmCt64 + ch * 8);
+    }
+  }
+}
+
 // ---- data gradient: Y[M,N] = X[M,K] . W[K,N]  (W row-major with the REDUCTION index as its slow axis) ------------
 // dX = dY . W for a Linear / 1x1 convolution whose weight is stored [out, in] = [K, N]: the kernel above would need
 // W transposed.  Here the W tile is staged as it lies in memory ([k][n], 16-byte loads along n) and the MFMA operand
@@ -252,83 +397,97 @@ struct GemmNNArgs {
   float gate_scale;                      //   backward): Y = A > 0 ? Y * gate_scale : 0;  nullptr = no gate
 };
 
+template <int TRS>
 __device__ __forceinline__ gemm_bf16x8 gemm_tr_frag(const uint16_t *tile, int byte_off) {
   typedef __attribute__((address_space(3))) gemm_bf16x4 lds_v4;
   const char *base = reinterpret_cast<const char *>(tile) + byte_off;
   const gemm_bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4 *)(base));
-  const gemm_bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4 *)(base + 16 * kGemmTrStride * 2));
+  const gemm_bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4 *)(base + 16 * TRS * 2));
   return gemm_bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 
-__global__ __launch_bounds__(kGemmThreads) __attribute__((amdgpu_waves_per_eu(3, 3))) void linear_bf16_nn_kernel(GemmNNArgs g) {
-  __shared__ __attribute__((aligned(16))) uint16_t smem[kGemmBM * kGemmPad + kGemmBK * kGemmTrStride];
+// BN = 128: the tile of linear_bf16_kernel (3 workgroups per CU), the only instantiation.  BN = 64 (each wave 64 x 32,
+// five workgroups per CU, as linear_bf16_n64_kernel) was built and measured SLOWER here at every shape of the step
+// (79000x384x384 41 -> 50 us, 60000x512x256 28 -> 33 us, 3800x2048x1024 29 -> 32 us; 6 VGPRs spilled at 5 waves): this
+// kernel's X operand costs two 8-byte LDS reads per fragment, and halving the W reuse doubles their share.
+// W rows in LDS: BN + 16 elements (288 bytes: the 8 k-rows a 32-lane half reads with ds_read_b64_tr_b16 land on 8
+// distinct groups of 8 banks).
+template <int BN>
+__global__ __launch_bounds__(kGemmThreads) __attribute__((amdgpu_waves_per_eu(BN == 128 ? 3 : 5, BN == 128 ? 3 : 5)))
+void linear_bf16_nn_kernel(GemmNNArgs g) {
+  constexpr int TRS = BN + 16;            // W tile row stride (elements)
+  constexpr int NI = BN / 32;             // 16-column blocks per wave
+  constexpr int WCH = BN / 8;             // 16-byte chunks per W k-row
+  constexpr int WROWS = kGemmThreads / WCH, WPASS = kGemmBK / WROWS;      // k-rows per loader pass, passes per K-step
+  constexpr int CTS = BN + 8;             // staged output row stride
+  __shared__ __attribute__((aligned(16))) uint16_t smem[kGemmBM * kGemmPad + kGemmBK * TRS];
   uint16_t *Xs = smem, *Ws = smem + kGemmBM * kGemmPad;
   const bool wide = gemm_wide_ok(g.Y, g.ldy, g.N);
   const bool gate_in_flush = wide && g.A && (g.lda % 8) == 0 && ((uintptr_t)g.A % 16) == 0;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave & 1, wn = wave >> 1;
-  int tm, tn;
-  gemm_tile_of_block((g.N + kGemmBN - 1) / kGemmBN, tm, tn);
+  const int tiles_n = (g.N + BN - 1) / BN;
+  const int xcd = blockIdx.x & 7, jb = (int)(blockIdx.x >> 3);
+  const int tm = xcd + 8 * (jb / tiles_n), tn = jb % tiles_n;
   if ((long long)tm * kGemmBM >= g.M) return;
-  const int m0 = tm * kGemmBM, n0 = tn * kGemmBN;
+  const int m0 = tm * kGemmBM, n0 = tn * BN;
 
   // loaders (raw buffer loads as in linear_bf16_kernel).  X: 128 rows x 8 chunks of 8 k, row = 32 * i + tid / 8; the
-  // descriptor covers the tile's rows, so rows past the end read as 0.  W: 64 k-rows x 16 chunks of 8 n, k-row =
-  // 16 * i + tid / 16; a lane whose columns lie past N gets an offset outside the descriptor (reads as 0).
-  const int lrow = tid >> 3, kc = tid & 7, krow = tid >> 4, nc = tid & 15;
+  // descriptor covers the tile's rows, so rows past the end read as 0.  W: 64 k-rows x WCH chunks of 8 n, k-row =
+  // WROWS * i + tid / WCH; a lane whose columns lie past N gets an offset outside the descriptor (reads as 0).
+  const int lrow = tid >> 3, kc = tid & 7, krow = tid / WCH, nc = tid % WCH;
   const unsigned x_voff = ((unsigned)lrow * (unsigned)g.ldx + kc * 8) * 2u, x_step = 32u * (unsigned)g.ldx * 2u;
-  const unsigned w_step = 16u * (unsigned)g.ldw * 2u;
+  const unsigned w_step = (unsigned)WROWS * (unsigned)g.ldw * 2u;
   const unsigned w_voff = n0 + nc * 8 < g.N ? ((unsigned)krow * (unsigned)g.ldw + nc * 8) * 2u : 0x80000000u;
-  int x_off[4], w_off[4];
+  int x_off[4], w_off[WPASS];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    x_off[i] = (lrow + 32 * i) * kGemmPad + kc * 8;
-    w_off[i] = (krow + 16 * i) * kGemmTrStride + nc * 8;
-  }
+  for (int i = 0; i < 4; ++i) x_off[i] = (lrow + 32 * i) * kGemmPad + kc * 8;
+#pragma unroll
+  for (int i = 0; i < WPASS; ++i) w_off[i] = (krow + WROWS * i) * TRS + nc * 8;
   const int mrows = min(kGemmBM, g.M - m0);
   const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<uint16_t *>(g.X + (long long)m0 * g.ldx), 0, (int)(((long long)(mrows - 1) * g.ldx + g.K) * 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<uint16_t *>(g.W + n0), 0, (int)(((long long)(g.K - 1) * g.ldw + (g.N - n0)) * 2), 0x00020000);
-  gemm_u32x4 xr[4], wr[4];
+  gemm_u32x4 xr[4], wr[WPASS];
   auto load_step = [&](int k0) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      xr[i] = __builtin_amdgcn_raw_buffer_load_b128(xsrc, x_voff + i * x_step, (unsigned)k0 * 2u, 0);
+    for (int i = 0; i < 4; ++i) xr[i] = __builtin_amdgcn_raw_buffer_load_b128(xsrc, x_voff + i * x_step, (unsigned)k0 * 2u, 0);
+#pragma unroll
+    for (int i = 0; i < WPASS; ++i)
       wr[i] = __builtin_amdgcn_raw_buffer_load_b128(wsrc, w_voff + i * w_step, (unsigned)k0 * (unsigned)g.ldw * 2u, 0);
-    }
   };
   load_step(0);
-  gemm_f32x4 acc[4][4];
+  gemm_f32x4 acc[NI][4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < NI; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = gemm_f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int grp = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
-  const int tr_base = ((grp * 4 + q) * kGemmTrStride + 4 * p) * 2;       // bytes (transposed W reads)
+  const int tr_base = ((grp * 4 + q) * TRS + 4 * p) * 2;       // bytes (transposed W reads)
   const int frag_row = lane & 15;
   for (int k0 = 0; k0 < g.K; k0 += kGemmBK) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      *reinterpret_cast<gemm_u32x4 *>(Xs + x_off[i]) = xr[i];
-      *reinterpret_cast<gemm_u32x4 *>(Ws + w_off[i]) = wr[i];
-    }
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<gemm_u32x4 *>(Xs + x_off[i]) = xr[i];
+#pragma unroll
+    for (int i = 0; i < WPASS; ++i) *reinterpret_cast<gemm_u32x4 *>(Ws + w_off[i]) = wr[i];
     __syncthreads();
     if (k0 + kGemmBK < g.K) load_step(k0 + kGemmBK);
 #pragma unroll
     for (int kk = 0; kk < kGemmBK; kk += 32) {
-      gemm_bf16x8 wf[4], xf[4];
+      gemm_bf16x8 wf[NI], xf[4];
+#pragma unroll
+      for (int i = 0; i < NI; ++i) wf[i] = gemm_tr_frag<TRS>(Ws, tr_base + (kk * TRS + wn * (BN / 2) + i * 16) * 2);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        wf[i] = gemm_tr_frag(Ws, tr_base + (kk * kGemmTrStride + wn * 64 + i * 16) * 2);
         const uint16_t *xrow = Xs + (wm * 64 + i * 16 + frag_row) * kGemmPad + kk + grp * 4;
         const gemm_bf16x4 lo = *reinterpret_cast<const gemm_bf16x4 *>(xrow);
         const gemm_bf16x4 hi = *reinterpret_cast<const gemm_bf16x4 *>(xrow + 16);
         xf[i] = gemm_bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
       }
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < NI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
@@ -336,8 +495,8 @@ __global__ __launch_bounds__(kGemmThreads) __attribute__((amdgpu_waves_per_eu(3,
     __syncthreads();
   }
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int n = n0 + wn * 64 + i * 16 + (lane >> 4) * 4;
+  for (int i = 0; i < NI; ++i) {
+    const int n = n0 + wn * (BN / 2) + i * 16 + (lane >> 4) * 4;
     if (n >= g.N) continue;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -363,11 +522,11 @@ __global__ __launch_bounds__(kGemmThreads) __attribute__((amdgpu_waves_per_eu(3,
       uint2 o;
       o.x = gemm_pack2(v.x, v.y);
       o.y = gemm_pack2(v.z, v.w);
-      if (wide) *reinterpret_cast<uint2 *>(smem + (m - m0) * kGemmCtStride + (n - n0)) = o;
+      if (wide) *reinterpret_cast<uint2 *>(smem + (m - m0) * CTS + (n - n0)) = o;
       else *reinterpret_cast<uint2 *>(g.Y + (long long)m * g.ldy + n) = o;
     }
   }
-  if (wide) gemm_flush_tile(smem, g.Y, g.ldy, m0, n0, g.M, g.N, gate_in_flush ? g.A : nullptr, g.lda);
+  if (wide) gemm_flush_tile_n<BN>(smem, g.Y, g.ldy, m0, n0, g.M, g.N, gate_in_flush ? g.A : nullptr, g.lda);
 }
 
 // Backward of (ReLU -> dropout) given only the layer's OUTPUT y: a kept, active element has y > 0, a dropped or

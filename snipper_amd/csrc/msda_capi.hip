@@ -438,6 +438,13 @@ int snipper_linear_bf16(void *stream, const uint16_t *X, long long ldx, const ui
       (dropout_p > 0.f && (long long)M * N >= (1LL << 32)))
     return SNIPPER_E_SHAPE;
   const GemmArgs g{X, ldx, W, bias, R, ldr, Y, ldy, M, N, K, dropout_p, (uint32_t)seed, (uint32_t)(seed >> 32)};
+  if (gemm_use_n64(M, N, K)) {
+    const long long tiles_m = (M + 127) / 128, tiles_n = (N + 63) / 64;
+    const dim3 grid64((unsigned)(tiles_n * 8 * ((tiles_m + 7) / 8)));
+    if (relu) hipLaunchKernelGGL(linear_bf16_n64_kernel<true>, grid64, dim3(kGemmThreads), 0, (hipStream_t)stream, g);
+    else hipLaunchKernelGGL(linear_bf16_n64_kernel<false>, grid64, dim3(kGemmThreads), 0, (hipStream_t)stream, g);
+    return launch_status();
+  }
   const dim3 grid(gemm_grid_size(M, N));
   if (relu)
     hipLaunchKernelGGL(linear_bf16_kernel<true>, grid, dim3(kGemmThreads), 0, (hipStream_t)stream, g);
@@ -456,7 +463,7 @@ int snipper_linear_nn_bf16(void *stream, const uint16_t *X, long long ldx, const
   if (((uintptr_t)X | (uintptr_t)W) & 15) return SNIPPER_E_SHAPE;
   const GemmNNArgs g{X, ldx, W, ldw, Y, ldy, M, N, K, R, ldr, A, lda, gate_scale};
   const dim3 grid(gemm_grid_size(M, N));
-  hipLaunchKernelGGL(linear_bf16_nn_kernel, grid, dim3(kGemmThreads), 0, (hipStream_t)stream, g);
+  hipLaunchKernelGGL(linear_bf16_nn_kernel<128>, grid, dim3(kGemmThreads), 0, (hipStream_t)stream, g);
   return launch_status();
 }
 
