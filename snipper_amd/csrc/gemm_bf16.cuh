@@ -571,18 +571,23 @@ struct Conv3x3Args {
   const uint16_t *gate;
 };
 
-template <bool RELU>
-__global__ __launch_bounds__(kGemmThreads) __attribute__((amdgpu_waves_per_eu(3, 3))) void conv3x3_bf16_kernel(Conv3x3Args g) {
-  __shared__ __attribute__((aligned(16))) uint16_t smem[(kGemmBM + kGemmBN) * kGemmPad];
+// BN = 128 or 64 output channels per workgroup (64: each wave 64 x 32, more workgroups per CU; the launcher takes it when
+// the 128-wide grid would not fill the chip -- layer3 / layer4 of the ResNet have 238 / 120 such tiles for 768 slots).
+template <bool RELU, int BN>
+__global__ __launch_bounds__(kGemmThreads) __attribute__((amdgpu_waves_per_eu(BN == 128 ? 3 : 4, BN == 128 ? 3 : 4)))
+void conv3x3_bf16_kernel(Conv3x3Args g) {
+  constexpr int NI = BN / 32, WL = BN / 32, CTS = BN + 8;      // 16-column blocks per wave, W loads per thread and step
+  __shared__ __attribute__((aligned(16))) uint16_t smem[(kGemmBM + BN) * kGemmPad];
   uint16_t *Xs = smem, *Ws = smem + kGemmBM * kGemmPad;
   const bool wide = gemm_wide_ok(g.Y, g.Cout, g.Cout) && !g.dgrad2;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave & 1, wn = wave >> 1;
   const int M = g.B * g.Ho * g.Wo;
-  int tm, tn;
-  gemm_tile_of_block((g.Cout + kGemmBN - 1) / kGemmBN, tm, tn);
+  const int tiles_n = (g.Cout + BN - 1) / BN;
+  const int xcd = blockIdx.x & 7, jb = (int)(blockIdx.x >> 3);
+  const int tm = xcd + 8 * (jb / tiles_n), tn = jb % tiles_n;
   if ((long long)tm * kGemmBM >= M) return;
-  const int m0 = tm * kGemmBM, n0 = tn * kGemmBN;
+  const int m0 = tm * kGemmBM, n0 = tn * BN;
   // taps of this launch: all nine, or the parity class's (dgrad2): ky in {1} / {0, 2} for cy = 0 / 1, kx likewise
   const int nty = g.dgrad2 ? (g.cy ? 2 : 1) : 3, ntx = g.dgrad2 ? (g.cx ? 2 : 1) : 3;
   const int kslices = g.Cin / kGemmBK, steps = nty * ntx * kslices;
@@ -606,11 +611,11 @@ __global__ __launch_bounds__(kGemmThreads) __attribute__((amdgpu_waves_per_eu(3,
   }
   const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<uint16_t *>(g.X), 0, (int)((long long)g.B * g.H * g.Wd * g.Cin * 2), 0x00020000);
-  const int nrows = min(kGemmBN, g.Cout - n0);
+  const int nrows = min(BN, g.Cout - n0);
   const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<uint16_t *>(g.W + (long long)n0 * 9 * g.Cin), 0, (int)((long long)nrows * 9 * g.Cin * 2), 0x00020000);
   const unsigned w_voff = ((unsigned)lrow * 9u * (unsigned)g.Cin + kc * 8) * 2u, w_step = 32u * 9u * (unsigned)g.Cin * 2u;
-  auto load_step = [&](int s, gemm_u32x4 (&xr)[4], gemm_u32x4 (&wr)[4]) {
+  auto load_step = [&](int s, gemm_u32x4 (&xr)[4], gemm_u32x4 (&wr)[WL]) {
     const int t = s / kslices, k0 = (s - t * kslices) * kGemmBK;
     const int ty = t / ntx, tx = t - ty * ntx;
     // forward: tap (ky, kx) reads input pixel (oy * s - 1 + ky, ...); dgrad2: tap ky = cy ? 2 * ty : 1 reads gradient
@@ -625,14 +630,14 @@ __global__ __launch_bounds__(kGemmThreads) __attribute__((amdgpu_waves_per_eu(3,
       const bool ok = iy >= 0 && iy < g.H && ix >= 0 && ix < g.Wd;
       const unsigned xoff = ok ? ((unsigned)(pix[i] + dpix) * (unsigned)g.Cin + (unsigned)(k0 + kc * 8)) * 2u : 0x80000000u;
       xr[i] = __builtin_amdgcn_raw_buffer_load_b128(xsrc, xoff, 0, 0);
-      wr[i] = __builtin_amdgcn_raw_buffer_load_b128(wsrc, w_voff + i * w_step, (unsigned)(tap * g.Cin + k0) * 2u, 0);
+      if (i < WL) wr[i] = __builtin_amdgcn_raw_buffer_load_b128(wsrc, w_voff + i * w_step, (unsigned)(tap * g.Cin + k0) * 2u, 0);
     }
   };
-  gemm_u32x4 xr[4], wr[4];
+  gemm_u32x4 xr[4], wr[WL];
   load_step(0, xr, wr);
-  gemm_f32x4 acc[4][4];
+  gemm_f32x4 acc[NI][4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < NI; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = gemm_f32x4{0.f, 0.f, 0.f, 0.f};
   const int frag_row = lane & 15, frag_k = (lane >> 4) * 8;
@@ -640,20 +645,21 @@ __global__ __launch_bounds__(kGemmThreads) __attribute__((amdgpu_waves_per_eu(3,
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       *reinterpret_cast<gemm_u32x4 *>(Xs + lds_off[i]) = xr[i];
-      *reinterpret_cast<gemm_u32x4 *>(Ws + lds_off[i]) = wr[i];
+      if (i < WL) *reinterpret_cast<gemm_u32x4 *>(Ws + lds_off[i]) = wr[i];
     }
     __syncthreads();
     if (s + 1 < steps) load_step(s + 1, xr, wr);
 #pragma unroll
     for (int kk = 0; kk < kGemmBK; kk += 32) {
-      gemm_bf16x8 wf[4], xf[4];
+      gemm_bf16x8 wf[NI], xf[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        wf[i] = *reinterpret_cast<const gemm_bf16x8 *>(Ws + (wn * 64 + i * 16 + frag_row) * kGemmPad + kk + frag_k);
-        xf[i] = *reinterpret_cast<const gemm_bf16x8 *>(Xs + (wm * 64 + i * 16 + frag_row) * kGemmPad + kk + frag_k);
-      }
+      for (int i = 0; i < NI; ++i)
+        wf[i] = *reinterpret_cast<const gemm_bf16x8 *>(Ws + (wn * (BN / 2) + i * 16 + frag_row) * kGemmPad + kk + frag_k);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
+        xf[i] = *reinterpret_cast<const gemm_bf16x8 *>(Xs + (wm * 64 + i * 16 + frag_row) * kGemmPad + kk + frag_k);
+#pragma unroll
+      for (int i = 0; i < NI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
@@ -661,8 +667,8 @@ __global__ __launch_bounds__(kGemmThreads) __attribute__((amdgpu_waves_per_eu(3,
     __syncthreads();
   }
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int n = n0 + wn * 64 + i * 16 + (lane >> 4) * 4;
+  for (int i = 0; i < NI; ++i) {
+    const int n = n0 + wn * (BN / 2) + i * 16 + (lane >> 4) * 4;
     if (n >= g.Cout) continue;
     gemm_f32x4 b = {0.f, 0.f, 0.f, 0.f};
     if (g.bias) b = *reinterpret_cast<const gemm_f32x4 *>(g.bias + n);
@@ -675,7 +681,7 @@ __global__ __launch_bounds__(kGemmThreads) __attribute__((amdgpu_waves_per_eu(3,
       uint2 o;
       o.x = gemm_pack2(v.x, v.y);
       o.y = gemm_pack2(v.z, v.w);
-      if (wide) *reinterpret_cast<uint2 *>(smem + (m - m0) * kGemmCtStride + (n - n0)) = o;
+      if (wide) *reinterpret_cast<uint2 *>(smem + (m - m0) * CTS + (n - n0)) = o;
       else {
         long long row = m;
         if (g.dgrad2) {
@@ -691,7 +697,7 @@ __global__ __launch_bounds__(kGemmThreads) __attribute__((amdgpu_waves_per_eu(3,
       }
     }
   }
-  if (wide) gemm_flush_tile(smem, g.Y, g.Cout, m0, n0, M, g.Cout, g.gate, g.Cout);
+  if (wide) gemm_flush_tile_n<BN>(smem, g.Y, g.Cout, m0, n0, M, g.Cout, g.gate, g.Cout);
 }
 
 // ---- the ResNet stem: 7x7 convolution, stride 2, padding 3, 3 input channels -> 64, NHWC bf16 ----------------

@@ -782,6 +782,18 @@ int snipper_colsum_segments_bf16(void *stream, const uint16_t *x, long long imag
   return launch_status();
 }
 
+namespace {
+// 128 x 64 tiles when the 128 x 128 grid would leave the chip under-filled (or Cout has a half-empty last tile)
+inline bool conv_use_n64(long long M, int Cout) {
+  const long long tiles128 = ((M + 127) / 128) * ((Cout + 127) / 128);
+  return tiles128 < 768 || (Cout % 128 != 0 && Cout % 128 <= 64);
+}
+inline unsigned conv_grid_n64(long long M, int Cout) {
+  const long long tiles_m = (M + 127) / 128, tiles_n = (Cout + 63) / 64;
+  return (unsigned)(tiles_n * 8 * ((tiles_m + 7) / 8));
+}
+}  // namespace
+
 int snipper_conv3x3_bf16(void *stream, const uint16_t *X, const uint16_t *W, const float *bias, uint16_t *Y,
                          int B, int H, int Wd, int Cin, int Cout, int stride, int relu, const uint16_t *gate) {
   if (!X || !W || !Y) return SNIPPER_E_NULL;
@@ -792,11 +804,17 @@ int snipper_conv3x3_bf16(void *stream, const uint16_t *X, const uint16_t *W, con
   const long long M = (long long)B * Ho * Wo;
   if (M >= (1LL << 31) || (long long)B * H * Wd * Cin >= (1LL << 30)) return SNIPPER_E_SHAPE;   // (32-bit byte offsets)
   const Conv3x3Args g{X, W, bias, Y, B, H, Wd, Cin, Cout, Ho, Wo, stride, 0, 0, 0, 0, 0, gate};
+  if (conv_use_n64(M, Cout)) {
+    const dim3 grid64(conv_grid_n64(M, Cout));
+    if (relu) hipLaunchKernelGGL((conv3x3_bf16_kernel<true, 64>), grid64, dim3(kGemmThreads), 0, (hipStream_t)stream, g);
+    else hipLaunchKernelGGL((conv3x3_bf16_kernel<false, 64>), grid64, dim3(kGemmThreads), 0, (hipStream_t)stream, g);
+    return launch_status();
+  }
   const dim3 grid(gemm_grid_size(M, Cout));
   if (relu)
-    hipLaunchKernelGGL(conv3x3_bf16_kernel<true>, grid, dim3(kGemmThreads), 0, (hipStream_t)stream, g);
+    hipLaunchKernelGGL((conv3x3_bf16_kernel<true, 128>), grid, dim3(kGemmThreads), 0, (hipStream_t)stream, g);
   else
-    hipLaunchKernelGGL(conv3x3_bf16_kernel<false>, grid, dim3(kGemmThreads), 0, (hipStream_t)stream, g);
+    hipLaunchKernelGGL((conv3x3_bf16_kernel<false, 128>), grid, dim3(kGemmThreads), 0, (hipStream_t)stream, g);
   return launch_status();
 }
 
@@ -825,8 +843,13 @@ int snipper_conv3x3_dgrad_s2_bf16(void *stream, const uint16_t *G, const uint16_
       const int Hc = (Hx - cy + 1) / 2, Wc = (Wx - cx + 1) / 2;    // input pixels (2a + cy, 2b + cx) of this class
       if (Hc <= 0 || Wc <= 0) continue;
       const Conv3x3Args g{G, Wt, nullptr, dX, B, Hg, Wg, Cg, Cx, Hc, Wc, 1, 1, cy, cx, Hx, Wx, gate};
-      hipLaunchKernelGGL(conv3x3_bf16_kernel<false>, dim3(gemm_grid_size((long long)B * Hc * Wc, Cx)), dim3(kGemmThreads), 0,
-                         (hipStream_t)stream, g);
+      const long long Mc = (long long)B * Hc * Wc;
+      if (conv_use_n64(Mc, Cx))
+        hipLaunchKernelGGL((conv3x3_bf16_kernel<false, 64>), dim3(conv_grid_n64(Mc, Cx)), dim3(kGemmThreads), 0,
+                           (hipStream_t)stream, g);
+      else
+        hipLaunchKernelGGL((conv3x3_bf16_kernel<false, 128>), dim3(gemm_grid_size(Mc, Cx)), dim3(kGemmThreads), 0,
+                           (hipStream_t)stream, g);
     }
   return launch_status();
 }
