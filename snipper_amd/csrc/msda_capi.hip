@@ -569,15 +569,17 @@ int snipper_relu_dropout_backward_bf16(void *stream, const uint16_t *grad_y, con
 }
 
 namespace {
-struct WgradPlan { int tiles_n, tiles_k, S, rows; };
+struct WgradPlan { int tiles_n, tiles_k, S, rows, wk; };
 // split the reduction axis so that the grid has about g_wgrad_wgs workgroups (2 per CU); a multiple of 8 row-ranges
 // lets the kernel keep the output tiles of one range on one XCD
 WgradPlan wgrad_plan(int M, int N, int Kc) {
   WgradPlan p;
+  const int wgs = kWgradWgs;
+  p.wk = 128;      // (64-column X tiles, 4 waves per SIMD: measured slower at 512 / 768 / 1024 workgroups, wgrad_bf16.cuh)
   p.tiles_n = (N + kWgTile - 1) / kWgTile;
-  p.tiles_k = (Kc + kWgTile - 1) / kWgTile;
+  p.tiles_k = (Kc + p.wk - 1) / p.wk;
   const int tiles = p.tiles_n * p.tiles_k;
-  int s0 = std::max(1, kWgradWgs / tiles);
+  int s0 = std::max(1, wgs / tiles);
   if (s0 >= 8) s0 = (s0 + 7) / 8 * 8;
   s0 = std::min(s0, std::max(1, M / kWgRows));
   p.rows = (M + s0 - 1) / s0;
@@ -603,7 +605,7 @@ int snipper_wgrad_bf16(void *stream, const uint16_t *G, long long ldg, const uin
   const WgradPlan p = wgrad_plan(M, N, Kc);
   float *P = (float *)workspace, *Pb = db ? P + (size_t)p.S * N * Kc : nullptr;
   const WgradArgs a{G, ldg, X, ldx, P, Pb, M, N, Kc, p.S, p.rows, p.tiles_n, p.tiles_k, 0, 0, 0, 0, 0, 0, 0};
-  hipLaunchKernelGGL(wgrad_bf16_kernel, dim3(p.tiles_n * p.tiles_k * p.S), dim3(kWgThreads), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(wgrad_bf16_kernel<128>, dim3(p.tiles_n * p.tiles_k * p.S), dim3(kWgThreads), 0, (hipStream_t)stream, a);
   const WgradReduceArgs r{P, Pb, dW, lddw, db, scale, N, Kc, p.S, accumulate};
   const long long quads = (long long)N * Kc / 4;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((quads + 63) / 64)), dim3(256), 0, (hipStream_t)stream, r);
@@ -631,7 +633,7 @@ int snipper_wgrad_conv3x3_bf16(void *stream, const uint16_t *G, const uint16_t *
   const WgradPlan p = wgrad_plan((int)M, Cout, Kc);
   float *P = (float *)workspace;
   const WgradArgs a{G, Cout, X, Cin, P, nullptr, (int)M, Cout, Kc, p.S, p.rows, p.tiles_n, p.tiles_k, 1, H, Wd, Cin, Ho, Wo, stride};
-  hipLaunchKernelGGL(wgrad_bf16_kernel, dim3(p.tiles_n * p.tiles_k * p.S), dim3(kWgThreads), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(wgrad_bf16_kernel<128>, dim3(p.tiles_n * p.tiles_k * p.S), dim3(kWgThreads), 0, (hipStream_t)stream, a);
   const WgradReduceArgs r{P, nullptr, dW, Kc, nullptr, scale, Cout, Kc, p.S, accumulate};
   const long long quads = (long long)Cout * Kc / 4;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((quads + 63) / 64)), dim3(256), 0, (hipStream_t)stream, r);

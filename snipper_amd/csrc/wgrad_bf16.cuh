@@ -46,17 +46,28 @@ struct WgradArgs {
   int conv, H, Wd, Cin, Ho, Wo, stride;
 };
 
+template <int STRIDE>
 __device__ __forceinline__ gemm_bf16x8 wgrad_frag(const uint16_t *tile, int byte_off) {
   typedef __attribute__((address_space(3))) wgrad_bf16x4 lds_v4;
   const char *base = reinterpret_cast<const char *>(tile) + byte_off;
   const wgrad_bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4 *)(base));
-  const wgrad_bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4 *)(base + 16 * kWgStride * 2));
+  const wgrad_bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4 *)(base + 16 * STRIDE * 2));
   return gemm_bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 
-__global__ __launch_bounds__(kWgThreads) void wgrad_bf16_kernel(WgradArgs g) {
+// WK = columns of X (of dW) per workgroup: 128 is the only instantiation.  WK = 64 (each wave 64 x 32 of the tile, 104
+// VGPRs, 4 waves per SIMD; the G column tile re-read by twice as many workgroups) was built, is parity-green, and made the
+// training step SLOWER at every grid size tried: 27.78 / 27.65 / 27.90 ms at 512 / 768 / 1024 workgroups against 27.47 ms.
+template <int WK>
+__global__ __launch_bounds__(kWgThreads) __attribute__((amdgpu_waves_per_eu(WK == 128 ? 3 : 4, WK == 128 ? 3 : 4)))
+void wgrad_bf16_kernel(WgradArgs g) {
+  constexpr int XSTRIDE = WK + 16;                 // 288 / 160-byte rows: conflict-free transposed reads either way
+  constexpr int XCH = WK / 8;                      // 16-byte chunks per X row
+  constexpr int XROWS = kWgThreads / XCH;          // X rows per loader pass
+  constexpr int XLOADS = kWgRows / XROWS;          // X loads per thread and step
+  constexpr int NJ = WK / 32;                      // 16-column blocks of X per wave
   __shared__ __attribute__((aligned(16))) uint16_t Gs[kWgRows * kWgStride];
-  __shared__ __attribute__((aligned(16))) uint16_t Xs[kWgRows * kWgStride];
+  __shared__ __attribute__((aligned(16))) uint16_t Xs[kWgRows * XSTRIDE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wn = wave & 1, wk = wave >> 1;
 
@@ -74,15 +85,16 @@ __global__ __launch_bounds__(kWgThreads) void wgrad_bf16_kernel(WgradArgs g) {
   }
   (void)total;
   const int tn = t / g.tiles_k, tk = t % g.tiles_k;
-  const int n0 = tn * kWgTile, k0 = tk * kWgTile;
+  const int n0 = tn * kWgTile, k0 = tk * WK;
   const int m_begin = s * g.rows_per_split, m_end = min(g.M, m_begin + g.rows_per_split);
   const bool do_bias = g.Pb != nullptr && tk == 0;
 
   // loader: 4 x 16 B per operand per thread and step; row = idx / 16, 8-column chunk = idx % 16 (fixed per thread)
-  const int chunk = tid & 15, row0 = tid >> 4;
-  const bool g_col_ok = n0 + chunk * 8 < g.N, x_col_ok = k0 + chunk * 8 < g.Kc;
+  const int chunk = tid & 15, row0 = tid >> 4;                 // G: 16 chunks per row, 16 rows per pass
+  const int xchunk = tid % XCH, xrow0 = tid / XCH;             // X: XCH chunks per row, XROWS rows per pass
+  const bool g_col_ok = n0 + chunk * 8 < g.N, x_col_ok = k0 + xchunk * 8 < g.Kc;
   const int tap = g.conv ? k0 / g.Cin : 0, ky = tap / 3 - 1, kx = tap - (tap / 3) * 3 - 1;     // (conv mode)
-  const unsigned conv_col = (unsigned)((g.conv ? k0 - tap * g.Cin : k0) + chunk * 8);
+  const unsigned conv_col = (unsigned)((g.conv ? k0 - tap * g.Cin : k0) + xchunk * 8);
   // G (and X outside conv mode) by raw buffer loads: the descriptor covers this workgroup's row range and column tile
   // (base = its first element, a uniform value), the per-lane offset is one 32-bit register per operand (+ the row
   // group and the step's row offset, added per load -- they must be part of the VECTOR offset, the only one the range
@@ -98,15 +110,17 @@ __global__ __launch_bounds__(kWgThreads) void wgrad_bf16_kernel(WgradArgs g) {
       : __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(g.X + (long long)m_begin * g.ldx + k0), 0,
                                           (int)(((long long)(nrows - 1) * g.ldx + (g.Kc - k0)) * 2), 0x00020000);
   const unsigned g_voff = g_col_ok ? ((unsigned)row0 * (unsigned)g.ldg + chunk * 8) * 2u : 0x80000000u;
-  const unsigned x_voff = x_col_ok ? ((unsigned)row0 * (unsigned)g.ldx + chunk * 8) * 2u : 0x80000000u;
-  const unsigned g_grp = 16u * (unsigned)g.ldg * 2u, x_grp = 16u * (unsigned)g.ldx * 2u;
-  auto load_step = [&](int m, gemm_u32x4 (&gr)[kWgLoads], gemm_u32x4 (&xr)[kWgLoads]) {
+  const unsigned x_voff = x_col_ok ? ((unsigned)xrow0 * (unsigned)g.ldx + xchunk * 8) * 2u : 0x80000000u;
+  const unsigned g_grp = 16u * (unsigned)g.ldg * 2u, x_grp = (unsigned)XROWS * (unsigned)g.ldx * 2u;
+  auto load_step = [&](int m, gemm_u32x4 (&gr)[kWgLoads], gemm_u32x4 (&xr)[XLOADS]) {
     const unsigned mrel = (unsigned)(m - m_begin);
 #pragma unroll
-    for (int i = 0; i < kWgLoads; ++i) {
+    for (int i = 0; i < kWgLoads; ++i)
       gr[i] = __builtin_amdgcn_raw_buffer_load_b128(gsrc, g_voff + i * g_grp + mrel * (unsigned)g.ldg * 2u, 0, 0);
+#pragma unroll
+    for (int i = 0; i < XLOADS; ++i) {
       if (g.conv) {
-        const int r = m + row0 + 16 * i;
+        const int r = m + xrow0 + XROWS * i;
         const bool ok = r < m_end;
         const int rr = ok ? r : m_begin;
         const int b = rr / (g.Ho * g.Wo), rem = rr - b * (g.Ho * g.Wo);
@@ -120,26 +134,27 @@ __global__ __launch_bounds__(kWgThreads) void wgrad_bf16_kernel(WgradArgs g) {
       }
     }
   };
-  gemm_u32x4 gr[kWgLoads], xr[kWgLoads];
+  gemm_u32x4 gr[kWgLoads], xr[XLOADS];
   if (m_begin < m_end) load_step(m_begin, gr, xr);
-  gemm_f32x4 acc[4][4];
+  gemm_f32x4 acc[4][NJ];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = gemm_f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NJ; ++j) acc[i][j] = gemm_f32x4{0.f, 0.f, 0.f, 0.f};
   float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
   // transposed-read addressing: lane 4q+p of a 16-lane group supplies row q, columns 4p..4p+3 of the block
   const int grp = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
   const int frag_base = ((grp * 4 + q) * kWgStride + 4 * p) * 2;      // bytes; + 32-row step + column offset
+  const int xfrag_base = ((grp * 4 + q) * XSTRIDE + 4 * p) * 2;
 
   for (int m = m_begin; m < m_end; m += kWgRows) {
 #pragma unroll
-    for (int i = 0; i < kWgLoads; ++i) {
-      const int off = (row0 + 16 * i) * kWgStride + chunk * 8;
-      *reinterpret_cast<gemm_u32x4 *>(Gs + off) = gr[i];
-      *reinterpret_cast<gemm_u32x4 *>(Xs + off) = xr[i];
-    }
+    for (int i = 0; i < kWgLoads; ++i)
+      *reinterpret_cast<gemm_u32x4 *>(Gs + (row0 + 16 * i) * kWgStride + chunk * 8) = gr[i];
+#pragma unroll
+    for (int i = 0; i < XLOADS; ++i)
+      *reinterpret_cast<gemm_u32x4 *>(Xs + (xrow0 + XROWS * i) * XSTRIDE + xchunk * 8) = xr[i];
     if (do_bias) {
 #pragma unroll
       for (int i = 0; i < kWgLoads; ++i) {
@@ -155,16 +170,15 @@ __global__ __launch_bounds__(kWgThreads) void wgrad_bf16_kernel(WgradArgs g) {
     if (m + kWgRows < m_end) load_step(m + kWgRows, gr, xr);
 #pragma unroll
     for (int kk = 0; kk < kWgRows; kk += 32) {
-      gemm_bf16x8 gf[4], xf[4];
+      gemm_bf16x8 gf[4], xf[NJ];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        gf[i] = wgrad_frag(Gs, frag_base + (kk * kWgStride + wn * 64 + i * 16) * 2);
-        xf[i] = wgrad_frag(Xs, frag_base + (kk * kWgStride + wk * 64 + i * 16) * 2);
-      }
+      for (int i = 0; i < 4; ++i) gf[i] = wgrad_frag<kWgStride>(Gs, frag_base + (kk * kWgStride + wn * 64 + i * 16) * 2);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) xf[j] = wgrad_frag<XSTRIDE>(Xs, xfrag_base + (kk * XSTRIDE + wk * (WK / 2) + j * 16) * 2);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < NJ; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[i], xf[j], acc[i][j], 0, 0, 0);
     }
     __syncthreads();
@@ -175,8 +189,8 @@ __global__ __launch_bounds__(kWgThreads) void wgrad_bf16_kernel(WgradArgs g) {
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int kc = k0 + wk * 64 + j * 16 + (lane & 15);
+    for (int j = 0; j < NJ; ++j) {
+      const int kc = k0 + wk * (WK / 2) + j * 16 + (lane & 15);
       const int n = n0 + wn * 64 + i * 16 + (lane >> 4) * 4;
       if (kc >= g.Kc) continue;
       const float v[4] = {acc[i][j].x, acc[i][j].y, acc[i][j].z, acc[i][j].w};
