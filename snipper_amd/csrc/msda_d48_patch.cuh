@@ -194,6 +194,7 @@ typedef unsigned int patch_u32x2 __attribute__((ext_vector_type(2)));
 template <typename VT, bool GO_BF16> struct PatchDot;
 template <bool GO_BF16> struct PatchDot<float, GO_BF16> {
   static constexpr unsigned kRowV = 192;
+  static constexpr bool kContig = false;      // lane j owns channels 4j..4j+3 and 32+2j, 33+2j (a 16-byte + an 8-byte load)
   static __device__ __forceinline__ float dot(__amdgpu_buffer_rsrc_t vsrc, unsigned off, int j, const float (&g)[6],
                                               const unsigned (&)[3]) {
     const Row6 v = buf_row(vsrc, off, j);
@@ -202,21 +203,25 @@ template <bool GO_BF16> struct PatchDot<float, GO_BF16> {
 };
 template <bool GO_BF16> struct PatchDot<uint16_t, GO_BF16> {
   static constexpr unsigned kRowV = 96;
+  // bf16 value rows are 96 bytes: lane j owns the 6 CONTIGUOUS channels 6j .. 6j+5, so a tap is ONE 12-byte load per lane
+  // (the float32 layout needs a 16-byte and an 8-byte one); the texture path's cost is per instruction and per 64-byte
+  // segment touched, and this halves the former (the forward kernel of msda_d48.cuh gathers the same way)
+  static constexpr bool kContig = true;
   static __device__ __forceinline__ float dot(__amdgpu_buffer_rsrc_t vsrc, unsigned off, int j, const float (&g)[6],
                                               const unsigned (&gp)[3]) {
-    const patch_u32x2 a = __builtin_amdgcn_raw_buffer_load_b64(vsrc, off + 8u * j, 0, 0);
-    const unsigned b = __builtin_amdgcn_raw_buffer_load_b32(vsrc, off + 64u + 4u * j, 0, 0);
-    // (elements by INDEX: with `.x` / `.y` on the loaded pair, hipcc of ROCm 7.2 narrows the load to one dword and feeds
+    typedef unsigned int u32x3_t __attribute__((ext_vector_type(3)));
+    const u32x3_t a = __builtin_amdgcn_raw_buffer_load_b96(vsrc, off + 12u * j, 0, 0);
+    // (elements by INDEX: with `.x` / `.y` on a loaded pair, hipcc of ROCm 7.2 narrowed a 64-bit load to one dword and fed
     //  the first element to both products -- reproduced in isolation, round 2)
-    const unsigned ax = a[0], ay = a[1];
+    const unsigned ax = a[0], ay = a[1], az = a[2];
     if constexpr (GO_BF16) {        // both operands are bf16 pairs: v_dot2c_f32_bf16, products exact, float32 sums
       float acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(patch_bf16x2, ax), __builtin_bit_cast(patch_bf16x2, gp[0]), 0.f, false);
       acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(patch_bf16x2, ay), __builtin_bit_cast(patch_bf16x2, gp[1]), acc, false);
-      return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(patch_bf16x2, b), __builtin_bit_cast(patch_bf16x2, gp[2]), acc, false);
+      return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(patch_bf16x2, az), __builtin_bit_cast(patch_bf16x2, gp[2]), acc, false);
     } else {
       return g[0] * __uint_as_float(ax << 16) + g[1] * __uint_as_float(ax & 0xffff0000u) +
              g[2] * __uint_as_float(ay << 16) + g[3] * __uint_as_float(ay & 0xffff0000u) +
-             g[4] * __uint_as_float(b << 16) + g[5] * __uint_as_float(b & 0xffff0000u);
+             g[4] * __uint_as_float(az << 16) + g[5] * __uint_as_float(az & 0xffff0000u);
     }
   }
 };
@@ -266,28 +271,43 @@ __global__ __launch_bounds__(kPatchThreads) void msda_bwd_d48_patchbin_kernel(
     const int q = rg_ok[ps] ? lvq.start + (b.qy0 + ry) * lvq.W + b.qx0 + rx : lvq.start;
     rowg[ps] = ((long long)b.n * d.Lq + q) * d.M + b.m;
     gp[ps][0] = gp[ps][1] = gp[ps][2] = 0u;
+    // channel offsets of this lane's two pieces (4 + 2 channels, or 6 contiguous ones as 4 + 2)
+    const int ca = DOT::kContig ? 6 * j : 4 * j, cb = DOT::kContig ? 6 * j + 4 : 32 + 2 * j;
     if constexpr (GO_BF16) {
       const uint16_t *gr = reinterpret_cast<const uint16_t *>(grad_out) + rowg[ps] * kD48;
-      const uint2 pa = *reinterpret_cast<const uint2 *>(gr + 4 * j);
-      const unsigned pb = *reinterpret_cast<const unsigned *>(gr + 32 + 2 * j);
-      gp[ps][0] = pa.x; gp[ps][1] = pa.y; gp[ps][2] = pb;
-      g[ps][0] = __uint_as_float(pa.x << 16); g[ps][1] = __uint_as_float(pa.x & 0xffff0000u);
-      g[ps][2] = __uint_as_float(pa.y << 16); g[ps][3] = __uint_as_float(pa.y & 0xffff0000u);
-      g[ps][4] = __uint_as_float(pb << 16);   g[ps][5] = __uint_as_float(pb & 0xffff0000u);
+      unsigned p0, p1, p2;
+      if constexpr (DOT::kContig) {            // 12 bytes at 12 j: 4-byte aligned
+        const unsigned *g32 = reinterpret_cast<const unsigned *>(gr + ca);
+        p0 = g32[0]; p1 = g32[1]; p2 = g32[2];
+      } else {
+        const uint2 pa = *reinterpret_cast<const uint2 *>(gr + ca);
+        p0 = pa.x; p1 = pa.y; p2 = *reinterpret_cast<const unsigned *>(gr + cb);
+      }
+      gp[ps][0] = p0; gp[ps][1] = p1; gp[ps][2] = p2;
+      g[ps][0] = __uint_as_float(p0 << 16); g[ps][1] = __uint_as_float(p0 & 0xffff0000u);
+      g[ps][2] = __uint_as_float(p1 << 16); g[ps][3] = __uint_as_float(p1 & 0xffff0000u);
+      g[ps][4] = __uint_as_float(p2 << 16); g[ps][5] = __uint_as_float(p2 & 0xffff0000u);
     } else {
       const float *gr = reinterpret_cast<const float *>(grad_out) + rowg[ps] * kD48;
-      const f32x4 pa = *reinterpret_cast<const f32x4 *>(gr + 4 * j);
-      const float2 pb = *reinterpret_cast<const float2 *>(gr + 32 + 2 * j);
-      g[ps][0] = pa.x; g[ps][1] = pa.y; g[ps][2] = pa.z; g[ps][3] = pa.w; g[ps][4] = pb.x; g[ps][5] = pb.y;
+      if constexpr (DOT::kContig) {
+        const float2 a0 = *reinterpret_cast<const float2 *>(gr + ca), a1 = *reinterpret_cast<const float2 *>(gr + ca + 2);
+        const float2 a2 = *reinterpret_cast<const float2 *>(gr + cb);
+        g[ps][0] = a0.x; g[ps][1] = a0.y; g[ps][2] = a1.x; g[ps][3] = a1.y; g[ps][4] = a2.x; g[ps][5] = a2.y;
+      } else {
+        const f32x4 pa = *reinterpret_cast<const f32x4 *>(gr + ca);
+        const float2 pb = *reinterpret_cast<const float2 *>(gr + cb);
+        g[ps][0] = pa.x; g[ps][1] = pa.y; g[ps][2] = pa.z; g[ps][3] = pa.w; g[ps][4] = pb.x; g[ps][5] = pb.y;
+      }
     }
     if (!rg_ok[ps]) {
 #pragma unroll
       for (int c = 0; c < 6; ++c) g[ps][c] = 0.f;
       gp[ps][0] = gp[ps][1] = gp[ps][2] = 0u;
     }
-    f32x4 ga4; ga4.x = g[ps][0]; ga4.y = g[ps][1]; ga4.z = g[ps][2]; ga4.w = g[ps][3];
-    *reinterpret_cast<f32x4 *>(s_g + r * kD48 + 4 * j) = ga4;
-    *reinterpret_cast<float2 *>(s_g + r * kD48 + 32 + 2 * j) = make_float2(g[ps][4], g[ps][5]);
+    // the row also goes to LDS (float32) for the atomic phase
+    *reinterpret_cast<float2 *>(s_g + r * kD48 + ca) = make_float2(g[ps][0], g[ps][1]);
+    *reinterpret_cast<float2 *>(s_g + r * kD48 + ca + 2) = make_float2(g[ps][2], g[ps][3]);
+    *reinterpret_cast<float2 *>(s_g + r * kD48 + cb) = make_float2(g[ps][4], g[ps][5]);
   }
 
   // slots of the first level (later levels: computed one level ahead, behind the gather of the current one)
