@@ -81,17 +81,25 @@ __global__ __launch_bounds__(kSgThreads) void small_gemm_batch_f32_kernel(SmallG
   float sum_part = 0.f;
   float *A = At[wave], *B = Bt[wave];
   const int li = lane & 31, lk = lane >> 5;
+  // operand tiles of chunk `it` of this wave (a chunk past R reads as zeros): the stored orientation decides which axis
+  // of the tile is the reduction
+  const int a_rows = a_tr ? g.R : g.I, a_cols = a_tr ? g.I : g.R, b_rows = b_tr ? g.J : g.R, b_cols = b_tr ? g.R : g.J;
+  float4 va[4], vb[4];
+  {
+    const int q0 = wave * kSgTile;
+    sg_load_tile(g.A, g.lda, a_rows, a_cols, a_tr ? q0 : r0, a_tr ? r0 : q0, va, lane);
+    sg_load_tile(g.B, g.ldb, b_rows, b_cols, b_tr ? c0 : q0, b_tr ? q0 : c0, vb, lane);
+  }
   for (int it = 0; it < per_wave; ++it) {
-    const int q0 = (it * 4 + wave) * kSgTile;         // this wave's chunk of the reduction axis (past R: zeros)
-    float4 va[4], vb[4];
-    if (a_tr) sg_load_tile(g.A, g.lda, g.R, g.I, q0, r0, va, lane);      // stored [r][i]
-    else sg_load_tile(g.A, g.lda, g.I, g.R, r0, q0, va, lane);           // stored [i][r]
-    if (b_tr) sg_load_tile(g.B, g.ldb, g.J, g.R, c0, q0, vb, lane);      // stored [j][r]
-    else sg_load_tile(g.B, g.ldb, g.R, g.J, q0, c0, vb, lane);           // stored [r][j]
     __syncthreads();                                                      // the previous chunk's reads are done
     sg_store_tile(A, va, lane);
     sg_store_tile(B, vb, lane);
     __syncthreads();
+    {                                                 // the next chunk: in flight while this one is multiplied (one or
+      const int q0 = ((it + 1) * 4 + wave) * kSgTile; // two workgroups per CU: nothing else would hide the latency)
+      sg_load_tile(g.A, g.lda, a_rows, a_cols, a_tr ? q0 : r0, a_tr ? r0 : q0, va, lane);
+      sg_load_tile(g.B, g.ldb, b_rows, b_cols, b_tr ? c0 : q0, b_tr ? q0 : c0, vb, lane);
+    }
     // MFMA operands: lane l holds A[i = l & 31][k = l >> 5] and B[k = l >> 5][j = l & 31] of each 2-step
 #pragma unroll
     for (int kk = 0; kk < kSgTile; kk += 2) {
