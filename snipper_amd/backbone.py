@@ -185,15 +185,15 @@ class _PointwiseConvBN(torch.autograd.Function):
         if ctx.relu:
             g = torch.ops.aten.threshold_backward(g, y, 0)
         from .dense import _dgrad
-        dx = None
-        if ctx.needs_input_grad[0]:
-            dx = _dgrad(g, w_eff, gskip if ctx.fork else None, x2 if ctx.gate_input else None)
         dw = None
         if ctx.needs_input_grad[1]:
             from .dense import wgrad_bf16
             dw, _ = wgrad_bf16(g, x2, want_bias=False, scale=scale)     # BN scale folded into the reduction kernel
             # same memory, the parameter's own strides (NHWC weights: DDP aliases its bucket only when they match)
             dw = dw.to(ctx.wdtype).as_strided(ctx.wshape, ctx.wstride)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = _dgrad(g, w_eff, gskip if ctx.fork else None, x2 if ctx.gate_input else None)
         return dx, dw, None, None, (g if ctx.has_res else None), None, None, None, None
 
 
@@ -243,6 +243,9 @@ class _Conv3x3BN(torch.autograd.Function):
                 dw = (dw.float() * scale.view(-1, 1, 1, 1)).to(ctx.wdtype)
             if dx is not None and ctx.gate_input:
                 dx = torch.ops.aten.threshold_backward(dx, x, 0)
+        if own_wgrad:
+            # split-reduction kernel, BN scale folded into its second pass; float32, channels_last like the parameter
+            dw = wgrad_conv3x3_bf16(g, x, ctx.stride, scale).to(ctx.wdtype)
         gate = x if ctx.gate_input else None      # x came out of a ReLU that left its backward to this node
         if own_dgrad and ctx.stride == 1:
             # stride 1: the data gradient is the same convolution with the taps reversed and the channel roles swapped
@@ -251,9 +254,6 @@ class _Conv3x3BN(torch.autograd.Function):
         elif own_dgrad:
             # stride 2: four parity classes of the input pixel, each with its 1 / 2 / 2 / 4 taps (csrc/gemm_bf16.cuh)
             dx = conv3x3_dgrad_s2_bf16(g, w_eff.transpose(0, 1), x.shape[-2:], gate)
-        if own_wgrad:
-            # split-reduction kernel, BN scale folded into its second pass; float32, channels_last like the parameter
-            dw = wgrad_conv3x3_bf16(g, x, ctx.stride, scale).to(ctx.wdtype)
         return dx, dw, None, None, None, None, None, None
 
 

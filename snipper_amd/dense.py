@@ -113,10 +113,10 @@ def wgrad_conv3x3_bf16(g: torch.Tensor, x: torch.Tensor, stride: int, scale: Opt
     Cout = g.shape[1]
     lib = _lib.load()
     nbytes = lib.snipper_wgrad_conv3x3_workspace_bytes(B, H, W, Cin, Cout, int(stride))
-    ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=g.device)
-    dw = torch.empty((Cout, 3, 3, Cin), dtype=torch.float32, device=g.device)
     if scale is not None and scale.dtype != torch.float32:
         scale = scale.float()
+    ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=g.device)
+    dw = torch.empty((Cout, 3, 3, Cin), dtype=torch.float32, device=g.device)
     with _lib.device_guard(g.device):
         rc = lib.snipper_wgrad_conv3x3_bf16(_lib.raw_stream(g.device), g.data_ptr(), x.data_ptr(), B, H, W, Cin, Cout,
                                             int(stride), scale.data_ptr() if scale is not None else None, dw.data_ptr(),
@@ -196,6 +196,8 @@ def wgrad_bf16(g: torch.Tensor, x: torch.Tensor, want_bias: bool = True, scale: 
     M, N = g.shape
     Kc = x.shape[1]
     lib = _lib.load()
+    if scale is not None and scale.dtype != torch.float32:
+        scale = scale.float()
     dW = out if out is not None else torch.empty((N, Kc), dtype=torch.float32, device=g.device)
     assert dW.dtype == torch.float32 and dW.stride(1) == 1 and dW.shape == (N, Kc)
     db = None
@@ -204,8 +206,6 @@ def wgrad_bf16(g: torch.Tensor, x: torch.Tensor, want_bias: bool = True, scale: 
         assert db.dtype == torch.float32 and db.is_contiguous()
     nbytes = lib.snipper_wgrad_workspace_bytes(M, N, Kc)
     ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=g.device)
-    if scale is not None and scale.dtype != torch.float32:
-        scale = scale.float()
     with _lib.device_guard(g.device):
         rc = lib.snipper_wgrad_bf16(
             _lib.raw_stream(g.device), g.data_ptr(), g.stride(0), x.data_ptr(), x.stride(0),
@@ -255,7 +255,6 @@ class _BigLinear(torch.autograd.Function):
         g = g.contiguous()
         if ctx.relu:
             g = _relu_dropout_backward(g, y, ctx.drop_p)
-        dx = _dgrad(g, wb).view(ctx.x_shape) if ctx.needs_input_grad[0] else None
         dW = db = None
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             dW, db = wgrad_bf16(g, xb, want_bias=ctx.has_bias and ctx.needs_input_grad[2])
@@ -263,6 +262,7 @@ class _BigLinear(torch.autograd.Function):
                 dW = dW.to(ctx.w_dtype)
             if db is not None and db.dtype != ctx.b_dtype:
                 db = db.to(ctx.b_dtype)
+        dx = _dgrad(g, wb).view(ctx.x_shape) if ctx.needs_input_grad[0] else None
         return dx, dW, db, None, None
 
 
@@ -301,10 +301,10 @@ class _BigFFN(torch.autograd.Function):
         if g.dtype != torch.bfloat16:
             g = g.to(torch.bfloat16)
         g = g.contiguous()
-        gh = linear_nn_bf16(g, w2b, None, h, 1.0 / (1.0 - ctx.p))            # gradient w.r.t. linear1's pre-activation
         dW2, db2 = wgrad_bf16(g, h)
-        dx = _dgrad(gh, w1b).view(ctx.x_shape) if ctx.needs_input_grad[0] else None
+        gh = linear_nn_bf16(g, w2b, None, h, 1.0 / (1.0 - ctx.p))            # gradient w.r.t. linear1's pre-activation
         dW1, db1 = wgrad_bf16(gh, xb)
+        dx = _dgrad(gh, w1b).view(ctx.x_shape) if ctx.needs_input_grad[0] else None
         outs = [dW1, db1, dW2, db2]
         outs = [o if o.dtype == dt else o.to(dt) for o, dt in zip(outs, ctx.dts)]
         return (dx, *outs, None)
