@@ -259,6 +259,11 @@ int snipper_st_msda_backward(void *stream, const void *grad_out, int grad_out_bf
  *   joint_vis, cont (the caller sums over the pairs of a layer and divides by the number of trajectories).
  * Backward: grad_terms [P, 9] = dL/d(out) -> grad_sk, grad_sd.
  * T * K <= 128, float32. */
+/* Gaussian blur of the heat-map targets (reference models/model.py:447-483: torchvision gaussian_blur of the one-hot joint
+ * maps): out[i] = separable ksize x ksize blur of min(in[i], clamp_max) with reflect padding, n_images maps of H x W
+ * float32.  `weights` is a HOST array of ksize taps (odd, <= 31, ksize / 2 < min(H, W)); in != out. */
+int snipper_heatmap_blur_f32(void *stream, const float *in, float *out, int n_images, int H, int W, int ksize,
+                             const float *weights, float clamp_max);
 int snipper_pair_losses_forward(void *stream, const float *sk, const float *sd, const float *tk, const float *td,
                                 const float *cont_w, const float *max_depth, int n_layers, int pairs, int T, int K,
                                 float eps, float *out);

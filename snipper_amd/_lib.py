@@ -85,6 +85,7 @@ EXPORTS = {
     "snipper_small_attention_backward_f32": ([c_void_p] + [c_void_p, c_longlong, c_longlong] * 4 + [c_void_p] +
                                               [c_void_p, c_longlong, c_longlong] * 4 + [c_int] * 4 +
                                               [ctypes.c_float, ctypes.c_float, ctypes.c_uint64], c_int),
+    "snipper_heatmap_blur_f32": ([c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, ctypes.c_float], c_int),
     "snipper_small_gemm_batch_f32": ([c_void_p, c_void_p, c_int], c_int),
     "snipper_small_linear_forward_f32": ([c_void_p, c_void_p, c_longlong, c_void_p, c_longlong, c_void_p, c_int, c_int, c_int,
                                           c_void_p, c_longlong], c_int),

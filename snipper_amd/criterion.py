@@ -202,9 +202,34 @@ class HungarianMatcher(nn.Module):
 _blur_kernels: Dict = {}
 
 
-def gaussian_blur(img: torch.Tensor, kernel_size: int) -> torch.Tensor:
+def gaussian_blur(img: torch.Tensor, kernel_size: int, clamp_max: Optional[float] = None) -> torch.Tensor:
     """torchvision.transforms.functional.gaussian_blur(img, [k, k]) restated (sigma = 0.3*((k-1)*0.5-1)+0.8,
-    reflect padding, separable kernel).  torchvision is not vendored by the reference: parity unpinned."""
+    reflect padding, separable kernel).  torchvision is not vendored by the reference: parity unpinned.
+    ``clamp_max``: blur ``img.clamp(max=clamp_max)`` (folded into the HIP kernel on the GPU)."""
+    if (img.is_cuda and img.dtype == torch.float32 and img.dim() >= 2 and 1 < kernel_size <= 31 and kernel_size % 2 == 1
+            and kernel_size // 2 < min(img.shape[-2:]) and img.is_contiguous()):
+        # one launch of csrc/heatmap_blur.cuh instead of a padding kernel and two library convolutions
+        import ctypes
+        from . import _lib
+        key = ("taps", kernel_size)
+        taps = _blur_kernels.get(key)
+        if taps is None:                            # the same float32 taps as the tensor formulation below
+            sigma = 0.3 * ((kernel_size - 1) * 0.5 - 1) + 0.8
+            half = (kernel_size - 1) * 0.5
+            xs = torch.linspace(-half, half, kernel_size, dtype=torch.float32)
+            k1 = torch.exp(-0.5 * (xs / sigma) ** 2)
+            k1 = k1 / k1.sum()
+            taps = _blur_kernels[key] = (ctypes.c_float * kernel_size)(*k1.tolist())
+        out = torch.empty_like(img)
+        h, w = img.shape[-2:]
+        with _lib.device_guard(img.device):
+            rc = _lib.load().snipper_heatmap_blur_f32(
+                _lib.raw_stream(img.device), img.data_ptr(), out.data_ptr(), img.numel() // (h * w), h, w, kernel_size,
+                ctypes.cast(taps, ctypes.c_void_p), float("inf") if clamp_max is None else float(clamp_max))
+        _lib.check(rc, "snipper_heatmap_blur_f32")
+        return out
+    if clamp_max is not None:
+        img = img.clamp(max=clamp_max)
     if kernel_size <= 1:
         return img
     key = (kernel_size, str(img.device), img.dtype)
@@ -379,8 +404,8 @@ class SetCriterion(nn.Module):
             lin = (((sample[:, None, None] * K + ki) * t + ti[:, :t]) * h + y) * w + x
             hm = torch.zeros(bs * K * t * h * w, device=device)
             hm.index_add_(0, lin.reshape(-1), ok.reshape(-1).to(hm.dtype))
-            hm = hm.clamp_(max=1).view(bs, K, t, h, w)
-            maps.append(gaussian_blur(hm, ksize).permute(0, 2, 3, 4, 1))             # [bs, t, h, w, K]
+            hm = hm.view(bs, K, t, h, w)
+            maps.append(gaussian_blur(hm, ksize, clamp_max=1.0).permute(0, 2, 3, 4, 1))   # [bs, t, h, w, K]
         return maps
 
     def loss_heatmap(self, outputs, targets):

@@ -21,6 +21,7 @@
 #include "ln_fused.cuh"
 #include "gn_tokens.cuh"
 #include "pair_losses.cuh"
+#include "heatmap_blur.cuh"
 #include "msda_prologue.cuh"
 #include "lsap.cuh"
 #include "msda_d48.cuh"
@@ -478,6 +479,20 @@ int small_attn_check(const void *q, long long q_ld, const void *k, long long k_l
   return SNIPPER_OK;
 }
 }  // namespace
+
+int snipper_heatmap_blur_f32(void *stream, const float *in, float *out, int n_images, int H, int W, int ksize,
+                             const float *weights, float clamp_max) {
+  if (!in || !out || !weights) return SNIPPER_E_NULL;
+  if (n_images <= 0 || H <= 0 || W <= 0 || ksize <= 0 || ksize > kBlurMaxTaps || (ksize & 1) == 0 || ksize / 2 >= H ||
+      ksize / 2 >= W || in == out)
+    return SNIPPER_E_SHAPE;
+  BlurArgs a{};
+  a.in = in; a.out = out; a.n_images = n_images; a.H = H; a.W = W; a.k = ksize; a.clamp_max = clamp_max;
+  for (int i = 0; i < ksize; ++i) a.w[i] = weights[i];              // (host array: the taps travel in the kernel argument)
+  const long long total = (long long)n_images * H * W;
+  hipLaunchKernelGGL(heatmap_blur_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+  return launch_status();
+}
 
 int snipper_small_attention_forward_f32(void *stream, const float *q, long long q_ld, long long q_bs, const float *k,
                                         long long k_ld, long long k_bs, const float *v, long long v_ld, long long v_bs,

@@ -110,3 +110,17 @@ def test_match_cost_kernel_equals_pytorch_formulation(n_dec, bs, nq, T, K, packe
         torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6)
     for a, b in zip(res[True][1][:3], res[False][1][:3]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("h,w,k", [(75, 100, 9), (38, 50, 5), (68, 120, 11), (9, 7, 3), (40, 40, 31)])
+def test_heatmap_blur_kernel_matches_the_convolution_formulation(h, w, k):
+    """csrc/heatmap_blur.cuh (one launch: clamp + reflect padding + separable Gaussian) against the tensor formulation of
+    criterion.gaussian_blur evaluated on the CPU (padding + 2-D convolution with the outer-product kernel)."""
+    from snipper_amd.criterion import gaussian_blur
+    g = torch.Generator().manual_seed(h * 31 + k)
+    img = (torch.rand(2, 5, 3, h, w, generator=g) < 0.02).float() * torch.randint(1, 4, (2, 5, 3, h, w), generator=g).float()
+    want = gaussian_blur(img.clamp(max=1.0), k)                       # CPU path
+    got = gaussian_blur(img.to(DEV), k, clamp_max=1.0)
+    torch.testing.assert_close(got.cpu(), want, rtol=1e-5, atol=1e-6)
+    noclamp = gaussian_blur(img.to(DEV), k)
+    torch.testing.assert_close(noclamp.cpu(), gaussian_blur(img, k), rtol=1e-5, atol=1e-6)
