@@ -80,6 +80,13 @@ typedef struct snipper_small_gemm {
   const float *bias;
   float *colsum;
   int I, J, R;
+  /* optional (zero = absent).  B2 / r_split (b_transposed == 0, r_split % 32 == 0): rows r >= r_split of opB come from
+   * B2[r - r_split] (two stacked weights stored apart).  Epilogue: out = gate(dropout(relu(acc + bias))): relu != 0,
+   * dropout_p with the counter-based hash of (seed, row * J + col), gate [I][J] (ldgate): result * gate_scale where
+   * gate > 0, else 0 -- the backward of ReLU + dropout given the layer's output. */
+  const float *B2; long long ldb2; int r_split;
+  int relu; float dropout_p; unsigned long long seed;
+  const float *gate; long long ldgate; float gate_scale;
 } snipper_small_gemm;
 int snipper_small_gemm_batch_f32(void *stream, const snipper_small_gemm *problems, int count);
 /* convenience: y[M,N] = x[M,K] . W[N,K]^T + b[N] (b may be NULL) */

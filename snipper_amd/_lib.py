@@ -182,7 +182,10 @@ class SmallGemm(ctypes.Structure):
     _fields_ = [("A", c_void_p), ("lda", c_longlong), ("a_transposed", c_int),
                 ("B", c_void_p), ("ldb", c_longlong), ("b_transposed", c_int),
                 ("out", c_void_p), ("ldo", c_longlong), ("bias", c_void_p), ("colsum", c_void_p),
-                ("I", c_int), ("J", c_int), ("R", c_int)]
+                ("I", c_int), ("J", c_int), ("R", c_int),
+                ("B2", c_void_p), ("ldb2", c_longlong), ("r_split", c_int),
+                ("relu", c_int), ("dropout_p", ctypes.c_float), ("seed", ctypes.c_ulonglong),
+                ("gate", c_void_p), ("ldgate", c_longlong), ("gate_scale", ctypes.c_float)]
 
 
 class Config(ctypes.Structure):

@@ -545,9 +545,17 @@ int snipper_small_gemm_batch_f32(void *stream, const snipper_small_gemm *problem
         q.ldb < b_cols || (q.out && q.ldo < q.J))
       return SNIPPER_E_SHAPE;
     if (((uintptr_t)q.A | (uintptr_t)q.B) & 15) return SNIPPER_E_SHAPE;
+    if (q.B2 && (q.b_transposed || q.r_split <= 0 || q.r_split >= q.R || q.r_split % kSgTile || q.ldb2 % 4 || q.ldb2 < q.J ||
+                 ((uintptr_t)q.B2 & 15)))
+      return SNIPPER_E_SHAPE;
+    if (!(q.dropout_p >= 0.f && q.dropout_p < 1.f) || (q.gate && q.ldgate < q.J) ||
+        (q.dropout_p > 0.f && (long long)q.I * q.J >= (1LL << 32)))
+      return SNIPPER_E_SHAPE;
     tiles += ((q.I + kSgTile - 1) / kSgTile) * ((q.J + kSgTile - 1) / kSgTile);
     batch.p[i] = SmallGemmProblem{q.A, q.lda, q.B, q.ldb, q.out, q.ldo, q.bias, q.colsum, q.I, q.J, q.R,
-                                  q.a_transposed ? 1 : 0, q.b_transposed ? 1 : 0, tiles};
+                                  q.a_transposed ? 1 : 0, q.b_transposed ? 1 : 0, tiles,
+                                  q.B2, q.ldb2, q.r_split, q.relu ? 1 : 0, q.dropout_p, (uint32_t)q.seed,
+                                  (uint32_t)(q.seed >> 32), q.gate, q.ldgate, q.gate_scale};
   }
   batch.count = count;
   hipLaunchKernelGGL(small_gemm_batch_f32_kernel, dim3(tiles), dim3(kSgThreads), 0, (hipStream_t)stream, batch);
@@ -556,7 +564,9 @@ int snipper_small_gemm_batch_f32(void *stream, const snipper_small_gemm *problem
 
 int snipper_small_linear_forward_f32(void *stream, const float *X, long long ldx, const float *W, long long ldw,
                                      const float *bias, int M, int N, int K, float *Y, long long ldy) {
-  const snipper_small_gemm q{X, ldx, 0, W, ldw, 1, Y, ldy, bias, nullptr, M, N, K};            // X . W^T + b
+  snipper_small_gemm q{};
+  q.A = X; q.lda = ldx; q.B = W; q.ldb = ldw; q.b_transposed = 1; q.out = Y; q.ldo = ldy; q.bias = bias;     // X . W^T + b
+  q.I = M; q.J = N; q.R = K;
   return snipper_small_gemm_batch_f32(stream, &q, 1);
 }
 
@@ -564,10 +574,16 @@ int snipper_small_linear_backward_f32(void *stream, const float *G, long long ld
                                       const float *W, long long ldw, int M, int N, int K, float *dX, long long lddx,
                                       float *dW, long long lddw, float *db) {
   if (!G || (dX && !W) || ((dW || db) && !X)) return SNIPPER_E_NULL;
-  snipper_small_gemm q[2];
+  snipper_small_gemm q[2] = {};
   int n = 0;
-  if (dX) q[n++] = snipper_small_gemm{G, ldg, 0, W, ldw, 0, dX, lddx, nullptr, nullptr, M, K, N};          // G . W
-  if (dW || db) q[n++] = snipper_small_gemm{G, ldg, 1, X, ldx, 0, dW, lddw, nullptr, db, N, K, M};          // G^T . X, column sums
+  if (dX) {                                                                                                // G . W
+    q[n].A = G; q[n].lda = ldg; q[n].B = W; q[n].ldb = ldw; q[n].out = dX; q[n].ldo = lddx;
+    q[n].I = M; q[n].J = K; q[n].R = N; ++n;
+  }
+  if (dW || db) {                                                                                          // G^T . X, column sums
+    q[n].A = G; q[n].lda = ldg; q[n].a_transposed = 1; q[n].B = X; q[n].ldb = ldx; q[n].out = dW; q[n].ldo = lddw;
+    q[n].colsum = db; q[n].I = N; q[n].J = K; q[n].R = M; ++n;
+  }
   if (n == 0) return SNIPPER_OK;
   return snipper_small_gemm_batch_f32(stream, q, n);
 }

@@ -15,6 +15,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "gemm_bf16.cuh"      // gemm_rand: the counter-based hash shared by the dropout epilogues
 
 namespace snipper {
 
@@ -29,6 +30,13 @@ struct SmallGemmProblem {
   float *colsum;                     // [I] = sum over r of opA(A)[i][r], or nullptr (needs a_tr == 1 or 0 alike)
   int I, J, R, a_tr, b_tr;
   int tile_end;                      // workgroups [previous tile_end, tile_end) belong to this product
+  // B split along the reduction axis (b_tr == 0 only): rows r >= r_split of opB come from B2[r - r_split] -- the data
+  // gradient of two Linears that share their input, g = [ga | gb], W = [Wa; Wb] stored apart.  r_split % 32 == 0.
+  const float *B2; long long ldb2; int r_split;
+  // epilogue: out = gate(dropout(relu(acc + bias))) -- relu / dropout for a forward Linear + ReLU + Dropout, gate for the
+  // data gradient that flows back through such a layer (gate = the layer's OUTPUT h: kept and active <=> h > 0)
+  int relu; float drop_p; uint32_t seed_lo, seed_hi;
+  const float *gate; long long ldgate; float gate_scale;
 };
 struct SmallGemmBatch {
   SmallGemmProblem p[kSgMaxProblems];
@@ -88,7 +96,8 @@ __global__ __launch_bounds__(kSgThreads) void small_gemm_batch_f32_kernel(SmallG
   {
     const int q0 = wave * kSgTile;
     sg_load_tile(g.A, g.lda, a_rows, a_cols, a_tr ? q0 : r0, a_tr ? r0 : q0, va, lane);
-    sg_load_tile(g.B, g.ldb, b_rows, b_cols, b_tr ? c0 : q0, b_tr ? q0 : c0, vb, lane);
+    if (!b_tr && g.B2 && q0 >= g.r_split) sg_load_tile(g.B2, g.ldb2, g.R - g.r_split, b_cols, q0 - g.r_split, c0, vb, lane);
+    else sg_load_tile(g.B, g.ldb, b_tr ? b_rows : (g.B2 ? g.r_split : b_rows), b_cols, b_tr ? c0 : q0, b_tr ? q0 : c0, vb, lane);
   }
   for (int it = 0; it < per_wave; ++it) {
     __syncthreads();                                                      // the previous chunk's reads are done
@@ -98,7 +107,8 @@ __global__ __launch_bounds__(kSgThreads) void small_gemm_batch_f32_kernel(SmallG
     {                                                 // the next chunk: in flight while this one is multiplied (one or
       const int q0 = ((it + 1) * 4 + wave) * kSgTile; // two workgroups per CU: nothing else would hide the latency)
       sg_load_tile(g.A, g.lda, a_rows, a_cols, a_tr ? q0 : r0, a_tr ? r0 : q0, va, lane);
-      sg_load_tile(g.B, g.ldb, b_rows, b_cols, b_tr ? c0 : q0, b_tr ? q0 : c0, vb, lane);
+      if (!b_tr && g.B2 && q0 >= g.r_split) sg_load_tile(g.B2, g.ldb2, g.R - g.r_split, b_cols, q0 - g.r_split, c0, vb, lane);
+      else sg_load_tile(g.B, g.ldb, b_tr ? b_rows : (g.B2 ? g.r_split : b_rows), b_cols, b_tr ? c0 : q0, b_tr ? q0 : c0, vb, lane);
     }
     // MFMA operands: lane l holds A[i = l & 31][k = l >> 5] and B[k = l >> 5][j = l & 31] of each 2-step
 #pragma unroll
@@ -124,6 +134,9 @@ __global__ __launch_bounds__(kSgThreads) void small_gemm_batch_f32_kernel(SmallG
   if (do_sum && lane < kSgTile) csum[wave][lane] = sum_part;
   __syncthreads();
   if (g.out) {
+    const bool drop = g.drop_p > 0.f;
+    const float keep_scale = drop ? 1.f / (1.f - g.drop_p) : 1.f;
+    const uint32_t thresh = (uint32_t)fminf(g.drop_p * 4294967296.f, 4294967040.f);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int e = tid + kSgThreads * i, row = e >> 5, col = e & 31;
@@ -131,6 +144,12 @@ __global__ __launch_bounds__(kSgThreads) void small_gemm_batch_f32_kernel(SmallG
       float s = (P[o] + P[kSgTile * kSgStride + o]) + (P[2 * kSgTile * kSgStride + o] + P[3 * kSgTile * kSgStride + o]);
       if (r0 + row < g.I && c0 + col < g.J) {
         if (g.bias) s += g.bias[c0 + col];
+        if (g.relu) s = fmaxf(s, 0.f);
+        if (drop) {
+          const uint32_t idx = (uint32_t)(r0 + row) * (uint32_t)g.J + (uint32_t)(c0 + col);
+          s = gemm_rand(idx, g.seed_lo, g.seed_hi) >= thresh ? s * keep_scale : 0.f;
+        }
+        if (g.gate) s = g.gate[(long long)(r0 + row) * g.ldgate + c0 + col] > 0.f ? s * g.gate_scale : 0.f;
         g.out[(long long)(r0 + row) * g.ldo + c0 + col] = s;
       }
     }

@@ -234,6 +234,9 @@ class _FFNMixin:
     def _ffn(self, x, drop_a, drop_b, norm):
         if self.activation is F.relu:
             y = big_ffn(x, self.linear1, self.linear2, drop_a)            # the whole block as one node when it applies
+            if y is None:
+                from .dense import small_ffn
+                y = small_ffn(x, self.linear1, self.linear2, drop_a)      # decoder-size float32 rows
             if y is not None:
                 return _residual_norm(x, y, norm, drop_b)
             h = big_linear(x, self.linear1, relu=True, dropout=drop_a)   # ReLU + dropout in the kernel's epilogue

@@ -385,12 +385,27 @@ def small_gemm_batch(problems) -> None:
     """One launch of csrc/small_linear.cuh for a list of float32 products (<= 6).  Each problem is a tuple
     ``(A, a_transposed, B, b_transposed, out, bias, colsum)``:  out[I, J] = opA(A) . opB(B) (+ bias), colsum[I] =
     row sums of opA(A); ``out`` (2-D, unit inner stride: may be a row block of a larger matrix), ``bias`` and ``colsum``
-    may be None (not both out and colsum).  Operands must satisfy ``_sg_ok``."""
+    may be None (not both out and colsum).  Operands must satisfy ``_sg_ok``.  An optional 8th element is a dict of
+    extras: ``B2`` (the rows of opB from ``r_split = B.shape[0]`` on, stored apart), ``relu``, ``drop_p`` + ``seed``,
+    ``gate`` + ``gate_scale`` (include/snipper_dense.h: snipper_small_gemm)."""
     from ._lib import SmallGemm
     n = len(problems)
     arr = (SmallGemm * n)()
     dev = None
-    for q, (A, a_tr, B, b_tr, out, bias, colsum) in zip(arr, problems):
+    for q, prob in zip(arr, problems):
+        A, a_tr, B, b_tr, out, bias, colsum = prob[:7]
+        extra = prob[7] if len(prob) > 7 else None
+        if extra:
+            B2 = extra.get("B2")
+            if B2 is not None:
+                assert not b_tr and B2.shape[1] == B.shape[1]
+                q.B2, q.ldb2, q.r_split = B2.data_ptr(), B2.stride(0), B.shape[0]
+                B = _StackedRows(B, B2)
+            q.relu = int(bool(extra.get("relu", False)))
+            q.dropout_p, q.seed = float(extra.get("drop_p", 0.0)), int(extra.get("seed", 0))
+            gate = extra.get("gate")
+            if gate is not None:
+                q.gate, q.ldgate, q.gate_scale = gate.data_ptr(), gate.stride(0), float(extra.get("gate_scale", 1.0))
         dev = A.device
         I, R = (A.shape[1], A.shape[0]) if a_tr else (A.shape[0], A.shape[1])
         J = B.shape[0] if b_tr else B.shape[1]
@@ -406,6 +421,19 @@ def small_gemm_batch(problems) -> None:
     with _lib.device_guard(dev):
         rc = _lib.load().snipper_small_gemm_batch_f32(_lib.raw_stream(dev), arr, n)
     _lib.check(rc, "snipper_small_gemm_batch_f32")
+
+
+class _StackedRows:
+    """Shape / pointer view of two row blocks [B; B2] stored apart (the B operand of a split-reduction problem)."""
+
+    def __init__(self, b, b2):
+        self.b, self.shape, self.device = b, (b.shape[0] + b2.shape[0], b.shape[1]), b.device
+
+    def data_ptr(self):
+        return self.b.data_ptr()
+
+    def stride(self, i):
+        return self.b.stride(i)
 
 
 def _sg_dense(t: torch.Tensor) -> torch.Tensor:
@@ -462,6 +490,107 @@ def small_linear_backward(g: torch.Tensor, x: torch.Tensor, w: torch.Tensor, nee
                 db.data_ptr() if db is not None else None)
         _lib.check(rc, "snipper_small_linear_backward_f32")
     return dx, dw, db
+
+
+class _SmallFFN(torch.autograd.Function):
+    """linear2(dropout(relu(linear1(x)))) for a few hundred float32 rows (the decoder's feed-forward block, reference
+    models/deformable_transformer.py:266-275) on the small-GEMM kernel: ReLU + dropout in linear1's epilogue; in the
+    backward the gate of the hidden gradient in the data-gradient product of linear2, and each layer's (dX | dH, dW, db)
+    triple as one launch -- 4 launches instead of 8, no mask tensor (a kept, active element of h is > 0)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, p):
+        x2 = _sg_dense(x.reshape(-1, x.shape[-1]))
+        M = x2.shape[0]
+        h = torch.empty((M, w1.shape[0]), dtype=torch.float32, device=x.device)
+        y = torch.empty((M, w2.shape[0]), dtype=torch.float32, device=x.device)
+        seed = 0
+        if p > 0.0:
+            from .fused import _next_seed
+            seed = _next_seed()
+        small_gemm_batch([(x2, False, w1, True, h, b1, None, {"relu": True, "drop_p": p, "seed": seed})])
+        small_gemm_batch([(h, False, w2, True, y, b2, None)])
+        ctx.save_for_backward(x2, w1, w2, h)
+        ctx.p, ctx.x_shape = float(p), x.shape
+        return y.view(*x.shape[:-1], w2.shape[0])
+
+    @staticmethod
+    def backward(ctx, gy):
+        x2, w1, w2, h = ctx.saved_tensors
+        g = _sg_dense(gy.reshape(-1, w2.shape[0]))
+        M = g.shape[0]
+        dev = g.device
+        gh = torch.empty_like(h)
+        dw2, db2 = torch.empty_like(w2), torch.empty((w2.shape[0],), dtype=torch.float32, device=dev)
+        small_gemm_batch([(g, False, w2, False, gh, None, None, {"gate": h, "gate_scale": 1.0 / (1.0 - ctx.p)}),
+                          (g, True, h, False, dw2, None, db2)])
+        dx = torch.empty_like(x2) if ctx.needs_input_grad[0] else None
+        dw1, db1 = torch.empty_like(w1), torch.empty((w1.shape[0],), dtype=torch.float32, device=dev)
+        probs = [(gh, True, x2, False, dw1, None, db1)]
+        if dx is not None:
+            probs.insert(0, (gh, False, w1, False, dx, None, None))
+        small_gemm_batch(probs)
+        return (dx.view(ctx.x_shape) if dx is not None else None), dw1, db1, dw2, db2, None
+
+
+def small_ffn(x: torch.Tensor, lin1: torch.nn.Linear, lin2: torch.nn.Linear, dropout: Optional[torch.nn.Dropout]
+              ) -> Optional[torch.Tensor]:
+    """``lin2(dropout(relu(lin1(x))))`` as one node on the small-GEMM kernel for decoder-size float32 inputs, or None."""
+    rows = x.numel() // max(1, x.shape[-1])
+    ok = (x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled('cuda') and torch.is_grad_enabled() and
+          16 <= rows < BIG_LINEAR_MIN_ROWS and lin1.bias is not None and lin2.bias is not None and
+          lin2.in_features == lin1.out_features and _sg_ok(lin1.weight, lin2.weight) and
+          lin1.bias.is_contiguous() and lin2.bias.is_contiguous() and lin1.out_features % 4 == 0 and
+          lin2.out_features % 4 == 0 and rows * lin1.out_features < 2 ** 32)
+    if not ok:
+        return None
+    p = dropout.p if (dropout is not None and dropout.training) else 0.0
+    return _SmallFFN.apply(x, lin1.weight, lin1.bias, lin2.weight, lin2.bias, float(p))
+
+
+class _SmallLinearPair(torch.autograd.Function):
+    """cat([x @ Wa^T + ba, x @ Wb^T + bb], -1) for decoder-size float32 rows (the cross attention's offset and weight
+    projections): one launch forward (two column blocks of one output), one launch backward (the shared input's gradient
+    as ONE product over the stacked weights [Wa; Wb] read in place, both weight gradients, both bias gradients)."""
+
+    @staticmethod
+    def forward(ctx, x, wa, ba, wb, bb):
+        x2 = _sg_dense(x.reshape(-1, x.shape[-1]))
+        na, nb = wa.shape[0], wb.shape[0]
+        y = torch.empty((x2.shape[0], na + nb), dtype=torch.float32, device=x.device)
+        small_gemm_batch([(x2, False, wa, True, y[:, :na], ba, None), (x2, False, wb, True, y[:, na:], bb, None)])
+        ctx.save_for_backward(x2, wa, wb)
+        ctx.x_shape = x.shape
+        return y.view(*x.shape[:-1], na + nb)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x2, wa, wb = ctx.saved_tensors
+        na, nb = wa.shape[0], wb.shape[0]
+        g = _sg_dense(gy.reshape(-1, na + nb))
+        dev = g.device
+        dwa, dwb = torch.empty_like(wa), torch.empty_like(wb)
+        dba = torch.empty((na,), dtype=torch.float32, device=dev)
+        dbb = torch.empty((nb,), dtype=torch.float32, device=dev)
+        probs = [(g[:, :na], True, x2, False, dwa, None, dba), (g[:, na:], True, x2, False, dwb, None, dbb)]
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x2)
+            probs.insert(0, (g, False, wa, False, dx, None, None, {"B2": wb}))
+        small_gemm_batch(probs)
+        return (dx.view(ctx.x_shape) if dx is not None else None), dwa, dba, dwb, dbb
+
+
+def small_linear_pair(x: torch.Tensor, lin_a: torch.nn.Linear, lin_b: torch.nn.Linear) -> Optional[torch.Tensor]:
+    rows = x.numel() // max(1, x.shape[-1])
+    ok = (x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled('cuda') and torch.is_grad_enabled() and
+          16 <= rows < BIG_LINEAR_MIN_ROWS and lin_a.bias is not None and lin_b.bias is not None and
+          lin_a.in_features == lin_b.in_features and _sg_ok(lin_a.weight, lin_b.weight) and
+          lin_a.out_features % 32 == 0 and lin_b.out_features % 4 == 0 and
+          lin_a.bias.is_contiguous() and lin_b.bias.is_contiguous())
+    if not ok:
+        return None
+    return _SmallLinearPair.apply(x, lin_a.weight, lin_a.bias, lin_b.weight, lin_b.bias)
 
 
 _ones_cache = {}
@@ -521,6 +650,8 @@ def big_linear_merged(x: torch.Tensor, lins) -> Optional[torch.Tensor]:
     in_bf16 = x.dtype == torch.bfloat16 or (torch.is_autocast_enabled('cuda') and
                                              torch.get_autocast_dtype('cuda') == torch.bfloat16)
     k = lins[0].in_features
+    if len(lins) == 2 and rows < BIG_LINEAR_MIN_ROWS:
+        return small_linear_pair(x, lins[0], lins[1])       # decoder-size float32 rows (None when it does not apply)
     if not (x.is_cuda and in_bf16 and rows >= BIG_LINEAR_MIN_ROWS and k % 64 == 0 and
             x.dtype in (torch.bfloat16, torch.float32) and
             all(l.in_features == k and l.out_features % 8 == 0 and l.bias is not None for l in lins)):

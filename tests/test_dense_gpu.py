@@ -521,3 +521,55 @@ def test_small_gemm_batch_all_operand_forms_in_one_launch():
     x, w, b = r(480, 384), r(1024, 384), r(1024)
     y = small_linear_forward(x, w, b)
     assert float((d(y) - (d(x) @ d(w).t() + d(b))).abs().max()) <= 1e-4
+
+
+@pytest.mark.parametrize("p", [0.0, 0.1])
+def test_small_ffn_node_matches_the_composition(p, monkeypatch):
+    """Decoder feed-forward block as one node on the small-GEMM kernel (ReLU + dropout in the first launch's epilogue,
+    the gate in the data-gradient product): against linear2(dropout(relu(linear1(x)))) written out in PyTorch under the
+    node's own dropout mask (recovered from the zeros of its hidden activation)."""
+    import snipper_amd.fused as fused
+    from snipper_amd import dense
+    monkeypatch.setattr(fused, "_next_seed", lambda: 99991)
+    torch.manual_seed(5)
+    lin1, lin2 = torch.nn.Linear(384, 1024).to(DEV), torch.nn.Linear(1024, 384).to(DEV)
+    drop = torch.nn.Dropout(p)
+    x = torch.randn(2, 4, 60, 384, device=DEV, requires_grad=True)
+    gy = torch.randn(2, 4, 60, 384, device=DEV)
+    y = dense.small_ffn(x, lin1, lin2, drop)
+    assert y is not None
+    params = [lin1.weight, lin1.bias, lin2.weight, lin2.bias]
+    g1 = torch.autograd.grad(y, [x] + params, gy)
+    # the mask: run the first launch alone with the same seed
+    h_kernel = torch.empty(480, 1024, device=DEV)
+    dense.small_gemm_batch([(x.detach().reshape(480, 384), False, lin1.weight.detach(), True, h_kernel, lin1.bias.detach(),
+                             None, {"relu": True, "drop_p": p, "seed": 99991})])
+    pre = torch.relu(lin1(x))
+    keep = ((h_kernel > 0) | (pre.reshape(480, 1024) <= 0)).float().view_as(pre)      # dropped = active but zero in h
+    if p > 0:
+        frac = float(((h_kernel > 0).float().sum() / (pre > 0).float().sum()))
+        assert abs(frac - (1 - p)) < 0.01, frac
+    yr = lin2(pre * keep / (1 - p))
+    g2 = torch.autograd.grad(yr, [x] + params, gy)
+    torch.testing.assert_close(y, yr, rtol=1e-4, atol=1e-4)
+    for a, b in zip(g1, g2):
+        torch.testing.assert_close(a, b, rtol=1e-3, atol=1e-3 * float(b.abs().max()))
+
+
+def test_small_linear_pair_matches_two_linears():
+    """The cross attention's offset + weight projections of the decoder as one launch each way (stacked weights read in
+    place for the shared input's gradient) against the two nn.Linear modules."""
+    from snipper_amd.dense import big_linear_merged
+    torch.manual_seed(6)
+    la, lb = torch.nn.Linear(384, 192).to(DEV), torch.nn.Linear(384, 96).to(DEV)
+    x = torch.randn(2, 4, 60, 384, device=DEV, requires_grad=True)
+    gy = torch.randn(2, 4, 60, 288, device=DEV)
+    y = big_linear_merged(x, [la, lb])
+    assert y is not None and y.shape == (2, 4, 60, 288)
+    params = [la.weight, la.bias, lb.weight, lb.bias]
+    g1 = torch.autograd.grad(y, [x] + params, gy)
+    yr = torch.cat([la(x), lb(x)], -1)
+    g2 = torch.autograd.grad(yr, [x] + params, gy)
+    torch.testing.assert_close(y, yr, rtol=1e-5, atol=2e-5)
+    for a, b in zip(g1, g2):
+        torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-4)
