@@ -196,9 +196,11 @@ int snipper_wgrad_conv3x3_bf16(void *stream, const uint16_t *G, const uint16_t *
                                size_t workspace_bytes);
 /* `gate` (optional, the layout of the result, 16-byte aligned, not together with relu): results whose gate value is not > 0
  * are written as 0.  A data gradient is itself such a convolution; when the activation it differentiates came out of a
- * ReLU, passing that activation as the gate does the ReLU's backward in the store phase (no separate pass). */
+ * ReLU, passing that activation as the gate does the ReLU's backward in the store phase (no separate pass).
+ * `flip_taps` != 0: tap (ky, kx) multiplies W[:, 2 - ky, 2 - kx, :] -- with the weight's channel axes swapped that is the
+ * stride-1 data gradient (no flipped copy of the weight). */
 int snipper_conv3x3_bf16(void *stream, const uint16_t *X, const uint16_t *W, const float *bias, uint16_t *Y,
-                         int B, int H, int Wd, int Cin, int Cout, int stride, int relu, const uint16_t *gate);
+                         int B, int H, int Wd, int Cin, int Cout, int stride, int relu, const uint16_t *gate, int flip_taps);
 
 /* ---- element-wise fusions around the core op (csrc/msda_prologue.cuh) --------------------------------
  * dtype codes: 0 = float32, 1 = bfloat16 bits.

@@ -55,7 +55,7 @@ EXPORTS = {
     "snipper_colsum_workspace_bytes": ([c_int] * 3, c_size_t),
     "snipper_colsum_segments_bf16": ([c_void_p, c_void_p, c_longlong, c_int, c_int, c_int, c_void_p, c_void_p,
                                       c_size_t], c_int),
-    "snipper_conv3x3_bf16": ([c_void_p] * 5 + [c_int] * 7 + [c_void_p], c_int),
+    "snipper_conv3x3_bf16": ([c_void_p] * 5 + [c_int] * 7 + [c_void_p, c_int], c_int),
     "snipper_stem7x7_bf16": ([c_void_p] * 4 + [c_int] * 3, c_int),
     "snipper_conv3x3_dgrad_s2_bf16": ([c_void_p] * 4 + [c_int] * 5 + [c_void_p], c_int),
     "snipper_wgrad_conv3x3_workspace_bytes": ([c_int] * 6, c_size_t),

@@ -249,8 +249,9 @@ class _Conv3x3BN(torch.autograd.Function):
         gate = x if ctx.gate_input else None      # x came out of a ReLU that left its backward to this node
         if own_dgrad and ctx.stride == 1:
             # stride 1: the data gradient is the same convolution with the taps reversed and the channel roles swapped
-            w_t = w_eff.flip(2, 3).transpose(0, 1).contiguous(memory_format=torch.channels_last)
-            dx = conv3x3_bf16(g, w_t, None, 1, False, gate)
+            # (the kernel reverses the taps itself; only the channel axes are swapped here)
+            w_t = w_eff.transpose(0, 1).contiguous(memory_format=torch.channels_last)
+            dx = conv3x3_bf16(g, w_t, None, 1, False, gate, flip_taps=True)
         elif own_dgrad:
             # stride 2: four parity classes of the input pixel, each with its 1 / 2 / 2 / 4 taps (csrc/gemm_bf16.cuh)
             dx = conv3x3_dgrad_s2_bf16(g, w_eff.transpose(0, 1), x.shape[-2:], gate)

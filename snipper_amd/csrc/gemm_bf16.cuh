@@ -569,6 +569,10 @@ struct Conv3x3Args {
   // gate (optional, the layout of Y): outputs whose gate value is not > 0 are written as 0 -- when this launch is a data
   // gradient and Y's activation came out of a ReLU, that ReLU's backward happens here, in the store phase
   const uint16_t *gate;
+  // flip != 0: the weight is read with its taps reversed (tap (ky, kx) uses W[:, 2 - ky, 2 - kx, :]) -- the stride-1 data
+  // gradient is the same convolution with reversed taps and swapped channel roles, so the caller only has to swap the
+  // channel axes of the weight, not to flip it as well
+  int flip;
 };
 
 // BN = 128 or 64 output channels per workgroup (64: each wave 64 x 32, more workgroups per CU; the launcher takes it when
@@ -622,7 +626,7 @@ void conv3x3_bf16_kernel(Conv3x3Args g) {
     // pixel a + (cy + 1 - ky) / 2
     const int ky = g.dgrad2 ? (g.cy ? 2 * ty : 1) : ty, kx = g.dgrad2 ? (g.cx ? 2 * tx : 1) : tx;
     const int dy = g.dgrad2 ? (g.cy + 1 - ky) / 2 : ky, dx = g.dgrad2 ? (g.cx + 1 - kx) / 2 : kx;
-    const int tap = ky * 3 + kx;
+    const int tap = g.flip ? 8 - (ky * 3 + kx) : ky * 3 + kx;      // (which slice of W this step multiplies)
     const int dpix = dy * g.Wd + dx;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {

@@ -828,7 +828,7 @@ inline unsigned conv_grid_n64(long long M, int Cout) {
 }  // namespace
 
 int snipper_conv3x3_bf16(void *stream, const uint16_t *X, const uint16_t *W, const float *bias, uint16_t *Y,
-                         int B, int H, int Wd, int Cin, int Cout, int stride, int relu, const uint16_t *gate) {
+                         int B, int H, int Wd, int Cin, int Cout, int stride, int relu, const uint16_t *gate, int flip_taps) {
   if (!X || !W || !Y) return SNIPPER_E_NULL;
   if (gate && (((uintptr_t)gate & 15) || relu)) return SNIPPER_E_SHAPE;
   if (B <= 0 || H <= 0 || Wd <= 0 || Cin <= 0 || Cout <= 0 || Cin % kGemmBK || Cout % 4 || (stride != 1 && stride != 2))
@@ -836,7 +836,7 @@ int snipper_conv3x3_bf16(void *stream, const uint16_t *X, const uint16_t *W, con
   const int Ho = (H - 1) / stride + 1, Wo = (Wd - 1) / stride + 1;
   const long long M = (long long)B * Ho * Wo;
   if (M >= (1LL << 31) || (long long)B * H * Wd * Cin >= (1LL << 30)) return SNIPPER_E_SHAPE;   // (32-bit byte offsets)
-  const Conv3x3Args g{X, W, bias, Y, B, H, Wd, Cin, Cout, Ho, Wo, stride, 0, 0, 0, 0, 0, gate};
+  const Conv3x3Args g{X, W, bias, Y, B, H, Wd, Cin, Cout, Ho, Wo, stride, 0, 0, 0, 0, 0, gate, flip_taps ? 1 : 0};
   if (conv_use_n64(M, Cout)) {
     const dim3 grid64(conv_grid_n64(M, Cout));
     if (relu) hipLaunchKernelGGL((conv3x3_bf16_kernel<true, 64>), grid64, dim3(kGemmThreads), 0, (hipStream_t)stream, g);
@@ -875,7 +875,7 @@ int snipper_conv3x3_dgrad_s2_bf16(void *stream, const uint16_t *G, const uint16_
     for (int cx = 0; cx < 2; ++cx) {
       const int Hc = (Hx - cy + 1) / 2, Wc = (Wx - cx + 1) / 2;    // input pixels (2a + cy, 2b + cx) of this class
       if (Hc <= 0 || Wc <= 0) continue;
-      const Conv3x3Args g{G, Wt, nullptr, dX, B, Hg, Wg, Cg, Cx, Hc, Wc, 1, 1, cy, cx, Hx, Wx, gate};
+      const Conv3x3Args g{G, Wt, nullptr, dX, B, Hg, Wg, Cg, Cx, Hc, Wc, 1, 1, cy, cx, Hx, Wx, gate, 0};
       const long long Mc = (long long)B * Hc * Wc;
       if (conv_use_n64(Mc, Cx))
         hipLaunchKernelGGL((conv3x3_bf16_kernel<false, 64>), dim3(conv_grid_n64(Mc, Cx)), dim3(kGemmThreads), 0,

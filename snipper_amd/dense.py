@@ -54,9 +54,10 @@ def _gate_ptr(gate: Optional[torch.Tensor], like: torch.Tensor):
 
 
 def conv3x3_bf16(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, stride: int = 1,
-                 relu: bool = False, gate: Optional[torch.Tensor] = None) -> torch.Tensor:
+                 relu: bool = False, gate: Optional[torch.Tensor] = None, flip_taps: bool = False) -> torch.Tensor:
     """act(conv2d(x, weight, padding=1, stride=stride) + bias) on the implicit-GEMM HIP kernel.  ``gate`` (shape of the
     result): results whose gate is not > 0 are written as 0 (a ReLU backward fused into a data gradient's store phase).
+    ``flip_taps``: the kernel reads the weight with reversed taps (``weight.flip(2, 3)`` without the copy).
 
     x [B, Cin, H, W] bf16 in channels_last memory, weight [Cout, Cin, 3, 3] bf16 in channels_last memory (i.e.
     [Cout][3][3][Cin] contiguous), bias [Cout] float32 or None  ->  [B, Cout, Ho, Wo] bf16, channels_last."""
@@ -74,7 +75,8 @@ def conv3x3_bf16(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Ten
     with _lib.device_guard(x.device):
         rc = _lib.load().snipper_conv3x3_bf16(
             _lib.raw_stream(x.device), x.data_ptr(), weight.data_ptr(),
-            bias.data_ptr() if bias is not None else None, out.data_ptr(), B, H, W, Cin, Cout, int(stride), int(relu), gp)
+            bias.data_ptr() if bias is not None else None, out.data_ptr(), B, H, W, Cin, Cout, int(stride), int(relu), gp,
+            int(flip_taps))
     _lib.check(rc, "snipper_conv3x3_bf16")
     return out
 
