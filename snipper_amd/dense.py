@@ -383,59 +383,53 @@ def _sg_ok(*ts) -> bool:
                t.shape[1] % 4 == 0 and t.data_ptr() % 16 == 0 for t in ts)
 
 
+_SG_FMT = "@PqiPqiPqPPiiiPqiifQPqf0P"      # include/snipper_dense.h: snipper_small_gemm (native alignment, padded to 8)
+
+
 def small_gemm_batch(problems) -> None:
     """One launch of csrc/small_linear.cuh for a list of float32 products (<= 6).  Each problem is a tuple
     ``(A, a_transposed, B, b_transposed, out, bias, colsum)``:  out[I, J] = opA(A) . opB(B) (+ bias), colsum[I] =
     row sums of opA(A); ``out`` (2-D, unit inner stride: may be a row block of a larger matrix), ``bias`` and ``colsum``
     may be None (not both out and colsum).  Operands must satisfy ``_sg_ok``.  An optional 8th element is a dict of
     extras: ``B2`` (the rows of opB from ``r_split = B.shape[0]`` on, stored apart), ``relu``, ``drop_p`` + ``seed``,
-    ``gate`` + ``gate_scale`` (include/snipper_dense.h: snipper_small_gemm)."""
-    from ._lib import SmallGemm
-    n = len(problems)
-    arr = (SmallGemm * n)()
+    ``gate`` + ``gate_scale`` (include/snipper_dense.h: snipper_small_gemm).
+    (The argument array is packed with ``struct`` -- setting ~20 ctypes fields per problem cost more host time than the
+    launch itself.)"""
+    import struct
+    parts = []
     dev = None
-    for q, prob in zip(arr, problems):
+    for prob in problems:
         A, a_tr, B, b_tr, out, bias, colsum = prob[:7]
         extra = prob[7] if len(prob) > 7 else None
+        dev = A.device
+        b2p, ldb2, r_split, relu, drop_p, seed, gatep, ldgate, gate_scale = 0, 0, 0, 0, 0.0, 0, 0, 0, 0.0
+        b_rows = B.shape[0]
         if extra:
             B2 = extra.get("B2")
             if B2 is not None:
                 assert not b_tr and B2.shape[1] == B.shape[1]
-                q.B2, q.ldb2, q.r_split = B2.data_ptr(), B2.stride(0), B.shape[0]
-                B = _StackedRows(B, B2)
-            q.relu = int(bool(extra.get("relu", False)))
-            q.dropout_p, q.seed = float(extra.get("drop_p", 0.0)), int(extra.get("seed", 0))
+                b2p, ldb2, r_split = B2.data_ptr(), B2.stride(0), B.shape[0]
+                b_rows += B2.shape[0]
+            relu = int(bool(extra.get("relu", False)))
+            drop_p, seed = float(extra.get("drop_p", 0.0)), int(extra.get("seed", 0))
             gate = extra.get("gate")
             if gate is not None:
-                q.gate, q.ldgate, q.gate_scale = gate.data_ptr(), gate.stride(0), float(extra.get("gate_scale", 1.0))
-        dev = A.device
+                gatep, ldgate, gate_scale = gate.data_ptr(), gate.stride(0), float(extra.get("gate_scale", 1.0))
         I, R = (A.shape[1], A.shape[0]) if a_tr else (A.shape[0], A.shape[1])
         J = B.shape[0] if b_tr else B.shape[1]
-        assert (B.shape[1] if b_tr else B.shape[0]) == R
+        assert (B.shape[1] if b_tr else b_rows) == R
+        outp, ldo = 0, 0
         if out is not None:
             assert out.dtype == torch.float32 and out.shape == (I, J) and out.stride(1) == 1
-        q.A, q.lda, q.a_transposed = A.data_ptr(), A.stride(0), int(bool(a_tr))
-        q.B, q.ldb, q.b_transposed = B.data_ptr(), B.stride(0), int(bool(b_tr))
-        q.out, q.ldo = (out.data_ptr(), out.stride(0)) if out is not None else (None, 0)
-        q.bias = bias.data_ptr() if bias is not None else None
-        q.colsum = colsum.data_ptr() if colsum is not None else None
-        q.I, q.J, q.R = I, J, R
+            outp, ldo = out.data_ptr(), out.stride(0)
+        parts.append(struct.pack(_SG_FMT, A.data_ptr(), A.stride(0), int(bool(a_tr)), B.data_ptr(), B.stride(0),
+                                 int(bool(b_tr)), outp, ldo, bias.data_ptr() if bias is not None else 0,
+                                 colsum.data_ptr() if colsum is not None else 0, I, J, R, b2p, ldb2, r_split, relu,
+                                 drop_p, seed, gatep, ldgate, gate_scale))
+    buf = b"".join(parts)
     with _lib.device_guard(dev):
-        rc = _lib.load().snipper_small_gemm_batch_f32(_lib.raw_stream(dev), arr, n)
+        rc = _lib.load().snipper_small_gemm_batch_f32(_lib.raw_stream(dev), buf, len(problems))
     _lib.check(rc, "snipper_small_gemm_batch_f32")
-
-
-class _StackedRows:
-    """Shape / pointer view of two row blocks [B; B2] stored apart (the B operand of a split-reduction problem)."""
-
-    def __init__(self, b, b2):
-        self.b, self.shape, self.device = b, (b.shape[0] + b2.shape[0], b.shape[1]), b.device
-
-    def data_ptr(self):
-        return self.b.data_ptr()
-
-    def stride(self, i):
-        return self.b.stride(i)
 
 
 def _sg_dense(t: torch.Tensor) -> torch.Tensor:
