@@ -205,6 +205,11 @@ bool make_patch_plan(const CoreDims &d, const int64_t *hs, const snipper_msda_co
   }
   p.nblocks = bbase;
   p.total_tiles = tbase;
+  for (int a = 0; a < d.L; ++a)
+    for (int b = 0; b < d.L; ++b) {      // IEEE float division on the host == __fdiv_rn on the device
+      p.rw[a][b] = (float)p.lv[a].W / (float)p.lv[b].W;
+      p.rh[a][b] = (float)p.lv[a].H / (float)p.lv[b].H;
+    }
   // marks geometry: bounds of the candidate block rectangles (patch_tile_cand: the span (edge + 1 + 2R) pixels of
   // level l rescaled to level lq, +2 cells of margin and +2 for rounding, in blocks of 8 queries, +2 for alignment)
   long long lvl_base = 0;
@@ -232,13 +237,16 @@ bool make_patch_plan(const CoreDims &d, const int64_t *hs, const snipper_msda_co
   return true;
 }
 
+// workspace of the owner-computes backward: the marks
+inline long long patch_workspace_bytes(long long nm, const PatchPlan &plan) { return nm * plan.words_per_nm * 8; }
+
 template <typename VT>
 int backward_d48_patch(hipStream_t st, const void *grad_out, const VT *value, const float *loc, const float *attn,
                        CoreDims d, PatchPlan plan, void *workspace, float *grad_value, float *grad_loc,
                        float *grad_attn, int go_bf16) {
   const long long nm = (long long)d.N * d.M;
   plan.marks = reinterpret_cast<unsigned long long *>(workspace);
-  hipError_t e = hipMemsetAsync(plan.marks, 0, (size_t)(nm * plan.words_per_nm) * 8, st);
+  hipError_t e = hipMemsetAsync(plan.marks, 0, (size_t)patch_workspace_bytes(nm, plan), st);
   if (e != hipSuccess) return (int)e;
   // 1) query side: grad_loc / grad_attn, marks, HBM atomics for the taps no tile owns
   const long long nblk = nm * plan.nblocks;
@@ -338,7 +346,7 @@ long long snipper_msda_backward_ex_workspace_bytes(const snipper_msda_config *cf
   const snipper_msda_config c = resolve(cfg);
   if (!owner_shape_ok(d, host_shapes, c.policy)) return 0;
   PatchPlan plan;
-  return make_patch_plan(d, host_shapes, c, &plan) ? (long long)N * M * plan.words_per_nm * 8 : 0;
+  return make_patch_plan(d, host_shapes, c, &plan) ? patch_workspace_bytes((long long)N * M, plan) : 0;
 }
 
 int snipper_msda_backward_ex(void *stream, const snipper_msda_config *cfg, const int64_t *host_shapes, void *workspace,
@@ -365,7 +373,7 @@ int snipper_msda_backward_ex(void *stream, const snipper_msda_config *cfg, const
     if (int rc = zero_grad_value(st, (float *)grad_value, d)) return rc;
     if (workspace && owner_shape_ok(d, host_shapes, c.policy)) {       // encoder shape: owner-computes (marks + sorted taps)
       PatchPlan plan;
-      if (make_patch_plan(d, host_shapes, c, &plan) && workspace_bytes >= (long long)N * M * plan.words_per_nm * 8)
+      if (make_patch_plan(d, host_shapes, c, &plan) && workspace_bytes >= patch_workspace_bytes((long long)N * M, plan))
         return backward_d48_patch<uint16_t>(st, grad_out, (const uint16_t *)value, (const float *)loc, (const float *)attn, d,
                                             plan, workspace, (float *)grad_value, (float *)grad_loc, (float *)grad_attn, 1);
     }
@@ -381,7 +389,7 @@ int snipper_msda_backward_ex(void *stream, const snipper_msda_config *cfg, const
   if (int rc = zero_grad_value(st, gv, d)) return rc;
   if (workspace && owner_shape_ok(d, host_shapes, c.policy)) {
     PatchPlan plan;
-    if (make_patch_plan(d, host_shapes, c, &plan) && workspace_bytes >= (long long)N * M * plan.words_per_nm * 8)
+    if (make_patch_plan(d, host_shapes, c, &plan) && workspace_bytes >= patch_workspace_bytes((long long)N * M, plan))
       return backward_d48_patch<float>(st, grad_out, v, lo, at, d, plan, workspace, gv, gl, ga, go_bf16);
   }
   if (d48_eligible<float>(d, c.policy))

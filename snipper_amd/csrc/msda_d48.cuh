@@ -217,6 +217,9 @@ __device__ __forceinline__ float px_coord(float l, int size) { return __fmaf_rn(
 __device__ __forceinline__ float anchor_coord(int qi, int size_l, int size_lq) {
   return __fmaf_rn((float)qi + 0.5f, __fdiv_rn((float)size_l, (float)size_lq), -0.5f);
 }
+// the same with the ratio size_l / size_lq handed in: the host computes it with one IEEE float division (bit-identical to
+// __fdiv_rn), so the kernels do no divisions for it
+__device__ __forceinline__ float anchor_from_ratio(int qi, float ratio) { return __fmaf_rn((float)qi + 0.5f, ratio, -0.5f); }
 __device__ __forceinline__ bool near_anchor(float x, float y, float ax, float ay, float R) {
   return (fabsf(x - ax) <= R) && (fabsf(y - ay) <= R);
 }

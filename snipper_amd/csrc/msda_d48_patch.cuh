@@ -70,6 +70,9 @@ struct PatchPlan {
   long long lvl_base[kPatchMaxLevels];
   long long words_per_nm;
   unsigned long long *marks;    // [N*M][words_per_nm], zeroed per backward call
+  // size ratios rw[a][b] = (float)W_a / (float)W_b (rh likewise), computed on the host with IEEE float division: the
+  // anchor arithmetic both kernels must agree on, without per-thread divisions (bit-identical to __fdiv_rn)
+  float rw[kPatchMaxLevels][kPatchMaxLevels], rh[kPatchMaxLevels][kPatchMaxLevels];
   int L, nblocks, total_tiles;
   float radius;    // a sample is "near" when |pixel - anchor| <= radius on both axes
   int debug;       // timing ablations (config.reserved[0]; results are WRONG when != 0): 1 no row staging, 2 no gather /
@@ -139,8 +142,7 @@ __device__ __forceinline__ Row6 buf_row(__amdgpu_buffer_rsrc_t rsrc, unsigned of
 // ------------------------------------------------------------------------------------------------------------------
 // conservative index range of the queries of an axis with n_lq cells whose anchor, expressed in the sampled level
 // (n_l cells), can fall in [lo_px, hi_px]
-__device__ __forceinline__ void patch_anchor_range(float lo_px, float hi_px, int n_l, int n_lq, int &i0, int &i1) {
-  const float inv = __fdiv_rn((float)n_lq, (float)n_l);
+__device__ __forceinline__ void patch_anchor_range(float lo_px, float hi_px, float inv, int n_lq, int &i0, int &i1) {
   i0 = (int)floorf(__fmaf_rn(lo_px + 0.5f, inv, -0.5f)) - 1;
   i1 = (int)ceilf(__fmaf_rn(hi_px + 0.5f, inv, -0.5f)) + 1;
   i0 = i0 < 0 ? 0 : i0;
@@ -151,16 +153,17 @@ __device__ __forceinline__ void patch_anchor_range(float lo_px, float hi_px, int
 __device__ __forceinline__ void patch_tile_cand(const PatchPlan &p, int l, int lq, int ty0, int tx0, int edge,
                                                 int &bx0, int &bx1, int &by0, int &by1) {
   int qx0, qx1, qy0, qy1;
-  patch_anchor_range((float)(tx0 - 1) - p.radius, (float)(tx0 + edge) + p.radius, p.lv[l].W, p.lv[lq].W, qx0, qx1);
-  patch_anchor_range((float)(ty0 - 1) - p.radius, (float)(ty0 + edge) + p.radius, p.lv[l].H, p.lv[lq].H, qy0, qy1);
+  patch_anchor_range((float)(tx0 - 1) - p.radius, (float)(tx0 + edge) + p.radius, p.rw[lq][l], p.lv[lq].W, qx0, qx1);
+  patch_anchor_range((float)(ty0 - 1) - p.radius, (float)(ty0 + edge) + p.radius, p.rh[lq][l], p.lv[lq].H, qy0, qy1);
   bx0 = qx0 >> 3; bx1 = qx1 >> 3; by0 = qy0 >> 3; by1 = qy1 >> 3;
 }
 // tiles of level l that near taps of block b can touch (anchor range +- (R + 1), clipped to the map)
 struct PatchTileBox { int tx0, ty0, ntx, nty; };
 __device__ __forceinline__ PatchTileBox patch_tile_box(const PatchPlan &p, const PatchBlock &b, int l) {
-  const PatchLevel &s = p.lv[l], &q = p.lv[b.lq];
-  const float ax0 = anchor_coord(b.qx0, s.W, q.W), ax1 = anchor_coord(b.qx0 + b.bw - 1, s.W, q.W);
-  const float ay0 = anchor_coord(b.qy0, s.H, q.H), ay1 = anchor_coord(b.qy0 + b.bh - 1, s.H, q.H);
+  const PatchLevel &s = p.lv[l];
+  const float rw = p.rw[l][b.lq], rh = p.rh[l][b.lq];
+  const float ax0 = anchor_from_ratio(b.qx0, rw), ax1 = anchor_from_ratio(b.qx0 + b.bw - 1, rw);
+  const float ay0 = anchor_from_ratio(b.qy0, rh), ay1 = anchor_from_ratio(b.qy0 + b.bh - 1, rh);
   const int x0 = max(0, (int)floorf(ax0 - p.radius) - 1), x1 = min(s.W - 1, (int)ceilf(ax1 + p.radius) + 1);
   const int y0 = max(0, (int)floorf(ay0 - p.radius) - 1), y1 = min(s.H - 1, (int)ceilf(ay1 + p.radius) + 1);
   PatchTileBox t;
@@ -351,8 +354,8 @@ __global__ __launch_bounds__(kPatchThreads) void msda_bwd_d48_patchbin_kernel(
       const float a_in = a_l[l];
       const float y = px_coord(xy.y, lvl.H), x = px_coord(xy.x, lvl.W);
       const bool inside = rd_ok && (y > -1.f) && (x > -1.f) && (y < (float)lvl.H) && (x < (float)lvl.W);
-      const bool near = inside && near_anchor(x, y, anchor_coord(b.qx0 + rdx, lvl.W, lvq.W),
-                                              anchor_coord(b.qy0 + rdy, lvl.H, lvq.H), plan.radius);
+      const bool near = inside && near_anchor(x, y, anchor_from_ratio(b.qx0 + rdx, plan.rw[l][b.lq]),
+                                              anchor_from_ratio(b.qy0 + rdy, plan.rh[l][b.lq]), plan.radius);
       const float yf = floorf(y), xf = floorf(x);
       const int y0 = (int)yf, x0 = (int)xf;
       PatchRec r;
@@ -499,6 +502,14 @@ __device__ __forceinline__ int hit_query(const PatchPlan &p, unsigned hit, int &
     if (lq == i) { start = p.lv[i].start; Wq = p.lv[i].W; Hq = p.lv[i].H; }
   }
   return start + qy * Wq + qx;
+}
+// size ratios of the tile's level l (uniform) over the hit's query level lq (per lane): the same select chain
+__device__ __forceinline__ void hit_ratios(const PatchPlan &p, int l, int lq, float &rw, float &rh) {
+  rw = p.rw[l][0]; rh = p.rh[l][0];
+#pragma unroll
+  for (int i = 1; i < kPatchMaxLevels; ++i) {
+    if (lq == i) { rw = p.rw[l][i]; rh = p.rh[l][i]; }
+  }
 }
 
 template <int HITCAP, bool GO_BF16>
@@ -650,7 +661,9 @@ __global__ __launch_bounds__(kPatchThreads) __attribute__((amdgpu_waves_per_eu(3
         if (inside) {
           int lq, qy, qx, Wq, Hq;
           hit_query(plan, S.hits[lo + h], lq, qy, qx, Wq, Hq);
-          if (near_anchor(x, y, anchor_coord(qx, me.W, Wq), anchor_coord(qy, me.H, Hq), plan.radius)) {
+          float rwq, rhq;
+          hit_ratios(plan, l, lq, rwq, rhq);
+          if (near_anchor(x, y, anchor_from_ratio(qx, rwq), anchor_from_ratio(qy, rhq), plan.radius)) {
             const float a = n_a[it];
             const float yf = floorf(y), xf = floorf(x);
             const int y0 = (int)yf, x0 = (int)xf;
@@ -771,7 +784,9 @@ __global__ __launch_bounds__(kPatchThreads) __attribute__((amdgpu_waves_per_eu(3
       }
     }
   }
-  // ---- add the tile to grad_value: plain read-modify-write (the query-side kernel has finished; tiles are disjoint) ----
+  // ---- add the tile to grad_value: plain read-modify-write (the query-side kernel has finished; tiles are disjoint).
+  //      (A per-tile "dirty" bit set by the query side's atomics, to let clean tiles store without reading, was measured:
+  //      no gain when nothing is far, and the bit's global atomics cost 4 - 20 ms per launch when 20 % of the taps are.) ----
   const size_t img_base = ((size_t)n * d.S + me.start) * d.M;
 #pragma unroll
   for (int u = 0; u < kMaxU; ++u) {
