@@ -137,6 +137,8 @@ __device__ __forceinline__ unsigned gemm_pack2(float a, float b) {
 // of the current one.  Measured with 3 workgroups per CU resident for the whole launch: no gain over one tile per
 // workgroup (79 000 x 384 x 384: 44.4 vs 44.6 us; x1024: 96 vs 92 us) -- the dispatcher already starts a new workgroup
 // while its two neighbours compute -- so the launcher uses gemm_grid_size() workgroups, one tile each.
+// Also measured without gain: a cross-workgroup L2 prefetch (the first N tile's workgroup touches the X rows of the M tile
+// its XCD starts 4 / 12 / 32 tiles later): 79 000 x 384 x 384 45.2 -> 46.5 - 46.7 us, every other shape equal or slower.
 template <bool RELU>
 __global__ __launch_bounds__(kGemmThreads) __attribute__((amdgpu_waves_per_eu(3, 3))) void linear_bf16_kernel(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) uint16_t smem[(kGemmBM + kGemmBN) * kGemmPad];
