@@ -394,18 +394,40 @@ class SetCriterion(nn.Module):
         xy = torch.minimum(xy.clamp(min=0), lim - 1)
         ti = torch.arange(t_all, device=device)[None, :, None]
         ki = torch.arange(K, device=device)[None, None, :]
+        ksizes = [max(h // 10 + h // 10 % 2 - 1, w // 10 + w // 10 % 2 - 1) for _, h, w in spatial]
+        # One scatter-add over the flattened [bs, K, t, h, w] maps.  No boolean-mask indexing (it would read the count
+        # back to the host) and no multi-index index_put_ (its accumulate path range-checks every index tensor with
+        # separate reductions and sorts: ~50 launches per call): invalid joints add 0 at a clamped position, valid ones
+        # add 1, several on one pixel still give 1 (the clamp is folded into the blur).
+        if all(t == t_all for t, _, _ in spatial):
+            # all levels in ONE buffer and one set of launches: level l's maps start at base[l]
+            sizes = [bs * K * t_all * h * w for _, h, w in spatial]
+            key = ("hm_geom", tuple(spatial), bs, K, str(device))
+            geom = getattr(self, "_hm_geom", None)
+            if geom is None or geom[0] != key:
+                hs = torch.tensor([h for _, h, _ in spatial], dtype=torch.long)
+                ws = torch.tensor([w for _, _, w in spatial], dtype=torch.long)
+                base = torch.tensor([sum(sizes[:i]) for i in range(len(sizes))], dtype=torch.long)
+                geom = self._hm_geom = (key, hs.to(device)[:, None, None, None], ws.to(device)[:, None, None, None],
+                                        base.to(device)[:, None, None, None])
+            _, hs, ws, base = geom
+            plane = ((sample[:, None, None] * K + ki) * t_all + ti)[None]                     # [1, Nsum, t, K]
+            lin = (plane * hs + xy[..., 1]) * ws + xy[..., 0] + base                          # [levels, Nsum, t, K]
+            hm_all = torch.zeros(sum(sizes), device=device)
+            hm_all.index_add_(0, lin.reshape(-1), ok_all.reshape(-1).to(hm_all.dtype))
+            off = 0
+            for (t, h, w), n, ksize in zip(spatial, sizes, ksizes):
+                hm = hm_all[off:off + n].view(bs, K, t, h, w)
+                off += n
+                maps.append(gaussian_blur(hm, ksize, clamp_max=1.0).permute(0, 2, 3, 4, 1))   # [bs, t, h, w, K]
+            return maps
         for lvl, (t, h, w) in enumerate(spatial):
-            ksize = max(h // 10 + h // 10 % 2 - 1, w // 10 + w // 10 % 2 - 1)
             x, y, ok = xy[lvl, :, :t, :, 0], xy[lvl, :, :t, :, 1], ok_all[lvl, :, :t]
-            # One scatter-add over the flattened [bs, K, t, h, w] map for all samples.  No boolean-mask indexing (it
-            # would read the count back to the host) and no multi-index index_put_ (its accumulate path range-checks
-            # every index tensor with separate reductions and sorts: ~50 launches per call): invalid joints add 0 at
-            # a clamped position, valid ones add 1, several on one pixel still give 1.
             lin = (((sample[:, None, None] * K + ki) * t + ti[:, :t]) * h + y) * w + x
             hm = torch.zeros(bs * K * t * h * w, device=device)
             hm.index_add_(0, lin.reshape(-1), ok.reshape(-1).to(hm.dtype))
             hm = hm.view(bs, K, t, h, w)
-            maps.append(gaussian_blur(hm, ksize, clamp_max=1.0).permute(0, 2, 3, 4, 1))   # [bs, t, h, w, K]
+            maps.append(gaussian_blur(hm, ksizes[lvl], clamp_max=1.0).permute(0, 2, 3, 4, 1))   # [bs, t, h, w, K]
         return maps
 
     def loss_heatmap(self, outputs, targets):
