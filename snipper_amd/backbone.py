@@ -309,11 +309,11 @@ def _hip_pointwise_fork(x, conv, bn, gate_input=False, pregated=False):
 class Bottleneck(nn.Module):
     expansion = 4
 
-    def __init__(self, inplanes, width, stride=1, downsample=False):
+    def __init__(self, inplanes, width, stride=1, downsample=False, dilation=1):
         super().__init__()
         self.conv1 = nn.Conv2d(inplanes, width, 1, bias=False)
         self.bn1 = FrozenBatchNorm2d(width)
-        self.conv2 = nn.Conv2d(width, width, 3, stride=stride, padding=1, bias=False)
+        self.conv2 = nn.Conv2d(width, width, 3, stride=stride, padding=dilation, dilation=dilation, bias=False)
         self.bn2 = FrozenBatchNorm2d(width)
         self.conv3 = nn.Conv2d(width, width * 4, 1, bias=False)
         self.bn3 = FrozenBatchNorm2d(width * 4)
@@ -349,15 +349,20 @@ class ResNet50Body(nn.Module):
 
     def __init__(self, return_interm_layers=True, dilation=False):
         super().__init__()
-        if dilation:
-            raise NotImplementedError("dilation (DC5) is not used by any Snipper recipe")
         self.conv1 = nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)
         self.bn1 = FrozenBatchNorm2d(64)
         inplanes = 64
         for i, (width, blocks, stride) in enumerate([(64, 3, 1), (128, 4, 2), (256, 6, 2), (512, 3, 2)]):
+            # reference backbone.py:105-107, replace_stride_with_dilation=[False, False, dilation] (the DC5 variant):
+            # layer4 keeps layer3's resolution -- its stride becomes 1, its first block keeps dilation 1 and the
+            # following blocks' 3x3 convolutions take dilation 2 (torchvision's _make_layer rule).  The dilated 3x3
+            # convolutions run through the library convolution (no Snipper recipe uses DC5); everything else is unchanged.
+            dil = 1
+            if dilation and i == 3:
+                dil, stride = stride, 1
             layers = [Bottleneck(inplanes, width, stride, downsample=True)]
             inplanes = width * 4
-            layers += [Bottleneck(inplanes, width) for _ in range(blocks - 1)]
+            layers += [Bottleneck(inplanes, width, dilation=dil) for _ in range(blocks - 1)]
             setattr(self, f"layer{i + 1}", nn.Sequential(*layers))
         self.return_interm_layers = return_interm_layers
         self._stem_frozen = None      # decided at the first forward; reset it after changing layer1's requires_grad
@@ -447,22 +452,54 @@ class ResNet50Body(nn.Module):
         return {"0": c5}
 
 
-class Backbone(nn.Module):
-    """ResNet backbone with frozen BatchNorm (reference ``BackboneBase`` + ``Backbone``, :67-110)."""
+def backbone_parameter_is_trainable(name: str, train_backbone: bool) -> bool:
+    """The reference's freeze rule (backbone.py:71-73): only layer2 / layer3 / layer4 parameters train, and only when the
+    backbone has a learning rate; conv1 + layer1 are always frozen."""
+    return bool(train_backbone) and any(k in name for k in ("layer2", "layer3", "layer4"))
 
-    def __init__(self, name: str = "resnet50", train_backbone: bool = True,
-                 return_interm_layers: bool = True, dilation: bool = False):
+
+class _LayerGetter(nn.ModuleDict):
+    """What the reference takes from torchvision as ``IntermediateLayerGetter`` (backbone.py:19,85): the children of a
+    network in registration order up to the last returned one; forward collects {new name: output} along the way."""
+
+    def __init__(self, model: nn.Module, return_layers: Dict[str, str]):
+        todo = dict(return_layers)
+        layers = {}
+        for name, module in model.named_children():
+            layers[name] = module
+            todo.pop(name, None)
+            if not todo:
+                break
+        if todo:
+            raise ValueError("return_layers are not present in model")
+        super().__init__(layers)
+        self.return_layers = dict(return_layers)
+
+    def forward(self, x):
+        out = {}
+        for name, module in self.items():
+            x = module(x)
+            if name in self.return_layers:
+                out[self.return_layers[name]] = x
+        return out
+
+
+class BackboneBase(nn.Module):
+    """Reference ``BackboneBase`` (backbone.py:67-99) for ANY network with ResNet's child names: freeze rule, the
+    layer2/3/4 (or layer4) taps, and the nearest-resized padding mask per tapped level."""
+
+    def __init__(self, backbone: nn.Module, train_backbone: bool, return_interm_layers: bool, body: nn.Module = None):
         super().__init__()
-        if name != "resnet50":
-            raise ValueError("only resnet50 is restated here (the Snipper recipes use nothing else)")
-        self.body = ResNet50Body(return_interm_layers, dilation)
-        for pname, p in self.body.named_parameters():     # conv1 + layer1 are always frozen (:71-73)
-            if not train_backbone or not any(k in pname for k in ("layer2", "layer3", "layer4")):
+        for pname, p in backbone.named_parameters():
+            if not backbone_parameter_is_trainable(pname, train_backbone):
                 p.requires_grad_(False)
         if return_interm_layers:
+            return_layers = {"layer2": "0", "layer3": "1", "layer4": "2"}
             self.strides, self.num_channels = [8, 16, 32], [512, 1024, 2048]
         else:
+            return_layers = {"layer4": "0"}
             self.strides, self.num_channels = [32], [2048]
+        self.body = body if body is not None else _LayerGetter(backbone, return_layers)
 
     def forward(self, tensor_list: NestedTensor):
         feats = self.body(tensor_list.tensors)
@@ -476,6 +513,20 @@ class Backbone(nn.Module):
                 mask = F.interpolate(m[None].float(), size=x.shape[-2:]).to(torch.bool)[0]    # nearest (:93)
             out[name] = NestedTensor(x, mask)
         return out
+
+
+class Backbone(BackboneBase):
+    """ResNet backbone with frozen BatchNorm (reference ``Backbone``, :102-111).  The network is this package's own
+    ResNet-50 (``ResNet50Body`` already returns the tapped levels, so it IS the body)."""
+
+    def __init__(self, name: str = "resnet50", train_backbone: bool = True,
+                 return_interm_layers: bool = True, dilation: bool = False):
+        if name != "resnet50":
+            raise ValueError("only resnet50 is restated here (the Snipper recipes use nothing else)")
+        body = ResNet50Body(return_interm_layers, dilation)
+        super().__init__(body, train_backbone, return_interm_layers, body=body)
+        if dilation:
+            self.strides[-1] = self.strides[-1] // 2
 
 
 from .misc import BoundedCache  # noqa: E402

@@ -211,3 +211,81 @@ def test_relu_backward_fold_protocol_gives_the_same_gradients():
         assert torch.equal(a, b)
     for a, b in zip(res[0][1], res[1][1]):
         assert torch.equal(a, b)
+
+
+# -- golden g9: the reference's own FrozenBatchNorm2d / BackboneBase / Joiner (models/backbone.py:27-131) ---------------
+def _tiny_resnet(g9_sd):
+    """The stand-in network of tests/golden/gen_g9_backbone.py (ResNet's child names, plain convolutions) rebuilt
+    from this package's FrozenBatchNorm2d; weights come from the golden state_dict."""
+    from collections import OrderedDict
+    from torch import nn
+
+    def block(cin, cout, stride):
+        return nn.Sequential(OrderedDict([("conv", nn.Conv2d(cin, cout, 3, stride, 1, bias=False)),
+                                          ("bn", FrozenBatchNorm2d(cout)), ("relu", nn.ReLU())]))
+    return nn.Sequential(OrderedDict([
+        ("conv1", nn.Conv2d(3, 4, 7, 2, 3, bias=False)), ("bn1", FrozenBatchNorm2d(4)), ("relu", nn.ReLU()),
+        ("maxpool", nn.MaxPool2d(3, 2, 1)), ("layer1", block(4, 6, 1)), ("layer2", block(6, 8, 2)),
+        ("layer3", block(8, 10, 2)), ("layer4", block(10, 12, 2)), ("avgpool", nn.AdaptiveAvgPool2d(1))]))
+
+
+@pytest.mark.parametrize("tag", ["f32", "f64"])
+def test_frozen_bn_matches_reference_golden(golden_dir, tag):
+    g = torch.load(os.path.join(golden_dir, "g9_backbone.pt"), weights_only=False)[f"bn_{tag}"]
+    bn = FrozenBatchNorm2d(5)
+    bn.load_state_dict(dict(g["state_dict"]), strict=True)      # carries num_batches_tracked: dropped like :43-51
+    assert sorted(bn.state_dict().keys()) == g["keys_after"]
+    bn = bn.to(g["x"].dtype)
+    tol = dict(rtol=1e-6, atol=1e-6) if tag == "f32" else dict(rtol=1e-13, atol=1e-13)
+    torch.testing.assert_close(bn(g["x"]), g["y"], **tol)
+
+
+@pytest.mark.parametrize("tag", ["interm", "last_frozen"])
+def test_backbone_base_and_joiner_match_reference_golden(golden_dir, tag):
+    """BackboneBase.forward (:87-99: nearest mask resize per tapped level), its freeze rule (:71-73), return_layers
+    (:74-85) and Joiner (:114-131: level order, position encoding per level) against the reference classes' outputs."""
+    from snipper_amd.backbone import BackboneBase, Joiner, backbone_parameter_is_trainable
+    g = torch.load(os.path.join(golden_dir, "g9_backbone.pt"), weights_only=False)[f"base_{tag}"]
+    net = _tiny_resnet(g)
+    base = BackboneBase(net, g["train_backbone"], g["return_interm_layers"])
+    assert sorted(base.body.state_dict().keys()) == sorted(g["body_state_dict"].keys())    # layers past the last tap dropped
+    base.body.load_state_dict(g["body_state_dict"], strict=True)
+    assert {k: p.requires_grad for k, p in base.named_parameters()} == g["requires_grad"]
+    for k, want in g["requires_grad"].items():
+        assert backbone_parameter_is_trainable(k, g["train_backbone"]) == want
+    joiner = Joiner(base, PositionEmbeddingSine(g["pos_feats"], num_frames=g["num_frames"], normalize=True))
+    assert joiner.strides == g["strides"] and joiner.num_channels == g["num_channels"]
+    out, pos = joiner(NestedTensor(g["imgs"], g["mask"]))
+    assert len(out) == len(g["features"]) == len(pos)
+    for o, f, m, p, pw in zip(out, g["features"], g["masks"], pos, g["pos"]):
+        torch.testing.assert_close(o.tensors, f, rtol=1e-5, atol=1e-5)
+        assert torch.equal(o.mask, m)
+        assert p.dtype == o.tensors.dtype and p.shape == pw.shape
+        torch.testing.assert_close(p, pw, rtol=0, atol=2e-6)
+    # the real Backbone shares forward and freeze rule with BackboneBase
+    bb = Backbone("resnet50", g["train_backbone"], g["return_interm_layers"], False)
+    assert isinstance(bb, BackboneBase)
+    assert all(p.requires_grad == backbone_parameter_is_trainable(n, g["train_backbone"]) for n, p in bb.body.named_parameters())
+
+
+def test_dilated_backbone_dc5_variant():
+    """--dilation (reference backbone.py:105-110, replace_stride_with_dilation=[False, False, True]): layer4 keeps
+    layer3's resolution, stride list ends in 16, layer4's blocks 1.. use dilation 2; checked against the plain
+    F.conv2d composition."""
+    torch.manual_seed(0)
+    bb = Backbone("resnet50", True, True, True).double()
+    assert bb.strides == [8, 16, 16]
+    l4 = bb.body.layer4
+    assert l4[0].conv2.stride == (1, 1) and l4[0].conv2.dilation == (1, 1) and l4[0].downsample[0].stride == (1, 1)
+    assert all(b.conv2.dilation == (2, 2) and b.conv2.padding == (2, 2) for b in list(l4)[1:])
+    g = torch.Generator().manual_seed(3)
+    x = torch.rand(1, 3, 64, 96, generator=g).double()
+    out = bb(NestedTensor(x, torch.zeros(1, 64, 96, dtype=torch.bool)))
+    assert out["2"].tensors.shape == (1, 2048, 4, 6) and out["1"].tensors.shape == (1, 1024, 4, 6)
+    y = out["1"].tensors
+    for blk in l4:
+        idn = y if blk.downsample is None else _ref_bn(blk.downsample[0](y), blk.downsample[1])
+        z = F.relu(_ref_bn(blk.conv1(y), blk.bn1))
+        z = F.relu(_ref_bn(blk.conv2(z), blk.bn2))
+        y = F.relu(_ref_bn(blk.conv3(z), blk.bn3) + idn)
+    torch.testing.assert_close(out["2"].tensors, y, rtol=1e-9, atol=1e-9)
