@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- snippets/sec of one training step of the Snipper hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W]        (N > 1: starts its own N ranks as a child process)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -388,7 +388,57 @@ def time_msda_modules(a, device):
     return res
 
 
+def self_launch_command(argv, gpus: int, port: int = None, script: str = None):
+    """The command line that starts ``gpus`` ranks of this script on one node (reference README.md:67 starts its 8 processes
+    with one `torch.distributed.launch --nproc_per_node=8` command): one process per GPU under torch.distributed.run,
+    rendezvous on 127.0.0.1 (the container hostname may not resolve)."""
+    port = port or int(os.environ.get("MASTER_PORT", 0)) or (29500 + os.getpid() % 2000)
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), script or os.path.abspath(__file__)] + list(argv)
+
+
+def maybe_self_launch(argv=None, script: str = None):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks as a CHILD process (nothing in
+    this process has touched the GPU yet -- an exec from a process that has is forbidden on this pool), relay rank 0's JSON
+    line on stdout, everything else on stderr, and return the child's exit code.  Returns None when there is nothing to
+    launch (N = 1, or WORLD_SIZE is set: we ARE a rank)."""
+    import subprocess
+    argv = list(sys.argv[1:] if argv is None else argv)
+    if "WORLD_SIZE" in os.environ:
+        return None
+    ap = argparse.ArgumentParser(add_help=False)
+    ap.add_argument("--gpus", type=int, default=1)
+    known, _ = ap.parse_known_args(argv)
+    if known.gpus <= 1:
+        return None
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = self_launch_command(argv, known.gpus, script=script)
+    print("bench.py: starting " + " ".join(cmd), file=sys.stderr, flush=True)
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    last_json = None
+    for ln in p.stdout:
+        t = ln.strip()
+        if t.startswith("{") and t.endswith("}"):
+            try:
+                json.loads(t)
+                last_json = t
+                continue
+            except ValueError:
+                pass
+        sys.stderr.write(ln)
+    rc = p.wait()
+    if last_json is not None:
+        sys.stdout.write(last_json + "\n")
+        sys.stdout.flush()
+    return rc
+
+
 def main():
+    rc = maybe_self_launch()
+    if rc is not None:
+        sys.exit(rc)
     # Native libraries write to the process's stdout too (RCCL prints a version banner when its first communicator comes
     # up): keep the real stdout for the ONE JSON line and send everything else that goes to fd 1 to stderr.
     sys.stdout.flush()
@@ -433,9 +483,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            sys.exit(f"--gpus {a.gpus} needs torch.distributed.run --nproc-per-node {a.gpus}")
+    if world != a.gpus:       # under a launcher the launcher's world size is authoritative
         a.gpus = world
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
     device = torch.device("cuda", local_rank)

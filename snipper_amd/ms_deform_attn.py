@@ -113,6 +113,15 @@ class MSDeformAttn(nn.Module):
         o0, a0 = self.sampling_offsets[0], self.attention_weights[0]
         return all(m is o0 for m in self.sampling_offsets) and all(m is a0 for m in self.attention_weights)
 
+    def untie_frame_weights(self):
+        """Give every value frame its own copy of the offset / weight Linears (what loading a checkpoint with genuinely
+        different ``sampling_offsets.{t}`` entries needs; the reference's forward indexes them by frame, :144,167).  The
+        forward then takes the general per-pair evaluation."""
+        import copy
+        self.sampling_offsets = nn.ModuleList([copy.deepcopy(self.sampling_offsets[0]) for _ in range(self.n_frame)])
+        self.attention_weights = nn.ModuleList([copy.deepcopy(self.attention_weights[0]) for _ in range(self.n_frame)])
+        return self
+
     def _core(self, value, shapes, lsi, loc, attn):
         if self.use_pytroch_deform:
             return ms_deform_attn_core_pytorch(value, shapes, loc, attn)

@@ -20,6 +20,8 @@ Fixtures:
                        3-layer outputs: every loss, the matching, gradients of the weighted sum.
   g3_module_*_d48.pt   the same module at Snipper's real head geometry (d_model 384, 8 heads -> D = 48, the width the tuned
                        HIP kernels are specialised for), float32 storage of a float64 evaluation.
+  g3_module_*_t1_d48.pt  the same at T = 1 (BASELINE configs[1]: no temporal neighbours, identity mix).
+  g3_module_*_untied_d48.pt  per-frame Linears untied with different values (general per-pair path).
   g7_posenc.npz        PositionEmbeddingSine (models/position_encoding.py:20-63) on padded and unpadded masks.
   g4_transformer.pt    one DeformableTransformer forward (T=2+1, enc2/dec2) + its state_dict
                        (pins the key schema) + gradients of a scalar loss.
@@ -184,7 +186,21 @@ def gen_g3(MSDeformAttn):
         torch.save(blob, os.path.join(OUT, f"g3_module_{name}.pt"))
 
 
-def gen_g3_d48(MSDeformAttn):
+def gen_g3_t1_d48(MSDeformAttn):
+    """BASELINE configs[1]'s frame count (T = 1: one query frame, one value frame, no temporal neighbours) at the same head
+    geometry: g3_module_enc_t1_d48 / g3_module_dec_t1_d48."""
+    gen_g3_d48(MSDeformAttn, {"enc_t1_d48": ("encoder", 1, 1, None, 203), "dec_t1_d48": ("decoder", 1, 1, 6, 204)})
+
+
+def gen_g3_untied_d48(MSDeformAttn):
+    """The per-frame offset / weight Linears UNTIED with different values per value frame (the reference's forward indexes
+    them by t2, ms_deform_attn.py:144,167,197,210, so it evaluates an untied module as written): pins the general
+    per-pair path -- joint softmax over L*P*|t2|, one core call per (t1, t2), non-contiguous value[:, t2] slices."""
+    gen_g3_d48(MSDeformAttn, {"enc_untied_d48": ("encoder", 3, 3, None, 205), "dec_untied_d48": ("decoder", 2, 3, 6, 206)},
+               untie=True)
+
+
+def gen_g3_d48(MSDeformAttn, cases=None, untie=False):
     """MSDeformAttn at d_model=384 / 8 heads (D=48): encoder (Lq == S, T=2) and decoder (Lq=6, T=2+1).  Everything is
     drawn in float32 and evaluated by the reference in float64; results are stored as float32 (the consumers are the
     float32 D=48 kernels, compared at 2e-4), which keeps the two files at a few MB."""
@@ -192,12 +208,23 @@ def gen_g3_d48(MSDeformAttn):
     shapes = torch.as_tensor([(12, 16), (6, 8), (3, 4)], dtype=torch.long)
     S = int(shapes.prod(1).sum())
     lsi = lsi_of(shapes)
-    cases = {"enc_d48": ("encoder", 2, 2, S, 201), "dec_d48": ("decoder", 2, 3, 6, 202)}
+    if cases is None:
+        cases = {"enc_d48": ("encoder", 2, 2, S, 201), "dec_d48": ("decoder", 2, 3, 6, 202)}
     for name, (mode, n_frame, T1, Lq, seed) in cases.items():
+        Lq = S if Lq is None else Lq
         g = torch.Generator().manual_seed(seed)
         torch.manual_seed(13)
         mod = MSDeformAttn(d_model, L, M, P, n_frame, mode, True, mode == "decoder")
-        randomise_(mod, g, scale=0.5)
+        if untie:
+            import copy
+            mod.sampling_offsets = torch.nn.ModuleList([copy.deepcopy(mod.sampling_offsets[0]) for _ in range(n_frame)])
+            mod.attention_weights = torch.nn.ModuleList([copy.deepcopy(mod.attention_weights[0]) for _ in range(n_frame)])
+        randomise_(mod, g, scale=0.5)       # (untied: every copy draws its own values)
+        if untie:
+            with torch.no_grad():
+                for lin in mod.sampling_offsets:
+                    lin.bias.add_(torch.randn(lin.bias.shape, generator=g) * 0.5)
+            assert not torch.equal(mod.sampling_offsets[0].weight, mod.sampling_offsets[1].weight)
         sd32 = {k: v.detach().clone() for k, v in mod.state_dict().items()}
         mod = mod.double()
         N, T2 = 1, n_frame
@@ -214,7 +241,7 @@ def gen_g3_d48(MSDeformAttn):
         query, ref, src = (t.double().requires_grad_(True) for t in (query32, ref32, src32))
         mask = torch.zeros(N, T2, S, dtype=torch.bool)
         mask[0, :, 7] = True
-        mask[0, 1, -2:] = True
+        mask[0, T2 - 1, -2:] = True
         mask_c = mask[..., None].expand(-1, -1, -1, d_model).contiguous()
         res = mod(query, ref, src, shapes, lsi, mask_c)
         vis = None
@@ -224,7 +251,8 @@ def gen_g3_d48(MSDeformAttn):
         params = dict(mod.named_parameters())
         grads = torch.autograd.grad(res, [query, ref, src] + list(params.values()), go32.double())
         blob = {
-            "cfg": dict(d_model=d_model, n_levels=L, n_heads=M, n_points=P, n_frame=n_frame, mode=mode),
+            "cfg": dict(d_model=d_model, n_levels=L, n_heads=M, n_points=P, n_frame=n_frame, mode=mode,
+                        **({"untied": True} if untie else {})),
             "state_dict": sd32, "shapes": shapes, "lsi": lsi, "query": query32, "ref": ref32, "src": src32,
             "mask": mask, "out": res.detach().float(), "grad_out": go32,
             "grad_query": grads[0].float(), "grad_ref": grads[1].float(), "grad_src": grads[2].float(),
@@ -461,7 +489,9 @@ if __name__ == "__main__":
     core, MSDeformAttn, DeformableTransformer = import_reference()
     only = set(sys.argv[1:])          # e.g. `gen_golden.py g3d48 g7` regenerates just those
     todo = [("g1", lambda: gen_g1(core)), ("g2", lambda: gen_g2(core)), ("g3", lambda: gen_g3(MSDeformAttn)),
-            ("g3d48", lambda: gen_g3_d48(MSDeformAttn)), ("g4", lambda: gen_g4(DeformableTransformer)),
+            ("g3d48", lambda: gen_g3_d48(MSDeformAttn)), ("g3t1", lambda: gen_g3_t1_d48(MSDeformAttn)),
+            ("g3untied", lambda: gen_g3_untied_d48(MSDeformAttn)),
+            ("g4", lambda: gen_g4(DeformableTransformer)),
             ("g7", gen_g7), ("g5", gen_g5), ("g6", lambda: gen_g6(DeformableTransformer))]
     for tag, fn in todo:
         if not only or tag in only:

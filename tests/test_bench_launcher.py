@@ -1,0 +1,66 @@
+"""`python bench.py --gpus N` starts its own N ranks (reference README.md:67 starts 8 processes with one command): the
+parent builds a torch.distributed.run command line BEFORE anything touches the GPU, runs it as a child process, relays
+rank 0's JSON line on stdout and returns the child's exit code.  CPU test with a stand-in rank script."""
+import importlib.util
+import json
+import os
+import subprocess
+import sys
+import textwrap
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench():
+    spec = importlib.util.spec_from_file_location("bench_mod_launcher", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    return b
+
+
+def test_command_line_and_no_launch_cases(monkeypatch):
+    b = _bench()
+    cmd = b.self_launch_command(["--gpus", "8", "--steps", "5"], 8, port=29611)
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=8" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29611"
+    assert cmd[-5:] == [os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "5"]
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    assert b.maybe_self_launch(["--steps", "3"]) is None               # N = 1: nothing to launch
+    assert b.maybe_self_launch(["--gpus", "1"]) is None
+    monkeypatch.setenv("WORLD_SIZE", "4")
+    assert b.maybe_self_launch(["--gpus", "4"]) is None                # already a rank of a launcher
+
+
+def test_parent_starts_ranks_and_forwards_the_line(tmp_path):
+    rank_script = tmp_path / "rank.py"
+    rank_script.write_text(textwrap.dedent("""
+        import json, os, sys
+        import torch.distributed as dist
+        dist.init_process_group("gloo")
+        t = __import__("torch").ones(1) * (dist.get_rank() + 1)
+        dist.all_reduce(t)
+        print("noise from rank", dist.get_rank(), flush=True)
+        if dist.get_rank() == 0:
+            print(json.dumps({"n_gpus": dist.get_world_size(), "sum": float(t), "argv": sys.argv[1:]}), flush=True)
+        dist.destroy_process_group()
+        sys.exit(3 if "--fail" in sys.argv else 0)
+    """))
+    driver = tmp_path / "driver.py"
+    driver.write_text(textwrap.dedent(f"""
+        import importlib.util, sys
+        spec = importlib.util.spec_from_file_location("b", {os.path.join(ROOT, "bench.py")!r})
+        b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)
+        sys.exit(b.maybe_self_launch(sys.argv[1:], script={str(rank_script)!r}))
+    """))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, str(driver), "--gpus", "2", "--steps", "7"], capture_output=True, text=True,
+                       env=env, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout                       # ONE JSON line on stdout, the ranks' chatter on stderr
+    line = json.loads(lines[0])
+    assert line == {"n_gpus": 2, "sum": 3.0, "argv": ["--gpus", "2", "--steps", "7"]}
+    assert "noise from rank" in p.stderr
+    p = subprocess.run([sys.executable, str(driver), "--gpus", "2", "--fail"], capture_output=True, text=True, env=env,
+                       timeout=300)
+    assert p.returncode != 0                               # the child's failure is the parent's

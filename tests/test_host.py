@@ -47,7 +47,7 @@ def test_module_tied_path_matches_reference(golden_dir, name):
         torch.testing.assert_close(g, b["param_grads"][k], rtol=1e-9, atol=1e-10, msg=lambda m: f"{k}: {m}")
 
 
-@pytest.mark.parametrize("name", ["enc_d48", "dec_d48"])
+@pytest.mark.parametrize("name", ["enc_d48", "dec_d48", "enc_t1_d48", "dec_t1_d48"])
 def test_module_d48_goldens_on_the_pytorch_path(golden_dir, name):
     """The d_model=384 / 8-head goldens (float32 storage of the reference's float64 evaluation) through this package's
     module in float64 with the reference's own ``use_pytorch_deform`` switch: pins the fixtures themselves on CPU; the GPU
@@ -85,6 +85,43 @@ def test_module_untied_path_matches_reference(golden_dir, name):
         for x, y in zip(wts, b["vis_w"]):
             torch.testing.assert_close(x, y, rtol=1e-10, atol=1e-13)
     torch.testing.assert_close(res, b["out"], rtol=1e-10, atol=1e-12)
+
+
+@pytest.mark.parametrize("name", ["enc_untied_d48", "dec_untied_d48"])
+def test_module_untied_with_different_weights_matches_reference(golden_dir, name):
+    """Goldens of the REFERENCE module with genuinely different per-frame Linears (gen_golden.py g3untied): this package's
+    per-pair path and the oracle's ``st_msdeform_attn`` against them, float64 (fixtures store float32)."""
+    from oracle import msda_oracle as O
+    b = torch.load(os.path.join(golden_dir, f"g3_module_{name}.pt"))
+    cfg = b["cfg"]
+    mod = MSDeformAttn(cfg["d_model"], cfg["n_levels"], cfg["n_heads"], cfg["n_points"], cfg["n_frame"], cfg["mode"],
+                       True, cfg["mode"] == "decoder").untie_frame_weights()
+    mod.load_state_dict(b["state_dict"], strict=True)
+    mod = mod.double()
+    assert not mod.weights_are_tied()
+    q, r, s = (b[k].double().clone().requires_grad_(True) for k in ("query", "ref", "src"))
+    mask_c = b["mask"][..., None].expand(-1, -1, -1, cfg["d_model"])
+    res = mod(q, r, s, b["shapes"], b["lsi"], mask_c)
+    if mod.attention_vis:
+        res, (locs, wts) = res
+        for x, y in zip(wts, b["vis_w"]):
+            torch.testing.assert_close(x.float(), y, rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(res.float(), b["out"], rtol=1e-6, atol=1e-6)
+    params = dict(mod.named_parameters())
+    grads = torch.autograd.grad(res, [q, r, s] + list(params.values()), b["grad_out"].double())
+    for got, key in zip(grads[:3], ("grad_query", "grad_ref", "grad_src")):
+        torch.testing.assert_close(got.float(), b[key], rtol=1e-5, atol=1e-5)
+    for (k, _), g in zip(params.items(), grads[3:]):
+        torch.testing.assert_close(g.float(), b["param_grads"][k], rtol=1e-5, atol=1e-4, msg=lambda m: f"{k}: {m}")
+    sd = {k: v.double() for k, v in b["state_dict"].items()}
+    T = cfg["n_frame"]
+    out, _, wts = O.st_msdeform_attn(
+        b["query"].double(), b["ref"].double(), b["src"].double(), b["shapes"], mask_c,
+        sd["value_proj.weight"], sd["value_proj.bias"],
+        [sd[f"sampling_offsets.{t}.weight"] for t in range(T)], [sd[f"sampling_offsets.{t}.bias"] for t in range(T)],
+        [sd[f"attention_weights.{t}.weight"] for t in range(T)], [sd[f"attention_weights.{t}.bias"] for t in range(T)],
+        sd["output_proj.weight"], sd["output_proj.bias"], cfg["n_heads"], cfg["n_levels"], cfg["n_points"], T)
+    torch.testing.assert_close(out.float(), b["out"], rtol=1e-6, atol=1e-6)
 
 
 def test_frame_neighbours():

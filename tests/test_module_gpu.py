@@ -52,7 +52,7 @@ def test_module_on_hip_matches_reference(golden_dir, name, dtype, rtol, atol):
                                    msg=lambda m: f"{k}: {m}")
 
 
-@pytest.mark.parametrize("name", ["enc_d48", "dec_d48"])
+@pytest.mark.parametrize("name", ["enc_d48", "dec_d48", "enc_t1_d48", "dec_t1_d48"])
 @pytest.mark.parametrize("mask_kind", ["expanded", "3d", "none"])
 def test_module_d48_on_hip_matches_reference(golden_dir, name, mask_kind):
     """The reference module at Snipper's head geometry (d_model 384 / 8 heads -> D = 48) against the kernels the
@@ -84,6 +84,40 @@ def test_module_d48_on_hip_matches_reference(golden_dir, name, mask_kind):
     params = dict(mod.named_parameters())
     grads = torch.autograd.grad(res, [q, r, s] + list(params.values()), _to(b["grad_out"]))
     assert _lib.last_variant() == ("d48_owner" if enc else "d48_lp12"), _lib.last_variant()
+    scale = lambda ref: max(float(ref.abs().max()), 1.0)
+    for got, key in zip(grads[:3], ("grad_query", "grad_ref", "grad_src")):
+        torch.testing.assert_close(got.cpu() / scale(b[key]), b[key] / scale(b[key]), rtol=1e-3, atol=1e-4,
+                                   msg=lambda m: f"{key}: {m}")
+    for (k, _), g in zip(params.items(), grads[3:]):
+        ref = b["param_grads"][k]
+        torch.testing.assert_close(g.cpu() / scale(ref), ref / scale(ref), rtol=1e-3, atol=1e-4, msg=lambda m: f"{k}: {m}")
+
+
+@pytest.mark.parametrize("name", ["enc_untied_d48", "dec_untied_d48"])
+def test_module_untied_per_pair_path_on_hip_matches_reference(golden_dir, name):
+    """Genuinely different per-frame Linears (goldens made by the reference module itself): the general per-pair path on
+    the HIP core op -- one launch per (t1, t2) on the non-contiguous ``value[:, t2]`` slices, joint softmax over
+    L*P*|t2| -- outputs, input and parameter gradients, vis lists."""
+    b = torch.load(os.path.join(golden_dir, f"g3_module_{name}.pt"))
+    cfg = b["cfg"]
+    enc = cfg["mode"] == "encoder"
+    mod = MSDeformAttn(cfg["d_model"], cfg["n_levels"], cfg["n_heads"], cfg["n_points"], cfg["n_frame"],
+                       cfg["mode"], False, not enc).untie_frame_weights()
+    mod.load_state_dict(b["state_dict"], strict=True)
+    mod = mod.to(DEV)
+    assert not mod.weights_are_tied()
+    q, r, s = (_to(b[k]).clone().requires_grad_(True) for k in ("query", "ref", "src"))
+    m3 = _to(b["mask"])
+    res = mod(q, r, s, _to(b["shapes"]), _to(b["lsi"]), m3[..., None].expand(-1, -1, -1, cfg["d_model"]))
+    assert _lib.last_variant() == "d48_lp12", _lib.last_variant()
+    if mod.attention_vis:
+        res, (locs, wts) = res
+        for x, y in zip(wts, b["vis_w"]):
+            torch.testing.assert_close(x.cpu(), y, rtol=2e-4, atol=2e-6)
+    torch.testing.assert_close(res.cpu(), b["out"], rtol=2e-4, atol=2e-4)
+    params = dict(mod.named_parameters())
+    assert len(params) == 4 + 4 * cfg["n_frame"]
+    grads = torch.autograd.grad(res, [q, r, s] + list(params.values()), _to(b["grad_out"]))
     scale = lambda ref: max(float(ref.abs().max()), 1.0)
     for got, key in zip(grads[:3], ("grad_query", "grad_ref", "grad_src")):
         torch.testing.assert_close(got.cpu() / scale(b[key]), b[key] / scale(b[key]), rtol=1e-3, atol=1e-4,

@@ -1,4 +1,4 @@
-"""GPU tests of the owner-computes backward (csrc/msda_d48_owner.cuh), ``-m gpu``.
+"""GPU tests of the owner-computes backward (csrc/msda_d48_patch.cuh), ``-m gpu``.
 
 The path is taken when the host knows the level shapes, D == 48 and Lq == S (encoder).  Its result
 must be the same function of the inputs for ANY locations: near samples are accumulated in LDS by

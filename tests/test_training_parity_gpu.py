@@ -83,9 +83,9 @@ def test_loss_trajectories_agree():
     assert all(torch.isfinite(torch.tensor(v)) for v in ref)
     assert min(ref[2:]) < ref[0], "the float32 reference trajectory does not descend: the test would prove nothing"
     for v, r in zip(res["hip_fp32"][0], ref):        # float32 kernels: same trajectory (Hungarian ties aside)
-        assert abs(v - r) <= 0.01 * abs(r), (res["hip_fp32"][0], ref)
+        assert abs(v - r) <= 2e-3 * abs(r), (res["hip_fp32"][0], ref)          # measured 2e-5
     for v, r in zip(res["bf16"][0], ref):            # bf16 dense layers + shadows: within bf16 accuracy of it
-        assert abs(v - r) <= 0.08 * abs(r), (res["bf16"][0], ref)
+        assert abs(v - r) <= 0.01 * abs(r), (res["bf16"][0], ref)              # measured 1.3e-3; a stale shadow costs 5 %
     # the trained weights moved by the same amount (a stale shadow shows up here as well)
     for arm in ("hip_fp32", "bf16"):
         assert abs(res[arm][1] - res["ref"][1]) <= 1e-3 * res["ref"][1]
