@@ -77,7 +77,9 @@ typedef struct snipper_msda_config {
   float near_radius;      /* owner-computes backward: a sample within this many pixels of its anchor is "near" (6)     */
   int32_t reserved0;      /* must be 0                                                                                 */
   int32_t tile_edge[3];   /* grad_value tile edge (power of two <= 16) for levels of > 4096 / > 1024 / fewer pixels    */
-  int32_t reserved[5];    /* must be 0 ([0] != 0 selects timing ablations of the owner-computes backward: WRONG results)  */
+  int32_t reserved[5];    /* must be 0, checked ([0] != 0 selects timing ablations of the owner-computes backward with WRONG
+                           * results; refused unless SNIPPER_MSDA_ALLOW_DEBUG=1 was in the environment at load time, and
+                           * then reported as variant "d48_owner_debug")                                                */
 } snipper_msda_config;
 void snipper_msda_config_init(snipper_msda_config *cfg);     /* fills in the defaults */
 
@@ -91,7 +93,8 @@ void snipper_msda_config_init(snipper_msda_config *cfg);     /* fills in the def
  *                  the L maps in level-major raster order -- they enable the owner-computes backward
  *                  (csrc/msda_d48_patch.cuh; float32 or bfloat16 value): grad_value summed per tile by owner workgroups
  *                  -- in a fixed order, so bit-reproducible -- instead of per tap by HBM float atomics.  The result is the same function of
- *                  the inputs for ANY locations; only the speed depends on how local they are.
+ *                  the inputs for ANY locations; only the speed depends on how local they are.  (Every H and W must be
+ *                  < 32768 for this path -- larger maps take the atomic kernels.)
  *   workspace    : backward only; device scratch of at least snipper_msda_backward_ex_workspace_bytes(...) bytes (0 when
  *                  the encoder-shape path would not be taken: then NULL is fine).  The library never allocates. */
 int snipper_msda_forward_ex(void *stream, const snipper_msda_config *cfg, const int64_t *host_shapes, const void *value,

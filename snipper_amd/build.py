@@ -17,13 +17,29 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
                "-Wall", "-Wno-cuda-compat", "-fno-gpu-rdc"]
 
 
-def _newest_source_mtime() -> float:
-    mt = 0.0
+HASH_PATH = LIB_PATH + ".srchash"
+
+
+def source_hash() -> str:
+    """SHA-256 over every source the library is built from (csrc/*.hip, *.cuh, include/*.h) and the compiler flags: the
+    library is rebuilt whenever this differs from the hash recorded beside it (file times do not survive a checkout or
+    a snapshot copy)."""
+    import hashlib
+    h = hashlib.sha256(" ".join(HIPCC_FLAGS).encode())
     for root in (CSRC, os.path.join(os.path.dirname(PKG_DIR), "include")):
-        for f in os.listdir(root):
+        for f in sorted(os.listdir(root)):
             if f.endswith((".hip", ".cuh", ".h")):
-                mt = max(mt, os.path.getmtime(os.path.join(root, f)))
-    return mt
+                h.update(f.encode())
+                with open(os.path.join(root, f), "rb") as fh:
+                    h.update(fh.read())
+    return h.hexdigest()
+
+
+def is_current() -> bool:
+    try:
+        return os.path.exists(LIB_PATH) and open(HASH_PATH).read().strip() == source_hash()
+    except OSError:
+        return False
 
 
 def hipcc_path():
@@ -31,17 +47,21 @@ def hipcc_path():
 
 
 def build_hip(force: bool = False, verbose: bool = False) -> str:
-    """Compile csrc/*.hip into LIB_PATH if it is missing or older than its sources."""
-    if not force and os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= _newest_source_mtime():
+    """Compile csrc/*.hip into LIB_PATH if it is missing or was built from different sources (source_hash)."""
+    if not force and is_current():
         return LIB_PATH
     hipcc = hipcc_path()
     if hipcc is None:
+        if os.path.exists(LIB_PATH):         # a box without the compiler uses the library that travelled with the tree
+            return LIB_PATH
         raise RuntimeError("hipcc not found: cannot build libsnipper_msda.so (gfx950)")
     cmd = [hipcc] + HIPCC_FLAGS + ["-o", LIB_PATH + ".tmp"] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=CSRC)
     os.replace(LIB_PATH + ".tmp", LIB_PATH)
+    with open(HASH_PATH, "w") as fh:
+        fh.write(source_hash() + "\n")
     return LIB_PATH
 
 

@@ -205,9 +205,12 @@ _blur_kernels: Dict = {}
 def gaussian_blur(img: torch.Tensor, kernel_size: int, clamp_max: Optional[float] = None) -> torch.Tensor:
     """torchvision.transforms.functional.gaussian_blur(img, [k, k]) restated (sigma = 0.3*((k-1)*0.5-1)+0.8,
     reflect padding, separable kernel).  torchvision is not vendored by the reference: parity unpinned.
-    ``clamp_max``: blur ``img.clamp(max=clamp_max)`` (folded into the HIP kernel on the GPU)."""
+    ``clamp_max``: blur ``img.clamp(max=clamp_max)`` (folded into the HIP kernel on the GPU).  The HIP kernel is a
+    forward-only fast path (the heat-map TARGETS need no gradient): an input that autograd tracks takes the differentiable
+    tensor formulation below."""
     if (img.is_cuda and img.dtype == torch.float32 and img.dim() >= 2 and 1 < kernel_size <= 31 and kernel_size % 2 == 1
-            and kernel_size // 2 < min(img.shape[-2:]) and img.is_contiguous()):
+            and kernel_size // 2 < min(img.shape[-2:]) and img.is_contiguous()
+            and not (img.requires_grad and torch.is_grad_enabled())):
         # one launch of csrc/heatmap_blur.cuh instead of a padding kernel and two library convolutions
         import ctypes
         from . import _lib

@@ -57,6 +57,14 @@ bool config_ok(const snipper_msda_config *cfg) {
     const int e = cfg->tile_edge[i];
     if (e < 1 || e > 16 || (e & (e - 1))) return false;
   }
+  // the header's "must be 0": a caller that fills the struct by hand without zeroing it must not get through
+  if (cfg->reserved0 != 0) return false;
+  for (int i = 1; i < 5; ++i)
+    if (cfg->reserved[i] != 0) return false;
+  // reserved[0] selects timing ablations of the owner-computes backward (WRONG gradients): only a process that asked
+  // for them in its environment BEFORE the library was loaded gets them (read once: no mutable state)
+  static const bool allow_debug = [] { const char *e = getenv("SNIPPER_MSDA_ALLOW_DEBUG"); return e && e[0] == '1'; }();
+  if (cfg->reserved[0] != 0 && !allow_debug) return false;
   return true;
 }
 snipper_msda_config resolve(const snipper_msda_config *cfg) { return cfg ? *cfg : default_config(); }
@@ -267,7 +275,7 @@ int backward_d48_patch(hipStream_t st, const void *grad_out, const VT *value, co
     hipLaunchKernelGGL((msda_bwd_d48_tile2_kernel<128, false>), dim3((unsigned)nblk_tiles), dim3(kPatchThreads), 0, st, grad_out,
                        loc, attn, d, plan, grad_value);
   }
-  g_last_variant = "d48_owner";
+  g_last_variant = plan.debug ? "d48_owner_debug" : "d48_owner";
   return launch_status();
 }
 
@@ -276,6 +284,7 @@ bool owner_shape_ok(const CoreDims &d, const int64_t *hs, int policy) {
   long long sum = 0;
   for (int l = 0; l < d.L; ++l) {
     if (hs[2 * l] <= 0 || hs[2 * l + 1] <= 0) return false;
+    if (hs[2 * l] >= 32768 || hs[2 * l + 1] >= 32768) return false;     // hit queries are packed level<<30 | qy<<15 | qx
     sum += hs[2 * l] * hs[2 * l + 1];
   }
   return sum == d.S && d.S < (1 << 24);
@@ -865,7 +874,9 @@ int snipper_stem7x7_bf16(void *stream, const uint16_t *X4, const uint16_t *Wp, u
   if (((uintptr_t)X4 | (uintptr_t)Wp | (uintptr_t)Y) & 15) return SNIPPER_E_SHAPE;
   const int Ho = (H - 1) / 2 + 1, Wo = (Wd - 1) / 2 + 1;           // (H + 2*3 - 7) / 2 + 1
   const long long M = (long long)B * Ho * Wo;
-  if (M >= (1LL << 31) * 64LL) return SNIPPER_E_SHAPE;
+  // the kernel addresses both arrays with 32-bit byte offsets (like the conv3x3 entry points): X4 is 8 B per pixel,
+  // Y 128 B per output pixel
+  if ((long long)B * H * Wd * 8 >= (1LL << 31) || M * 128 >= (1LL << 31)) return SNIPPER_E_SHAPE;
   const StemArgs g{X4, Wp, Y, B, H, Wd, Ho, Wo};
   hipLaunchKernelGGL(stem7x7_bf16_kernel, dim3((unsigned)((M + kGemmBM - 1) / kGemmBM)), dim3(kGemmThreads), 0,
                      (hipStream_t)stream, g);

@@ -59,21 +59,24 @@ def _dense_view(flat: torch.Tensor, offset: int, like: torch.Tensor) -> torch.Te
 
 
 class _Stage:
-    __slots__ = ("lo", "hi", "lo_elem", "hi_elem", "triggers", "pending", "launched", "works", "seen")
+    __slots__ = ("lo", "hi", "lo_elem", "hi_elem", "triggers", "pending", "ready", "launched", "works", "seen")
 
     def __init__(self, lo, hi, lo_elem, hi_elem, triggers):
         self.lo, self.hi, self.lo_elem, self.hi_elem = lo, hi, lo_elem, hi_elem
         self.triggers = triggers
-        self.pending, self.launched, self.works, self.seen = len(triggers), False, [], []
+        self.pending, self.ready, self.launched, self.works, self.seen = len(triggers), False, False, [], []
 
 
 class FlatGradSync:
     def __init__(self, params: Iterable[torch.nn.Parameter], group=None, chunks: int = 4,
                  early: Iterable[torch.nn.Parameter] = (), trigger: Iterable[torch.nn.Parameter] = (),
-                 stages: Optional[Sequence[Tuple[Sequence[torch.nn.Parameter], Sequence[torch.nn.Parameter]]]] = None):
+                 stages: Optional[Sequence[Tuple[Sequence[torch.nn.Parameter], Sequence[torch.nn.Parameter]]]] = None,
+                 late: Optional[Iterable[torch.nn.Parameter]] = None):
         """``stages``: [(parameters, trigger parameters), ...] in the order backward completes them; every stage must
         be a contiguous run of ``params``.  ``early`` / ``trigger`` is the one-stage shorthand; for it alone the early
-        parameters are moved to the front of the flat layout."""
+        parameters are moved to the front of the flat layout.  ``late``: parameters of a stage whose gradient is only
+        complete after the stage's triggers have fired (re-reduced by sync() on every rank); None = agreed on at the first
+        sync()."""
         params = [p for p in params if p.requires_grad]
         if stages is None:
             early_ids = {id(p) for p in early if p.requires_grad}
@@ -106,8 +109,19 @@ class FlatGradSync:
             trig = [p for p in trig if p.requires_grad]
             assert all(id(p) in index for p in trig)
             self.stages.append(_Stage(idx[0], idx[-1] + 1, self.offsets[idx[0]], hi_elem, trig))
-        # whatever no stage covers is reduced by sync()
-        self.rest = [(i, i + 1) for i in range(len(self.params)) if i not in covered]
+        # whatever no stage covers is reduced by sync(): consecutive uncovered parameters form ONE run (lo, hi), packed by
+        # one multi-tensor copy and all-reduced in max_chunk-sized messages -- few, large messages, not one per parameter
+        self.rest: List[Tuple[int, int]] = []
+        for i in range(len(self.params)):
+            if i in covered:
+                continue
+            if self.rest and self.rest[-1][1] == i:
+                self.rest[-1] = (self.rest[-1][0], i + 1)
+            else:
+                self.rest.append((i, i + 1))
+        self.late_idx: Optional[List[int]] = None if late is None else sorted(index[id(p)] for p in late if id(p) in index)
+        if not self.stages:
+            self.late_idx = []                    # nothing is launched before sync(): nothing can arrive late
         self.n_early = self.stages[0].hi if self.stages and self.stages[0].lo == 0 else 0     # (kept for callers / tests)
         self.early_elems = self.stages[0].hi_elem if self.n_early else 0
         if self.collective:
@@ -146,11 +160,22 @@ class FlatGradSync:
         st.pending -= 1
         if st.pending > 0:
             return
-        # Taken unconditionally once the stage's last trigger has fired, so that every rank issues the same collectives in
-        # the same order whatever its batch looked like; a parameter without a gradient contributes zeros.
+        # Collectives are issued strictly in STAGE ORDER, on every rank alike: a stage whose triggers have all fired is
+        # launched only once every earlier stage has been (a rank on which a trigger parameter got no gradient this step
+        # -- an unused branch of the loss for its batch -- never sees that stage's hook; it and the stages after it are
+        # then issued by sync(), in the same order the other ranks used).  A parameter without a gradient contributes zeros.
+        st.ready = True
+        for s2 in self.stages:
+            if s2.launched:
+                continue
+            if not s2.ready:
+                break
+            self._launch(s2)
+
+    def _launch(self, st: _Stage) -> None:
         st.seen = [p.grad for p in self.params[st.lo:st.hi]]          # what was packed (None = zeros)
         self._pack(st.lo, st.hi)
-        st.works = self._reduce(st.lo_elem, st.hi_elem)
+        st.works = self._reduce(st.lo_elem, st.hi_elem) if self.collective else []
         st.launched = True
 
     @torch.no_grad()
@@ -169,9 +194,7 @@ class FlatGradSync:
         # 1) everything that was not launched from a hook: pack and reduce now (stage by stage, then the uncovered rest)
         for st in self.stages:
             if not st.launched:
-                self._pack(st.lo, st.hi)
-                if self.collective:
-                    works += self._reduce(st.lo_elem, st.hi_elem)
+                self._launch(st)
         for lo, hi in self.rest:
             self._pack(lo, hi)
             if self.collective:
@@ -184,26 +207,56 @@ class FlatGradSync:
         for w in works:
             w.wait()
         # 3) gradients completed (or replaced) after their stage's launch: their slices hold a reduced stale value; put the
-        #    complete local gradient there and reduce those slices again
-        late = []
+        #    complete local gradient there and reduce those slices again.  WHICH parameters get that second all-reduce
+        #    must be the same on every rank (a rank whose batch left a trigger parameter unused launches its stages from
+        #    sync() and sees nothing arrive late): the set is fixed -- given as ``late=`` or agreed on at the first sync()
+        #    by one MAX all-reduce over per-parameter flags (the only host synchronisation this class ever makes) -- and
+        #    from then on every rank re-packs and re-reduces exactly those slices, late locally or not.
+        local_late = []
         for st in self.stages:
-            if st.launched:
-                for i, p in zip(range(st.lo, st.hi), self.params[st.lo:st.hi]):
-                    g = p.grad
-                    if g is not None and g is not st.seen[i - st.lo]:
-                        if id(g) in self._view_ids:
-                            raise RuntimeError("FlatGradSync: .grad is a stale view of the flat buffer (see _pack)")
-                        self.views[i].copy_(g)
-                        late.append((self.offsets[i], self.offsets[i] + p.numel()))
+            for i, p in zip(range(st.lo, st.hi), self.params[st.lo:st.hi]):
+                g = p.grad
+                if g is not None and g is not st.seen[i - st.lo]:
+                    if id(g) in self._view_ids:
+                        raise RuntimeError("FlatGradSync: .grad is a stale view of the flat buffer (see _pack)")
+                    local_late.append(i)
         if self.collective:
+            if self.late_idx is None:
+                flags = torch.zeros(len(self.params), dtype=torch.int32, device=self.flat.device)
+                if local_late:
+                    flags[torch.tensor(local_late, device=flags.device)] = 1
+                dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=self.group)
+                self.late_idx = [int(i) for i in flags.nonzero().flatten().tolist()]
+            unexpected = sorted(set(local_late) - set(self.late_idx))
+            if unexpected:
+                raise RuntimeError(
+                    f"FlatGradSync: the gradient of parameter #{unexpected[0]} was completed after its stage's all-reduce "
+                    "had been launched, and it is not in the agreed set of late parameters (pass it in `late=`): "
+                    "re-reducing it on this rank alone would break the collective order")
+            runs, prev = [], None
+            for i in self.late_idx:               # re-pack: the complete local gradient (zeros if there is none)
+                g = self.params[i].grad
+                if g is None:
+                    self.views[i].zero_()
+                else:
+                    self.views[i].copy_(g)
+                a, b = self.offsets[i], self.offsets[i] + self.params[i].numel()
+                if prev is not None and i == prev + 1:          # neighbours in the flat layout: one message
+                    runs[-1] = (runs[-1][0], b)
+                else:
+                    runs.append((a, b))
+                prev = i
             for w in [dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-                      for a, b in late]:
+                      for a, b in runs]:
                 w.wait()
             self.flat.mul_(1.0 / self.world)
+        else:
+            for i in local_late:
+                self.views[i].copy_(self.params[i].grad)
         for v, p in zip(self.views, self.params):
             p.grad = v
         for st in self.stages:
-            st.pending, st.launched, st.works, st.seen = len(st.triggers), False, [], []
+            st.pending, st.ready, st.launched, st.works, st.seen = len(st.triggers), False, False, [], []
 
     # (tests look at this)
     @property

@@ -73,3 +73,32 @@ def test_reference_import_line_binds_without_install():
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd="/tmp",
                          env=dict(os.environ, PYTHONDONTWRITEBYTECODE="1"))
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-2000:]
+
+
+def test_config_reserved_fields_and_owner_map_bounds_are_checked():
+    """the header's "must be 0" is enforced (a hand-filled, un-zeroed struct must not reach the kernels; the
+    wrong-result timing ablations behind reserved[0] need SNIPPER_MSDA_ALLOW_DEBUG=1 at load time), and maps with H or
+    W >= 32768 (the hit records pack qy / qx in 15 bits each) do not take the owner-computes path.  Host-only calls."""
+    lib = _lib.load()
+    import numpy as np
+    hs = np.array([[75, 100], [38, 50], [19, 25]], dtype=np.int64)
+    S = int((hs[:, 0] * hs[:, 1]).sum())
+    hp = hs.ctypes.data_as(ctypes.POINTER(ctypes.c_int64))
+    ws = lambda cfg, hp=hp, S=S, L=3: lib.snipper_msda_backward_ex_workspace_bytes(
+        None if cfg is None else ctypes.byref(cfg), hp, 0, 2, S, 8, 48, L, S, 4)
+    assert ws(None) > 0 and ws(_lib.Config.defaults()) == ws(None)
+    for field, idx in (("reserved0", None), ("reserved", 1), ("reserved", 4)):
+        cfg = _lib.Config.defaults()
+        if idx is None:
+            setattr(cfg, field, 1)
+        else:
+            getattr(cfg, field)[idx] = 1
+        assert ws(cfg) == 0, (field, idx)
+    cfg = _lib.Config.defaults()
+    cfg.reserved[0] = 1
+    if os.environ.get("SNIPPER_MSDA_ALLOW_DEBUG") != "1":
+        assert ws(cfg) == 0
+    wide = np.array([[1, 40000]], dtype=np.int64)
+    assert ws(None, wide.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), 40000, 1) == 0
+    ok = np.array([[1, 30000]], dtype=np.int64)
+    assert ws(None, ok.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), 30000, 1) > 0

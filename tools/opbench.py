@@ -13,6 +13,8 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if "--debug" in sys.argv:        # the wrong-result timing ablations are refused unless asked for before the library loads
+    os.environ.setdefault("SNIPPER_MSDA_ALLOW_DEBUG", "1")
 from snipper_amd import MultiScaleDeformableAttention as MSDA   # noqa: E402
 from snipper_amd import _lib                                     # noqa: E402
 from snipper_amd.ms_deform_attn_func import ms_deform_attn_core_pytorch  # noqa: E402
