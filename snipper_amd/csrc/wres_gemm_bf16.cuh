@@ -1,0 +1,254 @@
+// wres_gemm_bf16.cuh -- weight-stationary bf16 MFMA kernel for the encoder's short-reduction dense layers (gfx950).
+//
+//   Y[M, N] = gate( dropout( act( X[M, K] . W^T + bias ) ) )     K = 32 * KS <= 384,  M = tens of thousands of token rows
+//
+// Reference shapes: every nn.Linear of MSDeformAttn (models/ops/modules/ms_deform_attn.py:60-66: value / output / offset /
+// weight projections, 384 -> 384 / 288), linear1 of the encoder FFN (models/deformable_transformer.py:180-198, 384 -> 1024)
+// and the data gradients whose REDUCTION is that short axis (dX = dY . W for the 384- and 288-wide outputs, and the FFN's
+// hidden gradient dH = dZ . W2 with the ReLU / dropout gate), on M = B*T*S = 79 000 rows.
+//
+// Why another kernel.  With K = 384 a 128 x 128 output tile has six K-steps; csrc/gemm_bf16.cuh keeps one K-step of
+// operands in flight per workgroup, so every step pays a memory round trip (profiles/r02_gemm_phase_ablation.json: the
+// phases of a tile are additive, 44 us for 79 000 x 384 x 384 against a 19 us HBM floor), and X is read once per 128 output
+// columns.  Here the roles are turned round:
+//   * W is STATIONARY IN REGISTERS.  A workgroup of 8 waves covers up to 384 output columns, wave w the 48 columns
+//     [48w, 48w + 48): its W slice, 48 x K bf16 = 36 KB, is 3 x KS MFMA A-fragments = 144 VGPRs, loaded once per launch.
+//     There is no W traffic in the main loop at all (not from L2, not from LDS).
+//   * X is streamed through LDS by LDS-DMA (buffer_load ... lds) in chunks of 32 rows x K (24 KB), a ring of 3-4 slots per
+//     workgroup, ONE workgroup per CU walking a strided list of chunks: 48-72 KB of HBM reads are in flight per CU at any
+//     time, across the barriers (counted s_waitcnt vmcnt, raw s_barrier), which is what the HBM roofline needs
+//     (MI355X_MICROARCH.md: ~25 GB/s per CU at ~2 us of loaded latency).  X is read from HBM exactly once per 384 columns.
+//   * each wave multiplies the chunk's 2 x KS X fragments (ds_read_b128, XOR-swizzled image: conflict-free) with its
+//     resident W fragments: 72 v_mfma_f32_16x16x32_bf16 per chunk and wave, Y^T = W . X^T so that a lane owns 4
+//     consecutive columns of one row; the finished bf16 chunk is parked in LDS and written as whole rows, 16 B per lane.
+//   * the gate operand (the FFN's hidden activation, whose sign gates dH) rides the same DMA mechanism in its own ring.
+// Every vector-memory instruction of the loop is an LDS-DMA or a range-checked buffer store issued by ALL lanes, so the
+// counted waits are exact; rows / columns past the matrix are handled by the buffer range check (reads 0, stores dropped).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "gemm_bf16.cuh"
+
+namespace snipper {
+
+constexpr int kWrThreads = 512, kWrRows = 32, kWrPieces = 48, kWrRowB = kWrPieces * 16;     // LDS image: 768-byte rows
+constexpr int kWrSlotB = kWrRows * kWrRowB;                                                // 24 576
+constexpr int kWrStageStrideB = kWrRowB + 16, kWrStageB = kWrRows * kWrStageStrideB;       // 784-byte rows (2-way writes)
+constexpr int kWrCols = 384;                                                               // output columns per workgroup
+constexpr int kWrPerThread = kWrRows * kWrPieces / kWrThreads;                             // 3 pieces of 16 B per thread
+
+struct WresArgs {
+  const uint16_t *X; long long ldx;      // [M][K]
+  const uint16_t *W; long long ldw;      // [N][K] (row stride ldw): a data gradient passes the TRANSPOSED weight
+  const float *bias;                     // [N] or nullptr
+  const uint16_t *A; long long lda;      // [M][N] gate activation or nullptr (GATE instantiation only)
+  float gate_scale;
+  uint16_t *Y; long long ldy;            // [M][N]
+  int M, N, K;
+  int relu;
+  float drop_p; uint32_t seed_lo, seed_hi;
+  int n_series;                          // chunk lists: gridDim.x = n_series * ceil(N / 384)
+};
+
+typedef __attribute__((address_space(3))) void wres_lds_void;
+
+__device__ __forceinline__ void wres_dma16(__amdgpu_buffer_rsrc_t src, unsigned char *lds_wave_base, unsigned voff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(src, (wres_lds_void *)lds_wave_base, 16, voff, 0, 0, 0);
+}
+
+// NS = X ring slots; GATE adds a 2-slot ring for the gate operand.  LDS: NS * 24 KB (+ 48 KB) + 24.5 KB staging.
+template <int KS, bool GATE>
+__global__ __launch_bounds__(kWrThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void wres_gemm_kernel(WresArgs g) {
+  constexpr int NS = GATE ? 3 : 4, GS = 2;
+  constexpr int kRingB = NS * kWrSlotB, kGateB = GATE ? GS * kWrSlotB : 0;
+  // ONE LDS object (a second one beside an LDS-DMA target makes hipcc drain vmcnt before every ds_read)
+  __shared__ __attribute__((aligned(16))) unsigned char smem[kRingB + kGateB + kWrStageB];
+  unsigned char *ring = smem, *gring = smem + kRingB, *stage = smem + kRingB + kGateB;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+  // workgroup -> (column block cb, chunk list `series`): the ncb workgroups that share a chunk list sit on one XCD
+  // (ids b, b + 8, b + 16: round-robin placement), so a chunk comes from HBM once and from that XCD's L2 after
+  const int ncb = (g.N + kWrCols - 1) / kWrCols, per_group = 8 * ncb;
+  const int b = blockIdx.x, grp = b / per_group, within = b - grp * per_group;
+  const int cb = within >> 3, series = grp * 8 + (within & 7);
+  const int n0 = cb * kWrCols;
+  const int NC = (g.M + kWrRows - 1) / kWrRows;
+  const int n_iter = series < NC ? (NC - series + g.n_series - 1) / g.n_series : 0;
+  if (n_iter == 0) return;
+
+  // ---- per-thread DMA geometry: piece i = tid + 512 t of a chunk image; row r = i / 48, slot s = i % 48 holds the 16-byte
+  // piece c = s ^ (r & 15) of the row (the XOR makes the fragment reads below conflict-free; rows are 48 pieces = 3
+  // blocks of 16, the XOR stays inside a block)
+  unsigned x_voff[kWrPerThread];
+  int lds_piece[kWrPerThread];
+#pragma unroll
+  for (int t = 0; t < kWrPerThread; ++t) {
+    const int i = tid + kWrThreads * t, r = i / kWrPieces, s = i - r * kWrPieces, c = s ^ (r & 15);
+    x_voff[t] = c * 8 < g.K ? ((unsigned)r * (unsigned)g.ldx + (unsigned)c * 8u) * 2u : 0x80000000u;
+    lds_piece[t] = (i - lane) * 16;                 // wave-uniform: the hardware adds lane * 16
+  }
+  auto chunk_of = [&](int it) { return series + it * g.n_series; };
+  auto x_rsrc = [&](int chunk) {
+    const int rows = chunk < NC ? min(kWrRows, g.M - chunk * kWrRows) : 0;
+    const long long bytes = rows > 0 ? ((long long)(rows - 1) * g.ldx + g.K) * 2 : 0;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(g.X + (long long)(rows > 0 ? chunk : 0) * kWrRows * g.ldx), 0,
+                                             (int)bytes, 0x00020000);
+  };
+  auto issue_x = [&](int it) {                       // ALWAYS 3 instructions (an empty descriptor past the last chunk)
+    const __amdgpu_buffer_rsrc_t src = x_rsrc(it < n_iter ? chunk_of(it) : NC);
+    unsigned char *slot = ring + ((it + NS) % NS) * kWrSlotB;
+#pragma unroll
+    for (int t = 0; t < kWrPerThread; ++t) wres_dma16(src, slot + lds_piece[t], x_voff[t]);
+  };
+  // gate / output geometry: the same pieces, unswizzled (piece c of row r at r * 768 + c * 16); a thread DMA-writes
+  // exactly the gate pieces it reads back in the flush, so the gate ring needs no barrier of its own
+  unsigned a_voff[kWrPerThread], y_voff[kWrPerThread];
+  int flush_row[kWrPerThread], flush_c[kWrPerThread];
+#pragma unroll
+  for (int t = 0; t < kWrPerThread; ++t) {
+    const int i = tid + kWrThreads * t, r = i / kWrPieces, c = i - r * kWrPieces;
+    flush_row[t] = r; flush_c[t] = c;
+    const bool col_ok = n0 + c * 8 < g.N;
+    a_voff[t] = (GATE && col_ok) ? ((unsigned)r * (unsigned)g.lda + (unsigned)c * 8u) * 2u : 0x80000000u;
+    y_voff[t] = col_ok ? ((unsigned)r * (unsigned)g.ldy + (unsigned)c * 8u) * 2u : 0x80000000u;
+  }
+  auto issue_gate = [&](int it) {
+    const int chunk = (it >= 0 && it < n_iter) ? chunk_of(it) : NC;
+    const int rows = chunk < NC ? min(kWrRows, g.M - chunk * kWrRows) : 0;
+    const long long bytes = rows > 0 ? ((long long)(rows - 1) * g.lda + (g.N - n0)) * 2 : 0;
+    const __amdgpu_buffer_rsrc_t src = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint16_t *>(g.A + (long long)(rows > 0 ? chunk : 0) * kWrRows * g.lda + n0), 0, (int)bytes, 0x00020000);
+    unsigned char *slot = gring + ((it + GS) % GS) * kWrSlotB;
+#pragma unroll
+    for (int t = 0; t < kWrPerThread; ++t) wres_dma16(src, slot + lds_piece[t], a_voff[t]);
+  };
+
+  // ---- W slice of this wave into registers: fragment (nt, ks) = rows n = n0 + 48 wave + 16 nt + (lane & 15), reduction
+  // elements k = 32 ks + 8 (lane >> 4) .. + 7 (the A operand of v_mfma_f32_16x16x32_bf16)
+  gemm_bf16x8 wf[3][KS];
+  const int wn0 = n0 + 48 * wave;
+  // ---- prologue.  The counted waits of the main loop assume the steady-state instruction stream -- per iteration j:
+  // X DMA of chunk j + NS - 1, (gate DMA of chunk j + 1,) ... stores of chunk j, three instructions each -- so the NS - 1
+  // iterations "before the first" are issued in exactly that shape, with dropped stores (and an empty gate descriptor).
+  const __amdgpu_buffer_rsrc_t nowhere = __builtin_amdgcn_make_buffer_rsrc(g.Y, 0, 0, 0x00020000);
+#pragma unroll
+  for (int j = -(NS - 1); j < 0; ++j) {
+    issue_x(j + NS - 1);
+    if constexpr (GATE) issue_gate(j + 1);
+#pragma unroll
+    for (int t = 0; t < kWrPerThread; ++t)
+      __builtin_amdgcn_raw_buffer_store_b128(gemm_u32x4{0u, 0u, 0u, 0u}, nowhere, 0x80000000u, 0, 0);
+  }
+  {
+    const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint16_t *>(g.W), 0, (int)(((long long)(g.N - 1) * g.ldw + g.K) * 2), 0x00020000);
+#pragma unroll
+    for (int nt = 0; nt < 3; ++nt) {
+      const int n = wn0 + 16 * nt + (lane & 15);
+      const unsigned base = n < g.N ? ((unsigned)n * (unsigned)g.ldw + 8u * (unsigned)(lane >> 4)) * 2u : 0x80000000u;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+        wf[nt][ks] = __builtin_bit_cast(gemm_bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wsrc, base + ks * 64u, 0, 0));
+    }
+  }
+  // bias of this lane's 4 consecutive columns per n-tile
+  gemm_f32x4 bias[3];
+#pragma unroll
+  for (int nt = 0; nt < 3; ++nt) {
+    const int n = wn0 + 16 * nt + 4 * (lane >> 4);
+    bias[nt] = gemm_f32x4{0.f, 0.f, 0.f, 0.f};
+    if (g.bias && n < g.N) bias[nt] = *reinterpret_cast<const gemm_f32x4 *>(g.bias + n);
+  }
+  // the compiler's own waits for these register loads belong HERE, not at their first use inside the loop (where its
+  // conservative vmcnt(0) would drain the DMA ring every iteration): consume every value once
+#pragma unroll
+  for (int nt = 0; nt < 3; ++nt) {
+    asm volatile("" ::"v"(bias[nt]));
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) asm volatile("" ::"v"(wf[nt][ks]));
+  }
+  // n-tiles of this wave that hold real columns (wave-uniform)
+  const int nta = wn0 >= g.N ? 0 : min(3, (g.N - wn0 + 15) / 16);
+  const bool drop = g.drop_p > 0.f;
+  const float keep_scale = drop ? 1.f / (1.f - g.drop_p) : 1.f;
+  const uint32_t thresh = (uint32_t)fminf(g.drop_p * 4294967296.f, 4294967040.f);
+  const int frow = lane & 15, fk = lane >> 4;
+
+  for (int it = 0; it < n_iter; ++it) {
+    // ---- top: keep the rings full.  Slot (it - 1) % NS was last read before barrier B2 of iteration it - 1.
+    issue_x(it + NS - 1);
+    if constexpr (GATE) issue_gate(it + 1);
+    // vector-memory instructions younger than chunk `it`'s three DMAs (3 per chunk each of X, gate, stores):
+    //   plain: X(it+1 .. it+3) + stores(it-3 .. it-1) = 18;   gate (NS = 3): G(it-1), S(it-2), X(it+1), G(it), S(it-1), X(it+2), G(it+1) = 21
+    if constexpr (GATE) asm volatile("s_waitcnt vmcnt(21)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                   // B1: every wave's pieces of chunk `it` have landed
+    const unsigned char *slot = ring + (it % NS) * kWrSlotB;
+    const int chunk = chunk_of(it), m0 = chunk * kWrRows;
+
+    gemm_f32x4 acc[3][2];
+#pragma unroll
+    for (int nt = 0; nt < 3; ++nt)
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) acc[nt][mt] = gemm_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        const gemm_bf16x8 xf = *reinterpret_cast<const gemm_bf16x8 *>(
+            slot + (16 * mt + frow) * kWrRowB + 16 * ((4 * ks + fk) ^ frow));
+#pragma unroll
+        for (int nt = 0; nt < 3; ++nt)
+          if (nt < nta) acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt][ks], xf, acc[nt][mt], 0, 0, 0);
+      }
+    }
+
+    // ---- epilogue into the staging image: lane holds columns n .. n + 3 of row 16 mt + (lane & 15)
+#pragma unroll
+    for (int nt = 0; nt < 3; ++nt) {
+      if (nt >= nta) continue;
+      const int nl = 48 * wave + 16 * nt + 4 * (lane >> 4);          // column within the 384-wide block
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        gemm_f32x4 v = acc[nt][mt] + bias[nt];
+        if (g.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        if (drop) {
+          const uint32_t e = (uint32_t)(m0 + 16 * mt + frow) * (uint32_t)g.N + (uint32_t)(n0 + nl);
+          v.x = gemm_rand(e, g.seed_lo, g.seed_hi) >= thresh ? v.x * keep_scale : 0.f;
+          v.y = gemm_rand(e + 1, g.seed_lo, g.seed_hi) >= thresh ? v.y * keep_scale : 0.f;
+          v.z = gemm_rand(e + 2, g.seed_lo, g.seed_hi) >= thresh ? v.z * keep_scale : 0.f;
+          v.w = gemm_rand(e + 3, g.seed_lo, g.seed_hi) >= thresh ? v.w * keep_scale : 0.f;
+        }
+        if constexpr (GATE) { v.x *= g.gate_scale; v.y *= g.gate_scale; v.z *= g.gate_scale; v.w *= g.gate_scale; }
+        uint2 o;
+        o.x = gemm_pack2(v.x, v.y);
+        o.y = gemm_pack2(v.z, v.w);
+        *reinterpret_cast<uint2 *>(stage + (16 * mt + frow) * kWrStageStrideB + nl * 2) = o;
+      }
+    }
+    if constexpr (GATE) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");   // younger than G(it): S(it-1), X(it+2), G(it+1)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                   // B2: the chunk's output image is complete
+
+    // ---- flush: whole rows, 16 B per lane; rows past M and columns past N are dropped by the range check
+    const int rows = min(kWrRows, g.M - m0);
+    const __amdgpu_buffer_rsrc_t ysrc = __builtin_amdgcn_make_buffer_rsrc(
+        g.Y + (long long)m0 * g.ldy + n0, 0, (int)(((long long)(rows - 1) * g.ldy + (g.N - n0)) * 2), 0x00020000);
+#pragma unroll
+    for (int t = 0; t < kWrPerThread; ++t) {
+      gemm_u32x4 v = *reinterpret_cast<const gemm_u32x4 *>(stage + flush_row[t] * kWrStageStrideB + flush_c[t] * 16);
+      if constexpr (GATE) {
+        const gemm_u32x4 a = *reinterpret_cast<const gemm_u32x4 *>(gring + (it % GS) * kWrSlotB + (tid + kWrThreads * t) * 16);
+        auto keep = [](unsigned av, unsigned vv) {
+          const unsigned lo = ((av & 0x8000u) == 0u && (av & 0x7fffu) != 0u) ? 0x0000ffffu : 0u;
+          const unsigned hi = ((av & 0x80000000u) == 0u && (av & 0x7fff0000u) != 0u) ? 0xffff0000u : 0u;
+          return vv & (lo | hi);
+        };
+        v.x = keep(a.x, v.x); v.y = keep(a.y, v.y); v.z = keep(a.z, v.z); v.w = keep(a.w, v.w);
+      }
+      __builtin_amdgcn_raw_buffer_store_b128(v, ysrc, y_voff[t], 0, 0);
+    }
+  }
+}
+
+}  // namespace snipper

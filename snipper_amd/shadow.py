@@ -178,7 +178,18 @@ class WeightShadows:
             for e, w in zip(mul_dst, mul_src):
                 e.version = w._version
         if cp_src:
-            torch._foreach_copy_([d.dst if isinstance(d, _Entry) else d for d in cp_dst], cp_src)
+            # one multi-tensor launch per (destination dtype, source dtype) pair: a list that mixes bf16 <- f32 weight
+            # copies with f32 <- f32 bias copies is NOT safe -- PyTorch 2.10's _foreach_copy_ converted every source to
+            # the FIRST destination's dtype and wrote bf16 bits into the float32 bias buffers of the merged projections
+            # (found in round 3: the offset projection lost its bias under autocast)
+            groups: Dict[Tuple[torch.dtype, torch.dtype], Tuple[list, list]] = {}
+            for d, w in zip(cp_dst, cp_src):
+                t = d.dst if isinstance(d, _Entry) else d
+                gd, gs = groups.setdefault((t.dtype, w.dtype), ([], []))
+                gd.append(t)
+                gs.append(w)
+            for gd, gs in groups.values():
+                torch._foreach_copy_(gd, gs)
             for d, w in zip(cp_dst, cp_src):
                 if isinstance(d, _Entry):
                     d.version = w._version

@@ -40,3 +40,27 @@ def test_shadows_follow_a_fused_optimizer_on_the_gpu():
     ws.refresh()
     again = shadow.lookup(lin.weight)
     assert again is not None and torch.equal(again, lin.weight.detach().bfloat16())
+
+
+@pytest.mark.gpu
+def test_refresh_with_weights_and_merged_biases_in_one_pass_keeps_every_dtype():
+    """Round 3: one _foreach_copy_ over a list mixing bf16 <- f32 (weights) and f32 <- f32 (the merged projections' biases)
+    wrote bf16 bits into the float32 bias buffers -- the offset projection ran without its bias under autocast.  Every
+    shadow of a refresh that has Linears AND merged pairs must equal its source."""
+    torch.manual_seed(0)
+    lin = nn.Linear(128, 64).cuda()
+    off, att = nn.Linear(128, 48).cuda(), nn.Linear(128, 24).cuda()
+    with torch.no_grad():
+        off.bias.copy_(torch.arange(48.0) - 20.0)
+
+    class Holder(nn.Module):
+        pass
+    ws = shadow.WeightShadows(Holder())
+    ws.linears.append(lin)
+    ws.pairs.append((off, att))
+    ws.refresh()
+    assert torch.equal(shadow.lookup(lin.weight), lin.weight.detach().bfloat16())
+    w, b = shadow.lookup_merged(off, att)
+    assert w.dtype == torch.bfloat16 and b.dtype == torch.float32
+    assert torch.equal(w, torch.cat([off.weight, att.weight]).detach().bfloat16())
+    assert torch.equal(b, torch.cat([off.bias, att.bias]).detach())
