@@ -43,6 +43,24 @@ int snipper_linear_nn_bf16(void *stream, const uint16_t *X, long long ldx, const
                            const uint16_t *R, long long ldr, const uint16_t *A, long long lda, float gate_scale,
                            uint16_t *Y, long long ldy, int M, int N, int K);
 
+/* Weight-stationary form of snipper_linear_bf16 for SHORT reductions on many rows (csrc/wres_gemm_bf16.cuh):
+ *   Y[M,N] = gate( dropout( act( X[M,K] . W[N,K]^T + bias ) ) ),   K in {288, 384}, N % 8 == 0, M >= 8192.
+ * W (row stride ldw) stays in registers for the whole launch, X is streamed through an LDS-DMA ring, one persistent
+ * workgroup per CU; a data gradient dX = dY . Wl passes the TRANSPOSED weight (snipper_transpose_batch_bf16).  A = NULL or
+ * the gate activation [M][N]: gate(v) = A > 0 ? v * gate_scale : 0 (see snipper_linear_nn_bf16).  Same dropout hash as
+ * snipper_linear_bf16 (bit-identical masks).  ldx, ldw, ldy, lda % 8 == 0; X, W, Y, A 16-byte aligned.
+ * snipper_linear_wres_supported: 1 when the shape is taken (snipper_linear_bf16 itself dispatches here when it is and
+ * there is no residual), else 0 and the entry point returns SNIPPER_E_UNSUPPORTED. */
+int snipper_linear_wres_supported(int M, int N, int K);
+int snipper_linear_wres_bf16(void *stream, const uint16_t *X, long long ldx, const uint16_t *W, long long ldw,
+                             const float *bias, const uint16_t *A, long long lda, float gate_scale, uint16_t *Y,
+                             long long ldy, int M, int N, int K, int relu, float dropout_p, uint64_t seed);
+
+/* dst_i[c][r] = src_i[r][c] (bf16 bits) for count <= 48 small matrices in one launch: src_i [rows_i][cols_i] with row
+ * stride ld_src_i, dst_i [cols_i][rows_i] with row stride ld_dst_i.  The arrays are HOST arrays of count entries. */
+int snipper_transpose_batch_bf16(void *stream, int count, const void *const *src, void *const *dst, const int *rows,
+                                 const int *cols, const long long *ld_src, const long long *ld_dst);
+
 /* Backward of the (ReLU -> dropout) epilogue above from the layer's OUTPUT alone: a kept, active element has y > 0,
  * a dropped or inactive one y == 0, so grad_pre = y > 0 ? grad_y / (1 - p) : 0 (p = 0: plain ReLU backward).
  * bf16 bits, n % 8 == 0, 16-byte aligned. */

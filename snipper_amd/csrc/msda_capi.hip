@@ -15,6 +15,7 @@
 #include "../../include/snipper_dense.h"
 #include "gemm_bf16.cuh"
 #include "wgrad_bf16.cuh"
+#include "wres_gemm_bf16.cuh"
 #include "small_linear.cuh"
 #include "small_attention.cuh"
 #include "match_cost.cuh"
@@ -447,10 +448,85 @@ int snipper_msda_backward_bf16(void *stream, const uint16_t *grad_out, const uin
                                   N, S, M, D, L, Lq, P, grad_value, grad_loc, grad_attn);
 }
 
+namespace {
+// compute units of the current device (one persistent workgroup each in the weight-stationary kernel); read once
+int device_cu_count() {
+  static const int n = [] {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+      cus = 256;
+    return cus;
+  }();
+  return n;
+}
+// SNIPPER_GEMM_WRES=0 in the environment at load time keeps every product on the tile kernels (A/B measurements)
+bool wres_enabled() {
+  static const bool on = [] { const char *e = getenv("SNIPPER_GEMM_WRES"); return !(e && e[0] == '0'); }();
+  return on;
+}
+}  // namespace
+
+int snipper_linear_wres_supported(int M, int N, int K) {
+  return (K == 384 || K == 288) && N >= 16 && N % 8 == 0 && M >= 8192 && (long long)M * (N > K ? N : K) < (1LL << 30) ? 1 : 0;
+}
+
+int snipper_linear_wres_bf16(void *stream, const uint16_t *X, long long ldx, const uint16_t *W, long long ldw,
+                             const float *bias, const uint16_t *A, long long lda, float gate_scale, uint16_t *Y,
+                             long long ldy, int M, int N, int K, int relu, float dropout_p, uint64_t seed) {
+  if (!X || !W || !Y) return SNIPPER_E_NULL;
+  if (M <= 0 || N <= 0 || K <= 0 || ldx % 8 || ldw % 8 || ldy % 8 || ldx < K || ldw < K || ldy < N || (A && (lda % 8 || lda < N)) ||
+      !(dropout_p >= 0.f && dropout_p < 1.f) || (dropout_p > 0.f && (long long)M * N >= (1LL << 32)))
+    return SNIPPER_E_SHAPE;
+  if (((uintptr_t)X | (uintptr_t)W | (uintptr_t)Y | (uintptr_t)A) & 15) return SNIPPER_E_SHAPE;
+  if (!snipper_linear_wres_supported(M, N, K)) return SNIPPER_E_UNSUPPORTED;
+  // 32-bit byte offsets inside a 32-row chunk and 31-bit descriptor sizes
+  if (32 * ldx * 2 >= (1LL << 31) || 32 * ldy * 2 >= (1LL << 31) || (long long)N * ldw * 2 >= (1LL << 31) || (A && 32 * lda * 2 >= (1LL << 31)))
+    return SNIPPER_E_SHAPE;
+  const int ncb = (N + kWrCols - 1) / kWrCols;
+  const int chunks = (M + kWrRows - 1) / kWrRows;
+  int n_series = 8 * (device_cu_count() / (8 * ncb));
+  if (n_series < 8) n_series = 8;
+  if (n_series > ((chunks + 7) / 8) * 8) n_series = ((chunks + 7) / 8) * 8;
+  const WresArgs g{X, ldx, W, ldw, bias, A, lda, gate_scale, Y, ldy, M, N, K, relu ? 1 : 0, dropout_p,
+                   (uint32_t)seed, (uint32_t)(seed >> 32), n_series};
+  const dim3 grid((unsigned)(n_series * ncb)), block(kWrThreads);
+  hipStream_t st = (hipStream_t)stream;
+  if (K == 384) {
+    if (A) hipLaunchKernelGGL((wres_gemm_kernel<12, true>), grid, block, 0, st, g);
+    else hipLaunchKernelGGL((wres_gemm_kernel<12, false>), grid, block, 0, st, g);
+  } else {
+    if (A) hipLaunchKernelGGL((wres_gemm_kernel<9, true>), grid, block, 0, st, g);
+    else hipLaunchKernelGGL((wres_gemm_kernel<9, false>), grid, block, 0, st, g);
+  }
+  return launch_status();
+}
+
+int snipper_transpose_batch_bf16(void *stream, int count, const void *const *src, void *const *dst, const int *rows,
+                                 const int *cols, const long long *ld_src, const long long *ld_dst) {
+  if (count <= 0) return SNIPPER_OK;
+  if (!src || !dst || !rows || !cols || !ld_src || !ld_dst) return SNIPPER_E_NULL;
+  if (count > kTrMaxItems) return SNIPPER_E_SHAPE;
+  TransposeBatch b{};
+  int tiles = 0;
+  for (int i = 0; i < count; ++i) {
+    if (!src[i] || !dst[i]) return SNIPPER_E_NULL;
+    if (rows[i] <= 0 || cols[i] <= 0 || ld_src[i] < cols[i] || ld_dst[i] < rows[i]) return SNIPPER_E_SHAPE;
+    const int tr = (rows[i] + 63) / 64, tc = (cols[i] + 63) / 64;
+    b.it[i] = TransposeItem{(const uint16_t *)src[i], (uint16_t *)dst[i], rows[i], cols[i], (int)ld_src[i], (int)ld_dst[i], tiles, tc};
+    tiles += tr * tc;
+  }
+  b.count = count;
+  hipLaunchKernelGGL(transpose_batch_bf16_kernel, dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, b);
+  return launch_status();
+}
+
 int snipper_linear_bf16(void *stream, const uint16_t *X, long long ldx, const uint16_t *W,
                         const float *bias, const uint16_t *R, long long ldr, uint16_t *Y, long long ldy,
                         int M, int N, int K, int relu, float dropout_p, uint64_t seed) {
   if (!X || !W || !Y) return SNIPPER_E_NULL;
+  if (!R && wres_enabled() && snipper_linear_wres_supported(M, N, K) && ldx % 8 == 0 && ldy % 8 == 0 &&
+      !(((uintptr_t)X | (uintptr_t)W | (uintptr_t)Y) & 15))
+    return snipper_linear_wres_bf16(stream, X, ldx, W, K, bias, nullptr, 0, 1.f, Y, ldy, M, N, K, relu, dropout_p, seed);
   if (M <= 0 || N <= 0 || K <= 0 || K % kGemmBK || N % 4 || ldx % 8 || ldy % 4 || ldx < K || ldy < N ||
       (R && (ldr % 4 || ldr < N)) || !(dropout_p >= 0.f && dropout_p < 1.f) ||
       (dropout_p > 0.f && (long long)M * N >= (1LL << 32)))

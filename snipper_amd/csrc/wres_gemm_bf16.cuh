@@ -51,6 +51,7 @@ struct WresArgs {
 };
 
 typedef __attribute__((address_space(3))) void wres_lds_void;
+typedef __attribute__((ext_vector_type(2))) unsigned int wres_u32x2;
 
 __device__ __forceinline__ void wres_dma16(__amdgpu_buffer_rsrc_t src, unsigned char *lds_wave_base, unsigned voff) {
   __builtin_amdgcn_raw_ptr_buffer_load_lds(src, (wres_lds_void *)lds_wave_base, 16, voff, 0, 0, 0);
@@ -173,6 +174,7 @@ __global__ __launch_bounds__(kWrThreads) __attribute__((amdgpu_waves_per_eu(2, 2
   const float keep_scale = drop ? 1.f / (1.f - g.drop_p) : 1.f;
   const uint32_t thresh = (uint32_t)fminf(g.drop_p * 4294967296.f, 4294967040.f);
   const int frow = lane & 15, fk = lane >> 4;
+  const unsigned stage_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)stage;
 
   for (int it = 0; it < n_iter; ++it) {
     // ---- top: keep the rings full.  Slot (it - 1) % NS was last read before barrier B2 of iteration it - 1.
@@ -191,19 +193,23 @@ __global__ __launch_bounds__(kWrThreads) __attribute__((amdgpu_waves_per_eu(2, 2
     for (int nt = 0; nt < 3; ++nt)
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) acc[nt][mt] = gemm_f32x4{0.f, 0.f, 0.f, 0.f};
+    if (nta > 0) {          // (wave-uniform: a wave whose 48 columns lie past N only keeps the barriers company)
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
+      for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt) {
-        const gemm_bf16x8 xf = *reinterpret_cast<const gemm_bf16x8 *>(
-            slot + (16 * mt + frow) * kWrRowB + 16 * ((4 * ks + fk) ^ frow));
+        for (int mt = 0; mt < 2; ++mt) {
+          const gemm_bf16x8 xf = *reinterpret_cast<const gemm_bf16x8 *>(
+              slot + (16 * mt + frow) * kWrRowB + 16 * ((4 * ks + fk) ^ frow));
 #pragma unroll
-        for (int nt = 0; nt < 3; ++nt)
-          if (nt < nta) acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt][ks], xf, acc[nt][mt], 0, 0, 0);
+          for (int nt = 0; nt < 3; ++nt)
+            acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt][ks], xf, acc[nt][mt], 0, 0, 0);
+        }
       }
     }
 
-    // ---- epilogue into the staging image: lane holds columns n .. n + 3 of row 16 mt + (lane & 15)
+    // ---- epilogue into the staging image: lane holds columns n .. n + 3 of row 16 mt + (lane & 15).  The LDS stores are
+    // inline assembly: for a compiler-visible ds_write hipcc drains vmcnt(0) first (a pending LDS-DMA might alias it),
+    // which would empty the ring every iteration; the s_waitcnt lgkmcnt(0) in front of barrier B2 covers them.
 #pragma unroll
     for (int nt = 0; nt < 3; ++nt) {
       if (nt >= nta) continue;
@@ -220,10 +226,11 @@ __global__ __launch_bounds__(kWrThreads) __attribute__((amdgpu_waves_per_eu(2, 2
           v.w = gemm_rand(e + 3, g.seed_lo, g.seed_hi) >= thresh ? v.w * keep_scale : 0.f;
         }
         if constexpr (GATE) { v.x *= g.gate_scale; v.y *= g.gate_scale; v.z *= g.gate_scale; v.w *= g.gate_scale; }
-        uint2 o;
-        o.x = gemm_pack2(v.x, v.y);
-        o.y = gemm_pack2(v.z, v.w);
-        *reinterpret_cast<uint2 *>(stage + (16 * mt + frow) * kWrStageStrideB + nl * 2) = o;
+        wres_u32x2 o;
+        o[0] = gemm_pack2(v.x, v.y);
+        o[1] = gemm_pack2(v.z, v.w);
+        const unsigned addr = stage_lds + (unsigned)((16 * mt + frow) * kWrStageStrideB + nl * 2);
+        asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(o) : "memory");
       }
     }
     if constexpr (GATE) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");   // younger than G(it): S(it-1), X(it+2), G(it+1)
@@ -248,6 +255,31 @@ __global__ __launch_bounds__(kWrThreads) __attribute__((amdgpu_waves_per_eu(2, 2
       }
       __builtin_amdgcn_raw_buffer_store_b128(v, ysrc, y_voff[t], 0, 0);
     }
+  }
+}
+
+// ---- batched bf16 transpose: dst_i[c][r] = src_i[r][c] for a short list of small matrices in ONE launch -----------------
+// (the data gradients above want W^T; the per-step weight refresh, snipper_amd/shadow.py, writes the transposed bf16
+// copies of ~30 weights with this kernel instead of one strided-copy launch per weight)
+constexpr int kTrMaxItems = 48;
+struct TransposeItem { const uint16_t *src; uint16_t *dst; int rows, cols, ld_src, ld_dst, tile0, tiles_c; };
+struct TransposeBatch { TransposeItem it[kTrMaxItems]; int count; };
+
+__global__ __launch_bounds__(256) void transpose_batch_bf16_kernel(TransposeBatch b) {
+  __shared__ uint16_t tile[64][66];
+  int i = 0;
+  while (i + 1 < b.count && (int)blockIdx.x >= b.it[i + 1].tile0) ++i;          // tiny list: linear search
+  const TransposeItem &t = b.it[i];
+  const int local = blockIdx.x - t.tile0, tr = local / t.tiles_c, tc = local - tr * t.tiles_c;
+  const int r0 = tr * 64, c0 = tc * 64;
+  for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+    const int r = e >> 6, c = e & 63;
+    tile[r][c] = (r0 + r < t.rows && c0 + c < t.cols) ? t.src[(long long)(r0 + r) * t.ld_src + c0 + c] : (uint16_t)0;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+    const int c = e >> 6, r = e & 63;                                            // dst row = source column
+    if (c0 + c < t.cols && r0 + r < t.rows) t.dst[(long long)(c0 + c) * t.ld_dst + r0 + r] = tile[r][c];
   }
 }
 

@@ -43,6 +43,64 @@ def linear_bf16(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tens
     return out.view(*x.shape[:-1], N)
 
 
+def wres_supported(M: int, N: int, K: int) -> bool:
+    """Shape taken by the weight-stationary kernel (csrc/wres_gemm_bf16.cuh): K in {288, 384}, many rows."""
+    return bool(_lib.load().snipper_linear_wres_supported(int(M), int(N), int(K)))
+
+
+def linear_wres_bf16(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, relu: bool = False,
+                     dropout_p: float = 0.0, seed: int = 0, gate: Optional[torch.Tensor] = None,
+                     gate_scale: float = 1.0) -> torch.Tensor:
+    """gate(dropout(act(x @ weight.T + bias))) on the weight-stationary kernel: x [M, K] bf16 (K = 288 or 384, rows
+    16-byte aligned), weight [N, K] bf16 (row stride % 8 == 0) -- a data gradient dX = dY @ W passes W^T here --,
+    bias [N] float32 or None, gate [M, N] bf16 or None (result = gate > 0 ? result * gate_scale : 0)  ->  [M, N] bf16."""
+    assert x.is_cuda and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and x.dim() == 2 and weight.dim() == 2
+    M, K = x.shape
+    N = weight.shape[0]
+    if x.stride(1) != 1 or x.stride(0) % 8 or x.data_ptr() % 16:
+        x = x.contiguous()
+    if weight.stride(1) != 1 or weight.stride(0) % 8 or weight.data_ptr() % 16:
+        weight = weight.contiguous()
+    if gate is not None:
+        assert gate.dtype == torch.bfloat16 and gate.shape == (M, N)
+        if gate.stride(1) != 1 or gate.stride(0) % 8 or gate.data_ptr() % 16:
+            gate = gate.contiguous()
+    if bias is not None and bias.dtype != torch.float32:
+        bias = bias.float()
+    out = torch.empty((M, N), dtype=torch.bfloat16, device=x.device)
+    with _lib.device_guard(x.device):
+        rc = _lib.load().snipper_linear_wres_bf16(
+            _lib.raw_stream(x.device), x.data_ptr(), x.stride(0), weight.data_ptr(), weight.stride(0),
+            bias.data_ptr() if bias is not None else None, gate.data_ptr() if gate is not None else None,
+            gate.stride(0) if gate is not None else 0, float(gate_scale), out.data_ptr(), out.stride(0), M, N, K,
+            int(relu), float(dropout_p), int(seed))
+    _lib.check(rc, "snipper_linear_wres_bf16")
+    return out
+
+
+def transpose_batch_bf16(pairs) -> None:
+    """dst[c][r] = src[r][c] for a list of (src [rows, cols], dst [cols, rows]) bf16 matrices (unit inner strides) in ONE
+    launch per 48 matrices (csrc/wres_gemm_bf16.cuh, transpose_batch_bf16_kernel)."""
+    import ctypes
+    pairs = list(pairs)
+    lib = _lib.load()
+    for lo in range(0, len(pairs), 48):
+        part = pairs[lo:lo + 48]
+        n = len(part)
+        for s_, d_ in part:
+            assert s_.dtype == torch.bfloat16 and d_.dtype == torch.bfloat16 and s_.stride(1) == 1 and d_.stride(1) == 1
+            assert d_.shape == (s_.shape[1], s_.shape[0]) and s_.is_cuda and d_.device == s_.device
+        src = (ctypes.c_void_p * n)(*[s_.data_ptr() for s_, _ in part])
+        dst = (ctypes.c_void_p * n)(*[d_.data_ptr() for _, d_ in part])
+        rows = (ctypes.c_int * n)(*[s_.shape[0] for s_, _ in part])
+        cols = (ctypes.c_int * n)(*[s_.shape[1] for s_, _ in part])
+        lds = (ctypes.c_longlong * n)(*[s_.stride(0) for s_, _ in part])
+        ldd = (ctypes.c_longlong * n)(*[d_.stride(0) for _, d_ in part])
+        with _lib.device_guard(part[0][0].device):
+            rc = lib.snipper_transpose_batch_bf16(_lib.raw_stream(part[0][0].device), n, src, dst, rows, cols, lds, ldd)
+        _lib.check(rc, "snipper_transpose_batch_bf16")
+
+
 def _gate_ptr(gate: Optional[torch.Tensor], like: torch.Tensor):
     """Data pointer of a ReLU gate laid out exactly like ``like`` (bf16, channels_last), or None."""
     if gate is None:
@@ -170,9 +228,18 @@ _DGRAD_LIB_K = int(_os.environ.get("SNIPPER_DGRAD_LIB_K", "1000000"))
 
 
 def _dgrad(g: torch.Tensor, w: torch.Tensor, residual: Optional[torch.Tensor] = None,
-           gate: Optional[torch.Tensor] = None) -> torch.Tensor:
+           gate: Optional[torch.Tensor] = None, wt: Optional[torch.Tensor] = None, gate_scale: float = 1.0) -> torch.Tensor:
     """gate(g [M, out] @ w [out, in] (+ residual)): own kernel when the shape allows (out % 64 == 0, in % 8 == 0),
-    hipBLASLt otherwise.  ``gate`` [M, in]: the ReLU output the gradient flows back into (result zeroed where it is 0)."""
+    hipBLASLt otherwise.  ``gate`` [M, in]: the ReLU output the gradient flows back into (result zeroed where it is 0).
+    ``wt`` = w^T [in, out] (the per-step transposed shadow, shadow.lookup_t): with it a short reduction (out = 288 / 384)
+    over many rows goes to the weight-stationary kernel."""
+    if (wt is not None and residual is None and g.dtype == torch.bfloat16 and g.dim() == 2 and
+            wres_supported(g.shape[0], wt.shape[0], wt.shape[1]) and (gate is None or gate.dtype == torch.bfloat16)):
+        return linear_wres_bf16(g, wt, None, gate=None if gate is None else gate.reshape(g.shape[0], wt.shape[0]),
+                                gate_scale=gate_scale)
+    if gate_scale != 1.0:
+        assert gate is not None and w.shape[0] % 64 == 0 and w.shape[1] % 8 == 0 and g.shape[0] >= 256
+        return linear_nn_bf16(g, w, residual, gate, gate_scale)
     if w.shape[0] % 64 == 0 and w.shape[1] % 8 == 0 and g.shape[0] >= 256 and (
             w.shape[0] < _DGRAD_LIB_K or residual is not None or gate is not None):
         return linear_nn_bf16(g, w, residual, gate)
@@ -245,6 +312,7 @@ class _BigLinear(torch.autograd.Function):
         ctx.relu, ctx.has_bias = relu, bias is not None
         ctx.x_shape, ctx.w_dtype = x.shape, weight.dtype
         ctx.b_dtype = None if bias is None else bias.dtype
+        ctx.wt = shadow.lookup_t(weight) if weight.dtype != torch.bfloat16 else None     # W^T of THIS step's weight, if kept
         ctx.save_for_backward(xb, wb, y if relu else None)
         return y.view(*x.shape[:-1], n_out)
 
@@ -264,7 +332,7 @@ class _BigLinear(torch.autograd.Function):
                 dW = dW.to(ctx.w_dtype)
             if db is not None and db.dtype != ctx.b_dtype:
                 db = db.to(ctx.b_dtype)
-        dx = _dgrad(g, wb).view(ctx.x_shape) if ctx.needs_input_grad[0] else None
+        dx = _dgrad(g, wb, wt=ctx.wt).view(ctx.x_shape) if ctx.needs_input_grad[0] else None
         return dx, dW, db, None, None
 
 
@@ -293,6 +361,7 @@ class _BigFFN(torch.autograd.Function):
         z = linear_bf16(h, w2b, b2.float())
         ctx.p, ctx.x_shape = float(dropout_p), x.shape
         ctx.dts = (w1.dtype, b1.dtype, w2.dtype, b2.dtype)
+        ctx.w2t = shadow.lookup_t(w2)                        # W2^T [d_ffn, d_model]: dH = dZ . W2 on the weight-stationary kernel
         ctx.save_for_backward(xb, w1b, w2b, h)
         return z.view(*x.shape[:-1], w2.shape[0])
 
@@ -304,7 +373,7 @@ class _BigFFN(torch.autograd.Function):
             g = g.to(torch.bfloat16)
         g = g.contiguous()
         dW2, db2 = wgrad_bf16(g, h)
-        gh = linear_nn_bf16(g, w2b, None, h, 1.0 / (1.0 - ctx.p))            # gradient w.r.t. linear1's pre-activation
+        gh = _dgrad(g, w2b, None, h, wt=ctx.w2t, gate_scale=1.0 / (1.0 - ctx.p))    # gradient w.r.t. linear1's pre-activation
         dW1, db1 = wgrad_bf16(gh, xb)
         dx = _dgrad(gh, w1b).view(ctx.x_shape) if ctx.needs_input_grad[0] else None
         outs = [dW1, db1, dW2, db2]
@@ -671,8 +740,10 @@ class _BigLinearPair(torch.autograd.Function):
         x2 = x.reshape(-1, k_in)
         xb = x2 if x2.dtype == torch.bfloat16 else x2.to(torch.bfloat16)
         m = shadow.lookup_merged(lin_a, lin_b)
+        ctx.wt = None
         if m is not None:
             w16, bias = m
+            ctx.wt = shadow.lookup_merged_t(lin_a, lin_b)
         else:
             w16 = torch.cat([wa, wb_], 0).to(torch.bfloat16)
             bias = torch.cat([ba, bb], 0).float()
@@ -689,7 +760,7 @@ class _BigLinearPair(torch.autograd.Function):
         if g.dtype != torch.bfloat16:
             g = g.to(torch.bfloat16)
         g = g.contiguous()
-        dx = _dgrad(g, w16).view(ctx.x_shape) if ctx.needs_input_grad[0] else None
+        dx = _dgrad(g, w16, wt=ctx.wt).view(ctx.x_shape) if ctx.needs_input_grad[0] else None
         dW, db = wgrad_bf16(g, xb, want_bias=True)
         na = ctx.na
         outs = [dW[:na], db[:na], dW[na:], db[na:]]

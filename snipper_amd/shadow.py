@@ -32,18 +32,26 @@ _merged: Dict[Tuple[int, int], "_Merged"] = {}
 
 
 class _Entry:
-    __slots__ = ("ref", "dst", "scale", "scale_full", "version")
+    __slots__ = ("ref", "dst", "scale", "scale_full", "version", "dst_t")
 
     def __init__(self, param, dst, scale=None):
         self.ref, self.dst, self.scale, self.version = weakref.ref(param), dst, scale, -1
         self.scale_full = None     # the BN scale expanded to the weight's shape AND strides (multi-tensor fast path)
+        self.dst_t = None          # bf16 W^T [in, out], kept for the Linears whose data gradient wants it
 
 
 class _Merged:
-    __slots__ = ("refs", "w", "b", "versions")
+    __slots__ = ("refs", "w", "b", "versions", "w_t")
 
     def __init__(self, params, w, b):
         self.refs, self.w, self.b, self.versions = [weakref.ref(p) for p in params], w, b, None
+        self.w_t = None
+
+
+def wants_transpose(out_features: int, in_features: int) -> bool:
+    """Linears whose data gradient dX = dY . W has a reduction (out_features) the weight-stationary kernel takes
+    (csrc/wres_gemm_bf16.cuh: 288 or 384): their shadow also keeps W^T."""
+    return out_features in (288, 384) and in_features % 8 == 0
 
 
 def lookup(param: torch.Tensor, scale: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
@@ -54,6 +62,21 @@ def lookup(param: torch.Tensor, scale: Optional[torch.Tensor] = None) -> Optiona
             e.dst.data_ptr() != 0 and (scale is None or e.scale is None or e.scale is scale)):
         return e.dst
     return None
+
+
+def lookup_t(param: torch.Tensor) -> Optional[torch.Tensor]:
+    """The valid bf16 TRANSPOSED shadow (W^T, [in, out]) of a Linear weight, or None."""
+    e = _entries.get(id(param))
+    if (e is not None and e.ref() is param and e.version == param._version and e.dst_t is not None and
+            e.dst_t.device == param.device):
+        return e.dst_t
+    return None
+
+
+def lookup_merged_t(lin_a: nn.Linear, lin_b: nn.Linear) -> Optional[torch.Tensor]:
+    if lookup_merged(lin_a, lin_b) is None:
+        return None
+    return _merged[(id(lin_a.weight), id(lin_b.weight))].w_t
 
 
 def invalidate(params=None) -> None:
@@ -127,7 +150,7 @@ class WeightShadows:
     @torch.no_grad()
     def refresh(self) -> None:
         """Bring every stale shadow up to date (multi-tensor launches; nothing to do for unchanged parameters)."""
-        mul_src, mul_scale, mul_dst, cp_src, cp_dst = [], [], [], [], []
+        mul_src, mul_scale, mul_dst, cp_src, cp_dst, tr = [], [], [], [], [], []
         for conv, bn in self.convs:
             w = conv.weight
             if not (w.is_cuda and w.dtype == torch.float32):
@@ -152,9 +175,13 @@ class WeightShadows:
             e = _entries.get(id(w))
             if e is None or e.ref() is not w or e.dst.device != w.device:
                 e = _entries[id(w)] = _Entry(w, torch.empty_like(w, dtype=torch.bfloat16))
+                if w.dim() == 2 and wants_transpose(w.shape[0], w.shape[1]):
+                    e.dst_t = torch.empty((w.shape[1], w.shape[0]), dtype=torch.bfloat16, device=w.device)
             if e.version != w._version:
                 cp_src.append(w)
                 cp_dst.append(e)
+                if e.dst_t is not None:
+                    tr.append((e.dst, e.dst_t))
         fin = []
         for a, b in self.pairs:
             ps = [a.weight, a.bias, b.weight, b.bias]
@@ -166,12 +193,16 @@ class WeightShadows:
                 na, nb, k = a.out_features, b.out_features, a.in_features
                 m = _merged[key] = _Merged(ps, torch.empty((na + nb, k), dtype=torch.bfloat16, device=ps[0].device),
                                            torch.empty((na + nb,), dtype=torch.float32, device=ps[0].device))
+                if wants_transpose(na + nb, k):
+                    m.w_t = torch.empty((k, na + nb), dtype=torch.bfloat16, device=ps[0].device)
             vers = [p._version for p in ps]
             if m.versions != vers:
                 na = a.out_features
                 cp_src += [a.weight, b.weight, a.bias, b.bias]
                 cp_dst += [m.w[:na], m.w[na:], m.b[:na], m.b[na:]]
                 fin.append((m, vers))
+                if m.w_t is not None:
+                    tr.append((m.w, m.w_t))
         if mul_src:
             tmp = torch._foreach_mul(mul_src, mul_scale)
             torch._foreach_copy_([e.dst for e in mul_dst], tmp)
@@ -193,5 +224,8 @@ class WeightShadows:
             for d, w in zip(cp_dst, cp_src):
                 if isinstance(d, _Entry):
                     d.version = w._version
+        if tr:                                  # W^T of the freshly written bf16 copies: one launch for all of them
+            from .dense import transpose_batch_bf16
+            transpose_batch_bf16(tr)
         for m, vers in fin:
             m.versions = vers
