@@ -128,8 +128,12 @@ __device__ __forceinline__ uint32_t gemm_rand(uint32_t idx, uint32_t seed_lo, ui
 }
 
 __device__ __forceinline__ float gemm_bf16_to_f32(uint16_t b) { return __uint_as_float((unsigned)b << 16); }
+// two floats -> packed bf16 pair (a in the low half): ONE v_cvt_pk_bf16_f32 (the scalar casts compiled to two of them plus
+// a shift and an or; same round-to-nearest-even, NaN stays NaN)
+typedef __attribute__((ext_vector_type(2))) float gemm_f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 gemm_bf16x2;
 __device__ __forceinline__ unsigned gemm_pack2(float a, float b) {
-  return (unsigned)__builtin_bit_cast(uint16_t, (__bf16)a) | ((unsigned)__builtin_bit_cast(uint16_t, (__bf16)b) << 16);
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(gemm_f32x2{a, b}, gemm_bf16x2));
 }
 
 // The grid may be smaller than the tile count: workgroup (xcd, w) then walks the tiles j = w, w + W, w + 2W, ... of its

@@ -460,6 +460,10 @@ int device_cu_count() {
   return n;
 }
 // SNIPPER_GEMM_WRES=0 in the environment at load time keeps every product on the tile kernels (A/B measurements)
+int wres_debug() {       // SNIPPER_WRES_DEBUG: timing ablations of the weight-stationary kernel (wrong results), read once
+  static const int v = [] { const char *e = getenv("SNIPPER_WRES_DEBUG"); return e ? atoi(e) : 0; }();
+  return v;
+}
 bool wres_enabled() {
   static const bool on = [] { const char *e = getenv("SNIPPER_GEMM_WRES"); return !(e && e[0] == '0'); }();
   return on;
@@ -488,16 +492,19 @@ int snipper_linear_wres_bf16(void *stream, const uint16_t *X, long long ldx, con
   if (n_series < 8) n_series = 8;
   if (n_series > ((chunks + 7) / 8) * 8) n_series = ((chunks + 7) / 8) * 8;
   const WresArgs g{X, ldx, W, ldw, bias, A, lda, gate_scale, Y, ldy, M, N, K, relu ? 1 : 0, dropout_p,
-                   (uint32_t)seed, (uint32_t)(seed >> 32), n_series};
+                   (uint32_t)seed, (uint32_t)(seed >> 32), n_series, wres_debug()};
   const dim3 grid((unsigned)(n_series * ncb)), block(kWrThreads);
   hipStream_t st = (hipStream_t)stream;
+  const bool act = relu || dropout_p > 0.f;
+#define WRES_LAUNCH(KS_, GATE_, ACT_) hipLaunchKernelGGL((wres_gemm_kernel<KS_, GATE_, ACT_>), grid, block, 0, st, g)
   if (K == 384) {
-    if (A) hipLaunchKernelGGL((wres_gemm_kernel<12, true>), grid, block, 0, st, g);
-    else hipLaunchKernelGGL((wres_gemm_kernel<12, false>), grid, block, 0, st, g);
+    if (A) { if (act) WRES_LAUNCH(12, true, true); else WRES_LAUNCH(12, true, false); }
+    else { if (act) WRES_LAUNCH(12, false, true); else WRES_LAUNCH(12, false, false); }
   } else {
-    if (A) hipLaunchKernelGGL((wres_gemm_kernel<9, true>), grid, block, 0, st, g);
-    else hipLaunchKernelGGL((wres_gemm_kernel<9, false>), grid, block, 0, st, g);
+    if (A) { if (act) WRES_LAUNCH(9, true, true); else WRES_LAUNCH(9, true, false); }
+    else { if (act) WRES_LAUNCH(9, false, true); else WRES_LAUNCH(9, false, false); }
   }
+#undef WRES_LAUNCH
   return launch_status();
 }
 

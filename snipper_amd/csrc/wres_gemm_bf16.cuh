@@ -16,12 +16,17 @@
 //     There is no W traffic in the main loop at all (not from L2, not from LDS).
 //   * X is streamed through LDS by LDS-DMA (buffer_load ... lds) in chunks of 32 rows x K (24 KB), a ring of 3-4 slots per
 //     workgroup, ONE workgroup per CU walking a strided list of chunks: 48-72 KB of HBM reads are in flight per CU at any
-//     time, across the barriers (counted s_waitcnt vmcnt, raw s_barrier), which is what the HBM roofline needs
-//     (MI355X_MICROARCH.md: ~25 GB/s per CU at ~2 us of loaded latency).  X is read from HBM exactly once per 384 columns.
+//     time, across the barriers (counted s_waitcnt vmcnt, raw s_barrier).  X is read from HBM exactly once per 384 columns.
 //   * each wave multiplies the chunk's 2 x KS X fragments (ds_read_b128, XOR-swizzled image: conflict-free) with its
 //     resident W fragments: 72 v_mfma_f32_16x16x32_bf16 per chunk and wave, Y^T = W . X^T so that a lane owns 4
 //     consecutive columns of one row; the finished bf16 chunk is parked in LDS and written as whole rows, 16 B per lane.
-//   * the gate operand (the FFN's hidden activation, whose sign gates dH) rides the same DMA mechanism in its own ring.
+//   * THE TWO WAVES OF A SIMD RUN HALF AN ITERATION APART.  Waves 0-3 (group A, one per SIMD) multiply chunk i while waves
+//     4-7 (group B) convert / park / store chunk i - 1 and issue the DMAs, then the roles swap; one workgroup barrier per
+//     half-step.  The first version of this kernel ran all eight waves in lockstep and its phases were additive again
+//     (measured: MFMA 11.6 us + everything else 27.6 us = 39.2 us for 79 000 x 384 x 384); the matrix pipe of a SIMD is
+//     shared by its two waves, so matrix work beside the partner's vector / memory work is the pairing that nets
+//     (MI355X_MICROARCH.md, "Two waves per SIMD", items 5 and 9).
+//   * the gate operand (the FFN's hidden activation, whose sign gates dH) rides the same DMA mechanism in a slot of its own.
 // Every vector-memory instruction of the loop is an LDS-DMA or a range-checked buffer store issued by ALL lanes, so the
 // counted waits are exact; rows / columns past the matrix are handled by the buffer range check (reads 0, stores dropped).
 #pragma once
@@ -35,7 +40,7 @@ constexpr int kWrThreads = 512, kWrRows = 32, kWrPieces = 48, kWrRowB = kWrPiece
 constexpr int kWrSlotB = kWrRows * kWrRowB;                                                // 24 576
 constexpr int kWrStageStrideB = kWrRowB + 16, kWrStageB = kWrRows * kWrStageStrideB;       // 784-byte rows (2-way writes)
 constexpr int kWrCols = 384;                                                               // output columns per workgroup
-constexpr int kWrPerThread = kWrRows * kWrPieces / kWrThreads;                             // 3 pieces of 16 B per thread
+constexpr int kWrPerThread = 3;            // 16-byte pieces per thread: 1536 per chunk over 512 threads, 768 per half over 256
 
 struct WresArgs {
   const uint16_t *X; long long ldx;      // [M][K]
@@ -48,6 +53,8 @@ struct WresArgs {
   int relu;
   float drop_p; uint32_t seed_lo, seed_hi;
   int n_series;                          // chunk lists: gridDim.x = n_series * ceil(N / 384)
+  int debug;                             // timing ablations (WRONG results): 1 no W loads, 2 no MFMA, 4 no stores, 8 no X reads,
+                                         // 16 no epilogue, 32 no flush, 64 no counted waits, 128 no X DMA instructions
 };
 
 typedef __attribute__((address_space(3))) void wres_lds_void;
@@ -57,15 +64,18 @@ __device__ __forceinline__ void wres_dma16(__amdgpu_buffer_rsrc_t src, unsigned 
   __builtin_amdgcn_raw_ptr_buffer_load_lds(src, (wres_lds_void *)lds_wave_base, 16, voff, 0, 0, 0);
 }
 
-// NS = X ring slots; GATE adds a 2-slot ring for the gate operand.  LDS: NS * 24 KB (+ 48 KB) + 24.5 KB staging.
-template <int KS, bool GATE>
+// LDS: NS ring slots of 24 KB (+ one gate slot) + two 24.5 KB staging images = 145 KB either way: one workgroup per CU.
+// ACT: a ReLU and / or dropout epilogue is compiled in (the plain projections carry no trace of it).
+template <int KS, bool GATE, bool ACT>
 __global__ __launch_bounds__(kWrThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void wres_gemm_kernel(WresArgs g) {
-  constexpr int NS = GATE ? 3 : 4, GS = 2;
-  constexpr int kRingB = NS * kWrSlotB, kGateB = GATE ? GS * kWrSlotB : 0;
+  constexpr int NS = GATE ? 3 : 4;
+  constexpr int kRingB = NS * kWrSlotB, kGateB = GATE ? kWrSlotB : 0;
   // ONE LDS object (a second one beside an LDS-DMA target makes hipcc drain vmcnt before every ds_read)
-  __shared__ __attribute__((aligned(16))) unsigned char smem[kRingB + kGateB + kWrStageB];
-  unsigned char *ring = smem, *gring = smem + kRingB, *stage = smem + kRingB + kGateB;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[kRingB + kGateB + 2 * kWrStageB];
+  unsigned char *ring = smem, *gslot = smem + kRingB, *stage = smem + kRingB + kGateB;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // scalar: the group branch below must be a real branch
+  const int group = wave >> 2, tidg = tid & 255;
 
   // workgroup -> (column block cb, chunk list `series`): the ncb workgroups that share a chunk list sit on one XCD
   // (ids b, b + 8, b + 16: round-robin placement), so a chunk comes from HBM once and from that XCD's L2 after
@@ -77,9 +87,9 @@ __global__ __launch_bounds__(kWrThreads) __attribute__((amdgpu_waves_per_eu(2, 2
   const int n_iter = series < NC ? (NC - series + g.n_series - 1) / g.n_series : 0;
   if (n_iter == 0) return;
 
-  // ---- per-thread DMA geometry: piece i = tid + 512 t of a chunk image; row r = i / 48, slot s = i % 48 holds the 16-byte
-  // piece c = s ^ (r & 15) of the row (the XOR makes the fragment reads below conflict-free; rows are 48 pieces = 3
-  // blocks of 16, the XOR stays inside a block)
+  // ---- X DMA geometry (all 512 threads): piece i = tid + 512 t of a chunk image; row r = i / 48, slot s = i % 48 holds the
+  // 16-byte piece c = s ^ (r & 15) of the row (the XOR makes the fragment reads below conflict-free; rows are 48 pieces =
+  // 3 blocks of 16, the XOR stays inside a block)
   unsigned x_voff[kWrPerThread];
   int lds_piece[kWrPerThread];
 #pragma unroll
@@ -89,64 +99,67 @@ __global__ __launch_bounds__(kWrThreads) __attribute__((amdgpu_waves_per_eu(2, 2
     lds_piece[t] = (i - lane) * 16;                 // wave-uniform: the hardware adds lane * 16
   }
   auto chunk_of = [&](int it) { return series + it * g.n_series; };
-  auto x_rsrc = [&](int chunk) {
+  auto issue_x = [&](int it) {                       // ALWAYS 3 instructions (an empty descriptor outside the chunk list)
+    const int chunk = (it < n_iter && !(g.debug & 8)) ? chunk_of(it) : NC;
     const int rows = chunk < NC ? min(kWrRows, g.M - chunk * kWrRows) : 0;
     const long long bytes = rows > 0 ? ((long long)(rows - 1) * g.ldx + g.K) * 2 : 0;
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(g.X + (long long)(rows > 0 ? chunk : 0) * kWrRows * g.ldx), 0,
-                                             (int)bytes, 0x00020000);
-  };
-  auto issue_x = [&](int it) {                       // ALWAYS 3 instructions (an empty descriptor past the last chunk)
-    const __amdgpu_buffer_rsrc_t src = x_rsrc(it < n_iter ? chunk_of(it) : NC);
+    const __amdgpu_buffer_rsrc_t src = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint16_t *>(g.X + (long long)(rows > 0 ? chunk : 0) * kWrRows * g.ldx), 0, (int)bytes, 0x00020000);
     unsigned char *slot = ring + ((it + NS) % NS) * kWrSlotB;
+    if (g.debug & 128) return;
 #pragma unroll
     for (int t = 0; t < kWrPerThread; ++t) wres_dma16(src, slot + lds_piece[t], x_voff[t]);
   };
-  // gate / output geometry: the same pieces, unswizzled (piece c of row r at r * 768 + c * 16); a thread DMA-writes
-  // exactly the gate pieces it reads back in the flush, so the gate ring needs no barrier of its own
+  // ---- output / gate geometry: a GROUP writes out 16 of the chunk's 32 rows (A rows 0-15, B rows 16-31), piece
+  // p = tidg + 256 t of that half, row = 16 group + p / 48, 16-byte piece c = p % 48, unswizzled.  A thread DMA-writes exactly
+  // the gate pieces it reads back in its flush, so the gate slot needs no barrier of its own.
   unsigned a_voff[kWrPerThread], y_voff[kWrPerThread];
-  int flush_row[kWrPerThread], flush_c[kWrPerThread];
+  int stage_off[kWrPerThread], gate_off[kWrPerThread];
 #pragma unroll
   for (int t = 0; t < kWrPerThread; ++t) {
-    const int i = tid + kWrThreads * t, r = i / kWrPieces, c = i - r * kWrPieces;
-    flush_row[t] = r; flush_c[t] = c;
+    const int p = tidg + 256 * t, rl = p / kWrPieces, c = p - rl * kWrPieces, row = 16 * group + rl;
     const bool col_ok = n0 + c * 8 < g.N;
-    a_voff[t] = (GATE && col_ok) ? ((unsigned)r * (unsigned)g.lda + (unsigned)c * 8u) * 2u : 0x80000000u;
-    y_voff[t] = col_ok ? ((unsigned)r * (unsigned)g.ldy + (unsigned)c * 8u) * 2u : 0x80000000u;
+    stage_off[t] = row * kWrStageStrideB + c * 16;
+    gate_off[t] = (row * kWrPieces + c) * 16;
+    a_voff[t] = (GATE && col_ok) ? ((unsigned)row * (unsigned)g.lda + (unsigned)c * 8u) * 2u : 0x80000000u;
+    y_voff[t] = col_ok ? ((unsigned)row * (unsigned)g.ldy + (unsigned)c * 8u) * 2u : 0x80000000u;
   }
-  auto issue_gate = [&](int it) {
+  auto issue_gate = [&](int it) {                    // ALWAYS 3 instructions
     const int chunk = (it >= 0 && it < n_iter) ? chunk_of(it) : NC;
     const int rows = chunk < NC ? min(kWrRows, g.M - chunk * kWrRows) : 0;
     const long long bytes = rows > 0 ? ((long long)(rows - 1) * g.lda + (g.N - n0)) * 2 : 0;
     const __amdgpu_buffer_rsrc_t src = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint16_t *>(g.A + (long long)(rows > 0 ? chunk : 0) * kWrRows * g.lda + n0), 0, (int)bytes, 0x00020000);
-    unsigned char *slot = gring + ((it + GS) % GS) * kWrSlotB;
 #pragma unroll
-    for (int t = 0; t < kWrPerThread; ++t) wres_dma16(src, slot + lds_piece[t], a_voff[t]);
+    for (int t = 0; t < kWrPerThread; ++t) wres_dma16(src, gslot + (gate_off[t] - lane * 16), a_voff[t]);
   };
 
+  // ---- prologue.  The counted waits assume the steady-state instruction stream of a thread -- per iteration: 3 stores,
+  // (3 gate DMAs,) 3 X DMAs (chunk it + NS - 1) -- so the NS - 1 iterations "before the first" are issued in exactly that
+  // shape, with dropped stores and an empty gate descriptor.
+  const __amdgpu_buffer_rsrc_t nowhere = __builtin_amdgcn_make_buffer_rsrc(g.Y, 0, 0, 0x00020000);
+  auto dummy_stores = [&]() {
+#pragma unroll
+    for (int t = 0; t < kWrPerThread; ++t)
+      __builtin_amdgcn_raw_buffer_store_b128(gemm_u32x4{0u, 0u, 0u, 0u}, nowhere, 0x80000000u, 0, 0);
+  };
+#pragma unroll
+  for (int j = -(NS - 1); j < 0; ++j) {
+    dummy_stores();
+    if constexpr (GATE) issue_gate(-1);
+    issue_x(j + NS - 1);
+  }
   // ---- W slice of this wave into registers: fragment (nt, ks) = rows n = n0 + 48 wave + 16 nt + (lane & 15), reduction
   // elements k = 32 ks + 8 (lane >> 4) .. + 7 (the A operand of v_mfma_f32_16x16x32_bf16)
   gemm_bf16x8 wf[3][KS];
   const int wn0 = n0 + 48 * wave;
-  // ---- prologue.  The counted waits of the main loop assume the steady-state instruction stream -- per iteration j:
-  // X DMA of chunk j + NS - 1, (gate DMA of chunk j + 1,) ... stores of chunk j, three instructions each -- so the NS - 1
-  // iterations "before the first" are issued in exactly that shape, with dropped stores (and an empty gate descriptor).
-  const __amdgpu_buffer_rsrc_t nowhere = __builtin_amdgcn_make_buffer_rsrc(g.Y, 0, 0, 0x00020000);
-#pragma unroll
-  for (int j = -(NS - 1); j < 0; ++j) {
-    issue_x(j + NS - 1);
-    if constexpr (GATE) issue_gate(j + 1);
-#pragma unroll
-    for (int t = 0; t < kWrPerThread; ++t)
-      __builtin_amdgcn_raw_buffer_store_b128(gemm_u32x4{0u, 0u, 0u, 0u}, nowhere, 0x80000000u, 0, 0);
-  }
   {
     const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint16_t *>(g.W), 0, (int)(((long long)(g.N - 1) * g.ldw + g.K) * 2), 0x00020000);
 #pragma unroll
     for (int nt = 0; nt < 3; ++nt) {
       const int n = wn0 + 16 * nt + (lane & 15);
-      const unsigned base = n < g.N ? ((unsigned)n * (unsigned)g.ldw + 8u * (unsigned)(lane >> 4)) * 2u : 0x80000000u;
+      const unsigned base = (n < g.N && !(g.debug & 1)) ? ((unsigned)n * (unsigned)g.ldw + 8u * (unsigned)(lane >> 4)) * 2u : 0x80000000u;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks)
         wf[nt][ks] = __builtin_bit_cast(gemm_bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wsrc, base + ks * 64u, 0, 0));
@@ -172,80 +185,93 @@ __global__ __launch_bounds__(kWrThreads) __attribute__((amdgpu_waves_per_eu(2, 2
   const int nta = wn0 >= g.N ? 0 : min(3, (g.N - wn0 + 15) / 16);
   const bool drop = g.drop_p > 0.f;
   const float keep_scale = drop ? 1.f / (1.f - g.drop_p) : 1.f;
-  const uint32_t thresh = (uint32_t)fminf(g.drop_p * 4294967296.f, 4294967040.f);
+  const uint32_t thresh16 = (uint32_t)fminf(g.drop_p * 65536.f + 0.5f, 65535.f);
   const int frow = lane & 15, fk = lane >> 4;
   const unsigned stage_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)stage;
 
-  for (int it = 0; it < n_iter; ++it) {
-    // ---- top: keep the rings full.  Slot (it - 1) % NS was last read before barrier B2 of iteration it - 1.
-    issue_x(it + NS - 1);
-    if constexpr (GATE) issue_gate(it + 1);
-    // vector-memory instructions younger than chunk `it`'s three DMAs (3 per chunk each of X, gate, stores):
-    //   plain: X(it+1 .. it+3) + stores(it-3 .. it-1) = 18;   gate (NS = 3): G(it-1), S(it-2), X(it+1), G(it), S(it-1), X(it+2), G(it+1) = 21
-    if constexpr (GATE) asm volatile("s_waitcnt vmcnt(21)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                                   // B1: every wave's pieces of chunk `it` have landed
+  gemm_f32x4 acc[3][2];
+  // ---- C: the chunk's fragments against the resident W
+  auto compute = [&](int it) {
     const unsigned char *slot = ring + (it % NS) * kWrSlotB;
-    const int chunk = chunk_of(it), m0 = chunk * kWrRows;
-
-    gemm_f32x4 acc[3][2];
 #pragma unroll
     for (int nt = 0; nt < 3; ++nt)
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt) acc[nt][mt] = gemm_f32x4{0.f, 0.f, 0.f, 0.f};
-    if (nta > 0) {          // (wave-uniform: a wave whose 48 columns lie past N only keeps the barriers company)
+      for (int mt = 0; mt < 2; ++mt) acc[nt][mt] = bias[nt];        // the sums start at the bias
+    if (nta > 0 && !(g.debug & 2)) {          // (a wave whose 48 columns lie past N only keeps the barriers company)
+      // the X fragments of k-step ks + 1 are requested before the MFMAs of k-step ks: this wave is the only one of its
+      // SIMD in the matrix phase (its partner is in the store phase), so nobody else covers its LDS latency
+      auto xread = [&](int ks, int mt) {
+        return *reinterpret_cast<const gemm_bf16x8 *>(slot + (16 * mt + frow) * kWrRowB + 16 * ((4 * ks + fk) ^ frow));
+      };
+      gemm_bf16x8 xa = xread(0, 0), xb = xread(0, 1);
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
+        gemm_bf16x8 na = xa, nb = xb;
+        if (ks + 1 < KS) { na = xread(ks + 1, 0); nb = xread(ks + 1, 1); }
+        __builtin_amdgcn_sched_barrier(0);          // (hipcc otherwise sinks the two reads back down to their first use)
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-          const gemm_bf16x8 xf = *reinterpret_cast<const gemm_bf16x8 *>(
-              slot + (16 * mt + frow) * kWrRowB + 16 * ((4 * ks + fk) ^ frow));
+        for (int nt = 0; nt < 3; ++nt) acc[nt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt][ks], xa, acc[nt][0], 0, 0, 0);
 #pragma unroll
-          for (int nt = 0; nt < 3; ++nt)
-            acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt][ks], xf, acc[nt][mt], 0, 0, 0);
-        }
+        for (int nt = 0; nt < 3; ++nt) acc[nt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt][ks], xb, acc[nt][1], 0, 0, 0);
+        xa = na; xb = nb;
       }
     }
-
-    // ---- epilogue into the staging image: lane holds columns n .. n + 3 of row 16 mt + (lane & 15).  The LDS stores are
-    // inline assembly: for a compiler-visible ds_write hipcc drains vmcnt(0) first (a pending LDS-DMA might alias it),
-    // which would empty the ring every iteration; the s_waitcnt lgkmcnt(0) in front of barrier B2 covers them.
+  };
+  // ---- E: bias / ReLU / dropout / scale, rounded to bf16, into staging image it & 1: a lane holds columns n .. n + 3 of
+  // row 16 mt + (lane & 15).  The LDS stores are inline assembly: before a compiler-visible ds_write hipcc drains vmcnt(0)
+  // (a pending LDS-DMA might alias it), which would empty the ring every iteration; the s_waitcnt lgkmcnt(0) in front of
+  // the next barrier covers them.
+  auto epilogue = [&](int it) {
+    if (g.debug & 16) return;
+    const int m0 = chunk_of(it) * kWrRows;
+    const unsigned base = stage_lds + (unsigned)((it & 1) * kWrStageB);
 #pragma unroll
     for (int nt = 0; nt < 3; ++nt) {
       if (nt >= nta) continue;
       const int nl = 48 * wave + 16 * nt + 4 * (lane >> 4);          // column within the 384-wide block
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) {
-        gemm_f32x4 v = acc[nt][mt] + bias[nt];
-        if (g.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-        if (drop) {
+        gemm_f32x4 v = acc[nt][mt];
+        if (ACT && g.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        if (ACT && drop) {
+          // one double hash per 4 consecutive elements (their index e is a multiple of 4) and a cheap second word: four
+          // 16-bit uniforms against p * 2^16 -- a quarter of the per-element hashes of csrc/gemm_bf16.cuh (here the
+          // store phase of a wave runs beside its partner's matrix phase, so its VALU count is what is left to pay)
           const uint32_t e = (uint32_t)(m0 + 16 * mt + frow) * (uint32_t)g.N + (uint32_t)(n0 + nl);
-          v.x = gemm_rand(e, g.seed_lo, g.seed_hi) >= thresh ? v.x * keep_scale : 0.f;
-          v.y = gemm_rand(e + 1, g.seed_lo, g.seed_hi) >= thresh ? v.y * keep_scale : 0.f;
-          v.z = gemm_rand(e + 2, g.seed_lo, g.seed_hi) >= thresh ? v.z * keep_scale : 0.f;
-          v.w = gemm_rand(e + 3, g.seed_lo, g.seed_hi) >= thresh ? v.w * keep_scale : 0.f;
+          const uint32_t h = gemm_rand(e >> 2, g.seed_lo, g.seed_hi);
+          uint32_t h2 = (h ^ (h >> 16)) * 0x9e3779b9u;
+          h2 ^= h2 >> 15;
+          v.x = (h & 0xffffu) >= thresh16 ? v.x * keep_scale : 0.f;
+          v.y = (h >> 16) >= thresh16 ? v.y * keep_scale : 0.f;
+          v.z = (h2 & 0xffffu) >= thresh16 ? v.z * keep_scale : 0.f;
+          v.w = (h2 >> 16) >= thresh16 ? v.w * keep_scale : 0.f;
         }
         if constexpr (GATE) { v.x *= g.gate_scale; v.y *= g.gate_scale; v.z *= g.gate_scale; v.w *= g.gate_scale; }
         wres_u32x2 o;
         o[0] = gemm_pack2(v.x, v.y);
         o[1] = gemm_pack2(v.z, v.w);
-        const unsigned addr = stage_lds + (unsigned)((16 * mt + frow) * kWrStageStrideB + nl * 2);
+        const unsigned addr = base + (unsigned)((16 * mt + frow) * kWrStageStrideB + nl * 2);
         asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(o) : "memory");
       }
     }
-    if constexpr (GATE) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");   // younger than G(it): S(it-1), X(it+2), G(it+1)
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                                   // B2: the chunk's output image is complete
-
-    // ---- flush: whole rows, 16 B per lane; rows past M and columns past N are dropped by the range check
-    const int rows = min(kWrRows, g.M - m0);
+  };
+  // ---- F: this group's 16 rows of chunk `it` from staging image it & 1 to memory, whole rows, 16 B per lane (ALWAYS 3
+  // store instructions: an empty descriptor outside the chunk list, rows past M and columns past N dropped by the range
+  // check); the gate pieces were DMA'd by this very thread
+  auto flush = [&](int it) {
+    if (g.debug & 32) return;
+    const bool valid = it >= 0 && it < n_iter && !(g.debug & 4);
+    const int m0 = valid ? chunk_of(it) * kWrRows : 0;
+    const int rows = valid ? min(kWrRows, g.M - m0) : 0;
     const __amdgpu_buffer_rsrc_t ysrc = __builtin_amdgcn_make_buffer_rsrc(
-        g.Y + (long long)m0 * g.ldy + n0, 0, (int)(((long long)(rows - 1) * g.ldy + (g.N - n0)) * 2), 0x00020000);
+        g.Y + (long long)m0 * g.ldy + n0, 0, rows > 0 ? (int)(((long long)(rows - 1) * g.ldy + (g.N - n0)) * 2) : 0, 0x00020000);
+    const unsigned char *img = stage + (it & 1) * kWrStageB;
+    if constexpr (GATE) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");   // younger than this thread's gate DMAs: 3 X DMAs
 #pragma unroll
     for (int t = 0; t < kWrPerThread; ++t) {
-      gemm_u32x4 v = *reinterpret_cast<const gemm_u32x4 *>(stage + flush_row[t] * kWrStageStrideB + flush_c[t] * 16);
+      gemm_u32x4 v = *reinterpret_cast<const gemm_u32x4 *>(img + stage_off[t]);
       if constexpr (GATE) {
-        const gemm_u32x4 a = *reinterpret_cast<const gemm_u32x4 *>(gring + (it % GS) * kWrSlotB + (tid + kWrThreads * t) * 16);
+        const gemm_u32x4 a = *reinterpret_cast<const gemm_u32x4 *>(gslot + gate_off[t]);
         auto keep = [](unsigned av, unsigned vv) {
           const unsigned lo = ((av & 0x8000u) == 0u && (av & 0x7fffu) != 0u) ? 0x0000ffffu : 0u;
           const unsigned hi = ((av & 0x80000000u) == 0u && (av & 0x7fff0000u) != 0u) ? 0xffff0000u : 0u;
@@ -255,6 +281,52 @@ __global__ __launch_bounds__(kWrThreads) __attribute__((amdgpu_waves_per_eu(2, 2
       }
       __builtin_amdgcn_raw_buffer_store_b128(v, ysrc, y_voff[t], 0, 0);
     }
+  };
+  // vector-memory instructions of a thread younger than the X DMAs of the chunk it is about to wait for: the NS - 2 full
+  // iterations issued since (plain: 2 x (3 stores + 3 DMAs) = 12;  gate: 1 x (3 + 3 + 3) = 9)
+  auto wait_chunk = [&]() {
+    if (g.debug & 64) return;
+    if constexpr (GATE) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  };
+  auto lds_done_barrier = [&]() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  };
+
+  wait_chunk();                                   // chunk 0 (this thread's pieces; everything older has completed too)
+  __builtin_amdgcn_s_barrier();
+  if (group == 0) {
+    // group A: half-step 2 it = C(it); half-step 2 it + 1 = E(it), F(it - 1), DMAs, wait for chunk it + 1
+    for (int it = 0; it < n_iter; ++it) {
+      compute(it);
+      lds_done_barrier();
+      epilogue(it);
+      flush(it - 1);
+      if constexpr (GATE) issue_gate(it);
+      issue_x(it + NS - 1);                       // slot (it - 1) % NS: last read in half-step 2 it - 1
+      wait_chunk();
+      lds_done_barrier();
+    }
+    __builtin_amdgcn_s_barrier();                 // half-step 2 n: group B parks chunk n - 1
+    flush(n_iter - 1);
+  } else {
+    // group B, half an iteration behind: half-step 2 it = E(it - 1), F(it - 2), DMAs; half-step 2 it + 1 = C(it), wait
+    for (int it = 0; it < n_iter; ++it) {
+      if (it > 0) epilogue(it - 1);
+      flush(it - 2);
+      if constexpr (GATE) issue_gate(it - 1);
+      issue_x(it + NS - 1);
+      lds_done_barrier();
+      compute(it);
+      wait_chunk();
+      lds_done_barrier();
+    }
+    epilogue(n_iter - 1);
+    flush(n_iter - 2);
+    if constexpr (GATE) { issue_gate(n_iter - 1); issue_x(n_iter + NS - 1); }   // (the X DMAs keep flush's count exact)
+    lds_done_barrier();
+    flush(n_iter - 1);
   }
 }
 
