@@ -71,9 +71,11 @@ def test_dropout_epilogue_statistics_and_seed():
     assert abs(frac - (1 - p)) < 2e-3, frac
     torch.testing.assert_close(y1[kept], (plain / (1 - p))[kept], rtol=2 ** -7, atol=1e-6)
     assert float(y1[~active].abs().max()) == 0.0
-    # the four lanes of a hash word are independent enough: per-column keep rates stay near 1 - p
-    col = ((y1 != 0) & active).float().sum(0) / active.float().sum(0).clamp_min(1)
-    assert float((col - (1 - p)).abs().max()) < 0.03
+    # the four 16-bit fields of a hash word pair are usable uniforms: per-column keep rates within 5 sigma of 1 - p
+    n_act = active.float().sum(0)
+    col = ((y1 != 0) & active).float().sum(0) / n_act.clamp_min(1)
+    z = (col - (1 - p)).abs() / (p * (1 - p) / n_act.clamp_min(1)).sqrt()
+    assert float(z[n_act > 500].max()) < 5.0, float(z[n_act > 500].max())
 
 
 def test_transposed_shadows_and_dgrad_route():
