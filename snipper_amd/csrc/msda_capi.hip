@@ -705,7 +705,9 @@ int snipper_relu_dropout_backward_bf16(void *stream, const uint16_t *grad_y, con
 namespace {
 struct WgradPlan { int tiles_n, tiles_k, S, rows, wk; };
 // split the reduction axis so that the grid has about g_wgrad_wgs workgroups (2 per CU); a multiple of 8 row-ranges
-// lets the kernel keep the output tiles of one range on one XCD
+// lets the kernel keep the output tiles of one range on one XCD.
+// (Round 3: an LDS-DMA ring variant -- one 4-wave workgroup per CU, 96 KB in flight -- was built, parity-green and slower:
+//  49 against 40 us at 79 000 x 384 x 384, memory not the limiter; profiles/r03_wgrad_ring_experiment.json.)
 WgradPlan wgrad_plan(int M, int N, int Kc) {
   WgradPlan p;
   const int wgs = kWgradWgs;

@@ -1,22 +1,26 @@
-import torch, time, sys
-sys.path.insert(0, '/root/repo')
+#!/usr/bin/env python3
+"""Weight-gradient kernels (split reduction): time per call incl. the partial reduction and the bias gradient.
+`SNIPPER_WGRAD_RING=0 python tools/wgradbench.py` times the register-prefetch kernel behind the same entry point."""
+import json, os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from snipper_amd.dense import wgrad_bf16
-from snipper_amd import _lib
 dev = 'cuda:0'
-def t(fn, n=20):
-    for _ in range(3): fn()
+def t(fn, n=30):
+    for _ in range(5): fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(n): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
-for (M, N, Kc) in [(79000, 384, 384), (79000, 1024, 384), (79000, 384, 1024), (79000, 192, 384), (79000, 96, 384), (60000, 512, 256), (15200, 1024, 512), (3800, 2048, 1024)]:
+ring = os.environ.get("SNIPPER_WGRAD_RING", "1") != "0"
+for (M, N, Kc) in [(79000, 384, 384), (79000, 1024, 384), (79000, 384, 1024), (79000, 288, 384), (79000, 192, 384), (158000, 384, 384),
+                   (60000, 512, 256), (240000, 64, 256), (15200, 1024, 512)]:
     g = torch.randn(M, N, device=dev).bfloat16(); x = torch.randn(M, Kc, device=dev).bfloat16()
-    base = t(lambda: torch.mm(g.t(), x))
-    baseb = t(lambda: g.sum(0))
-    res = []
-    for wgs in (256, 512, 768, 1024, 2048):
-        _lib.set_param("wgrad_wgs", wgs)
-        res.append((wgs, round(t(lambda: wgrad_bf16(g, x)), 1)))
-    print(f"M={M} N={N} Kc={Kc}: torch.mm {base:.1f} us + bias-sum {baseb:.1f} us | ours (incl. bias) {res}", flush=True)
+    us = t(lambda: wgrad_bf16(g, x))
+    dW, db = wgrad_bf16(g, x)
+    ref = g.double().t() @ x.double()
+    err = float((dW.double() - ref).abs().max() / ref.abs().max())
+    errb = float((db.double() - g.double().sum(0)).abs().max() / g.double().sum(0).abs().max())
+    print(json.dumps({"M": M, "N": N, "Kc": Kc, "ring": ring, "us_incl_reduce_and_bias": round(us, 1), "rel_err_dW": err, "rel_err_db": errb,
+                      "GBps": round(2 * M * (N + Kc) / us / 1e3, 1)}), flush=True)
