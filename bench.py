@@ -435,6 +435,30 @@ def maybe_self_launch(argv=None, script: str = None):
     return rc
 
 
+def set_offset_sigma(model, sigma_px: float, net, batch, amp: bool) -> None:
+    """Give the encoder's sampling offsets a per-query spread of about ``sigma_px`` pixels (standard deviation of the
+    weight-dependent part; the reference's 8-direction bias grid stays): ``sampling_offsets.weight`` is zero at
+    initialisation (models/ops/modules/ms_deform_attn.py:82-90), so a freshly built model samples every query at the same
+    <= 4 px bias grid -- the best case for the owner-computes backward, whose speed depends on how many taps lie within
+    ``near_radius`` of the query's anchor.  A trained model spreads them; this emulates that.  The weight is drawn N(0, 1)
+    and scaled per layer by sigma / mean ||query||_2, measured with one forward pass."""
+    layers = list(model.transformer.encoder.layers)
+    norms, hooks = {}, []
+    for i, layer in enumerate(layers):
+        def pre(mod, args, i=i):
+            norms[i] = float(args[0].detach().float().norm(dim=-1).mean())
+        hooks.append(layer.self_attn.register_forward_pre_hook(pre))
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+        net(list(batch[0]))
+    for h in hooks:
+        h.remove()
+    gen = torch.Generator(device="cpu").manual_seed(1234)
+    with torch.no_grad():
+        for i, layer in enumerate(layers):
+            w = layer.self_attn.sampling_offsets[0].weight
+            w.copy_((torch.randn(w.shape, generator=gen) * (sigma_px / max(norms.get(i, 1.0), 1e-6))).to(w.device))
+
+
 def main():
     rc = maybe_self_launch()
     if rc is not None:
@@ -476,6 +500,10 @@ def main():
     ap.add_argument("--gc-every", type=int, default=10,
                     help="collect garbage by hand every N steps and keep the automatic collector off in between (its "
                          "generation-0/1 passes cost the issuing thread ~1 ms per step); 0 = leave the collector alone")
+    ap.add_argument("--offset-sigma-px", type=float, default=0.0,
+                    help="spread of the encoder's sampling offsets in pixels for the TIMED region (0 = as initialised: every "
+                         "query samples its <= 4 px bias grid); the default run also reports steps at 3 and 8 px in `locality`")
+    ap.add_argument("--no-locality-sweep", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip roofline/msda extras (profiling runs)")
     a = ap.parse_args()
@@ -654,6 +682,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if a.offset_sigma_px > 0:
+        set_offset_sigma(model, a.offset_sigma_px, net, batches[0], amp)
     for i in range(a.warmup):
         step(i)
     fence()
@@ -799,6 +829,35 @@ def main():
                 train_step(*batches[i % len(batches)])
         fence()
 
+    # ---- the same step at trained-like locality: sigma 3 px and 8 px, a few steps each, after the contract's timed region; one GPU only
+    locality = []
+
+    def owner_bwd_ms(ls):
+        t = [ms for kind, variant, d, ms in ls if kind == "bwd" and d["Lq"] > 1000]
+        return round(sum(t) / len(t), 4) if t else None
+
+    if rank == 0 and world == 1 and not a.no_extras and not a.no_locality_sweep and graph is None:
+        locality.append({"offset_sigma_px": a.offset_sigma_px, "ms_per_step": round(elapsed / a.steps * 1e3, 3),
+                         "encoder_bwd_ms_per_launch": owner_bwd_ms(launches), "note": "the timed region"})
+        for sig in (3.0, 8.0):
+            if sig == a.offset_sigma_px:
+                continue
+            set_offset_sigma(model, sig, net, batches[0], amp)
+            for i in range(4):
+                step(i)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for i in range(12):
+                step(i)
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t1) / 12 * 1e3
+            MSDA.enable_launch_timing(True)
+            train_step(*batches[0])
+            ls = MSDA.launch_timings()
+            MSDA.enable_launch_timing(False)
+            locality.append({"offset_sigma_px": sig, "ms_per_step": round(ms, 3), "encoder_bwd_ms_per_launch": owner_bwd_ms(ls),
+                             "note": "12 steps after 4 warm-up steps"})
+
     if rank == 0:
         snippets = a.batch * world * a.steps
         line = {
@@ -829,6 +888,8 @@ def main():
                                      "torch.optim.AdamW (fused) + clip_grad_norm_ per parameter")},
             "final_loss": round(loss_val, 5),
         }
+        if locality:
+            line["locality"] = locality
         if launches:
             by = {}
             for kind, variant, d, ms in launches:

@@ -45,7 +45,10 @@ snipper_msda_config default_config() {
   snipper_msda_config c{};
   c.struct_bytes = (int32_t)sizeof(snipper_msda_config);
   c.policy = 0;
-  c.near_radius = 6.0f;
+  // 24 px: measured at N = 8, bf16 value, reference offset bias grid + N(0, sigma) px (tools/sweep_radius.sh, profiles/
+  // r03_radius_sweep.txt): backward 0.85 / 0.96 / 0.96 ms at sigma ~0 / 3 / 8 px, against 0.87 / 1.39 / 2.34 ms at round 2's
+  // 6 px, which had been tuned on freshly initialised offsets only
+  c.near_radius = 24.0f;
   c.tile_edge[0] = 16; c.tile_edge[1] = 8; c.tile_edge[2] = 4;
   return c;
 }

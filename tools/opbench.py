@@ -23,7 +23,7 @@ SHAPES = [(75, 100), (38, 50), (19, 25)]
 M, D, L, P = 8, 48, 3, 4
 
 
-def make(N, Lq, local, dtype, seed=0, dev="cuda:0", sigma=3.0, far=0.0):
+def make(N, Lq, local, dtype, seed=0, dev="cuda:0", sigma=3.0, far=0.0, grid=False):
     g = torch.Generator().manual_seed(seed)
     S = sum(h * w for h, w in SHAPES)
     value = torch.randn(N, S, M, D, generator=g)
@@ -34,7 +34,14 @@ def make(N, Lq, local, dtype, seed=0, dev="cuda:0", sigma=3.0, far=0.0):
             refs.append(torch.stack([xs.reshape(-1) / w, ys.reshape(-1) / h], -1))
         ref = torch.cat(refs)[None, :, None, None, None, :]
         norm = torch.tensor([[w, h] for h, w in SHAPES], dtype=torch.float32)[None, None, None, :, None, :]
-        loc = ref + torch.randn(N, Lq, M, L, P, 2, generator=g) * sigma / norm
+        off = torch.randn(N, Lq, M, L, P, 2, generator=g) * sigma
+        if grid:          # the reference's offset bias: 8 directions (one per head) x point index 1..P (ms_deform_attn.py:82-90)
+            import math
+            th = torch.arange(M, dtype=torch.float32) * (2.0 * math.pi / M)
+            d_ = torch.stack([th.cos(), th.sin()], -1)
+            d_ = d_ / d_.abs().max(-1, keepdim=True)[0]
+            off = off + (d_.view(1, 1, M, 1, 1, 2) * torch.arange(1, P + 1, dtype=torch.float32).view(1, 1, 1, 1, P, 1))
+        loc = ref + off / norm
         if far > 0:
             pick = torch.rand(N, Lq, M, L, P, 1, generator=g) < far
             loc = torch.where(pick, torch.rand(N, Lq, M, L, P, 2, generator=g) * 1.4 - 0.2, loc)
@@ -80,6 +87,7 @@ def main():
     ap.add_argument("--dtypes", nargs="+", default=["float32", "bfloat16"])
     ap.add_argument("--sigma", type=float, nargs="+", default=[3.0], help="enc_local: std of the offsets in pixels")
     ap.add_argument("--far", type=float, nargs="+", default=[0.0], help="enc_local: fraction of samples placed anywhere")
+    ap.add_argument("--grid", type=int, default=0, help="enc_local: 1 = add the reference's 8-direction x (1..P) offset bias grid")
     ap.add_argument("--rows-bf16", type=int, default=0, help="1 = bf16 out / grad_out rows beside f32 value (the step's mode)")
     args = ap.parse_args()
     S = sum(h * w for h, w in SHAPES)
@@ -97,7 +105,7 @@ def main():
             sweeps = [(sg, fr) for sg in args.sigma for fr in args.far] if name == "enc_local" else [(3.0, 0.0)]
             for dtype in [getattr(torch, x) for x in args.dtypes]:
               for sg, fr in sweeps:
-                v, shapes, lsi, loc, attn, go = make(N, Lq, local, dtype, sigma=sg, far=fr)
+                v, shapes, lsi, loc, attn, go = make(N, Lq, local, dtype, sigma=sg, far=fr, grid=bool(args.grid))
                 rows16 = bool(args.rows_bf16) and dtype == torch.float32
                 if rows16:
                     go = go.to(torch.bfloat16)
@@ -114,7 +122,7 @@ def main():
                     tb, tb0 = timeit(b, args.iters)
                     e = v.element_size()
                     print(json.dumps({
-                        "case": name, "N": N, "sigma_px": sg, "far": fr, "rows_bf16": int(rows16),
+                        "case": name, "N": N, "sigma_px": sg, "far": fr, "grid": args.grid, "radius": args.radius, "edges": args.edges, "rows_bf16": int(rows16),
                         "dtype": str(dtype).split(".")[-1], "fwd_variant": var_f,
                         "bwd_variant": var_b, "fwd_ms": round(tf, 4), "fwd_min_ms": round(tf0, 4),
                         "bwd_ms": round(tb, 4), "bwd_min_ms": round(tb0, 4),
