@@ -829,6 +829,37 @@ def main():
                 train_step(*batches[i % len(batches)])
         fence()
 
+    # ---- where the staged all-reduces are launched on the GPU timeline of a step (events on the compute stream): the stages
+    #      launched from autograd hooks must sit INSIDE backward.  (On one GPU with a 1-rank group RCCL launches no kernel for
+    #      an in-place all-reduce, so a kernel trace cannot show them; the launch points can.)
+    sync_trace = None
+    if gsync is not None and not a.no_extras and graph is None:
+        imgs_, tgt_ = batches[0]
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+            out_, _ = net(list(imgs_))
+        if criterion is not None:
+            l_, _ = criterion(out_, tgt_["targets"])
+            loss_ = criterion.weighted_sum(l_)
+        else:
+            loss_ = surrogate_loss(out_, tgt_)
+        if flatp is not None:
+            flatp.drop_param_grads()
+        else:
+            opt.zero_grad(set_to_none=True)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        gsync.trace = []
+        e0.record()
+        loss_.backward()
+        e1.record()
+        gsync.sync()
+        torch.cuda.synchronize()
+        sync_trace = {"backward_ms": round(e0.elapsed_time(e1), 3),
+                      "stage_launch_ms_after_backward_start": [[i, round(e0.elapsed_time(ev), 3)] for i, ev in gsync.trace],
+                      "stages": ["transformer + heads + projections", "layer4", "layer3", "layer2"]}
+        gsync.trace = None
+        if flatp is not None:
+            flatp.pack()
+
     # ---- the same step at trained-like locality: sigma 3 px and 8 px, a few steps each, after the contract's timed region; one GPU only
     locality = []
 
@@ -890,6 +921,8 @@ def main():
         }
         if locality:
             line["locality"] = locality
+        if sync_trace:
+            line["grad_sync_trace"] = sync_trace
         if launches:
             by = {}
             for kind, variant, d, ms in launches:

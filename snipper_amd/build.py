@@ -11,10 +11,12 @@ import subprocess
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
-LIB_PATH = os.path.join(PKG_DIR, "libsnipper_msda.so")
+# (diagnostic builds: SNIPPER_MSDA_LIB = another file name in this directory, SNIPPER_HIPCC_EXTRA = extra compiler flags,
+#  e.g. -DWRES_STAMPS for the in-kernel cycle stamps of tools/wres_stamps.py; the product never sets them)
+LIB_PATH = os.path.join(PKG_DIR, os.path.basename(os.environ.get("SNIPPER_MSDA_LIB", "libsnipper_msda.so")))
 SOURCES = ["msda_capi.hip"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-               "-Wall", "-Wno-cuda-compat", "-fno-gpu-rdc"]
+               "-Wall", "-Wno-cuda-compat", "-fno-gpu-rdc"] + os.environ.get("SNIPPER_HIPCC_EXTRA", "").split()
 
 
 HASH_PATH = LIB_PATH + ".srchash"

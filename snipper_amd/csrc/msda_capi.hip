@@ -16,6 +16,7 @@
 #include "gemm_bf16.cuh"
 #include "wgrad_bf16.cuh"
 #include "wres_gemm_bf16.cuh"
+#include "wgrad_ring_bf16.cuh"
 #include "small_linear.cuh"
 #include "small_attention.cuh"
 #include "match_cost.cuh"
@@ -467,6 +468,12 @@ int wres_debug() {       // SNIPPER_WRES_DEBUG: timing ablations of the weight-s
   static const int v = [] { const char *e = getenv("SNIPPER_WRES_DEBUG"); return e ? atoi(e) : 0; }();
   return v;
 }
+// diagnostic builds only (-DWRES_STAMPS): SNIPPER_WRES_STAMPS=<device address, hex> of a 2 x 320 x 8-byte buffer that workgroup 0
+// fills with s_memtime stamps (tools/wres_stamps.py allocates it and passes the address through the environment)
+unsigned long long *wres_stamp_buffer() {
+  static unsigned long long *const p = [] { const char *e = getenv("SNIPPER_WRES_STAMPS"); return e ? (unsigned long long *)strtoull(e, nullptr, 16) : nullptr; }();
+  return p;
+}
 bool wres_enabled() {
   static const bool on = [] { const char *e = getenv("SNIPPER_GEMM_WRES"); return !(e && e[0] == '0'); }();
   return on;
@@ -495,7 +502,7 @@ int snipper_linear_wres_bf16(void *stream, const uint16_t *X, long long ldx, con
   if (n_series < 8) n_series = 8;
   if (n_series > ((chunks + 7) / 8) * 8) n_series = ((chunks + 7) / 8) * 8;
   const WresArgs g{X, ldx, W, ldw, bias, A, lda, gate_scale, Y, ldy, M, N, K, relu ? 1 : 0, dropout_p,
-                   (uint32_t)seed, (uint32_t)(seed >> 32), n_series, wres_debug()};
+                   (uint32_t)seed, (uint32_t)(seed >> 32), n_series, wres_stamp_buffer(), wres_debug()};
   const dim3 grid((unsigned)(n_series * ncb)), block(kWrThreads);
   hipStream_t st = (hipStream_t)stream;
   const bool act = relu || dropout_p > 0.f;
@@ -730,7 +737,8 @@ WgradPlan wgrad_plan(int M, int N, int Kc) {
 size_t snipper_wgrad_workspace_bytes(int M, int N, int Kc) {
   if (M <= 0 || N <= 0 || Kc <= 0) return 0;
   const WgradPlan p = wgrad_plan(M, N, Kc);
-  return ((size_t)p.S * N * Kc + (size_t)p.S * N) * sizeof(float);
+  // partial tiles are whole 128 x 128 accumulator images (wgrad_bf16.cuh), then the [S][N] partial column sums
+  return ((size_t)p.S * p.tiles_n * p.tiles_k * 16384 + (size_t)p.S * N) * sizeof(float);
 }
 
 int snipper_wgrad_bf16(void *stream, const uint16_t *G, long long ldg, const uint16_t *X, long long ldx,
@@ -742,11 +750,19 @@ int snipper_wgrad_bf16(void *stream, const uint16_t *G, long long ldg, const uin
   if (((uintptr_t)G | (uintptr_t)X | (uintptr_t)dW | (uintptr_t)workspace) & 15) return SNIPPER_E_SHAPE;
   if (workspace_bytes < snipper_wgrad_workspace_bytes(M, N, Kc)) return SNIPPER_E_SHAPE;
   const WgradPlan p = wgrad_plan(M, N, Kc);
-  float *P = (float *)workspace, *Pb = db ? P + (size_t)p.S * N * Kc : nullptr;
-  const WgradArgs a{G, ldg, X, ldx, P, Pb, M, N, Kc, p.S, p.rows, p.tiles_n, p.tiles_k, 0, 0, 0, 0, 0, 0, 0};
-  hipLaunchKernelGGL(wgrad_bf16_kernel<128>, dim3(p.tiles_n * p.tiles_k * p.S), dim3(kWgThreads), 0, (hipStream_t)stream, a);
-  const WgradReduceArgs r{P, Pb, dW, lddw, db, scale, N, Kc, p.S, accumulate};
-  const long long quads = (long long)N * Kc / 4;
+  float *P = (float *)workspace, *Pb = db ? P + (size_t)p.S * p.tiles_n * p.tiles_k * 16384 : nullptr;
+  static const bool ring_on = [] { const char *e = getenv("SNIPPER_WGRAD_RING"); return !(e && e[0] == '0'); }();
+  // long reductions onto few output tiles: the LDS-DMA ring kernel (csrc/wgrad_ring_bf16.cuh).  Measured (kernel only, us,
+  // ring / register prefetch): 79 000 x 384 x 384 34.9 / 38.9, x 288 x 384 the same; 79 000 x 1024 x 384 (24 tiles) 115 / 103
+  if (ring_on && M >= 8192 && p.rows >= 4 * kWrgRows && p.tiles_n * p.tiles_k <= 12) {
+    const WgradRingArgs a{G, ldg, X, ldx, P, Pb, M, N, Kc, p.S, p.rows, p.tiles_n, p.tiles_k, wres_debug()};
+    hipLaunchKernelGGL(wgrad_ring_kernel, dim3(p.tiles_n * p.tiles_k * p.S), dim3(kWrgThreads), 0, (hipStream_t)stream, a);
+  } else {
+    const WgradArgs a{G, ldg, X, ldx, P, Pb, M, N, Kc, p.S, p.rows, p.tiles_n, p.tiles_k, 0, 0, 0, 0, 0, 0, 0};
+    hipLaunchKernelGGL(wgrad_bf16_kernel<128>, dim3(p.tiles_n * p.tiles_k * p.S), dim3(kWgThreads), 0, (hipStream_t)stream, a);
+  }
+  const WgradReduceArgs r{P, Pb, dW, lddw, db, scale, N, Kc, p.S, accumulate, p.tiles_n, p.tiles_k};
+  const long long quads = (long long)p.tiles_n * p.tiles_k * 4096;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((quads + 63) / 64)), dim3(256), 0, (hipStream_t)stream, r);
   return launch_status();
 }
@@ -773,8 +789,8 @@ int snipper_wgrad_conv3x3_bf16(void *stream, const uint16_t *G, const uint16_t *
   float *P = (float *)workspace;
   const WgradArgs a{G, Cout, X, Cin, P, nullptr, (int)M, Cout, Kc, p.S, p.rows, p.tiles_n, p.tiles_k, 1, H, Wd, Cin, Ho, Wo, stride};
   hipLaunchKernelGGL(wgrad_bf16_kernel<128>, dim3(p.tiles_n * p.tiles_k * p.S), dim3(kWgThreads), 0, (hipStream_t)stream, a);
-  const WgradReduceArgs r{P, nullptr, dW, Kc, nullptr, scale, Cout, Kc, p.S, accumulate};
-  const long long quads = (long long)Cout * Kc / 4;
+  const WgradReduceArgs r{P, nullptr, dW, Kc, nullptr, scale, Cout, Kc, p.S, accumulate, p.tiles_n, p.tiles_k};
+  const long long quads = (long long)p.tiles_n * p.tiles_k * 4096;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((quads + 63) / 64)), dim3(256), 0, (hipStream_t)stream, r);
   return launch_status();
 }

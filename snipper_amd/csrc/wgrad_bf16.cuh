@@ -184,20 +184,16 @@ void wgrad_bf16_kernel(WgradArgs g) {
     __syncthreads();
   }
 
-  // partial tile: rows n = 4 * (lane >> 4) + reg, column kc = lane & 15 of each 16 x 16 block
-  float *P = g.P + (long long)s * g.N * g.Kc;
+  // partial tile, in ACCUMULATOR order: the workspace is scratch, so each lane stores its 16 x 4 floats as 16 coalesced
+  // 16-byte pieces (one KB per wave-instruction) and wgrad_reduce_kernel undoes the permutation.  Written as dW is laid
+  // out ([n][kc], 4-byte pieces of 4 rows per instruction) the store epilogue alone took 9 us of a 40 us launch (round 3,
+  // profiles/r03_wgrad_ring_experiment.json).  Position: ((((s * tiles + t) * 4 + wave) * 16 + 4 i + j) * 64 + lane) * 4 + reg.
+  static_assert(NJ == 4, "the partial layout assumes 4 x 4 accumulator tiles per wave");
+  gemm_f32x4 *Pq = reinterpret_cast<gemm_f32x4 *>(g.P) + ((((long long)s * tiles + t) * 4 + wave) * 16) * 64 + lane;
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-      const int kc = k0 + wk * (WK / 2) + j * 16 + (lane & 15);
-      const int n = n0 + wn * 64 + i * 16 + (lane >> 4) * 4;
-      if (kc >= g.Kc) continue;
-      const float v[4] = {acc[i][j].x, acc[i][j].y, acc[i][j].z, acc[i][j].w};
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        if (n + r < g.N) P[(long long)(n + r) * g.Kc + kc] = v[r];
-    }
+    for (int j = 0; j < NJ; ++j) Pq[(i * 4 + j) * 64] = acc[i][j];
   if (do_bias) {                                   // 16 row-groups x 128 columns -> 128 column sums
     float *red = reinterpret_cast<float *>(Gs);    // 8 KB of the 18 KB tile; all reads of it are behind a barrier
 #pragma unroll
@@ -212,43 +208,82 @@ void wgrad_bf16_kernel(WgradArgs g) {
   }
 }
 
-// out[n][kc] (+)= scale[n] * sum_s P[s][n][kc];  db[n] (+)= sum_s Pb[s][n].  Fixed summation order.
+// out[n][kc] (+)= scale[n] * sum_s P[s][...];  db[n] (+)= sum_s Pb[s][n].  Fixed summation order.  The partials lie in
+// accumulator order (see the store at the end of wgrad_bf16_kernel): quad q of a partial = (tile t, wave, 4 i + j, lane) holds
+// rows n .. n + 3 of ONE column kc.
 struct WgradReduceArgs {
   const float *P; const float *Pb;
   float *dW; long long lddw;     // [N][Kc] with leading dimension
   float *db;                     // [N] or nullptr
   const float *scale;            // [N] or nullptr: per-output-row factor (the folded BatchNorm scale)
-  int N, Kc, S, accumulate;
+  int N, Kc, S, accumulate, tiles_n, tiles_k;
 };
 
-// 256 threads = 64 quads of 4 consecutive kc x 4 slices of the S partials; the slices meet in LDS
+// 256 threads = 64 quads x 4 slices of the S partials; the slices meet in LDS
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgradReduceArgs g) {
   __shared__ gemm_f32x4 red[4][64];
-  const long long total = (long long)g.N * g.Kc;
+  const long long total = (long long)g.tiles_n * g.tiles_k * 16384;        // floats per partial
   const int qi = threadIdx.x & 63, slice = threadIdx.x >> 6;
-  const long long e = ((long long)blockIdx.x * 64 + qi) * 4;
+  const long long q = (long long)blockIdx.x * 64 + qi, e = q * 4;
   gemm_f32x4 sum = {0.f, 0.f, 0.f, 0.f};
   if (e < total) {
     const float *p = g.P + e;
-#pragma unroll 4
-    for (int s = slice; s < g.S; s += 4) sum += *reinterpret_cast<const gemm_f32x4 *>(p + (long long)s * total);
+    // 8 partials of this slice in flight per thread (2.25 workgroups per CU at 384 x 384: the kernel is bound by the loads
+    // each wave keeps outstanding, not by bandwidth); the summation order stays fixed: s ascending within the slice
+    int s = slice;
+    for (; s + 28 < g.S; s += 32) {
+      gemm_f32x4 v[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const gemm_f32x4 *>(p + (long long)(s + 4 * i) * total);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) sum += v[i];
+    }
+    for (; s < g.S; s += 4) sum += *reinterpret_cast<const gemm_f32x4 *>(p + (long long)s * total);
   }
   red[slice][qi] = sum;
   __syncthreads();
   if (slice == 0 && e < total) {
     sum = (red[0][qi] + red[1][qi]) + (red[2][qi] + red[3][qi]);
-    const int n = (int)(e / g.Kc), kc = (int)(e - (long long)n * g.Kc);      // Kc % 4 == 0: one row per quad
-    if (g.scale) sum *= g.scale[n];
-    float *o = g.dW + (long long)n * g.lddw + kc;
-    if (g.accumulate) sum += *reinterpret_cast<const gemm_f32x4 *>(o);
-    *reinterpret_cast<gemm_f32x4 *>(o) = sum;
+    const int lane = (int)(q & 63), ij = (int)(q >> 6) & 15, wave = (int)(q >> 10) & 3, t = (int)(q >> 12);
+    const int tn = t / g.tiles_k, tk = t - tn * g.tiles_k;
+    const int n = tn * 128 + (wave & 1) * 64 + (ij >> 2) * 16 + (lane >> 4) * 4;
+    const int kc = tk * 128 + (wave >> 1) * 64 + (ij & 3) * 16 + (lane & 15);
+    if (kc < g.Kc) {
+      const float v[4] = {sum.x, sum.y, sum.z, sum.w};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (n + r < g.N) {
+          float o = g.scale ? v[r] * g.scale[n + r] : v[r];
+          float *dst = g.dW + (long long)(n + r) * g.lddw + kc;
+          if (g.accumulate) o += *dst;
+          *dst = o;
+        }
+      }
+    }
   }
+  // bias gradient: column n = 64 blockIdx + qi, the S partial sums split over the 4 slices like the tiles above.  (One
+  // thread per column walking all S partials serially -- 57 dependent round trips in two workgroups -- made this 12-KB
+  // reduction the longest thing in the launch: 19.8 us of kernel time at 384 x 384, S = 57.)
   if (g.db && g.Pb) {
-    const long long n = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long n = (long long)blockIdx.x * 64 + qi;
+    float bs = 0.f;
     if (n < g.N) {
-      float bs = 0.f;
-      for (int s = 0; s < g.S; ++s) bs += g.Pb[(long long)s * g.N + n];
-      g.db[n] = g.accumulate ? g.db[n] + bs : bs;
+      int s = slice;
+      for (; s + 28 < g.S; s += 32) {
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = g.Pb[(long long)(s + 4 * i) * g.N + n];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) bs += v[i];
+      }
+      for (; s < g.S; s += 4) bs += g.Pb[(long long)s * g.N + n];
+    }
+    __syncthreads();                               // (the tile sums above have been read out of `red`)
+    red[slice][qi].x = bs;
+    __syncthreads();
+    if (slice == 0 && n < g.N) {
+      const float tot = (red[0][qi].x + red[1][qi].x) + (red[2][qi].x + red[3][qi].x);
+      g.db[n] = g.accumulate ? g.db[n] + tot : tot;
     }
   }
 }

@@ -53,6 +53,7 @@ struct WresArgs {
   int relu;
   float drop_p; uint32_t seed_lo, seed_hi;
   int n_series;                          // chunk lists: gridDim.x = n_series * ceil(N / 384)
+  unsigned long long *stamps;            // diagnostic builds (-DWRES_STAMPS): s_memtime stamps of workgroup 0, waves 0 and 4
   int debug;                             // timing ablations (WRONG results): 1 no W loads, 2 no MFMA, 4 no stores, 8 no X reads,
                                          // 16 no epilogue, 32 no flush, 64 no counted waits, 128 no X DMA instructions
 };
@@ -66,6 +67,12 @@ __device__ __forceinline__ void wres_dma16(__amdgpu_buffer_rsrc_t src, unsigned 
 
 // LDS: NS ring slots of 24 KB (+ one gate slot) + two 24.5 KB staging images = 145 KB either way: one workgroup per CU.
 // ACT: a ReLU and / or dropout epilogue is compiled in (the plain projections carry no trace of it).
+#ifdef WRES_STAMPS
+#define WRES_STAMP(slot) do { if (blockIdx.x == 0 && lane == 0 && (wave & 3) == 0 && stamp_n < 8 * 40) { stamp_buf[(wave >> 2) * 320 + stamp_n] = ((unsigned long long)(slot) << 56) | (__builtin_amdgcn_s_memtime() & 0x00ffffffffffffffull); ++stamp_n; } } while (0)
+#else
+#define WRES_STAMP(slot) do { } while (0)
+#endif
+
 template <int KS, bool GATE, bool ACT>
 __global__ __launch_bounds__(kWrThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void wres_gemm_kernel(WresArgs g) {
   constexpr int NS = GATE ? 3 : 4;
@@ -76,6 +83,10 @@ __global__ __launch_bounds__(kWrThreads) __attribute__((amdgpu_waves_per_eu(2, 2
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // scalar: the group branch below must be a real branch
   const int group = wave >> 2, tidg = tid & 255;
+#ifdef WRES_STAMPS
+  unsigned long long *stamp_buf = g.stamps;
+  int stamp_n = 0;
+#endif
 
   // workgroup -> (column block cb, chunk list `series`): the ncb workgroups that share a chunk list sit on one XCD
   // (ids b, b + 8, b + 16: round-robin placement), so a chunk comes from HBM once and from that XCD's L2 after
@@ -299,13 +310,20 @@ __global__ __launch_bounds__(kWrThreads) __attribute__((amdgpu_waves_per_eu(2, 2
   if (group == 0) {
     // group A: half-step 2 it = C(it); half-step 2 it + 1 = E(it), F(it - 1), DMAs, wait for chunk it + 1
     for (int it = 0; it < n_iter; ++it) {
+      WRES_STAMP(1);
       compute(it);
+      WRES_STAMP(2);
       lds_done_barrier();
+      WRES_STAMP(3);
       epilogue(it);
+      WRES_STAMP(4);
       flush(it - 1);
+      WRES_STAMP(5);
       if constexpr (GATE) issue_gate(it);
       issue_x(it + NS - 1);                       // slot (it - 1) % NS: last read in half-step 2 it - 1
+      WRES_STAMP(6);
       wait_chunk();
+      WRES_STAMP(7);
       lds_done_barrier();
     }
     __builtin_amdgcn_s_barrier();                 // half-step 2 n: group B parks chunk n - 1
@@ -313,13 +331,20 @@ __global__ __launch_bounds__(kWrThreads) __attribute__((amdgpu_waves_per_eu(2, 2
   } else {
     // group B, half an iteration behind: half-step 2 it = E(it - 1), F(it - 2), DMAs; half-step 2 it + 1 = C(it), wait
     for (int it = 0; it < n_iter; ++it) {
+      WRES_STAMP(3);
       if (it > 0) epilogue(it - 1);
+      WRES_STAMP(4);
       flush(it - 2);
+      WRES_STAMP(5);
       if constexpr (GATE) issue_gate(it - 1);
       issue_x(it + NS - 1);
+      WRES_STAMP(6);
       lds_done_barrier();
+      WRES_STAMP(1);
       compute(it);
+      WRES_STAMP(2);
       wait_chunk();
+      WRES_STAMP(7);
       lds_done_barrier();
     }
     epilogue(n_iter - 1);

@@ -119,6 +119,7 @@ class FlatGradSync:
                 self.rest[-1] = (self.rest[-1][0], i + 1)
             else:
                 self.rest.append((i, i + 1))
+        self.trace: Optional[list] = None          # set to [] to record (stage index, event on the compute stream) per launch
         self.late_idx: Optional[List[int]] = None if late is None else sorted(index[id(p)] for p in late if id(p) in index)
         if not self.stages:
             self.late_idx = []                    # nothing is launched before sync(): nothing can arrive late
@@ -173,6 +174,10 @@ class FlatGradSync:
             self._launch(s2)
 
     def _launch(self, st: _Stage) -> None:
+        if self.trace is not None and self.flat.is_cuda:               # where in the GPU timeline the stage was launched
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            self.trace.append((self.stages.index(st), ev))
         st.seen = [p.grad for p in self.params[st.lo:st.hi]]          # what was packed (None = zeros)
         self._pack(st.lo, st.hi)
         st.works = self._reduce(st.lo_elem, st.hi_elem) if self.collective else []
