@@ -62,6 +62,10 @@ int snipper_linear_wres_bf16(void *stream, const uint16_t *X, long long ldx, con
 int snipper_transpose_batch_bf16(void *stream, int count, const void *const *src, void *const *dst, const int *rows,
                                  const int *cols, const long long *ld_src, const long long *ld_dst);
 
+/* Measurement aid (tools/copybench.py): dst[i] = src[i], 16 bytes per lane, grid-stride -- the copy whose rate is the
+ * achievable-HBM figure the roofline fractions are read beside.  bytes % 16 == 0, 16-byte aligned pointers. */
+int snipper_hbm_copy_probe(void *stream, const void *src, void *dst, long long bytes);
+
 /* Backward of the (ReLU -> dropout) epilogue above from the layer's OUTPUT alone: a kept, active element has y > 0,
  * a dropped or inactive one y == 0, so grad_pre = y > 0 ? grad_y / (1 - p) : 0 (p = 0: plain ReLU backward).
  * bf16 bits, n % 8 == 0, 16-byte aligned. */

@@ -518,6 +518,24 @@ int snipper_linear_wres_bf16(void *stream, const uint16_t *X, long long ldx, con
   return launch_status();
 }
 
+namespace {
+// measurement aid: a float4 device-to-device copy, the form MI355X_MICROARCH.md quotes the achievable HBM rate for
+__global__ __launch_bounds__(256) void hbm_copy_probe_kernel(const gemm_u32x4 *__restrict__ src, gemm_u32x4 *__restrict__ dst, long long n16) {
+  const long long stride = (long long)gridDim.x * 256;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n16; i += stride) dst[i] = src[i];
+}
+}  // namespace
+
+int snipper_hbm_copy_probe(void *stream, const void *src, void *dst, long long bytes) {
+  if (!src || !dst) return SNIPPER_E_NULL;
+  if (bytes <= 0 || bytes % 16 || (((uintptr_t)src | (uintptr_t)dst) & 15)) return SNIPPER_E_SHAPE;
+  const long long n16 = bytes / 16;
+  const long long want = (n16 + 255) / 256;
+  const unsigned grid = (unsigned)(want < 8192 ? want : 8192);          // 32 workgroups per CU, grid-stride
+  hipLaunchKernelGGL(hbm_copy_probe_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const gemm_u32x4 *)src, (gemm_u32x4 *)dst, n16);
+  return launch_status();
+}
+
 int snipper_transpose_batch_bf16(void *stream, int count, const void *const *src, void *const *dst, const int *rows,
                                  const int *cols, const long long *ld_src, const long long *ld_dst) {
   if (count <= 0) return SNIPPER_OK;
