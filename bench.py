@@ -176,7 +176,7 @@ def msda_alg_bytes(d, bwd):
     return e * v + re * o + ge * v + ce * 6 * lp
 
 
-PMC_PROFILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_bench_step.csv")
+PMC_PROFILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_pmc_bench_step.csv")
 
 
 BWD_KERNELS = ("msda_bwd_d48_patchbin_kernel", "msda_bwd_d48_tile2_kernel")       # query side, grad_value side
@@ -937,8 +937,9 @@ def main():
             raw, corrected = pmc_traffic() if dom[1] == "d48_owner" and d["N"] == 8 and d["Lq"] == 9875 else (None, None)
             line["roofline"] = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                 "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": corrected, "traffic_raw_counters": raw,
-                                "traffic_source": ("profiles/r02_pmc_bench_step.csv: rocprofv3 --pmc FETCH_SIZE and "
-                                                   "WRITE_SIZE (separate passes) of this command, query-side + grad_value-side kernel; "
+                                "traffic_source": ("NOT measured in this run: read from the committed profiles/r03_pmc_bench_step.csv = "
+                                                   "rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE (separate passes, tools/collect_profiles.sh) of "
+                                                   "this command at the same kernels, query-side + grad_value-side kernel; "
                                                    "`traffic` doubles the latter's FETCH_SIZE (gfx950 counts half of a "
                                                    "16-B-per-lane stream: MI355X_MICROARCH.md, HBM), `traffic_raw_counters` "
                                                    "is what the counters read" if corrected else None),

@@ -47,9 +47,10 @@ int snipper_linear_nn_bf16(void *stream, const uint16_t *X, long long ldx, const
  *   Y[M,N] = gate( dropout( act( X[M,K] . W[N,K]^T + bias ) ) ),   K in {288, 384}, N % 8 == 0, M >= 8192.
  * W (row stride ldw) stays in registers for the whole launch, X is streamed through an LDS-DMA ring, one persistent
  * workgroup per CU; a data gradient dX = dY . Wl passes the TRANSPOSED weight (snipper_transpose_batch_bf16).  A = NULL or
- * the gate activation [M][N]: gate(v) = A > 0 ? v * gate_scale : 0 (see snipper_linear_nn_bf16).  Dropout: a counter-based
- * hash of (seed, element index / 4) yields four 16-bit uniforms (p is resolved to 2^-16); the mask differs from
- * snipper_linear_bf16's for the same seed.  ldx, ldw, ldy, lda % 8 == 0; X, W, Y, A 16-byte aligned.
+ * the gate activation [M][N]: gate(v) = A > 0 ? v * gate_scale : 0 (see snipper_linear_nn_bf16).  Dropout: every lane draws
+ * 16-bit uniforms from its own xorshift32 stream seeded by a hash of (seed, global thread id) (p is resolved to 2^-16): the
+ * mask is a deterministic function of (seed, shape, device CU count), not of the element index alone, and differs from the
+ * tile kernel's for the same seed.  ldx, ldw, ldy, lda % 8 == 0; X, W, Y, A 16-byte aligned.
  * snipper_linear_wres_supported: 1 when the shape is taken (snipper_linear_bf16 itself dispatches here when it is and
  * there is no residual), else 0 and the entry point returns SNIPPER_E_UNSUPPORTED. */
 int snipper_linear_wres_supported(int M, int N, int K);

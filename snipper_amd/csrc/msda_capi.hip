@@ -559,10 +559,7 @@ int snipper_linear_bf16(void *stream, const uint16_t *X, long long ldx, const ui
                         const float *bias, const uint16_t *R, long long ldr, uint16_t *Y, long long ldy,
                         int M, int N, int K, int relu, float dropout_p, uint64_t seed) {
   if (!X || !W || !Y) return SNIPPER_E_NULL;
-  // (with dropout the tile kernel stays: the hash is vector work in the store phase of a wave, which here runs beside its
-  //  SIMD partner's matrix phase and competes with it for the issue port -- 79 000 x 384 x 1024 with ReLU + dropout:
-  //  124 us weight-stationary against 119 us on tiles; without dropout 64 against 92)
-  if (!R && dropout_p == 0.f && wres_enabled() && snipper_linear_wres_supported(M, N, K) && ldx % 8 == 0 && ldy % 8 == 0 &&
+  if (!R && wres_enabled() && snipper_linear_wres_supported(M, N, K) && ldx % 8 == 0 && ldy % 8 == 0 &&
       !(((uintptr_t)X | (uintptr_t)W | (uintptr_t)Y) & 15))
     return snipper_linear_wres_bf16(stream, X, ldx, W, K, bias, nullptr, 0, 1.f, Y, ldy, M, N, K, relu, dropout_p, seed);
   if (M <= 0 || N <= 0 || K <= 0 || K % kGemmBK || N % 4 || ldx % 8 || ldy % 4 || ldx < K || ldy < N ||

@@ -197,6 +197,7 @@ __global__ __launch_bounds__(kWrThreads) __attribute__((amdgpu_waves_per_eu(2, 2
   const bool drop = g.drop_p > 0.f;
   const float keep_scale = drop ? 1.f / (1.f - g.drop_p) : 1.f;
   const uint32_t thresh16 = (uint32_t)fminf(g.drop_p * 65536.f + 0.5f, 65535.f);
+  uint32_t rng = gemm_rand((uint32_t)blockIdx.x * kWrThreads + (uint32_t)tid, g.seed_lo, g.seed_hi) | 1u;     // dropout stream of this lane
   const int frow = lane & 15, fk = lane >> 4;
   const unsigned stage_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)stage;
 
@@ -245,13 +246,17 @@ __global__ __launch_bounds__(kWrThreads) __attribute__((amdgpu_waves_per_eu(2, 2
         gemm_f32x4 v = acc[nt][mt];
         if (ACT && g.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
         if (ACT && drop) {
-          // one double hash per 4 consecutive elements (their index e is a multiple of 4) and a cheap second word: four
-          // 16-bit uniforms against p * 2^16 -- a quarter of the per-element hashes of csrc/gemm_bf16.cuh (here the
-          // store phase of a wave runs beside its partner's matrix phase, so its VALU count is what is left to pay)
-          const uint32_t e = (uint32_t)(m0 + 16 * mt + frow) * (uint32_t)g.N + (uint32_t)(n0 + nl);
-          const uint32_t h = gemm_rand(e >> 2, g.seed_lo, g.seed_hi);
-          uint32_t h2 = (h ^ (h >> 16)) * 0x9e3779b9u;
-          h2 ^= h2 >> 15;
+          // two xorshift32 steps of this lane's own stream (seeded from the double hash of (seed, global thread id)) give
+          // the four 16-bit uniforms of the quad, compared with p * 2^16.  Shifts and xors only: v_mul_lo_u32 runs at a
+          // quarter of the vector rate, and the per-element double hash of csrc/gemm_bf16.cuh (4 of them) made this epilogue
+          // -- which here runs beside the partner wave's matrix phase -- the longer half of every half-step (124 us for
+          // 79 000 x 384 x 1024 against 64 without dropout).  The mask is a function of (seed, launch geometry), not of the
+          // element index alone; the backward of dropout(relu(.)) reads it off the output (y > 0).
+          uint32_t h = rng;
+          h ^= h << 13; h ^= h >> 17; h ^= h << 5;
+          uint32_t h2 = h;
+          h2 ^= h2 << 13; h2 ^= h2 >> 17; h2 ^= h2 << 5;
+          rng = h2;
           v.x = (h & 0xffffu) >= thresh16 ? v.x * keep_scale : 0.f;
           v.y = (h >> 16) >= thresh16 ? v.y * keep_scale : 0.f;
           v.z = (h2 & 0xffffu) >= thresh16 ? v.z * keep_scale : 0.f;
