@@ -121,7 +121,9 @@ def test_conv3x3_bn_function_grads():
 
 
 @pytest.mark.parametrize("M,N,Kc", [(79000, 384, 384), (79000, 1024, 384), (79000, 384, 1024), (79000, 96, 384),
-                                    (60000, 192, 384), (1000, 8, 8), (63, 136, 72), (4097, 264, 128), (1, 128, 128)])
+                                    (60000, 192, 384), (1000, 8, 8), (63, 136, 72), (4097, 264, 128), (1, 128, 128),
+                                    # the LDS-DMA ring kernel (M >= 8192, <= 12 output tiles): ragged rows, partial tiles
+                                    (8209, 288, 384), (9001, 136, 200), (20000, 384, 8), (8192, 8, 384)])
 def test_wgrad_kernel(M, N, Kc):
     """Split-reduction weight/bias gradient against a float64 product of the same bf16 operands."""
     from snipper_amd.dense import wgrad_bf16
