@@ -196,6 +196,10 @@ bool make_patch_plan(const CoreDims &d, const int64_t *hs, const snipper_msda_co
   p.L = d.L;
   p.radius = cfg.near_radius;
   p.debug = cfg.reserved[0];
+#ifdef TILE2_STAMPS       // diagnostic builds only: SNIPPER_TILE2_STAMPS=<device address, hex> of a 256 x 128 x 8-byte buffer
+  static unsigned long long *const stamps = [] { const char *e = getenv("SNIPPER_TILE2_STAMPS"); return e ? (unsigned long long *)strtoull(e, nullptr, 16) : nullptr; }();
+  p.stamps = stamps;
+#endif
   int start = 0, tbase = 0, bbase = 0;
   for (int l = 0; l < d.L; ++l) {
     PatchLevel &v = p.lv[l];

@@ -77,6 +77,7 @@ struct PatchPlan {
   float radius;    // a sample is "near" when |pixel - anchor| <= radius on both axes
   int debug;       // timing ablations (config.reserved[0]; results are WRONG when != 0): 1 no row staging, 2 no gather /
                    // accumulate, 4 no decode, 8 skeleton only
+  unsigned long long *stamps;   // diagnostic builds (-DTILE2_STAMPS, tools/tile2_stamps.py): s_memtime stamps of sampled workgroups
 };
 
 struct PatchBlock { int n, m, lq, qy0, qx0, bh, bw; };
@@ -462,10 +463,14 @@ template <int HITCAP, bool GO_BF16> struct Tile2Lds {
   int2 tap[HITCAP * 16];              // sorted taps of the round: (byte offset of the hit's row in `rows`, weight bits)
   unsigned hits[kTile2HitList];       // queries with a mark in this tile, packed (level << 30 | qy << 15 | qx): the decode of a
                                       // sample needs the query's grid position, not only its index
-  int cntw[4][kTile2MaxPx];           // per wave and pixel: taps counted, then the wave's first position
+  __attribute__((aligned(16))) int cntw[4][kTile2MaxPx];           // per wave and pixel: taps counted, then the wave's first position
   int off[kTile2MaxPx + 1];           // exclusive prefix over pixels
   int wsum[4];
   int total_hits;
+#ifdef TILE2_STAMPS
+  unsigned long long st[128];         // (stamps are kept in LDS and copied out at the end: a global store per stamp made hipcc
+                                      //  drain the vector-memory counter at every stamp, i.e. undid the prefetches)
+#endif
 };
 
 
@@ -491,26 +496,54 @@ __device__ __forceinline__ void tile2_fma(float (&a6)[6], float w, const unsigne
   a6[3] = fmaf(w, v.a.w, a6[3]); a6[4] = fmaf(w, v.b.x, a6[4]); a6[5] = fmaf(w, v.b.y, a6[5]);
 }
 
-// (level, qy, qx) of a packed hit -> query index; the level's start / width by a select chain (a run-time index into the
-// kernel argument would put a copy of the plan in scratch memory)
-__device__ __forceinline__ int hit_query(const PatchPlan &p, unsigned hit, int &lq, int &qy, int &qx, int &Wq, int &Hq) {
+// The query levels' geometry and the size ratios of the tile's level over them, read from the kernel argument ONCE (uniform
+// scalar loads) and pinned in registers.  (Round 2 selected `plan.lv[i].start` etc. per hit: hipcc turned the chain of
+// selected loads into a load from a selected ADDRESS -- two dependent vector loads from the kernel-argument segment in front
+// of every gather of the loc / attn / grad_out rows of a hit; found in the ISA in round 3.)
+struct Tile2Levels {
+  int start[kPatchMaxLevels], W[kPatchMaxLevels];
+  float rw[kPatchMaxLevels], rh[kPatchMaxLevels];
+};
+__device__ __forceinline__ Tile2Levels tile2_levels(const PatchPlan &p, int l) {
+  Tile2Levels t;
+#pragma unroll
+  for (int i = 0; i < kPatchMaxLevels; ++i) {
+    t.start[i] = p.lv[i].start; t.W[i] = p.lv[i].W; t.rw[i] = p.rw[l][i]; t.rh[i] = p.rh[l][i];
+    asm volatile("" : "+s"(t.start[i]), "+s"(t.W[i]), "+s"(t.rw[i]), "+s"(t.rh[i]));
+  }
+  return t;
+}
+// (level, qy, qx) of a packed hit -> query index
+__device__ __forceinline__ int hit_query(const Tile2Levels &t, unsigned hit, int &lq, int &qy, int &qx) {
   lq = (int)(hit >> 30); qy = (int)((hit >> 15) & 0x7fffu); qx = (int)(hit & 0x7fffu);
-  int start = p.lv[0].start;
-  Wq = p.lv[0].W; Hq = p.lv[0].H;
+  int start = t.start[0], Wq = t.W[0];
 #pragma unroll
   for (int i = 1; i < kPatchMaxLevels; ++i) {
-    if (lq == i) { start = p.lv[i].start; Wq = p.lv[i].W; Hq = p.lv[i].H; }
+    start = lq == i ? t.start[i] : start;
+    Wq = lq == i ? t.W[i] : Wq;
   }
   return start + qy * Wq + qx;
 }
-// size ratios of the tile's level l (uniform) over the hit's query level lq (per lane): the same select chain
-__device__ __forceinline__ void hit_ratios(const PatchPlan &p, int l, int lq, float &rw, float &rh) {
-  rw = p.rw[l][0]; rh = p.rh[l][0];
+__device__ __forceinline__ int hit_query(const Tile2Levels &t, unsigned hit) {
+  int lq, qy, qx;
+  return hit_query(t, hit, lq, qy, qx);
+}
+// size ratios of the tile's level over the hit's query level lq (per lane)
+__device__ __forceinline__ void hit_ratios(const Tile2Levels &t, int lq, float &rw, float &rh) {
+  rw = t.rw[0]; rh = t.rh[0];
 #pragma unroll
   for (int i = 1; i < kPatchMaxLevels; ++i) {
-    if (lq == i) { rw = p.rw[l][i]; rh = p.rh[l][i]; }
+    rw = lq == i ? t.rw[i] : rw;
+    rh = lq == i ? t.rh[i] : rh;
   }
 }
+
+// phase stamps of every 61st workgroup (wave 0): 128 slots per sampled workgroup, slot id in the top byte
+#ifdef TILE2_STAMPS
+#define TILE2_STAMP(slot) do { if (stamp_buf && tid == 0 && stamp_n < 128) { S.st[stamp_n] = ((unsigned long long)(slot) << 56) | (__builtin_amdgcn_s_memtime() & 0x00ffffffffffffffull); ++stamp_n; } } while (0)
+#else
+#define TILE2_STAMP(slot) do { } while (0)
+#endif
 
 template <int HITCAP, bool GO_BF16>
 __global__ __launch_bounds__(kPatchThreads) __attribute__((amdgpu_waves_per_eu(3, 3))) void msda_bwd_d48_tile2_kernel(
@@ -530,6 +563,7 @@ __global__ __launch_bounds__(kPatchThreads) __attribute__((amdgpu_waves_per_eu(3
   int l = 0;
   for (int i = 1; i < plan.L; ++i) l = (tile_id >= plan.lv[i].tile_base) ? i : l;
   const PatchLevel me = plan.lv[l];
+  const Tile2Levels lv = tile2_levels(plan, l);
   const int t = tile_id - me.tile_base;
   const int edge = 1 << me.shift, tpx = edge * edge, tsh = 2 * me.shift;
   const int tyi = t / me.ntx, txi = t - tyi * me.ntx;
@@ -537,6 +571,11 @@ __global__ __launch_bounds__(kPatchThreads) __attribute__((amdgpu_waves_per_eu(3
   const int tid = threadIdx.x, wave = tid >> 6;
   const int LP = d.L * kPatchP;
   const size_t row_base = (size_t)n * d.Lq;
+#ifdef TILE2_STAMPS
+  unsigned long long *stamp_buf = (plan.stamps && blockIdx.x % 61 == 0 && blockIdx.x / 61 < 256) ? plan.stamps + (blockIdx.x / 61) * 128 : nullptr;
+  int stamp_n = 0;
+#endif
+  TILE2_STAMP(0);
 
   // ---- A. this thread's candidate block: its mark word ----
   unsigned long long mask = 0ull;
@@ -561,9 +600,13 @@ __global__ __launch_bounds__(kPatchThreads) __attribute__((amdgpu_waves_per_eu(3
   const int my_cnt = __popcll(mask);
   const int my_excl = block_incl_scan(my_cnt, S.wsum, tid) - my_cnt;
   if (tid == kPatchThreads - 1) S.total_hits = my_excl + my_cnt;
-  for (int i = tid; i < 4 * kTile2MaxPx; i += kPatchThreads) (&S.cntw[0][0])[i] = 0;
+  reinterpret_cast<u32x4 *>(&S.cntw[0][0])[tid] = u32x4{0u, 0u, 0u, 0u};       // 4 x 256 counters = 256 x 16 B
   lds_barrier();
   const int total_hits = (plan.debug & 8) ? 0 : S.total_hits;
+  TILE2_STAMP(1);
+#ifdef TILE2_STAMPS
+  if (stamp_buf && tid == 0) S.st[stamp_n++] = (200ull << 56) | (unsigned long long)total_hits;
+#endif
 
   // accumulators: 32 groups of 8 lanes own the tile's pixels
   const int grp = tid >> 3, j = tid & 7;
@@ -582,16 +625,24 @@ __global__ __launch_bounds__(kPatchThreads) __attribute__((amdgpu_waves_per_eu(3
   for (int pass0 = 0; pass0 < total_hits; pass0 += kTile2HitList) {
     const int pass1 = min(pass0 + kTile2HitList, total_hits), np = pass1 - pass0;
     // ---- expand the marks into the hit list (order: candidate, then bit -- fixed) ----
-    if (my_cnt && my_excl < pass1 && my_excl + my_cnt > pass0) {
-      unsigned long long mm = mask;
-      int gi = my_excl;
-      while (mm) {
-        const int i = __builtin_ctzll(mm);
-        mm &= mm - 1;
-        if (gi >= pass0 && gi < pass1)
-          S.hits[gi - pass0] = ((unsigned)c_lq << 30) | ((unsigned)(c_by * kPatchB + (i >> 3)) << 15) |
-                               (unsigned)(c_bx * kPatchB + (i & 7));
-        ++gi;
+    //      A wave takes its candidates with marks one after the other (a wave-uniform loop); lane i expands bit i = query
+    //      (i >> 3, i & 7) of the block: its place is the candidate's prefix + the set bits below i.  (Round 2 had every
+    //      thread walk its own word bit by bit: a serial loop of up to 64 trips in a few lanes, 13 % of a workgroup's life.)
+    {
+      unsigned long long todo = __ballot(my_cnt && my_excl < pass1 && my_excl + my_cnt > pass0);
+      const int lane = tid & 63;
+      while (todo) {
+        const int src = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        const unsigned mlo = __builtin_amdgcn_readlane((unsigned)mask, src);
+        const unsigned mhi = __builtin_amdgcn_readlane((unsigned)(mask >> 32), src);
+        const int ex = __builtin_amdgcn_readlane(my_excl, src);
+        const unsigned lqv = __builtin_amdgcn_readlane(c_lq, src);
+        const unsigned byv = __builtin_amdgcn_readlane(c_by, src), bxv = __builtin_amdgcn_readlane(c_bx, src);
+        const bool bit = (((lane < 32 ? mlo : mhi) >> (lane & 31)) & 1u) != 0u;
+        const int gi = ex + (int)__builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u));
+        if (bit && gi >= pass0 && gi < pass1)
+          S.hits[gi - pass0] = (lqv << 30) | ((byv * kPatchB + (unsigned)(lane >> 3)) << 15) | (bxv * kPatchB + (unsigned)(lane & 7));
       }
     }
     lds_barrier();
@@ -604,17 +655,18 @@ __global__ __launch_bounds__(kPatchThreads) __attribute__((amdgpu_waves_per_eu(3
         const int h = (tid + it * kPatchThreads) >> 2;
         n_xy[it] = make_float2(-4.f, -4.f); n_a[it] = 0.f;      // (a location outside every map: decodes to "not near")
         if (h < nh_ && !(plan.debug & 4)) {
-          int lq_, qy_, qx_, wq_, hq_;
-          const size_t so = (size_t)hit_query(plan, S.hits[lo_ + h], lq_, qy_, qx_, wq_, hq_) * s_stride;
+          const size_t so = (size_t)hit_query(lv, S.hits[lo_ + h]) * s_stride;
           n_xy[it] = *reinterpret_cast<const float2 *>(loc_nm + 2 * so);
           n_a[it] = attn_nm[so];
         }
       }
     };
     fetch(0, min(HITCAP, np));
+    TILE2_STAMP(2);
 
     for (int lo = 0; lo < np; lo += HITCAP) {
       const int nh = min(HITCAP, np - lo);
+      TILE2_STAMP(3);
       // ---- the hits' grad_out rows -> LDS: float32 rows by LDS-DMA, bfloat16 rows through registers (issued here,
       //      widened and written behind decode / prefix / scatter) ----
       constexpr int kPieces = HITCAP * 6 / kPatchThreads;       // bf16: 16-B pieces (8 channels) per thread and round
@@ -625,9 +677,7 @@ __global__ __launch_bounds__(kPatchThreads) __attribute__((amdgpu_waves_per_eu(3
           const int g = tid + i * kPatchThreads, h = g / 6, piece = g - h * 6;
           pc[i] = u32x4{0u, 0u, 0u, 0u};
           if (h < nh && !(plan.debug & 1)) {
-            int lq_, qy_, qx_, wq_, hq_;
-            pc[i] = *reinterpret_cast<const u32x4 *>(go_nm + (size_t)hit_query(plan, S.hits[lo + h], lq_, qy_, qx_, wq_, hq_) *
-                                                     q_stride + piece * 16);
+            pc[i] = *reinterpret_cast<const u32x4 *>(go_nm + (size_t)hit_query(lv, S.hits[lo + h]) * q_stride + piece * 16);
           }
         }
       } else if (!(plan.debug & 1)) {
@@ -637,9 +687,7 @@ __global__ __launch_bounds__(kPatchThreads) __attribute__((amdgpu_waves_per_eu(3
           const int g = g0 + tid;
           if (g < G) {
             const int h = g / gpr, piece = g - h * gpr;
-            int lq_, qy_, qx_, wq_, hq_;
-            const unsigned char *src = go_nm + (size_t)hit_query(plan, S.hits[lo + h], lq_, qy_, qx_, wq_, hq_) * q_stride +
-                                       piece * 16;
+            const unsigned char *src = go_nm + (size_t)hit_query(lv, S.hits[lo + h]) * q_stride + piece * 16;
             unsigned char *dst = S.rows + (size_t)(g - (tid & 63)) * 16;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                              (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
@@ -647,6 +695,7 @@ __global__ __launch_bounds__(kPatchThreads) __attribute__((amdgpu_waves_per_eu(3
         }
       }
       // ---- decode: item = (hit h, point p); rank every tap of this tile within its (wave, pixel) ----
+      TILE2_STAMP(4);
       unsigned t_pix[kItems], t_ok[kItems];   // 4 x 8 bits: pixel of each tap; bit k: tap k is in this tile
       unsigned t_rank[kItems][2];             // 4 x 16 bits
       float t_w[kItems][4];
@@ -659,10 +708,10 @@ __global__ __launch_bounds__(kPatchThreads) __attribute__((amdgpu_waves_per_eu(3
         const float x = px_coord(n_xy[it].x, me.W), y = px_coord(n_xy[it].y, me.H);
         const bool inside = h < nh && (y > -1.f) && (x > -1.f) && (y < (float)me.H) && (x < (float)me.W);
         if (inside) {
-          int lq, qy, qx, Wq, Hq;
-          hit_query(plan, S.hits[lo + h], lq, qy, qx, Wq, Hq);
+          int lq, qy, qx;
+          hit_query(lv, S.hits[lo + h], lq, qy, qx);
           float rwq, rhq;
-          hit_ratios(plan, l, lq, rwq, rhq);
+          hit_ratios(lv, lq, rwq, rhq);
           if (near_anchor(x, y, anchor_from_ratio(qx, rwq), anchor_from_ratio(qy, rhq), plan.radius)) {
             const float a = n_a[it];
             const float yf = floorf(y), xf = floorf(x);
@@ -686,7 +735,9 @@ __global__ __launch_bounds__(kPatchThreads) __attribute__((amdgpu_waves_per_eu(3
           }
         }
       }
+      TILE2_STAMP(5);
       lds_barrier();     // ranks complete
+      TILE2_STAMP(6);
       // ---- exclusive prefix over pixels; per wave the position of its first tap of every pixel ----
       {
         int c[4] = {0, 0, 0, 0};
@@ -705,6 +756,7 @@ __global__ __launch_bounds__(kPatchThreads) __attribute__((amdgpu_waves_per_eu(3
         if (tid == kPatchThreads - 1) S.off[tpx] = incl;      // (threads >= tpx carry the total)
       }
       lds_barrier();
+      TILE2_STAMP(7);
       // ---- scatter the taps into pixel order ----
 #pragma unroll
       for (int it = 0; it < kItems; ++it) {
@@ -718,6 +770,7 @@ __global__ __launch_bounds__(kPatchThreads) __attribute__((amdgpu_waves_per_eu(3
           }
         }
       }
+      TILE2_STAMP(8);
       if constexpr (GO_BF16) {
 #pragma unroll
         for (int i = 0; i < kPieces; ++i) {
@@ -735,10 +788,13 @@ __global__ __launch_bounds__(kPatchThreads) __attribute__((amdgpu_waves_per_eu(3
       } else {
         vm_drain();      // this wave's share of the rows has landed
       }
+      TILE2_STAMP(9);
       lds_barrier();     // taps sorted, every wave's rows in LDS
+      TILE2_STAMP(10);
       // the next round's samples: in flight while this round accumulates
       if (lo + HITCAP < np) fetch(lo + HITCAP, min(HITCAP, np - lo - HITCAP));
-      for (int i = tid; i < 4 * tpx; i += kPatchThreads) S.cntw[i / tpx][i - (i / tpx) * tpx] = 0;   // for the next round
+      reinterpret_cast<u32x4 *>(&S.cntw[0][0])[tid] = u32x4{0u, 0u, 0u, 0u};                          // for the next round
+      TILE2_STAMP(11);
       // ---- accumulate: every pixel by one group (tiles of < 32 pixels: 32 / tpx groups share a pixel's taps) ----
       if (!(plan.debug & 2)) {       // pixels one after the other, 4 taps per trip
         auto run = [&](float (&a6)[6], int b0, int e0) {
@@ -764,9 +820,12 @@ __global__ __launch_bounds__(kPatchThreads) __attribute__((amdgpu_waves_per_eu(3
           run(acc[0], pb + (nt * s) / gpp, pb + (nt * (s + 1)) / gpp);
         }
       }
+      TILE2_STAMP(12);
       lds_barrier();     // before the next round overwrites rows / taps
+      TILE2_STAMP(13);
     }
   }
+  TILE2_STAMP(14);
 
   // ---- tiles of fewer than 32 pixels: add the groups' partial sums in a fixed order ----
   if (tpx < 32) {
@@ -805,6 +864,11 @@ __global__ __launch_bounds__(kPatchThreads) __attribute__((amdgpu_waves_per_eu(3
       }
     }
   }
+  TILE2_STAMP(15);
+#ifdef TILE2_STAMPS
+  if (stamp_buf && tid == 0)
+    for (int i = 0; i < stamp_n; ++i) stamp_buf[i] = S.st[i];
+#endif
 }
 
 }  // namespace snipper
