@@ -7,6 +7,8 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $out -- python3 $GRAFT_REPO_ROOT/bench.py --steps 12 --warmup 8 --no-extras --no-cpu-baseline "$@" > $out.log 2>&1
 f=$(ls $out/*/*kernel_stats.csv | head -1)
 cp $f $GRAFT_REPO_ROOT/gpurun_out/kstats_$tag.csv
+t=$(ls $out/*/*kernel_trace.csv | head -1)
+python3 $GRAFT_REPO_ROOT/tools/step_sequence.py $t > $GRAFT_REPO_ROOT/gpurun_out/kseq_$tag.txt 2>&1
 python3 - "$f" <<'PY'
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
