@@ -746,6 +746,15 @@ WgradPlan wgrad_plan(int M, int N, int Kc) {
   const int tiles = p.tiles_n * p.tiles_k;
   int s0 = std::max(1, wgs / tiles);
   if (s0 >= 8) s0 = (s0 + 7) / 8 * 8;
+  // the register-prefetch kernel runs three workgroups per CU: a grid between 2 and 3 per CU (24 tiles x 24 ranges = 576)
+  // leaves a quarter of the CUs with a third workgroup and the rest waiting for them; 3 per CU is balanced
+  // (79 000 x 1024 x 384: 112 -> 102 us, x 384 x 1024: 105 -> 93 us; tools/wgradbench.py with SNIPPER_WGRAD_S)
+  if (tiles > 12 && tiles * s0 > wgs && tiles * s0 < wgs * 3 / 2) {
+    const int s3 = (wgs * 3 / 2 / tiles) / 8 * 8;
+    if (s3 > s0) s0 = s3;
+  }
+  static const int s_env = [] { const char *e = getenv("SNIPPER_WGRAD_S"); return e ? atoi(e) : 0; }();   // (measurement aid)
+  if (s_env > 0) s0 = s_env;
   s0 = std::min(s0, std::max(1, M / kWgRows));
   p.rows = (M + s0 - 1) / s0;
   p.S = (M + p.rows - 1) / p.rows;

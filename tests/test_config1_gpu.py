@@ -101,7 +101,7 @@ def test_config1_bf16_autocast_path_runs_the_tied_sampler_with_one_frame():
     rel = lambda a, b: float((a.detach().float() - b.detach().float()).norm() / b.detach().float().norm().clamp_min(1e-20))
     errs = {k: rel(oa[k], of[k]) for k in ("pred_logits", "pred_kpts2d", "pred_depth")}
     gerrs = {n: rel(a, b) for n, a, b in zip(GRAD_NAMES, ga, gf)}
-    print("[config1 bf16 vs fp32] outputs", {k: f"{v:.3e}" for k, v in errs.items()}, "grads", {k.split(".")[-3] + "." + k.split(".")[-1]: f"{v:.3e}" for k, v in gerrs.items()})
+    print("[config1 bf16 vs fp32] outputs", {k: f"{v:.3e}" for k, v in errs.items()}, "grads", {".".join(k.split(".")[-3:]): f"{v:.3e}" for k, v in gerrs.items()})
     # measured: outputs 3.0-4.5e-2 (bf16 backbone 0.9 % -> encoder 1.4 % -> four decoder layers); the shadow bug that this
     # test found (merged offset bias lost under autocast) gave 0.39-0.55
     for k, v in errs.items():
