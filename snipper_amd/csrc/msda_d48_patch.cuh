@@ -238,8 +238,13 @@ __global__ __launch_bounds__(kPatchThreads) void msda_bwd_d48_patchbin_kernel(
   using DOT = PatchDot<VT, GO_BF16>;
   constexpr unsigned kRowV = DOT::kRowV;                 // bytes of one head row of `value`
   constexpr int kRows = kPatchB * kPatchB;
+#ifdef TILE2_STAMPS
+  constexpr int kStampBytes = 64 * 8;
+#else
+  constexpr int kStampBytes = 0;
+#endif
   __shared__ __attribute__((aligned(16))) unsigned char smem[kPatchThreads * sizeof(PatchRec) + 2 * kPatchMaxTiles * 16 +
-                                                           kRows * kPatchRowBytes];
+                                                           kRows * kPatchRowBytes + kStampBytes];
   PatchRec *recs = reinterpret_cast<PatchRec *>(smem);
   unsigned long long *s_mask = reinterpret_cast<unsigned long long *>(recs + kPatchThreads);   // [2][kPatchMaxTiles]
   long long *s_slot = reinterpret_cast<long long *>(s_mask + 2 * kPatchMaxTiles);              // [2][kPatchMaxTiles]
@@ -247,6 +252,16 @@ __global__ __launch_bounds__(kPatchThreads) void msda_bwd_d48_patchbin_kernel(
   PatchBlock b;
   if (!patch_block(plan, d, nblk_padded, b)) return;
   const int tid = threadIdx.x;
+#ifdef TILE2_STAMPS
+  // (tools/tile2_stamps.py: the second half of the stamp buffer, wave 0 of every 97th workgroup)
+  unsigned long long *pst = reinterpret_cast<unsigned long long *>(s_g + kRows * kD48);
+  unsigned long long *pst_out = (plan.stamps && blockIdx.x % 97 == 0 && blockIdx.x / 97 < 256) ? plan.stamps + 256 * 128 + (blockIdx.x / 97) * 64 : nullptr;
+  int pst_n = 0;
+#define PATCH_STAMP(slot) do { if (pst_out && tid == 0 && pst_n < 64) { pst[pst_n] = ((unsigned long long)(slot) << 56) | (__builtin_amdgcn_s_memtime() & 0x00ffffffffffffffull); ++pst_n; } } while (0)
+#else
+#define PATCH_STAMP(slot) do { } while (0)
+#endif
+  PATCH_STAMP(0);
   const PatchLevel lvq = plan.lv[b.lq];
   const int LP = d.L * kPatchP;
   const int rd = tid >> 2, pd = tid & 3;
@@ -340,7 +355,9 @@ __global__ __launch_bounds__(kPatchThreads) void msda_bwd_d48_patchbin_kernel(
       a_l[l] = attn[li];
     }
   }
+  PATCH_STAMP(1);
   __syncthreads();
+  PATCH_STAMP(2);
 
 #pragma unroll
   for (int l = 0; l < kPatchMaxLevels; ++l) {
@@ -384,10 +401,13 @@ __global__ __launch_bounds__(kPatchThreads) void msda_bwd_d48_patchbin_kernel(
       r.g.x = go[0]; r.g.y = go[1]; r.g.z = go[2]; r.g.w = go[3];
       recs[tid] = r;
     }
+    PATCH_STAMP(3);
     const int any_need = __syncthreads_or((int)my_bits);     // records and masks complete; does ANY tap need an atomic?
+    PATCH_STAMP(4);
 
     if (tid < kPatchMaxTiles && slot_l[tid] >= 0 && mask_l[tid] != 0ull) plan.marks[slot_l[tid]] = mask_l[tid];
     if (l + 1 < plan.L) fill_slots(l + 1);
+    PATCH_STAMP(5);
 
     if (!(plan.debug & 2))
 #pragma unroll
@@ -418,6 +438,7 @@ __global__ __launch_bounds__(kPatchThreads) void msda_bwd_d48_patchbin_kernel(
         *reinterpret_cast<float2 *>(grad_loc + 2 * li) = make_float2(keep_x, keep_y);
       }
     }
+    PATCH_STAMP(6);
     // taps no tile owns (sample not near its anchor, or beyond the marks' capacity): the HBM float atomic of
     // msda_d48.cuh.  Re-dealt to 16 lanes per row, lane i adding channels {i, i+16, i+32}: every atomic instruction then
     // adds 64 contiguous bytes per row (the shape the memory-side atomic units take at full rate).
@@ -447,8 +468,15 @@ __global__ __launch_bounds__(kPatchThreads) void msda_bwd_d48_patchbin_kernel(
         }
       }
     }
+    PATCH_STAMP(7);
     __syncthreads();     // before the records and the other half of the slots are overwritten
+    PATCH_STAMP(8);
   }
+#ifdef TILE2_STAMPS
+  if (pst_out && tid == 0)
+    for (int i = 0; i < pst_n; ++i) pst_out[i] = pst[i];
+#endif
+#undef PATCH_STAMP
 }
 
 // ------------------------------------------------------------------------------------------------------------------

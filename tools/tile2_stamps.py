@@ -9,7 +9,7 @@ Thread 0 of every 61st workgroup records s_memtime at the phase boundaries (up t
 workgroups, the median / mean cycles of every segment and its share of the workgroup's life time."""
 import os, sys, statistics, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-buf = torch.zeros(256 * 128, dtype=torch.int64, device="cuda:0")
+buf = torch.zeros(256 * 128 + 256 * 64, dtype=torch.int64, device="cuda:0")     # tile kernel, then query-side kernel
 os.environ["SNIPPER_TILE2_STAMPS"] = hex(buf.data_ptr())
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import opbench
@@ -24,7 +24,9 @@ torch.cuda.synchronize()
 buf.zero_()
 run()
 torch.cuda.synchronize()
-v = buf.cpu().view(256, 128).tolist()
+allv = buf.cpu()
+v = allv[:256 * 128].view(256, 128).tolist()
+pv = allv[256 * 128:].view(256, 64).tolist()
 names = {0: "start", 1: "marks+scan done", 2: "hits expanded, first fetch issued", 3: "round start", 4: "row loads issued",
          5: "decode+rank done", 6: "barrier (ranks)", 7: "prefix done", 8: "scatter done", 9: "rows written",
          10: "barrier (sorted)", 11: "next fetch issued + counters zeroed", 12: "accumulate done", 13: "barrier (round end)",
@@ -50,3 +52,24 @@ for k, ds in sorted(seg.items(), key=lambda kv: -sum(kv[1])):
     share = sum(ds) / len(life) / tot
     print(f"  {names.get(k[0], k[0])!s:38s} -> {names.get(k[1], k[1])!s:38s}: per-workgroup total median {statistics.median(ds):8.0f}  mean {statistics.mean(ds):8.0f}  "
           f"share {100 * share:5.1f} %  (n {len(ds)})")
+
+# ---- the query-side kernel (msda_bwd_d48_patchbin_kernel): wave 0 of every 97th workgroup
+pnames = {0: "start", 1: "rows + first loads issued", 2: "barrier", 3: "level: decode + marks done", 4: "level: barrier (records)",
+          5: "level: marks stored, next slots", 6: "level: gather + dots + stores done", 7: "level: far atomics done", 8: "level: barrier (end)"}
+seg, life = {}, []
+for wg in pv:
+    st = [((x >> 56) & 0xff, x & ((1 << 56) - 1)) for x in wg if x]
+    if len(st) < 4 or st[0][0] != 0:
+        continue
+    life.append(st[-1][1] - st[0][1])
+    acc = {}
+    for (a, ta), (b, tb) in zip(st[:-1], st[1:]):
+        acc[(a, b)] = acc.get((a, b), 0) + (tb - ta)
+    for k, d in acc.items():
+        seg.setdefault(k, []).append(d)
+if life:
+    tot = statistics.mean(life)
+    print(f"query-side kernel: {len(life)} sampled workgroups, life time median {statistics.median(life):.0f} mean {tot:.0f} cycles")
+    for k, ds in sorted(seg.items(), key=lambda kv: -sum(kv[1])):
+        print(f"  {pnames.get(k[0], k[0])!s:38s} -> {pnames.get(k[1], k[1])!s:38s}: per-workgroup total median {statistics.median(ds):8.0f}  mean {statistics.mean(ds):8.0f}  "
+              f"share {100 * sum(ds) / len(life) / tot:5.1f} %  (n {len(ds)})")
