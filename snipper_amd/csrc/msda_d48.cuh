@@ -210,7 +210,7 @@ __device__ __forceinline__ float row16_sum(float v) {
   return v;
 }
 
-// ---- shared geometry of the owner-computes backward (msda_d48_owner.cuh) -----------------------
+// ---- shared geometry of the owner-computes backward (msda_d48_patch.cuh) -----------------------
 // Both kernels of that path must classify a sample as near/far identically, so the arithmetic is
 // pinned with explicit intrinsics (no compiler-chosen fma contraction).
 __device__ __forceinline__ float px_coord(float l, int size) { return __fmaf_rn(l, (float)size, -0.5f); }
