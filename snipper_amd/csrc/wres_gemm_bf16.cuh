@@ -235,7 +235,6 @@ __global__ __launch_bounds__(kWrThreads) __attribute__((amdgpu_waves_per_eu(2, 2
   // the next barrier covers them.
   auto epilogue = [&](int it) {
     if (g.debug & 16) return;
-    const int m0 = chunk_of(it) * kWrRows;
     const unsigned base = stage_lds + (unsigned)((it & 1) * kWrStageB);
 #pragma unroll
     for (int nt = 0; nt < 3; ++nt) {
