@@ -468,8 +468,12 @@ int device_cu_count() {
   return n;
 }
 // SNIPPER_GEMM_WRES=0 in the environment at load time keeps every product on the tile kernels (A/B measurements)
-int wres_debug() {       // SNIPPER_WRES_DEBUG: timing ablations of the weight-stationary kernel (wrong results), read once
-  static const int v = [] { const char *e = getenv("SNIPPER_WRES_DEBUG"); return e ? atoi(e) : 0; }();
+int wres_debug() {       // SNIPPER_WRES_DEBUG: timing ablations of the weight-stationary / ring kernels (WRONG results), read once;
+                         // like the owner-computes ablations they need SNIPPER_MSDA_ALLOW_DEBUG=1 in the same environment
+  static const int v = [] {
+    const char *e = getenv("SNIPPER_WRES_DEBUG"), *a = getenv("SNIPPER_MSDA_ALLOW_DEBUG");
+    return (e && a && a[0] == '1') ? atoi(e) : 0;
+  }();
   return v;
 }
 // diagnostic builds only (-DWRES_STAMPS): SNIPPER_WRES_STAMPS=<device address, hex> of a 2 x 320 x 8-byte buffer that workgroup 0

@@ -8,7 +8,7 @@ R=$GRAFT_REPO_ROOT
 SHAPES=${SHAPES:-"79000x384x384 79000x1024x384"}
 for dbg in ${DBGS:-0 1 2 8 10}; do
   out=$R/gpurun_out/wgrad_dbg$dbg
-  SNIPPER_WRES_DEBUG=$dbg rocprofv3 --kernel-trace --output-format csv -d $out -- python3 $R/tools/wgradprof.py $SHAPES > $out.log 2>&1
+  SNIPPER_MSDA_ALLOW_DEBUG=1 SNIPPER_WRES_DEBUG=$dbg rocprofv3 --kernel-trace --output-format csv -d $out -- python3 $R/tools/wgradprof.py $SHAPES > $out.log 2>&1
   python3 - "$out" "$dbg" <<'PY'
 import csv, glob, sys
 f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]

@@ -6,7 +6,7 @@ R=$GRAFT_REPO_ROOT
 SHAPES=${SHAPES:-"79000x384x384 8192x384x384 158000x384x384"}
 for dbg in ${DBGS:-0 1 2 4 8 15 6}; do
   out=$R/gpurun_out/wres_dbg$dbg
-  SNIPPER_WRES_DEBUG=$dbg rocprofv3 --kernel-trace --output-format csv -d $out -- python3 $R/tools/wresprof.py $SHAPES > $out.log 2>&1
+  SNIPPER_MSDA_ALLOW_DEBUG=1 SNIPPER_WRES_DEBUG=$dbg rocprofv3 --kernel-trace --output-format csv -d $out -- python3 $R/tools/wresprof.py $SHAPES > $out.log 2>&1
   python3 - "$out" "$dbg" <<'PY'
 import csv, glob, sys
 f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
