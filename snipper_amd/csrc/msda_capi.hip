@@ -786,7 +786,8 @@ int snipper_wgrad_bf16(void *stream, const uint16_t *G, long long ldg, const uin
   static const bool ring_on = [] { const char *e = getenv("SNIPPER_WGRAD_RING"); return !(e && e[0] == '0'); }();
   // long reductions onto few output tiles: the LDS-DMA ring kernel (csrc/wgrad_ring_bf16.cuh).  Measured (kernel only, us,
   // ring / register prefetch): 79 000 x 384 x 384 34.9 / 38.9, x 288 x 384 the same; 79 000 x 1024 x 384 (24 tiles) 115 / 103
-  if (ring_on && M >= 8192 && p.rows >= 4 * kWrgRows && p.tiles_n * p.tiles_k <= 12) {
+  static const int ring_tiles = [] { const char *e = getenv("SNIPPER_WGRAD_RING_TILES"); return e ? atoi(e) : 12; }();   // (measurement aid)
+  if (ring_on && M >= 8192 && p.rows >= 4 * kWrgRows && p.tiles_n * p.tiles_k <= ring_tiles) {
     const WgradRingArgs a{G, ldg, X, ldx, P, Pb, M, N, Kc, p.S, p.rows, p.tiles_n, p.tiles_k, wres_debug()};
     hipLaunchKernelGGL(wgrad_ring_kernel, dim3(p.tiles_n * p.tiles_k * p.S), dim3(kWrgThreads), 0, (hipStream_t)stream, a);
   } else {
