@@ -494,6 +494,10 @@ def main():
     ap.add_argument("--flat-params", type=int, default=1,
                     help="1 = one flat tensor per optimizer group (snipper_amd/flat_params.py): the same AdamW + clipping on "
                          "3 tensors instead of ~330; 0 = per-parameter form")
+    ap.add_argument("--optimizer", choices=["flat-kernel", "torch"], default="flat-kernel",
+                    help="with --flat-params 1: flat-kernel = clipping + AdamW as two launches of csrc/adamw_flat.cuh "
+                         "(snipper_amd.flat_params.FlatAdamW, the arithmetic of torch.optim.AdamW); torch = clip_grad_norm_ + "
+                         "torch.optim.AdamW (fused) on the three flat leaves")
     ap.add_argument("--pin-cores", type=int, default=8,
                     help="keep this process on a block of N neighbouring CPUs (block index = local rank); 0 = leave the "
                          "affinity alone")
@@ -566,7 +570,7 @@ def main():
             mp.grad = torch.zeros_like(mp)
         masters = ([mp for _, mp in master_named], [p for _, p in named])
         opt = build_optimizer(master_named, capturable=bool(a.graph))
-    net, gsync, flatp = model, None, None
+    net, gsync, flatp, own_opt = model, None, None, None
     use_flat = bool(a.flat_params) and masters is None and not a.graph and not (use_ddp and a.ddp == "torch")
     if use_ddp and a.ddp == "torch":
         net = torch.nn.parallel.DistributedDataParallel(
@@ -589,6 +593,10 @@ def main():
                 assert [id(p) for p in gsync.params] == [id(p) for p in g_main + g_slow + g_backbone]
             flatp = FlatParameters([g_main, g_slow, g_backbone], grad_flat=gsync.flat if gsync is not None else None)
         opt = build_optimizer(list(model.named_parameters()), capturable=bool(a.graph), flat=flatp)
+        if flatp is not None and a.optimizer == "flat-kernel" and not a.graph and not os.environ.get("SNIPPER_OPT_PLAIN"):
+            from snipper_amd.flat_params import FlatAdamW
+            # groups in FlatParameters' order (main, slow, backbone): the reference's learning rates (main.py:201-221)
+            own_opt = FlatAdamW(flatp, [1e-4, 1e-5, 1e-5], weight_decay=1e-4)
     batches = make_batches(a, device, 2, seed=1000 + rank)
 
     criterion = None
@@ -634,15 +642,20 @@ def main():
             t = mark("backward", t)
             if gsync is not None:
                 gsync.sync()
-            if flatp is not None:
+            if own_opt is not None:
                 flatp.pack()                 # (after sync() the gradients already live in the shared flat buffer)
-                torch.nn.utils.clip_grad_norm_(flatp.leaves, 0.1)
+                t = mark("clip", t)
+                own_opt.step(0.1)            # global-norm clipping (engine.py:74) + AdamW in two launches; bumps the versions
             else:
-                torch.nn.utils.clip_grad_norm_(clip_params, 0.1)
-            t = mark("clip", t)
-            opt.step()
-            if flatp is not None:
-                flatp.after_step()
+                if flatp is not None:
+                    flatp.pack()
+                    torch.nn.utils.clip_grad_norm_(flatp.leaves, 0.1)
+                else:
+                    torch.nn.utils.clip_grad_norm_(clip_params, 0.1)
+                t = mark("clip", t)
+                opt.step()
+                if flatp is not None:
+                    flatp.after_step()
             t = mark("optimizer", t)
         else:
             mp, pp = masters
@@ -922,7 +935,10 @@ def main():
                                    "fp32 parameters" + (" under bf16 autocast" if amp else "")),
                        "host": (f"gc.collect every {a.gc_every} steps, automatic collector off" if a.gc_every else "default gc") +
                                (f"; process pinned to {a.pin_cores} neighbouring CPUs" if a.pin_cores else ""),
-                       "optimizer": ("torch.optim.AdamW (fused) + clip_grad_norm_ on one flat tensor per group "
+                       "optimizer": ("global-norm clipping + AdamW on the flat parameter buffer in two launches "
+                                     "(snipper_amd.flat_params.FlatAdamW, csrc/adamw_flat.cuh: the arithmetic of "
+                                     "torch.optim.AdamW + clip_grad_norm_)" if own_opt is not None else
+                                     "torch.optim.AdamW (fused) + clip_grad_norm_ on one flat tensor per group "
                                      "(snipper_amd/flat_params.py)" if flatp is not None else
                                      "torch.optim.AdamW (fused) + clip_grad_norm_ per parameter")},
             "final_loss": round(loss_val, 5),

@@ -334,6 +334,25 @@ int snipper_refine_reference_f32(void *stream, const float *delta, long long ld_
  * (SciPy's order).  Float64 arithmetic inside. */
 int snipper_lsap_f32(void *stream, const float *cost, int P, int n, int m, long long *out_src, long long *out_tgt);
 
+/* ---- gradient clipping + AdamW on one flat float32 buffer (csrc/adamw_flat.cuh) -------------------------------
+ * Replaces `torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm)` (engine.py:74) + `torch.optim.AdamW.step()` over the
+ * reference's parameter groups (main.py:201-221) when parameters, gradients and both moments live in flat buffers of n
+ * elements (n % 4 == 0, 16-byte aligned; snipper_amd/flat_params.py).  Two launches, deterministic:
+ *   snipper_gradnorm_partials_f32   partials[nparts] (nparts <= 4096) = per-workgroup sums of grad^2
+ *   snipper_adamw_clip_f32          coef = min(1, max_norm / (sqrt(sum partials) + 1e-6)) (max_norm <= 0 or partials == NULL:
+ *                                   no clipping), then per element of every group k (elements [seg_begin[k], seg_end[k]),
+ *                                   multiples of 4, lr / weight decay seg_lr[k] / seg_wd[k]; HOST arrays, nseg <= 8):
+ *                                   p *= 1 - lr wd;  m += (coef g - m)(1 - beta1);  v = beta2 v + (1 - beta2)(coef g)^2;
+ *                                   p -= lr / (1 - beta1^step) * m / (sqrt(v) / sqrt(1 - beta2^step) + eps)
+ *                                   (torch.optim.AdamW, amsgrad = False, maximize = False; step counts from 1).  Elements
+ *                                   outside every group are left alone; the gradient is not modified; norm_out (device, or
+ *                                   NULL) receives the unclipped global norm. */
+int snipper_gradnorm_partials_f32(void *stream, const float *grad, long long n, float *partials, int nparts);
+int snipper_adamw_clip_f32(void *stream, float *param, const float *grad, float *exp_avg, float *exp_avg_sq, long long n,
+                           const long long *seg_begin, const long long *seg_end, const float *seg_lr, const float *seg_wd, int nseg,
+                           float beta1, float beta2, float eps, long long step, const float *partials, int nparts,
+                           float max_norm, float *norm_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -83,6 +83,10 @@ EXPORTS = {
                                   ctypes.c_float, c_void_p, c_longlong, c_int, c_int, c_int, c_int, ctypes.c_float,
                                   ctypes.c_uint64], c_int),
     "snipper_hbm_copy_probe": ([c_void_p, c_void_p, c_void_p, c_longlong], c_int),
+    "snipper_gradnorm_partials_f32": ([c_void_p, c_void_p, c_longlong, c_void_p, c_int], c_int),
+    "snipper_adamw_clip_f32": ([c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_void_p, c_void_p, c_void_p,
+                                c_void_p, c_int, ctypes.c_float, ctypes.c_float, ctypes.c_float, c_longlong, c_void_p, c_int,
+                                ctypes.c_float, c_void_p], c_int),
     "snipper_transpose_batch_bf16": ([c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p], c_int),
     "snipper_linear_nn_bf16": ([c_void_p, c_void_p, c_longlong, c_void_p, c_longlong, c_void_p, c_longlong, c_void_p,
                                 c_longlong, ctypes.c_float, c_void_p, c_longlong, c_int, c_int, c_int], c_int),

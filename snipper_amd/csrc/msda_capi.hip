@@ -26,6 +26,7 @@
 #include "heatmap_blur.cuh"
 #include "msda_prologue.cuh"
 #include "lsap.cuh"
+#include "adamw_flat.cuh"
 #include "msda_d48.cuh"
 #include "msda_d48_patch.cuh"
 #include "msda_generic.cuh"
@@ -523,6 +524,39 @@ int snipper_linear_wres_bf16(void *stream, const uint16_t *X, long long ldx, con
     else { if (act) WRES_LAUNCH(9, false, true); else WRES_LAUNCH(9, false, false); }
   }
 #undef WRES_LAUNCH
+  return launch_status();
+}
+
+// ---- gradient clipping + AdamW on a flat buffer (csrc/adamw_flat.cuh) ----
+int snipper_gradnorm_partials_f32(void *stream, const float *grad, long long n, float *partials, int nparts) {
+  if (!grad || !partials) return SNIPPER_E_NULL;
+  if (n <= 0 || n % 4 || nparts <= 0 || nparts > kAdamMaxParts || ((uintptr_t)grad & 15)) return SNIPPER_E_SHAPE;
+  hipLaunchKernelGGL(gradnorm_partials_kernel, dim3((unsigned)nparts), dim3(kAdamThreads), 0, (hipStream_t)stream, grad, n / 4, partials);
+  return launch_status();
+}
+
+int snipper_adamw_clip_f32(void *stream, float *param, const float *grad, float *exp_avg, float *exp_avg_sq, long long n,
+                           const long long *seg_begin, const long long *seg_end, const float *seg_lr, const float *seg_wd, int nseg,
+                           float beta1, float beta2, float eps, long long step, const float *partials, int nparts,
+                           float max_norm, float *norm_out) {
+  if (!param || !grad || !exp_avg || !exp_avg_sq || !seg_begin || !seg_end || !seg_lr || !seg_wd) return SNIPPER_E_NULL;
+  if (n <= 0 || n % 4 || nseg <= 0 || nseg > kAdamMaxSeg || step <= 0 || !(beta1 >= 0.f && beta1 < 1.f) || !(beta2 >= 0.f && beta2 < 1.f) ||
+      !(eps > 0.f) || (partials && (nparts <= 0 || nparts > kAdamMaxParts)))
+    return SNIPPER_E_SHAPE;
+  if (((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) return SNIPPER_E_SHAPE;
+  AdamArgs a{};
+  a.p = param; a.g = grad; a.m = exp_avg; a.v = exp_avg_sq; a.n = n; a.nseg = nseg;
+  for (int k = 0; k < nseg; ++k) {
+    if (seg_begin[k] < 0 || seg_end[k] > n || seg_begin[k] > seg_end[k] || seg_begin[k] % 4 || seg_end[k] % 4) return SNIPPER_E_SHAPE;
+    a.seg[k] = AdamSeg{seg_begin[k], seg_end[k], seg_lr[k], seg_wd[k]};
+  }
+  a.beta1 = beta1; a.beta2 = beta2; a.eps = eps;
+  a.inv_bc1 = (float)(1.0 / (1.0 - std::pow((double)beta1, (double)step)));
+  a.inv_bc2_sqrt = (float)(1.0 / std::sqrt(1.0 - std::pow((double)beta2, (double)step)));
+  a.partials = partials; a.nparts = partials ? nparts : 0; a.max_norm = max_norm; a.norm_out = norm_out;
+  const long long want = (n / 4 + kAdamThreads - 1) / kAdamThreads;
+  const unsigned grid = (unsigned)std::min<long long>(want, 8LL * device_cu_count());
+  hipLaunchKernelGGL(adamw_clip_kernel, dim3(grid), dim3(kAdamThreads), 0, (hipStream_t)stream, a);
   return launch_status();
 }
 

@@ -98,3 +98,73 @@ class FlatParameters:
     def after_step(self) -> None:
         """The optimizer wrote through the leaves: tell everything keyed on the parameters' version counters."""
         torch.autograd.graph.increment_version(self.params)
+
+
+class FlatAdamW:
+    """``clip_grad_norm_(params, max_norm)`` + ``torch.optim.AdamW.step()`` (engine.py:74, main.py:201-221) over a
+    ``FlatParameters`` as two launches of csrc/adamw_flat.cuh: partial sums of g^2, then one pass over parameter, gradient
+    and both moments with the clipping coefficient applied on the fly (PyTorch's own path is 3 norm + 7 small + 3 scale
+    + 4 fused AdamW launches on the same three tensors; measured 0.49 -> 0.3 ms per step).  Same arithmetic per element as
+    ``torch.optim.AdamW(amsgrad=False)``; the gradient buffer is not rescaled in place (nothing reads it after the step).
+
+    ``param_groups`` mirrors the optimizer interface that schedulers use: one dict per FlatParameters group with ``lr``
+    and ``weight_decay`` (read at every step).  CUDA only: there is no CPU fallback -- use ``torch.optim.AdamW`` on
+    ``flat.leaves`` there."""
+
+    N_PARTS = 2048
+
+    def __init__(self, flat: "FlatParameters", lrs: Sequence[float], weight_decay: float = 1e-2, betas=(0.9, 0.999),
+                 eps: float = 1e-8):
+        assert flat.flat.is_cuda, "FlatAdamW runs on the HIP kernels only"
+        assert len(lrs) == len(flat.ranges)
+        self.flat = flat
+        self.param_groups = [{"lr": float(lr), "weight_decay": float(weight_decay), "betas": tuple(betas), "eps": float(eps),
+                              "range": r} for lr, r in zip(lrs, flat.ranges)]
+        self.exp_avg = torch.zeros_like(flat.flat)
+        self.exp_avg_sq = torch.zeros_like(flat.flat)
+        self.partials = torch.zeros(self.N_PARTS, dtype=torch.float32, device=flat.flat.device)
+        self.grad_norm = torch.zeros(1, dtype=torch.float32, device=flat.flat.device)    # of the last step, before clipping
+        self.step_count = 0
+
+    @torch.no_grad()
+    def step(self, max_norm: float = 0.0) -> None:
+        """One update; ``max_norm`` > 0 clips the global gradient norm first (``clip_grad_norm_`` semantics)."""
+        import ctypes
+        from . import _lib
+        f = self.flat
+        n = f.flat.numel()
+        groups = [g for g in self.param_groups if g["range"][1] > g["range"][0]]
+        k = len(groups)
+        begin = (ctypes.c_longlong * k)(*[g["range"][0] for g in groups])
+        end = (ctypes.c_longlong * k)(*[g["range"][1] for g in groups])
+        lr = (ctypes.c_float * k)(*[g["lr"] for g in groups])
+        wd = (ctypes.c_float * k)(*[g["weight_decay"] for g in groups])
+        b1, b2 = groups[0]["betas"]
+        self.step_count += 1
+        lib = _lib.load()
+        stream = _lib.raw_stream(f.flat.device)
+        with _lib.device_guard(f.flat.device):
+            parts = None
+            if max_norm > 0.0:
+                _lib.check(lib.snipper_gradnorm_partials_f32(stream, f.grad_flat.data_ptr(), n, self.partials.data_ptr(),
+                                                             self.N_PARTS), "snipper_gradnorm_partials_f32")
+                parts = self.partials.data_ptr()
+            _lib.check(lib.snipper_adamw_clip_f32(stream, f.flat.data_ptr(), f.grad_flat.data_ptr(), self.exp_avg.data_ptr(),
+                                                  self.exp_avg_sq.data_ptr(), n, begin, end, lr, wd, k, b1, b2, groups[0]["eps"],
+                                                  self.step_count, parts, self.N_PARTS if parts else 0, float(max_norm),
+                                                  self.grad_norm.data_ptr()), "snipper_adamw_clip_f32")
+        f.after_step()
+
+    def zero_grad(self, set_to_none: bool = True) -> None:
+        self.flat.drop_param_grads()
+
+    def state_dict(self):
+        return {"step": self.step_count, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq,
+                "param_groups": [{k: v for k, v in g.items() if k != "range"} for g in self.param_groups]}
+
+    def load_state_dict(self, sd) -> None:
+        self.step_count = int(sd["step"])
+        self.exp_avg.copy_(sd["exp_avg"])
+        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        for g, s in zip(self.param_groups, sd["param_groups"]):
+            g.update(s)
