@@ -75,7 +75,9 @@ typedef struct snipper_msda_config {
   int32_t struct_bytes;   /* sizeof(snipper_msda_config), checked                                                    */
   int32_t policy;         /* 0 auto; 1 generic kernels only; 2 tuned D=48 kernels but never the encoder-shape ones     */
   float near_radius;      /* owner-computes backward: a sample within this many pixels of its anchor is "near" (24)    */
-  int32_t reserved0;      /* must be 0                                                                                 */
+  int32_t tile_kernel;    /* owner-computes backward, grad_value side, bfloat16 grad_out rows: 0 / 2 = per-tile dense scatter
+                           * on the matrix pipe (csrc/msda_d48_tilemm.cuh), 1 = the vector / LDS sorted-list kernel
+                           * (csrc/msda_d48_patch.cuh; float32 grad_out rows always take it)                            */
   int32_t tile_edge[3];   /* grad_value tile edge (power of two <= 16) for levels of > 4096 / > 1024 / fewer pixels    */
   int32_t reserved[5];    /* must be 0, checked ([0] != 0 selects timing ablations of the owner-computes backward with WRONG
                            * results; refused unless SNIPPER_MSDA_ALLOW_DEBUG=1 was in the environment at load time, and

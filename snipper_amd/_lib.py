@@ -202,7 +202,7 @@ class Config(ctypes.Structure):
     """``snipper_msda_config`` (include/snipper_msda.h).  The library itself keeps no tuning state; the wrappers in
     MultiScaleDeformableAttention.py pass the caller's Config -- or ``None`` (the library defaults) -- with every call."""
     _fields_ = [("struct_bytes", ctypes.c_int32), ("policy", ctypes.c_int32), ("near_radius", ctypes.c_float),
-                ("reserved0", ctypes.c_int32), ("tile_edge", ctypes.c_int32 * 3), ("reserved", ctypes.c_int32 * 5)]
+                ("tile_kernel", ctypes.c_int32), ("tile_edge", ctypes.c_int32 * 3), ("reserved", ctypes.c_int32 * 5)]
 
     @classmethod
     def defaults(cls) -> "Config":
@@ -217,7 +217,7 @@ _test_config = None
 
 _KNOBS = {"near_radius": ("near_radius", float),
           "owner_tile_edge_big": (("tile_edge", 0), int), "owner_tile_edge_mid": (("tile_edge", 1), int),
-          "owner_tile_edge_small": (("tile_edge", 2), int), "debug": (("reserved", 0), int)}
+          "owner_tile_edge_small": (("tile_edge", 2), int), "debug": (("reserved", 0), int), "tile_kernel": ("tile_kernel", int)}
 
 
 def active_config():

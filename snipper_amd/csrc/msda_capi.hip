@@ -29,6 +29,7 @@
 #include "adamw_flat.cuh"
 #include "msda_d48.cuh"
 #include "msda_d48_patch.cuh"
+#include "msda_d48_tilemm.cuh"
 #include "msda_generic.cuh"
 
 using namespace snipper;
@@ -63,8 +64,8 @@ bool config_ok(const snipper_msda_config *cfg) {
     const int e = cfg->tile_edge[i];
     if (e < 1 || e > 16 || (e & (e - 1))) return false;
   }
+  if (cfg->tile_kernel < 0 || cfg->tile_kernel > 2) return false;
   // the header's "must be 0": a caller that fills the struct by hand without zeroing it must not get through
-  if (cfg->reserved0 != 0) return false;
   for (int i = 1; i < 5; ++i)
     if (cfg->reserved[i] != 0) return false;
   // reserved[0] selects timing ablations of the owner-computes backward (WRONG gradients): only a process that asked
@@ -261,7 +262,7 @@ inline long long patch_workspace_bytes(long long nm, const PatchPlan &plan) { re
 template <typename VT>
 int backward_d48_patch(hipStream_t st, const void *grad_out, const VT *value, const float *loc, const float *attn,
                        CoreDims d, PatchPlan plan, void *workspace, float *grad_value, float *grad_loc,
-                       float *grad_attn, int go_bf16) {
+                       float *grad_attn, int go_bf16, int tile_kernel) {
   const long long nm = (long long)d.N * d.M;
   plan.marks = reinterpret_cast<unsigned long long *>(workspace);
   hipError_t e = hipMemsetAsync(plan.marks, 0, (size_t)patch_workspace_bytes(nm, plan), st);
@@ -276,6 +277,14 @@ int backward_d48_patch(hipStream_t st, const void *grad_out, const VT *value, co
     hipLaunchKernelGGL((msda_bwd_d48_patchbin_kernel<VT, true>), dim3((unsigned)nblk_padded), dim3(kPatchThreads), 0, st, grad_out,
                        value, loc, attn, d, plan, grad_value, grad_loc, grad_attn, (int)nblk_padded);
     if (int rc = launch_status()) return rc;
+    // grad_value side: dense per-tile scatter on the matrix pipe (msda_d48_tilemm.cuh) unless the caller asks for the
+    // vector / LDS kernel (config.tile_kernel = 1; the ablation flags exist for that one only)
+    if (tile_kernel != 1 && !plan.debug) {
+      hipLaunchKernelGGL(msda_bwd_d48_tile3_kernel, dim3((unsigned)nblk_tiles), dim3(kPatchThreads), 0, st, grad_out, loc, attn,
+                         d, plan, grad_value);
+      g_last_variant = "d48_owner_mfma";
+      return launch_status();
+    }
     hipLaunchKernelGGL((msda_bwd_d48_tile2_kernel<128, true>), dim3((unsigned)nblk_tiles), dim3(kPatchThreads), 0, st, grad_out,
                        loc, attn, d, plan, grad_value);
   } else {
@@ -394,7 +403,7 @@ int snipper_msda_backward_ex(void *stream, const snipper_msda_config *cfg, const
       PatchPlan plan;
       if (make_patch_plan(d, host_shapes, c, &plan) && workspace_bytes >= patch_workspace_bytes((long long)N * M, plan))
         return backward_d48_patch<uint16_t>(st, grad_out, (const uint16_t *)value, (const float *)loc, (const float *)attn, d,
-                                            plan, workspace, (float *)grad_value, (float *)grad_loc, (float *)grad_attn, 1);
+                                            plan, workspace, (float *)grad_value, (float *)grad_loc, (float *)grad_attn, 1, c.tile_kernel);
     }
     return backward_generic<uint16_t, float, float>(st, (const uint16_t *)grad_out, (const uint16_t *)value, shapes,
                                                     level_start, (const float *)loc, (const float *)attn, d,
@@ -409,7 +418,7 @@ int snipper_msda_backward_ex(void *stream, const snipper_msda_config *cfg, const
   if (workspace && owner_shape_ok(d, host_shapes, c.policy)) {
     PatchPlan plan;
     if (make_patch_plan(d, host_shapes, c, &plan) && workspace_bytes >= patch_workspace_bytes((long long)N * M, plan))
-      return backward_d48_patch<float>(st, grad_out, v, lo, at, d, plan, workspace, gv, gl, ga, go_bf16);
+      return backward_d48_patch<float>(st, grad_out, v, lo, at, d, plan, workspace, gv, gl, ga, go_bf16, c.tile_kernel);
   }
   if (d48_eligible<float>(d, c.policy))
     return backward_d48_f32(st, (const float *)grad_out, v, shapes, level_start, lo, at, d, gv, gl, ga, go_bf16);

@@ -87,10 +87,10 @@ def test_config_reserved_fields_and_owner_map_bounds_are_checked():
     ws = lambda cfg, hp=hp, S=S, L=3: lib.snipper_msda_backward_ex_workspace_bytes(
         None if cfg is None else ctypes.byref(cfg), hp, 0, 2, S, 8, 48, L, S, 4)
     assert ws(None) > 0 and ws(_lib.Config.defaults()) == ws(None)
-    for field, idx in (("reserved0", None), ("reserved", 1), ("reserved", 4)):
+    for field, idx in (("tile_kernel", None), ("reserved", 1), ("reserved", 4)):
         cfg = _lib.Config.defaults()
         if idx is None:
-            setattr(cfg, field, 1)
+            setattr(cfg, field, 3)          # (tile_kernel: 0 / 2 matrix pipe, 1 vector kernel; anything else is refused)
         else:
             getattr(cfg, field)[idx] = 1
         assert ws(cfg) == 0, (field, idx)

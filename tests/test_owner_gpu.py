@@ -202,10 +202,90 @@ def test_bf16_value_owner_backward_against_oracle(geom, spread, far):
     np.testing.assert_allclose(out.float().cpu().numpy(), ref_out, rtol=2 ** -7, atol=2e-2)
     gv, gl, ga = MSDA.ms_deform_attn_backward(v16, t(sh), t(lsi), t(loc), t(attn), go16, 64, host_shapes=shapes,
                                               grad_value_f32=True)
-    assert _lib.last_variant() == "d48_owner" and gv.dtype == torch.float32
+    assert _lib.last_variant() == "d48_owner_mfma" and gv.dtype == torch.float32      # bf16 rows: msda_d48_tilemm.cuh
     np.testing.assert_allclose(gv.cpu().numpy(), ref[0], rtol=1e-4, atol=2e-4)
     s = float(np.abs(ref[1]).max())
     np.testing.assert_allclose(gl.cpu().numpy() / s, ref[1] / s, rtol=1e-4, atol=2e-5)
     np.testing.assert_allclose(ga.cpu().numpy(), ref[2], rtol=1e-4, atol=1e-4)
     gv2 = MSDA.ms_deform_attn_backward(v16, t(sh), t(lsi), t(loc), t(attn), go16, 64, host_shapes=shapes)[0]
     assert gv2.dtype == torch.bfloat16
+
+
+# ---- the matrix-pipe tile kernel (csrc/msda_d48_tilemm.cuh): taken for bfloat16 grad_out rows ------------------------
+def _bf16_rows_case(name):
+    N, shapes, M, P, spread, far = CASES[name]
+    v, sh, lsi, loc, attn, go = grid_case(N, shapes, M, P, seed=len(name) + 40, spread_px=spread, frac_far=far)
+    go16 = torch.from_numpy(go).to(torch.bfloat16)
+    return v, sh, lsi, loc, attn, go16, go16.float().numpy()
+
+
+def _run_rows16(v, sh, lsi, loc, attn, go16, host_shapes):
+    t = lambda a: torch.from_numpy(a).to(DEV)
+    out = MSDA.ms_deform_attn_backward(t(v), t(sh), t(lsi), t(loc), t(attn), go16.to(DEV), 64, host_shapes=host_shapes)
+    return [x.cpu().numpy() for x in out], _lib.last_variant()
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_mfma_tile_kernel_matches_oracle(name):
+    """float32 value, bfloat16 grad_out rows (the training step's mode): grad_value by the dense per-tile scatter on the
+    matrix pipe, against the C oracle in float64 on the SAME bf16-rounded rows, at the float32 kernels' tolerance (the
+    weights are split into bf16 hi + lo parts: float32-class), and against the vector tile kernel of the same library."""
+    v, sh, lsi, loc, attn, go16, go_r = _bf16_rows_case(name)
+    f64 = lambda a: a.astype(np.float64)
+    ref = O.core_c_backward(f64(v), sh, lsi, f64(loc), f64(attn), f64(go_r), threads=4)
+    hs = [tuple(x) for x in sh.tolist()]
+    (gv, gl, ga), variant = _run_rows16(v, sh, lsi, loc, attn, go16, hs)
+    assert variant == "d48_owner_mfma", variant
+    np.testing.assert_allclose(gv, ref[0], rtol=1e-4, atol=5e-5)
+    s = float(np.abs(ref[1]).max())
+    np.testing.assert_allclose(gl / s, ref[1] / s, rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(ga, ref[2], rtol=1e-4, atol=1e-4)
+    try:
+        _lib.set_param("tile_kernel", 1)
+        (gv1, gl1, ga1), variant1 = _run_rows16(v, sh, lsi, loc, attn, go16, hs)
+    finally:
+        _lib.reset_config()
+    assert variant1 == "d48_owner", variant1
+    np.testing.assert_allclose(gv, gv1, rtol=1e-4, atol=5e-5)
+    assert np.array_equal(gl, gl1) and np.array_equal(ga, ga1)          # the query side is the same kernel
+
+
+@pytest.mark.parametrize("radius", [0.0, 3.0, 40.0])
+@pytest.mark.parametrize("edges", [(16, 8, 4), (8, 8, 8), (4, 4, 2), (16, 16, 16), (1, 1, 1)])
+def test_mfma_tile_kernel_partition_holds_for_any_radius_and_tiling(radius, edges):
+    v, sh, lsi, loc, attn, go = grid_case(2, [(21, 26), (11, 13), (6, 7)], 4, 4, seed=6, spread_px=2.5, frac_far=0.1)
+    go16 = torch.from_numpy(go).to(torch.bfloat16)
+    f64 = lambda a: a.astype(np.float64)
+    ref = O.core_c_backward(f64(v), sh, lsi, f64(loc), f64(attn), f64(go16.float().numpy()), threads=4)[0]
+    try:
+        _lib.set_param("near_radius", radius)
+        for k, e in zip(("big", "mid", "small"), edges):
+            _lib.set_param(f"owner_tile_edge_{k}", e)
+        (gv, _, _), variant = _run_rows16(v, sh, lsi, loc, attn, go16, [tuple(x) for x in sh.tolist()])
+    finally:
+        _lib.reset_config()
+    assert variant == "d48_owner_mfma"
+    np.testing.assert_allclose(gv, ref, rtol=1e-4, atol=5e-5)
+
+
+@pytest.mark.parametrize("edges", [(16, 8, 4), (16, 16, 16)])
+@pytest.mark.parametrize("spread,far", [(2.0, 0.0), (8.0, 0.3)], ids=["local", "wide_far30"])
+def test_mfma_tile_kernel_full_size_against_oracle(edges, spread, far):
+    """600x800 geometry, N = 1, directly against the C oracle; tiles whose hit list needs several passes (16 x 16 tiles on
+    the coarse levels are reached by most queries)."""
+    shapes = GEOMETRIES["600x800"]
+    v, sh, lsi, loc, attn, go = grid_case(1, shapes, 8, 4, seed=12, spread_px=spread, frac_far=far)
+    go16 = torch.from_numpy(go).to(torch.bfloat16)
+    f64 = lambda a: a.astype(np.float64)
+    ref = O.core_c_backward(f64(v), sh, lsi, f64(loc), f64(attn), f64(go16.float().numpy()), threads=32)[0]
+    try:
+        for k, e in zip(("big", "mid", "small"), edges):
+            _lib.set_param(f"owner_tile_edge_{k}", e)
+        (gv, _, _), variant = _run_rows16(v, sh, lsi, loc, attn, go16, shapes)
+        (gvb, _, _), _ = _run_rows16(v, sh, lsi, loc, attn, go16, shapes)
+    finally:
+        _lib.reset_config()
+    assert variant == "d48_owner_mfma"
+    np.testing.assert_allclose(gv, ref, rtol=1e-4, atol=2e-4)
+    if far == 0.0:
+        assert np.array_equal(gv, gvb)          # no far taps, no atomics: bit-reproducible

@@ -83,6 +83,7 @@ def main():
     ap.add_argument("--radius", type=float, default=None)
     ap.add_argument("--debug", type=int, default=0, help="timing ablations of the encoder-shape kernels (wrong results)")
     ap.add_argument("--edges", type=int, nargs=3, default=None)
+    ap.add_argument("--tile-kernel", type=int, default=None, help="owner-computes grad_value side for bf16 rows: 1 = vector / LDS kernel, 2 = matrix pipe (default)")
     ap.add_argument("--cases", nargs="+", default=["enc_local", "enc_uniform", "dec"])
     ap.add_argument("--dtypes", nargs="+", default=["float32", "bfloat16"])
     ap.add_argument("--sigma", type=float, nargs="+", default=[3.0], help="enc_local: std of the offsets in pixels")
@@ -95,6 +96,8 @@ def main():
         _lib.set_param("near_radius", args.radius)
     if args.debug:
         _lib.set_param("debug", args.debug)
+    if args.tile_kernel is not None:
+        _lib.set_param("tile_kernel", args.tile_kernel)
     if args.edges:
         for k, e in zip(("big", "mid", "small"), args.edges):
             _lib.set_param(f"owner_tile_edge_{k}", e)
@@ -122,7 +125,7 @@ def main():
                     tb, tb0 = timeit(b, args.iters)
                     e = v.element_size()
                     print(json.dumps({
-                        "case": name, "N": N, "sigma_px": sg, "far": fr, "grid": args.grid, "radius": args.radius, "edges": args.edges, "rows_bf16": int(rows16),
+                        "case": name, "N": N, "sigma_px": sg, "far": fr, "grid": args.grid, "radius": args.radius, "edges": args.edges, "tile_kernel": args.tile_kernel, "rows_bf16": int(rows16),
                         "dtype": str(dtype).split(".")[-1], "fwd_variant": var_f,
                         "bwd_variant": var_b, "fwd_ms": round(tf, 4), "fwd_min_ms": round(tf0, 4),
                         "bwd_ms": round(tb, 4), "bwd_min_ms": round(tb0, 4),
