@@ -78,7 +78,8 @@ typedef struct snipper_msda_config {
   int32_t tile_kernel;    /* owner-computes backward, grad_value side, bfloat16 grad_out rows: 0 / 2 = per-tile dense scatter
                            * on the matrix pipe (csrc/msda_d48_tilemm.cuh), 1 = the vector / LDS sorted-list kernel
                            * (csrc/msda_d48_patch.cuh; float32 grad_out rows always take it)                            */
-  int32_t tile_edge[3];   /* grad_value tile edge (power of two <= 16) for levels of > 4096 / > 1024 / fewer pixels    */
+  int32_t tile_edge[3];   /* grad_value tile edge (power of two <= 16) for levels of > 4096 / > 1024 / fewer pixels;
+                           * 0 (default) = the grad_value-side kernel's own choice: 16 / 8 / 4 vector, 16 / 8 / 8 matrix pipe  */
   int32_t reserved[5];    /* must be 0, checked ([0] != 0 selects timing ablations of the owner-computes backward with WRONG
                            * results; refused unless SNIPPER_MSDA_ALLOW_DEBUG=1 was in the environment at load time, and
                            * then reported as variant "d48_owner_debug")                                                */

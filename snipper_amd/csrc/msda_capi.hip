@@ -52,7 +52,7 @@ snipper_msda_config default_config() {
   // r03_radius_sweep.txt): backward 0.85 / 0.96 / 0.96 ms at sigma ~0 / 3 / 8 px, against 0.87 / 1.39 / 2.34 ms at round 2's
   // 6 px, which had been tuned on freshly initialised offsets only
   c.near_radius = 24.0f;
-  c.tile_edge[0] = 16; c.tile_edge[1] = 8; c.tile_edge[2] = 4;
+  c.tile_edge[0] = 0; c.tile_edge[1] = 0; c.tile_edge[2] = 0;     // 0 = the kernel's own best (patch_edge below)
   return c;
 }
 bool config_ok(const snipper_msda_config *cfg) {
@@ -62,7 +62,7 @@ bool config_ok(const snipper_msda_config *cfg) {
   if (!(cfg->near_radius >= 0.f && cfg->near_radius <= 64.f)) return false;
   for (int i = 0; i < 3; ++i) {
     const int e = cfg->tile_edge[i];
-    if (e < 1 || e > 16 || (e & (e - 1))) return false;
+    if (e < 0 || e > 16 || (e & (e - 1))) return false;       // (0 = auto)
   }
   if (cfg->tile_kernel < 0 || cfg->tile_kernel > 2) return false;
   // the header's "must be 0": a caller that fills the struct by hand without zeroing it must not get through
@@ -193,7 +193,20 @@ int backward_d48_f32(hipStream_t st, const float *grad_out, const float *value, 
 
 // ---- owner-computes backward for the encoder shape (msda_d48_patch.cuh): needs the level shapes on the HOST ----
 // Returns false when the geometry does not fit the marks' bounds (then the plain D=48 kernels run).
-bool make_patch_plan(const CoreDims &d, const int64_t *hs, const snipper_msda_config &cfg, PatchPlan *out) {
+// grad_value tile edge of a level class (0 big, 1 mid, 2 small).  tile_edge = 0 (the default) lets the grad_value-side kernel
+// pick: 16 / 8 / 4 for the vector / LDS kernel (round 1-3 sweeps), 16 / 8 / 8 for the matrix-pipe kernel, whose cost is per
+// hit and per workgroup, not per tap (whole backward at N = 8, sigma 0 / 3 px: 0.669 / 0.844 ms against 0.677 / 0.861)
+int patch_edge(const snipper_msda_config &cfg, int cls, bool mfma_tiles) {
+  if (cfg.tile_edge[cls] > 0) return cfg.tile_edge[cls];
+  return cls == 0 ? 16 : (cls == 1 ? 8 : (mfma_tiles ? 8 : 4));
+}
+// which grad_value-side kernel a backward call with these row / value types takes (config.tile_kernel: 1 forces the vector one)
+bool patch_uses_mfma(const CoreDims &d, const snipper_msda_config &cfg, int go_bf16) {
+  const bool fits = (long long)d.Lq * d.M * d.L * kPatchP * 8 < (1LL << 31) && (long long)d.Lq * d.M * kT3RowB < (1LL << 31);
+  return go_bf16 && fits && (cfg.tile_kernel == 2 || (cfg.tile_kernel == 0 && !cfg.reserved[0]));
+}
+
+bool make_patch_plan(const CoreDims &d, const int64_t *hs, const snipper_msda_config &cfg, bool mfma_tiles, PatchPlan *out) {
   PatchPlan p{};
   p.L = d.L;
   p.radius = cfg.near_radius;
@@ -214,7 +227,7 @@ bool make_patch_plan(const CoreDims &d, const int64_t *hs, const snipper_msda_co
     v.blk_base = bbase;
     bbase += v.nbx * v.nby;
     const int area = v.H * v.W;
-    const int e = cfg.tile_edge[area > 4096 ? 0 : (area > 1024 ? 1 : 2)];
+    const int e = patch_edge(cfg, area > 4096 ? 0 : (area > 1024 ? 1 : 2), mfma_tiles);
     v.shift = e >= 16 ? 4 : (e >= 8 ? 3 : (e >= 4 ? 2 : (e >= 2 ? 1 : 0)));
     const int edge = 1 << v.shift;
     v.ntx = (v.W + edge - 1) / edge;
@@ -262,7 +275,7 @@ inline long long patch_workspace_bytes(long long nm, const PatchPlan &plan) { re
 template <typename VT>
 int backward_d48_patch(hipStream_t st, const void *grad_out, const VT *value, const float *loc, const float *attn,
                        CoreDims d, PatchPlan plan, void *workspace, float *grad_value, float *grad_loc,
-                       float *grad_attn, int go_bf16, int tile_kernel) {
+                       float *grad_attn, int go_bf16, bool mfma_tiles) {
   const long long nm = (long long)d.N * d.M;
   plan.marks = reinterpret_cast<unsigned long long *>(workspace);
   hipError_t e = hipMemsetAsync(plan.marks, 0, (size_t)patch_workspace_bytes(nm, plan), st);
@@ -278,11 +291,11 @@ int backward_d48_patch(hipStream_t st, const void *grad_out, const VT *value, co
                        value, loc, attn, d, plan, grad_value, grad_loc, grad_attn, (int)nblk_padded);
     if (int rc = launch_status()) return rc;
     // grad_value side: dense per-tile scatter on the matrix pipe (msda_d48_tilemm.cuh) unless the caller asks for the
-    // vector / LDS kernel (config.tile_kernel = 1; the ablation flags exist for that one only)
-    if (tile_kernel != 1 && !plan.debug) {
+    // vector / LDS kernel (config.tile_kernel = 1), see patch_uses_mfma
+    if (mfma_tiles) {
       hipLaunchKernelGGL(msda_bwd_d48_tile3_kernel, dim3((unsigned)nblk_tiles), dim3(kPatchThreads), 0, st, grad_out, loc, attn,
                          d, plan, grad_value);
-      g_last_variant = "d48_owner_mfma";
+      g_last_variant = plan.debug ? "d48_owner_mfma_debug" : "d48_owner_mfma";
       return launch_status();
     }
     hipLaunchKernelGGL((msda_bwd_d48_tile2_kernel<128, true>), dim3((unsigned)nblk_tiles), dim3(kPatchThreads), 0, st, grad_out,
@@ -373,8 +386,14 @@ long long snipper_msda_backward_ex_workspace_bytes(const snipper_msda_config *cf
   if (check_dims(N, S, M, D, L, Lq, P) != SNIPPER_OK || !config_ok(cfg) || (value_dtype != 0 && value_dtype != 1)) return 0;
   const snipper_msda_config c = resolve(cfg);
   if (!owner_shape_ok(d, host_shapes, c.policy)) return 0;
+  // (the query does not know the grad_out row type: enough for either grad_value-side kernel's tiling)
   PatchPlan plan;
-  return make_patch_plan(d, host_shapes, c, &plan) ? patch_workspace_bytes((long long)N * M, plan) : 0;
+  long long need = 0;
+  for (int mf = 0; mf < 2; ++mf) {
+    if (!make_patch_plan(d, host_shapes, c, mf != 0, &plan)) return 0;
+    need = std::max(need, patch_workspace_bytes((long long)N * M, plan));
+  }
+  return need;
 }
 
 int snipper_msda_backward_ex(void *stream, const snipper_msda_config *cfg, const int64_t *host_shapes, void *workspace,
@@ -401,9 +420,10 @@ int snipper_msda_backward_ex(void *stream, const snipper_msda_config *cfg, const
     if (int rc = zero_grad_value(st, (float *)grad_value, d)) return rc;
     if (workspace && owner_shape_ok(d, host_shapes, c.policy)) {       // encoder shape: owner-computes (marks + sorted taps)
       PatchPlan plan;
-      if (make_patch_plan(d, host_shapes, c, &plan) && workspace_bytes >= patch_workspace_bytes((long long)N * M, plan))
+      const bool mf = patch_uses_mfma(d, c, 1);
+      if (make_patch_plan(d, host_shapes, c, mf, &plan) && workspace_bytes >= patch_workspace_bytes((long long)N * M, plan))
         return backward_d48_patch<uint16_t>(st, grad_out, (const uint16_t *)value, (const float *)loc, (const float *)attn, d,
-                                            plan, workspace, (float *)grad_value, (float *)grad_loc, (float *)grad_attn, 1, c.tile_kernel);
+                                            plan, workspace, (float *)grad_value, (float *)grad_loc, (float *)grad_attn, 1, mf);
     }
     return backward_generic<uint16_t, float, float>(st, (const uint16_t *)grad_out, (const uint16_t *)value, shapes,
                                                     level_start, (const float *)loc, (const float *)attn, d,
@@ -417,8 +437,9 @@ int snipper_msda_backward_ex(void *stream, const snipper_msda_config *cfg, const
   if (int rc = zero_grad_value(st, gv, d)) return rc;
   if (workspace && owner_shape_ok(d, host_shapes, c.policy)) {
     PatchPlan plan;
-    if (make_patch_plan(d, host_shapes, c, &plan) && workspace_bytes >= patch_workspace_bytes((long long)N * M, plan))
-      return backward_d48_patch<float>(st, grad_out, v, lo, at, d, plan, workspace, gv, gl, ga, go_bf16, c.tile_kernel);
+    const bool mf = patch_uses_mfma(d, c, go_bf16);
+    if (make_patch_plan(d, host_shapes, c, mf, &plan) && workspace_bytes >= patch_workspace_bytes((long long)N * M, plan))
+      return backward_d48_patch<float>(st, grad_out, v, lo, at, d, plan, workspace, gv, gl, ga, go_bf16, mf);
   }
   if (d48_eligible<float>(d, c.policy))
     return backward_d48_f32(st, (const float *)grad_out, v, shapes, level_start, lo, at, d, gv, gl, ga, go_bf16);

@@ -24,8 +24,8 @@
 // lo), so grad_value stays BIT-REPRODUCIBLE from launch to launch for every tap the tiles own.
 //
 // LDS images (brute-forced against the lane groups of MI355X_MICROARCH.md, LDS table):
-//   Wt  4 planes x [pixels][8 floats], plane stride pixels * 32 + 16 bytes: lane (row r = lane & 15, k-group g = lane >> 4)
-//       of an A fragment reads the 32 contiguous bytes of pixel 16 pb + r in plane g with two ds_read_b128, conflict-free;
+//   Wt  4 planes x [pixels][8 floats], plane stride pixels * 32 + 16 bytes: lane (pixel r = lane & 15, k-group g = lane >> 4)
+//       of a Wt fragment reads the 32 contiguous bytes of pixel 16 pb + r in plane g with two ds_read_b128, conflict-free;
 //   G   [32 hits][96 B] unpadded; B fragments by ds_read_b64_tr_b16, lane group g taking hit rows {4g..4g+3} and
 //       {16+4g..16+4g+3} (the 8 rows a 32-lane half reads are consecutive: conflict-free at a 96-byte stride), so hit h
 //       sits in plane (h >> 2) & 3, slot (h & 3) + 4 (h >> 4) of Wt -- the same k order on both operands.
@@ -42,14 +42,20 @@
 namespace snipper {
 
 constexpr int kT3Hits = 64;                         // hits per round = two k-steps of v_mfma_f32_16x16x32_bf16
+constexpr int kT3List = 512;                        // hits expanded per pass over a tile
 constexpr int kT3PlaneMax = kTile2MaxPx * 32 + 16;  // bytes of one Wt plane of a 256-pixel tile
 constexpr int kT3RowB = 96;                         // one bfloat16 grad_out head row
+
+// one hit = one query with a mark in this tile: what every use of it needs, computed ONCE when the marks are expanded (a
+// wave expands one candidate block per trip, lane i = query i of the block, so the level's constants are uniform there)
+struct T3Hit { int q; float ax, ay; int pad; };     // query index; its anchor in the tile's level
 
 struct Tile3Lds {
   __attribute__((aligned(16))) unsigned char W[2 * 4 * kT3PlaneMax];  // 65 664 B: two k-steps x four planes
   __attribute__((aligned(16))) unsigned char G[kT3Hits * kT3RowB];    // 6 144 B
+  __attribute__((aligned(16))) T3Hit hits[kT3List];                   // 8 192 B
   float trash[kPatchThreads];                                         // where the taps this tile does not own go
-  unsigned hits[kTile2HitList];                                       // 6 144 B
+  __attribute__((aligned(16))) unsigned dirty[4];                     // per wave: (k-step, pixel block) pairs its hits tapped this round
   int wsum[4];
   int total_hits;
 };
@@ -76,7 +82,9 @@ __device__ __forceinline__ void tile3_split(const f32x4 &r0, const f32x4 &r1, ge
 }
 
 // LDS accesses of the Wt build as inline assembly: the ORDER of the four points' read-add-write passes is what makes the
-// sums right, and hipcc may merge / reorder identical exec-masked bodies (it did: the four passes became one)
+// sums right, and hipcc may merge / reorder identical exec-masked bodies (it did: the four passes became one).
+// (LDS float atomics -- ds_add_f32 without return, no wait at all -- were measured: 527 us per launch against 379 us for
+//  the read-add-write passes; the LDS executes them an order of magnitude slower than plain accesses.)
 __device__ __forceinline__ float t3_lds_read(unsigned addr) {
   float v;
   asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"(addr) : "memory");
@@ -128,38 +136,58 @@ __device__ __forceinline__ void tile3_body(Tile3Lds &S, const unsigned char *__r
       c -= cnt;
     }
   }
+  // The accumulators START from the tile's current grad_value (zeros from the callee's memset plus whatever the query side's
+  // far-tap atomics added; that kernel has finished) and the finished tile is stored plainly: the loads are in flight behind
+  // everything up to the first round's matrix instructions, no read sits between the last round and the store.  The product is
+  // evaluated transposed (G^T as the A operand, Wt^T as B), so lane (column c = lane & 15, k-group g) holds the FOUR
+  // CONSECUTIVE channels 16 cb + 4 g .. + 3 of pixel 16 pb + c: one 16-byte access per accumulator, the four lanes of a
+  // pixel covering 64 contiguous bytes.
+  const int r16 = lane & 15, g4 = lane >> 4;
+  gemm_f32x4 acc[NACC][3];
+  float *dst[NACC];
+  {
+    const size_t img_base = ((size_t)n * d.S + me.start) * d.M;
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) {
+      const int pix = 16 * (NPB >= 4 ? 4 * i + wave : 0) + r16;
+      const int ty = ty0 + (pix >> me.shift), tx = tx0 + (pix & (edge - 1));
+      const bool on = (NPB >= 4 || wave == 0) && pix < tpx && ty < me.H && tx < me.W;
+      dst[i] = on ? grad_value + (img_base + (size_t)(ty * me.W + tx) * d.M + m) * kD48 + 4 * g4 : nullptr;
+#pragma unroll
+      for (int cb = 0; cb < 3; ++cb)
+        acc[i][cb] = on ? *reinterpret_cast<const gemm_f32x4 *>(dst[i] + 16 * cb) : gemm_f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  // Wt starts as zeros and a column is cleared again by the lanes that wrote it; rows of G beyond a round's last hit are
+  // written as zeros by the loader (0 x stale bits must not make a NaN).  (Placed between the mark load and its first use.)
+  for (int i = tid; i < 2 * 4 * PLANE / 16; i += kPatchThreads) reinterpret_cast<u32x4 *>(S.W)[i] = u32x4{0u, 0u, 0u, 0u};
+  for (int i = tid; i < kT3Hits * kT3RowB / 16; i += kPatchThreads) reinterpret_cast<u32x4 *>(S.G)[i] = u32x4{0u, 0u, 0u, 0u};
   const int my_cnt = __popcll(mask);
   const int my_excl = block_incl_scan(my_cnt, S.wsum, tid) - my_cnt;
   if (tid == kPatchThreads - 1) S.total_hits = my_excl + my_cnt;
-  // Wt starts as zeros and a column is cleared again by the lanes that wrote it; rows of G beyond a round's last hit are
-  // written as zeros by the loader (0 x stale bits must not make a NaN)
-  for (int i = tid; i < 2 * 4 * PLANE / 16; i += kPatchThreads) reinterpret_cast<u32x4 *>(S.W)[i] = u32x4{0u, 0u, 0u, 0u};
-  for (int i = tid; i < kT3Hits * kT3RowB / 16; i += kPatchThreads) reinterpret_cast<u32x4 *>(S.G)[i] = u32x4{0u, 0u, 0u, 0u};
   lds_barrier();
-  const int total_hits = S.total_hits;
-
-  gemm_f32x4 acc[NACC][3];
-#pragma unroll
-  for (int i = 0; i < NACC; ++i)
-#pragma unroll
-    for (int cb = 0; cb < 3; ++cb) acc[i][cb] = gemm_f32x4{0.f, 0.f, 0.f, 0.f};
+  const int total_hits = (plan.debug & 8) ? 0 : S.total_hits;      // (plan.debug: timing ablations, WRONG results)
 
   // roles of a round: item = (hit h, point p), its four taps; G piece g = (hit g / 6, 16-byte part g % 6), 384 per round
   const int h = tid >> 2, p = tid & 3, h5 = h & 31;
   const unsigned w_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)S.W;
   const unsigned wcol = w_lds + (unsigned)(((h >> 5) * 4 + ((h5 >> 2) & 3)) * PLANE + ((h5 & 3) + ((h5 >> 4) << 2)) * 4);
   const unsigned trash = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)(S.trash + tid);
-  const unsigned char *go_nm = grad_out + (row_base * d.M + m) * kT3RowB;
-  const size_t q_stride = (size_t)d.M * kT3RowB;
-  const float *loc_nm = loc + ((row_base * d.M + m) * LP + l * kPatchP + p) * 2;
-  const float *attn_nm = attn + (row_base * d.M + m) * LP + l * kPatchP + p;
-  const size_t s_stride = (size_t)d.M * LP;
-  const int r16 = lane & 15, g4 = lane >> 4;
+  // loc / attn / grad_out of this sample (n): raw buffers with 32-bit offsets (the launcher checked the sizes)
+  const unsigned q_loc = (unsigned)(d.M * LP) * 8u, q_attn = (unsigned)(d.M * LP) * 4u, q_go = (unsigned)d.M * kT3RowB;
+  const auto loc_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(loc + row_base * d.M * LP * 2), 0,
+                                                         (int)((unsigned)d.Lq * q_loc), 0x00020000);
+  const auto attn_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(attn + row_base * d.M * LP), 0,
+                                                          (int)((unsigned)d.Lq * q_attn), 0x00020000);
+  const auto go_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char *>(grad_out + row_base * d.M * kT3RowB), 0,
+                                                        (int)((unsigned)d.Lq * q_go), 0x00020000);
+  const unsigned my_item = (unsigned)((m * LP + l * kPatchP + p) * 4);          // (x 2 for loc)
   const unsigned char *gfrag = S.G + (4 * g4 + ((lane >> 2) & 3)) * kT3RowB + 8 * (lane & 3);
 
-  for (int pass0 = 0; pass0 < total_hits; pass0 += kTile2HitList) {
-    const int pass1 = min(pass0 + kTile2HitList, total_hits), np = pass1 - pass0;
-    // ---- expand the marks into the hit list (order: candidate, then bit -- fixed; see msda_bwd_d48_tile2_kernel) ----
+  for (int pass0 = 0; pass0 < total_hits; pass0 += kT3List) {
+    const int pass1 = min(pass0 + kT3List, total_hits), np = pass1 - pass0;
+    // ---- expand the marks into the hit list (order: candidate, then bit -- fixed; see msda_bwd_d48_tile2_kernel): a wave
+    //      takes its candidates with marks one after the other, lane i = query (i >> 3, i & 7) of the block ----
     {
       unsigned long long todo = __ballot(my_cnt && my_excl < pass1 && my_excl + my_cnt > pass0);
       while (todo) {
@@ -168,66 +196,74 @@ __device__ __forceinline__ void tile3_body(Tile3Lds &S, const unsigned char *__r
         const unsigned mlo = __builtin_amdgcn_readlane((unsigned)mask, src);
         const unsigned mhi = __builtin_amdgcn_readlane((unsigned)(mask >> 32), src);
         const int ex = __builtin_amdgcn_readlane(my_excl, src);
-        const unsigned lqv = __builtin_amdgcn_readlane(c_lq, src);
-        const unsigned byv = __builtin_amdgcn_readlane(c_by, src), bxv = __builtin_amdgcn_readlane(c_bx, src);
+        const int lqv = __builtin_amdgcn_readlane(c_lq, src);
+        const int byv = __builtin_amdgcn_readlane(c_by, src), bxv = __builtin_amdgcn_readlane(c_bx, src);
+        int start = lv.start[0], Wq = lv.W[0];
+        float rwq = lv.rw[0], rhq = lv.rh[0];
+#pragma unroll
+        for (int i = 1; i < kPatchMaxLevels; ++i) {
+          start = lqv == i ? lv.start[i] : start; Wq = lqv == i ? lv.W[i] : Wq;
+          rwq = lqv == i ? lv.rw[i] : rwq; rhq = lqv == i ? lv.rh[i] : rhq;
+        }
         const bool bit = (((lane < 32 ? mlo : mhi) >> (lane & 31)) & 1u) != 0u;
         const int gi = ex + (int)__builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u));
-        if (bit && gi >= pass0 && gi < pass1)
-          S.hits[gi - pass0] = (lqv << 30) | ((byv * kPatchB + (unsigned)(lane >> 3)) << 15) | (bxv * kPatchB + (unsigned)(lane & 7));
+        if (bit && gi >= pass0 && gi < pass1) {
+          const int qy = byv * kPatchB + (lane >> 3), qx = bxv * kPatchB + (lane & 7);
+          T3Hit r;
+          r.q = start + qy * Wq + qx; r.ax = anchor_from_ratio(qx, rwq); r.ay = anchor_from_ratio(qy, rhq); r.pad = 0;
+          S.hits[gi - pass0] = r;
+        }
       }
     }
     lds_barrier();
 
     // this thread's item and G pieces of the first round (later rounds: in flight behind the previous round)
-    unsigned n_hit = 0u;
-    float2 n_xy = make_float2(-4.f, -4.f);
+    float2 n_xy = make_float2(-4.f, -4.f), n_an = make_float2(0.f, 0.f);
     float n_a = 0.f;
     u32x4 n_g[2];
     auto fetch = [&](int lo_, int nh_) {
-      n_hit = 0u; n_xy = make_float2(-4.f, -4.f); n_a = 0.f;       // (a location outside every map decodes to "not near")
-      if (h < nh_) {
-        n_hit = S.hits[lo_ + h];
-        const size_t so = (size_t)hit_query(lv, n_hit) * s_stride;
-        n_xy = *reinterpret_cast<const float2 *>(loc_nm + 2 * so);
-        n_a = attn_nm[so];
+      n_xy = make_float2(-4.f, -4.f); n_a = 0.f;       // (a location outside every map decodes to "not near")
+      if (h < nh_ && !(plan.debug & 4)) {
+        const T3Hit r = S.hits[lo_ + h];
+        n_an = make_float2(r.ax, r.ay);
+        typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+        const u32x2_t xy = __builtin_amdgcn_raw_buffer_load_b64(loc_src, (unsigned)r.q * q_loc + 2u * my_item, 0, 0);
+        n_xy = make_float2(__uint_as_float(xy[0]), __uint_as_float(xy[1]));
+        n_a = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(attn_src, (unsigned)r.q * q_attn + my_item, 0, 0));
       }
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int g = tid + i * kPatchThreads, gh = g / 6, gpart = g - gh * 6;
         n_g[i] = u32x4{0u, 0u, 0u, 0u};
-        if (gh < nh_)       // (gh < 64 follows: nh_ <= 64)
-          n_g[i] = *reinterpret_cast<const u32x4 *>(go_nm + (size_t)hit_query(lv, S.hits[lo_ + gh]) * q_stride + gpart * 16);
+        if (gh < nh_ && !(plan.debug & 1))       // (gh < 64 follows: nh_ <= 64)
+          n_g[i] = __builtin_amdgcn_raw_buffer_load_b128(go_src, (unsigned)S.hits[lo_ + gh].q * q_go + (unsigned)(m * kT3RowB + gpart * 16), 0, 0);
       }
     };
     fetch(0, min(kT3Hits, np));
 
     for (int lo = 0; lo < np; lo += kT3Hits) {
-      const int nh = min(kT3Hits, np - lo);
       // ---- decode this thread's item: the four taps of sample (h, p); a tap this tile does not own adds 0 to `trash` ----
       unsigned ta[4] = {trash, trash, trash, trash};
       float tw[4] = {0.f, 0.f, 0.f, 0.f};
+      unsigned dm = 0u;        // bit 16 s + pb: this item taps pixel block pb in k-step s
       {
         const float x = px_coord(n_xy.x, me.W), y = px_coord(n_xy.y, me.H);
         const bool inside = (y > -1.f) && (x > -1.f) && (y < (float)me.H) && (x < (float)me.W);
-        if (inside) {
-          int lq, qy, qx;
-          hit_query(lv, n_hit, lq, qy, qx);
-          float rwq, rhq;
-          hit_ratios(lv, lq, rwq, rhq);
-          if (near_anchor(x, y, anchor_from_ratio(qx, rwq), anchor_from_ratio(qy, rhq), plan.radius)) {
-            const float yf = floorf(y), xf = floorf(x);
-            const int y0 = (int)yf, x0 = (int)xf;
-            const float lh = y - yf, lw = x - xf, hh = 1.f - lh, hw = 1.f - lw;
-            const float w4[4] = {hh * hw * n_a, hh * lw * n_a, lh * hw * n_a, lh * lw * n_a};
+        if (inside && near_anchor(x, y, n_an.x, n_an.y, plan.radius)) {
+          const float yf = floorf(y), xf = floorf(x);
+          const int y0 = (int)yf, x0 = (int)xf;
+          const float lh = y - yf, lw = x - xf, hh = 1.f - lh, hw = 1.f - lw;
+          const float w4[4] = {hh * hw * n_a, hh * lw * n_a, lh * hw * n_a, lh * lw * n_a};
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-              const int ty = y0 + (k >> 1), tx = x0 + (k & 1);
-              const bool mine = ty >= 0 && ty <= me.H - 1 && tx >= 0 && tx <= me.W - 1 && (ty >> me.shift) == tyi &&
-                                (tx >> me.shift) == txi;
-              if (mine) {
-                ta[k] = wcol + (unsigned)(((ty - ty0) << me.shift) + (tx - tx0)) * 32u;
-                tw[k] = w4[k];
-              }
+          for (int k = 0; k < 4; ++k) {
+            const int ty = y0 + (k >> 1), tx = x0 + (k & 1);
+            const bool mine = ty >= 0 && ty <= me.H - 1 && tx >= 0 && tx <= me.W - 1 && (ty >> me.shift) == tyi &&
+                              (tx >> me.shift) == txi;
+            if (mine) {
+              const unsigned pix = (unsigned)(((ty - ty0) << me.shift) + (tx - tx0));
+              ta[k] = wcol + pix * 32u;
+              tw[k] = w4[k];
+              dm |= 1u << ((pix >> 4) + 16u * (unsigned)(h >> 5));
             }
           }
         }
@@ -239,9 +275,9 @@ __device__ __forceinline__ void tile3_body(Tile3Lds &S, const unsigned char *__r
       if (lo + kT3Hits < np) fetch(lo + kT3Hits, min(kT3Hits, np - lo - kT3Hits));
       // ---- build Wt: the four points of a hit may tap the same pixel, so they add one after the other (the LDS executes
       //      a wave's instructions in order; point 0 finds its column clear and only writes); the taps of ONE point are
-      //      four different pixels and different hits are different columns: no two lanes of an instruction meet ----
-      //      (the phase numbers are made opaque: hipcc otherwise sees four mutually exclusive branches on p and is free to
-      //      run them in ANY order -- it built a decision tree that ran point 3 first and point 0's plain store third)
+      //      four different pixels and different hits are different columns: no two lanes of an instruction meet.
+      //      (The phase numbers are made opaque: hipcc otherwise sees four mutually exclusive branches on p and is free to
+      //      run them in ANY order -- it built a decision tree that ran point 3 first and point 0's plain store third.) ----
 #pragma unroll
       for (int ph = 0; ph < kPatchP; ++ph) {
         int phv = ph;
@@ -260,26 +296,40 @@ __device__ __forceinline__ void tile3_body(Tile3Lds &S, const unsigned char *__r
           }
         }
       }
-      lds_barrier();      // Wt and G complete
-      // ---- tile += Wt . G on the matrix pipe ----
-      if (NPB >= 4 || wave == 0) {
+      // which (k-step, pixel block) fragments are not all zeros: OR over the wave (DPP within rows of 16, then the 4 rows)
+      {
+        unsigned v = dm;
+        v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);     // quad_perm [1,0,3,2]
+        v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);     // quad_perm [2,3,0,1]
+        v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true);    // row_half_mirror
+        v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, true);    // row_mirror
+        const unsigned wv = __builtin_amdgcn_readlane(v, 0) | __builtin_amdgcn_readlane(v, 16) |
+                            __builtin_amdgcn_readlane(v, 32) | __builtin_amdgcn_readlane(v, 48);
+        if (lane == 0) S.dirty[wave] = wv;
+      }
+      lds_barrier();      // Wt, G and the dirty words complete
+      // ---- tile^T += G^T . Wt^T on the matrix pipe ----
+      if ((NPB >= 4 || wave == 0) && !(plan.debug & 2)) {
+        const u32x4 dw = *reinterpret_cast<const u32x4 *>(S.dirty);
+        const unsigned dirty = __builtin_amdgcn_readfirstlane(dw.x | dw.y | dw.z | dw.w);
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-          if (s == 1 && nh <= 32) break;
+          if (((dirty >> (16 * s)) & 0xffffu) == 0u) continue;        // (covers a last round of <= 32 hits)
           gemm_bf16x8 bf[3];
 #pragma unroll
           for (int cb = 0; cb < 3; ++cb) bf[cb] = tile3_bfrag(gfrag + s * 32 * kT3RowB + 32 * cb);
 #pragma unroll
           for (int i = 0; i < NACC; ++i) {
             const int pb = NPB >= 4 ? 4 * i + wave : 0;
+            if (!((dirty >> (16 * s + pb)) & 1u)) continue;           // every weight of this fragment is zero
             const unsigned char *wp = S.W + (s * 4 + g4) * PLANE + (16 * pb + r16) * 32;
             const f32x4 r0 = *reinterpret_cast<const f32x4 *>(wp), r1 = *reinterpret_cast<const f32x4 *>(wp + 16);
             gemm_bf16x8 ahi, alo;
             tile3_split(r0, r1, ahi, alo);
 #pragma unroll
-            for (int cb = 0; cb < 3; ++cb) acc[i][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi, bf[cb], acc[i][cb], 0, 0, 0);
+            for (int cb = 0; cb < 3; ++cb) acc[i][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[cb], ahi, acc[i][cb], 0, 0, 0);
 #pragma unroll
-            for (int cb = 0; cb < 3; ++cb) acc[i][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(alo, bf[cb], acc[i][cb], 0, 0, 0);
+            for (int cb = 0; cb < 3; ++cb) acc[i][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[cb], alo, acc[i][cb], 0, 0, 0);
           }
         }
       }
@@ -290,23 +340,12 @@ __device__ __forceinline__ void tile3_body(Tile3Lds &S, const unsigned char *__r
     lds_barrier();        // before the next pass overwrites the hit list
   }
 
-  // ---- add the tile to grad_value: plain read-modify-write (the query-side kernel has finished; tiles are disjoint).
-  //      Accumulator layout: lane (column c = lane & 15, k-group g) holds channel 16 cb + c of pixels 16 pb + 4 g + reg. ----
-  if (NPB >= 4 || wave == 0) {
-    const size_t img_base = ((size_t)n * d.S + me.start) * d.M;
+  // ---- store the tile (tiles are disjoint; the accumulators started from grad_value) ----
 #pragma unroll
-    for (int i = 0; i < NACC; ++i) {
-      const int pb = NPB >= 4 ? 4 * i + wave : 0;
+  for (int i = 0; i < NACC; ++i) {
+    if (dst[i]) {
 #pragma unroll
-      for (int reg = 0; reg < 4; ++reg) {
-        const int pix = 16 * pb + 4 * g4 + reg;
-        const int ty = ty0 + (pix >> me.shift), tx = tx0 + (pix & (edge - 1));
-        if (pix < tpx && ty < me.H && tx < me.W) {
-          float *dst = grad_value + (img_base + (size_t)(ty * me.W + tx) * d.M + m) * kD48 + r16;
-#pragma unroll
-          for (int cb = 0; cb < 3; ++cb) dst[16 * cb] += acc[i][cb][reg];
-        }
-      }
+      for (int cb = 0; cb < 3; ++cb) *reinterpret_cast<gemm_f32x4 *>(dst[i] + 16 * cb) = acc[i][cb];
     }
   }
 }

@@ -41,7 +41,7 @@ def test_library_loads_and_reports():
     assert lib.snipper_msda_forward_f64(None, one, one, one, one, one, 1, 1 << 20, 64, 64, 1, 1, 1, one) == -2
     cfg = _lib.Config.defaults()
     assert cfg.struct_bytes == ctypes.sizeof(_lib.Config) and cfg.policy == 0 and cfg.near_radius == 24.0
-    assert list(cfg.tile_edge) == [16, 8, 4]
+    assert list(cfg.tile_edge) == [0, 0, 0]          # 0 = the grad_value-side kernel's own choice
     cfg.policy = 7      # a config the library rejects is an error, not a silent default
     assert lib.snipper_msda_forward_ex(None, ctypes.byref(cfg), None, one, 0, one, one, one, one, 1, 1, 1, 1, 1, 1, 1, one, 0) == -2
 

@@ -329,9 +329,12 @@ def test_bf16_rows_interface_matches_f32(Lq_is_S):
     hs = shapes if Lq_is_S else None
     a = MSDA.ms_deform_attn_backward(value, sh, lsi, loc, attn, go16, 64, host_shapes=hs)
     b = MSDA.ms_deform_attn_backward(value, sh, lsi, loc, attn, go16.float(), 64, host_shapes=hs)
-    for x, y in zip(a, b):
+    for i, (x, y) in enumerate(zip(a, b)):
         scale = max(float(y.abs().max()), 1.0)
-        torch.testing.assert_close(x / scale, y / scale, rtol=1e-5, atol=2e-6)
+        # grad_value of the owner-computes shape: bf16 rows take the matrix-pipe tile kernel, whose weights are split into
+        # bf16 hi + lo parts (relative error <= 2^-17 per weight), float32 rows the vector kernel
+        tol = dict(rtol=4e-5, atol=8e-6) if (Lq_is_S and i == 0) else dict(rtol=1e-5, atol=2e-6)
+        torch.testing.assert_close(x / scale, y / scale, **tol)
 
 
 def test_bf16_rows_unsupported_shape_falls_back_to_cast():
