@@ -399,7 +399,10 @@ class ResNet50Body(nn.Module):
                     x4[..., :3] = x.permute(0, 2, 3, 1)
                     y = torch.empty((n, 64, (h - 1) // 2 + 1, (wd - 1) // 2 + 1), dtype=torch.bfloat16, device=x.device,
                                     memory_format=torch.channels_last)
-                    with _lib.device_guard(x.device):
+                    from . import dense as _dense
+                    ho_, wo_ = (h - 1) // 2 + 1, (wd - 1) // 2 + 1
+                    with _dense._timed("stem7x7", (n, h, wd, 3, 64, 2), 2 * n * ho_ * wo_ * 64 * 147,
+                                       2 * (n * h * wd * 4 + 64 * 256 + n * ho_ * wo_ * 64), x.device), _lib.device_guard(x.device):
                         rc = _lib.load().snipper_stem7x7_bf16(_lib.raw_stream(x.device), x4.data_ptr(), cached[2].data_ptr(),
                                                               y.data_ptr(), n, h, wd)
                     _lib.check(rc, "snipper_stem7x7_bf16")

@@ -7,6 +7,48 @@ import torch
 
 from . import _lib
 
+# ---- optional launch timing (bench.py `roofline_dense`, tools/dense_roofline.py) -------------------------------------
+# When enabled, every GEMM-shaped C-ABI call below is bracketed by two events on the stream it is launched on, together
+# with its FLOPs and compulsory HBM bytes (operands read once, result written once); nothing synchronises until the list
+# is read.  Off (the default) the bracket is one shared no-op object.
+_timing = None
+
+
+def enable_launch_timing(on: bool = True) -> None:
+    global _timing
+    _timing = [] if on else None
+
+
+def launch_timings():
+    """[(kind, shape tuple, flops, bytes, elapsed_ms)] for the calls since enable_launch_timing(True); synchronises."""
+    if not _timing:
+        return []
+    torch.cuda.synchronize()
+    return [(k, sh, f, b, s.elapsed_time(e)) for (k, sh, f, b, s, e) in _timing]
+
+
+class _Timed:
+    __slots__ = ("kind", "shape", "flops", "bytes", "device", "start")
+
+    def __init__(self, kind, shape, flops, nbytes, device):
+        self.kind, self.shape, self.flops, self.bytes, self.device = kind, shape, flops, nbytes, device
+
+    def __enter__(self):
+        self.start = torch.cuda.Event(enable_timing=True)
+        self.start.record(torch.cuda.current_stream(self.device))
+        return self
+
+    def __exit__(self, *exc):
+        if _timing is not None and exc[0] is None:
+            end = torch.cuda.Event(enable_timing=True)
+            end.record(torch.cuda.current_stream(self.device))
+            _timing.append((self.kind, self.shape, self.flops, self.bytes, self.start, end))
+        return False
+
+
+def _timed(kind, shape, flops, nbytes, device):
+    return _lib._NO_GUARD if _timing is None else _Timed(kind, shape, flops, nbytes, device)
+
 
 def linear_bf16(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
                 residual: Optional[torch.Tensor] = None, relu: bool = False, dropout_p: float = 0.0,
@@ -33,7 +75,8 @@ def linear_bf16(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tens
     if bias is not None and bias.dtype != torch.float32:
         bias = bias.float()
     lib = _lib.load()
-    with _lib.device_guard(x.device):
+    with _timed("linear", (M, N, K), 2 * M * N * K, 2 * (M * K + N * K + M * N * (2 if r2 is not None else 1)), x.device), \
+            _lib.device_guard(x.device):
         rc = lib.snipper_linear_bf16(
             _lib.raw_stream(x.device), x2.data_ptr(), x2.stride(0), weight.data_ptr(),
             bias.data_ptr() if bias is not None else None, r2.data_ptr() if r2 is not None else None,
@@ -68,7 +111,8 @@ def linear_wres_bf16(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch
     if bias is not None and bias.dtype != torch.float32:
         bias = bias.float()
     out = torch.empty((M, N), dtype=torch.bfloat16, device=x.device)
-    with _lib.device_guard(x.device):
+    with _timed("linear_wres", (M, N, K), 2 * M * N * K, 2 * (M * K + N * K + M * N * (2 if gate is not None else 1)), x.device), \
+            _lib.device_guard(x.device):
         rc = _lib.load().snipper_linear_wres_bf16(
             _lib.raw_stream(x.device), x.data_ptr(), x.stride(0), weight.data_ptr(), weight.stride(0),
             bias.data_ptr() if bias is not None else None, gate.data_ptr() if gate is not None else None,
@@ -130,7 +174,9 @@ def conv3x3_bf16(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Ten
     if bias is not None and bias.dtype != torch.float32:
         bias = bias.float()
     gp, _keep = _gate_ptr(gate, out)
-    with _lib.device_guard(x.device):
+    with _timed("conv3x3" + ("_dgrad" if flip_taps else ""), (B, H, W, Cin, Cout, stride), 2 * B * Ho * Wo * Cout * 9 * Cin,
+                2 * (B * H * W * Cin + 9 * Cin * Cout + B * Ho * Wo * Cout * (2 if gate is not None else 1)), x.device), \
+            _lib.device_guard(x.device):
         rc = _lib.load().snipper_conv3x3_bf16(
             _lib.raw_stream(x.device), x.data_ptr(), weight.data_ptr(),
             bias.data_ptr() if bias is not None else None, out.data_ptr(), B, H, W, Cin, Cout, int(stride), int(relu), gp,
@@ -154,7 +200,9 @@ def conv3x3_dgrad_s2_bf16(g: torch.Tensor, weight_t: torch.Tensor, in_hw, gate: 
     assert weight_t.shape[1] == Cg and (H - 1) // 2 + 1 == Hg and (W - 1) // 2 + 1 == Wg
     dx = torch.empty((B, Cx, H, W), dtype=torch.bfloat16, device=g.device, memory_format=torch.channels_last)
     gp, _keep = _gate_ptr(gate, dx)
-    with _lib.device_guard(g.device):
+    with _timed("conv3x3_dgrad_s2", (B, H, W, Cx, Cg, 2), 2 * B * Hg * Wg * Cg * 9 * Cx,
+                2 * (B * Hg * Wg * Cg + 9 * Cx * Cg + B * H * W * Cx * (2 if gate is not None else 1)), g.device), \
+            _lib.device_guard(g.device):
         rc = _lib.load().snipper_conv3x3_dgrad_s2_bf16(_lib.raw_stream(g.device), g.data_ptr(), weight_t.data_ptr(),
                                                        dx.data_ptr(), B, H, W, Cx, Cg, gp)
     _lib.check(rc, "snipper_conv3x3_dgrad_s2_bf16")
@@ -177,7 +225,9 @@ def wgrad_conv3x3_bf16(g: torch.Tensor, x: torch.Tensor, stride: int, scale: Opt
         scale = scale.float()
     ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=g.device)
     dw = torch.empty((Cout, 3, 3, Cin), dtype=torch.float32, device=g.device)
-    with _lib.device_guard(g.device):
+    Ho_, Wo_ = g.shape[2], g.shape[3]
+    with _timed("conv3x3_wgrad", (B, H, W, Cin, Cout, int(stride)), 2 * B * Ho_ * Wo_ * Cout * 9 * Cin,
+                2 * (B * H * W * Cin + B * Ho_ * Wo_ * Cout) + 4 * 9 * Cin * Cout, g.device), _lib.device_guard(g.device):
         rc = lib.snipper_wgrad_conv3x3_bf16(_lib.raw_stream(g.device), g.data_ptr(), x.data_ptr(), B, H, W, Cin, Cout,
                                             int(stride), scale.data_ptr() if scale is not None else None, dw.data_ptr(),
                                             0, ws.data_ptr(), nbytes)
@@ -210,7 +260,8 @@ def linear_nn_bf16(x: torch.Tensor, w: torch.Tensor, residual: Optional[torch.Te
         a2 = gate.reshape(M, N)
         if a2.dtype != torch.bfloat16 or a2.stride(1) != 1 or a2.stride(0) % 4:
             a2 = a2.to(torch.bfloat16).contiguous()
-    with _lib.device_guard(x.device):
+    with _timed("linear_nn", (M, N, K), 2 * M * N * K,
+                2 * (M * K + N * K + M * N * (1 + (r2 is not None) + (a2 is not None))), x.device), _lib.device_guard(x.device):
         rc = _lib.load().snipper_linear_nn_bf16(
             _lib.raw_stream(x.device), x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0),
             r2.data_ptr() if r2 is not None else None, r2.stride(0) if r2 is not None else 0,
@@ -275,7 +326,7 @@ def wgrad_bf16(g: torch.Tensor, x: torch.Tensor, want_bias: bool = True, scale: 
         assert db.dtype == torch.float32 and db.is_contiguous()
     nbytes = lib.snipper_wgrad_workspace_bytes(M, N, Kc)
     ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=g.device)
-    with _lib.device_guard(g.device):
+    with _timed("wgrad", (M, N, Kc), 2 * M * N * Kc, 2 * (M * N + M * Kc) + 4 * N * Kc, g.device), _lib.device_guard(g.device):
         rc = lib.snipper_wgrad_bf16(
             _lib.raw_stream(g.device), g.data_ptr(), g.stride(0), x.data_ptr(), x.stride(0),
             M, N, Kc, scale.data_ptr() if scale is not None else None, dW.data_ptr(), dW.stride(0),

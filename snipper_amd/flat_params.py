@@ -37,6 +37,7 @@ class FlatParameters:
         assert all(p.device == dev and p.dtype == torch.float32 for p in self.params), "float32 parameters on one device"
         from .grad_sync import flat_offsets
         offsets, total = flat_offsets(self.params)            # the layout FlatGradSync uses for the same list
+        self.offsets: List[int] = list(offsets[:len(self.params)])
         self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
         if grad_flat is None:
             grad_flat = torch.zeros(total, dtype=torch.float32, device=dev)
@@ -100,26 +101,33 @@ class FlatParameters:
         torch.autograd.graph.increment_version(self.params)
 
 
-class FlatAdamW:
+class FlatAdamW(torch.optim.Optimizer):
     """``clip_grad_norm_(params, max_norm)`` + ``torch.optim.AdamW.step()`` (engine.py:74, main.py:201-221) over a
     ``FlatParameters`` as two launches of csrc/adamw_flat.cuh: partial sums of g^2, then one pass over parameter, gradient
     and both moments with the clipping coefficient applied on the fly (PyTorch's own path is 3 norm + 7 small + 3 scale
     + 4 fused AdamW launches on the same three tensors; measured 0.49 -> 0.3 ms per step).  Same arithmetic per element as
     ``torch.optim.AdamW(amsgrad=False)``; the gradient buffer is not rescaled in place (nothing reads it after the step).
 
-    ``param_groups`` mirrors the optimizer interface that schedulers use: one dict per FlatParameters group with ``lr``
-    and ``weight_decay`` (read at every step).  CUDA only: there is no CPU fallback -- use ``torch.optim.AdamW`` on
-    ``flat.leaves`` there."""
+    A ``torch.optim.Optimizer``: one param_group per non-empty FlatParameters group (its flat leaf as the only "params"
+    entry), so the reference's ``StepLR(optimizer, lr_drop)`` (main.py:222) and any other scheduler drive ``lr`` as usual.
+    ``state_dict()`` / ``load_state_dict()`` speak ``torch.optim.AdamW``'s per-parameter format over the MODEL's parameters
+    (``group_order`` = the FlatParameters group behind each group of the optimizer being mirrored: the reference's groups are
+    (main, backbone, slow), FlatParameters' (main, slow, backbone) -> ``group_order=(0, 2, 1)``), so the reference's
+    ``checkpoint['optimizer']`` (main.py:236-262) can be produced and resumed from.  CUDA only: there is no CPU fallback --
+    use ``torch.optim.AdamW`` on ``flat.leaves`` there."""
 
     N_PARTS = 2048
 
     def __init__(self, flat: "FlatParameters", lrs: Sequence[float], weight_decay: float = 1e-2, betas=(0.9, 0.999),
-                 eps: float = 1e-8):
+                 eps: float = 1e-8, group_order: Optional[Sequence[int]] = None):
         assert flat.flat.is_cuda, "FlatAdamW runs on the HIP kernels only"
         assert len(lrs) == len(flat.ranges)
         self.flat = flat
-        self.param_groups = [{"lr": float(lr), "weight_decay": float(weight_decay), "betas": tuple(betas), "eps": float(eps),
-                              "range": r} for lr, r in zip(lrs, flat.ranges)]
+        groups = [{"params": [flat.leaf_of_group(i)], "lr": float(lr), "flat_group": i}
+                  for i, lr in enumerate(lrs) if flat.leaf_of_group(i) is not None]
+        super().__init__(groups, dict(lr=float(lrs[0]), weight_decay=float(weight_decay), betas=tuple(betas), eps=float(eps)))
+        self.group_order = tuple(group_order) if group_order is not None else tuple(range(len(flat.ranges)))
+        assert sorted(self.group_order) == list(range(len(flat.ranges)))
         self.exp_avg = torch.zeros_like(flat.flat)
         self.exp_avg_sq = torch.zeros_like(flat.flat)
         self.partials = torch.zeros(self.N_PARTS, dtype=torch.float32, device=flat.flat.device)
@@ -133,14 +141,19 @@ class FlatAdamW:
         from . import _lib
         f = self.flat
         n = f.flat.numel()
-        groups = [g for g in self.param_groups if g["range"][1] > g["range"][0]]
+        groups = self.param_groups
         k = len(groups)
-        begin = (ctypes.c_longlong * k)(*[g["range"][0] for g in groups])
-        end = (ctypes.c_longlong * k)(*[g["range"][1] for g in groups])
+        # the kernel takes ONE (beta1, beta2, eps): refuse silently different values (after load_state_dict / a manual edit)
+        b1, b2 = groups[0]["betas"]
+        eps = groups[0]["eps"]
+        for g in groups[1:]:
+            if tuple(g["betas"]) != (b1, b2) or g["eps"] != eps:
+                raise RuntimeError("FlatAdamW: betas and eps must be the same in every param_group")
+        ranges = [f.ranges[g["flat_group"]] for g in groups]
+        begin = (ctypes.c_longlong * k)(*[r[0] for r in ranges])
+        end = (ctypes.c_longlong * k)(*[r[1] for r in ranges])
         lr = (ctypes.c_float * k)(*[g["lr"] for g in groups])
         wd = (ctypes.c_float * k)(*[g["weight_decay"] for g in groups])
-        b1, b2 = groups[0]["betas"]
-        self.step_count += 1
         lib = _lib.load()
         stream = _lib.raw_stream(f.flat.device)
         with _lib.device_guard(f.flat.device):
@@ -150,21 +163,70 @@ class FlatAdamW:
                                                              self.N_PARTS), "snipper_gradnorm_partials_f32")
                 parts = self.partials.data_ptr()
             _lib.check(lib.snipper_adamw_clip_f32(stream, f.flat.data_ptr(), f.grad_flat.data_ptr(), self.exp_avg.data_ptr(),
-                                                  self.exp_avg_sq.data_ptr(), n, begin, end, lr, wd, k, b1, b2, groups[0]["eps"],
-                                                  self.step_count, parts, self.N_PARTS if parts else 0, float(max_norm),
+                                                  self.exp_avg_sq.data_ptr(), n, begin, end, lr, wd, k, b1, b2, eps,
+                                                  self.step_count + 1, parts, self.N_PARTS if parts else 0, float(max_norm),
                                                   self.grad_norm.data_ptr()), "snipper_adamw_clip_f32")
+        self.step_count += 1          # (only once both launches were accepted: a refused launch must not advance the bias correction)
         f.after_step()
 
     def zero_grad(self, set_to_none: bool = True) -> None:
         self.flat.drop_param_grads()
 
-    def state_dict(self):
-        return {"step": self.step_count, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq,
-                "param_groups": [{k: v for k, v in g.items() if k != "range"} for g in self.param_groups]}
+    # ---- torch.optim.AdamW's state_dict format over the model's parameters -------------------------------------------
+    def _moment_views(self, buf: torch.Tensor):
+        f = self.flat
+        return [buf.as_strided(p.shape, p.stride(), off) for p, off in zip(f.params, f.offsets)]
 
+    def _ordered_param_indices(self):
+        """Index (in FlatParameters.params) of every model parameter, group by group in ``group_order``."""
+        f = self.flat
+        first = [0]
+        for g in f.groups:
+            first.append(first[-1] + len(g))
+        return [list(range(first[i], first[i + 1])) for i in self.group_order]
+
+    def state_dict(self):
+        ea, es = self._moment_views(self.exp_avg), self._moment_views(self.exp_avg_sq)
+        by_flat_group = {g["flat_group"]: g for g in self.param_groups}
+        state, groups, k = {}, [], 0
+        for fg, idxs in zip(self.group_order, self._ordered_param_indices()):
+            if not idxs:
+                continue
+            g = by_flat_group[fg]
+            groups.append({"lr": g["lr"], "betas": tuple(g["betas"]), "eps": g["eps"], "weight_decay": g["weight_decay"],
+                           "amsgrad": False, "maximize": False, "foreach": None, "capturable": False, "differentiable": False,
+                           "fused": None, **({"initial_lr": g["initial_lr"]} if "initial_lr" in g else {}),
+                           "params": list(range(k, k + len(idxs)))})
+            for i in idxs:
+                if self.step_count > 0:           # (torch's AdamW has no state for a parameter before its first step)
+                    state[k] = {"step": torch.tensor(float(self.step_count)), "exp_avg": ea[i].clone(),
+                                "exp_avg_sq": es[i].clone()}
+                k += 1
+        return {"state": state, "param_groups": groups}
+
+    @torch.no_grad()
     def load_state_dict(self, sd) -> None:
-        self.step_count = int(sd["step"])
-        self.exp_avg.copy_(sd["exp_avg"])
-        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
-        for g, s in zip(self.param_groups, sd["param_groups"]):
-            g.update(s)
+        ea, es = self._moment_views(self.exp_avg), self._moment_views(self.exp_avg_sq)
+        by_flat_group = {g["flat_group"]: g for g in self.param_groups}
+        order = [(fg, idxs) for fg, idxs in zip(self.group_order, self._ordered_param_indices()) if idxs]
+        if len(sd["param_groups"]) != len(order):
+            raise ValueError("FlatAdamW.load_state_dict: number of param_groups differs")
+        steps = set()
+        self.exp_avg.zero_(); self.exp_avg_sq.zero_()
+        for (fg, idxs), sg in zip(order, sd["param_groups"]):
+            if len(sg["params"]) != len(idxs):
+                raise ValueError("FlatAdamW.load_state_dict: a param_group has a different number of parameters")
+            g = by_flat_group[fg]
+            for key in ("lr", "betas", "eps", "weight_decay", "initial_lr"):
+                if key in sg:
+                    g[key] = tuple(sg[key]) if key == "betas" else sg[key]
+            for i, pid in zip(idxs, sg["params"]):
+                st = sd["state"].get(pid)
+                if st is None:
+                    steps.add(0)
+                    continue
+                ea[i].copy_(st["exp_avg"]); es[i].copy_(st["exp_avg_sq"])
+                steps.add(int(float(st["step"])))
+        if len(steps) > 1:
+            raise ValueError(f"FlatAdamW.load_state_dict: parameters at different steps {sorted(steps)} (one bias correction)")
+        self.step_count = steps.pop() if steps else 0

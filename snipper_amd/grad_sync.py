@@ -58,6 +58,11 @@ def _dense_view(flat: torch.Tensor, offset: int, like: torch.Tensor) -> torch.Te
     return flat.as_strided(like.shape, like.stride(), offset)
 
 
+class _DoneEvent:          # CPU tensors (gloo tests): the copy above is synchronous
+    def synchronize(self) -> None:
+        pass
+
+
 class _Stage:
     __slots__ = ("lo", "hi", "lo_elem", "hi_elem", "triggers", "pending", "ready", "launched", "works", "seen")
 
@@ -120,6 +125,10 @@ class FlatGradSync:
             else:
                 self.rest.append((i, i + 1))
         self.trace: Optional[list] = None          # set to [] to record (stage index, event on the compute stream) per launch
+        # "a gradient arrived late on SOME rank outside the agreed set": MAX-all-reduced with every sync() and read at the NEXT
+        # one (through pinned memory and an event of its own: no wait on the step in flight), so that all ranks raise together
+        self._err_dev = self._err_host = self._err_event = None
+        self._err_text = ""
         self.late_idx: Optional[List[int]] = None if late is None else sorted(index[id(p)] for p in late if id(p) in index)
         if not self.stages:
             self.late_idx = []                    # nothing is launched before sync(): nothing can arrive late
@@ -155,8 +164,10 @@ class FlatGradSync:
     @torch.no_grad()
     def _on_trigger(self, st: _Stage) -> None:
         """Runs on the autograd thread when one trigger parameter's gradient is complete."""
-        if st.launched:
-            raise RuntimeError("FlatGradSync: a second backward reached a stage whose all-reduce is already in flight; "
+        if st.launched or st.ready or st.pending <= 0:
+            # (ready but not launched = waiting for an earlier stage: a second backward would re-mark it and the stage would
+            #  later be packed from ACCUMULATED gradients -- ADVICE r03)
+            raise RuntimeError("FlatGradSync: a second backward reached a stage whose triggers have already fired; "
                                "call sync() after every backward (no gradient accumulation across backwards)")
         st.pending -= 1
         if st.pending > 0:
@@ -192,9 +203,23 @@ class FlatGradSync:
             # (detach() shares the parameter's version counter, .data does not: shadow.py keys its bf16 copies on it)
             dist.broadcast(t.detach() if isinstance(t, torch.nn.Parameter) else t, src, group=self.group)
 
+    def check_errors(self) -> None:
+        """Raise, on EVERY rank, if any rank saw an unexpected late gradient at the previous sync() (called by sync();
+        call it once more after the last step of a run)."""
+        if self._err_event is None:
+            return
+        self._err_event.synchronize()
+        self._err_event = None
+        if int(self._err_host[0]) != 0:
+            raise RuntimeError(
+                "FlatGradSync: on at least one rank a gradient was completed after its stage's all-reduce had been launched "
+                "and is not in the agreed set of late parameters (pass it in `late=`); that rank's slice was reduced from a "
+                "stale value in the previous step" + (": " + self._err_text if self._err_text else ""))
+
     @torch.no_grad()
     def sync(self) -> None:
         """Mean of the ranks' gradients into every ``p.grad`` (collective: every rank must call it)."""
+        self.check_errors()
         works = []
         # 1) everything that was not launched from a hook: pack and reduce now (stage by stage, then the uncovered rest)
         for st in self.stages:
@@ -232,12 +257,19 @@ class FlatGradSync:
                     flags[torch.tensor(local_late, device=flags.device)] = 1
                 dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=self.group)
                 self.late_idx = [int(i) for i in flags.nonzero().flatten().tolist()]
+            # A locally late gradient OUTSIDE the agreed set: raising here would leave the other ranks blocked in their next
+            # all-reduce until the process-group timeout.  This rank keeps the collective order, flags the step,
+            # and every rank raises from its next sync() / check_errors().
             unexpected = sorted(set(local_late) - set(self.late_idx))
-            if unexpected:
-                raise RuntimeError(
-                    f"FlatGradSync: the gradient of parameter #{unexpected[0]} was completed after its stage's all-reduce "
-                    "had been launched, and it is not in the agreed set of late parameters (pass it in `late=`): "
-                    "re-reducing it on this rank alone would break the collective order")
+            err_work = None
+            if self.stages and self._err_dev is None:
+                self._err_dev = torch.zeros(1, dtype=torch.int32, device=self.flat.device)
+                self._err_host = torch.zeros(1, dtype=torch.int32, pin_memory=self.flat.is_cuda)
+            if self.stages:                       # (without stages nothing is launched before sync(): nothing can be late)
+                self._err_dev.fill_(1 if unexpected else 0)
+                if unexpected:
+                    self._err_text = f"parameter #{unexpected[0]} on rank {dist.get_rank(self.group)}"
+                err_work = dist.all_reduce(self._err_dev, op=dist.ReduceOp.MAX, group=self.group, async_op=True)
             runs, prev = [], None
             for i in self.late_idx:               # re-pack: the complete local gradient (zeros if there is none)
                 g = self.params[i].grad
@@ -254,6 +286,14 @@ class FlatGradSync:
             for w in [dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
                       for a, b in runs]:
                 w.wait()
+            if err_work is not None:
+                err_work.wait()
+                self._err_host.copy_(self._err_dev, non_blocking=True)
+                if self.flat.is_cuda:
+                    self._err_event = torch.cuda.Event()
+                    self._err_event.record()
+                else:
+                    self._err_event = _DoneEvent()
             self.flat.mul_(1.0 / self.world)
         else:
             for i in local_late:

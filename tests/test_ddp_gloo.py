@@ -35,7 +35,7 @@ def _batch(b, rank, mode):
     if mode == "flat_stages" and rank:
         for t in tgt["targets"]:
             for k in ("kpts2d", "depth", "traj_ids"):
-                t[k] = t[k][rank:]
+                t[k] = t[k][min(rank, 3):]
     return imgs, tgt
 
 
@@ -91,7 +91,7 @@ def _worker(rank, world, port, out_dir, mode):
         if gsync is not None:
             assert gsync._early_done, "the early slice must have been launched from the hook"
             if mode == "flat_stages":
-                assert all(st.launched for st in gsync.stages) and len(gsync.stages) == 4
+                assert all(st.launched for st in gsync.stages) and len(gsync.stages) == 5
             gsync.sync()
         if it == 0:
             grads = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
@@ -109,7 +109,8 @@ def _worker(rank, world, port, out_dir, mode):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode,world", [("flat", 2), ("flat_late", 2), ("flat_params", 2), ("torch", 2), ("flat_stages", 4)])
+@pytest.mark.parametrize("mode,world", [("flat", 2), ("flat_late", 2), ("flat_params", 2), ("torch", 2), ("flat_stages", 4),
+                                        ("flat_stages", 8)])
 def test_gloo_step_matches_single_process(tmp_path, mode, world):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -214,10 +215,20 @@ def _toy_worker(rank, world, port, out_dir, case):
                 pass
             calls.clear()
             loss.backward()
-            if case == "late":
+            if case in ("late", "unexpected_late"):
                 b.grad = b.grad + 1.0 + rank
+            if case == "unexpected_late" and rank == 1 and step == 1:
+                a.grad = a.grad * 2.0        # late on ONE rank and outside the set agreed at step 0 ({b})
             local.append([None if p.grad is None else p.grad.clone() for p in ps])
+            if case == "unexpected_late" and step == 2:
+                # rank 1 must not raise alone at step 1 (rank 0 would hang in its next all-reduce): the step
+                # completes everywhere and BOTH ranks raise from the next sync()
+                with pytest.raises(RuntimeError, match="late"):
+                    gs.sync()
+                break
             gs.sync()
+            if case == "unexpected_late" and step == 1:
+                continue                     # (rank 1's slice of `a` was reduced from the stale value: that is the error)
             n_calls = list(calls)
             got = [p.grad.clone() for p in ps]
             # mean over ranks of the local gradients, gathered for the check
@@ -229,7 +240,7 @@ def _toy_worker(rank, world, port, out_dir, case):
                                            msg=lambda m: f"{case} rank {rank} step {step} param {i}: {m}")
             if case == "unstaged":
                 assert len(n_calls) == 2, n_calls            # 6 parameters, 2 messages (chunks=2), not 6
-            if case == "late":
+            if case in ("late", "unexpected_late"):
                 assert gs.late_idx == [1]                    # agreed at the first sync(), fixed from then on
     finally:
         dist.all_reduce = orig
@@ -237,7 +248,7 @@ def _toy_worker(rank, world, port, out_dir, case):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("case", ["unstaged", "staged", "unused_trigger", "late"])
+@pytest.mark.parametrize("case", ["unstaged", "staged", "unused_trigger", "late", "unexpected_late"])
 def test_flat_grad_sync_toy_cases(tmp_path, case):
     """uncovered parameters are reduced as runs (message count); VERDICT r02 #6: a trigger parameter without a
     gradient on ONE rank must not change the order of the collectives; a late gradient is re-reduced on every rank."""

@@ -74,8 +74,70 @@ def test_flat_adamw_is_deterministic_and_state_round_trips():
         grad = torch.randn(fa.flat.numel(), generator=g).to(DEV)
         fa.grad_flat.copy_(grad); fb.grad_flat.copy_(grad)
         if step == 2:                                   # b continues from a's state through the state_dict
-            ob.load_state_dict(oa.state_dict())
+            sd = oa.state_dict()
+            assert all(v["exp_avg"].data_ptr() != oa.exp_avg.data_ptr() for v in sd["state"].values())    # copies, not live views
+            ob.load_state_dict(sd)
             fb.flat.copy_(fa.flat)
         oa.step(0.1); ob.step(0.1)
         if step != 1:
             assert torch.equal(fa.flat, fb.flat)
+
+
+def test_flat_adamw_is_an_optimizer_schedulers_and_torch_state_dicts_work():
+    """the reference wraps its optimizer in ``StepLR`` (main.py:222) and checkpoints ``optimizer.state_dict()``
+    (main.py:236-262).  FlatAdamW is a torch.optim.Optimizer; its state_dict is torch.optim.AdamW's over the MODEL's
+    parameters in the mirrored optimizer's group order, in both directions."""
+    ref, new = _model(2), _model(2)
+    lrs = [1e-2, 1e-3, 3e-3]                       # of the flat groups (g0, g1, g2)
+    order = (0, 2, 1)                              # the mirrored optimizer lists them as (g0, g2, g1)
+    rg = _groups(ref)
+    opt_ref = torch.optim.AdamW([{"params": rg[i], "lr": lrs[i]} for i in order], lr=1e-2, weight_decay=1e-2, fused=False,
+                                foreach=False)
+    fp = FlatParameters(_groups(new))
+    opt_new = FlatAdamW(fp, lrs, weight_decay=1e-2, group_order=order)
+    assert isinstance(opt_new, torch.optim.Optimizer)
+    sch_ref = torch.optim.lr_scheduler.StepLR(opt_ref, 2, gamma=0.5)
+    sch_new = torch.optim.lr_scheduler.StepLR(opt_new, 2, gamma=0.5)
+    g = torch.Generator().manual_seed(8)
+
+    def one_step(copy_grads=True):
+        x = torch.randn(5, 3, 9, 9, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+        y = torch.randn(5, 5, generator=g).to(DEV)
+        opt_ref.zero_grad(set_to_none=True)
+        (ref(x) - y).pow(2).sum().backward()
+        with torch.no_grad():
+            for gv, p in zip(fp.grad_views, ref.parameters()):
+                gv.copy_(p.grad)
+        opt_ref.step(); opt_new.step(0.0)
+        sch_ref.step(); sch_new.step()
+
+    for _ in range(3):
+        one_step()
+    assert [g_["lr"] for g_ in opt_new.param_groups] == [lrs[0] * 0.5, lrs[1] * 0.5, lrs[2] * 0.5]      # StepLR fired once
+    for a, b in zip(ref.parameters(), new.parameters()):
+        torch.testing.assert_close(b, a, rtol=2e-5, atol=2e-7)
+    # FlatAdamW -> torch.optim.AdamW: same keys / group layout, loads, and the next step agrees
+    sd_new, sd_ref = opt_new.state_dict(), opt_ref.state_dict()
+    assert [len(g_["params"]) for g_ in sd_new["param_groups"]] == [len(g_["params"]) for g_ in sd_ref["param_groups"]]
+    assert [g_["lr"] for g_ in sd_new["param_groups"]] == [g_["lr"] for g_ in sd_ref["param_groups"]]
+    for k, st in sd_ref["state"].items():
+        torch.testing.assert_close(sd_new["state"][k]["exp_avg"], st["exp_avg"], rtol=2e-5, atol=1e-9)
+        torch.testing.assert_close(sd_new["state"][k]["exp_avg_sq"], st["exp_avg_sq"], rtol=2e-5, atol=1e-12)
+        assert float(sd_new["state"][k]["step"]) == float(st["step"])
+    opt_ref.load_state_dict(sd_new)
+    # torch.optim.AdamW -> FlatAdamW on a fresh optimizer
+    new2 = _model(2)
+    fp2 = FlatParameters(_groups(new2))
+    with torch.no_grad():
+        fp2.flat.copy_(fp.flat)
+    opt2 = FlatAdamW(fp2, lrs, weight_decay=1e-2, group_order=order)
+    opt2.load_state_dict(sd_ref)
+    assert opt2.step_count == 3 and [g_["lr"] for g_ in opt2.param_groups] == [g_["lr"] for g_ in opt_new.param_groups]
+    grad = torch.randn(fp.flat.numel(), generator=g).to(DEV)
+    fp.grad_flat.copy_(grad); fp2.grad_flat.copy_(grad)
+    opt_new.step(0.1); opt2.step(0.1)
+    torch.testing.assert_close(fp2.flat, fp.flat, rtol=2e-5, atol=2e-7)
+    # betas / eps that differ between groups are refused instead of silently ignored
+    opt2.param_groups[1]["eps"] = 1e-6
+    with pytest.raises(RuntimeError):
+        opt2.step(0.0)

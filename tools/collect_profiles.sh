@@ -18,6 +18,7 @@ pass tcc TCC_HIT_sum TCC_MISS_sum
 cd $R
 sumfile() { ls $out/pmc_$1/*/*counter_collection.csv 2>/dev/null | head -1; }
 {
+  echo "# srchash=$(cat snipper_amd/libsnipper_msda.so.srchash)"
   echo "kernel,counter,dispatches,mean_value_KB"
   for c in FETCH_SIZE; do f=$(sumfile fetch); [ -n "$f" ] && python3 tools/pmc_summary.py $f $c snipper:: | head -16; done
   for c in WRITE_SIZE; do f=$(sumfile write); [ -n "$f" ] && python3 tools/pmc_summary.py $f $c snipper:: | head -16; done
@@ -33,11 +34,11 @@ sumfile() { ls $out/pmc_$1/*/*counter_collection.csv 2>/dev/null | head -1; }
   echo "kernel,counter,dispatches,mean_value"
   f=$(sumfile lds)
   for c in SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY; do
-    [ -n "$f" ] && python3 tools/pmc_summary.py $f $c msda_bwd_d48_tile2 msda_bwd_d48_patchbin msda_fwd_d48 wres_gemm wgrad_ring
+    [ -n "$f" ] && python3 tools/pmc_summary.py $f $c msda_bwd_d48_tile3 msda_bwd_d48_patchbin msda_fwd_d48 wres_gemm wgrad_ring
   done
   f=$(sumfile tcc)
   for c in TCC_HIT_sum TCC_MISS_sum; do
-    [ -n "$f" ] && python3 tools/pmc_summary.py $f $c msda_bwd_d48_tile2 msda_bwd_d48_patchbin msda_fwd_d48 wres_gemm wgrad_ring wgrad_bf16_kernel
+    [ -n "$f" ] && python3 tools/pmc_summary.py $f $c msda_bwd_d48_tile3 msda_bwd_d48_patchbin msda_fwd_d48 wres_gemm wgrad_ring wgrad_bf16_kernel
   done
 } > $out/pmc_lds_tcc.csv
 rm -rf $out/pmc_fetch $out/pmc_write $out/pmc_mfma $out/pmc_lds $out/pmc_tcc
