@@ -500,6 +500,9 @@ def set_offset_sigma(model, sigma_px: float, net, batch, amp: bool) -> None:
         for i, layer in enumerate(layers):
             w = layer.self_attn.sampling_offsets[0].weight
             w.copy_((torch.randn(w.shape, generator=gen) * (sigma_px / max(norms.get(i, 1.0), 1e-6))).to(w.device))
+            # the scale was measured on THIS rank's batch: every replica takes rank 0's weights
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                dist.broadcast(w.detach(), 0)
 
 
 def main():
@@ -945,6 +948,7 @@ def main():
     if rank == 0 and world == 1 and not a.no_extras and not a.no_locality_sweep and graph is None:
         locality.append({"offset_sigma_px": a.offset_sigma_px, "ms_per_step": round(elapsed / a.steps * 1e3, 3),
                          "encoder_bwd_ms_per_launch": owner_bwd_ms(launches), "note": "the timed region"})
+        saved_offsets = [l.self_attn.sampling_offsets[0].weight.detach().clone() for l in model.transformer.encoder.layers]
         for sig in (3.0, 8.0):
             if sig == a.offset_sigma_px:
                 continue
@@ -971,6 +975,10 @@ def main():
             MSDA.enable_launch_timing(False)
             locality.append({"offset_sigma_px": sig, "ms_per_step": round(ms, 3), "encoder_bwd_ms_per_launch": owner_bwd_ms(ls),
                              "mean_ms_per_step": round(mean_ms, 3), "note": "median of 16 steps after 6 warm-up steps"})
+        with torch.no_grad():                  # what runs after the sweep (module timings) sees the model as it was
+            for l, w0 in zip(model.transformer.encoder.layers, saved_offsets):
+                l.self_attn.sampling_offsets[0].weight.copy_(w0)
+            torch.autograd.graph.increment_version([l.self_attn.sampling_offsets[0].weight for l in model.transformer.encoder.layers])
 
     if rank == 0:
         snippets = a.batch * world * a.steps

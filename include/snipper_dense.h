@@ -27,8 +27,12 @@ extern "C" {
  * X/W rows 16-byte aligned (ldx % 8 == 0), Y/R rows 8-byte aligned (ldy, ldr % 4 == 0).
  * Accumulation in float32, one rounding to bf16 at the end.
  * dropout_p > 0 applies inverted dropout AFTER the activation in the same epilogue (the FFN's
- * ``dropout(relu(linear1(x)))``, models/deformable_transformer.py:196): element (m, n) is kept iff a counter-based
- * hash of (seed, m * N + n) is >= p * 2^32; kept values are scaled by 1 / (1 - p).  M * N < 2^32 then. */
+ * ``dropout(relu(linear1(x)))``, models/deformable_transformer.py:196); kept values are scaled by 1 / (1 - p).
+ * WHICH elements are kept is IMPLEMENTATION-DEFINED: a deterministic function of (seed, shape, device) that is not
+ * part of the contract -- the tile kernel hashes (seed, m * N + n), the weight-stationary kernel this entry forwards to
+ * for K in {288, 384}, M >= 8192 draws 16-bit uniforms per thread (snipper_linear_wres_bf16 below; p resolved to 2^-16,
+ * the stream depends on the device's CU count).  A caller must recover the mask FROM THE OUTPUT (with relu != 0 a kept,
+ * active element is > 0 -- what this package's backward does) and never regenerate it from the seed.  M * N < 2^32. */
 int snipper_linear_bf16(void *stream, const uint16_t *X, long long ldx, const uint16_t *W,
                         const float *bias, const uint16_t *R, long long ldr, uint16_t *Y, long long ldy,
                         int M, int N, int K, int relu, float dropout_p, uint64_t seed);

@@ -52,9 +52,19 @@ def build_hip(force: bool = False, verbose: bool = False) -> str:
     """Compile csrc/*.hip into LIB_PATH if it is missing or was built from different sources (source_hash)."""
     if not force and is_current():
         return LIB_PATH
+    # the timing-ablation builds (-DWRES_STAMPS, -DTILE2_STAMPS: in-kernel stamps, slower kernels) must never become the
+    # product library: they need a library name of their own (SNIPPER_MSDA_LIB)
+    if any(f.startswith("-D") and "STAMPS" in f for f in HIPCC_FLAGS) and os.path.basename(LIB_PATH) == "libsnipper_msda.so":
+        raise RuntimeError("diagnostic build flags (…_STAMPS) need SNIPPER_MSDA_LIB=<another file name>")
     hipcc = hipcc_path()
     if hipcc is None:
         if os.path.exists(LIB_PATH):         # a box without the compiler uses the library that travelled with the tree
+            if not is_current() and os.environ.get("SNIPPER_ALLOW_STALE_LIB") != "1":
+                # kernels' argument structs / workspace layouts / exports change with the sources: a stale library fails
+                # with an opaque missing symbol at best and runs old kernels against new host code at worst
+                raise RuntimeError(
+                    f"{LIB_PATH} was built from other sources than the tree's (source hash mismatch) and hipcc is not "
+                    "available to rebuild it; set SNIPPER_ALLOW_STALE_LIB=1 to load it anyway")
             return LIB_PATH
         raise RuntimeError("hipcc not found: cannot build libsnipper_msda.so (gfx950)")
     cmd = [hipcc] + HIPCC_FLAGS + ["-o", LIB_PATH + ".tmp"] + [os.path.join(CSRC, s) for s in SOURCES]

@@ -270,7 +270,9 @@ bool make_patch_plan(const CoreDims &d, const int64_t *hs, const snipper_msda_co
 }
 
 // workspace of the owner-computes backward: the marks
-inline long long patch_workspace_bytes(long long nm, const PatchPlan &plan) { return nm * plan.words_per_nm * 8; }
+inline long long patch_workspace_bytes(long long nm, const PatchPlan &plan) {
+  return nm * plan.words_per_nm * 8 + (nm * plan.total_tiles + 7) / 8 * 8;       // marks, then one dirty byte per tile
+}
 
 template <typename VT>
 int backward_d48_patch(hipStream_t st, const void *grad_out, const VT *value, const float *loc, const float *attn,
@@ -278,6 +280,7 @@ int backward_d48_patch(hipStream_t st, const void *grad_out, const VT *value, co
                        float *grad_attn, int go_bf16, bool mfma_tiles) {
   const long long nm = (long long)d.N * d.M;
   plan.marks = reinterpret_cast<unsigned long long *>(workspace);
+  plan.dirty = reinterpret_cast<unsigned char *>(plan.marks + nm * plan.words_per_nm);
   hipError_t e = hipMemsetAsync(plan.marks, 0, (size_t)patch_workspace_bytes(nm, plan), st);
   if (e != hipSuccess) return (int)e;
   // 1) query side: grad_loc / grad_attn, marks, HBM atomics for the taps no tile owns
@@ -293,6 +296,11 @@ int backward_d48_patch(hipStream_t st, const void *grad_out, const VT *value, co
     // grad_value side: dense per-tile scatter on the matrix pipe (msda_d48_tilemm.cuh) unless the caller asks for the
     // vector / LDS kernel (config.tile_kernel = 1), see patch_uses_mfma
     if (mfma_tiles) {
+      // persistent: two workgroups per CU (its LDS footprint), a multiple of the 8 XCDs
+      // (persistent workgroups -- two per CU walking a static list of tiles with the next tile's marks prefetched -- were
+      //  measured: 373 / 544 / 664 us at sigma 0 / 3 / 8 px against 330 / 478 / 588 for one workgroup per tile: the
+      //  dispatcher balances the very unequal tiles better than a static list, and the fixed cost is not launch latency but
+      //  the read-modify-write of grad_value)
       hipLaunchKernelGGL(msda_bwd_d48_tile3_kernel, dim3((unsigned)nblk_tiles), dim3(kPatchThreads), 0, st, grad_out, loc, attn,
                          d, plan, grad_value);
       g_last_variant = plan.debug ? "d48_owner_mfma_debug" : "d48_owner_mfma";

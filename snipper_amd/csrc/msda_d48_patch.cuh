@@ -70,6 +70,7 @@ struct PatchPlan {
   long long lvl_base[kPatchMaxLevels];
   long long words_per_nm;
   unsigned long long *marks;    // [N*M][words_per_nm], zeroed per backward call
+  unsigned char *dirty;         // [N*M][total_tiles], zeroed with the marks: 1 = a tap no tile owns (HBM atomic) landed in this tile
   // size ratios rw[a][b] = (float)W_a / (float)W_b (rh likewise), computed on the host with IEEE float division: the
   // anchor arithmetic both kernels must agree on, without per-thread divisions (bit-identical to __fdiv_rn)
   float rw[kPatchMaxLevels][kPatchMaxLevels], rh[kPatchMaxLevels][kPatchMaxLevels];
@@ -396,6 +397,10 @@ __global__ __launch_bounds__(kPatchThreads) void msda_bwd_d48_patchbin_kernel(
           }
         }
         my_bits |= (in_map && !owned) ? (16u << k) : 0u;        // need: no tile owns the tap -> HBM atomic here
+        // ... and the tile it lands in is told so (plain byte stores of the same value: no atomic needed), which lets the
+        // matrix-pipe tile kernel start clean tiles from zero instead of reading grad_value back
+        if (in_map && !owned)
+          plan.dirty[((size_t)b.n * d.M + b.m) * plan.total_tiles + lvl.tile_base + (ty >> lvl.shift) * lvl.ntx + (tx >> lvl.shift)] = 1;
       }
       r.w.w = __uint_as_float(my_bits);
       r.g.x = go[0]; r.g.y = go[1]; r.g.z = go[2]; r.g.w = go[3];
