@@ -153,6 +153,17 @@ int snipper_add_dropout_layernorm_forward(void *stream, const void *x, int x_dt,
                                           int rows, int C, float p, float eps, uint64_t seed,
                                           float *s_save, float *mean, float *rstd, uint8_t *keep,
                                           float *y32, uint16_t *y16, uint16_t *yq16);
+/* The same with a LAZY residual: when x_mean / x_rstd [rows] and x_gamma / x_beta [C] are given (all four or none), `x`
+ * (float32) is the s_save of the PREVIOUS sub-layer's call and its LayerNorm output is recomputed on load,
+ *   x := (x - x_mean[row]) * x_rstd[row] * x_gamma + x_beta,
+ * so that call need not write y32 at all (a chain of sub-layers keeps only the s_save arrays its backward needs anyway).
+ * The gradient of this call's x (dx of the backward below) is the previous call's g32, as before. */
+int snipper_add_dropout_layernorm_forward_ex(void *stream, const void *x, int x_dt, const float *x_mean, const float *x_rstd,
+                                             const float *x_gamma, const float *x_beta, const void *z, int z_dt,
+                                             const void *pos, int pos_dt, const float *gamma, const float *beta,
+                                             int rows, int C, float p, float eps, uint64_t seed,
+                                             float *s_save, float *mean, float *rstd, uint8_t *keep,
+                                             float *y32, uint16_t *y16, uint16_t *yq16);
 /* Backward of the above.  g32 / g16 / gq16 = gradients of y32 / y16 / yq16 (any non-empty subset; they are summed).
  * dx (= dL/ds) and dz (masked and rescaled) may each be NULL; dgamma / dbeta [C] float32 are overwritten (summed in
  * a fixed order through `workspace`, >= snipper_add_dropout_layernorm_workspace_bytes(rows, C) bytes). */

@@ -44,6 +44,9 @@ EXPORTS = {
     "snipper_add_dropout_layernorm_forward": ([c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p,
                                                c_void_p, c_int, c_int, ctypes.c_float, ctypes.c_float,
                                                ctypes.c_uint64] + [c_void_p] * 7, c_int),
+    "snipper_add_dropout_layernorm_forward_ex": ([c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                                  c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, ctypes.c_float,
+                                                  ctypes.c_float, ctypes.c_uint64] + [c_void_p] * 7, c_int),
     "snipper_add_dropout_layernorm_workspace_bytes": ([c_int, c_int], c_size_t),
     "snipper_add_dropout_layernorm_backward": ([c_void_p] * 9 + [c_int, c_int, ctypes.c_float, c_void_p, c_int,
                                                 c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_size_t], c_int),

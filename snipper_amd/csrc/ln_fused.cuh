@@ -28,6 +28,11 @@ constexpr int kLnMaxIter = 4;        // 64 lanes x 4 elements x 4 = C <= 1024
 constexpr int kLnThreads = 256;      // 4 rows per workgroup
 
 struct LnFwdArgs {
+  // "lazy" residual: x is the PREVIOUS LayerNorm's saved pre-norm sum and its output is recomputed on load,
+  //   x := (x - x_mean[row]) * x_rstd[row] * x_gamma + x_beta      (float32 x only)
+  // -- the expression that kernel would have written as y32, so a chain of sub-layers never materialises the float32
+  // residual stream between two LayerNorms (121 MB written and 121 MB allocated less per encoder sub-layer).  NULL = plain x.
+  const float *x_mean, *x_rstd, *x_gamma, *x_beta;
   const void *x; int x_dt;           // [rows][C] residual; dtype code 0 = f32, 1 = bf16
   const void *z; int z_dt;           // [rows][C] branch output, or nullptr (plain LayerNorm of x)
   const void *pos; int pos_dt;       // [rows][C] addend of the third output, or nullptr
@@ -90,12 +95,18 @@ __global__ __launch_bounds__(kLnThreads) void ln_fused_fwd_kernel(LnFwdArgs a) {
   const uint32_t thresh = (uint32_t)fminf(a.p * 4294967296.f, 4294967040.f);
   float4 v[kLnMaxIter];
   float sum = 0.f;
+  const float xm = a.x_mean ? a.x_mean[row] : 0.f, xr = a.x_mean ? a.x_rstd[row] : 1.f;
 #pragma unroll
   for (int it = 0; it < kLnMaxIter; ++it) {
     const int c = (lane + 64 * it) * 4;
     v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (c < a.C) {
       float4 x = ln_load4(a.x, a.x_dt, base + c);
+      if (a.x_mean) {
+        const float4 gm = *reinterpret_cast<const float4 *>(a.x_gamma + c), bt = *reinterpret_cast<const float4 *>(a.x_beta + c);
+        x.x = (x.x - xm) * xr * gm.x + bt.x; x.y = (x.y - xm) * xr * gm.y + bt.y;
+        x.z = (x.z - xm) * xr * gm.z + bt.z; x.w = (x.w - xm) * xr * gm.w + bt.w;
+      }
       if (a.z) {
         float4 z = ln_load4(a.z, a.z_dt, base + c);
         if (a.p > 0.f) {

@@ -905,20 +905,33 @@ inline int ln_bwd_blocks(int rows) { return std::max(1, std::min((rows + 3) / 4,
 inline bool ln_dt_ok(int dt) { return dt == 0 || dt == 1; }
 }  // namespace
 
+int snipper_add_dropout_layernorm_forward_ex(void *stream, const void *x, int x_dt, const float *x_mean, const float *x_rstd,
+                                             const float *x_gamma, const float *x_beta, const void *z, int z_dt,
+                                             const void *pos, int pos_dt, const float *gamma, const float *beta,
+                                             int rows, int C, float p, float eps, uint64_t seed,
+                                             float *s_save, float *mean, float *rstd, uint8_t *keep,
+                                             float *y32, uint16_t *y16, uint16_t *yq16) {
+  if (!x || !gamma || !beta || (!y32 && !y16 && !yq16)) return SNIPPER_E_NULL;
+  if ((yq16 && !pos) || ((mean == nullptr) != (rstd == nullptr))) return SNIPPER_E_NULL;
+  const bool lazy = x_mean || x_rstd || x_gamma || x_beta;
+  if (lazy && (!x_mean || !x_rstd || !x_gamma || !x_beta)) return SNIPPER_E_NULL;
+  if (rows <= 0 || C <= 0 || C % 4 || C > kLnMaxIter * 256 || !(p >= 0.f && p < 1.f) ||
+      (long long)rows * C >= (1LL << 32) || !ln_dt_ok(x_dt) || !ln_dt_ok(z_dt) || !ln_dt_ok(pos_dt) || (lazy && x_dt != 0))
+    return SNIPPER_E_SHAPE;
+  const LnFwdArgs a{x_mean, x_rstd, x_gamma, x_beta, x, x_dt, z, z_dt, pos, pos_dt, gamma, beta, s_save, mean, rstd,
+                    (z && p > 0.f) ? keep : nullptr, y32, y16, yq16, rows, C, z ? p : 0.f, eps, (uint32_t)seed,
+                    (uint32_t)(seed >> 32)};
+  hipLaunchKernelGGL(ln_fused_fwd_kernel, dim3((rows + 3) / 4), dim3(kLnThreads), 0, (hipStream_t)stream, a);
+  return launch_status();
+}
+
 int snipper_add_dropout_layernorm_forward(void *stream, const void *x, int x_dt, const void *z, int z_dt,
                                           const void *pos, int pos_dt, const float *gamma, const float *beta,
                                           int rows, int C, float p, float eps, uint64_t seed,
                                           float *s_save, float *mean, float *rstd, uint8_t *keep,
                                           float *y32, uint16_t *y16, uint16_t *yq16) {
-  if (!x || !gamma || !beta || (!y32 && !y16 && !yq16)) return SNIPPER_E_NULL;
-  if ((yq16 && !pos) || ((mean == nullptr) != (rstd == nullptr))) return SNIPPER_E_NULL;
-  if (rows <= 0 || C <= 0 || C % 4 || C > kLnMaxIter * 256 || !(p >= 0.f && p < 1.f) ||
-      (long long)rows * C >= (1LL << 32) || !ln_dt_ok(x_dt) || !ln_dt_ok(z_dt) || !ln_dt_ok(pos_dt))
-    return SNIPPER_E_SHAPE;
-  const LnFwdArgs a{x, x_dt, z, z_dt, pos, pos_dt, gamma, beta, s_save, mean, rstd, (z && p > 0.f) ? keep : nullptr,
-                    y32, y16, yq16, rows, C, z ? p : 0.f, eps, (uint32_t)seed, (uint32_t)(seed >> 32)};
-  hipLaunchKernelGGL(ln_fused_fwd_kernel, dim3((rows + 3) / 4), dim3(kLnThreads), 0, (hipStream_t)stream, a);
-  return launch_status();
+  return snipper_add_dropout_layernorm_forward_ex(stream, x, x_dt, nullptr, nullptr, nullptr, nullptr, z, z_dt, pos, pos_dt, gamma,
+                                                  beta, rows, C, p, eps, seed, s_save, mean, rstd, keep, y32, y16, yq16);
 }
 
 size_t snipper_add_dropout_layernorm_workspace_bytes(int rows, int C) {

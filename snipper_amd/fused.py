@@ -206,10 +206,15 @@ class AddDropoutLayerNorm(Function):
 
     x [..., C] float32 / bf16, z like x (float32 / bf16) or None, pos like x or None, gamma / beta [C] float32.
     ``want`` = (y32, y16, yq16) flags; returns those three (None where not wanted): y in float32, y in bf16 and
-    bf16(y + pos).  ``seed`` None draws a fresh one."""
+    bf16(y + pos).  ``seed`` None draws a fresh one.
+
+    LAZY float32 output (``want[0] == "lazy"``): y32 is not written; the first result is the saved pre-norm sum, tagged
+    (``_lazy_ln``) with this call's statistics and affine parameters, and stands for y32 ONLY as the ``x`` of the next
+    ``add_dropout_layer_norm``, whose kernel recomputes this LayerNorm's output on load (csrc/ln_fused.cuh).  The autograd
+    edge is the ordinary one: the next call's dx is this call's g32."""
 
     @staticmethod
-    def forward(ctx, x, z, pos, gamma, beta, p, eps, want, seed):
+    def forward(ctx, x, z, pos, gamma, beta, p, eps, want, seed, lazy_x=None):
         x = x.contiguous()
         z = z.contiguous() if z is not None else None
         pos = pos.contiguous() if pos is not None else None
@@ -221,22 +226,33 @@ class AddDropoutLayerNorm(Function):
         s_save = torch.empty((rows, C), dtype=torch.float32, device=dev) if need_bwd else None
         stats = torch.empty((2, rows), dtype=torch.float32, device=dev) if need_bwd else None
         keep = torch.empty((rows, C // 4), dtype=torch.uint8, device=dev) if (need_bwd and p > 0) else None
-        y32 = torch.empty(x.shape, dtype=torch.float32, device=dev) if want[0] else None
+        lazy_out = want[0] == "lazy"
+        if lazy_out:
+            assert need_bwd, "a lazy float32 output is the saved pre-norm sum: it exists only when a backward will run"
+        y32 = torch.empty(x.shape, dtype=torch.float32, device=dev) if (want[0] and not lazy_out) else None
         y16 = torch.empty(x.shape, dtype=torch.bfloat16, device=dev) if want[1] else None
         yq = torch.empty(x.shape, dtype=torch.bfloat16, device=dev) if want[2] else None
         g32, b32 = gamma.float(), beta.float()
         ptr = lambda t: t.data_ptr() if t is not None else None
+        lx = lazy_x if lazy_x is not None else (None, None, None)          # (stats [2, rows], gamma32, beta32) of x's producer
+        if lazy_x is not None:
+            assert x.dtype == torch.float32 and lx[0].shape == (2, rows)
         with _lib.device_guard(dev):
-            rc = _lib.load().snipper_add_dropout_layernorm_forward(
-                _stream(dev), x.data_ptr(), _DT[x.dtype], ptr(z), _DT[z.dtype] if z is not None else 0,
+            rc = _lib.load().snipper_add_dropout_layernorm_forward_ex(
+                _stream(dev), x.data_ptr(), _DT[x.dtype],
+                lx[0][0].data_ptr() if lazy_x is not None else None, lx[0][1].data_ptr() if lazy_x is not None else None,
+                ptr(lx[1]), ptr(lx[2]), ptr(z), _DT[z.dtype] if z is not None else 0,
                 ptr(pos), _DT[pos.dtype] if pos is not None else 0, g32.data_ptr(), b32.data_ptr(), rows, C,
                 p, float(eps), int(seed if seed is not None else (_next_seed() if p > 0 else 0)), ptr(s_save),
                 stats[0].data_ptr() if stats is not None else None, stats[1].data_ptr() if stats is not None else None,
                 ptr(keep), ptr(y32), ptr(y16), ptr(yq))
-        _lib.check(rc, "snipper_add_dropout_layernorm_forward")
-        ctx.save_for_backward(s_save, stats, keep, g32)
+        _lib.check(rc, "snipper_add_dropout_layernorm_forward_ex")
         ctx.meta = (p, x.dtype, None if z is None else z.dtype, None if pos is None else pos.dtype, x.shape,
                     gamma.dtype, beta.dtype)
+        ctx.save_for_backward(s_save, stats, keep, g32)
+        if lazy_out:
+            ctx.lazy_aux = (stats, g32, b32)         # add_dropout_layer_norm tags the result with it
+            return s_save.view(x.shape), y16, yq
         return y32, y16, yq
 
     @staticmethod
@@ -246,7 +262,7 @@ class AddDropoutLayerNorm(Function):
         rows, C = s_save.shape
         dev = s_save.device
         if g32 is None and g16 is None and gq is None:
-            return (None,) * 9
+            return (None,) * 10
         g32 = g32.contiguous().float() if g32 is not None else None
         g16 = g16.contiguous().to(torch.bfloat16) if g16 is not None else None
         gq = gq.contiguous().to(torch.bfloat16) if gq is not None else None
@@ -266,14 +282,23 @@ class AddDropoutLayerNorm(Function):
         dpos = gq if (pos_dt is not None and ctx.needs_input_grad[2]) else None
         dgamma = dgb[0].to(gamma_dt) if ctx.needs_input_grad[3] else None
         dbeta = dgb[1].to(beta_dt) if ctx.needs_input_grad[4] else None
-        return dx, dz, dpos, dgamma, dbeta, None, None, None, None
+        return dx, dz, dpos, dgamma, dbeta, None, None, None, None, None
 
 
 def add_dropout_layer_norm(x, z, norm: torch.nn.LayerNorm, p: float, training: bool, pos=None,
                            want=(True, False, False), seed=None):
     """``norm(x + dropout(z, p, training))`` on the fused kernel -> (y32, y16, yq16) per ``want``.  The caller checks
-    ``ln_fusable`` first."""
-    return AddDropoutLayerNorm.apply(x, z, pos, norm.weight, norm.bias, p if training else 0.0, norm.eps, tuple(want), seed)
+    ``ln_fusable`` first.  ``want[0] == "lazy"``: the float32 result is not materialised (see AddDropoutLayerNorm); it is
+    honoured only when a backward will run (otherwise there is no saved sum to stand for it) and falls back to True."""
+    want = tuple(want)
+    if want[0] == "lazy" and not (torch.is_grad_enabled() and (x.requires_grad or (z is not None and z.requires_grad) or
+                                                               norm.weight.requires_grad)):
+        want = (True,) + want[1:]
+    lazy_x = getattr(x, "_lazy_ln", None)
+    out = AddDropoutLayerNorm.apply(x, z, pos, norm.weight, norm.bias, p if training else 0.0, norm.eps, want, seed, lazy_x)
+    if want[0] == "lazy":
+        out[0]._lazy_ln = out[0].grad_fn.lazy_aux
+    return out
 
 
 def ln_fusable(x: torch.Tensor, norm: torch.nn.LayerNorm) -> bool:

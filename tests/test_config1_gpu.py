@@ -106,8 +106,11 @@ def test_config1_bf16_autocast_path_runs_the_tied_sampler_with_one_frame():
     # test found (merged offset bias lost under autocast) gave 0.39-0.55
     for k, v in errs.items():
         assert v <= 8e-2, (k, v)
+    # measured (round 4): the first encoder layer's sampling_offsets weight 0.22 (its gradient passes through every bf16 layer
+    # above it and the bilinear kernel's derivative), every other gradient 3.0e-2 .. 6.7e-2: bounds = ~2x the other ones,
+    # 1.35x the worst
     for n, v in gerrs.items():
-        assert v <= 0.25, (n, v)
+        assert v <= (0.30 if "sampling_offsets" in n else 0.14), (n, v)
 
 
 def test_bench_runs_config1():

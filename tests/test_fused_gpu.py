@@ -263,3 +263,41 @@ def test_full_size_layernorm_and_groupnorm_tokens():
     assert s32.shape == (2, 4, h * w, C)
     assert (s32 - refg).abs().max().item() < 1e-4 * max(1.0, refg.abs().max().item())
     assert torch.equal(s16, s32.to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("rows,C", [(515, 384), (64, 128)])
+def test_lazy_layernorm_chain_equals_materialised_chain(rows, C):
+    """Three chained sub-layers ``x <- norm_k(x + dropout(z_k))`` (the encoder's norm1 / norm2 / next layer's norm1): with
+    ``want[0] == "lazy"`` the float32 result between two LayerNorms is never written -- the consumer recomputes it from the
+    producer's saved pre-norm sum, statistics and affine parameters (csrc/ln_fused.cuh) -- and outputs and every gradient
+    must equal the materialised chain's (same dropout masks: the seed is given)."""
+    from snipper_amd.fused import add_dropout_layer_norm
+    g = torch.Generator().manual_seed(rows + C)
+    x0 = torch.randn(rows, C, generator=g).to(DEV)
+    zs = [torch.randn(rows, C, generator=g).to(DEV).bfloat16() for _ in range(3)]
+    pos = torch.randn(rows, C, generator=g).to(DEV).bfloat16()
+    res = {}
+    for mode in ("plain", "lazy"):
+        torch.manual_seed(1)
+        norms = [torch.nn.LayerNorm(C).to(DEV) for _ in range(3)]
+        with torch.no_grad():
+            for n in norms:
+                n.weight.uniform_(0.5, 1.5); n.bias.uniform_(-0.5, 0.5)
+        x = x0.clone().requires_grad_(True)
+        zz = [z.clone().requires_grad_(True) for z in zs]
+        cur, bf = x, []
+        for k in range(3):
+            last = k == 2
+            w0 = True if (mode == "plain" or last) else "lazy"
+            cur, y16, yq = add_dropout_layer_norm(cur, zz[k], norms[k], 0.1, True, pos=pos, want=(w0, True, True), seed=77 + k)
+            if mode == "lazy" and not last:
+                assert hasattr(cur, "_lazy_ln")
+            bf += [y16, yq]
+        loss = (cur * torch.linspace(-1, 1, C, device=DEV)).sum() + sum((t.float() ** 2).sum() * 1e-2 for t in bf)
+        grads = torch.autograd.grad(loss, [x] + zz + [p for n in norms for p in n.parameters()])
+        res[mode] = ([cur.detach()] + [t.detach() for t in bf], grads)
+    for a, b in zip(res["lazy"][0], res["plain"][0]):
+        torch.testing.assert_close(a.float(), b.float(), rtol=1e-6, atol=1e-6)
+    for a, b in zip(res["lazy"][1], res["plain"][1]):
+        scale = max(float(b.float().abs().max()), 1.0)
+        torch.testing.assert_close(a.float() / scale, b.float() / scale, rtol=1e-5, atol=2e-6)
