@@ -148,47 +148,60 @@ int backward_generic(hipStream_t st, const VT *grad_out, const VT *value, const 
 // The D=48 kernels address `value` through one raw-buffer descriptor with 32-bit byte offsets.
 template <typename VT> bool d48_eligible(const CoreDims &d, int policy = 0) {
   if (policy == 1) return false;
-  if (d.D != kD48 || d.L > kMaxLevelsFast) return false;
-  if ((long long)d.N * d.S * d.M * kD48 * (long long)sizeof(VT) >= (1LL << 31)) return false;
+  if ((d.D != kD48 && d.D != 24) || d.L > kMaxLevelsFast) return false;        // 48 = hidden 384, 24 = the reference's default 192
+  if ((long long)d.N * d.S * d.M * d.D * (long long)sizeof(VT) >= (1LL << 31)) return false;
   return d.L * d.P <= 64;
 }
 
-template <typename VT>
-int forward_d48(hipStream_t st, const VT *value, const int64_t *shapes, const int64_t *lsi,
-                const float *loc, const float *attn, CoreDims d, VT *out, int out_bf16 = 0) {
-  constexpr int kRows = kD48Block / D48Fwd<VT>::G;
+template <typename VT, int DT>
+int forward_d48_t(hipStream_t st, const VT *value, const int64_t *shapes, const int64_t *lsi,
+                  const float *loc, const float *attn, CoreDims d, VT *out, int out_bf16) {
+  constexpr int kRows = kD48Block / (D48Fwd<VT>::G * DT / kD48);
   const long long rows = (long long)d.N * d.Lq * d.M;
   const int LP = d.L * d.P;
   const int nblk = (int)((rows + kRows - 1) / kRows);
   const int nblk_padded = (nblk + 7) & ~7;
   const size_t lds = (size_t)kRows * (LP * sizeof(FwdRecord) + 16);
   if (LP == 12 && d.P == 4) {
-    g_last_variant = "d48_lp12";
-    hipLaunchKernelGGL((msda_fwd_d48_kernel<VT, 12>), dim3(nblk_padded), dim3(kD48Block), lds, st, value, shapes, lsi, loc, attn, d, out, nblk_padded, out_bf16);
+    g_last_variant = DT == kD48 ? "d48_lp12" : "d24_lp12";
+    hipLaunchKernelGGL((msda_fwd_d48_kernel<VT, 12, DT>), dim3(nblk_padded), dim3(kD48Block), lds, st, value, shapes, lsi, loc, attn, d, out, nblk_padded, out_bf16);
   } else {
-    g_last_variant = "d48";
-    hipLaunchKernelGGL((msda_fwd_d48_kernel<VT, 0>), dim3(nblk_padded), dim3(kD48Block), lds, st, value, shapes, lsi, loc, attn, d, out, nblk_padded, out_bf16);
+    g_last_variant = DT == kD48 ? "d48" : "d24";
+    hipLaunchKernelGGL((msda_fwd_d48_kernel<VT, 0, DT>), dim3(nblk_padded), dim3(kD48Block), lds, st, value, shapes, lsi, loc, attn, d, out, nblk_padded, out_bf16);
   }
   return launch_status();
 }
+template <typename VT>
+int forward_d48(hipStream_t st, const VT *value, const int64_t *shapes, const int64_t *lsi,
+                const float *loc, const float *attn, CoreDims d, VT *out, int out_bf16 = 0) {
+  return d.D == kD48 ? forward_d48_t<VT, kD48>(st, value, shapes, lsi, loc, attn, d, out, out_bf16)
+                     : forward_d48_t<VT, 24>(st, value, shapes, lsi, loc, attn, d, out, out_bf16);
+}
 
-int backward_d48_f32(hipStream_t st, const float *grad_out, const float *value, const int64_t *shapes,
-                     const int64_t *lsi, const float *loc, const float *attn, CoreDims d,
-                     float *grad_value, float *grad_loc, float *grad_attn, int go_bf16 = 0) {
-  constexpr int kRows = kD48Block / 16;
+template <int DT>
+int backward_d48_f32_t(hipStream_t st, const float *grad_out, const float *value, const int64_t *shapes,
+                       const int64_t *lsi, const float *loc, const float *attn, CoreDims d,
+                       float *grad_value, float *grad_loc, float *grad_attn, int go_bf16) {
+  constexpr int kRows = kD48Block / (DT / 3);
   const long long rows = (long long)d.N * d.Lq * d.M;
   const int LP = d.L * d.P;
   const int nblk = (int)((rows + kRows - 1) / kRows);
   const int nblk_padded = (nblk + 7) & ~7;
   const size_t lds = (size_t)kRows * (LP * sizeof(BwdRecord) + 16);
   if (LP == 12 && d.P == 4) {
-    g_last_variant = "d48_lp12";
-    hipLaunchKernelGGL((msda_bwd_d48_f32_kernel<12>), dim3(nblk_padded), dim3(kD48Block), lds, st, grad_out, value, shapes, lsi, loc, attn, d, grad_value, grad_loc, grad_attn, nblk_padded, go_bf16);
+    g_last_variant = DT == kD48 ? "d48_lp12" : "d24_lp12";
+    hipLaunchKernelGGL((msda_bwd_d48_f32_kernel<12, DT>), dim3(nblk_padded), dim3(kD48Block), lds, st, grad_out, value, shapes, lsi, loc, attn, d, grad_value, grad_loc, grad_attn, nblk_padded, go_bf16);
   } else {
-    g_last_variant = "d48";
-    hipLaunchKernelGGL((msda_bwd_d48_f32_kernel<0>), dim3(nblk_padded), dim3(kD48Block), lds, st, grad_out, value, shapes, lsi, loc, attn, d, grad_value, grad_loc, grad_attn, nblk_padded, go_bf16);
+    g_last_variant = DT == kD48 ? "d48" : "d24";
+    hipLaunchKernelGGL((msda_bwd_d48_f32_kernel<0, DT>), dim3(nblk_padded), dim3(kD48Block), lds, st, grad_out, value, shapes, lsi, loc, attn, d, grad_value, grad_loc, grad_attn, nblk_padded, go_bf16);
   }
   return launch_status();
+}
+int backward_d48_f32(hipStream_t st, const float *grad_out, const float *value, const int64_t *shapes,
+                     const int64_t *lsi, const float *loc, const float *attn, CoreDims d,
+                     float *grad_value, float *grad_loc, float *grad_attn, int go_bf16 = 0) {
+  return d.D == kD48 ? backward_d48_f32_t<kD48>(st, grad_out, value, shapes, lsi, loc, attn, d, grad_value, grad_loc, grad_attn, go_bf16)
+                     : backward_d48_f32_t<24>(st, grad_out, value, shapes, lsi, loc, attn, d, grad_value, grad_loc, grad_attn, go_bf16);
 }
 
 // ---- owner-computes backward for the encoder shape (msda_d48_patch.cuh): needs the level shapes on the HOST ----
@@ -320,7 +333,7 @@ int backward_d48_patch(hipStream_t st, const void *grad_out, const VT *value, co
 }
 
 bool owner_shape_ok(const CoreDims &d, const int64_t *hs, int policy) {
-  if (policy != 0 || !hs || !d48_eligible<float>(d, policy) || d.L > kPatchMaxLevels || d.P != kPatchP || d.Lq != d.S) return false;
+  if (policy != 0 || !hs || d.D != kD48 || !d48_eligible<float>(d, policy) || d.L > kPatchMaxLevels || d.P != kPatchP || d.Lq != d.S) return false;
   long long sum = 0;
   for (int l = 0; l < d.L; ++l) {
     if (hs[2 * l] <= 0 || hs[2 * l + 1] <= 0) return false;

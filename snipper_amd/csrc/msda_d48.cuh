@@ -57,6 +57,8 @@ __device__ __forceinline__ int xcd_band_block(int nblk_padded) {
   return (b & 7) * (nblk_padded >> 3) + (b >> 3);
 }
 
+// (D = 24 -- the reference's default hidden_dim 192 / 8 heads, main.py:88, the same shm_reduce branch as D = 48 in the
+//  reference, .cuh:1272-1295 -- takes the same kernels with half the lanes per row: DT below)
 template <typename VT> struct D48Fwd;
 template <> struct D48Fwd<float> {
   static constexpr int G = 16, CPL = 3;
@@ -99,8 +101,8 @@ __device__ __forceinline__ void stage_levels(LevelTable &t, const int64_t *shape
   }
 }
 
-// LP_T = L*P when known at compile time (12 for Snipper's L=3,P=4), 0 = runtime.
-template <typename VT, int LP_T>
+// LP_T = L*P when known at compile time (12 for Snipper's L=3,P=4), 0 = runtime.  DT = channels per head: 48 or 24.
+template <typename VT, int LP_T, int DT = kD48>
 __global__ __launch_bounds__(kD48Block) void msda_fwd_d48_kernel(
     const VT *__restrict__ value, const int64_t *__restrict__ shapes,
     const int64_t *__restrict__ level_start, const float *__restrict__ loc,
@@ -108,7 +110,7 @@ __global__ __launch_bounds__(kD48Block) void msda_fwd_d48_kernel(
   // out_bf16 (float kernel only): `out` holds bfloat16 rows -- the consumer (the output projection) rounds to bf16
   // anyway, so writing it here saves the cast pass and half the store traffic without changing any result
   using TR = D48Fwd<VT>;
-  constexpr int G = TR::G, CPL = TR::CPL, kRows = kD48Block / G;
+  constexpr int G = TR::G * DT / kD48, CPL = TR::CPL, kRows = kD48Block / G;
   __shared__ LevelTable lv;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int LP = LP_T ? LP_T : d.L * d.P;
@@ -125,7 +127,7 @@ __global__ __launch_bounds__(kD48Block) void msda_fwd_d48_kernel(
   if (live) {
     const int m = (int)(row % d.M);
     const long long n = row / ((long long)d.M * d.Lq);
-    const unsigned row_bytes = kD48 * sizeof(VT);
+    const unsigned row_bytes = DT * sizeof(VT);
     const unsigned px_stride = (unsigned)d.M * row_bytes;              // next pixel, same head
     const unsigned base = (unsigned)(n * d.S) * px_stride + (unsigned)m * row_bytes;
     for (int s = lane; s < LP; s += G) {
@@ -156,7 +158,7 @@ __global__ __launch_bounds__(kD48Block) void msda_fwd_d48_kernel(
   __syncthreads();
   if (!live) return;
 
-  const unsigned value_bytes = (unsigned)((size_t)d.N * d.S * d.M * kD48 * sizeof(VT));
+  const unsigned value_bytes = (unsigned)((size_t)d.N * d.S * d.M * DT * sizeof(VT));
   const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<VT *>(value), 0, (int)value_bytes, 0x00020000);
   const unsigned lane_off = (unsigned)lane * 12u;
   float acc[CPL];
@@ -176,13 +178,13 @@ __global__ __launch_bounds__(kD48Block) void msda_fwd_d48_kernel(
   }
   if constexpr (sizeof(VT) == 4) {
     if (out_bf16) {
-      uint16_t *o16 = reinterpret_cast<uint16_t *>(out) + (size_t)row * kD48 + lane * 3;
+      uint16_t *o16 = reinterpret_cast<uint16_t *>(out) + (size_t)row * DT + lane * 3;
       o16[0] = f32_to_bf16_bits(acc[0]); o16[1] = f32_to_bf16_bits(acc[1]); o16[2] = f32_to_bf16_bits(acc[2]);
       return;
     }
   }
   const u32x3 packed = TR::pack(acc);
-  unsigned char *o = reinterpret_cast<unsigned char *>(out) + (size_t)row * kD48 * sizeof(VT) + lane_off;
+  unsigned char *o = reinterpret_cast<unsigned char *>(out) + (size_t)row * DT * sizeof(VT) + lane_off;
   *reinterpret_cast<u32x3 *>(o) = packed;
 }
 
@@ -232,14 +234,22 @@ __device__ __forceinline__ void query_to_grid(int q, const int *start, const int
   qx = r - qy * W[lq];
 }
 
-template <int LP_T>
+// all-reduce over the 8 lanes of an aligned group (quad xor 1, quad xor 2, mirror within the half row)
+__device__ __forceinline__ float row8_sum_d(float v) {
+  v += dpp_f32<0xB1>(v);
+  v += dpp_f32<0x4E>(v);
+  v += dpp_f32<0x141>(v);
+  return v;
+}
+
+template <int LP_T, int DT = kD48>
 __global__ __launch_bounds__(kD48Block) void msda_bwd_d48_f32_kernel(
     const float *__restrict__ grad_out, const float *__restrict__ value,
     const int64_t *__restrict__ shapes, const int64_t *__restrict__ level_start,
     const float *__restrict__ loc, const float *__restrict__ attn, CoreDims d,
     float *__restrict__ grad_value, float *__restrict__ grad_loc, float *__restrict__ grad_attn,
     int nblk_padded, int go_bf16) {
-  constexpr int G = 16, kRows = kD48Block / G;
+  constexpr int G = DT / 3, kRows = kD48Block / G;        // lane i owns channels {i, i + G, i + 2G}
   __shared__ LevelTable lv;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int LP = LP_T ? LP_T : d.L * d.P;
@@ -256,8 +266,8 @@ __global__ __launch_bounds__(kD48Block) void msda_bwd_d48_f32_kernel(
   if (live) {
     const int m = (int)(row % d.M);
     const long long n = row / ((long long)d.M * d.Lq);
-    const unsigned px_stride = (unsigned)d.M * kD48 * 4u;
-    const unsigned base = (unsigned)(n * d.S) * px_stride + (unsigned)m * (kD48 * 4u);
+    const unsigned px_stride = (unsigned)d.M * DT * 4u;
+    const unsigned base = (unsigned)(n * d.S) * px_stride + (unsigned)m * (DT * 4u);
     for (int s = lane; s < LP; s += G) {
       const int l = s / d.P;
       const int H = lv.H[l], W = lv.W[l];
@@ -286,12 +296,12 @@ __global__ __launch_bounds__(kD48Block) void msda_bwd_d48_f32_kernel(
   // the DPP reduction stays inside a 16-lane row, which is either fully live or fully dead).
   if (!live) return;
 
-  const unsigned value_bytes = (unsigned)((size_t)d.N * d.S * d.M * kD48 * 4u);
+  const unsigned value_bytes = (unsigned)((size_t)d.N * d.S * d.M * DT * 4u);
   const auto vsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(value), 0, (int)value_bytes, 0x00020000);
   const auto gsrc = __builtin_amdgcn_make_buffer_rsrc(grad_value, 0, (int)value_bytes, 0x00020000);
   const unsigned lane_off = (unsigned)lane * 4u;
-  const size_t gi = (size_t)row * kD48 + lane;
-  const float g0 = ld_go(grad_out, gi, go_bf16), g1 = ld_go(grad_out, gi + 16, go_bf16), g2 = ld_go(grad_out, gi + 32, go_bf16);
+  const size_t gi = (size_t)row * DT + lane;
+  const float g0 = ld_go(grad_out, gi, go_bf16), g1 = ld_go(grad_out, gi + G, go_bf16), g2 = ld_go(grad_out, gi + 2 * G, go_bf16);
 
   float keep_a = 0.f, keep_x = 0.f, keep_y = 0.f;
 #pragma unroll(LP_T ? 2 : 1)
@@ -306,28 +316,32 @@ __global__ __launch_bounds__(kD48Block) void msda_bwd_d48_f32_kernel(
     for (int k = 0; k < 4; ++k) {
       const unsigned o = off[k] + lane_off;
       const float v0 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(vsrc, o, 0, 0));
-      const float v1 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(vsrc, o + 64u, 0, 0));
-      const float v2 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(vsrc, o + 128u, 0, 0));
+      const float v1 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(vsrc, o + 4u * G, 0, 0));
+      const float v2 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(vsrc, o + 8u * G, 0, 0));
       dot[k] = g0 * v0 + g1 * v1 + g2 * v2;
       const float wa = w[k] * a;
       __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(wa * g0, gsrc, o, 0, 0);
-      __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(wa * g1, gsrc, o + 64u, 0, 0);
-      __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(wa * g2, gsrc, o + 128u, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(wa * g1, gsrc, o + 4u * G, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(wa * g2, gsrc, o + 8u * G, 0, 0);
     }
     float pa = w[0] * dot[0] + w[1] * dot[1] + w[2] * dot[2] + w[3] * dot[3];
     float px = hh * (dot[1] - dot[0]) + lh * (dot[3] - dot[2]);
     float py = hw * (dot[2] - dot[0]) + lw * (dot[3] - dot[1]);
-    pa = row16_sum(pa);
-    px = row16_sum(px) * r.q0.w;
-    py = row16_sum(py) * r.q2.x;
-    if (LP <= 16) {
+    if constexpr (G == 16) {
+      pa = row16_sum(pa); px = row16_sum(px); py = row16_sum(py);
+    } else {
+      pa = row8_sum_d(pa); px = row8_sum_d(px); py = row8_sum_d(py);
+    }
+    px *= r.q0.w;
+    py *= r.q2.x;
+    if (LP <= G) {
       if (lane == s) { keep_a = pa; keep_x = px; keep_y = py; }
     } else if (lane == 0) {
       const long long li = row * LP + s;
       grad_attn[li] = pa; grad_loc[2 * li] = px; grad_loc[2 * li + 1] = py;
     }
   }
-  if (LP <= 16 && lane < LP) {
+  if (LP <= G && lane < LP) {
     const long long li = row * LP + lane;
     grad_attn[li] = keep_a;
     *reinterpret_cast<float2 *>(grad_loc + 2 * li) = make_float2(keep_x, keep_y);

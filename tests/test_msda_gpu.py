@@ -131,6 +131,7 @@ CASES = {
     "d48_lp_runtime": (3, [(7, 9), (4, 5)], 5, 48, 33, 3),
     "d48_many_points": (1, [(6, 6), (3, 3), (2, 2), (1, 1), (5, 2)], 2, 48, 9, 5),   # L*P=25 > 16
     "d24_hidden192": (2, [(9, 12), (5, 6), (3, 3)], 8, 24, 41, 4),
+    "d24_lp_runtime": (1, [(7, 5), (3, 4)], 3, 24, 19, 3),
     "d2": (1, [(6, 4), (3, 2)], 2, 2, 2, 2),
     "d71": (2, [(5, 4), (2, 3)], 3, 71, 7, 2),
     "d130": (1, [(4, 4)], 2, 130, 5, 3),
@@ -153,8 +154,8 @@ def test_hip_matches_oracle_f32(name, policy):
         gv, gl, ga = MSDA.ms_deform_attn_backward(tv, ts, ti, tl, ta, tg, 64)
     finally:
         _lib.set_policy(0)
-    if policy == 0 and CASES[name][3] == 48:
-        assert variant.startswith("d48"), variant
+    if policy == 0 and CASES[name][3] in (48, 24):          # 24 = hidden_dim 192, the reference's default (main.py:88)
+        assert variant.startswith("d%d" % CASES[name][3]), variant
     else:
         assert variant == "generic"
     # fp32 kernel vs fp64 oracle: a handful of ulps of the largest term
@@ -201,6 +202,30 @@ def test_hip_bf16_against_fp32_oracle(name):
     np.testing.assert_allclose(ga.cpu().numpy(), ref_ga, rtol=1e-3, atol=1e-3)
     scale = float(np.abs(ref_gl).max())
     np.testing.assert_allclose(gl.cpu().numpy() / scale, ref_gl / scale, rtol=1e-3, atol=1e-4)
+
+
+def test_d24_bf16_rows_and_full_size_forward_backward():
+    """hidden_dim = 192 (D = 24) on the tuned kernels at the 600x800 geometry: float32 with bf16 rows against the float32
+    interface (same kernel, rows converted in place), and the bf16-value forward against the oracle."""
+    shapes = [(75, 100), (38, 50), (19, 25)]
+    v, sh, lsi, loc, attn, go = _case(1, shapes, 8, 24, 9875, 4, seed=3, lo=0.0, hi=1.0)
+    tv, tl, ta, tg = (torch.from_numpy(x).to(DEV) for x in (v, loc, attn, go))
+    ts, ti = torch.from_numpy(sh).to(DEV), torch.from_numpy(lsi).to(DEV)
+    out = MSDA.ms_deform_attn_forward(tv, ts, ti, tl, ta, 64)
+    assert _lib.last_variant() == "d24_lp12", _lib.last_variant()
+    f64 = lambda a: a.astype(np.float64)
+    ref_out = O.core_c_forward(f64(v), sh, lsi, f64(loc), f64(attn), threads=16)
+    np.testing.assert_allclose(out.cpu().numpy(), ref_out, rtol=1e-4, atol=2e-5)
+    out16 = MSDA.ms_deform_attn_forward(tv, ts, ti, tl, ta, 64, out_bf16=True)
+    assert torch.equal(out16, out.to(torch.bfloat16))
+    go16 = tg.bfloat16()
+    a = MSDA.ms_deform_attn_backward(tv, ts, ti, tl, ta, go16, 64)
+    assert _lib.last_variant() == "d24_lp12", _lib.last_variant()
+    ref = O.core_c_backward(f64(v), sh, lsi, f64(loc), f64(attn), f64(go16.float().cpu().numpy()), threads=16)
+    np.testing.assert_allclose(a[0].cpu().numpy(), ref[0], rtol=1e-4, atol=2e-4)
+    s = float(np.abs(ref[1]).max())
+    np.testing.assert_allclose(a[1].cpu().numpy() / s, ref[1] / s, rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(a[2].cpu().numpy(), ref[2], rtol=1e-4, atol=1e-4)
 
 
 def test_edge_cases_all_outside_and_nonfinite():
