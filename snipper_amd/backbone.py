@@ -455,6 +455,55 @@ class ResNet50Body(nn.Module):
         return {"0": c5}
 
 
+class _Segment(nn.Module):
+    """One capturable piece of ``ResNet50Body.forward``: ``first`` = stem + layer1 (frozen, no autograd) + layer2, else one
+    residual stage.  Holds the body's own sub-modules (shared parameters)."""
+
+    def __init__(self, body: "ResNet50Body", which: str):
+        super().__init__()
+        self.which = which
+        self.body_ref = [body]                    # (a list: not registered as a child again)
+        self.layer = getattr(body, {"first": "layer2", "layer3": "layer3", "layer4": "layer4"}[which])
+
+    def forward(self, x):
+        body = self.body_ref[0]
+        with torch.autocast("cuda", dtype=torch.bfloat16, cache_enabled=False):
+            if self.which == "first":
+                x = x.contiguous(memory_format=torch.channels_last)
+                x = body._stem(x)
+                with torch.no_grad():
+                    x = body.layer1(x)
+            return body._run_layer(self.layer, x)
+
+
+def graphed_segments(body: "ResNet50Body", sample_images: torch.Tensor):
+    """``body`` as three hipGraph-captured callables (forward AND backward each; ``torch.cuda.make_graphed_callables``):
+    stem + layer1 + layer2 | layer3 | layer4.  Every shape in here is static (the images' size) and every kernel is this
+    package's own (stream-ordered, no allocation outside torch's caching allocator, no host synchronisation), so the ~350
+    launches of the region replay from three graph launches each way.  The cuts are the gradient all-reduce's stage
+    boundaries (bench.grad_sync_stages): a stage's trigger parameters receive their gradients when its segment's backward
+    has been replayed, i.e. in the same order as eagerly.  Returns ``f(images) -> {"0": c3, "1": c4, "2": c5}``.
+    EXPERIMENT (round 4, tools/graph_backbone.py, tests/test_backbone.py): features bit-identical, host issue time of the
+    region 4.1 -> 0.7 ms, its GPU time 5.2 -> 5.8 ms (replay costs ~1.7 us per node on the GPU side) -- a loss while the
+    step is GPU-bound (25 ms of kernels against 19.6 ms of host issue), so nothing in the product path uses it; wired into
+    bench.py's full step it also crashed the process (segmentation fault inside the captured backward), not root-caused.
+    Requires bf16 autocast, training mode, frozen stem + layer1 (the reference's freeze rule) and all three taps."""
+    assert body.return_interm_layers and sample_images.is_cuda
+    segs = [_Segment(body, w) for w in ("first", "layer3", "layer4")]
+    with torch.no_grad():
+        c3 = segs[0](sample_images)
+        c4 = segs[1](c3)
+    samples = ((sample_images,), (c3.detach().clone().requires_grad_(True),), (c4.detach().clone().requires_grad_(True),))
+    g = torch.cuda.make_graphed_callables(tuple(segs), samples)
+
+    def fwd(images):
+        c3 = g[0](images)
+        c4 = g[1](c3)
+        c5 = g[2](c4)
+        return {"0": c3, "1": c4, "2": c5}
+    return fwd
+
+
 def backbone_parameter_is_trainable(name: str, train_backbone: bool) -> bool:
     """The reference's freeze rule (backbone.py:71-73): only layer2 / layer3 / layer4 parameters train, and only when the
     backbone has a learning rate; conv1 + layer1 are always frozen."""
