@@ -43,6 +43,11 @@ sumfile() { ls $out/pmc_$1/*/*counter_collection.csv 2>/dev/null | head -1; }
 } > $out/pmc_lds_tcc.csv
 rm -rf $out/pmc_fetch $out/pmc_write $out/pmc_mfma $out/pmc_lds $out/pmc_tcc
 python3 tools/copybench.py > $out/copybench.json 2> $out/copybench.err
+python3 tools/graphbench.py > $out/graphbench.jsonl 2> $out/graphbench.err
+python3 tools/graph_backbone.py > $out/graph_backbone.json 2> $out/graph_backbone.err
+for tk in 1 2; do python3 tools/opbench.py --N 8 --cases enc_local --dtypes bfloat16 --skip-torch --sigma 0.01 1.5 3 8 --grid 1 --iters 20 --tile-kernel $tk; done > $out/opbench_tile_kernels_ab.jsonl 2> $out/opbench_ab.err
+{ for s in 0.01 3 8; do EDGES="" bash tools/kstats_t3.sh $s 0; done; EDGES="" bash tools/kstats_t3.sh 0.01 1 2 4 6 7 8; } > $out/tile3_ablations.txt 2>&1
+SNIPPER_DENSE_TABLE=$out/dense.json python3 bench.py --steps 4 --warmup 3 --no-cpu-baseline --no-locality-sweep > /dev/null 2> $out/dense.err; python3 tools/dense_roofline.py $out/dense.json > $out/backbone_roofline.csv
 python3 tools/opbench.py --N 8 --cases enc_local --dtypes bfloat16 --skip-torch --sigma 0.01 3 8 --grid 1 --iters 10 > $out/opbench_locality_bf16_value.jsonl 2> $out/opbench.err
 python3 tools/opbench.py --N 8 --cases enc_local --dtypes float32 --skip-torch --rows-bf16 1 --sigma 0.01 3 8 --grid 1 --iters 10 > $out/opbench_locality_f32_value.jsonl 2>> $out/opbench.err
 python3 tools/wresbench.py > $out/wresbench.jsonl 2> $out/wresbench.err

@@ -5,7 +5,7 @@ import csv, re, sys
 
 rows = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(open(sys.argv[1]))]
 rows.sort()
-marks = [i for i, r in enumerate(rows) if "FusedAdam" in r[2]]
+marks = [i for i, r in enumerate(rows) if "FusedAdam" in r[2] or "adamw_clip_kernel" in r[2]]      # (torch fused AdamW, or csrc/adamw_flat.cuh)
 ends = [m for j, m in enumerate(marks) if j + 1 == len(marks) or rows[marks[j + 1]][0] - rows[m][1] > 5_000_000]
 seg = rows[ends[-2] + 1: ends[-1] + 1]
 
