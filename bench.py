@@ -857,15 +857,6 @@ def main():
         loss = step(a.warmup + i)
     fence()
     elapsed = time.perf_counter() - t0
-    if gc_every:
-        import gc
-        gc.enable()
-    if affinity0 is not None:               # every thread: the intra-op pool's workers were born with the narrow mask
-        for tid in os.listdir("/proc/self/task"):
-            try:
-                os.sched_setaffinity(int(tid), affinity0)
-            except OSError:
-                pass
     loss_val = float(loss.detach())
     per_rank_ms = None
     if use_ddp:
@@ -980,6 +971,18 @@ def main():
                 l.self_attn.sampling_offsets[0].weight.copy_(w0)
             torch.autograd.graph.increment_version([l.self_attn.sampling_offsets[0].weight for l in model.transformer.encoder.layers])
 
+    # (only now: the extra steps above -- launch timings, gradient-sync trace, locality sweep -- run under the host conditions of
+    #  the timed region; unpinned and with the automatic collector on, the sigma = 8 px sweep was host-bound in some runs: 30.1
+    #  against 26.1 ms per step)
+    if gc_every:
+        import gc
+        gc.enable()
+    if affinity0 is not None:               # every thread: the intra-op pool's workers were born with the narrow mask
+        for tid in os.listdir("/proc/self/task"):
+            try:
+                os.sched_setaffinity(int(tid), affinity0)
+            except OSError:
+                pass
     if rank == 0:
         snippets = a.batch * world * a.steps
         line = {

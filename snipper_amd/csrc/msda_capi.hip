@@ -314,8 +314,25 @@ int backward_d48_patch(hipStream_t st, const void *grad_out, const VT *value, co
       //  measured: 373 / 544 / 664 us at sigma 0 / 3 / 8 px against 330 / 478 / 588 for one workgroup per tile: the
       //  dispatcher balances the very unequal tiles better than a static list, and the fixed cost is not launch latency but
       //  the read-modify-write of grad_value)
-      hipLaunchKernelGGL(msda_bwd_d48_tile3_kernel, dim3((unsigned)nblk_tiles), dim3(kPatchThreads), 0, st, grad_out, loc, attn,
-                         d, plan, grad_value);
+      // two instances by tile size (their LDS footprints differ 2.4x: two against five workgroups per CU); small tiles first:
+      // they hold the longest-running workgroups (coarse levels)
+      T3Class big{}, small{};
+      for (int l = 0; l < kPatchMaxLevels; ++l) {
+        big.base[l] = small.base[l] = -1;
+        if (l >= plan.L) continue;
+        T3Class &c = plan.lv[l].shift >= 4 ? big : small;
+        c.base[l] = c.tiles;
+        c.tiles += plan.lv[l].ntx * plan.lv[l].nty;
+      }
+      const long long nm8 = ((nm + 7) / 8) * 8;
+      if (small.tiles) {
+        hipLaunchKernelGGL(msda_bwd_d48_tile3_kernel<64>, dim3((unsigned)(nm8 * small.tiles)), dim3(kPatchThreads), 0, st, grad_out,
+                           loc, attn, d, plan, small, grad_value);
+        if (int rc = launch_status()) return rc;
+      }
+      if (big.tiles)
+        hipLaunchKernelGGL(msda_bwd_d48_tile3_kernel<256>, dim3((unsigned)(nm8 * big.tiles)), dim3(kPatchThreads), 0, st, grad_out,
+                           loc, attn, d, plan, big, grad_value);
       g_last_variant = plan.debug ? "d48_owner_mfma_debug" : "d48_owner_mfma";
       return launch_status();
     }

@@ -50,14 +50,22 @@ constexpr int kT3RowB = 96;                         // one bfloat16 grad_out hea
 // wave expands one candidate block per trip, lane i = query i of the block, so the level's constants are uniform there)
 struct T3Hit { int q; float ax, ay; int pad; };     // query index; its anchor in the tile's level
 
+// WPX = pixels of the largest tile a kernel instance serves: 256 (16 x 16 tiles: 65 664 B of Wt, two workgroups per CU) or 64
+// (8 x 8 and smaller: 16 512 B, 32 KB in all -- the kernel is LATENCY-bound: padded to one workgroup per CU it takes 1.72x
+// as long (profiles/r04_tile3_ablations.txt), so the small tiles, 2/3 of all rounds, get an instance of their own at five
+// workgroups per CU)
+template <int WPX>
 struct Tile3Lds {
-  __attribute__((aligned(16))) unsigned char W[2 * 4 * kT3PlaneMax];  // 65 664 B: two k-steps x four planes
+  __attribute__((aligned(16))) unsigned char W[2 * 4 * (WPX * 32 + 16)];  // two k-steps x four planes
   __attribute__((aligned(16))) unsigned char G[kT3Hits * kT3RowB];    // 6 144 B
   __attribute__((aligned(16))) T3Hit hits[kT3List];                   // 8 192 B
   float trash[kPatchThreads];                                         // where the taps this tile does not own go
   __attribute__((aligned(16))) unsigned dirty[4];                     // per wave: (k-step, pixel block) pairs its hits tapped this round
   int wsum[4];
   int total_hits;
+#ifdef T3_LDS_PAD       // occupancy experiment (diagnostic builds only): pad the footprint to one workgroup per CU
+  unsigned char pad[T3_LDS_PAD];
+#endif
 };
 
 __device__ __forceinline__ gemm_bf16x8 tile3_bfrag(const unsigned char *base) {
@@ -100,8 +108,8 @@ __device__ __forceinline__ void t3_lds_wait(float (&v)[4]) {
 }
 
 // NPB = 16-pixel blocks of the tile (16 x 16 tiles: 16; 8 x 8: 4; smaller: 1 block padded with never-written rows)
-template <int NPB>
-__device__ __forceinline__ void tile3_body(Tile3Lds &S, const unsigned char *__restrict__ grad_out,
+template <int NPB, typename LDS>
+__device__ __forceinline__ void tile3_body(LDS &S, const unsigned char *__restrict__ grad_out,
                                            const float *__restrict__ loc, const float *__restrict__ attn,
                                            const CoreDims &d, const PatchPlan &plan, float *__restrict__ grad_value,
                                            int n, int m, int l, int t) {
@@ -352,26 +360,36 @@ __device__ __forceinline__ void tile3_body(Tile3Lds &S, const unsigned char *__r
   }
 }
 
-__global__ __launch_bounds__(kPatchThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void msda_bwd_d48_tile3_kernel(
-    const void *__restrict__ grad_out, const float *__restrict__ loc, const float *__restrict__ attn, CoreDims d,
-    PatchPlan plan, float *__restrict__ grad_value) {
-  __shared__ Tile3Lds S;
+// the tiles one kernel instance serves: levels whose tiles have <= WPX pixels (and, for WPX = 256, more than 64)
+struct T3Class {
+  int tiles;                        // per (n, m)
+  int base[kPatchMaxLevels];        // class-local index of the level's first tile, or -1 when the level is not in the class
+};
+
+template <int WPX>
+__global__ __launch_bounds__(kPatchThreads) __attribute__((amdgpu_waves_per_eu(WPX == 256 ? 2 : 5, WPX == 256 ? 2 : 5)))
+void msda_bwd_d48_tile3_kernel(const void *__restrict__ grad_out, const float *__restrict__ loc, const float *__restrict__ attn,
+                               CoreDims d, PatchPlan plan, T3Class cls, float *__restrict__ grad_value) {
+  __shared__ Tile3Lds<WPX> S;
   // XCD-major walk of the (n, m) pairs, as msda_bwd_d48_tile2_kernel; within an (n, m) the tiles of the COARSE levels go
   // first: they are reached by the most queries, i.e. they are the longest-running workgroups
-  const int tiles = plan.total_tiles;
+  const int tiles = cls.tiles;
   const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
   const int nm = xcd * ((d.N * d.M + 7) >> 3) + jb / tiles;
   if (nm >= d.N * d.M) return;
-  const int tile_id = tiles - 1 - jb % tiles;
+  const int ct = tiles - 1 - jb % tiles;
   const int m = nm % d.M, n = nm / d.M;
-  int l = 0;
-  for (int i = 1; i < plan.L; ++i) l = (tile_id >= plan.lv[i].tile_base) ? i : l;
-  const int t = tile_id - plan.lv[l].tile_base;
+  int l = 0, t = 0;
+  for (int i = 0; i < plan.L; ++i)
+    if (cls.base[i] >= 0 && ct >= cls.base[i]) { l = i; t = ct - cls.base[i]; }
   const unsigned char *go = reinterpret_cast<const unsigned char *>(grad_out);
   const int shift = plan.lv[l].shift;
-  if (shift >= 4) tile3_body<16>(S, go, loc, attn, d, plan, grad_value, n, m, l, t);
-  else if (shift == 3) tile3_body<4>(S, go, loc, attn, d, plan, grad_value, n, m, l, t);
-  else tile3_body<1>(S, go, loc, attn, d, plan, grad_value, n, m, l, t);
+  if constexpr (WPX == 256) {
+    tile3_body<16>(S, go, loc, attn, d, plan, grad_value, n, m, l, t);
+  } else {
+    if (shift == 3) tile3_body<4>(S, go, loc, attn, d, plan, grad_value, n, m, l, t);
+    else tile3_body<1>(S, go, loc, attn, d, plan, grad_value, n, m, l, t);
+  }
 }
 
 }  // namespace snipper
