@@ -553,6 +553,9 @@ def main():
     ap.add_argument("--offset-sigma-px", type=float, default=0.0,
                     help="spread of the encoder's sampling offsets in pixels for the TIMED region (0 = as initialised: every "
                          "query samples its <= 4 px bias grid); the default run also reports steps at 3 and 8 px in `locality`")
+    ap.add_argument("--tile-kernel", type=int, default=0,
+                    help="A/B aid: grad_value side of the encoder's owner-computes backward: 0 = library default (matrix pipe for "
+                         "bf16 rows), 1 = the vector / LDS kernel of rounds 1-3")
     ap.add_argument("--no-locality-sweep", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip roofline/msda extras (profiling runs)")
@@ -586,6 +589,8 @@ def main():
     from snipper_amd import _lib
     from snipper_amd.model import build_model
     _lib.load()                                                   # fail loudly if the HIP library is missing
+    if a.tile_kernel:
+        _lib.set_param("tile_kernel", a.tile_kernel)
 
     if os.environ.get("SNIPPER_BLAS"):                            # "cublas" = rocBLAS, "cublaslt" = hipBLASLt (aid)
         torch.backends.cuda.preferred_blas_library(os.environ["SNIPPER_BLAS"])

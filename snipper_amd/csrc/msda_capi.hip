@@ -330,9 +330,14 @@ int backward_d48_patch(hipStream_t st, const void *grad_out, const VT *value, co
                            loc, attn, d, plan, small, grad_value);
         if (int rc = launch_status()) return rc;
       }
-      if (big.tiles)
-        hipLaunchKernelGGL(msda_bwd_d48_tile3_kernel<256>, dim3((unsigned)(nm8 * big.tiles)), dim3(kPatchThreads), 0, st, grad_out,
-                           loc, attn, d, plan, big, grad_value);
+      if (big.tiles) {      // 16 x 16 tiles: 8-wave workgroups (tile_kernel = 2 with debug bit 32: the 4-wave form, for A/B runs)
+        if (plan.debug & 32)
+          hipLaunchKernelGGL(msda_bwd_d48_tile3_kernel<256>, dim3((unsigned)(nm8 * big.tiles)), dim3(kPatchThreads), 0, st, grad_out,
+                             loc, attn, d, plan, big, grad_value);
+        else
+          hipLaunchKernelGGL(msda_bwd_d48_tile3_wide_kernel, dim3((unsigned)(nm8 * big.tiles)), dim3(kT3WideThreads), 0, st, grad_out,
+                             loc, attn, d, plan, big, grad_value);
+      }
       g_last_variant = plan.debug ? "d48_owner_mfma_debug" : "d48_owner_mfma";
       return launch_status();
     }

@@ -366,6 +366,269 @@ struct T3Class {
   int base[kPatchMaxLevels];        // class-local index of the level's first tile, or -1 when the level is not in the class
 };
 
+// ---- 16 x 16 tiles on EIGHT waves (512 threads) ----------------------------------------------------------------------
+// The 256-pixel instance is held to two workgroups per CU by its 64 KB of Wt, and the kernel is latency-bound (above): a
+// workgroup of 8 waves doubles the waves per CU at the same footprint.  Item = (hit, point, tap ROW): 64 x 4 x 2 = 512
+// threads, two taps each; waves 0-3 multiply k-step 0 (hits 0-31) and waves 4-7 k-step 1 (hits 32-63) of every round, each
+// for the pixel blocks {4 i + (wave & 3)}; the two halves meet once, through LDS, in a fixed order, before the tile is stored.
+constexpr int kT3WideThreads = 512;
+constexpr int kT3WideList = 448;                    // hits per pass (so that two workgroups fit the 160 KB of a CU)
+struct Tile3LdsWide {
+  __attribute__((aligned(16))) unsigned char W[2 * 4 * kT3PlaneMax];
+  __attribute__((aligned(16))) unsigned char G[kT3Hits * kT3RowB];
+  __attribute__((aligned(16))) T3Hit hits[kT3WideList];
+  float trash[kT3WideThreads];
+  __attribute__((aligned(16))) unsigned dirty[8];
+  int wsum[8];
+  int total_hits;
+};
+
+__device__ __forceinline__ void tile3_body_wide(Tile3LdsWide &S, const unsigned char *__restrict__ grad_out,
+                                                const float *__restrict__ loc, const float *__restrict__ attn,
+                                                const CoreDims &d, const PatchPlan &plan, float *__restrict__ grad_value,
+                                                int n, int m, int l, int t) {
+  constexpr int NPX = 256, PLANE = NPX * 32 + 16, NACC = 4;
+  const PatchLevel me = plan.lv[l];
+  const Tile2Levels lv = tile2_levels(plan, l);
+  const int edge = 1 << me.shift, tpx = edge * edge;
+  const int tyi = t / me.ntx, txi = t - tyi * me.ntx;
+  const int ty0 = tyi << me.shift, tx0 = txi << me.shift;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int kstep = wave >> 2, wq = wave & 3;
+  const int LP = d.L * kPatchP;
+  const size_t row_base = (size_t)n * d.Lq;
+
+  // ---- this thread's candidate block: its mark word (threads 256.. have none: <= 256 candidates per tile) ----
+  unsigned long long mask = 0ull;
+  int c_lq = 0, c_by = 0, c_bx = 0;
+  {
+    int c = tid;
+    const unsigned long long *slab = plan.marks + ((long long)n * d.M + m) * plan.words_per_nm + plan.lvl_base[l] +
+                                     (long long)t * plan.tstride[l];
+    for (int lq = 0; lq < plan.L; ++lq) {
+      int bx0, bx1, by0, by1;
+      patch_tile_cand(plan, l, lq, ty0, tx0, edge, bx0, bx1, by0, by1);
+      const int cw = min(bx1 - bx0 + 1, plan.cbw[l][lq]), ch = min(by1 - by0 + 1, plan.cbh[l][lq]);
+      const int cnt = (cw > 0 && ch > 0) ? cw * ch : 0;
+      if (c >= 0 && c < cnt) {
+        const int dy = c / cw, dx = c - dy * cw;
+        mask = slab[plan.coff[l][lq] + dy * plan.cbw[l][lq] + dx];
+        c_lq = lq; c_by = by0 + dy; c_bx = bx0 + dx;
+      }
+      c -= cnt;
+    }
+  }
+  const int r16 = lane & 15, g4 = lane >> 4;
+  gemm_f32x4 acc[NACC][3];
+  float *dst[NACC];
+  const bool dirty_tile = plan.dirty[((size_t)n * d.M + m) * plan.total_tiles + me.tile_base + t] != 0;
+  {
+    const size_t img_base = ((size_t)n * d.S + me.start) * d.M;
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) {
+      const int pix = 16 * (4 * i + wq) + r16;
+      const int ty = ty0 + (pix >> me.shift), tx = tx0 + (pix & (edge - 1));
+      const bool on = kstep == 0 && pix < tpx && ty < me.H && tx < me.W;       // (waves 0-3 own the store)
+      dst[i] = on ? grad_value + (img_base + (size_t)(ty * me.W + tx) * d.M + m) * kD48 + 4 * g4 : nullptr;
+#pragma unroll
+      for (int cb = 0; cb < 3; ++cb)
+        acc[i][cb] = (on && dirty_tile) ? *reinterpret_cast<const gemm_f32x4 *>(dst[i] + 16 * cb) : gemm_f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  for (int i = tid; i < 2 * 4 * PLANE / 16; i += kT3WideThreads) reinterpret_cast<u32x4 *>(S.W)[i] = u32x4{0u, 0u, 0u, 0u};
+  const int my_cnt = __popcll(mask);
+  const int my_excl = block_incl_scan(my_cnt, S.wsum, tid) - my_cnt;
+  if (tid == kT3WideThreads - 1) S.total_hits = my_excl + my_cnt;
+  lds_barrier();
+  const int total_hits = (plan.debug & 8) ? 0 : S.total_hits;
+
+  // item = (hit h, point p, tap row dy): the taps (y0 + dy, x0) and (y0 + dy, x0 + 1); G piece = (hit tid / 6, part tid % 6)
+  const int h = tid >> 3, p = (tid >> 1) & 3, dy = tid & 1, h5 = h & 31;
+  const unsigned w_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)S.W;
+  const unsigned wcol = w_lds + (unsigned)(((h >> 5) * 4 + ((h5 >> 2) & 3)) * PLANE + ((h5 & 3) + ((h5 >> 4) << 2)) * 4);
+  const unsigned trash = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)(S.trash + tid);
+  const unsigned q_loc = (unsigned)(d.M * LP) * 8u, q_attn = (unsigned)(d.M * LP) * 4u, q_go = (unsigned)d.M * kT3RowB;
+  const auto loc_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(loc + row_base * d.M * LP * 2), 0,
+                                                         (int)((unsigned)d.Lq * q_loc), 0x00020000);
+  const auto attn_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(attn + row_base * d.M * LP), 0,
+                                                          (int)((unsigned)d.Lq * q_attn), 0x00020000);
+  const auto go_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char *>(grad_out + row_base * d.M * kT3RowB), 0,
+                                                        (int)((unsigned)d.Lq * q_go), 0x00020000);
+  const unsigned my_item = (unsigned)((m * LP + l * kPatchP + p) * 4);
+  const int gh = tid / 6, gpart = tid - gh * 6;
+  const bool g_thread = tid < kT3Hits * 6;
+  const unsigned char *gfrag = S.G + (kstep * 32 + 4 * g4 + ((lane >> 2) & 3)) * kT3RowB + 8 * (lane & 3);
+
+  for (int pass0 = 0; pass0 < total_hits; pass0 += kT3WideList) {
+    const int pass1 = min(pass0 + kT3WideList, total_hits), np = pass1 - pass0;
+    {
+      unsigned long long todo = __ballot(my_cnt && my_excl < pass1 && my_excl + my_cnt > pass0);
+      while (todo) {
+        const int src = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        const unsigned mlo = __builtin_amdgcn_readlane((unsigned)mask, src);
+        const unsigned mhi = __builtin_amdgcn_readlane((unsigned)(mask >> 32), src);
+        const int ex = __builtin_amdgcn_readlane(my_excl, src);
+        const int lqv = __builtin_amdgcn_readlane(c_lq, src);
+        const int byv = __builtin_amdgcn_readlane(c_by, src), bxv = __builtin_amdgcn_readlane(c_bx, src);
+        int start = lv.start[0], Wq = lv.W[0];
+        float rwq = lv.rw[0], rhq = lv.rh[0];
+#pragma unroll
+        for (int i = 1; i < kPatchMaxLevels; ++i) {
+          start = lqv == i ? lv.start[i] : start; Wq = lqv == i ? lv.W[i] : Wq;
+          rwq = lqv == i ? lv.rw[i] : rwq; rhq = lqv == i ? lv.rh[i] : rhq;
+        }
+        const bool bit = (((lane < 32 ? mlo : mhi) >> (lane & 31)) & 1u) != 0u;
+        const int gi = ex + (int)__builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u));
+        if (bit && gi >= pass0 && gi < pass1) {
+          const int qy = byv * kPatchB + (lane >> 3), qx = bxv * kPatchB + (lane & 7);
+          T3Hit r;
+          r.q = start + qy * Wq + qx; r.ax = anchor_from_ratio(qx, rwq); r.ay = anchor_from_ratio(qy, rhq); r.pad = 0;
+          S.hits[gi - pass0] = r;
+        }
+      }
+    }
+    lds_barrier();
+
+    float2 n_xy = make_float2(-4.f, -4.f), n_an = make_float2(0.f, 0.f);
+    float n_a = 0.f;
+    u32x4 n_g = u32x4{0u, 0u, 0u, 0u};
+    auto fetch = [&](int lo_, int nh_) {
+      n_xy = make_float2(-4.f, -4.f); n_a = 0.f;
+      if (h < nh_ && !(plan.debug & 4)) {
+        const T3Hit r = S.hits[lo_ + h];
+        n_an = make_float2(r.ax, r.ay);
+        typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+        const u32x2_t xy = __builtin_amdgcn_raw_buffer_load_b64(loc_src, (unsigned)r.q * q_loc + 2u * my_item, 0, 0);
+        n_xy = make_float2(__uint_as_float(xy[0]), __uint_as_float(xy[1]));
+        n_a = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(attn_src, (unsigned)r.q * q_attn + my_item, 0, 0));
+      }
+      n_g = u32x4{0u, 0u, 0u, 0u};
+      if (g_thread && gh < nh_ && !(plan.debug & 1))
+        n_g = __builtin_amdgcn_raw_buffer_load_b128(go_src, (unsigned)S.hits[lo_ + gh].q * q_go + (unsigned)(m * kT3RowB + gpart * 16), 0, 0);
+    };
+    fetch(0, min(kT3Hits, np));
+
+    for (int lo = 0; lo < np; lo += kT3Hits) {
+      unsigned ta[2] = {trash, trash};
+      float tw[2] = {0.f, 0.f};
+      unsigned dm = 0u;
+      {
+        const float x = px_coord(n_xy.x, me.W), y = px_coord(n_xy.y, me.H);
+        const bool inside = (y > -1.f) && (x > -1.f) && (y < (float)me.H) && (x < (float)me.W);
+        if (inside && near_anchor(x, y, n_an.x, n_an.y, plan.radius)) {
+          const float yf = floorf(y), xf = floorf(x);
+          const int y0 = (int)yf, x0 = (int)xf;
+          const float lh = y - yf, lw = x - xf, hh = 1.f - lh, hw = 1.f - lw;
+          const float wr = dy ? lh : hh;
+          const float w2[2] = {wr * hw * n_a, wr * lw * n_a};
+          const int ty = y0 + dy;
+          const bool row_ok = ty >= 0 && ty <= me.H - 1 && (ty >> me.shift) == tyi;
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            const int tx = x0 + k;
+            if (row_ok && tx >= 0 && tx <= me.W - 1 && (tx >> me.shift) == txi) {
+              const unsigned pix = (unsigned)(((ty - ty0) << me.shift) + (tx - tx0));
+              ta[k] = wcol + pix * 32u;
+              tw[k] = w2[k];
+              dm |= 1u << ((pix >> 4) + 16u * (unsigned)(h >> 5));
+            }
+          }
+        }
+      }
+      if (g_thread) reinterpret_cast<u32x4 *>(S.G)[tid] = n_g;
+      if (lo + kT3Hits < np) fetch(lo + kT3Hits, min(kT3Hits, np - lo - kT3Hits));
+      // the four points of a hit add one after the other (see tile3_body); point 0 finds its column clear
+#pragma unroll
+      for (int ph = 0; ph < kPatchP; ++ph) {
+        int phv = ph;
+        asm volatile("" : "+s"(phv));
+        if (p == phv) {
+          if (ph == 0) {
+            t3_lds_write(ta[0], tw[0]); t3_lds_write(ta[1], tw[1]);
+          } else {
+            float v[4] = {t3_lds_read(ta[0]), t3_lds_read(ta[1]), 0.f, 0.f};
+            t3_lds_wait(v);
+            t3_lds_write(ta[0], v[0] + tw[0]); t3_lds_write(ta[1], v[1] + tw[1]);
+          }
+        }
+      }
+      {
+        unsigned v = dm;
+        v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);
+        v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);
+        v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true);
+        v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, true);
+        const unsigned wv = __builtin_amdgcn_readlane(v, 0) | __builtin_amdgcn_readlane(v, 16) |
+                            __builtin_amdgcn_readlane(v, 32) | __builtin_amdgcn_readlane(v, 48);
+        if (lane == 0) S.dirty[wave] = wv;
+      }
+      lds_barrier();
+      if (!(plan.debug & 2)) {
+        const u32x4 d0 = *reinterpret_cast<const u32x4 *>(S.dirty), d1 = *reinterpret_cast<const u32x4 *>(S.dirty + 4);
+        const unsigned dirty = __builtin_amdgcn_readfirstlane(d0.x | d0.y | d0.z | d0.w | d1.x | d1.y | d1.z | d1.w) >> (16 * kstep);
+        if (dirty & 0xffffu) {
+          gemm_bf16x8 bf[3];
+#pragma unroll
+          for (int cb = 0; cb < 3; ++cb) bf[cb] = tile3_bfrag(gfrag + 32 * cb);
+#pragma unroll
+          for (int i = 0; i < NACC; ++i) {
+            const int pb = 4 * i + wq;
+            if (!((dirty >> pb) & 1u)) continue;
+            const unsigned char *wp = S.W + (kstep * 4 + g4) * PLANE + (16 * pb + r16) * 32;
+            const f32x4 r0 = *reinterpret_cast<const f32x4 *>(wp), r1 = *reinterpret_cast<const f32x4 *>(wp + 16);
+            gemm_bf16x8 ahi, alo;
+            tile3_split(r0, r1, ahi, alo);
+#pragma unroll
+            for (int cb = 0; cb < 3; ++cb) acc[i][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[cb], ahi, acc[i][cb], 0, 0, 0);
+#pragma unroll
+            for (int cb = 0; cb < 3; ++cb) acc[i][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[cb], alo, acc[i][cb], 0, 0, 0);
+          }
+        }
+      }
+      lds_barrier();
+      t3_lds_write(ta[0], 0.f); t3_lds_write(ta[1], 0.f);
+    }
+    lds_barrier();
+  }
+
+  // ---- the two k-step halves meet (waves 4-7 park theirs in the Wt region, free by now), then waves 0-3 store the tile ----
+  f32x4 *park = reinterpret_cast<f32x4 *>(S.W);
+  if (kstep == 1) {
+#pragma unroll
+    for (int i = 0; i < NACC; ++i)
+#pragma unroll
+      for (int cb = 0; cb < 3; ++cb) park[((wq * NACC + i) * 3 + cb) * 64 + lane] = acc[i][cb];
+  }
+  lds_barrier();
+  if (kstep == 0) {
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) {
+      if (dst[i]) {
+#pragma unroll
+        for (int cb = 0; cb < 3; ++cb)
+          *reinterpret_cast<gemm_f32x4 *>(dst[i] + 16 * cb) = acc[i][cb] + park[((wq * NACC + i) * 3 + cb) * 64 + lane];
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(kT3WideThreads) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void msda_bwd_d48_tile3_wide_kernel(const void *__restrict__ grad_out, const float *__restrict__ loc, const float *__restrict__ attn,
+                                    CoreDims d, PatchPlan plan, T3Class cls, float *__restrict__ grad_value) {
+  __shared__ Tile3LdsWide S;
+  const int tiles = cls.tiles;
+  const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+  const int nm = xcd * ((d.N * d.M + 7) >> 3) + jb / tiles;
+  if (nm >= d.N * d.M) return;
+  const int ct = tiles - 1 - jb % tiles;
+  const int m = nm % d.M, n = nm / d.M;
+  int l = 0, t = 0;
+  for (int i = 0; i < plan.L; ++i)
+    if (cls.base[i] >= 0 && ct >= cls.base[i]) { l = i; t = ct - cls.base[i]; }
+  tile3_body_wide(S, reinterpret_cast<const unsigned char *>(grad_out), loc, attn, d, plan, grad_value, n, m, l, t);
+}
+
 template <int WPX>
 __global__ __launch_bounds__(kPatchThreads) __attribute__((amdgpu_waves_per_eu(WPX == 256 ? 2 : 5, WPX == 256 ? 2 : 5)))
 void msda_bwd_d48_tile3_kernel(const void *__restrict__ grad_out, const float *__restrict__ loc, const float *__restrict__ attn,
