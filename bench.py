@@ -208,7 +208,7 @@ def msda_alg_bytes(d, bwd):
 PMC_PROFILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r04_pmc_bench_step.csv")
 
 
-BWD_KERNELS = ("msda_bwd_d48_patchbin_kernel", "msda_bwd_d48_tile3_kernel")       # query side, grad_value side (bf16 rows)
+BWD_KERNELS = ("msda_bwd_d48_patchbin", "msda_bwd_d48_tile3")       # query side; grad_value side (bf16 rows: two kernels, by tile size)
 
 
 def pmc_traffic(path=PMC_PROFILE):
@@ -231,8 +231,8 @@ def pmc_traffic(path=PMC_PROFILE):
                 continue
             name, counter, _, kb = line.rsplit(",", 3)
             for tag in BWD_KERNELS:
-                if tag in name:
-                    vals[(tag, counter.strip())] = float(kb) * 1024.0
+                if tag in name:             # (per launch of the C call: the grad_value side's kernels add up)
+                    vals[(tag, counter.strip())] = vals.get((tag, counter.strip()), 0.0) + float(kb) * 1024.0
         try:
             lib_hash = open(_build.HASH_PATH).read().strip()
         except OSError:

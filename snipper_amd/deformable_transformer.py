@@ -292,13 +292,18 @@ class DeformableTransformerEncoderLayer(nn.Module, _FFNMixin):
         attended = self.self_attn(q16, reference_points, src16, spatial_shapes, level_start_index, padding_mask)
         # (the float32 result of norm1 feeds norm2's residual only, and -- unless this is the last layer -- norm2's feeds the
         #  next layer's norm1 only: neither is materialised, the consuming kernel recomputes it from the saved pre-norm sum)
+        lazy = "lazy" if _LN_LAZY else True
         y32, y16, _ = add_dropout_layer_norm(src32, attended, self.norm1, self.dropout1.p, self.training,
-                                             want=("lazy", True, False))
+                                             want=(lazy, True, False))
         z = big_ffn(y16, self.linear1, self.linear2, self.dropout2)
         if z is None:
             z = big_linear(big_linear(y16, self.linear1, relu=True, dropout=self.dropout2), self.linear2)
         return add_dropout_layer_norm(y32, z, self.norm2, self.dropout3.p, self.training, pos=pos16,
-                                      want=(True if last else "lazy", True, not last))
+                                      want=(True if last else lazy, True, not last))
+
+
+import os as _os
+_LN_LAZY = _os.environ.get("SNIPPER_LN_LAZY", "1") != "0"      # (A/B aid: 0 = materialise the float32 residual stream)
 
 
 class DeformableTransformerEncoder(nn.Module):

@@ -20,8 +20,8 @@ sumfile() { ls $out/pmc_$1/*/*counter_collection.csv 2>/dev/null | head -1; }
 {
   echo "# srchash=$(cat snipper_amd/libsnipper_msda.so.srchash)"
   echo "kernel,counter,dispatches,mean_value_KB"
-  for c in FETCH_SIZE; do f=$(sumfile fetch); [ -n "$f" ] && python3 tools/pmc_summary.py $f $c snipper:: | head -16; done
-  for c in WRITE_SIZE; do f=$(sumfile write); [ -n "$f" ] && python3 tools/pmc_summary.py $f $c snipper:: | head -16; done
+  for c in FETCH_SIZE; do f=$(sumfile fetch); [ -n "$f" ] && python3 tools/pmc_summary.py $f $c snipper:: | head -60; done
+  for c in WRITE_SIZE; do f=$(sumfile write); [ -n "$f" ] && python3 tools/pmc_summary.py $f $c snipper:: | head -60; done
 } > $out/pmc_bench_step.csv
 {
   echo "kernel,counter,dispatches,mean_value"
