@@ -123,6 +123,7 @@ __device__ __forceinline__ void tile3_body(LDS &S, const unsigned char *__restri
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int LP = d.L * kPatchP;
   const size_t row_base = (size_t)n * d.Lq;
+  const unsigned th = (unsigned)min(edge, me.H - ty0), tw_ = (unsigned)min(edge, me.W - tx0);     // the tile's extent inside the map
 
   // ---- A. this thread's candidate block: its mark word (as msda_bwd_d48_tile2_kernel) ----
   unsigned long long mask = 0ull;
@@ -266,14 +267,13 @@ __device__ __forceinline__ void tile3_body(LDS &S, const unsigned char *__restri
           const float w4[4] = {hh * hw * n_a, hh * lw * n_a, lh * hw * n_a, lh * lw * n_a};
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
-            const int ty = y0 + (k >> 1), tx = x0 + (k & 1);
-            const bool mine = ty >= 0 && ty <= me.H - 1 && tx >= 0 && tx <= me.W - 1 && (ty >> me.shift) == tyi &&
-                              (tx >> me.shift) == txi;
-            if (mine) {
-              const unsigned pix = (unsigned)(((ty - ty0) << me.shift) + (tx - tx0));
+            // in the map AND in this tile <=> inside the tile's extent within the map (two unsigned compares)
+            const unsigned ry = (unsigned)(y0 + (k >> 1) - ty0), rx = (unsigned)(x0 + (k & 1) - tx0);
+            if (ry < th && rx < tw_) {
+              const unsigned pix = (ry << me.shift) + rx;
               ta[k] = wcol + pix * 32u;
               tw[k] = w4[k];
-              dm |= 1u << ((pix >> 4) + 16u * (unsigned)(h >> 5));
+              if constexpr (NPB >= 16) dm |= 1u << ((pix >> 4) + 16u * (unsigned)(h >> 5));
             }
           }
         }
@@ -306,8 +306,9 @@ __device__ __forceinline__ void tile3_body(LDS &S, const unsigned char *__restri
           }
         }
       }
-      // which (k-step, pixel block) fragments are not all zeros: OR over the wave (DPP within rows of 16, then the 4 rows)
-      {
+      // which (k-step, pixel block) fragments are not all zeros: OR over the wave (DPP within rows of 16, then the 4 rows).
+      // (16 x 16 tiles only: a small tile has one or two fragments per wave and round, the bookkeeping costs more than it saves)
+      if constexpr (NPB >= 16) {
         unsigned v = dm;
         v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);     // quad_perm [1,0,3,2]
         v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);     // quad_perm [2,3,0,1]
@@ -320,8 +321,13 @@ __device__ __forceinline__ void tile3_body(LDS &S, const unsigned char *__restri
       lds_barrier();      // Wt, G and the dirty words complete
       // ---- tile^T += G^T . Wt^T on the matrix pipe ----
       if ((NPB >= 4 || wave == 0) && !(plan.debug & 2)) {
-        const u32x4 dw = *reinterpret_cast<const u32x4 *>(S.dirty);
-        const unsigned dirty = __builtin_amdgcn_readfirstlane(dw.x | dw.y | dw.z | dw.w);
+        unsigned dirty = 0xffffffffu;
+        if constexpr (NPB >= 16) {
+          const u32x4 dw = *reinterpret_cast<const u32x4 *>(S.dirty);
+          dirty = __builtin_amdgcn_readfirstlane(dw.x | dw.y | dw.z | dw.w);
+        } else if (min(kT3Hits, np - lo) <= 32) {
+          dirty = 0x0000ffffu;                                        // a last round of <= 32 hits: no second k-step
+        }
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
           if (((dirty >> (16 * s)) & 0xffffu) == 0u) continue;        // (covers a last round of <= 32 hits)
@@ -397,6 +403,7 @@ __device__ __forceinline__ void tile3_body_wide(Tile3LdsWide &S, const unsigned 
   const int kstep = wave >> 2, wq = wave & 3;
   const int LP = d.L * kPatchP;
   const size_t row_base = (size_t)n * d.Lq;
+  const unsigned th = (unsigned)min(edge, me.H - ty0), tw_ = (unsigned)min(edge, me.W - tx0);
 
   // ---- this thread's candidate block: its mark word (threads 256.. have none: <= 256 candidates per tile) ----
   unsigned long long mask = 0ull;
@@ -522,13 +529,12 @@ __device__ __forceinline__ void tile3_body_wide(Tile3LdsWide &S, const unsigned 
           const float lh = y - yf, lw = x - xf, hh = 1.f - lh, hw = 1.f - lw;
           const float wr = dy ? lh : hh;
           const float w2[2] = {wr * hw * n_a, wr * lw * n_a};
-          const int ty = y0 + dy;
-          const bool row_ok = ty >= 0 && ty <= me.H - 1 && (ty >> me.shift) == tyi;
+          const unsigned ry = (unsigned)(y0 + dy - ty0);
 #pragma unroll
           for (int k = 0; k < 2; ++k) {
-            const int tx = x0 + k;
-            if (row_ok && tx >= 0 && tx <= me.W - 1 && (tx >> me.shift) == txi) {
-              const unsigned pix = (unsigned)(((ty - ty0) << me.shift) + (tx - tx0));
+            const unsigned rx = (unsigned)(x0 + k - tx0);
+            if (ry < th && rx < tw_) {         // in the map AND in this tile
+              const unsigned pix = (ry << me.shift) + rx;
               ta[k] = wcol + pix * 32u;
               tw[k] = w2[k];
               dm |= 1u << ((pix >> 4) + 16u * (unsigned)(h >> 5));
