@@ -231,6 +231,26 @@ template <bool GO_BF16> struct PatchDot<uint16_t, GO_BF16> {
   }
 };
 
+// the rows of a wave (16 of them, 4 point lanes each) that take part, as a 16-bit set: OR over each row's 4 lanes of a ballot,
+// then every 4th bit gathered (scalar arithmetic: the ballot is wave-uniform)
+__device__ __forceinline__ unsigned long long patch_rows_of(unsigned long long bal) {
+  unsigned long long x = (bal | (bal >> 1) | (bal >> 2) | (bal >> 3)) & 0x1111111111111111ull;
+  x = (x | (x >> 3)) & 0x0303030303030303ull;
+  x = (x | (x >> 6)) & 0x000F000F000F000Full;
+  x = (x | (x >> 12)) & 0x000000FF000000FFull;
+  return (x | (x >> 24)) & 0xFFFFull;
+}
+
+// One workgroup = one (n, m, 8 x 8 block of queries of one level).  Three phases, TWO barriers (round 4; before, every
+// sampled level ran decode -> barrier -> marks -> gather -> barrier in turn, and the phase stamps of tools/tile2_stamps.py
+// showed 62 % of a workgroup's life outside the gathers: profiles/r04_patchbin_stamps.txt):
+//   0. issue every global load the workgroup needs (loc / attn of all levels, its grad_out rows) and, one thread per
+//      (level, tile), the mark-word slots of all levels at once;
+//   1. decode the samples of ALL levels (thread = (row, point), one sample per level) into LDS records and OR the rows into
+//      the tiles' mark words -- per wave and tile ONE LDS atomic carrying the rows of all its lanes (64 lanes OR-ing bits
+//      into the same word serialise in the LDS atomic unit);
+//   2. store the marks, gather + dot + reduce (32 rows x 8 lanes, twice) and store grad_loc / grad_attn for all levels,
+//      then the far taps' HBM atomics of the levels that have any.
 template <typename VT, bool GO_BF16>
 __global__ __launch_bounds__(kPatchThreads) void msda_bwd_d48_patchbin_kernel(
     const void *__restrict__ grad_out, const VT *__restrict__ value, const float *__restrict__ loc,
@@ -244,15 +264,17 @@ __global__ __launch_bounds__(kPatchThreads) void msda_bwd_d48_patchbin_kernel(
 #else
   constexpr int kStampBytes = 0;
 #endif
-  __shared__ __attribute__((aligned(16))) unsigned char smem[kPatchThreads * sizeof(PatchRec) + 2 * kPatchMaxTiles * 16 +
-                                                           kRows * kPatchRowBytes + kStampBytes];
-  PatchRec *recs = reinterpret_cast<PatchRec *>(smem);
-  unsigned long long *s_mask = reinterpret_cast<unsigned long long *>(recs + kPatchThreads);   // [2][kPatchMaxTiles]
-  long long *s_slot = reinterpret_cast<long long *>(s_mask + 2 * kPatchMaxTiles);              // [2][kPatchMaxTiles]
-  float *s_g = reinterpret_cast<float *>(s_slot + 2 * kPatchMaxTiles);                         // [64 rows][48]: grad_out rows
+  __shared__ __attribute__((aligned(16))) unsigned char smem[kPatchMaxLevels * kPatchThreads * sizeof(PatchRec) +
+                                                           kPatchMaxLevels * kPatchMaxTiles * 16 + kRows * kPatchRowBytes + kStampBytes];
+  PatchRec *recs = reinterpret_cast<PatchRec *>(smem);                                                   // [level][row][point]
+  unsigned long long *s_mask = reinterpret_cast<unsigned long long *>(recs + kPatchMaxLevels * kPatchThreads);   // [level][tile]
+  long long *s_slot = reinterpret_cast<long long *>(s_mask + kPatchMaxLevels * kPatchMaxTiles);          // [level][tile]
+  float *s_g = reinterpret_cast<float *>(s_slot + kPatchMaxLevels * kPatchMaxTiles);                     // [64 rows][48]: grad_out rows
+  __shared__ unsigned s_need_word;
+  unsigned *s_need = &s_need_word;                                                                       // bit l: level l has far taps
   PatchBlock b;
   if (!patch_block(plan, d, nblk_padded, b)) return;
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #ifdef TILE2_STAMPS
   // (tools/tile2_stamps.py: the second half of the stamp buffer, wave 0 of every 97th workgroup)
   unsigned long long *pst = reinterpret_cast<unsigned long long *>(s_g + kRows * kD48);
@@ -278,73 +300,7 @@ __global__ __launch_bounds__(kPatchThreads) void msda_bwd_d48_patchbin_kernel(
   const auto vsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<VT *>(value), 0, (int)value_bytes, 0x00020000);
   const auto gsrc = __builtin_amdgcn_make_buffer_rsrc(grad_value, 0, (int)gv_bytes, 0x00020000);
 
-  // this thread's slices of the two grad_out rows it gathers for (channels 4j..4j+3, 32+2j, 33+2j); the rows also go to
-  // LDS for the atomic phase, which re-deals them over 16 lanes per row
-  float g[2][6];
-  unsigned gp[2][3];
-  long long rowg[2];
-  bool rg_ok[2];
-#pragma unroll
-  for (int ps = 0; ps < 2; ++ps) {
-    const int r = ps * 32 + rg, ry = r >> 3, rx = r & 7;
-    rg_ok[ps] = ry < b.bh && rx < b.bw;
-    const int q = rg_ok[ps] ? lvq.start + (b.qy0 + ry) * lvq.W + b.qx0 + rx : lvq.start;
-    rowg[ps] = ((long long)b.n * d.Lq + q) * d.M + b.m;
-    gp[ps][0] = gp[ps][1] = gp[ps][2] = 0u;
-    // channel offsets of this lane's two pieces (4 + 2 channels, or 6 contiguous ones as 4 + 2)
-    const int ca = DOT::kContig ? 6 * j : 4 * j, cb = DOT::kContig ? 6 * j + 4 : 32 + 2 * j;
-    if constexpr (GO_BF16) {
-      const uint16_t *gr = reinterpret_cast<const uint16_t *>(grad_out) + rowg[ps] * kD48;
-      unsigned p0, p1, p2;
-      if constexpr (DOT::kContig) {            // 12 bytes at 12 j: 4-byte aligned
-        const unsigned *g32 = reinterpret_cast<const unsigned *>(gr + ca);
-        p0 = g32[0]; p1 = g32[1]; p2 = g32[2];
-      } else {
-        const uint2 pa = *reinterpret_cast<const uint2 *>(gr + ca);
-        p0 = pa.x; p1 = pa.y; p2 = *reinterpret_cast<const unsigned *>(gr + cb);
-      }
-      gp[ps][0] = p0; gp[ps][1] = p1; gp[ps][2] = p2;
-      g[ps][0] = __uint_as_float(p0 << 16); g[ps][1] = __uint_as_float(p0 & 0xffff0000u);
-      g[ps][2] = __uint_as_float(p1 << 16); g[ps][3] = __uint_as_float(p1 & 0xffff0000u);
-      g[ps][4] = __uint_as_float(p2 << 16); g[ps][5] = __uint_as_float(p2 & 0xffff0000u);
-    } else {
-      const float *gr = reinterpret_cast<const float *>(grad_out) + rowg[ps] * kD48;
-      if constexpr (DOT::kContig) {
-        const float2 a0 = *reinterpret_cast<const float2 *>(gr + ca), a1 = *reinterpret_cast<const float2 *>(gr + ca + 2);
-        const float2 a2 = *reinterpret_cast<const float2 *>(gr + cb);
-        g[ps][0] = a0.x; g[ps][1] = a0.y; g[ps][2] = a1.x; g[ps][3] = a1.y; g[ps][4] = a2.x; g[ps][5] = a2.y;
-      } else {
-        const f32x4 pa = *reinterpret_cast<const f32x4 *>(gr + ca);
-        const float2 pb = *reinterpret_cast<const float2 *>(gr + cb);
-        g[ps][0] = pa.x; g[ps][1] = pa.y; g[ps][2] = pa.z; g[ps][3] = pa.w; g[ps][4] = pb.x; g[ps][5] = pb.y;
-      }
-    }
-    if (!rg_ok[ps]) {
-#pragma unroll
-      for (int c = 0; c < 6; ++c) g[ps][c] = 0.f;
-      gp[ps][0] = gp[ps][1] = gp[ps][2] = 0u;
-    }
-    // the row also goes to LDS (float32) for the atomic phase
-    *reinterpret_cast<float2 *>(s_g + r * kD48 + ca) = make_float2(g[ps][0], g[ps][1]);
-    *reinterpret_cast<float2 *>(s_g + r * kD48 + ca + 2) = make_float2(g[ps][2], g[ps][3]);
-    *reinterpret_cast<float2 *>(s_g + r * kD48 + cb) = make_float2(g[ps][4], g[ps][5]);
-  }
-
-  // slots of the first level (later levels: computed one level ahead, behind the gather of the current one)
-  auto fill_slots = [&](int l) {
-    const PatchTileBox tb = patch_tile_box(plan, b, l);
-    const int nt = min(tb.ntx * tb.nty, kPatchMaxTiles);
-    if (tid < kPatchMaxTiles) {
-      long long s = -1;
-      if (tid < nt) {
-        const int tiy = tid / tb.ntx, tix = tid - tiy * tb.ntx;
-        s = patch_slot(plan, b, d.M, l, tb.ty0 + tiy, tb.tx0 + tix);
-      }
-      s_slot[(l & 1) * kPatchMaxTiles + tid] = s;
-      s_mask[(l & 1) * kPatchMaxTiles + tid] = 0ull;
-    }
-  };
-  fill_slots(0);
+  // ---- phase 0: loads.  loc / attn of this thread's sample in every level first (phase 1 waits for them only) ...
   float2 xy_l[kPatchMaxLevels];
   float a_l[kPatchMaxLevels];
 #pragma unroll
@@ -356,68 +312,165 @@ __global__ __launch_bounds__(kPatchThreads) void msda_bwd_d48_patchbin_kernel(
       a_l[l] = attn[li];
     }
   }
+  // ... then this thread's slices of the two grad_out rows it gathers for (channels 4j..4j+3, 32+2j, 33+2j, or 6j..6j+5),
+  // left in flight until phase 1 is done
+  unsigned graw[2][6];
+  long long rowg[2];
+  bool rg_ok[2];
+  constexpr int kCa = DOT::kContig ? 6 : 4;
+#pragma unroll
+  for (int ps = 0; ps < 2; ++ps) {
+    const int r = ps * 32 + rg, ry = r >> 3, rx = r & 7;
+    rg_ok[ps] = ry < b.bh && rx < b.bw;
+    const int q = rg_ok[ps] ? lvq.start + (b.qy0 + ry) * lvq.W + b.qx0 + rx : lvq.start;
+    rowg[ps] = ((long long)b.n * d.Lq + q) * d.M + b.m;
+    const int ca = kCa * j, cb = DOT::kContig ? 6 * j + 4 : 32 + 2 * j;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) graw[ps][c] = 0u;
+    if constexpr (GO_BF16) {
+      const uint16_t *gr = reinterpret_cast<const uint16_t *>(grad_out) + rowg[ps] * kD48;
+      if constexpr (DOT::kContig) {            // 12 bytes at 12 j: 4-byte aligned
+        const unsigned *g32 = reinterpret_cast<const unsigned *>(gr + ca);
+        graw[ps][0] = g32[0]; graw[ps][1] = g32[1]; graw[ps][2] = g32[2];
+      } else {
+        const uint2 pa = *reinterpret_cast<const uint2 *>(gr + ca);
+        graw[ps][0] = pa.x; graw[ps][1] = pa.y; graw[ps][2] = *reinterpret_cast<const unsigned *>(gr + cb);
+      }
+    } else {
+      const float *gr = reinterpret_cast<const float *>(grad_out) + rowg[ps] * kD48;
+      if constexpr (DOT::kContig) {
+        const uint2 a0 = *reinterpret_cast<const uint2 *>(gr + ca), a1 = *reinterpret_cast<const uint2 *>(gr + ca + 2);
+        const uint2 a2 = *reinterpret_cast<const uint2 *>(gr + cb);
+        graw[ps][0] = a0.x; graw[ps][1] = a0.y; graw[ps][2] = a1.x; graw[ps][3] = a1.y; graw[ps][4] = a2.x; graw[ps][5] = a2.y;
+      } else {
+        const u32x4 pa = *reinterpret_cast<const u32x4 *>(gr + ca);
+        const uint2 pb = *reinterpret_cast<const uint2 *>(gr + cb);
+        graw[ps][0] = pa.x; graw[ps][1] = pa.y; graw[ps][2] = pa.z; graw[ps][3] = pa.w; graw[ps][4] = pb.x; graw[ps][5] = pb.y;
+      }
+    }
+  }
+  // mark-word slots of every level: thread (wave = level, lane = tile of the level's box)
+  if (wave < plan.L) {
+    const PatchTileBox tb = patch_tile_box(plan, b, wave);
+    const int nt = min(tb.ntx * tb.nty, kPatchMaxTiles);
+    long long sl = -1;
+    if (lane < nt) {
+      const int tiy = lane / tb.ntx, tix = lane - tiy * tb.ntx;
+      sl = patch_slot(plan, b, d.M, wave, tb.ty0 + tiy, tb.tx0 + tix);
+    }
+    s_slot[wave * kPatchMaxTiles + lane] = sl;
+    s_mask[wave * kPatchMaxTiles + lane] = 0ull;
+  }
+  if (tid == 0) *s_need = 0u;
   PATCH_STAMP(1);
-  __syncthreads();
+  lds_barrier();                 // slots and cleared masks visible (the global loads stay in flight)
   PATCH_STAMP(2);
 
+  // ---- phase 1: decode + marks, all levels ----
+  unsigned need_lv = 0u;         // bit l: a tap of this thread's sample in level l needs an HBM atomic
 #pragma unroll
   for (int l = 0; l < kPatchMaxLevels; ++l) {
     if (l >= plan.L) break;
     const PatchLevel lvl = plan.lv[l];
     const PatchTileBox tb = patch_tile_box(plan, b, l);
-    unsigned long long *mask_l = s_mask + (l & 1) * kPatchMaxTiles;
-    const long long *slot_l = s_slot + (l & 1) * kPatchMaxTiles;
+    unsigned long long *mask_l = s_mask + l * kPatchMaxTiles;
+    const long long *slot_l = s_slot + l * kPatchMaxTiles;
     unsigned my_bits = 0u;
-    {
-      const float2 xy = xy_l[l];
-      const float a_in = a_l[l];
-      const float y = px_coord(xy.y, lvl.H), x = px_coord(xy.x, lvl.W);
-      const bool inside = rd_ok && (y > -1.f) && (x > -1.f) && (y < (float)lvl.H) && (x < (float)lvl.W);
-      const bool near = inside && near_anchor(x, y, anchor_from_ratio(b.qx0 + rdx, plan.rw[l][b.lq]),
-                                              anchor_from_ratio(b.qy0 + rdy, plan.rh[l][b.lq]), plan.radius);
-      const float yf = floorf(y), xf = floorf(x);
-      const int y0 = (int)yf, x0 = (int)xf;
-      PatchRec r;
-      r.w.x = inside ? y - yf : 0.f; r.w.y = inside ? x - xf : 0.f; r.w.z = inside ? a_in : 0.f;
-      unsigned go[4];
+    const float2 xy = xy_l[l];
+    const float a_in = a_l[l];
+    const float y = px_coord(xy.y, lvl.H), x = px_coord(xy.x, lvl.W);
+    const bool inside = rd_ok && (y > -1.f) && (x > -1.f) && (y < (float)lvl.H) && (x < (float)lvl.W);
+    const bool near = inside && near_anchor(x, y, anchor_from_ratio(b.qx0 + rdx, plan.rw[l][b.lq]),
+                                            anchor_from_ratio(b.qy0 + rdy, plan.rh[l][b.lq]), plan.radius);
+    const float yf = floorf(y), xf = floorf(x);
+    const int y0 = (int)yf, x0 = (int)xf;
+    PatchRec r;
+    r.w.x = inside ? y - yf : 0.f; r.w.y = inside ? x - xf : 0.f; r.w.z = inside ? a_in : 0.f;
+    unsigned go[4];
+    int ti_k[4];                 // the tile (index in the level's box) that owns tap k, or -1
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int ty = y0 + (k >> 1), tx = x0 + (k & 1);
-        const bool in_map = inside && ty >= 0 && ty <= lvl.H - 1 && tx >= 0 && tx <= lvl.W - 1;
-        go[k] = in_map ? gbase + (unsigned)(lvl.start + ty * lvl.W + tx) * px_stride : kOobOffset;
-        bool owned = false;
-        if (near && in_map) {
-          const int tix = (tx >> lvl.shift) - tb.tx0, tiy = (ty >> lvl.shift) - tb.ty0;
-          if (tix >= 0 && tix < tb.ntx && tiy >= 0 && tiy < tb.nty) {
-            const int ti = tiy * tb.ntx + tix;
-            if (ti < kPatchMaxTiles && slot_l[ti] >= 0) {
-              owned = true;
-              atomicOr(&mask_l[ti], 1ull << rd);
-            }
-          }
+    for (int k = 0; k < 4; ++k) {
+      const int ty = y0 + (k >> 1), tx = x0 + (k & 1);
+      const bool in_map = inside && ty >= 0 && ty <= lvl.H - 1 && tx >= 0 && tx <= lvl.W - 1;
+      go[k] = in_map ? gbase + (unsigned)(lvl.start + ty * lvl.W + tx) * px_stride : kOobOffset;
+      ti_k[k] = -1;
+      if (near && in_map) {
+        const int tix = (tx >> lvl.shift) - tb.tx0, tiy = (ty >> lvl.shift) - tb.ty0;
+        if (tix >= 0 && tix < tb.ntx && tiy >= 0 && tiy < tb.nty) {
+          const int ti = tiy * tb.ntx + tix;
+          if (ti < kPatchMaxTiles && slot_l[ti] >= 0) ti_k[k] = ti;
         }
-        my_bits |= (in_map && !owned) ? (16u << k) : 0u;        // need: no tile owns the tap -> HBM atomic here
-        // ... and the tile it lands in is told so (plain byte stores of the same value: no atomic needed), which lets the
-        // matrix-pipe tile kernel start clean tiles from zero instead of reading grad_value back
-        if (in_map && !owned)
-          plan.dirty[((size_t)b.n * d.M + b.m) * plan.total_tiles + lvl.tile_base + (ty >> lvl.shift) * lvl.ntx + (tx >> lvl.shift)] = 1;
       }
-      r.w.w = __uint_as_float(my_bits);
-      r.g.x = go[0]; r.g.y = go[1]; r.g.z = go[2]; r.g.w = go[3];
-      recs[tid] = r;
+      const bool owned = ti_k[k] >= 0;
+      my_bits |= (in_map && !owned) ? (16u << k) : 0u;        // need: no tile owns the tap -> HBM atomic here
+      // ... and the tile it lands in is told so (plain byte stores of the same value: no atomic needed), which lets the
+      // matrix-pipe tile kernel start clean tiles from zero instead of reading grad_value back
+      if (in_map && !owned)
+        plan.dirty[((size_t)b.n * d.M + b.m) * plan.total_tiles + lvl.tile_base + (ty >> lvl.shift) * lvl.ntx + (tx >> lvl.shift)] = 1;
     }
-    PATCH_STAMP(3);
-    const int any_need = __syncthreads_or((int)my_bits);     // records and masks complete; does ANY tap need an atomic?
-    PATCH_STAMP(4);
+    // marks: a tap whose tile an earlier tap of the sample already marks adds nothing
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      bool want = ti_k[k] >= 0;
+#pragma unroll
+      for (int e = 0; e < k; ++e) want = want && ti_k[e] != ti_k[k];
+      if (want) atomicOr(&mask_l[ti_k[k]], 1ull << rd);
+    }
+    r.w.w = __uint_as_float(my_bits);
+    r.g.x = go[0]; r.g.y = go[1]; r.g.z = go[2]; r.g.w = go[3];
+    recs[l * kPatchThreads + tid] = r;
+    need_lv |= my_bits ? (1u << l) : 0u;
+  }
+  // the grad_out rows have landed by now: float32 copy to LDS for the atomic phase (re-dealt there over 16 lanes per row)
+  float g[2][6];
+  unsigned gp[2][3];
+#pragma unroll
+  for (int ps = 0; ps < 2; ++ps) {
+    const int r = ps * 32 + rg;
+    const int ca = kCa * j, cb = DOT::kContig ? 6 * j + 4 : 32 + 2 * j;
+    if constexpr (GO_BF16) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        gp[ps][c] = rg_ok[ps] ? graw[ps][c] : 0u;
+        g[ps][2 * c] = __uint_as_float(gp[ps][c] << 16); g[ps][2 * c + 1] = __uint_as_float(gp[ps][c] & 0xffff0000u);
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) gp[ps][c] = 0u;
+#pragma unroll
+      for (int c = 0; c < 6; ++c) g[ps][c] = rg_ok[ps] ? __uint_as_float(graw[ps][c]) : 0.f;
+    }
+    *reinterpret_cast<float2 *>(s_g + r * kD48 + ca) = make_float2(g[ps][0], g[ps][1]);
+    *reinterpret_cast<float2 *>(s_g + r * kD48 + ca + 2) = make_float2(g[ps][2], g[ps][3]);
+    *reinterpret_cast<float2 *>(s_g + r * kD48 + cb) = make_float2(g[ps][4], g[ps][5]);
+  }
+  // which levels need atomics at all (workgroup-wide; __syncthreads_or only says whether ANY bit is set)
+  {
+    unsigned wneed = 0u;
+#pragma unroll
+    for (int l = 0; l < kPatchMaxLevels; ++l) wneed |= __ballot((need_lv >> l) & 1u) != 0ull ? (1u << l) : 0u;
+    if (lane == 0 && wneed) atomicOr(s_need, wneed);
+  }
+  PATCH_STAMP(3);
+  lds_barrier();                 // records, masks and rows complete
+  const unsigned any_need = *s_need;
+  PATCH_STAMP(4);
 
-    if (tid < kPatchMaxTiles && slot_l[tid] >= 0 && mask_l[tid] != 0ull) plan.marks[slot_l[tid]] = mask_l[tid];
-    if (l + 1 < plan.L) fill_slots(l + 1);
-    PATCH_STAMP(5);
-
+  // ---- phase 2: marks out, gathers, far atomics ----
+  if (wave < plan.L) {
+    const long long sl = s_slot[wave * kPatchMaxTiles + lane];
+    const unsigned long long mk = s_mask[wave * kPatchMaxTiles + lane];
+    if (sl >= 0 && mk != 0ull) plan.marks[sl] = mk;
+  }
+  PATCH_STAMP(5);
+#pragma unroll
+  for (int l = 0; l < kPatchMaxLevels; ++l) {
+    if (l >= plan.L) break;
+    const PatchLevel lvl = plan.lv[l];
     if (!(plan.debug & 2))
 #pragma unroll
     for (int ps = 0; ps < 2; ++ps) {
-      const PatchRec *mine = recs + (ps * 32 + rg) * kPatchP;
+      const PatchRec *mine = recs + l * kPatchThreads + (ps * 32 + rg) * kPatchP;
       float keep_a = 0.f, keep_x = 0.f, keep_y = 0.f;
 #pragma unroll
       for (int p = 0; p < kPatchP; ++p) {
@@ -447,7 +500,7 @@ __global__ __launch_bounds__(kPatchThreads) void msda_bwd_d48_patchbin_kernel(
     // taps no tile owns (sample not near its anchor, or beyond the marks' capacity): the HBM float atomic of
     // msda_d48.cuh.  Re-dealt to 16 lanes per row, lane i adding channels {i, i+16, i+32}: every atomic instruction then
     // adds 64 contiguous bytes per row (the shape the memory-side atomic units take at full rate).
-    if (any_need) {
+    if (any_need & (1u << l)) {
       const int ai = tid & 15, ar = tid >> 4;
 #pragma unroll 1
       for (int pass = 0; pass < kRows / 16; ++pass) {
@@ -455,7 +508,7 @@ __global__ __launch_bounds__(kPatchThreads) void msda_bwd_d48_patchbin_kernel(
         const float g0 = s_g[r * kD48 + ai], g1 = s_g[r * kD48 + 16 + ai], g2 = s_g[r * kD48 + 32 + ai];
 #pragma unroll
         for (int p = 0; p < kPatchP; ++p) {
-          const PatchRec rc = recs[r * kPatchP + p];
+          const PatchRec rc = recs[l * kPatchThreads + r * kPatchP + p];
           const unsigned bits = __float_as_uint(rc.w.w) >> 4;
           if (__builtin_amdgcn_ballot_w64(bits != 0u) == 0ull) continue;
           const float lh = rc.w.x, lw = rc.w.y, a = rc.w.z;
@@ -474,8 +527,6 @@ __global__ __launch_bounds__(kPatchThreads) void msda_bwd_d48_patchbin_kernel(
       }
     }
     PATCH_STAMP(7);
-    __syncthreads();     // before the records and the other half of the slots are overwritten
-    PATCH_STAMP(8);
   }
 #ifdef TILE2_STAMPS
   if (pst_out && tid == 0)

@@ -14,6 +14,9 @@ os.environ["SNIPPER_TILE2_STAMPS"] = hex(buf.data_ptr())
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import opbench
 from opbench import MSDA, SHAPES
+if os.environ.get("SNIPPER_TILE_KERNEL"):
+    from snipper_amd import _lib as _l
+    _l.set_param("tile_kernel", int(os.environ["SNIPPER_TILE_KERNEL"]))
 sigma = float(sys.argv[1]) if len(sys.argv) > 1 else 0.01
 S = sum(h * w for h, w in SHAPES)
 v_, shapes, lsi, loc, attn, go = opbench.make(8, S, True, torch.bfloat16, sigma=sigma, grid=True)
@@ -45,13 +48,16 @@ for wg in v:
         acc[(a, b)] = acc.get((a, b), 0) + (tb - ta)
     for k, d in acc.items():
         seg.setdefault(k, []).append(d)
-print(f"sigma {sigma} px: {len(life)} sampled workgroups, life time median {statistics.median(life):.0f} mean {statistics.mean(life):.0f} cycles, "
-      f"rounds per workgroup mean {statistics.mean(rounds):.2f}, hits per tile mean {statistics.mean(hits):.0f} max {max(hits)}")
-tot = statistics.mean(life)
-for k, ds in sorted(seg.items(), key=lambda kv: -sum(kv[1])):
-    share = sum(ds) / len(life) / tot
-    print(f"  {names.get(k[0], k[0])!s:38s} -> {names.get(k[1], k[1])!s:38s}: per-workgroup total median {statistics.median(ds):8.0f}  mean {statistics.mean(ds):8.0f}  "
-          f"share {100 * share:5.1f} %  (n {len(ds)})")
+if life:
+    print(f"sigma {sigma} px: {len(life)} sampled workgroups, life time median {statistics.median(life):.0f} mean {statistics.mean(life):.0f} cycles, "
+          f"rounds per workgroup mean {statistics.mean(rounds):.2f}, hits per tile mean {statistics.mean(hits):.0f} max {max(hits)}")
+    tot = statistics.mean(life)
+    for k, ds in sorted(seg.items(), key=lambda kv: -sum(kv[1])):
+        share = sum(ds) / len(life) / tot
+        print(f"  {names.get(k[0], k[0])!s:38s} -> {names.get(k[1], k[1])!s:38s}: per-workgroup total median {statistics.median(ds):8.0f}  mean {statistics.mean(ds):8.0f}  "
+              f"share {100 * share:5.1f} %  (n {len(ds)})")
+else:
+    print("tile kernel: no stamps (the matrix-pipe tile kernel carries none; SNIPPER_TILE_KERNEL=1 selects the vector kernel)")
 
 # ---- the query-side kernel (msda_bwd_d48_patchbin_kernel): wave 0 of every 97th workgroup
 pnames = {0: "start", 1: "rows + first loads issued", 2: "barrier", 3: "level: decode + marks done", 4: "level: barrier (records)",
