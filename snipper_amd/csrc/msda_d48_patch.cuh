@@ -200,9 +200,9 @@ template <typename VT, bool GO_BF16> struct PatchDot;
 template <bool GO_BF16> struct PatchDot<float, GO_BF16> {
   static constexpr unsigned kRowV = 192;
   static constexpr bool kContig = false;      // lane j owns channels 4j..4j+3 and 32+2j, 33+2j (a 16-byte + an 8-byte load)
-  static __device__ __forceinline__ float dot(__amdgpu_buffer_rsrc_t vsrc, unsigned off, int j, const float (&g)[6],
-                                              const unsigned (&)[3]) {
-    const Row6 v = buf_row(vsrc, off, j);
+  typedef Row6 Raw;
+  static __device__ __forceinline__ Raw load(__amdgpu_buffer_rsrc_t vsrc, unsigned off, int j) { return buf_row(vsrc, off, j); }
+  static __device__ __forceinline__ float dot(const Raw &v, const float (&g)[6], const unsigned (&)[3]) {
     return g[0] * v.a.x + g[1] * v.a.y + g[2] * v.a.z + g[3] * v.a.w + g[4] * v.b.x + g[5] * v.b.y;
   }
 };
@@ -212,10 +212,11 @@ template <bool GO_BF16> struct PatchDot<uint16_t, GO_BF16> {
   // (the float32 layout needs a 16-byte and an 8-byte one); the texture path's cost is per instruction and per 64-byte
   // segment touched, and this halves the former (the forward kernel of msda_d48.cuh gathers the same way)
   static constexpr bool kContig = true;
-  static __device__ __forceinline__ float dot(__amdgpu_buffer_rsrc_t vsrc, unsigned off, int j, const float (&g)[6],
-                                              const unsigned (&gp)[3]) {
-    typedef unsigned int u32x3_t __attribute__((ext_vector_type(3)));
-    const u32x3_t a = __builtin_amdgcn_raw_buffer_load_b96(vsrc, off + 12u * j, 0, 0);
+  typedef unsigned int Raw __attribute__((ext_vector_type(3)));
+  static __device__ __forceinline__ Raw load(__amdgpu_buffer_rsrc_t vsrc, unsigned off, int j) {
+    return __builtin_amdgcn_raw_buffer_load_b96(vsrc, off + 12u * j, 0, 0);
+  }
+  static __device__ __forceinline__ float dot(const Raw &a, const float (&g)[6], const unsigned (&gp)[3]) {
     // (elements by INDEX: with `.x` / `.y` on a loaded pair, hipcc of ROCm 7.2 narrowed a 64-bit load to one dword and fed
     //  the first element to both products -- reproduced in isolation, round 2)
     const unsigned ax = a[0], ay = a[1], az = a[2];
@@ -230,6 +231,36 @@ template <bool GO_BF16> struct PatchDot<uint16_t, GO_BF16> {
     }
   }
 };
+
+// x + (x of the DPP partner lane), ONE instruction (v_add_f32_dpp).  Inline assembly: from `v + dpp(v)` hipcc builds
+// v_mov_b32_dpp pairs feeding v_pk_add_f32 (1.5 instructions per sum).  A DPP operand written by the preceding VALU
+// instruction needs two wait states the assembler does not insert: callers pass the inputs through patch_dpp_fence first.
+__device__ __forceinline__ float patch_add_xor1(float x) {
+  float r;
+  asm volatile("v_add_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(x));
+  return r;
+}
+__device__ __forceinline__ float patch_add_xor2(float x) {
+  float r;
+  asm volatile("v_add_f32_dpp %0, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(x));
+  return r;
+}
+__device__ __forceinline__ float patch_add_mirror8(float x) {
+  float r;
+  asm volatile("v_add_f32_dpp %0, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(x));
+  return r;
+}
+template <int N> __device__ __forceinline__ void patch_dpp_fence(float (&v)[N]);
+template <> __device__ __forceinline__ void patch_dpp_fence<3>(float (&v)[3]) {
+  asm volatile("s_nop 1" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]));
+}
+template <> __device__ __forceinline__ void patch_dpp_fence<6>(float (&v)[6]) {
+  asm volatile("s_nop 1" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]));
+}
+template <> __device__ __forceinline__ void patch_dpp_fence<12>(float (&v)[12]) {
+  asm volatile("s_nop 1" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]),
+               "+v"(v[8]), "+v"(v[9]), "+v"(v[10]), "+v"(v[11]));
+}
 
 // the rows of a wave (16 of them, 4 point lanes each) that take part, as a 16-bit set: OR over each row's 4 lanes of a ballot,
 // then every 4th bit gathered (scalar arithmetic: the ballot is wave-uniform)
@@ -463,40 +494,72 @@ __global__ __launch_bounds__(kPatchThreads) void msda_bwd_d48_patchbin_kernel(
     if (sl >= 0 && mk != 0ull) plan.marks[sl] = mk;
   }
   PATCH_STAMP(5);
+  // The gathers: per (level, pass) 16 tap loads in flight, then the dots and the reduction.  (Measured and dropped, round 4:
+  // a software pipeline over points that keeps 8 or 16 loads of the NEXT points in flight across passes and levels --
+  // 294 / 297 us against 282: the phase is bound by the texture path / L1 footprint of three workgroups per CU, more loads
+  // in flight thrash it; the same reason four waves per SIMD are slower.)
+  // 12 sums over the row's 8 lanes of which lane p < 4 needs those of point p only: a transposing reduction, every
+  // stage halves what a lane carries (12 -> 6 -> 3 values: 30 instructions against 4 x 3 x 3 all-reduce steps).
+  // Lane i ends with point tgt(i) = {0, 1, 2, 3, 3, 2, 1, 0}[i]; stage 1 (lane ^ 1) keeps the points of tgt's parity,
+  // stage 2 (lane ^ 2) those of tgt's half, stage 3 adds lane 7 - i (same target).  Order of every sum fixed.
+  const bool keep_even = ((j ^ (j >> 2)) & 1) == 0, keep_h0 = (((j >> 1) ^ (j >> 2)) & 1) == 0;
 #pragma unroll
   for (int l = 0; l < kPatchMaxLevels; ++l) {
-    if (l >= plan.L) break;
-    const PatchLevel lvl = plan.lv[l];
-    if (!(plan.debug & 2))
+    if (l >= plan.L || (plan.debug & 2)) break;
 #pragma unroll
     for (int ps = 0; ps < 2; ++ps) {
       const PatchRec *mine = recs + l * kPatchThreads + (ps * 32 + rg) * kPatchP;
-      float keep_a = 0.f, keep_x = 0.f, keep_y = 0.f;
+      // per point: this lane's share (6 channels) of the four tap dots, folded into its share of
+      //   A = sum_k w_k dot_k,  X = hh (d1 - d0) + lh (d3 - d2),  Y = hw (d2 - d0) + lw (d3 - d1)
+      // in lerp form (10 operations: with f = (d3 - d2) - (d1 - d0), X = e01 + lh f, Y = e02 + lw f)
+      float q[12];             // [quantity A / X / Y][point]
 #pragma unroll
       for (int p = 0; p < kPatchP; ++p) {
         const PatchRec r = mine[p];
-        const float lh = r.w.x, lw = r.w.y, a = r.w.z;
-        const float hh = 1.f - lh, hw = 1.f - lw;
+        const float lh = r.w.x, lw = r.w.y;
         const unsigned go[4] = {r.g.x, r.g.y, r.g.z, r.g.w};
         float dot[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k)            // (a tap outside the map has offset kOobOffset: the buffer load returns 0)
-          dot[k] = DOT::dot(vsrc, go[k], j, g[ps], gp[ps]);
-        float pa = hh * hw * dot[0] + hh * lw * dot[1] + lh * hw * dot[2] + lh * lw * dot[3];
-        float px = hh * (dot[1] - dot[0]) + lh * (dot[3] - dot[2]);
-        float py = hw * (dot[2] - dot[0]) + lw * (dot[3] - dot[1]);
-        pa = row8_sum(pa);
-        px = row8_sum(px) * (a * (float)lvl.W);
-        py = row8_sum(py) * (a * (float)lvl.H);
-        if (j == p) { keep_a = pa; keep_x = px; keep_y = py; }
+          dot[k] = DOT::dot(DOT::load(vsrc, go[k], j), g[ps], gp[ps]);
+        const float e01 = dot[1] - dot[0], e23 = dot[3] - dot[2], e02 = dot[2] - dot[0], f = e23 - e01;
+        const float t0 = __fmaf_rn(lw, e01, dot[0]), t1 = __fmaf_rn(lw, e23, dot[2]);
+        q[p] = __fmaf_rn(lh, t1 - t0, t0);
+        q[4 + p] = __fmaf_rn(lh, f, e01);
+        q[8 + p] = __fmaf_rn(lw, f, e02);
       }
+      patch_dpp_fence(q);
+      float r6[6];             // [quantity][pair h]: point 2 h + parity
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int hh2 = 0; hh2 < 2; ++hh2) {
+          const float se = patch_add_xor1(q[4 * c + 2 * hh2]), so = patch_add_xor1(q[4 * c + 2 * hh2 + 1]);
+          r6[2 * c + hh2] = keep_even ? se : so;
+        }
+      patch_dpp_fence(r6);
+      float r3[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float s0 = patch_add_xor2(r6[2 * c]), s1 = patch_add_xor2(r6[2 * c + 1]);
+        r3[c] = keep_h0 ? s0 : s1;
+      }
+      patch_dpp_fence(r3);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) r3[c] = patch_add_mirror8(r3[c]);
       if (rg_ok[ps] && j < kPatchP) {
+        const float a = mine[j].w.z;
         const long long li = rowg[ps] * LP + l * kPatchP + j;
-        grad_attn[li] = keep_a;
-        *reinterpret_cast<float2 *>(grad_loc + 2 * li) = make_float2(keep_x, keep_y);
+        grad_attn[li] = r3[0];
+        *reinterpret_cast<float2 *>(grad_loc + 2 * li) =
+            make_float2(r3[1] * (a * (float)plan.lv[l].W), r3[2] * (a * (float)plan.lv[l].H));
       }
     }
-    PATCH_STAMP(6);
+  }
+  PATCH_STAMP(6);
+#pragma unroll
+  for (int l = 0; l < kPatchMaxLevels; ++l) {
+    if (l >= plan.L) break;
     // taps no tile owns (sample not near its anchor, or beyond the marks' capacity): the HBM float atomic of
     // msda_d48.cuh.  Re-dealt to 16 lanes per row, lane i adding channels {i, i+16, i+32}: every atomic instruction then
     // adds 64 contiguous bytes per row (the shape the memory-side atomic units take at full rate).
