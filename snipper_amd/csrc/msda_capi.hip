@@ -17,6 +17,7 @@
 #include "wgrad_bf16.cuh"
 #include "wres_gemm_bf16.cuh"
 #include "wgrad_ring_bf16.cuh"
+#include "conv3x3_ring_bf16.cuh"
 #include "small_linear.cuh"
 #include "small_attention.cuh"
 #include "match_cost.cuh"
@@ -1102,6 +1103,14 @@ inline unsigned conv_grid_n64(long long M, int Cout) {
   const long long tiles_m = (M + 127) / 128, tiles_n = (Cout + 63) / 64;
   return (unsigned)(tiles_n * 8 * ((tiles_m + 7) / 8));
 }
+// the LDS-DMA ring instance of the 128 x 64 kernel (csrc/conv3x3_ring_bf16.cuh)
+// -- where it is faster: the small maps (layer3 / layer4 of the ResNet, M <= 32 768 output pixels: 42.5 against 46.0 us and
+// 63 against 67 us, profiles/r04_conv_ring_ab.jsonl); on the large maps the register-prefetch kernel's four workgroups per
+// CU win (40 against 53 us at 150 x 200).  SNIPPER_CONV_RING = 0 / 2: never / always (A/B runs).
+inline bool conv_ring_on(long long M) {
+  static const int mode = [] { const char *e = getenv("SNIPPER_CONV_RING"); return e ? atoi(e) : 1; }();
+  return mode == 2 || (mode == 1 && M <= 32768);
+}
 }  // namespace
 
 int snipper_conv3x3_bf16(void *stream, const uint16_t *X, const uint16_t *W, const float *bias, uint16_t *Y,
@@ -1116,6 +1125,11 @@ int snipper_conv3x3_bf16(void *stream, const uint16_t *X, const uint16_t *W, con
   const Conv3x3Args g{X, W, bias, Y, B, H, Wd, Cin, Cout, Ho, Wo, stride, 0, 0, 0, 0, 0, gate, flip_taps ? 1 : 0};
   if (conv_use_n64(M, Cout)) {
     const dim3 grid64(conv_grid_n64(M, Cout));
+    if (conv_ring_on(M)) {
+      if (relu) hipLaunchKernelGGL(conv3x3_ring_kernel<true>, grid64, dim3(kGemmThreads), 0, (hipStream_t)stream, g);
+      else hipLaunchKernelGGL(conv3x3_ring_kernel<false>, grid64, dim3(kGemmThreads), 0, (hipStream_t)stream, g);
+      return launch_status();
+    }
     if (relu) hipLaunchKernelGGL((conv3x3_bf16_kernel<true, 64>), grid64, dim3(kGemmThreads), 0, (hipStream_t)stream, g);
     else hipLaunchKernelGGL((conv3x3_bf16_kernel<false, 64>), grid64, dim3(kGemmThreads), 0, (hipStream_t)stream, g);
     return launch_status();
@@ -1156,7 +1170,9 @@ int snipper_conv3x3_dgrad_s2_bf16(void *stream, const uint16_t *G, const uint16_
       if (Hc <= 0 || Wc <= 0) continue;
       const Conv3x3Args g{G, Wt, nullptr, dX, B, Hg, Wg, Cg, Cx, Hc, Wc, 1, 1, cy, cx, Hx, Wx, gate, 0};
       const long long Mc = (long long)B * Hc * Wc;
-      if (conv_use_n64(Mc, Cx))
+      if (conv_use_n64(Mc, Cx) && conv_ring_on(Mc))
+        hipLaunchKernelGGL(conv3x3_ring_kernel<false>, dim3(conv_grid_n64(Mc, Cx)), dim3(kGemmThreads), 0, (hipStream_t)stream, g);
+      else if (conv_use_n64(Mc, Cx))
         hipLaunchKernelGGL((conv3x3_bf16_kernel<false, 64>), dim3(conv_grid_n64(Mc, Cx)), dim3(kGemmThreads), 0,
                            (hipStream_t)stream, g);
       else

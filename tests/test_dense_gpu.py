@@ -579,3 +579,35 @@ def test_small_linear_pair_matches_two_linears():
     torch.testing.assert_close(y, yr, rtol=1e-5, atol=2e-5)
     for a, b in zip(g1, g2):
         torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-4)
+
+
+def test_conv3x3_ring_kernel_is_bit_identical_to_the_register_prefetch_kernel():
+    """csrc/conv3x3_ring_bf16.cuh streams the operands through an LDS-DMA ring; tiles, summation order and store phase are
+    those of conv3x3_bf16_kernel, so the two must agree bit for bit (forward with bias + ReLU at a ragged size, flipped taps
+    with a gate, and the stride-2 data gradient's parity classes).  The switch is read once per process: two children."""
+    import hashlib, os, subprocess, sys
+    code = r'''
+import hashlib, torch
+from snipper_amd.dense import conv3x3_bf16, conv3x3_dgrad_s2_bf16
+from snipper_amd import _lib
+torch.manual_seed(3)
+dev = "cuda:0"
+h = hashlib.sha256()
+for cin, cout, hh, ww, st in [(64, 96, 21, 19, 1), (128, 64, 13, 37, 2), (256, 256, 38, 50, 1)]:
+    x = torch.randn(2, cin, hh, ww, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    wt = (torch.randn(cout, cin, 3, 3, device=dev) * 0.05).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    y = conv3x3_bf16(x, wt, torch.randn(cout, device=dev), st, True)
+    h.update(y.float().cpu().numpy().tobytes())
+    if st == 2:
+        d = conv3x3_dgrad_s2_bf16(torch.randn_like(y), wt.transpose(0, 1), (hh, ww))
+        h.update(d.float().cpu().numpy().tobytes())
+print(h.hexdigest())
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = {}
+    for mode in ("0", "2"):
+        env = dict(os.environ, SNIPPER_CONV_RING=mode, PYTHONPATH=root)
+        r = subprocess.run([sys.executable, "-c", code], env=env, cwd=root, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out[mode] = r.stdout.strip().splitlines()[-1]
+    assert out["0"] == out["2"], out
