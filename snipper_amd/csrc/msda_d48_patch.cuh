@@ -305,7 +305,8 @@ __global__ __launch_bounds__(kPatchThreads) void msda_bwd_d48_patchbin_kernel(
   unsigned *s_need = &s_need_word;                                                                       // bit l: level l has far taps
   PatchBlock b;
   if (!patch_block(plan, d, nblk_padded, b)) return;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // (uniform: the level tables below are then SCALAR loads)
 #ifdef TILE2_STAMPS
   // (tools/tile2_stamps.py: the second half of the stamp buffer, wave 0 of every 97th workgroup)
   unsigned long long *pst = reinterpret_cast<unsigned long long *>(s_g + kRows * kD48);
@@ -419,18 +420,30 @@ __global__ __launch_bounds__(kPatchThreads) void msda_bwd_d48_patchbin_kernel(
     r.w.x = inside ? y - yf : 0.f; r.w.y = inside ? x - xf : 0.f; r.w.z = inside ? a_in : 0.f;
     unsigned go[4];
     int ti_k[4];                 // the tile (index in the level's box) that owns tap k, or -1
+    // per AXIS first (two columns, two rows): in the map, tile index within the level's box, inside the box -- one unsigned
+    // compare each; a tap then only combines its row's and its column's results
+    bool okx[2], oky[2], boxx[2], boxy[2];
+    int tixa[2], tiya[2];
+    unsigned rowoff[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      okx[a] = inside && (unsigned)(x0 + a) < (unsigned)lvl.W;
+      oky[a] = inside && (unsigned)(y0 + a) < (unsigned)lvl.H;
+      tixa[a] = ((x0 + a) >> lvl.shift) - tb.tx0;
+      tiya[a] = ((y0 + a) >> lvl.shift) - tb.ty0;
+      boxx[a] = near && (unsigned)tixa[a] < (unsigned)tb.ntx;
+      boxy[a] = (unsigned)tiya[a] < (unsigned)tb.nty;
+      rowoff[a] = gbase + (unsigned)(lvl.start + (y0 + a) * lvl.W + x0) * px_stride;
+    }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int ty = y0 + (k >> 1), tx = x0 + (k & 1);
-      const bool in_map = inside && ty >= 0 && ty <= lvl.H - 1 && tx >= 0 && tx <= lvl.W - 1;
-      go[k] = in_map ? gbase + (unsigned)(lvl.start + ty * lvl.W + tx) * px_stride : kOobOffset;
+      const bool in_map = oky[k >> 1] && okx[k & 1];
+      go[k] = in_map ? rowoff[k >> 1] + (unsigned)(k & 1) * px_stride : kOobOffset;
       ti_k[k] = -1;
-      if (near && in_map) {
-        const int tix = (tx >> lvl.shift) - tb.tx0, tiy = (ty >> lvl.shift) - tb.ty0;
-        if (tix >= 0 && tix < tb.ntx && tiy >= 0 && tiy < tb.nty) {
-          const int ti = tiy * tb.ntx + tix;
-          if (ti < kPatchMaxTiles && slot_l[ti] >= 0) ti_k[k] = ti;
-        }
+      if (in_map && boxy[k >> 1] && boxx[k & 1]) {
+        const int ti = tiya[k >> 1] * tb.ntx + tixa[k & 1];
+        if (ti < kPatchMaxTiles && slot_l[ti] >= 0) ti_k[k] = ti;
       }
       const bool owned = ti_k[k] >= 0;
       my_bits |= (in_map && !owned) ? (16u << k) : 0u;        // need: no tile owns the tap -> HBM atomic here

@@ -60,8 +60,9 @@ else:
     print("tile kernel: no stamps (the matrix-pipe tile kernel carries none; SNIPPER_TILE_KERNEL=1 selects the vector kernel)")
 
 # ---- the query-side kernel (msda_bwd_d48_patchbin_kernel): wave 0 of every 97th workgroup
-pnames = {0: "start", 1: "rows + first loads issued", 2: "barrier", 3: "level: decode + marks done", 4: "level: barrier (records)",
-          5: "level: marks stored, next slots", 6: "level: gather + dots + stores done", 7: "level: far atomics done", 8: "level: barrier (end)"}
+pnames = {0: "start", 1: "loads of all levels issued, slots of all levels computed", 2: "barrier (slots)",
+          3: "decode + marks of all levels done, grad_out rows in LDS", 4: "barrier (records)", 5: "marks stored",
+          6: "gathers + dots + reductions + stores of all levels done", 7: "level: far atomics done"}
 seg, life = {}, []
 for wg in pv:
     st = [((x >> 56) & 0xff, x & ((1 << 56) - 1)) for x in wg if x]
