@@ -89,13 +89,14 @@ struct PatchRec {   // 32 B per (row, point) of the level in flight
 };
 
 __device__ __forceinline__ bool patch_block(const PatchPlan &p, const CoreDims &d, int nblk_padded, PatchBlock &b) {
-  const long long id = xcd_band_block(nblk_padded);          // (n, block, m), m fastest: the 8 heads of a block share lines
-  const long long total = (long long)d.N * p.nblocks * d.M;
+  // (32-bit: the launcher's grid is an int, and 64-bit divisions by run-time values are ~100 scalar instructions each)
+  const unsigned id = (unsigned)xcd_band_block(nblk_padded);     // (n, block, m), m fastest: the 8 heads of a block share lines
+  const unsigned total = (unsigned)d.N * (unsigned)p.nblocks * (unsigned)d.M;
   if (id >= total) return false;
-  b.m = (int)(id % d.M);
-  const long long t = id / d.M;
-  const int blk = (int)(t % p.nblocks);
-  b.n = (int)(t / p.nblocks);
+  const unsigned t = id / (unsigned)d.M;
+  b.m = (int)(id - t * (unsigned)d.M);
+  b.n = (int)(t / (unsigned)p.nblocks);
+  const int blk = (int)(t - (unsigned)b.n * (unsigned)p.nblocks);
   int lq = 0;
   for (int i = 1; i < p.L; ++i) lq = (blk >= p.lv[i].blk_base) ? i : lq;
   const int r = blk - p.lv[lq].blk_base;
@@ -458,7 +459,7 @@ __global__ __launch_bounds__(kPatchThreads) void msda_bwd_d48_patchbin_kernel(
       bool want = ti_k[k] >= 0;
 #pragma unroll
       for (int e = 0; e < k; ++e) want = want && ti_k[e] != ti_k[k];
-      if (want) atomicOr(&mask_l[ti_k[k]], 1ull << rd);
+      if (want && !(plan.debug & 16)) atomicOr(&mask_l[ti_k[k]], 1ull << rd);      // (debug 16: timing ablation, WRONG results)
     }
     r.w.w = __uint_as_float(my_bits);
     r.g.x = go[0]; r.g.y = go[1]; r.g.z = go[2]; r.g.w = go[3];
