@@ -56,5 +56,9 @@ bash tools/bench_kstats.sh $1 > $out/kstats.txt 2>&1
 cp gpurun_out/kstats_$1.csv $out/kernel_stats.csv
 python3 bench.py --steps 20 --warmup 5 --precision fp32 --no-cpu-baseline --no-locality-sweep > $out/bench_fp32.json 2> $out/bench_fp32.err
 SNIPPER_FORCE_DDP=1 SNIPPER_SYNC_FORCE=1 python3 bench.py --steps 20 --warmup 8 --no-cpu-baseline --no-locality-sweep > $out/bench_forced_ddp.json 2> $out/bench_forced_ddp.err
+python3 bench.py --steps 20 --warmup 5 --pin-cores 0 --gc-every 0 --no-cpu-baseline --no-locality-sweep > $out/bench_host_untuned.json 2> $out/bench_host_untuned.err
+python3 tools/convbench.py > $out/conv_ring_default.jsonl 2> $out/convbench.err
+SNIPPER_CONV_RING=0 python3 tools/convbench.py > $out/conv_ring_off.jsonl 2>> $out/convbench.err
+SNIPPER_CONV_RING=2 python3 tools/convbench.py > $out/conv_ring_all.jsonl 2>> $out/convbench.err
 python3 bench.py > $out/bench_bf16_default.json 2> $out/bench_bf16_default.err
 tail -c 900 $out/bench_bf16_default.json; echo; cat $out/copybench.json; head -5 $out/pmc_mfma_busy.csv; head -12 $out/pmc_lds_tcc.csv
