@@ -283,9 +283,11 @@ bool make_patch_plan(const CoreDims &d, const int64_t *hs, const snipper_msda_co
   return true;
 }
 
-// workspace of the owner-computes backward: the marks
-inline long long patch_workspace_bytes(long long nm, const PatchPlan &plan) {
-  return nm * plan.words_per_nm * 8 + (nm * plan.total_tiles + 7) / 8 * 8;       // marks, then one dirty byte per tile
+// workspace of the owner-computes backward: the marks, the far list's counter (zeroed with the marks), the far list (one
+// 8-byte entry per sample at most: never zeroed, only its first far_count entries are read)
+inline long long patch_zeroed_bytes(long long nm, const PatchPlan &plan) { return nm * plan.words_per_nm * 8 + 8; }
+inline long long patch_workspace_bytes(long long nm, const CoreDims &d, const PatchPlan &plan) {
+  return patch_zeroed_bytes(nm, plan) + (long long)d.N * d.Lq * d.M * d.L * kPatchP * 8;
 }
 
 template <typename VT>
@@ -294,10 +296,19 @@ int backward_d48_patch(hipStream_t st, const void *grad_out, const VT *value, co
                        float *grad_attn, int go_bf16, bool mfma_tiles) {
   const long long nm = (long long)d.N * d.M;
   plan.marks = reinterpret_cast<unsigned long long *>(workspace);
-  plan.dirty = reinterpret_cast<unsigned char *>(plan.marks + nm * plan.words_per_nm);
-  hipError_t e = hipMemsetAsync(plan.marks, 0, (size_t)patch_workspace_bytes(nm, plan), st);
+  plan.far_count = reinterpret_cast<unsigned *>(plan.marks + nm * plan.words_per_nm);
+  plan.far_list = reinterpret_cast<uint2 *>(plan.far_count + 2);
+  if ((long long)d.N * d.Lq * d.M * d.L * kPatchP >= (1LL << 32)) return SNIPPER_E_SHAPE;      // (sample indices are 32-bit)
+  hipError_t e = hipMemsetAsync(plan.marks, 0, (size_t)patch_zeroed_bytes(nm, plan), st);
   if (e != hipSuccess) return (int)e;
-  // 1) query side: grad_loc / grad_attn, marks, HBM atomics for the taps no tile owns
+  // 1) query side: grad_loc / grad_attn, marks, the list of samples with taps no tile owns
+  // 2) grad_value side: every tile stores what it owns (plain stores: grad_value needs no zeroing)
+  // 3) the far list's taps: HBM float atomics on top of the stored tiles
+  auto launch_far = [&]() {
+    if (go_bf16) hipLaunchKernelGGL(msda_bwd_d48_far_kernel<true>, dim3(kFarBlocks), dim3(kPatchThreads), 0, st, grad_out, loc, attn, d, plan, grad_value);
+    else hipLaunchKernelGGL(msda_bwd_d48_far_kernel<false>, dim3(kFarBlocks), dim3(kPatchThreads), 0, st, grad_out, loc, attn, d, plan, grad_value);
+    return launch_status();
+  };
   const long long nblk = nm * plan.nblocks;
   const long long nblk_padded = (nblk + 7) & ~7LL;
   // 2) grad_value side: every tile adds what it owns (XCD-major grid, see the kernel)
@@ -340,7 +351,8 @@ int backward_d48_patch(hipStream_t st, const void *grad_out, const VT *value, co
                              loc, attn, d, plan, big, grad_value);
       }
       g_last_variant = plan.debug ? "d48_owner_mfma_debug" : "d48_owner_mfma";
-      return launch_status();
+      if (int rc = launch_status()) return rc;
+      return launch_far();
     }
     hipLaunchKernelGGL((msda_bwd_d48_tile2_kernel<128, true>), dim3((unsigned)nblk_tiles), dim3(kPatchThreads), 0, st, grad_out,
                        loc, attn, d, plan, grad_value);
@@ -352,7 +364,8 @@ int backward_d48_patch(hipStream_t st, const void *grad_out, const VT *value, co
                        loc, attn, d, plan, grad_value);
   }
   g_last_variant = plan.debug ? "d48_owner_debug" : "d48_owner";
-  return launch_status();
+  if (int rc = launch_status()) return rc;
+  return launch_far();
 }
 
 bool owner_shape_ok(const CoreDims &d, const int64_t *hs, int policy) {
@@ -435,7 +448,7 @@ long long snipper_msda_backward_ex_workspace_bytes(const snipper_msda_config *cf
   long long need = 0;
   for (int mf = 0; mf < 2; ++mf) {
     if (!make_patch_plan(d, host_shapes, c, mf != 0, &plan)) return 0;
-    need = std::max(need, patch_workspace_bytes((long long)N * M, plan));
+    need = std::max(need, patch_workspace_bytes((long long)N * M, d, plan));
   }
   return need;
 }
@@ -461,14 +474,14 @@ int snipper_msda_backward_ex(void *stream, const snipper_msda_config *cfg, const
   }
   if (value_dtype == 1) {        // bf16 value / grad_out, gradients accumulate in float32
     if (grad_out_dtype != 1) return SNIPPER_E_UNSUPPORTED;
-    if (int rc = zero_grad_value(st, (float *)grad_value, d)) return rc;
     if (workspace && owner_shape_ok(d, host_shapes, c.policy)) {       // encoder shape: owner-computes (marks + sorted taps)
       PatchPlan plan;
       const bool mf = patch_uses_mfma(d, c, 1);
-      if (make_patch_plan(d, host_shapes, c, mf, &plan) && workspace_bytes >= patch_workspace_bytes((long long)N * M, plan))
+      if (make_patch_plan(d, host_shapes, c, mf, &plan) && workspace_bytes >= patch_workspace_bytes((long long)N * M, d, plan))
         return backward_d48_patch<uint16_t>(st, grad_out, (const uint16_t *)value, (const float *)loc, (const float *)attn, d,
                                             plan, workspace, (float *)grad_value, (float *)grad_loc, (float *)grad_attn, 1, mf);
     }
+    if (int rc = zero_grad_value(st, (float *)grad_value, d)) return rc;      // (the atomic kernels accumulate)
     return backward_generic<uint16_t, float, float>(st, (const uint16_t *)grad_out, (const uint16_t *)value, shapes,
                                                     level_start, (const float *)loc, (const float *)attn, d,
                                                     (float *)grad_value, (float *)grad_loc, (float *)grad_attn);
@@ -478,13 +491,13 @@ int snipper_msda_backward_ex(void *stream, const snipper_msda_config *cfg, const
   float *gv = (float *)grad_value, *gl = (float *)grad_loc, *ga = (float *)grad_attn;
   const int go_bf16 = grad_out_dtype == 1;
   if (go_bf16 && !d48_eligible<float>(d, c.policy)) return SNIPPER_E_UNSUPPORTED;   // bf16 rows: D = 48 kernels only
-  if (int rc = zero_grad_value(st, gv, d)) return rc;
   if (workspace && owner_shape_ok(d, host_shapes, c.policy)) {
     PatchPlan plan;
     const bool mf = patch_uses_mfma(d, c, go_bf16);
-    if (make_patch_plan(d, host_shapes, c, mf, &plan) && workspace_bytes >= patch_workspace_bytes((long long)N * M, plan))
+    if (make_patch_plan(d, host_shapes, c, mf, &plan) && workspace_bytes >= patch_workspace_bytes((long long)N * M, d, plan))
       return backward_d48_patch<float>(st, grad_out, v, lo, at, d, plan, workspace, gv, gl, ga, go_bf16, mf);
   }
+  if (int rc = zero_grad_value(st, gv, d)) return rc;                         // (the atomic kernels accumulate)
   if (d48_eligible<float>(d, c.policy))
     return backward_d48_f32(st, (const float *)grad_out, v, shapes, level_start, lo, at, d, gv, gl, ga, go_bf16);
   return backward_generic<float, float, float>(st, (const float *)grad_out, v, shapes, level_start, lo, at, d, gv, gl, ga);

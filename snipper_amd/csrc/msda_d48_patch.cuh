@@ -70,7 +70,12 @@ struct PatchPlan {
   long long lvl_base[kPatchMaxLevels];
   long long words_per_nm;
   unsigned long long *marks;    // [N*M][words_per_nm], zeroed per backward call
-  unsigned char *dirty;         // [N*M][total_tiles], zeroed with the marks: 1 = a tap no tile owns (HBM atomic) landed in this tile
+  // taps no tile owns (their sample is not near its anchor, or the block is not among the tile's candidates): the query
+  // side appends the SAMPLE to this list (far_count zeroed with the marks) and msda_bwd_d48_far_kernel, launched after the
+  // tile kernels, adds its far taps with HBM float atomics -- so the tile kernels write every pixel of grad_value with plain
+  // stores, nothing has to be zeroed beforehand (121 MB per launch at N = 8) and no tile reads grad_value back.
+  unsigned *far_count;          // entries in far_list
+  uint2 *far_list;              // {sample index ((n Lq + q) M + m) L P + l P + p, bit k: tap k is far}; capacity = all samples
   // size ratios rw[a][b] = (float)W_a / (float)W_b (rh likewise), computed on the host with IEEE float division: the
   // anchor arithmetic both kernels must agree on, without per-thread divisions (bit-identical to __fdiv_rn)
   float rw[kPatchMaxLevels][kPatchMaxLevels], rh[kPatchMaxLevels][kPatchMaxLevels];
@@ -290,27 +295,23 @@ __global__ __launch_bounds__(kPatchThreads) void msda_bwd_d48_patchbin_kernel(
     float *__restrict__ grad_loc, float *__restrict__ grad_attn, int nblk_padded) {
   using DOT = PatchDot<VT, GO_BF16>;
   constexpr unsigned kRowV = DOT::kRowV;                 // bytes of one head row of `value`
-  constexpr int kRows = kPatchB * kPatchB;
 #ifdef TILE2_STAMPS
   constexpr int kStampBytes = 64 * 8;
 #else
   constexpr int kStampBytes = 0;
 #endif
   __shared__ __attribute__((aligned(16))) unsigned char smem[kPatchMaxLevels * kPatchThreads * sizeof(PatchRec) +
-                                                           kPatchMaxLevels * kPatchMaxTiles * 16 + kRows * kPatchRowBytes + kStampBytes];
+                                                           kPatchMaxLevels * kPatchMaxTiles * 16 + kStampBytes];
   PatchRec *recs = reinterpret_cast<PatchRec *>(smem);                                                   // [level][row][point]
   unsigned long long *s_mask = reinterpret_cast<unsigned long long *>(recs + kPatchMaxLevels * kPatchThreads);   // [level][tile]
   long long *s_slot = reinterpret_cast<long long *>(s_mask + kPatchMaxLevels * kPatchMaxTiles);          // [level][tile]
-  float *s_g = reinterpret_cast<float *>(s_slot + kPatchMaxLevels * kPatchMaxTiles);                     // [64 rows][48]: grad_out rows
-  __shared__ unsigned s_need_word;
-  unsigned *s_need = &s_need_word;                                                                       // bit l: level l has far taps
   PatchBlock b;
   if (!patch_block(plan, d, nblk_padded, b)) return;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // (uniform: the level tables below are then SCALAR loads)
 #ifdef TILE2_STAMPS
   // (tools/tile2_stamps.py: the second half of the stamp buffer, wave 0 of every 97th workgroup)
-  unsigned long long *pst = reinterpret_cast<unsigned long long *>(s_g + kRows * kD48);
+  unsigned long long *pst = reinterpret_cast<unsigned long long *>(s_slot + kPatchMaxLevels * kPatchMaxTiles);
   unsigned long long *pst_out = (plan.stamps && blockIdx.x % 97 == 0 && blockIdx.x / 97 < 256) ? plan.stamps + 256 * 128 + (blockIdx.x / 97) * 64 : nullptr;
   int pst_n = 0;
 #define PATCH_STAMP(slot) do { if (pst_out && tid == 0 && pst_n < 64) { pst[pst_n] = ((unsigned long long)(slot) << 56) | (__builtin_amdgcn_s_memtime() & 0x00ffffffffffffffull); ++pst_n; } } while (0)
@@ -329,9 +330,7 @@ __global__ __launch_bounds__(kPatchThreads) void msda_bwd_d48_patchbin_kernel(
   const unsigned gbase = (unsigned)(b.n * d.S) * px_stride + (unsigned)b.m * kRowV;
   const int j = tid & 7, rg = tid >> 3;
   const unsigned value_bytes = (unsigned)((size_t)d.N * d.S * d.M * kRowV);
-  const unsigned gv_bytes = (unsigned)((size_t)d.N * d.S * d.M * kPatchRowBytes);
   const auto vsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<VT *>(value), 0, (int)value_bytes, 0x00020000);
-  const auto gsrc = __builtin_amdgcn_make_buffer_rsrc(grad_value, 0, (int)gv_bytes, 0x00020000);
 
   // ---- phase 0: loads.  loc / attn of this thread's sample in every level first (phase 1 waits for them only) ...
   float2 xy_l[kPatchMaxLevels];
@@ -394,13 +393,11 @@ __global__ __launch_bounds__(kPatchThreads) void msda_bwd_d48_patchbin_kernel(
     s_slot[wave * kPatchMaxTiles + lane] = sl;
     s_mask[wave * kPatchMaxTiles + lane] = 0ull;
   }
-  if (tid == 0) *s_need = 0u;
   PATCH_STAMP(1);
   lds_barrier();                 // slots and cleared masks visible (the global loads stay in flight)
   PATCH_STAMP(2);
 
   // ---- phase 1: decode + marks, all levels ----
-  unsigned need_lv = 0u;         // bit l: a tap of this thread's sample in level l needs an HBM atomic
 #pragma unroll
   for (int l = 0; l < kPatchMaxLevels; ++l) {
     if (l >= plan.L) break;
@@ -438,7 +435,6 @@ __global__ __launch_bounds__(kPatchThreads) void msda_bwd_d48_patchbin_kernel(
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const int ty = y0 + (k >> 1), tx = x0 + (k & 1);
       const bool in_map = oky[k >> 1] && okx[k & 1];
       go[k] = in_map ? rowoff[k >> 1] + (unsigned)(k & 1) * px_stride : kOobOffset;
       ti_k[k] = -1;
@@ -446,12 +442,19 @@ __global__ __launch_bounds__(kPatchThreads) void msda_bwd_d48_patchbin_kernel(
         const int ti = tiya[k >> 1] * tb.ntx + tixa[k & 1];
         if (ti < kPatchMaxTiles && slot_l[ti] >= 0) ti_k[k] = ti;
       }
-      const bool owned = ti_k[k] >= 0;
-      my_bits |= (in_map && !owned) ? (16u << k) : 0u;        // need: no tile owns the tap -> HBM atomic here
-      // ... and the tile it lands in is told so (plain byte stores of the same value: no atomic needed), which lets the
-      // matrix-pipe tile kernel start clean tiles from zero instead of reading grad_value back
-      if (in_map && !owned)
-        plan.dirty[((size_t)b.n * d.M + b.m) * plan.total_tiles + lvl.tile_base + (ty >> lvl.shift) * lvl.ntx + (tx >> lvl.shift)] = 1;
+      my_bits |= (in_map && ti_k[k] < 0) ? (1u << k) : 0u;    // no tile owns the tap: msda_bwd_d48_far_kernel adds it
+    }
+    // samples with a far tap go to the far list: one counter bump per wave that has any (ballot + prefix count)
+    {
+      const unsigned long long fb = __ballot(my_bits != 0u);
+      if (fb) {
+        unsigned base = 0u;
+        if (lane == 0) base = atomicAdd(plan.far_count, (unsigned)__popcll(fb));
+        base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+        if (my_bits)
+          plan.far_list[base + __builtin_amdgcn_mbcnt_hi((unsigned)(fb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)fb, 0u))] =
+              make_uint2((unsigned)(rowd * LP + l * kPatchP + pd), my_bits);
+      }
     }
     // marks: a tap whose tile an earlier tap of the sample already marks adds nothing
 #pragma unroll
@@ -461,18 +464,15 @@ __global__ __launch_bounds__(kPatchThreads) void msda_bwd_d48_patchbin_kernel(
       for (int e = 0; e < k; ++e) want = want && ti_k[e] != ti_k[k];
       if (want && !(plan.debug & 16)) atomicOr(&mask_l[ti_k[k]], 1ull << rd);      // (debug 16: timing ablation, WRONG results)
     }
-    r.w.w = __uint_as_float(my_bits);
+    r.w.w = 0.f;
     r.g.x = go[0]; r.g.y = go[1]; r.g.z = go[2]; r.g.w = go[3];
     recs[l * kPatchThreads + tid] = r;
-    need_lv |= my_bits ? (1u << l) : 0u;
   }
-  // the grad_out rows have landed by now: float32 copy to LDS for the atomic phase (re-dealt there over 16 lanes per row)
+  // the grad_out rows have landed by now
   float g[2][6];
   unsigned gp[2][3];
 #pragma unroll
   for (int ps = 0; ps < 2; ++ps) {
-    const int r = ps * 32 + rg;
-    const int ca = kCa * j, cb = DOT::kContig ? 6 * j + 4 : 32 + 2 * j;
     if constexpr (GO_BF16) {
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
@@ -485,23 +485,12 @@ __global__ __launch_bounds__(kPatchThreads) void msda_bwd_d48_patchbin_kernel(
 #pragma unroll
       for (int c = 0; c < 6; ++c) g[ps][c] = rg_ok[ps] ? __uint_as_float(graw[ps][c]) : 0.f;
     }
-    *reinterpret_cast<float2 *>(s_g + r * kD48 + ca) = make_float2(g[ps][0], g[ps][1]);
-    *reinterpret_cast<float2 *>(s_g + r * kD48 + ca + 2) = make_float2(g[ps][2], g[ps][3]);
-    *reinterpret_cast<float2 *>(s_g + r * kD48 + cb) = make_float2(g[ps][4], g[ps][5]);
-  }
-  // which levels need atomics at all (workgroup-wide; __syncthreads_or only says whether ANY bit is set)
-  {
-    unsigned wneed = 0u;
-#pragma unroll
-    for (int l = 0; l < kPatchMaxLevels; ++l) wneed |= __ballot((need_lv >> l) & 1u) != 0ull ? (1u << l) : 0u;
-    if (lane == 0 && wneed) atomicOr(s_need, wneed);
   }
   PATCH_STAMP(3);
-  lds_barrier();                 // records, masks and rows complete
-  const unsigned any_need = *s_need;
+  lds_barrier();                 // records and masks complete
   PATCH_STAMP(4);
 
-  // ---- phase 2: marks out, gathers, far atomics ----
+  // ---- phase 2: marks out, gathers ----
   if (wave < plan.L) {
     const long long sl = s_slot[wave * kPatchMaxTiles + lane];
     const unsigned long long mk = s_mask[wave * kPatchMaxTiles + lane];
@@ -571,45 +560,64 @@ __global__ __launch_bounds__(kPatchThreads) void msda_bwd_d48_patchbin_kernel(
     }
   }
   PATCH_STAMP(6);
-#pragma unroll
-  for (int l = 0; l < kPatchMaxLevels; ++l) {
-    if (l >= plan.L) break;
-    // taps no tile owns (sample not near its anchor, or beyond the marks' capacity): the HBM float atomic of
-    // msda_d48.cuh.  Re-dealt to 16 lanes per row, lane i adding channels {i, i+16, i+32}: every atomic instruction then
-    // adds 64 contiguous bytes per row (the shape the memory-side atomic units take at full rate).
-    if (any_need & (1u << l)) {
-      const int ai = tid & 15, ar = tid >> 4;
-#pragma unroll 1
-      for (int pass = 0; pass < kRows / 16; ++pass) {
-        const int r = pass * 16 + ar;
-        const float g0 = s_g[r * kD48 + ai], g1 = s_g[r * kD48 + 16 + ai], g2 = s_g[r * kD48 + 32 + ai];
-#pragma unroll
-        for (int p = 0; p < kPatchP; ++p) {
-          const PatchRec rc = recs[l * kPatchThreads + r * kPatchP + p];
-          const unsigned bits = __float_as_uint(rc.w.w) >> 4;
-          if (__builtin_amdgcn_ballot_w64(bits != 0u) == 0ull) continue;
-          const float lh = rc.w.x, lw = rc.w.y, a = rc.w.z;
-          const float hh = 1.f - lh, hw = 1.f - lw;
-          const float wk[4] = {hh * hw * a, hh * lw * a, lh * hw * a, lh * lw * a};
-          const unsigned go[4] = {rc.g.x, rc.g.y, rc.g.z, rc.g.w};
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            // value offsets are in rows of kRowV bytes, grad_value rows are 192 B
-            const unsigned o = ((bits >> k) & 1u) ? go[k] * (kPatchRowBytes / kRowV) + 4u * ai : kOobOffset;
-            __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(wk[k] * g0, gsrc, o, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(wk[k] * g1, gsrc, o + 64u, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(wk[k] * g2, gsrc, o + 128u, 0, 0);
-          }
-        }
-      }
-    }
-    PATCH_STAMP(7);
-  }
 #ifdef TILE2_STAMPS
   if (pst_out && tid == 0)
     for (int i = 0; i < pst_n; ++i) pst_out[i] = pst[i];
 #endif
 #undef PATCH_STAMP
+}
+
+// The far taps: the samples the query side put on the far list, their marked taps added to grad_value with HBM float atomics
+// (the reference's own formulation, ms_deform_im2col_cuda.cuh:125-152, for these few).  Launched AFTER the tile kernels, which
+// have written every pixel by then.  16 lanes per sample, lane i adding channels {i, i + 16, i + 32} of w_k * grad_out: every
+// atomic instruction adds 64 contiguous bytes per row (the shape the memory-side atomic units take at full rate).  A fixed
+// grid walks the list (its length is only known on the device); with no far taps the kernel is ~3 us of launch.
+constexpr int kFarBlocks = 1024;
+template <bool GO_BF16>
+__global__ __launch_bounds__(kPatchThreads) void msda_bwd_d48_far_kernel(
+    const void *__restrict__ grad_out, const float *__restrict__ loc, const float *__restrict__ attn, CoreDims d,
+    PatchPlan plan, float *__restrict__ grad_value) {
+  const unsigned count = *plan.far_count;
+  const int tid = threadIdx.x, ai = tid & 15;
+  const unsigned LP = (unsigned)(d.L * kPatchP);
+  const unsigned gv_bytes = (unsigned)((size_t)d.N * d.S * d.M * kPatchRowBytes);
+  const auto gsrc = __builtin_amdgcn_make_buffer_rsrc(grad_value, 0, (int)gv_bytes, 0x00020000);
+  for (unsigned e = blockIdx.x * (kPatchThreads / 16) + (tid >> 4); e < count; e += gridDim.x * (kPatchThreads / 16)) {
+    const uint2 ent = plan.far_list[e];
+    const unsigned li = ent.x, bits = ent.y;
+    const unsigned row = li / LP, s = li - row * LP;            // row = (n Lq + q) M + m
+    const int l = (int)(s / kPatchP);
+    const unsigned nq = row / (unsigned)d.M, m = row - nq * (unsigned)d.M, n = nq / (unsigned)d.Lq;
+    PatchLevel lvl = plan.lv[0];
+#pragma unroll
+    for (int i = 1; i < kPatchMaxLevels; ++i)
+      if (l == i) lvl = plan.lv[i];
+    const float2 xy = *reinterpret_cast<const float2 *>(loc + 2 * (size_t)li);
+    const float a = attn[li];
+    const float y = px_coord(xy.y, lvl.H), x = px_coord(xy.x, lvl.W);
+    const float yf = floorf(y), xf = floorf(x);
+    const int y0 = (int)yf, x0 = (int)xf;
+    const float lh = y - yf, lw = x - xf, hh = 1.f - lh, hw = 1.f - lw;
+    const float wk[4] = {hh * hw * a, hh * lw * a, lh * hw * a, lh * lw * a};
+    float g0, g1, g2;
+    if constexpr (GO_BF16) {
+      const uint16_t *gr = reinterpret_cast<const uint16_t *>(grad_out) + (size_t)row * kD48;
+      g0 = __uint_as_float((unsigned)gr[ai] << 16); g1 = __uint_as_float((unsigned)gr[16 + ai] << 16);
+      g2 = __uint_as_float((unsigned)gr[32 + ai] << 16);
+    } else {
+      const float *gr = reinterpret_cast<const float *>(grad_out) + (size_t)row * kD48;
+      g0 = gr[ai]; g1 = gr[16 + ai]; g2 = gr[32 + ai];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      // (a far tap is inside the map by construction: the query side only lists those)
+      const unsigned pix = (unsigned)(lvl.start + (y0 + (k >> 1)) * lvl.W + x0 + (k & 1));
+      const unsigned o = ((bits >> k) & 1u) ? ((n * (unsigned)d.S + pix) * (unsigned)d.M + m) * kPatchRowBytes + 4u * ai : kOobOffset;
+      __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(wk[k] * g0, gsrc, o, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(wk[k] * g1, gsrc, o + 64u, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(wk[k] * g2, gsrc, o + 128u, 0, 0);
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1008,9 +1016,8 @@ __global__ __launch_bounds__(kPatchThreads) __attribute__((amdgpu_waves_per_eu(3
       }
     }
   }
-  // ---- add the tile to grad_value: plain read-modify-write (the query-side kernel has finished; tiles are disjoint).
-  //      (A per-tile "dirty" bit set by the query side's atomics, to let clean tiles store without reading, was measured:
-  //      no gain when nothing is far, and the bit's global atomics cost 4 - 20 ms per launch when 20 % of the taps are.) ----
+  // ---- store the tile: plain stores (tiles are disjoint and cover the map; the far taps are added afterwards by
+  //      msda_bwd_d48_far_kernel, so nothing was in grad_value before) ----
   const size_t img_base = ((size_t)n * d.S + me.start) * d.M;
 #pragma unroll
   for (int u = 0; u < kMaxU; ++u) {
@@ -1020,12 +1027,8 @@ __global__ __launch_bounds__(kPatchThreads) __attribute__((amdgpu_waves_per_eu(3
       const int ty = ty0 + (pix >> me.shift), tx = tx0 + (pix & (edge - 1));
       if (ty < me.H && tx < me.W) {
         float *dst = grad_value + (img_base + (size_t)(ty * me.W + tx) * d.M + m) * kD48;
-        f32x4 va = *reinterpret_cast<f32x4 *>(dst + 4 * j);
-        float2 vb = *reinterpret_cast<float2 *>(dst + 32 + 2 * j);
-        va.x += acc[u][0]; va.y += acc[u][1]; va.z += acc[u][2]; va.w += acc[u][3];
-        vb.x += acc[u][4]; vb.y += acc[u][5];
-        *reinterpret_cast<f32x4 *>(dst + 4 * j) = va;
-        *reinterpret_cast<float2 *>(dst + 32 + 2 * j) = vb;
+        *reinterpret_cast<f32x4 *>(dst + 4 * j) = f32x4{acc[u][0], acc[u][1], acc[u][2], acc[u][3]};
+        *reinterpret_cast<float2 *>(dst + 32 + 2 * j) = make_float2(acc[u][4], acc[u][5]);
       }
     }
   }

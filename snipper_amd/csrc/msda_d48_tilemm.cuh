@@ -145,17 +145,14 @@ __device__ __forceinline__ void tile3_body(LDS &S, const unsigned char *__restri
       c -= cnt;
     }
   }
-  // The accumulators START from the tile's current grad_value when the query side's far-tap atomics added anything to it
-  // (its `dirty` byte; that kernel has finished) and from zero otherwise -- the callee's memset left zeros there --, and the
-  // finished tile is stored plainly: a clean tile never reads grad_value (121 MB per launch at N = 8), a dirty one has its
-  // loads in flight behind everything up to the first round's matrix instructions.  The product is
+  // The accumulators start from zero and the finished tile is stored plainly: the tiles cover the map, the taps no tile owns
+  // are added afterwards (msda_bwd_d48_far_kernel), so grad_value is neither zeroed beforehand nor read here.  The product is
   // evaluated transposed (G^T as the A operand, Wt^T as B), so lane (column c = lane & 15, k-group g) holds the FOUR
   // CONSECUTIVE channels 16 cb + 4 g .. + 3 of pixel 16 pb + c: one 16-byte access per accumulator, the four lanes of a
   // pixel covering 64 contiguous bytes.
   const int r16 = lane & 15, g4 = lane >> 4;
   gemm_f32x4 acc[NACC][3];
   float *dst[NACC];
-  const bool dirty = plan.dirty[((size_t)n * d.M + m) * plan.total_tiles + me.tile_base + t] != 0;
   {
     const size_t img_base = ((size_t)n * d.S + me.start) * d.M;
 #pragma unroll
@@ -166,7 +163,7 @@ __device__ __forceinline__ void tile3_body(LDS &S, const unsigned char *__restri
       dst[i] = on ? grad_value + (img_base + (size_t)(ty * me.W + tx) * d.M + m) * kD48 + 4 * g4 : nullptr;
 #pragma unroll
       for (int cb = 0; cb < 3; ++cb)
-        acc[i][cb] = (on && dirty) ? *reinterpret_cast<const gemm_f32x4 *>(dst[i] + 16 * cb) : gemm_f32x4{0.f, 0.f, 0.f, 0.f};
+        acc[i][cb] = gemm_f32x4{0.f, 0.f, 0.f, 0.f};
     }
   }
   // Wt starts as zeros and a column is cleared again by the lanes that wrote it; rows of G beyond a round's last hit are
@@ -428,7 +425,6 @@ __device__ __forceinline__ void tile3_body_wide(Tile3LdsWide &S, const unsigned 
   const int r16 = lane & 15, g4 = lane >> 4;
   gemm_f32x4 acc[NACC][3];
   float *dst[NACC];
-  const bool dirty_tile = plan.dirty[((size_t)n * d.M + m) * plan.total_tiles + me.tile_base + t] != 0;
   {
     const size_t img_base = ((size_t)n * d.S + me.start) * d.M;
 #pragma unroll
@@ -439,7 +435,7 @@ __device__ __forceinline__ void tile3_body_wide(Tile3LdsWide &S, const unsigned 
       dst[i] = on ? grad_value + (img_base + (size_t)(ty * me.W + tx) * d.M + m) * kD48 + 4 * g4 : nullptr;
 #pragma unroll
       for (int cb = 0; cb < 3; ++cb)
-        acc[i][cb] = (on && dirty_tile) ? *reinterpret_cast<const gemm_f32x4 *>(dst[i] + 16 * cb) : gemm_f32x4{0.f, 0.f, 0.f, 0.f};
+        acc[i][cb] = gemm_f32x4{0.f, 0.f, 0.f, 0.f};
     }
   }
   for (int i = tid; i < 2 * 4 * PLANE / 16; i += kT3WideThreads) reinterpret_cast<u32x4 *>(S.W)[i] = u32x4{0u, 0u, 0u, 0u};
