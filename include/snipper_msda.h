@@ -99,7 +99,9 @@ void snipper_msda_config_init(snipper_msda_config *cfg);     /* fills in the def
  *                  the inputs for ANY locations; only the speed depends on how local they are.  (Every H and W must be
  *                  < 32768 for this path -- larger maps take the atomic kernels.)
  *   workspace    : backward only; device scratch of at least snipper_msda_backward_ex_workspace_bytes(...) bytes (0 when
- *                  the encoder-shape path would not be taken: then NULL is fine).  The library never allocates. */
+ *                  the encoder-shape path would not be taken: then NULL is fine).  The library never allocates.  (The
+ *                  scratch holds the tiles' mark words and a list with room for one 8-byte entry per sample -- the samples
+ *                  with a tap no tile owns; only the marks and the list's counter are zeroed per call.) */
 int snipper_msda_forward_ex(void *stream, const snipper_msda_config *cfg, const int64_t *host_shapes, const void *value,
                             int value_dtype, const int64_t *shapes, const int64_t *level_start, const void *loc,
                             const void *attn, int N, int S, int M, int D, int L, int Lq, int P, void *out, int out_dtype);

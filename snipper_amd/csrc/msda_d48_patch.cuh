@@ -8,23 +8,25 @@
 //
 // Idea: in the encoder the queries ARE the pixels of the L feature maps and a query samples each level near its own
 // position rescaled to that level (its "anchor").  grad_value is cut into tiles (one level, one (batch, head), 16 x 16 /
-// 8 x 8 / 4 x 4 pixels); every tile has ONE owner workgroup that sums the taps landing in it and adds the tile to HBM with
-// plain stores.  Two kernels:
+// 8 x 8 / 4 x 4 pixels); every tile has ONE owner workgroup that sums the taps landing in it and writes the tile to HBM with
+// plain stores (the tiles cover the maps: grad_value needs no zeroing beforehand).  Three kernels:
 //   msda_bwd_d48_patchbin_kernel  query side, one workgroup per (batch, head, 8 x 8 block of queries of one level):
 //                                 grad_loc / grad_attn for every sample (64 rows x 4 points decoded by 256 threads, then
 //                                 32 rows x 8 lanes gather the tap rows -- lane j owns channels 4j..4j+3 and 32+2j, 33+2j
 //                                 -- with v_dot2c_f32_bf16 when value and grad_out are both bf16); "which queries of the
 //                                 block have a near tap in which tile" as ONE 64-bit word per (tile, block), OR-ed in LDS
 //                                 and stored once (4 MB of marks per launch at N = 8; round 1's byte map was 58 MB and
-//                                 had to be scanned); HBM float atomics for the taps no tile owns, re-dealt through LDS
-//                                 to 16 lanes per row so that every atomic instruction adds 64 contiguous bytes per row.
+//                                 had to be scanned); a sample with a tap no tile owns is appended to the far list.
 //   msda_bwd_d48_tile2_kernel     grad_value side, one workgroup per (n, m, tile): expands the marks of its <= 256
 //                                 candidate blocks into a hit list (prefix over popcounts), re-decodes the hits' samples
 //                                 in rounds of 128 (the next round's locations prefetched behind the accumulate phase),
 //                                 ranks every owned tap within its (wave, pixel) counter and places it with a prefix over
 //                                 pixels, accumulates every pixel in registers from float32 rows staged in LDS, adds the
 //                                 tile.  No float sum depends on an arrival order: grad_value is BIT-REPRODUCIBLE from
-//                                 launch to launch for every tap the tiles own.
+//                                 launch to launch for every tap the tiles own.  (bf16 grad_out rows: the matrix-pipe
+//                                 kernels of msda_d48_tilemm.cuh take this kernel's place.)
+//   msda_bwd_d48_far_kernel       after the tile kernels: the far list's taps, HBM float atomics on top of the stored
+//                                 tiles, 16 lanes per sample so that every atomic instruction adds 64 contiguous bytes.
 // "near" = inside the map and |pixel - anchor| <= R on both axes, anchor a fixed function of the query INDEX; "owned" =
 // near, in the map, and the block is among the tile's candidates.  Both kernels evaluate them with the pinned arithmetic of
 // msda_d48.cuh, so owned + unowned is a partition of the taps for ANY input; locality only decides how many taps go the
