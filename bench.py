@@ -208,7 +208,7 @@ def msda_alg_bytes(d, bwd):
 PMC_PROFILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r04_pmc_bench_step.csv")
 
 
-BWD_KERNELS = ("msda_bwd_d48_patchbin", "msda_bwd_d48_tile3")       # query side; grad_value side (bf16 rows: two kernels, by tile size)
+BWD_KERNELS = ("msda_bwd_d48_patchbin", "msda_bwd_d48_tile3", "msda_bwd_d48_far")   # query side; grad_value side (bf16 rows: two kernels, by tile size); far list
 
 
 def pmc_traffic(path=PMC_PROFILE):
@@ -241,8 +241,8 @@ def pmc_traffic(path=PMC_PROFILE):
             return None, None, (f"profiles/{os.path.basename(path)} was collected with library source hash "
                                 f"{(prof_hash or 'unrecorded')[:12]}, the loaded library is {(lib_hash or 'unrecorded')[:12]}: "
                                 "counters not quoted (re-run tools/collect_profiles.sh)")
-        if len(vals) != 4:
-            return None, None, "the profile lacks FETCH_SIZE / WRITE_SIZE of the two backward kernels"
+        if any((tag, c) not in vals for tag in BWD_KERNELS[:2] for c in ("FETCH_SIZE", "WRITE_SIZE")):
+            return None, None, "the profile lacks FETCH_SIZE / WRITE_SIZE of the backward kernels"
         raw = sum(vals.values())
         corrected = raw + vals[(BWD_KERNELS[1], "FETCH_SIZE")]
         return int(raw), int(corrected), None

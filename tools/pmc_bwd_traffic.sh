@@ -18,4 +18,4 @@ cd $R
   done
 } > $out/pmc_bench_step.csv
 rm -rf $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE
-grep "tile3\|patchbin" $out/pmc_bench_step.csv
+grep "tile3\|patchbin\|far_kernel" $out/pmc_bench_step.csv
