@@ -127,7 +127,7 @@ __device__ __forceinline__ void tile3_body(LDS &S, const unsigned char *__restri
 
   // ---- A. this thread's candidate block: its mark word (as msda_bwd_d48_tile2_kernel) ----
   unsigned long long mask = 0ull;
-  int c_lq = 0, c_by = 0, c_bx = 0;
+  int c_pack = 0;          // this thread's candidate block: level << 28 | block row << 14 | block column (maps < 32 768 pixels a side)
   {
     int c = tid;
     const unsigned long long *slab = plan.marks + ((long long)n * d.M + m) * plan.words_per_nm + plan.lvl_base[l] +
@@ -140,7 +140,7 @@ __device__ __forceinline__ void tile3_body(LDS &S, const unsigned char *__restri
       if (c >= 0 && c < cnt) {
         const int dy = c / cw, dx = c - dy * cw;
         mask = slab[plan.coff[l][lq] + dy * plan.cbw[l][lq] + dx];
-        c_lq = lq; c_by = by0 + dy; c_bx = bx0 + dx;
+        c_pack = (lq << 28) | ((by0 + dy) << 14) | (bx0 + dx);
       }
       c -= cnt;
     }
@@ -152,20 +152,18 @@ __device__ __forceinline__ void tile3_body(LDS &S, const unsigned char *__restri
   // pixel covering 64 contiguous bytes.
   const int r16 = lane & 15, g4 = lane >> 4;
   gemm_f32x4 acc[NACC][3];
-  float *dst[NACC];
-  {
-    const size_t img_base = ((size_t)n * d.S + me.start) * d.M;
 #pragma unroll
-    for (int i = 0; i < NACC; ++i) {
-      const int pix = 16 * (NPB >= 4 ? 4 * i + wave : 0) + r16;
-      const int ty = ty0 + (pix >> me.shift), tx = tx0 + (pix & (edge - 1));
-      const bool on = (NPB >= 4 || wave == 0) && pix < tpx && ty < me.H && tx < me.W;
-      dst[i] = on ? grad_value + (img_base + (size_t)(ty * me.W + tx) * d.M + m) * kD48 + 4 * g4 : nullptr;
+  for (int i = 0; i < NACC; ++i)
 #pragma unroll
-      for (int cb = 0; cb < 3; ++cb)
-        acc[i][cb] = gemm_f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-  }
+    for (int cb = 0; cb < 3; ++cb) acc[i][cb] = gemm_f32x4{0.f, 0.f, 0.f, 0.f};
+  // where accumulator i of this lane goes (computed when the tile is stored: pointers held across the rounds cost registers
+  // this kernel does not have -- at 96 it spilled three, and the reload sat in front of every round's prefetch)
+  auto tile_dst = [&](int i) -> float * {
+    const int pix = 16 * (NPB >= 4 ? 4 * i + wave : 0) + r16;
+    const int ty = ty0 + (pix >> me.shift), tx = tx0 + (pix & (edge - 1));
+    const bool on = (NPB >= 4 || wave == 0) && pix < tpx && ty < me.H && tx < me.W;
+    return on ? grad_value + (((size_t)n * d.S + me.start) * d.M + (size_t)(ty * me.W + tx) * d.M + m) * kD48 + 4 * g4 : nullptr;
+  };
   // Wt starts as zeros and a column is cleared again by the lanes that wrote it; rows of G beyond a round's last hit are
   // written as zeros by the loader (0 x stale bits must not make a NaN).  (Placed between the mark load and its first use.)
   for (int i = tid; i < 2 * 4 * PLANE / 16; i += kPatchThreads) reinterpret_cast<u32x4 *>(S.W)[i] = u32x4{0u, 0u, 0u, 0u};
@@ -204,8 +202,8 @@ __device__ __forceinline__ void tile3_body(LDS &S, const unsigned char *__restri
         const unsigned mlo = __builtin_amdgcn_readlane((unsigned)mask, src);
         const unsigned mhi = __builtin_amdgcn_readlane((unsigned)(mask >> 32), src);
         const int ex = __builtin_amdgcn_readlane(my_excl, src);
-        const int lqv = __builtin_amdgcn_readlane(c_lq, src);
-        const int byv = __builtin_amdgcn_readlane(c_by, src), bxv = __builtin_amdgcn_readlane(c_bx, src);
+        const int cpv = __builtin_amdgcn_readlane(c_pack, src);
+        const int lqv = (int)((unsigned)cpv >> 28), byv = (cpv >> 14) & 0x3fff, bxv = cpv & 0x3fff;
         int start = lv.start[0], Wq = lv.W[0];
         float rwq = lv.rw[0], rhq = lv.rh[0];
 #pragma unroll
@@ -356,9 +354,10 @@ __device__ __forceinline__ void tile3_body(LDS &S, const unsigned char *__restri
   // ---- store the tile (tiles are disjoint; the accumulators started from grad_value) ----
 #pragma unroll
   for (int i = 0; i < NACC; ++i) {
-    if (dst[i]) {
+    float *dst = tile_dst(i);
+    if (dst) {
 #pragma unroll
-      for (int cb = 0; cb < 3; ++cb) *reinterpret_cast<gemm_f32x4 *>(dst[i] + 16 * cb) = acc[i][cb];
+      for (int cb = 0; cb < 3; ++cb) *reinterpret_cast<gemm_f32x4 *>(dst + 16 * cb) = acc[i][cb];
     }
   }
 }
@@ -404,7 +403,7 @@ __device__ __forceinline__ void tile3_body_wide(Tile3LdsWide &S, const unsigned 
 
   // ---- this thread's candidate block: its mark word (threads 256.. have none: <= 256 candidates per tile) ----
   unsigned long long mask = 0ull;
-  int c_lq = 0, c_by = 0, c_bx = 0;
+  int c_pack = 0;          // this thread's candidate block: level << 28 | block row << 14 | block column (maps < 32 768 pixels a side)
   {
     int c = tid;
     const unsigned long long *slab = plan.marks + ((long long)n * d.M + m) * plan.words_per_nm + plan.lvl_base[l] +
@@ -417,27 +416,23 @@ __device__ __forceinline__ void tile3_body_wide(Tile3LdsWide &S, const unsigned 
       if (c >= 0 && c < cnt) {
         const int dy = c / cw, dx = c - dy * cw;
         mask = slab[plan.coff[l][lq] + dy * plan.cbw[l][lq] + dx];
-        c_lq = lq; c_by = by0 + dy; c_bx = bx0 + dx;
+        c_pack = (lq << 28) | ((by0 + dy) << 14) | (bx0 + dx);
       }
       c -= cnt;
     }
   }
   const int r16 = lane & 15, g4 = lane >> 4;
   gemm_f32x4 acc[NACC][3];
-  float *dst[NACC];
-  {
-    const size_t img_base = ((size_t)n * d.S + me.start) * d.M;
 #pragma unroll
-    for (int i = 0; i < NACC; ++i) {
-      const int pix = 16 * (4 * i + wq) + r16;
-      const int ty = ty0 + (pix >> me.shift), tx = tx0 + (pix & (edge - 1));
-      const bool on = kstep == 0 && pix < tpx && ty < me.H && tx < me.W;       // (waves 0-3 own the store)
-      dst[i] = on ? grad_value + (img_base + (size_t)(ty * me.W + tx) * d.M + m) * kD48 + 4 * g4 : nullptr;
+  for (int i = 0; i < NACC; ++i)
 #pragma unroll
-      for (int cb = 0; cb < 3; ++cb)
-        acc[i][cb] = gemm_f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-  }
+    for (int cb = 0; cb < 3; ++cb) acc[i][cb] = gemm_f32x4{0.f, 0.f, 0.f, 0.f};
+  auto tile_dst = [&](int i) -> float * {     // (computed when the tile is stored, see tile3_body)
+    const int pix = 16 * (4 * i + wq) + r16;
+    const int ty = ty0 + (pix >> me.shift), tx = tx0 + (pix & (edge - 1));
+    const bool on = kstep == 0 && pix < tpx && ty < me.H && tx < me.W;         // (waves 0-3 own the store)
+    return on ? grad_value + (((size_t)n * d.S + me.start) * d.M + (size_t)(ty * me.W + tx) * d.M + m) * kD48 + 4 * g4 : nullptr;
+  };
   for (int i = tid; i < 2 * 4 * PLANE / 16; i += kT3WideThreads) reinterpret_cast<u32x4 *>(S.W)[i] = u32x4{0u, 0u, 0u, 0u};
   const int my_cnt = __popcll(mask);
   const int my_excl = block_incl_scan(my_cnt, S.wsum, tid) - my_cnt;
@@ -472,8 +467,8 @@ __device__ __forceinline__ void tile3_body_wide(Tile3LdsWide &S, const unsigned 
         const unsigned mlo = __builtin_amdgcn_readlane((unsigned)mask, src);
         const unsigned mhi = __builtin_amdgcn_readlane((unsigned)(mask >> 32), src);
         const int ex = __builtin_amdgcn_readlane(my_excl, src);
-        const int lqv = __builtin_amdgcn_readlane(c_lq, src);
-        const int byv = __builtin_amdgcn_readlane(c_by, src), bxv = __builtin_amdgcn_readlane(c_bx, src);
+        const int cpv = __builtin_amdgcn_readlane(c_pack, src);
+        const int lqv = (int)((unsigned)cpv >> 28), byv = (cpv >> 14) & 0x3fff, bxv = cpv & 0x3fff;
         int start = lv.start[0], Wq = lv.W[0];
         float rwq = lv.rw[0], rhq = lv.rh[0];
 #pragma unroll
@@ -606,10 +601,11 @@ __device__ __forceinline__ void tile3_body_wide(Tile3LdsWide &S, const unsigned 
   if (kstep == 0) {
 #pragma unroll
     for (int i = 0; i < NACC; ++i) {
-      if (dst[i]) {
+      float *dst = tile_dst(i);
+      if (dst) {
 #pragma unroll
         for (int cb = 0; cb < 3; ++cb)
-          *reinterpret_cast<gemm_f32x4 *>(dst[i] + 16 * cb) = acc[i][cb] + park[((wq * NACC + i) * 3 + cb) * 64 + lane];
+          *reinterpret_cast<gemm_f32x4 *>(dst + 16 * cb) = acc[i][cb] + park[((wq * NACC + i) * 3 + cb) * 64 + lane];
       }
     }
   }
