@@ -4,7 +4,7 @@ tag=$1; shift
 out=$GRAFT_REPO_ROOT/gpurun_out/kstats_$tag
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $out -- python3 $GRAFT_REPO_ROOT/tools/opbench.py "$@" > $out.log 2>&1
-f=$(ls $out/*/*kernel_stats.csv | head -1)
+f=$(ls -t $out/*/*kernel_stats.csv | head -1)
 python3 - "$f" "$tag" <<'PY'
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
