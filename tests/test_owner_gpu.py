@@ -289,3 +289,28 @@ def test_mfma_tile_kernel_full_size_against_oracle(edges, spread, far):
     np.testing.assert_allclose(gv, ref, rtol=1e-4, atol=2e-4)
     if far == 0.0:
         assert np.array_equal(gv, gvb)          # no far taps, no atomics: bit-reproducible
+
+
+def test_owner_backward_writes_every_element_of_grad_value():
+    """The owner-computes path no longer zeroes grad_value: the tile kernels store every pixel of every (n, m) plainly and
+    the far kernel adds on top.  Poison the memory the caching allocator is about to hand out (NaN) and compare with the
+    oracle, for float32 rows (vector tile kernel) and bf16 rows (matrix-pipe kernels), with far taps present."""
+    N, shapes, M, P = 2, [(37, 29), (19, 15), (10, 8)], 4, 4
+    v, sh, lsi, loc, attn, go = grid_case(N, shapes, M, P, seed=11, spread_px=2.5, frac_far=0.1)
+    f64 = lambda a: a.astype(np.float64)
+    ref = O.core_c_backward(f64(v), sh, lsi, f64(loc), f64(attn), f64(go), threads=4)
+    t = lambda a: torch.from_numpy(a).to(DEV)
+    hs = [tuple(x) for x in sh.tolist()]
+    for rows16 in (False, True):
+        gt = t(go).to(torch.bfloat16) if rows16 else t(go)
+        ref_gv = ref[0]
+        if rows16:
+            ref_gv = O.core_c_backward(f64(v), sh, lsi, f64(loc), f64(attn), f64(gt.float().cpu().numpy()), threads=4)[0]
+        for _ in range(3):
+            poison = torch.full((N * sum(h * w for h, w in shapes) * M * 48 + 4096,), float("nan"), device=DEV)
+            del poison                     # back to the allocator: the next float32 block of this size is this one
+            gv, _, _ = MSDA.ms_deform_attn_backward(t(v), t(sh), t(lsi), t(loc), t(attn), gt, 64, host_shapes=hs,
+                                                    grad_value_f32=True)
+            assert _lib.last_variant().startswith("d48_owner")
+            assert torch.isfinite(gv).all()
+            np.testing.assert_allclose(gv.cpu().numpy(), ref_gv, rtol=1e-4, atol=5e-5)
