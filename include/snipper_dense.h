@@ -251,6 +251,12 @@ int snipper_conv3x3_bf16(void *stream, const uint16_t *X, const uint16_t *W, con
  *   Replaces masked_fill + the per-frame core-op loop's frame averaging + dtype casts. */
 int snipper_temporal_mix(void *stream, const void *in, int in_dtype, const unsigned char *mask, int mask_on_input,
                          const float *mix, int N, int Ti, int To, long long S, int C, void *out, int out_dtype);
+/* The same with either side in the head-major layout of snipper_msda_config.value_layout = 1: `in` [N, Ti, M, S, head_dim]
+ * (in_head_major) and / or `out` [N, To, M, S, head_dim] (out_head_major), M = C / head_dim; head_dim % 8 == 0, C % 8 == 0,
+ * Ti, To <= 4, 16-byte aligned arrays.  All flags 0 = snipper_temporal_mix. */
+int snipper_temporal_mix_ex(void *stream, const void *in, int in_dtype, const unsigned char *mask, int mask_on_input,
+                            const float *mix, int N, int Ti, int To, long long S, int C, void *out, int out_dtype,
+                            int head_dim, int in_head_major, int out_head_major);
 
 /* snipper_msda_prologue_forward: rows = N*T*Lq*M, one row = the L*P samples of a (query, head) (L*P <= 16, L <= 8)
  *   loc[row, l, p, :] = ref[row / M, l, :] + off[row, l, p, :] * (inv_w[l], inv_h[l])       (ms_deform_attn.py:164-165)

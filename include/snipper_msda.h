@@ -80,9 +80,16 @@ typedef struct snipper_msda_config {
                            * (csrc/msda_d48_patch.cuh; float32 grad_out rows always take it)                            */
   int32_t tile_edge[3];   /* grad_value tile edge (power of two <= 16) for levels of > 4096 / > 1024 / fewer pixels;
                            * 0 (default) = the grad_value-side kernel's own choice: 16 / 8 / 4 vector, 16 / 8 / 8 matrix pipe  */
-  int32_t reserved[5];    /* must be 0, checked ([0] != 0 selects timing ablations of the owner-computes backward with WRONG
-                           * results; refused unless SNIPPER_MSDA_ALLOW_DEBUG=1 was in the environment at load time, and
-                           * then reported as variant "d48_owner_debug")                                                */
+  int32_t debug_ablation; /* must be 0 (!= 0 selects timing ablations of the owner-computes backward with WRONG results;
+                           * refused unless SNIPPER_MSDA_ALLOW_DEBUG=1 was in the environment at load time, and then
+                           * reported as variant "d48_owner_debug")                                                     */
+  int32_t value_layout;   /* 0 = `value` / `grad_value` as the reference holds them, [N, S, M, D]; 1 = head-major
+                           * [N, M, S, D] -- a head's rows of neighbouring pixels are contiguous (the x-neighbour taps of a
+                           * sample are one 2 D-element run): fewer L1 segments and a smaller footprint for the gathers.
+                           * For callers that own both the producer and the consumer of `value` (the tied module core:
+                           * snipper_temporal_mix_ex writes / reads this layout).  Tuned D = 48 / 24 kernels only, else
+                           * SNIPPER_E_UNSUPPORTED; `out`, `loc`, `attn` and their gradients are unaffected.             */
+  int32_t reserved[3];    /* must be 0, checked                                                                         */
 } snipper_msda_config;
 void snipper_msda_config_init(snipper_msda_config *cfg);     /* fills in the defaults */
 

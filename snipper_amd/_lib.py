@@ -33,6 +33,8 @@ EXPORTS = {
     "snipper_msda_backward_bf16": (_BWD_ARGS, c_int),
     "snipper_temporal_mix": ([c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int,
                               ctypes.c_longlong, c_int, c_void_p, c_int], c_int),
+    "snipper_temporal_mix_ex": ([c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int,
+                                 ctypes.c_longlong, c_int, c_void_p, c_int, c_int, c_int, c_int], c_int),
     "snipper_msda_prologue_forward": ([c_void_p, c_void_p, c_longlong, c_void_p, c_longlong, c_int, c_void_p, c_void_p,
                                        c_void_p, c_longlong, c_int, c_int, c_int, c_void_p, c_void_p], c_int),
     "snipper_msda_prologue_backward": ([c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong,
@@ -205,7 +207,8 @@ class Config(ctypes.Structure):
     """``snipper_msda_config`` (include/snipper_msda.h).  The library itself keeps no tuning state; the wrappers in
     MultiScaleDeformableAttention.py pass the caller's Config -- or ``None`` (the library defaults) -- with every call."""
     _fields_ = [("struct_bytes", ctypes.c_int32), ("policy", ctypes.c_int32), ("near_radius", ctypes.c_float),
-                ("tile_kernel", ctypes.c_int32), ("tile_edge", ctypes.c_int32 * 3), ("reserved", ctypes.c_int32 * 5)]
+                ("tile_kernel", ctypes.c_int32), ("tile_edge", ctypes.c_int32 * 3), ("debug_ablation", ctypes.c_int32),
+                ("value_layout", ctypes.c_int32), ("reserved", ctypes.c_int32 * 3)]
 
     @classmethod
     def defaults(cls) -> "Config":
@@ -220,7 +223,7 @@ _test_config = None
 
 _KNOBS = {"near_radius": ("near_radius", float),
           "owner_tile_edge_big": (("tile_edge", 0), int), "owner_tile_edge_mid": (("tile_edge", 1), int),
-          "owner_tile_edge_small": (("tile_edge", 2), int), "debug": (("reserved", 0), int), "tile_kernel": ("tile_kernel", int)}
+          "owner_tile_edge_small": (("tile_edge", 2), int), "debug": ("debug_ablation", int), "tile_kernel": ("tile_kernel", int), "value_layout": ("value_layout", int)}
 
 
 def active_config():

@@ -67,12 +67,13 @@ bool config_ok(const snipper_msda_config *cfg) {
   }
   if (cfg->tile_kernel < 0 || cfg->tile_kernel > 2) return false;
   // the header's "must be 0": a caller that fills the struct by hand without zeroing it must not get through
-  for (int i = 1; i < 5; ++i)
+  for (int i = 0; i < 3; ++i)
     if (cfg->reserved[i] != 0) return false;
-  // reserved[0] selects timing ablations of the owner-computes backward (WRONG gradients): only a process that asked
+  if (cfg->value_layout != 0 && cfg->value_layout != 1) return false;
+  // debug_ablation selects timing ablations of the owner-computes backward (WRONG gradients): only a process that asked
   // for them in its environment BEFORE the library was loaded gets them (read once: no mutable state)
   static const bool allow_debug = [] { const char *e = getenv("SNIPPER_MSDA_ALLOW_DEBUG"); return e && e[0] == '1'; }();
-  if (cfg->reserved[0] != 0 && !allow_debug) return false;
+  if (cfg->debug_ablation != 0 && !allow_debug) return false;
   return true;
 }
 snipper_msda_config resolve(const snipper_msda_config *cfg) { return cfg ? *cfg : default_config(); }
@@ -217,14 +218,14 @@ int patch_edge(const snipper_msda_config &cfg, int cls, bool mfma_tiles) {
 // which grad_value-side kernel a backward call with these row / value types takes (config.tile_kernel: 1 forces the vector one)
 bool patch_uses_mfma(const CoreDims &d, const snipper_msda_config &cfg, int go_bf16) {
   const bool fits = (long long)d.Lq * d.M * d.L * kPatchP * 8 < (1LL << 31) && (long long)d.Lq * d.M * kT3RowB < (1LL << 31);
-  return go_bf16 && fits && (cfg.tile_kernel == 2 || (cfg.tile_kernel == 0 && !cfg.reserved[0]));
+  return go_bf16 && fits && (cfg.tile_kernel == 2 || (cfg.tile_kernel == 0 && !cfg.debug_ablation));
 }
 
 bool make_patch_plan(const CoreDims &d, const int64_t *hs, const snipper_msda_config &cfg, bool mfma_tiles, PatchPlan *out) {
   PatchPlan p{};
   p.L = d.L;
   p.radius = cfg.near_radius;
-  p.debug = cfg.reserved[0];
+  p.debug = cfg.debug_ablation;
 #ifdef TILE2_STAMPS       // diagnostic builds only: SNIPPER_TILE2_STAMPS=<device address, hex> of a 256 x 128 x 8-byte buffer
   static unsigned long long *const stamps = [] { const char *e = getenv("SNIPPER_TILE2_STAMPS"); return e ? (unsigned long long *)strtoull(e, nullptr, 16) : nullptr; }();
   p.stamps = stamps;
@@ -414,8 +415,10 @@ int snipper_msda_forward_ex(void *stream, const snipper_msda_config *cfg, const 
   if (int rc = check_dims(N, S, M, D, L, Lq, P)) return rc;
   if (!config_ok(cfg)) return SNIPPER_E_SHAPE;
   const snipper_msda_config c = resolve(cfg);
-  const CoreDims d{N, S, M, D, L, Lq, P};
+  const CoreDims d{N, S, M, D, L, Lq, P, c.value_layout};
   hipStream_t st = (hipStream_t)stream;
+  // head-major value rows: the tuned D = 48 / 24 kernels only (the generic ones would silently read the other layout)
+  if (d.head_major && (value_dtype == 2 || !d48_eligible<float>(d, c.policy))) return SNIPPER_E_UNSUPPORTED;
   if (value_dtype == 2) {
     if (out_dtype != 2) return SNIPPER_E_UNSUPPORTED;
     return forward_generic<double, double>(st, (const double *)value, shapes, level_start, (const double *)loc,
@@ -463,8 +466,9 @@ int snipper_msda_backward_ex(void *stream, const snipper_msda_config *cfg, const
   if (int rc = check_dims(N, S, M, D, L, Lq, P)) return rc;
   if (!config_ok(cfg)) return SNIPPER_E_SHAPE;
   const snipper_msda_config c = resolve(cfg);
-  const CoreDims d{N, S, M, D, L, Lq, P};
+  const CoreDims d{N, S, M, D, L, Lq, P, c.value_layout};
   hipStream_t st = (hipStream_t)stream;
+  if (d.head_major && (value_dtype == 2 || !d48_eligible<float>(d, c.policy))) return SNIPPER_E_UNSUPPORTED;
   if (value_dtype == 2) {
     if (grad_out_dtype != 2) return SNIPPER_E_UNSUPPORTED;
     if (int rc = zero_grad_value(st, (double *)grad_value, d)) return rc;
@@ -481,6 +485,7 @@ int snipper_msda_backward_ex(void *stream, const snipper_msda_config *cfg, const
         return backward_d48_patch<uint16_t>(st, grad_out, (const uint16_t *)value, (const float *)loc, (const float *)attn, d,
                                             plan, workspace, (float *)grad_value, (float *)grad_loc, (float *)grad_attn, 1, mf);
     }
+    if (d.head_major) return SNIPPER_E_UNSUPPORTED;       // (bf16 value without the owner path: generic kernels, reference layout only)
     if (int rc = zero_grad_value(st, (float *)grad_value, d)) return rc;      // (the atomic kernels accumulate)
     return backward_generic<uint16_t, float, float>(st, (const uint16_t *)grad_out, (const uint16_t *)value, shapes,
                                                     level_start, (const float *)loc, (const float *)attn, d,
@@ -1197,9 +1202,19 @@ int snipper_conv3x3_dgrad_s2_bf16(void *stream, const uint16_t *G, const uint16_
 
 int snipper_temporal_mix(void *stream, const void *in, int in_dtype, const unsigned char *mask, int mask_on_input,
                          const float *mix, int N, int Ti, int To, long long S, int C, void *out, int out_dtype) {
+  return snipper_temporal_mix_ex(stream, in, in_dtype, mask, mask_on_input, mix, N, Ti, To, S, C, out, out_dtype, 0, 0, 0);
+}
+
+int snipper_temporal_mix_ex(void *stream, const void *in, int in_dtype, const unsigned char *mask, int mask_on_input,
+                            const float *mix, int N, int Ti, int To, long long S, int C, void *out, int out_dtype,
+                            int head_dim, int in_head_major, int out_head_major) {
   if (!in || !out || !mix) return SNIPPER_E_NULL;
   if (N <= 0 || Ti <= 0 || To <= 0 || Ti > kMixMaxFrames || To > kMixMaxFrames || S <= 0 || C <= 0 || C % 4)
     return SNIPPER_E_SHAPE;
+  const bool hm = in_head_major || out_head_major;
+  if (hm && (head_dim <= 0 || head_dim % 8 || C % head_dim || C % 8 || Ti > 4 || To > 4 ||
+             (((uintptr_t)in | (uintptr_t)out) & 15)))
+    return SNIPPER_E_SHAPE;                 // (head-major: 8 channels per lane within one head row, <= 4 frames)
   MixMatrix m{};
   for (int a = 0; a < To; ++a)
     for (int b = 0; b < Ti; ++b) m.w[a][b] = mix[a * Ti + b];
@@ -1214,7 +1229,10 @@ int snipper_temporal_mix(void *stream, const void *in, int in_dtype, const unsig
                      Ti, To, (int)S, C, (TO *)out)
 #define SNIPPER_MIX_M(TI, TO, MI)                                                                                 \
   do {                                                                                                            \
-    if (wide) SNIPPER_MIX_FW(TI, TO, MI, 4, 8);                                                                   \
+    if (hm) hipLaunchKernelGGL((temporal_mix_kernel<TI, TO, MI, 4, 8, true>), dim3(grid), dim3(256), 0, st,       \
+                               (const TI *)in, mask, m, N, Ti, To, (int)S, C, (TO *)out, head_dim,                \
+                               in_head_major ? 1 : 0, out_head_major ? 1 : 0);                                    \
+    else if (wide) SNIPPER_MIX_FW(TI, TO, MI, 4, 8);                                                              \
     else if (few) SNIPPER_MIX_FW(TI, TO, MI, 4, 4);                                                               \
     else SNIPPER_MIX_FW(TI, TO, MI, 8, 4);                                                                        \
   } while (0)

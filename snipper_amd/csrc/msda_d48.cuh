@@ -128,8 +128,8 @@ __global__ __launch_bounds__(kD48Block) void msda_fwd_d48_kernel(
     const int m = (int)(row % d.M);
     const long long n = row / ((long long)d.M * d.Lq);
     const unsigned row_bytes = DT * sizeof(VT);
-    const unsigned px_stride = (unsigned)d.M * row_bytes;              // next pixel, same head
-    const unsigned base = (unsigned)(n * d.S) * px_stride + (unsigned)m * row_bytes;
+    const unsigned px_stride = msda_px_stride(d, row_bytes);           // next pixel, same head
+    const unsigned base = msda_row_base(d, (unsigned)n, (unsigned)m, row_bytes);
     for (int s = lane; s < LP; s += G) {
       const int l = s / d.P;
       const int H = lv.H[l], W = lv.W[l];
@@ -266,8 +266,8 @@ __global__ __launch_bounds__(kD48Block) void msda_bwd_d48_f32_kernel(
   if (live) {
     const int m = (int)(row % d.M);
     const long long n = row / ((long long)d.M * d.Lq);
-    const unsigned px_stride = (unsigned)d.M * DT * 4u;
-    const unsigned base = (unsigned)(n * d.S) * px_stride + (unsigned)m * (DT * 4u);
+    const unsigned px_stride = msda_px_stride(d, DT * 4u);
+    const unsigned base = msda_row_base(d, (unsigned)n, (unsigned)m, DT * 4u);
     for (int s = lane; s < LP; s += G) {
       const int l = s / d.P;
       const int H = lv.H[l], W = lv.W[l];

@@ -328,8 +328,8 @@ __global__ __launch_bounds__(kPatchThreads) void msda_bwd_d48_patchbin_kernel(
   const bool rd_ok = rdy < b.bh && rdx < b.bw;
   const int qd = rd_ok ? lvq.start + (b.qy0 + rdy) * lvq.W + b.qx0 + rdx : lvq.start;
   const long long rowd = ((long long)b.n * d.Lq + qd) * d.M + b.m;
-  const unsigned px_stride = (unsigned)d.M * kRowV;
-  const unsigned gbase = (unsigned)(b.n * d.S) * px_stride + (unsigned)b.m * kRowV;
+  const unsigned px_stride = msda_px_stride(d, kRowV);
+  const unsigned gbase = msda_row_base(d, (unsigned)b.n, (unsigned)b.m, kRowV);
   const int j = tid & 7, rg = tid >> 3;
   const unsigned value_bytes = (unsigned)((size_t)d.N * d.S * d.M * kRowV);
   const auto vsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<VT *>(value), 0, (int)value_bytes, 0x00020000);
@@ -614,7 +614,7 @@ __global__ __launch_bounds__(kPatchThreads) void msda_bwd_d48_far_kernel(
     for (int k = 0; k < 4; ++k) {
       // (a far tap is inside the map by construction: the query side only lists those)
       const unsigned pix = (unsigned)(lvl.start + (y0 + (k >> 1)) * lvl.W + x0 + (k & 1));
-      const unsigned o = ((bits >> k) & 1u) ? ((n * (unsigned)d.S + pix) * (unsigned)d.M + m) * kPatchRowBytes + 4u * ai : kOobOffset;
+      const unsigned o = ((bits >> k) & 1u) ? msda_row_base(d, n, m, kPatchRowBytes) + pix * msda_px_stride(d, kPatchRowBytes) + 4u * ai : kOobOffset;
       __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(wk[k] * g0, gsrc, o, 0, 0);
       __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(wk[k] * g1, gsrc, o + 64u, 0, 0);
       __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(wk[k] * g2, gsrc, o + 128u, 0, 0);
@@ -1020,7 +1020,7 @@ __global__ __launch_bounds__(kPatchThreads) __attribute__((amdgpu_waves_per_eu(3
   }
   // ---- store the tile: plain stores (tiles are disjoint and cover the map; the far taps are added afterwards by
   //      msda_bwd_d48_far_kernel, so nothing was in grad_value before) ----
-  const size_t img_base = ((size_t)n * d.S + me.start) * d.M;
+  const size_t gv_base = msda_row_base(d, (unsigned)n, (unsigned)m, kPatchRowBytes), gv_px = msda_px_stride(d, kPatchRowBytes);
 #pragma unroll
   for (int u = 0; u < kMaxU; ++u) {
     const bool on = tpx >= 32 ? (u < (tpx >> 5)) : (u == 0 && (grp >> tsh) == 0);
@@ -1028,7 +1028,8 @@ __global__ __launch_bounds__(kPatchThreads) __attribute__((amdgpu_waves_per_eu(3
       const int pix = tpx >= 32 ? grp + 32 * u : (grp & (tpx - 1));
       const int ty = ty0 + (pix >> me.shift), tx = tx0 + (pix & (edge - 1));
       if (ty < me.H && tx < me.W) {
-        float *dst = grad_value + (img_base + (size_t)(ty * me.W + tx) * d.M + m) * kD48;
+        float *dst = reinterpret_cast<float *>(reinterpret_cast<unsigned char *>(grad_value) + gv_base +
+                                               (size_t)(me.start + ty * me.W + tx) * gv_px);
         *reinterpret_cast<f32x4 *>(dst + 4 * j) = f32x4{acc[u][0], acc[u][1], acc[u][2], acc[u][3]};
         *reinterpret_cast<float2 *>(dst + 32 + 2 * j) = make_float2(acc[u][4], acc[u][5]);
       }

@@ -162,7 +162,8 @@ __device__ __forceinline__ void tile3_body(LDS &S, const unsigned char *__restri
     const int pix = 16 * (NPB >= 4 ? 4 * i + wave : 0) + r16;
     const int ty = ty0 + (pix >> me.shift), tx = tx0 + (pix & (edge - 1));
     const bool on = (NPB >= 4 || wave == 0) && pix < tpx && ty < me.H && tx < me.W;
-    return on ? grad_value + (((size_t)n * d.S + me.start) * d.M + (size_t)(ty * me.W + tx) * d.M + m) * kD48 + 4 * g4 : nullptr;
+    return on ? reinterpret_cast<float *>(reinterpret_cast<unsigned char *>(grad_value) + msda_row_base(d, (unsigned)n, (unsigned)m, kPatchRowBytes) +
+                                         (size_t)(me.start + ty * me.W + tx) * msda_px_stride(d, kPatchRowBytes)) + 4 * g4 : nullptr;
   };
   // Wt starts as zeros and a column is cleared again by the lanes that wrote it; rows of G beyond a round's last hit are
   // written as zeros by the loader (0 x stale bits must not make a NaN).  (Placed between the mark load and its first use.)
@@ -431,7 +432,8 @@ __device__ __forceinline__ void tile3_body_wide(Tile3LdsWide &S, const unsigned 
     const int pix = 16 * (4 * i + wq) + r16;
     const int ty = ty0 + (pix >> me.shift), tx = tx0 + (pix & (edge - 1));
     const bool on = kstep == 0 && pix < tpx && ty < me.H && tx < me.W;         // (waves 0-3 own the store)
-    return on ? grad_value + (((size_t)n * d.S + me.start) * d.M + (size_t)(ty * me.W + tx) * d.M + m) * kD48 + 4 * g4 : nullptr;
+    return on ? reinterpret_cast<float *>(reinterpret_cast<unsigned char *>(grad_value) + msda_row_base(d, (unsigned)n, (unsigned)m, kPatchRowBytes) +
+                                         (size_t)(me.start + ty * me.W + tx) * msda_px_stride(d, kPatchRowBytes)) + 4 * g4 : nullptr;
   };
   for (int i = tid; i < 2 * 4 * PLANE / 16; i += kT3WideThreads) reinterpret_cast<u32x4 *>(S.W)[i] = u32x4{0u, 0u, 0u, 0u};
   const int my_cnt = __popcll(mask);

@@ -21,7 +21,18 @@ constexpr int kGenericBlock = 256;
 
 struct CoreDims {
   int N, S, M, D, L, Lq, P;
+  // layout of value / grad_value: 0 = the reference's [N, S, M, D]; 1 = head-major [N, M, S, D] (snipper_msda_config
+  // .value_layout, the tuned D = 48 / 24 kernels only): a head's rows of neighbouring pixels are contiguous, so the two
+  // x-neighbour taps of a sample are 2 D contiguous elements
+  int head_major;
 };
+// byte offset of row (n, pixel s, head m) = msda_row_base(n, m) + s * msda_px_stride(), rows of row_bytes bytes
+__device__ __forceinline__ unsigned msda_px_stride(const CoreDims &d, unsigned row_bytes) {
+  return d.head_major ? row_bytes : (unsigned)d.M * row_bytes;
+}
+__device__ __forceinline__ unsigned msda_row_base(const CoreDims &d, unsigned n, unsigned m, unsigned row_bytes) {
+  return d.head_major ? (n * (unsigned)d.M + m) * (unsigned)d.S * row_bytes : n * (unsigned)d.S * (unsigned)d.M * row_bytes + m * row_bytes;
+}
 
 template <typename VT, typename CT, int G>
 __global__ __launch_bounds__(kGenericBlock) void msda_fwd_generic_kernel(

@@ -80,20 +80,33 @@ template <typename T, int W> struct VecIO {
 // F = frames the instantiation holds in registers (4 or 8 >= Ti, To), W = channels per lane (8 when C % 8 == 0: a bf16
 // frame row then moves as 16 bytes per lane; measured 47 -> see DESIGN 3.5).  One position per thread: the grid covers
 // N * S * C / W exactly (< 2^31), so the index arithmetic is 32-bit.
-template <typename TI, typename TO, bool MASK_IN, int F, int W>
+// HM: one side (or both) is HEAD-MAJOR, [frames][M][S][Dh] instead of [frames][S][M * Dh] (snipper_msda_config.value_layout):
+// the threads are then dealt in head-major order (n, head, position, vector of the head row), so that side moves as
+// contiguous runs and the other one as whole head rows (Dh elements: 96 or 192 bytes).
+template <typename TI, typename TO, bool MASK_IN, int F, int W, bool HM = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void temporal_mix_kernel(
     const TI *__restrict__ in, const unsigned char *__restrict__ mask, MixMatrix mix, int N, int Ti, int To, int S, int C,
-    TO *__restrict__ out) {
+    TO *__restrict__ out, int Dh = 0, int in_hm = 0, int out_hm = 0) {
   const unsigned XW = (unsigned)S * (unsigned)C / W;    // vectors of W channels per frame
   const unsigned i = blockIdx.x * 256u + threadIdx.x;
   if (i >= (unsigned)N * XW) return;
-  const unsigned n = i / XW, xw = i - n * XW;
-  const unsigned s = xw / ((unsigned)C / W);
+  const unsigned n = i / XW;
+  unsigned xw = i - n * XW, s, xw_hm = 0;
+  if constexpr (HM) {
+    const unsigned DV = (unsigned)Dh / W, per_head = (unsigned)S * DV;
+    const unsigned m = xw / per_head, r = xw - m * per_head;
+    s = r / DV;
+    xw_hm = xw;                                                        // ((m S + s) Dh + dv W) / W
+    xw = s * ((unsigned)C / W) + m * DV + (r - s * DV);                // ((s M + m) Dh + dv W) / W
+  } else {
+    s = xw / ((unsigned)C / W);
+  }
+  const unsigned xw_in = (HM && in_hm) ? xw_hm : xw, xw_out = (HM && out_hm) ? xw_hm : xw;
   float v[F][W];
 #pragma unroll
   for (int ti = 0; ti < F; ++ti) {
     if (ti < Ti) {
-      VecIO<TI, W>::ld(in + ((size_t)(n * Ti + ti) * XW + xw) * W, v[ti]);
+      VecIO<TI, W>::ld(in + ((size_t)(n * Ti + ti) * XW + xw_in) * W, v[ti]);
       if (MASK_IN && mask && mask[(size_t)(n * Ti + ti) * S + s]) {
 #pragma unroll
         for (int k = 0; k < W; ++k) v[ti][k] = 0.f;
@@ -118,7 +131,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 #pragma unroll
         for (int k = 0; k < W; ++k) o[k] = 0.f;
       }
-      VecIO<TO, W>::st(out + ((size_t)(n * To + to) * XW + xw) * W, o);
+      VecIO<TO, W>::st(out + ((size_t)(n * To + to) * XW + xw_out) * W, o);
     }
   }
 }

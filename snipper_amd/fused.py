@@ -27,17 +27,36 @@ def supported(t: torch.Tensor) -> bool:
     return t.is_cuda and t.dtype in _DT
 
 
-def _mix_launch(x, mask, mask_on_input, mix_rows: List[List[float]], out_dtype):
+def _mix_launch(x, mask, mask_on_input, mix_rows: List[List[float]], out_dtype, head_dim: int = 0,
+                in_head_major: bool = False, out_head_major: bool = False):
+    """``x`` [N, Ti, S, C] -> [N, To, S, C]; with ``in_head_major`` / ``out_head_major`` that side's MEMORY is
+    [N, frames, C // head_dim, S, head_dim] (snipper_msda_config.value_layout = 1) under the same logical shape."""
     N, Ti, S, C = x.shape
     To = len(mix_rows)
     out = torch.empty((N, To, S, C), dtype=out_dtype, device=x.device)
     flat = _farray([w for row in mix_rows for w in row])
     with _lib.device_guard(x.device):
-        rc = _lib.load().snipper_temporal_mix(
+        rc = _lib.load().snipper_temporal_mix_ex(
             _stream(x.device), x.data_ptr(), _DT[x.dtype], mask.data_ptr() if mask is not None else None,
-            int(mask_on_input), ctypes.cast(flat, ctypes.c_void_p), N, Ti, To, S, C, out.data_ptr(), _DT[out_dtype])
-    _lib.check(rc, "snipper_temporal_mix")
+            int(mask_on_input), ctypes.cast(flat, ctypes.c_void_p), N, Ti, To, S, C, out.data_ptr(), _DT[out_dtype],
+            int(head_dim), int(in_head_major), int(out_head_major))
+    _lib.check(rc, "snipper_temporal_mix_ex")
     return out
+
+
+def _head_major_config():
+    """The caller's (test) Config, or the defaults, with value_layout = 1."""
+    base = _lib.active_config()
+    cfg = _lib.Config.defaults()
+    if base is not None:
+        ctypes.memmove(ctypes.byref(cfg), ctypes.byref(base), ctypes.sizeof(cfg))
+    cfg.value_layout = 1
+    return cfg
+
+
+import os as _os
+# the encoder's bf16 temporal mean in the head-major layout (0 = the reference layout: A/B runs)
+_HEAD_MAJOR = _os.environ.get("SNIPPER_VALUE_HEAD_MAJOR", "1") != "0"
 
 
 class TemporalMix(Function):
@@ -86,11 +105,24 @@ class TiedSampler(Function):
         if mask is not None:
             m8 = mask.contiguous().view(torch.uint8) if mask.dtype == torch.bool else mask.contiguous()
         host_shapes = getattr(shapes, "_snipper_host", None)
-        vbar = _mix_launch(value, m8, True, mix, torch.bfloat16 if vbar_bf16 else torch.float32)
-        v4 = vbar.view(N * len(mix), S, M, C // M)
+        # The encoder's bf16 mean is internal to this node -- its producer (the mix kernel) and its consumers (the core
+        # op's kernels) are this library's -- so it is kept HEAD-MAJOR, [n, head, position, 48]: the x-neighbour taps of a
+        # sample are then one contiguous 192-byte run (forward 158 -> 146 us, query side of the backward 227 -> 207 us at
+        # freshly initialised offsets, 296 -> 229 us at sigma = 3 px: profiles/r04_head_major_experiment.txt).
+        D = C // M
+        # (only where BOTH directions have a kernel for it: the tuned forward and the owner-computes backward -- D = 48, P = 4,
+        #  L <= 4, Lq == S, default policy; anything else keeps the reference layout)
+        base_cfg = _lib.active_config()
+        hm = bool(_HEAD_MAJOR and vbar_bf16 and host_shapes is not None and D == 48 and loc.shape[-2] == 4 and
+                  loc.shape[-3] <= 4 and loc.shape[1] == S and len(mix) <= 4 and T2 <= 4 and
+                  (base_cfg is None or base_cfg.policy == 0))
+        cfg = _head_major_config() if hm else None
+        vbar = _mix_launch(value, m8, True, mix, torch.bfloat16 if vbar_bf16 else torch.float32, D, False, hm)
+        v4 = vbar.view(N * len(mix), S, M, D)             # (logical shape; the memory is head-major when `hm`)
         out = MSDA.ms_deform_attn_forward(v4, shapes, lsi, loc, prob, im2col_step,
-                                          out_bf16=bool(rows_bf16) and not vbar_bf16, host_shapes=host_shapes)
+                                          out_bf16=bool(rows_bf16) and not vbar_bf16, host_shapes=host_shapes, config=cfg)
         ctx.mix, ctx.in_dtype, ctx.dims, ctx.host_shapes, ctx.step = mix, value.dtype, (N, len(mix), S, C), host_shapes, im2col_step
+        ctx.hm, ctx.head_dim = hm, D
         ctx.has_mask = m8 is not None
         ctx.save_for_backward(v4, shapes, lsi, loc, prob, *([m8] if m8 is not None else []))
         return out
@@ -108,10 +140,10 @@ class TiedSampler(Function):
         elif v4.dtype == torch.float32 and go.dtype not in (torch.float32, torch.bfloat16):
             go = go.float()
         gv, gl, ga = MSDA.ms_deform_attn_backward(v4, shapes, lsi, loc, prob, go, ctx.step, host_shapes=ctx.host_shapes,
-                                                  grad_value_f32=True)
+                                                  grad_value_f32=True, config=_head_major_config() if ctx.hm else None)
         mix = ctx.mix
         mix_t = [[mix[a][b] for a in range(len(mix))] for b in range(len(mix[0]))]
-        g_value = _mix_launch(gv.view(N, T1, S, C), m8, False, mix_t, ctx.in_dtype)
+        g_value = _mix_launch(gv.view(N, T1, S, C), m8, False, mix_t, ctx.in_dtype, ctx.head_dim, ctx.hm, False)
         return g_value, None, None, gl, ga, None, None, None, None, None, None
 
 

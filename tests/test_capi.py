@@ -77,7 +77,7 @@ def test_reference_import_line_binds_without_install():
 
 def test_config_reserved_fields_and_owner_map_bounds_are_checked():
     """the header's "must be 0" is enforced (a hand-filled, un-zeroed struct must not reach the kernels; the
-    wrong-result timing ablations behind reserved[0] need SNIPPER_MSDA_ALLOW_DEBUG=1 at load time), and maps with H or
+    wrong-result timing ablations behind debug_ablation need SNIPPER_MSDA_ALLOW_DEBUG=1 at load time), and maps with H or
     W >= 32768 (the hit records pack qy / qx in 15 bits each) do not take the owner-computes path.  Host-only calls."""
     lib = _lib.load()
     import numpy as np
@@ -87,15 +87,15 @@ def test_config_reserved_fields_and_owner_map_bounds_are_checked():
     ws = lambda cfg, hp=hp, S=S, L=3: lib.snipper_msda_backward_ex_workspace_bytes(
         None if cfg is None else ctypes.byref(cfg), hp, 0, 2, S, 8, 48, L, S, 4)
     assert ws(None) > 0 and ws(_lib.Config.defaults()) == ws(None)
-    for field, idx in (("tile_kernel", None), ("reserved", 1), ("reserved", 4)):
+    for field, idx in (("tile_kernel", None), ("value_layout", None), ("reserved", 0), ("reserved", 2)):
         cfg = _lib.Config.defaults()
         if idx is None:
-            setattr(cfg, field, 3)          # (tile_kernel: 0 / 2 matrix pipe, 1 vector kernel; anything else is refused)
+            setattr(cfg, field, 3)          # (tile_kernel: 0 / 2 matrix pipe, 1 vector kernel; value_layout 0 / 1; anything else is refused)
         else:
             getattr(cfg, field)[idx] = 1
         assert ws(cfg) == 0, (field, idx)
     cfg = _lib.Config.defaults()
-    cfg.reserved[0] = 1
+    cfg.debug_ablation = 1
     if os.environ.get("SNIPPER_MSDA_ALLOW_DEBUG") != "1":
         assert ws(cfg) == 0
     wide = np.array([[1, 40000]], dtype=np.int64)

@@ -301,3 +301,24 @@ def test_lazy_layernorm_chain_equals_materialised_chain(rows, C):
     for a, b in zip(res["lazy"][1], res["plain"][1]):
         scale = max(float(b.float().abs().max()), 1.0)
         torch.testing.assert_close(a.float() / scale, b.float() / scale, rtol=1e-5, atol=2e-6)
+
+
+def test_temporal_mix_head_major_sides():
+    """snipper_temporal_mix_ex: either side in the head-major layout [N, frames, M, S, D] gives the same numbers as the
+    reference layout, permuted -- forward direction (bf16 in, bf16 head-major out, padding mask on the input) and the
+    backward direction (float32 head-major in, bf16 out, mask on the output)."""
+    from snipper_amd.fused import _mix_launch
+    torch.manual_seed(2)
+    N, T, S, M, D = 2, 4, 517, 8, 48
+    C = M * D
+    mix = [[0.5, 0.5, 0, 0], [1 / 3, 1 / 3, 1 / 3, 0], [0, 1 / 3, 1 / 3, 1 / 3], [0, 0, 0.5, 0.5]]
+    mask = (torch.rand(N, T, S, device="cuda:0") < 0.1).to(torch.uint8)
+    x = torch.randn(N, T, S, C, device="cuda:0").to(torch.bfloat16)
+    ref = _mix_launch(x, mask, True, mix, torch.bfloat16)
+    hm = _mix_launch(x, mask, True, mix, torch.bfloat16, D, False, True)
+    assert torch.equal(hm.view(N, T, M, S, D).permute(0, 1, 3, 2, 4).reshape(N, T, S, C), ref)
+    g = torch.randn(N, T, S, C, device="cuda:0")
+    g_hm = g.view(N, T, S, M, D).permute(0, 1, 3, 2, 4).contiguous().view(N, T, S, C)
+    mix_t = [[mix[a][b] for a in range(T)] for b in range(T)]
+    assert torch.equal(_mix_launch(g_hm, mask, False, mix_t, torch.bfloat16, D, True, False),
+                       _mix_launch(g, mask, False, mix_t, torch.bfloat16))

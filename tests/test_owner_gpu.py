@@ -314,3 +314,38 @@ def test_owner_backward_writes_every_element_of_grad_value():
             assert _lib.last_variant().startswith("d48_owner")
             assert torch.isfinite(gv).all()
             np.testing.assert_allclose(gv.cpu().numpy(), ref_gv, rtol=1e-4, atol=5e-5)
+
+
+def test_head_major_value_layout_equals_the_reference_layout():
+    """snipper_msda_config.value_layout = 1: value / grad_value as [N, M, S, D].  The same inputs in the two layouts must
+    give the same forward rows and the same gradients (grad_value compared after permuting back; the owned taps bit for
+    bit -- the layout only changes addresses, not the order of any sum -- everything within the usual tolerance because the
+    far taps' atomics are unordered).  bf16 value with bf16 rows (matrix-pipe tile kernels) and float32 value (vector kernel)."""
+    from snipper_amd.fused import _head_major_config
+    N, shapes, M, P = 2, [(37, 29), (19, 15), (10, 8)], 4, 4
+    v, sh, lsi, loc, attn, go = grid_case(N, shapes, M, P, seed=5, spread_px=2.0, frac_far=0.05)
+    t = lambda a: torch.from_numpy(a).to(DEV)
+    hs = [tuple(x) for x in sh.tolist()]
+    cfg = _head_major_config()
+    for dtype in (torch.bfloat16, torch.float32):
+        val = t(v).to(dtype)
+        got = t(go).to(dtype)
+        val_hm = val.permute(0, 2, 1, 3).contiguous().view(val.shape)          # memory [N, M, S, D] under the logical shape
+        out = MSDA.ms_deform_attn_forward(val, t(sh), t(lsi), t(loc), t(attn), 64, host_shapes=hs)
+        out_hm = MSDA.ms_deform_attn_forward(val_hm, t(sh), t(lsi), t(loc), t(attn), 64, host_shapes=hs, config=cfg)
+        assert torch.equal(out, out_hm)
+        gv, gl, ga = MSDA.ms_deform_attn_backward(val, t(sh), t(lsi), t(loc), t(attn), got, 64, host_shapes=hs, grad_value_f32=True)
+        assert _lib.last_variant().startswith("d48_owner")
+        gv2, gl2, ga2 = MSDA.ms_deform_attn_backward(val_hm, t(sh), t(lsi), t(loc), t(attn), got, 64, host_shapes=hs,
+                                                     grad_value_f32=True, config=cfg)
+        assert _lib.last_variant().startswith("d48_owner")
+        S = val.shape[1]
+        gv2 = gv2.view(N, M, S, 48).permute(0, 2, 1, 3)
+        assert torch.equal(gl, gl2) and torch.equal(ga, ga2)
+        torch.testing.assert_close(gv2, gv.view(N, S, M, 48), rtol=1e-5, atol=1e-5)
+    # shapes without a tuned kernel refuse the layout instead of reading the wrong one
+    val71 = torch.randn(1, 9 * 31, 5, 71, device=DEV)
+    sh1 = torch.tensor([[9, 31]], device=DEV)
+    with pytest.raises(RuntimeError):
+        MSDA.ms_deform_attn_forward(val71, sh1, torch.zeros(1, dtype=torch.int64, device=DEV),
+                                    torch.rand(1, 7, 5, 1, 4, 2, device=DEV), torch.rand(1, 7, 5, 1, 4, device=DEV), 64, config=cfg)
