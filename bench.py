@@ -1007,7 +1007,11 @@ def main():
                                      ("DistributedDataParallel" if a.ddp == "torch" else
                                       "flat buffer, 5 stages (decoder side, encoder side, layer4, layer3, layer2) all-reduced over RCCL "
                                       "from autograd hooks while backward runs (snipper_amd/grad_sync.py)")),
-                       "msda_path": "pytorch grid_sample" if a.use_pytorch_deform else "snipper_amd HIP (tied single-launch)",
+                       "msda_path": "pytorch grid_sample" if a.use_pytorch_deform else
+                                    ("snipper_amd HIP (tied single-launch" +
+                                     ("; encoder's bf16 temporal mean and grad_value head-major [n, head, position, 48] inside the "
+                                      "module core, snipper_msda_config.value_layout = 1)"
+                                      if amp and os.environ.get("SNIPPER_VALUE_HEAD_MAJOR", "1") != "0" else ")")),
                        "launch": graph_note,
                        "weights": ("bf16 parameters + fp32 master weights" if masters is not None else
                                    "fp32 parameters" + (" under bf16 autocast" if amp else "")),
