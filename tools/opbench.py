@@ -84,6 +84,7 @@ def main():
     ap.add_argument("--debug", type=int, default=0, help="timing ablations of the encoder-shape kernels (wrong results)")
     ap.add_argument("--edges", type=int, nargs=3, default=None)
     ap.add_argument("--tile-kernel", type=int, default=None, help="owner-computes grad_value side for bf16 rows: 1 = vector / LDS kernel, 2 = matrix pipe (default)")
+    ap.add_argument("--value-layout", type=int, default=0, help="1 = address value / grad_value head-major (timing: the buffers keep their shape)")
     ap.add_argument("--cases", nargs="+", default=["enc_local", "enc_uniform", "dec"])
     ap.add_argument("--dtypes", nargs="+", default=["float32", "bfloat16"])
     ap.add_argument("--sigma", type=float, nargs="+", default=[3.0], help="enc_local: std of the offsets in pixels")
@@ -98,6 +99,8 @@ def main():
         _lib.set_param("debug", args.debug)
     if args.tile_kernel is not None:
         _lib.set_param("tile_kernel", args.tile_kernel)
+    if args.value_layout:
+        _lib.set_param("value_layout", args.value_layout)
     if args.edges:
         for k, e in zip(("big", "mid", "small"), args.edges):
             _lib.set_param(f"owner_tile_edge_{k}", e)
