@@ -375,12 +375,13 @@ struct T3Class {
 // threads, two taps each; waves 0-3 multiply k-step 0 (hits 0-31) and waves 4-7 k-step 1 (hits 32-63) of every round, each
 // for the pixel blocks {4 i + (wave & 3)}; the two halves meet once, through LDS, in a fixed order, before the tile is stored.
 constexpr int kT3WideThreads = 512;
-constexpr int kT3WideList = 448;                    // hits per pass (so that two workgroups fit the 160 KB of a CU)
+constexpr int kT3WideList = 512;                    // hits per pass (two workgroups fit the 160 KB of a CU: 80 336 B each; 448 with a
+                                                    // trash word per thread left most 16 x 16 tiles a second, nearly empty pass: 114 -> 111 us)
 struct Tile3LdsWide {
   __attribute__((aligned(16))) unsigned char W[2 * 4 * kT3PlaneMax];
   __attribute__((aligned(16))) unsigned char G[kT3Hits * kT3RowB];
   __attribute__((aligned(16))) T3Hit hits[kT3WideList];
-  float trash[kT3WideThreads];
+  float trash[64];                                                    // (one word per LANE: what lands here is never read)
   __attribute__((aligned(16))) unsigned dirty[8];
   int wsum[8];
   int total_hits;
@@ -446,7 +447,7 @@ __device__ __forceinline__ void tile3_body_wide(Tile3LdsWide &S, const unsigned 
   const int h = tid >> 3, p = (tid >> 1) & 3, dy = tid & 1, h5 = h & 31;
   const unsigned w_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)S.W;
   const unsigned wcol = w_lds + (unsigned)(((h >> 5) * 4 + ((h5 >> 2) & 3)) * PLANE + ((h5 & 3) + ((h5 >> 4) << 2)) * 4);
-  const unsigned trash = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)(S.trash + tid);
+  const unsigned trash = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)(S.trash + lane);
   const unsigned q_loc = (unsigned)(d.M * LP) * 8u, q_attn = (unsigned)(d.M * LP) * 4u, q_go = (unsigned)d.M * kT3RowB;
   const auto loc_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(loc + row_base * d.M * LP * 2), 0,
                                                          (int)((unsigned)d.Lq * q_loc), 0x00020000);
