@@ -7,7 +7,7 @@ R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 pass() {
   name=$1; shift
-  timeout 150 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $out/p_$name -- python3 $R/tools/opbench.py --N 8 --cases enc_local --dtypes bfloat16 --skip-torch --sigma 0.01 --grid 1 --iters 4 > $out/p_$name.log 2>&1
+  timeout 150 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $out/p_$name -- python3 $R/tools/opbench.py --N 8 --cases enc_local --dtypes bfloat16 --skip-torch --sigma ${SIGMA:-0.01} --grid 1 --iters 4 --value-layout ${VL:-0} > $out/p_$name.log 2>&1
 }
 pass a TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_READ_sum TCP_PENDING_STALL_CYCLES_sum
 # (a pass with TA_* counters -- TA_TA_BUSY_sum, TA_BUFFER_READ_WAVEFRONTS_sum, ... -- aborted inside rocprofv3 on this image and
@@ -22,7 +22,7 @@ cd $R
     for c in $(python3 -c "
 import csv
 print(' '.join(sorted({r['Counter_Name'] for r in csv.DictReader(open('$f'))})))"); do
-      python3 tools/pmc_summary.py $f $c msda_bwd_d48_tile2 msda_bwd_d48_patchbin msda_fwd_d48
+      python3 tools/pmc_summary.py $f $c msda_bwd_d48_tile3 msda_bwd_d48_patchbin msda_fwd_d48
     done
   done
 } > $out/pmc_gather_l1.csv
