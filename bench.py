@@ -138,6 +138,18 @@ def optimizer_groups(named_params):
     return (main, named(lambda n: "backbone" in n), named(slow))
 
 
+def reference_param_groups(named_params):
+    """The reference optimizer's param_groups exactly as main.py:201-217 builds them: (main, backbone, slow), each in
+    ``model.named_parameters()`` order.  ``checkpoint['optimizer']`` numbers parameters by position in THESE lists, so
+    FlatAdamW maps its state dict through them (``reference_groups``), whatever order the flat layout uses."""
+    match = lambda n, kws: any(k in n for k in kws)
+    bb, slow = ["backbone.0"], ["reference_points", "sampling_offsets"]
+    named_params = [(n, p) for n, p in named_params if p.requires_grad]
+    return ([p for n, p in named_params if not match(n, bb) and not match(n, slow)],
+            [p for n, p in named_params if match(n, bb)],
+            [p for n, p in named_params if match(n, slow)])
+
+
 STAGE_NAMES = ["decoder + heads + queries", "encoder + input projections + slow group", "layer4", "layer3", "layer2"]
 
 
@@ -647,7 +659,8 @@ def main():
         if flatp is not None and a.optimizer == "flat-kernel" and not a.graph and not os.environ.get("SNIPPER_OPT_PLAIN"):
             from snipper_amd.flat_params import FlatAdamW
             # groups in FlatParameters' order (main, slow, backbone): the reference's learning rates (main.py:201-221)
-            own_opt = FlatAdamW(flatp, [1e-4, 1e-5, 1e-5], weight_decay=1e-4, group_order=(0, 2, 1))   # (the reference lists main, backbone, slow)
+            own_opt = FlatAdamW(flatp, [1e-4, 1e-5, 1e-5], weight_decay=1e-4,
+                                reference_groups=reference_param_groups(list(model.named_parameters())))
     batches = make_batches(a, device, 2, seed=1000 + rank)
 
     criterion = None
@@ -862,6 +875,8 @@ def main():
         loss = step(a.warmup + i)
     fence()
     elapsed = time.perf_counter() - t0
+    if gsync is not None:
+        gsync.check_errors()          # a late gradient flagged by the LAST step's sync() would otherwise never be reported
     loss_val = float(loss.detach())
     per_rank_ms = None
     if use_ddp:
@@ -931,6 +946,7 @@ def main():
                       "fraction_of_bytes_launched_before_last_10pct_of_backward": round(early_mb / total_mb, 3),
                       "stages": STAGE_NAMES[:len(gsync.stages)]}
         gsync.trace = None
+        gsync.check_errors()
         if flatp is not None:
             flatp.pack()
 

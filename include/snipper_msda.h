@@ -38,9 +38,13 @@
  *
  * Outputs
  *   forward : `out` is fully overwritten (no pre-zeroing needed).
- *   backward: `grad_loc` and `grad_attn` are fully overwritten; `grad_value` is
- *             ZEROED BY THE CALLEE (hipMemsetAsync on `stream`) and then
- *             accumulated into.
+ *   backward: `grad_value`, `grad_loc` and `grad_attn` are fully written by the
+ *             callee: nobody has to zero anything beforehand, and nothing the
+ *             buffers held before the call is read.  (How: the kernels that
+ *             accumulate with float atomics zero `grad_value` themselves with a
+ *             hipMemsetAsync on `stream` first; the owner-computes backward of the
+ *             encoder shape stores every element plainly and adds the far taps on
+ *             top -- tests/test_owner_gpu.py poisons the buffer with NaN.)
  */
 #ifndef SNIPPER_MSDA_H_
 #define SNIPPER_MSDA_H_

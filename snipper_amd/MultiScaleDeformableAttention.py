@@ -179,7 +179,7 @@ def ms_deform_attn_backward(value: torch.Tensor, spatial_shapes: torch.Tensor,
     N, S, M, D, L, Lq, P = _dims(value, spatial_shapes, sampling_loc, attn_weight)
     _require(grad_output.numel() == N * Lq * M * D, "grad_output shape mismatch")
     acc_dtype = torch.float32 if value.dtype == torch.bfloat16 else value.dtype
-    # grad_value is zeroed by the callee (include/snipper_msda.h, "Outputs")
+    # grad_value is fully written by the callee, no pre-zeroing (include/snipper_msda.h, "Outputs")
     grad_value = torch.empty(value.shape, dtype=acc_dtype, device=value.device)
     grad_loc = torch.empty_like(sampling_loc)
     grad_attn = torch.empty_like(attn_weight)

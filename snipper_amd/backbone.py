@@ -487,7 +487,12 @@ def graphed_segments(body: "ResNet50Body", sample_images: torch.Tensor):
     region 4.1 -> 0.7 ms, its GPU time 5.2 -> 5.8 ms (replay costs ~1.7 us per node on the GPU side) -- a loss while the
     step is GPU-bound (25 ms of kernels against 19.6 ms of host issue), so nothing in the product path uses it; wired into
     bench.py's full step it also crashed the process (segmentation fault inside the captured backward), not root-caused.
-    Requires bf16 autocast, training mode, frozen stem + layer1 (the reference's freeze rule) and all three taps."""
+    Requires bf16 autocast, training mode, frozen stem + layer1 (the reference's freeze rule) and all three taps.
+    OPT-IN ONLY (``SNIPPER_EXPERIMENTAL_GRAPHS=1``): a known process-killing path must not be one import away."""
+    import os
+    if os.environ.get("SNIPPER_EXPERIMENTAL_GRAPHS") != "1":
+        raise RuntimeError("graphed_segments is an experiment (inside the full training step its captured backward crashed "
+                           "the process, not root-caused): set SNIPPER_EXPERIMENTAL_GRAPHS=1 to use it")
     assert body.return_interm_layers and sample_images.is_cuda
     segs = [_Segment(body, w) for w in ("first", "layer3", "layer4")]
     with torch.no_grad():

@@ -221,10 +221,11 @@ bool patch_uses_mfma(const CoreDims &d, const snipper_msda_config &cfg, int go_b
   return go_bf16 && fits && (cfg.tile_kernel == 2 || (cfg.tile_kernel == 0 && !cfg.debug_ablation));
 }
 
-bool make_patch_plan(const CoreDims &d, const int64_t *hs, const snipper_msda_config &cfg, bool mfma_tiles, PatchPlan *out) {
+bool make_patch_plan_r(const CoreDims &d, const int64_t *hs, const snipper_msda_config &cfg, bool mfma_tiles, float radius,
+                       PatchPlan *out) {
   PatchPlan p{};
   p.L = d.L;
-  p.radius = cfg.near_radius;
+  p.radius = radius;
   p.debug = cfg.debug_ablation;
 #ifdef TILE2_STAMPS       // diagnostic builds only: SNIPPER_TILE2_STAMPS=<device address, hex> of a 256 x 128 x 8-byte buffer
   static unsigned long long *const stamps = [] { const char *e = getenv("SNIPPER_TILE2_STAMPS"); return e ? (unsigned long long *)strtoull(e, nullptr, 16) : nullptr; }();
@@ -282,6 +283,17 @@ bool make_patch_plan(const CoreDims &d, const int64_t *hs, const snipper_msda_co
   p.words_per_nm = lvl_base;
   *out = p;
   return true;
+}
+// The plan at the configured near radius, or -- when a tile's candidate rectangles would not fit one thread each
+// (kPatchMaxCand; maps well above 600 x 800: 720 x 1280, 1080 x 1920) -- at the largest smaller radius of a fixed ladder
+// that fits.  Near + far is a partition of the taps at ANY radius (tests/test_owner_gpu.py), so the radius only decides how
+// many taps go the fast way; the same ladder runs in the workspace query and in the launch, so both see the same plan.
+bool make_patch_plan(const CoreDims &d, const int64_t *hs, const snipper_msda_config &cfg, bool mfma_tiles, PatchPlan *out) {
+  if (make_patch_plan_r(d, hs, cfg, mfma_tiles, cfg.near_radius, out)) return true;
+  const float ladder[] = {16.f, 12.f, 8.f, 6.f, 4.f, 3.f};
+  for (float r : ladder)
+    if (r < cfg.near_radius && make_patch_plan_r(d, hs, cfg, mfma_tiles, r, out)) return true;
+  return false;
 }
 
 // workspace of the owner-computes backward: the marks, the far list's counter (zeroed with the marks), the far list (one
@@ -377,6 +389,7 @@ bool owner_shape_ok(const CoreDims &d, const int64_t *hs, int policy) {
     if (hs[2 * l] >= 32768 || hs[2 * l + 1] >= 32768) return false;     // hit queries are packed level<<30 | qy<<15 | qx
     sum += hs[2 * l] * hs[2 * l + 1];
   }
+  if ((long long)d.N * d.Lq * d.M * d.L * kPatchP >= (1LL << 32)) return false;       // (sample indices are 32-bit)
   return sum == d.S && d.S < (1 << 24);
 }
 

@@ -110,24 +110,52 @@ class FlatAdamW(torch.optim.Optimizer):
 
     A ``torch.optim.Optimizer``: one param_group per non-empty FlatParameters group (its flat leaf as the only "params"
     entry), so the reference's ``StepLR(optimizer, lr_drop)`` (main.py:222) and any other scheduler drive ``lr`` as usual.
-    ``state_dict()`` / ``load_state_dict()`` speak ``torch.optim.AdamW``'s per-parameter format over the MODEL's parameters
-    (``group_order`` = the FlatParameters group behind each group of the optimizer being mirrored: the reference's groups are
-    (main, backbone, slow), FlatParameters' (main, slow, backbone) -> ``group_order=(0, 2, 1)``), so the reference's
-    ``checkpoint['optimizer']`` (main.py:236-262) can be produced and resumed from.  CUDA only: there is no CPU fallback --
-    use ``torch.optim.AdamW`` on ``flat.leaves`` there."""
+    ``state_dict()`` / ``load_state_dict()`` speak ``torch.optim.AdamW``'s per-parameter format over the MODEL's parameters,
+    so the reference's ``checkpoint['optimizer']`` (main.py:236-262) can be produced and resumed from.  That format numbers
+    the parameters by POSITION inside the mirrored optimizer's param_groups, and the reference builds those from
+    ``model.named_parameters()`` (main.py:201-217) -- an order the flat layout is free to differ from (bench.py puts the
+    decoder-side parameters first inside `main` so that they form one all-reduce stage).  ``reference_groups`` = the
+    parameter lists of the optimizer being mirrored, in ITS group and parameter order (e.g. ``[d["params"] for d in
+    param_dicts]``); ids are mapped through it, whatever the flat layout is.  Without it the flat order itself is used,
+    with ``group_order`` = the FlatParameters group behind each mirrored group (the reference lists (main, backbone, slow),
+    FlatParameters (main, slow, backbone) -> ``group_order=(0, 2, 1)``): only right when the flat groups list their
+    parameters in the mirrored optimizer's order.  CUDA only: there is no CPU fallback -- use ``torch.optim.AdamW`` on
+    ``flat.leaves`` there."""
 
     N_PARTS = 2048
 
     def __init__(self, flat: "FlatParameters", lrs: Sequence[float], weight_decay: float = 1e-2, betas=(0.9, 0.999),
-                 eps: float = 1e-8, group_order: Optional[Sequence[int]] = None):
-        assert flat.flat.is_cuda, "FlatAdamW runs on the HIP kernels only"
-        assert len(lrs) == len(flat.ranges)
+                 eps: float = 1e-8, group_order: Optional[Sequence[int]] = None,
+                 reference_groups: Optional[Sequence[Sequence[nn.Parameter]]] = None):
+        assert len(lrs) == len(flat.ranges)      # (a CPU FlatParameters can be built and its state_dict exchanged; step() is HIP only)
         self.flat = flat
         groups = [{"params": [flat.leaf_of_group(i)], "lr": float(lr), "flat_group": i}
                   for i, lr in enumerate(lrs) if flat.leaf_of_group(i) is not None]
         super().__init__(groups, dict(lr=float(lrs[0]), weight_decay=float(weight_decay), betas=tuple(betas), eps=float(eps)))
         self.group_order = tuple(group_order) if group_order is not None else tuple(range(len(flat.ranges)))
         assert sorted(self.group_order) == list(range(len(flat.ranges)))
+        self._ref_order = None
+        if reference_groups is not None:
+            index = {id(p): i for i, p in enumerate(flat.params)}
+            group_of, first = {}, 0
+            for gi, g in enumerate(flat.groups):
+                for i in range(first, first + len(g)):
+                    group_of[i] = gi
+                first += len(g)
+            order, seen = [], set()
+            for ref in reference_groups:
+                idxs = [index[id(p)] for p in ref if p.requires_grad]          # KeyError: not a parameter of `flat`
+                fgs = {group_of[i] for i in idxs}
+                if len(fgs) > 1:
+                    raise ValueError("FlatAdamW: a reference group spans several FlatParameters groups (one lr each)")
+                if idxs:
+                    order.append((fgs.pop(), idxs))
+                seen.update(idxs)
+            if len(seen) != len(flat.params) or sum(len(i) for _, i in order) != len(flat.params):
+                raise ValueError("FlatAdamW: reference_groups must list every trainable parameter exactly once")
+            if len({fg for fg, _ in order}) != len(order):
+                raise ValueError("FlatAdamW: two reference groups map to one FlatParameters group")
+            self._ref_order = order
         self.exp_avg = torch.zeros_like(flat.flat)
         self.exp_avg_sq = torch.zeros_like(flat.flat)
         self.partials = torch.zeros(self.N_PARTS, dtype=torch.float32, device=flat.flat.device)
@@ -140,6 +168,9 @@ class FlatAdamW(torch.optim.Optimizer):
         import ctypes
         from . import _lib
         f = self.flat
+        if not f.flat.is_cuda:
+            raise RuntimeError("FlatAdamW.step runs on the HIP kernels only (no CPU fallback): use torch.optim.AdamW on "
+                               "flat.leaves for a CPU model")
         n = f.flat.numel()
         groups = self.param_groups
         k = len(groups)
@@ -177,19 +208,22 @@ class FlatAdamW(torch.optim.Optimizer):
         f = self.flat
         return [buf.as_strided(p.shape, p.stride(), off) for p, off in zip(f.params, f.offsets)]
 
-    def _ordered_param_indices(self):
-        """Index (in FlatParameters.params) of every model parameter, group by group in ``group_order``."""
+    def _ordered_groups(self):
+        """[(FlatParameters group, [index in FlatParameters.params of every parameter, in the MIRRORED optimizer's order])]
+        group by group in the mirrored optimizer's group order."""
+        if self._ref_order is not None:
+            return list(self._ref_order)
         f = self.flat
         first = [0]
         for g in f.groups:
             first.append(first[-1] + len(g))
-        return [list(range(first[i], first[i + 1])) for i in self.group_order]
+        return [(i, list(range(first[i], first[i + 1]))) for i in self.group_order]
 
     def state_dict(self):
         ea, es = self._moment_views(self.exp_avg), self._moment_views(self.exp_avg_sq)
         by_flat_group = {g["flat_group"]: g for g in self.param_groups}
         state, groups, k = {}, [], 0
-        for fg, idxs in zip(self.group_order, self._ordered_param_indices()):
+        for fg, idxs in self._ordered_groups():
             if not idxs:
                 continue
             g = by_flat_group[fg]
@@ -208,7 +242,7 @@ class FlatAdamW(torch.optim.Optimizer):
     def load_state_dict(self, sd) -> None:
         ea, es = self._moment_views(self.exp_avg), self._moment_views(self.exp_avg_sq)
         by_flat_group = {g["flat_group"]: g for g in self.param_groups}
-        order = [(fg, idxs) for fg, idxs in zip(self.group_order, self._ordered_param_indices()) if idxs]
+        order = [(fg, idxs) for fg, idxs in self._ordered_groups() if idxs]
         if len(sd["param_groups"]) != len(order):
             raise ValueError("FlatAdamW.load_state_dict: number of param_groups differs")
         steps = set()
@@ -225,6 +259,9 @@ class FlatAdamW(torch.optim.Optimizer):
                 if st is None:
                     steps.add(0)
                     continue
+                if tuple(st["exp_avg"].shape) != tuple(ea[i].shape):
+                    raise ValueError(f"FlatAdamW.load_state_dict: state {pid} has shape {tuple(st['exp_avg'].shape)}, the "
+                                     f"parameter at that position {tuple(ea[i].shape)} (other parameter order?)")
                 ea[i].copy_(st["exp_avg"]); es[i].copy_(st["exp_avg_sq"])
                 steps.add(int(float(st["step"])))
         if len(steps) > 1:

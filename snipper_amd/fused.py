@@ -54,6 +54,23 @@ def _head_major_config():
     return cfg
 
 
+def _owner_backward_available(cfg, host_shapes, n, S, M, D, L, P) -> bool:
+    """Does snipper_msda_backward_ex have an owner-computes plan (the only bf16-value backward that knows the head-major
+    layout) for an encoder-shape call (Lq == S) of this geometry?  A host-side query, no launch."""
+    key = (bytes(cfg), tuple(tuple(int(v) for v in hw) for hw in host_shapes), n, S, M, D, L, P)
+    ok = _OWNER_OK.get(key)
+    if ok is None:
+        hs = (ctypes.c_int64 * (2 * L))(*[v for hw in key[1] for v in hw])
+        ok = _lib.load().snipper_msda_backward_ex_workspace_bytes(
+            ctypes.byref(cfg), ctypes.cast(hs, ctypes.c_void_p), 1, n, S, M, D, L, S, P) > 0
+        if len(_OWNER_OK) < 64:
+            _OWNER_OK[key] = ok
+    return ok
+
+
+_OWNER_OK = {}
+
+
 import os as _os
 # the encoder's bf16 temporal mean in the head-major layout (0 = the reference layout: A/B runs)
 _HEAD_MAJOR = _os.environ.get("SNIPPER_VALUE_HEAD_MAJOR", "1") != "0"
@@ -117,6 +134,10 @@ class TiedSampler(Function):
                   loc.shape[-3] <= 4 and loc.shape[1] == S and len(mix) <= 4 and T2 <= 4 and
                   (base_cfg is None or base_cfg.policy == 0))
         cfg = _head_major_config() if hm else None
+        if hm and not _owner_backward_available(cfg, host_shapes, N * len(mix), S, M, D, loc.shape[-3], loc.shape[-2]):
+            # the library has no owner-computes plan for this geometry (maps too large for the marks' bounds, or 2^32
+            # samples): its backward would have to run kernels that only know the reference layout -- keep that layout
+            hm, cfg = False, None
         vbar = _mix_launch(value, m8, True, mix, torch.bfloat16 if vbar_bf16 else torch.float32, D, False, hm)
         v4 = vbar.view(N * len(mix), S, M, D)             # (logical shape; the memory is head-major when `hm`)
         out = MSDA.ms_deform_attn_forward(v4, shapes, lsi, loc, prob, im2col_step,
@@ -327,10 +348,21 @@ def add_dropout_layer_norm(x, z, norm: torch.nn.LayerNorm, p: float, training: b
                                                                norm.weight.requires_grad)):
         want = (True,) + want[1:]
     lazy_x = getattr(x, "_lazy_ln", None)
+    if lazy_x is None and x.is_cuda and x.data_ptr() in _LAZY_PTRS:
+        # a view / detach / hook product of a lazy result: same memory (the UN-normalised pre-norm sum), tag lost
+        raise RuntimeError("add_dropout_layer_norm: `x` aliases a lazy LayerNorm result but does not carry its statistics "
+                           "(a lazy float32 output may only be passed on unchanged; see AddDropoutLayerNorm)")
     out = AddDropoutLayerNorm.apply(x, z, pos, norm.weight, norm.bias, p if training else 0.0, norm.eps, want, seed, lazy_x)
     if want[0] == "lazy":
         out[0]._lazy_ln = out[0].grad_fn.lazy_aux
+        ptr = out[0].data_ptr()
+        _LAZY_PTRS.add(ptr)
+        weakref.finalize(out[0], _LAZY_PTRS.discard, ptr)      # (the tagged tensor object gone: nobody can pass it on)
     return out
+
+
+import weakref
+_LAZY_PTRS = set()        # data pointers of live lazy results (an untagged alias must not be read as y32)
 
 
 def ln_fusable(x: torch.Tensor, norm: torch.nn.LayerNorm) -> bool:

@@ -29,6 +29,12 @@ all-reduce of that slice has completed.
 Contract: ONE backward per ``sync()``, and gradients reset with ``set_to_none=True`` (or ``FlatParameters.
 drop_param_grads()``) in between.  A second backward before ``sync()`` or a gradient that still is last step's view of
 the flat buffer would silently corrupt a slice that is being all-reduced, so both raise.
+
+Deferred error.  A gradient that arrives late on ONE rank outside the agreed late set cannot raise there and then (the
+other ranks would hang in their next collective): the step completes everywhere and every rank raises together from its
+NEXT ``sync()`` / ``check_errors()``.  The optimizer step that followed the flagged ``sync()`` has therefore used a wrong
+(stale-reduced) gradient for that slice: call ``check_errors()`` after the last step of a run and before saving a
+checkpoint, and treat a raise as "the previous step's update is not to be trusted".
 """
 from __future__ import annotations
 
@@ -211,10 +217,11 @@ class FlatGradSync:
         self._err_event.synchronize()
         self._err_event = None
         if int(self._err_host[0]) != 0:
+            text, self._err_text = self._err_text, ""            # (reported once: a later, unrelated error must not quote it)
             raise RuntimeError(
                 "FlatGradSync: on at least one rank a gradient was completed after its stage's all-reduce had been launched "
                 "and is not in the agreed set of late parameters (pass it in `late=`); that rank's slice was reduced from a "
-                "stale value in the previous step" + (": " + self._err_text if self._err_text else ""))
+                "stale value in the previous step, and the optimizer step that followed used it" + (": " + text if text else ""))
 
     @torch.no_grad()
     def sync(self) -> None:

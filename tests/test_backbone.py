@@ -292,7 +292,7 @@ def test_dilated_backbone_dc5_variant():
 
 
 @pytest.mark.gpu
-def test_graphed_backbone_segments_equal_the_eager_body():
+def test_graphed_backbone_segments_equal_the_eager_body(monkeypatch):
     """VERDICT r03 #2 (experiment): the ResNet-50 body as three hipGraph-captured segments (forward and backward) gives the
     eager body's features bit for bit and its weight gradients to bf16 accuracy, also after the weights have changed
     (the captured kernels read the live shadows / parameters)."""
@@ -323,6 +323,9 @@ def test_graphed_backbone_segments_equal_the_eager_body():
         return [f.detach().float().clone() for f in feats], [p.grad.detach().float().clone() for p in params]
 
     run(body)
+    with pytest.raises(RuntimeError):               # opt-in only
+        graphed_segments(body, x)
+    monkeypatch.setenv("SNIPPER_EXPERIMENTAL_GRAPHS", "1")
     graphed = graphed_segments(body, x)
     for trial in range(2):
         f0, g0 = run(body)

@@ -116,7 +116,7 @@ def _train(arm):
         from snipper_amd.flat_params import FlatAdamW, FlatParameters
         g_main, g_backbone, g_slow = bench.optimizer_groups(named)
         flatp = FlatParameters([g_main, g_slow, g_backbone])
-        own_opt = FlatAdamW(flatp, [1e-4, 1e-5, 1e-5], weight_decay=1e-4, group_order=(0, 2, 1))
+        own_opt = FlatAdamW(flatp, [1e-4, 1e-5, 1e-5], weight_decay=1e-4, reference_groups=bench.reference_param_groups(named))
     else:
         opt = bench.build_optimizer(named)
     criterion = build_criterion(bench.criterion_args(a)).to(DEV)

@@ -69,3 +69,80 @@ def test_missing_gradients_count_as_zero_and_external_gradient_buffer():
     fp.pack()
     assert torch.equal(fp.grad_views[0], torch.ones_like(ps[0])) and torch.all(fp.grad_views[1] == 3.0)
     assert all(torch.all(v == 0) for v in fp.grad_views[2:])
+
+
+def _bench_module():
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    return b
+
+
+def test_flat_adamw_state_dict_is_in_the_reference_optimizers_parameter_order():
+    """``checkpoint['optimizer']`` numbers parameters by position inside the reference's
+    param_groups, which main.py:201-217 builds in ``model.named_parameters()`` order; bench.py's flat layout lists the
+    decoder-side parameters first.  With ``reference_groups`` the state dict FlatAdamW emits / consumes pairs every
+    moment tensor with the parameter torch.optim.AdamW -- built the reference's way on the REAL model -- means."""
+    from types import SimpleNamespace
+    from snipper_amd.flat_params import FlatAdamW
+    from snipper_amd.model import build_model
+    b = _bench_module()
+    a = SimpleNamespace(hidden_dim=192, enc_layers=2, dec_layers=2, frames=2, future_frames=0, use_pytorch_deform=0,
+                        batch=1, height=96, width=128)
+    torch.manual_seed(0)
+    model = build_model(b.model_args(a))
+    named = list(model.named_parameters())
+
+    def match(n, kws):                       # main.py:190-196
+        return any(k in n for k in kws)
+    bb, slow = ["backbone.0"], ["reference_points", "sampling_offsets"]
+    ref_groups = [[p for n, p in named if not match(n, bb) and not match(n, slow) and p.requires_grad],
+                  [p for n, p in named if match(n, bb) and p.requires_grad],
+                  [p for n, p in named if match(n, slow) and p.requires_grad]]
+    assert [[id(p) for p in g] for g in b.reference_param_groups(named)] == [[id(p) for p in g] for g in ref_groups]
+    opt_ref = torch.optim.AdamW([{"params": g, "lr": lr} for g, lr in zip(ref_groups, (1e-4, 1e-5, 1e-5))], lr=1e-4,
+                                weight_decay=1e-4)
+    main, backbone, slow_g = b.optimizer_groups(named)
+    assert [id(p) for p in main] != [id(p) for p in ref_groups[0]], "the flat layout is expected to reorder `main`"
+    assert {id(p) for p in main} == {id(p) for p in ref_groups[0]}
+    fp = FlatParameters([main, slow_g, backbone])
+    opt = FlatAdamW(fp, [1e-4, 1e-5, 1e-5], weight_decay=1e-4, reference_groups=ref_groups)
+    # FlatAdamW -> torch.optim.AdamW: moment of flat parameter i holds the constant i + 1
+    for i, (m1, m2) in enumerate(zip(opt._moment_views(opt.exp_avg), opt._moment_views(opt.exp_avg_sq))):
+        m1.fill_(float(i + 1)); m2.fill_(float(i + 1) * 0.5)
+    opt.step_count = 3
+    sd = opt.state_dict()
+    assert [len(g["params"]) for g in sd["param_groups"]] == [len(g) for g in ref_groups]
+    assert [g["lr"] for g in sd["param_groups"]] == [1e-4, 1e-5, 1e-5]
+    opt_ref.load_state_dict(sd)
+    flat_index = {id(p): i for i, p in enumerate(fp.params)}
+    for g in opt_ref.param_groups:
+        for p in g["params"]:
+            st = opt_ref.state[p]
+            assert st["exp_avg"].shape == p.shape
+            assert float(st["exp_avg"].flatten()[0]) == flat_index[id(p)] + 1.0
+            assert float(st["exp_avg_sq"].flatten()[-1]) == (flat_index[id(p)] + 1.0) * 0.5
+            assert float(st["step"]) == 3.0
+    # torch.optim.AdamW -> FlatAdamW: tag every state by the parameter's position in named_parameters()
+    pos = {id(p): k for k, (n, p) in enumerate(named)}
+    for g in opt_ref.param_groups:
+        for p in g["params"]:
+            opt_ref.state[p]["exp_avg"].fill_(float(pos[id(p)]))
+            opt_ref.state[p]["exp_avg_sq"].fill_(float(pos[id(p)]) + 0.25)
+    opt2 = FlatAdamW(fp, [1e-4, 1e-5, 1e-5], weight_decay=1e-4, reference_groups=ref_groups)
+    opt2.load_state_dict(opt_ref.state_dict())
+    assert opt2.step_count == 3
+    for p, m1, m2 in zip(fp.params, opt2._moment_views(opt2.exp_avg), opt2._moment_views(opt2.exp_avg_sq)):
+        assert float(m1.flatten()[0]) == float(pos[id(p)]) and float(m2.flatten()[-1]) == float(pos[id(p)]) + 0.25
+    # the flat order itself (no reference_groups) is NOT the reference's: a state dict loaded that way must not pass silently
+    # where shapes differ
+    opt3 = FlatAdamW(fp, [1e-4, 1e-5, 1e-5], weight_decay=1e-4, group_order=(0, 2, 1))
+    import pytest
+    with pytest.raises(ValueError):
+        opt3.load_state_dict(opt_ref.state_dict())
+    # every trainable parameter exactly once
+    with pytest.raises(ValueError):
+        FlatAdamW(fp, [1e-4, 1e-5, 1e-5], reference_groups=[ref_groups[0], ref_groups[1]])

@@ -303,6 +303,23 @@ def test_lazy_layernorm_chain_equals_materialised_chain(rows, C):
         torch.testing.assert_close(a.float() / scale, b.float() / scale, rtol=1e-5, atol=2e-6)
 
 
+def test_untagged_alias_of_a_lazy_layernorm_result_is_refused():
+    """a lazy float32 result is the UN-normalised pre-norm sum; a view of it (tag lost) handed to the next
+    ``add_dropout_layer_norm`` would be read as y32 silently -- it raises instead; the tagged tensor itself goes through."""
+    from snipper_amd.fused import add_dropout_layer_norm
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(64, 128, generator=g).to(DEV).requires_grad_(True)
+    z = torch.randn(64, 128, generator=g).to(DEV).bfloat16().requires_grad_(True)
+    n1, n2 = torch.nn.LayerNorm(128).to(DEV), torch.nn.LayerNorm(128).to(DEV)
+    y_lazy, y16, _ = add_dropout_layer_norm(x, z, n1, 0.0, True, want=("lazy", True, False))
+    assert hasattr(y_lazy, "_lazy_ln")
+    with pytest.raises(RuntimeError):
+        add_dropout_layer_norm(y_lazy.view(64, 128), z, n2, 0.0, True, want=(True, False, False))
+    out = add_dropout_layer_norm(y_lazy, z, n2, 0.0, True, want=(True, False, False))[0]
+    ref = n2(n1(x + z.float()) + z.float())
+    torch.testing.assert_close(out, ref, rtol=1e-5, atol=1e-5)
+
+
 def test_temporal_mix_head_major_sides():
     """snipper_temporal_mix_ex: either side in the head-major layout [N, frames, M, S, D] gives the same numbers as the
     reference layout, permuted -- forward direction (bf16 in, bf16 head-major out, padding mask on the input) and the

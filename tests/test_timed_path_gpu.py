@@ -1,0 +1,158 @@
+"""The path bench.py's headline is quoted on, pinned DIRECTLY to the C oracle at full size (``-m gpu``).
+
+The timed training step samples a bfloat16, HEAD-MAJOR temporal mean (``snipper_msda_config.value_layout = 1``,
+snipper_amd/fused.py TiedSampler), reads / writes bfloat16 rows and takes the matrix-pipe tile kernels of
+csrc/msda_d48_tilemm.cuh for grad_value -- both instances: ``msda_bwd_d48_tile3_kernel<64>`` for the 8 x 8 tiles and
+``msda_bwd_d48_tile3_wide_kernel`` for the 16 x 16 tiles of levels above 4 096 pixels, whose head-major stores only
+run at full map size.  These tests run exactly that combination against ``oracle/msda_oracle.c`` on the same
+bf16-rounded inputs (reference semantics: models/ops/src/cuda/ms_deform_im2col_cuda.cuh:87-159, 237-299, 513-616),
+at the geometries of BASELINE configs[2] (600 x 800) and the README recipe (540 x 960), at the bench's launch size
+N = B * T = 8, and through ``MSDeformAttn`` under bf16 autocast against the reference module's goldens
+(models/ops/modules/ms_deform_attn.py:99-243).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import msda_oracle as O
+from snipper_amd import MultiScaleDeformableAttention as MSDA
+from snipper_amd import _lib
+from tests.test_owner_gpu import GEOMETRIES, grid_case
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _timed_path_case(N, shapes, spread, far, seed):
+    """Inputs as the step holds them: float32 loc / attn, bf16 value (head-major memory) and bf16 grad_out rows; plus
+    the float64 copies of the SAME rounded numbers for the oracle."""
+    v, sh, lsi, loc, attn, go = grid_case(N, shapes, 8, 4, seed=seed, spread_px=spread, frac_far=far)
+    t = lambda a: torch.from_numpy(a).to(DEV)
+    v16, go16 = t(v).to(torch.bfloat16), t(go).to(torch.bfloat16)
+    v_hm = v16.permute(0, 2, 1, 3).contiguous().view(v16.shape)      # memory [N, M, S, D] under the logical shape
+    f64 = lambda a: a.astype(np.float64)
+    return dict(v_hm=v_hm, go16=go16, sh=t(sh), lsi=t(lsi), loc=t(loc), attn=t(attn), sh_np=sh, lsi_np=lsi,
+                v64=f64(v16.float().cpu().numpy()), go64=f64(go16.float().cpu().numpy()), loc64=f64(loc), attn64=f64(attn))
+
+
+def _run_timed_path(c, shapes):
+    from snipper_amd.fused import _head_major_config
+    cfg = _head_major_config()
+    assert cfg.value_layout == 1
+    out = MSDA.ms_deform_attn_forward(c["v_hm"], c["sh"], c["lsi"], c["loc"], c["attn"], 64, host_shapes=shapes, config=cfg)
+    assert _lib.last_variant() == "d48_lp12" and out.dtype == torch.bfloat16
+    gv, gl, ga = MSDA.ms_deform_attn_backward(c["v_hm"], c["sh"], c["lsi"], c["loc"], c["attn"], c["go16"], 64,
+                                              host_shapes=shapes, grad_value_f32=True, config=cfg)
+    assert _lib.last_variant() == "d48_owner_mfma", _lib.last_variant()
+    N, S, M, D = c["v_hm"].shape
+    assert gv.dtype == torch.float32
+    gv = gv.view(N, M, S, D).permute(0, 2, 1, 3)                      # back to the reference layout [N, S, M, D]
+    return out.float().cpu().numpy(), gv.cpu().numpy(), gl.cpu().numpy(), ga.cpu().numpy()
+
+
+def _check_against_oracle(c, got, threads=32):
+    out, gv, gl, ga = got
+    ref_out = O.core_c_forward(c["v64"], c["sh_np"], c["lsi_np"], c["loc64"], c["attn64"], threads=threads)
+    ref = O.core_c_backward(c["v64"], c["sh_np"], c["lsi_np"], c["loc64"], c["attn64"], c["go64"], threads=threads)
+    # forward rows are float32 sums rounded ONCE to bf16: half an ulp of bf16 (2^-9 relative) + the float32 noise
+    np.testing.assert_allclose(out, ref_out, rtol=2 ** -8, atol=1e-3)
+    # gradients are float32 throughout (the float32 kernels' tolerances of tests/test_owner_gpu.py)
+    np.testing.assert_allclose(gv, ref[0], rtol=1e-4, atol=2e-4)
+    s = float(np.abs(ref[1]).max())
+    np.testing.assert_allclose(gl / s, ref[1] / s, rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(ga, ref[2], rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("geom", sorted(GEOMETRIES))
+@pytest.mark.parametrize("spread", [0.01, 3.0, 8.0], ids=["sigma0", "sigma3", "sigma8"])
+def test_head_major_bf16_matrix_pipe_path_at_full_size_against_oracle(geom, spread):
+    """N = 2, bf16 head-major value + bf16 rows, 20 % of the samples anywhere (far list + HBM atomics on top of the
+    plainly stored tiles): forward and all three gradients against the C oracle."""
+    shapes = GEOMETRIES[geom]
+    c = _timed_path_case(2, shapes, spread, 0.2, seed=31 + int(spread))
+    _check_against_oracle(c, _run_timed_path(c, shapes))
+
+
+def test_head_major_bf16_matrix_pipe_path_at_the_bench_launch_size():
+    """The bench's launch: N = B * T = 8 at 600 x 800, offsets like a freshly initialised model's (a few pixels), no
+    far samples -- bit-reproducible, and equal to the oracle everywhere (all rows, the full grad_value)."""
+    shapes = GEOMETRIES["600x800"]
+    c = _timed_path_case(8, shapes, 2.0, 0.0, seed=8)
+    got = _run_timed_path(c, shapes)
+    _check_against_oracle(c, got)
+    again = _run_timed_path(c, shapes)
+    for a, b in zip(got, again):
+        assert np.array_equal(a, b)
+
+
+def test_bf16_training_above_the_marks_bounds_keeps_working():
+    """at 720 x 1280 the owner-computes plan did not fit at the default near radius and the
+    head-major bf16 backward had no kernel to fall back to.  The library now plans at a smaller radius (near + far is a
+    partition at any radius) and TiedSampler asks the library before choosing the layout: forward + backward of the
+    tied sampler node at that geometry against the oracle."""
+    from snipper_amd import fused
+    shapes = [(90, 160), (45, 80), (23, 40)]
+    v, sh, lsi, loc, attn, go = grid_case(1, shapes, 8, 4, seed=13, spread_px=3.0, frac_far=0.05)
+    t = lambda a: torch.from_numpy(a).to(DEV)
+    S = v.shape[1]
+    value = t(v).to(torch.bfloat16).view(1, 1, S, 384).requires_grad_(True)
+    locs, probs = t(loc).requires_grad_(True), t(attn).requires_grad_(True)
+    sht = t(sh)
+    sht._snipper_host = shapes
+    out = fused.TiedSampler.apply(value, None, [[1.0]], locs, probs, sht, t(lsi), 8, 64, True, True)
+    go16 = t(go).to(torch.bfloat16)
+    gv, gl, ga = torch.autograd.grad(out, (value, locs, probs), go16)
+    assert _lib.last_variant() == "d48_owner_mfma", _lib.last_variant()
+    f64 = lambda a: a.astype(np.float64)
+    v64, go64 = f64(value.detach().float().view(1, S, 8, 48).cpu().numpy()), f64(go16.float().cpu().numpy())
+    ref_out = O.core_c_forward(v64, sh, lsi, f64(loc), f64(attn), threads=32)
+    ref = O.core_c_backward(v64, sh, lsi, f64(loc), f64(attn), go64, threads=32)
+    np.testing.assert_allclose(out.float().cpu().numpy(), ref_out, rtol=2 ** -8, atol=1e-3)
+    # the node returns the value gradient in the value's dtype (bf16): one rounding of the float32 sum
+    np.testing.assert_allclose(gv.float().view(1, S, 8, 48).cpu().numpy(), ref[0], rtol=2 ** -8, atol=1e-3)
+    s = float(np.abs(ref[1]).max())
+    np.testing.assert_allclose(gl.cpu().numpy() / s, ref[1] / s, rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(ga.cpu().numpy(), ref[2], rtol=1e-4, atol=1e-4)
+    # a geometry with NO owner plan at all (more than 2^24 positions is refused by the library): the layout query says no
+    cfg = fused._head_major_config()
+    assert fused._owner_backward_available(cfg, shapes, 1, S, 8, 48, 3, 4)
+    assert not fused._owner_backward_available(cfg, [(4100, 4100)], 1, 4100 * 4100, 8, 48, 1, 4)
+
+
+@pytest.mark.parametrize("name", ["enc_d48", "enc_t1_d48"])
+def test_module_goldens_under_bf16_autocast_take_the_head_major_path(golden_dir, name, monkeypatch):
+    """The reference module's own outputs / gradients (goldens g3 at D = 48) against ``MSDeformAttn`` run the way the
+    bench runs it -- bf16 autocast, so that fused.TiedSampler keeps the temporal mean in bf16, head-major -- at bf16
+    tolerance (relative L2: the golden is float32 arithmetic throughout)."""
+    from snipper_amd import fused
+    from snipper_amd.ms_deform_attn import MSDeformAttn
+    b = torch.load(os.path.join(golden_dir, f"g3_module_{name}.pt"))
+    cfg = b["cfg"]
+    mod = MSDeformAttn(cfg["d_model"], cfg["n_levels"], cfg["n_heads"], cfg["n_points"], cfg["n_frame"], cfg["mode"], False, False)
+    mod.load_state_dict(b["state_dict"], strict=True)
+    mod = mod.to(DEV)
+    mv = lambda x: x.to(DEV)
+    q, r, s = (mv(b[k]).clone().requires_grad_(True) for k in ("query", "ref", "src"))
+    shapes = mv(b["shapes"])
+    shapes._snipper_host = [tuple(x) for x in b["shapes"].tolist()]
+    calls = []
+    real = fused._head_major_config
+    monkeypatch.setattr(fused, "_head_major_config", lambda: (calls.append(1), real())[1])
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        res = mod(q, r, s, shapes, mv(b["lsi"]), mv(b["mask"]))
+    assert _lib.last_variant() == "d48_lp12" and calls, "the head-major bf16 path was not taken"
+    params = dict(mod.named_parameters())
+    grads = torch.autograd.grad(res.float(), [q, r, s] + list(params.values()), mv(b["grad_out"]))
+    assert _lib.last_variant() == "d48_owner_mfma", _lib.last_variant()
+    rel = lambda a, c: ((a.double().cpu() - c.double()).norm() / c.double().norm().clamp_min(1e-30)).item()
+    errs = {"out": rel(res, b["out"])}
+    for got, key in zip(grads[:3], ("grad_query", "grad_ref", "grad_src")):
+        errs[key] = rel(got, b[key])
+    for (k, _), g in zip(params.items(), grads[3:]):
+        errs[k] = rel(g, b["param_grads"][k])
+    print(name, {k: round(v, 4) for k, v in errs.items()})
+    assert errs["out"] < 1.5e-2, errs
+    bad = {k: v for k, v in errs.items() if v > 4e-2}
+    assert not bad, bad

@@ -13,6 +13,7 @@ from types import SimpleNamespace
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("SNIPPER_EXPERIMENTAL_GRAPHS", "1")   # this tool IS the experiment
 import bench                                            # noqa: E402
 from snipper_amd.backbone import graphed_segments       # noqa: E402
 from snipper_amd.model import build_model               # noqa: E402
