@@ -126,15 +126,38 @@ def decoder_side(name: str) -> bool:
     return name.startswith(("transformer.decoder.", "query_embed", "joint_embed", "transformer.reference_points"))
 
 
+def _encoder_layer_index(name: str):
+    """i for "transformer.encoder.layers.<i>....", else None."""
+    pre = "transformer.encoder.layers."
+    if not name.startswith(pre):
+        return None
+    head = name[len(pre):].split(".", 1)[0]
+    return int(head) if head.isdigit() else None
+
+
+def _encoder_upper_from(named_params) -> int:
+    """First layer of the encoder's UPPER half (its gradients are complete first: backward walks the layers downwards)."""
+    idx = [i for i in (_encoder_layer_index(n) for n, _ in named_params) if i is not None]
+    return (max(idx) + 1 + 1) // 2 if idx else 0
+
+
 def optimizer_groups(named_params):
     """The reference's three groups (main.py:201-221) over (name, parameter) pairs: (main, backbone, slow) lists.  Inside
-    `main` the decoder-side parameters come first (a stable partition): the flat layout then has them as one contiguous run,
-    which the gradient all-reduce launches as a stage of its own (grad_sync_stages)."""
+    `main` the parameters are listed in the order backward COMPLETES them, as a stable partition into three runs -- decoder
+    side, upper half of the encoder's layers, everything else -- so that each run is contiguous in the flat layout and the
+    gradient all-reduce can launch it as a stage of its own (grad_sync_stages).  The optimizer's state dict does not see
+    this order (FlatAdamW maps ids through reference_param_groups)."""
+    named_params = list(named_params)
+
     def named(pred):
         return [p for n, p in named_params if p.requires_grad and pred(n)]
     slow = lambda n: ("reference_points" in n or "sampling_offsets" in n) and "backbone" not in n
     is_main = lambda n: "backbone" not in n and not slow(n)
-    main = named(lambda n: is_main(n) and decoder_side(n)) + named(lambda n: is_main(n) and not decoder_side(n))
+    upper_from = _encoder_upper_from(named_params)
+    upper = lambda n: (_encoder_layer_index(n) or 0) >= upper_from and _encoder_layer_index(n) is not None and upper_from > 0
+    main = (named(lambda n: is_main(n) and decoder_side(n)) +
+            named(lambda n: is_main(n) and not decoder_side(n) and upper(n)) +
+            named(lambda n: is_main(n) and not decoder_side(n) and not upper(n)))
     return (main, named(lambda n: "backbone" in n), named(slow))
 
 
@@ -150,36 +173,67 @@ def reference_param_groups(named_params):
             [p for n, p in named_params if match(n, slow)])
 
 
-STAGE_NAMES = ["decoder + heads + queries", "encoder + input projections + slow group", "layer4", "layer3", "layer2"]
-
-
-def grad_sync_stages(model, non_backbone):
-    """Stages of the gradient all-reduce, in the order backward completes them: the decoder side of the `main` group
-    (complete when the first decoder layer's and the query embedding's gradients are), the rest of everything but the backbone
-    (complete when the 1x1 input projections' gradients are), then layer4, layer3, layer2 of the ResNet (each complete when
-    its FIRST block's gradients are: the blocks of a stage run backwards).  Each stage's slice is all-reduced over RCCL while
-    backward is still working on the next one.  (Round 3 had the first two as ONE 70 MB stage launched 80 % into backward:
-    grad_sync_trace.)  ``non_backbone`` = main + slow in flat-layout order."""
+def grad_sync_stages(model, non_backbone, names_out=None):
+    """Stages of the gradient all-reduce, in the order backward completes them (round 5: eight, none above 43 MB):
+      1. the decoder side of the `main` group (complete when the first decoder layer's and the query embedding's gradients
+         are: ~30 % into backward);
+      2. the upper half of the encoder's layers (complete when the LOWEST of them has run backwards);
+      3. the rest of everything but the backbone: lower encoder layers, input projections, embeddings, the slow group
+         (complete when the 1x1 input projections' gradients are);
+      4-6. layer4 of the ResNet block by block (its three bottlenecks run backwards 2, 1, 0), 7. layer3, 8. layer2 (each
+         complete when its FIRST block's gradients are: the blocks of a stage run backwards).
+    Each stage's slice is all-reduced over RCCL while backward is still working on the next one.  (Round 3 had 1-3 as ONE
+    70 MB stage launched 80 % into backward; round 4 had 2 + 3 as one 36 MB stage complete at 14.5 of 18 ms and layer4 as
+    one 60 MB stage at 15.5 ms: 129 of 171 MB entered the wire in the last 20 % of backward -- grad_sync_trace.)
+    ``non_backbone`` = main + slow in flat-layout order (optimizer_groups); ``names_out``: a list that receives one label
+    per stage."""
     names = {id(p): n for n, p in model.named_parameters()}
+    labels = []
     n_dec = 0
     while (n_dec < len(non_backbone) and decoder_side(names[id(non_backbone[n_dec])]) and
            "sampling_offsets" not in names[id(non_backbone[n_dec])] and "reference_points" not in names[id(non_backbone[n_dec])]):
         n_dec += 1
+    upper_from = _encoder_upper_from(list(model.named_parameters()))
+    n_up = n_dec
+    while (n_up < len(non_backbone) and upper_from > 0 and
+           (_encoder_layer_index(names[id(non_backbone[n_up])]) or -1) >= upper_from):
+        n_up += 1
     stages = []
+    rest_from = 0
     if 0 < n_dec < len(non_backbone):
         head = {id(p) for p in non_backbone[:n_dec]}
         dec0 = [p for n, p in model.named_parameters() if p.requires_grad and id(p) in head and
                 (n.startswith("transformer.decoder.layers.0.") or n.startswith("query_embed"))]
         stages.append((non_backbone[:n_dec], dec0))
-        stages.append((non_backbone[n_dec:], list(model.input_proj.parameters())))
-    else:
-        stages.append((non_backbone, list(model.input_proj.parameters())))
+        labels.append("decoder + heads + queries")
+        rest_from = n_dec
+        if n_dec < n_up < len(non_backbone):
+            run = non_backbone[n_dec:n_up]
+            trig = [p for p in run if _encoder_layer_index(names[id(p)]) == upper_from]
+            stages.append((run, trig))
+            labels.append(f"encoder layers {upper_from}..")
+            rest_from = n_up
+    stages.append((non_backbone[rest_from:], list(model.input_proj.parameters())))
+    labels.append("lower encoder layers + input projections + slow group" if rest_from > n_dec else
+                  ("encoder + input projections + slow group" if rest_from else "everything but the backbone"))
     body = model.backbone[0].body
     for name in ("layer4", "layer3", "layer2"):
         layer = getattr(body, name, None)
-        ps = [p for p in layer.parameters() if p.requires_grad] if layer is not None else []
+        if layer is None:
+            continue
+        blocks = list(layer) if name == "layer4" else None
+        if blocks and len(blocks) > 1 and all(any(p.requires_grad for p in b.parameters()) for b in blocks):
+            for bi in range(len(blocks) - 1, -1, -1):          # a stage per bottleneck, in backward order
+                ps = [p for p in blocks[bi].parameters() if p.requires_grad]
+                stages.append((ps, ps))
+                labels.append(f"{name}.{bi}")
+            continue
+        ps = [p for p in layer.parameters() if p.requires_grad]
         if ps:
             stages.append((ps, [p for p in layer[0].parameters() if p.requires_grad]))
+            labels.append(name)
+    if names_out is not None:
+        names_out[:] = labels
     return stages
 
 
@@ -200,6 +254,62 @@ def build_optimizer(named_params, capturable=False, flat=None):
     if os.environ.get("SNIPPER_OPT_PLAIN"):               # single-tensor reference implementation (debugging only)
         return torch.optim.AdamW(groups, lr=1e-4, weight_decay=1e-4, foreach=False, fused=False)
     return torch.optim.AdamW(groups, lr=1e-4, weight_decay=1e-4, capturable=capturable, fused=fused)
+
+
+def _ranges(cpus):
+    """[0,1,2,3,8,9] -> "0-3,8-9"."""
+    out, cpus = [], sorted(cpus)
+    i = 0
+    while i < len(cpus):
+        j = i
+        while j + 1 < len(cpus) and cpus[j + 1] == cpus[j] + 1:
+            j += 1
+        out.append(str(cpus[i]) if i == j else f"{cpus[i]}-{cpus[j]}")
+        i = j + 1
+    return ",".join(out)
+
+
+def _parse_cpulist(text):
+    cpus = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus += list(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def gpu_numa_node(index, sysfs="/sys"):
+    """NUMA node of GPU ``index`` (torch's device order) from its PCI address, or None when the platform does not say
+    (no sysfs entry, node -1, or a torch without the PCI fields)."""
+    try:
+        pr = torch.cuda.get_device_properties(index)
+        addr = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+        node = int(open(f"{sysfs}/bus/pci/devices/{addr}/numa_node").read().strip())
+        return node if node >= 0 else None
+    except Exception:
+        return None
+
+
+def pick_cpus(local_rank, n, allowed, node_of=gpu_numa_node, n_gpus=None, sysfs="/sys"):
+    """The block of ``n`` CPUs this rank's two issuing threads are pinned to -> (cpus, numa node or None, rule).
+    Rule "numa": CPUs of the NUMA node the rank's GPU hangs off (the reference starts 8 processes on a 2-socket host,
+    README.md:67; a step here is within 20 % of its host-issue floor, so submitting to a GPU across the socket link is
+    what would eat the scaling target), the k-th block of that node for the k-th GPU of that node.  Rule "block": the
+    round-4 rule (block = local rank over the allowed CPUs) when the platform does not expose the topology."""
+    node = node_of(local_rank)
+    if node is not None:
+        try:
+            node_cpus = [c for c in _parse_cpulist(open(f"{sysfs}/devices/system/node/node{node}/cpulist").read()) if c in set(allowed)]
+            n_gpus = torch.cuda.device_count() if n_gpus is None else n_gpus
+            k = sum(1 for j in range(min(local_rank, n_gpus)) if node_of(j) == node)      # GPUs of this node before mine
+            if len(node_cpus) >= n:
+                start = (k * n) % (len(node_cpus) - n + 1)
+                return node_cpus[start:start + n], node, "numa"
+        except Exception:
+            pass
+    start = (local_rank * n) % (len(allowed) - n + 1)
+    return allowed[start:start + n], node, "block"
 
 
 def msda_alg_bytes(d, bwd):
@@ -593,10 +703,11 @@ def main():
     # neighbouring cores 28.3-28.6 ms every time (12 alternating runs).  Each rank takes its own block of the CPUs it is
     # allowed to use; the affinity is restored before the CPU baseline.
     affinity0 = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else None
+    pin_info = {"cpus": None, "numa_node": None, "rule": "unpinned"}
     if affinity0 is not None and a.pin_cores > 0 and len(affinity0) >= 2 * a.pin_cores:
-        allowed = sorted(affinity0)
-        start = (local_rank * a.pin_cores) % (len(allowed) - a.pin_cores + 1)
-        os.sched_setaffinity(0, set(allowed[start:start + a.pin_cores]))
+        cpus, node, rule = pick_cpus(local_rank, a.pin_cores, sorted(affinity0))
+        os.sched_setaffinity(0, set(cpus))
+        pin_info = {"cpus": _ranges(cpus), "numa_node": node, "rule": rule}
     from snipper_amd import MultiScaleDeformableAttention as MSDA
     from snipper_amd import _lib
     from snipper_amd.model import build_model
@@ -646,7 +757,8 @@ def main():
         g_main, g_backbone, g_slow = optimizer_groups(list(model.named_parameters()))
         # flat layout [main | slow | backbone]: group by group so that the optimizer's flat leaves (flat_params.py) line up
         # with it, and in stages that backward completes one after the other (grad_sync_stages)
-        gsync = FlatGradSync(g_main + g_slow + g_backbone, stages=grad_sync_stages(model, g_main + g_slow))
+        stage_names = []
+        gsync = FlatGradSync(g_main + g_slow + g_backbone, stages=grad_sync_stages(model, g_main + g_slow, stage_names))
         gsync.broadcast_parameters(list(model.parameters()) + list(model.buffers()))
     if masters is None:
         if use_flat:
@@ -884,6 +996,8 @@ def main():
         every = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(every, mine)
         per_rank_ms = [round(float(x) / a.steps * 1e3, 3) for x in every]
+        per_rank_pin = [None] * world               # every rank's CPU set and its GPU's NUMA node
+        dist.all_gather_object(per_rank_pin, pin_info)
         t = mine.clone()
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
@@ -940,11 +1054,14 @@ def main():
         stage_mb = [round((st.hi_elem - st.lo_elem) * 4 / 1e6, 2) for st in gsync.stages]
         total_mb = gsync.flat.numel() * 4 / 1e6
         early_mb = sum(mb for i, mb in enumerate(stage_mb) if i in at and at[i] <= 0.9 * bwd_ms)
+        # what enters the wire in the last 20 % of backward (or only from sync(), after it): the exposed tail at N > 1
+        late20_mb = total_mb - sum(mb for i, mb in enumerate(stage_mb) if i in at and at[i] <= 0.8 * bwd_ms)
         sync_trace = {"backward_ms": round(bwd_ms, 3),
                       "stage_launch_ms_after_backward_start": [[i, round(at[i], 3)] for i in sorted(at)],
                       "stage_mbytes": stage_mb, "total_mbytes": round(total_mb, 2),
                       "fraction_of_bytes_launched_before_last_10pct_of_backward": round(early_mb / total_mb, 3),
-                      "stages": STAGE_NAMES[:len(gsync.stages)]}
+                      "mbytes_launched_in_last_20pct_of_backward_or_later": round(late20_mb, 2),
+                      "stages": stage_names[:len(gsync.stages)]}
         gsync.trace = None
         gsync.check_errors()
         if flatp is not None:
@@ -1032,7 +1149,8 @@ def main():
                        "weights": ("bf16 parameters + fp32 master weights" if masters is not None else
                                    "fp32 parameters" + (" under bf16 autocast" if amp else "")),
                        "host": (f"gc.collect every {a.gc_every} steps, automatic collector off" if a.gc_every else "default gc") +
-                               (f"; process pinned to {a.pin_cores} neighbouring CPUs" if a.pin_cores else ""),
+                               (f"; process pinned to {a.pin_cores} neighbouring CPUs: {pin_info['cpus']} "
+                                f"(rule {pin_info['rule']}, GPU's NUMA node {pin_info['numa_node']})" if a.pin_cores else ""),
                        "optimizer": ("global-norm clipping + AdamW on the flat parameter buffer in two launches "
                                      "(snipper_amd.flat_params.FlatAdamW, csrc/adamw_flat.cuh: the arithmetic of "
                                      "torch.optim.AdamW + clip_grad_norm_)" if own_opt is not None else
@@ -1050,6 +1168,7 @@ def main():
             line["distributed"] = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "rccl_version": rccl,
                                    "per_rank_ms_per_step": per_rank_ms,
                                    "per_rank_ms_per_step_min_max": [min(per_rank_ms), max(per_rank_ms)],
+                                   "per_rank_cpu_pinning": per_rank_pin,
                                    "grad_allreduce_mbytes_per_step": round(gsync.flat.numel() * 4 / 1e6, 2) if gsync is not None else None}
         if locality:
             line["locality"] = locality

@@ -25,7 +25,7 @@ def _bench():
     return mod
 
 
-ARGS = SimpleNamespace(hidden_dim=192, enc_layers=1, dec_layers=2, frames=2, future_frames=1,
+ARGS = SimpleNamespace(hidden_dim=192, enc_layers=2, dec_layers=2, frames=2, future_frames=1,
                        use_pytorch_deform=1, batch=1, height=64, width=96)
 
 
@@ -66,7 +66,7 @@ def _worker(rank, world, port, out_dir, mode):
         # AFTER the early launch -- exercises the late-arrival path of sync()
         trig = list(model.class_embed[0].parameters()) if mode == "flat_late" else list(model.input_proj.parameters())
         g_main, g_backbone, g_slow = b.optimizer_groups(list(model.named_parameters()))
-        if mode == "flat_stages":        # bench.py's default: transformer, layer4, layer3, layer2 launched from hooks
+        if mode == "flat_stages":        # bench.py's default: eight stages launched from hooks (bench.grad_sync_stages)
             gsync = FlatGradSync(g_main + g_slow + g_backbone, stages=b.grad_sync_stages(model, g_main + g_slow))
         else:
             gsync = FlatGradSync(g_main + g_slow + g_backbone, chunks=3, early=early, trigger=trig)   # bench.py's order
@@ -91,7 +91,8 @@ def _worker(rank, world, port, out_dir, mode):
         if gsync is not None:
             assert gsync._early_done, "the early slice must have been launched from the hook"
             if mode == "flat_stages":
-                assert all(st.launched for st in gsync.stages) and len(gsync.stages) == 5
+                # round 5: decoder side | upper encoder half | the rest | layer4.2 | layer4.1 | layer4.0 | layer3 | layer2
+                assert all(st.launched for st in gsync.stages) and len(gsync.stages) == 8
             gsync.sync()
         if it == 0:
             grads = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}

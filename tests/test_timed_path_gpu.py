@@ -109,7 +109,7 @@ def test_bf16_training_above_the_marks_bounds_keeps_working():
     v64, go64 = f64(value.detach().float().view(1, S, 8, 48).cpu().numpy()), f64(go16.float().cpu().numpy())
     ref_out = O.core_c_forward(v64, sh, lsi, f64(loc), f64(attn), threads=32)
     ref = O.core_c_backward(v64, sh, lsi, f64(loc), f64(attn), go64, threads=32)
-    np.testing.assert_allclose(out.float().cpu().numpy(), ref_out, rtol=2 ** -8, atol=1e-3)
+    np.testing.assert_allclose(out.detach().float().cpu().numpy(), ref_out, rtol=2 ** -8, atol=1e-3)
     # the node returns the value gradient in the value's dtype (bf16): one rounding of the float32 sum
     np.testing.assert_allclose(gv.float().view(1, S, 8, 48).cpu().numpy(), ref[0], rtol=2 ** -8, atol=1e-3)
     s = float(np.abs(ref[1]).max())
