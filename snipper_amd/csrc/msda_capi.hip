@@ -17,6 +17,7 @@
 #include "wgrad_bf16.cuh"
 #include "wres_gemm_bf16.cuh"
 #include "wgrad_ring_bf16.cuh"
+#include "wgrad_wide_bf16.cuh"
 #include "conv3x3_ring_bf16.cuh"
 #include "small_linear.cuh"
 #include "small_attention.cuh"
@@ -905,11 +906,52 @@ WgradPlan wgrad_plan(int M, int N, int Kc) {
 }
 }  // namespace
 
+// ---- 128 x 384 output tiles, one 8-wave workgroup per CU (csrc/wgrad_wide_bf16.cuh): long reductions whose output tiles well
+// in one of the two orientations (dW = G^T X, or dW^T = X^T G with the second pass storing the transpose)
+struct WidePlan { bool use, swapped; int rows_dim, cols_dim, tiles_n, tiles_kw, S, rows; };
+WidePlan wgrad_wide_plan(int M, int N, int Kc) {
+  WidePlan w{};
+  static const bool wide_on = [] { const char *e = getenv("SNIPPER_WGRAD_WIDE"); return !(e && e[0] == '0'); }();      // (A/B aid)
+  if (!wide_on || M < 32768) return w;
+  double best = 0.0, best_rows = 0.0;
+  for (int sw = 0; sw < 2; ++sw) {
+    const int r = sw ? Kc : N, c = sw ? N : Kc;
+    const int tn = (r + kWwTileN - 1) / kWwTileN, tk = (c + kWwTileK - 1) / kWwTileK;
+    const double eff = (double)r * c / ((double)tn * kWwTileN * tk * kWwTileK), row_util = (double)r / (tn * kWwTileN);
+    if (tn * tk > 32) continue;
+    // (a tie goes to the orientation whose padding sits on the wide side: padded columns cost no operand traffic)
+    if (eff > best + 1e-9 || (eff > best - 1e-9 && row_util > best_rows + 1e-9)) {
+      best = eff; best_rows = row_util;
+      w.swapped = sw != 0; w.rows_dim = r; w.cols_dim = c; w.tiles_n = tn; w.tiles_kw = tk;
+    }
+  }
+  if (best < 0.7) return w;
+  const int tiles = w.tiles_n * w.tiles_kw;
+  // Measured on MI355X (tools/run_wgrad_ablation.sh, kernel + second pass, us; profiles/r05_wgrad_wide.txt): 79 000 x 1024 x 384
+  // 82 against 102 and x 384 x 1024 99 against 105 for the 128 x 128-tile kernels, but 79 000 x 384 x 384 a tie (33.5 + 10.4
+  // against 35.3 + 8.6) and x 288 x 384 slower (50 against 43): with three wide tiles the grid is 240 workgroups of 192 KB of
+  // partial sums each (47 MB to write and re-read against 33), and the memory system's floor for that shape (121 MB from HBM
+  // + 121 MB from L2 = 25 us, reached with the MFMAs compiled out) leaves the 4-wave ring kernel little to lose.
+  static const int min_tiles = [] { const char *e = getenv("SNIPPER_WGRAD_WIDE_MIN_TILES"); return e ? atoi(e) : 6; }();
+  if (tiles < min_tiles) return w;
+  static const int wgs_env = [] { const char *e = getenv("SNIPPER_WGRAD_WIDE_WGS"); return e ? atoi(e) : 256; }();     // (measurement aid)
+  int s0 = std::max(8, wgs_env / tiles / 8 * 8);           // one workgroup per CU; a multiple of 8 row ranges (XCD placement)
+  const int rows = ((M + s0 - 1) / s0 + kWwRows - 1) / kWwRows * kWwRows;
+  w.rows = rows;
+  w.S = (M + rows - 1) / rows;
+  w.use = w.S >= 1 && rows >= 4 * kWwRows;
+  return w;
+}
+
 size_t snipper_wgrad_workspace_bytes(int M, int N, int Kc) {
   if (M <= 0 || N <= 0 || Kc <= 0) return 0;
   const WgradPlan p = wgrad_plan(M, N, Kc);
   // partial tiles are whole 128 x 128 accumulator images (wgrad_bf16.cuh), then the [S][N] partial column sums
-  return ((size_t)p.S * p.tiles_n * p.tiles_k * 16384 + (size_t)p.S * N) * sizeof(float);
+  size_t need = ((size_t)p.S * p.tiles_n * p.tiles_k * 16384 + (size_t)p.S * N) * sizeof(float);
+  const WidePlan w = wgrad_wide_plan(M, N, Kc);
+  if (w.use)
+    need = std::max(need, ((size_t)w.S * w.tiles_n * 3 * w.tiles_kw * 16384 + (size_t)w.S * std::max(N, Kc)) * sizeof(float));
+  return need;
 }
 
 int snipper_wgrad_bf16(void *stream, const uint16_t *G, long long ldg, const uint16_t *X, long long ldx,
@@ -920,6 +962,18 @@ int snipper_wgrad_bf16(void *stream, const uint16_t *G, long long ldg, const uin
     return SNIPPER_E_SHAPE;
   if (((uintptr_t)G | (uintptr_t)X | (uintptr_t)dW | (uintptr_t)workspace) & 15) return SNIPPER_E_SHAPE;
   if (workspace_bytes < snipper_wgrad_workspace_bytes(M, N, Kc)) return SNIPPER_E_SHAPE;
+  const WidePlan w = wgrad_wide_plan(M, N, Kc);
+  if (w.use) {
+    float *P = (float *)workspace, *Pb = db ? P + (size_t)w.S * w.tiles_n * 3 * w.tiles_kw * 16384 : nullptr;
+    const WgradWideArgs a{w.swapped ? X : G, w.swapped ? ldx : ldg, w.swapped ? G : X, w.swapped ? ldg : ldx, P, Pb, M,
+                          w.rows_dim, w.cols_dim, w.S, w.rows, w.tiles_n, w.tiles_kw, db ? (w.swapped ? 2 : 1) : 0, wres_debug()};
+    hipLaunchKernelGGL(wgrad_wide_kernel, dim3(w.tiles_n * w.tiles_kw * w.S), dim3(kWwThreads), 0, (hipStream_t)stream, a);
+    const WgradReduceArgs r{P, Pb, dW, lddw, db, scale, w.rows_dim, w.cols_dim, w.S, accumulate, w.tiles_n, 3 * w.tiles_kw,
+                            w.swapped ? 1 : 0, N};
+    const long long quads = (long long)w.tiles_n * 3 * w.tiles_kw * 4096;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((quads + 63) / 64)), dim3(256), 0, (hipStream_t)stream, r);
+    return launch_status();
+  }
   const WgradPlan p = wgrad_plan(M, N, Kc);
   float *P = (float *)workspace, *Pb = db ? P + (size_t)p.S * p.tiles_n * p.tiles_k * 16384 : nullptr;
   static const bool ring_on = [] { const char *e = getenv("SNIPPER_WGRAD_RING"); return !(e && e[0] == '0'); }();

@@ -217,6 +217,10 @@ struct WgradReduceArgs {
   float *db;                     // [N] or nullptr
   const float *scale;            // [N] or nullptr: per-output-row factor (the folded BatchNorm scale)
   int N, Kc, S, accumulate, tiles_n, tiles_k;
+  // transpose != 0 (csrc/wgrad_wide_bf16.cuh, "swapped" use): the partials hold dW^T -- N / Kc / tiles describe THAT matrix,
+  // element (n, kc) of it is stored at dW[kc][n], `scale` is indexed by kc.  bias_len: length of db and row stride of Pb
+  // (0 = N; the swapped use sums the columns of the other operand: Kc).
+  int transpose, bias_len;
 };
 
 // 256 threads = 64 quads x 4 slices of the S partials; the slices meet in LDS
@@ -248,7 +252,20 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgradReduceArgs g) {
     const int tn = t / g.tiles_k, tk = t - tn * g.tiles_k;
     const int n = tn * 128 + (wave & 1) * 64 + (ij >> 2) * 16 + (lane >> 4) * 4;
     const int kc = tk * 128 + (wave >> 1) * 64 + (ij & 3) * 16 + (lane & 15);
-    if (kc < g.Kc) {
+    if (g.transpose) {
+      if (kc < g.Kc && n < g.N) {                    // rows n .. n + 3 of dW^T are 4 consecutive elements of row kc of dW
+        float *dst = g.dW + (long long)kc * g.lddw + n;
+        const float sc = g.scale ? g.scale[kc] : 1.f;
+        if (n + 3 < g.N) {
+          gemm_f32x4 o = {sum.x * sc, sum.y * sc, sum.z * sc, sum.w * sc};
+          if (g.accumulate) o += *reinterpret_cast<const gemm_f32x4 *>(dst);
+          *reinterpret_cast<gemm_f32x4 *>(dst) = o;
+        } else {
+          const float v[4] = {sum.x, sum.y, sum.z, sum.w};
+          for (int r = 0; r < 4 && n + r < g.N; ++r) dst[r] = g.accumulate ? dst[r] + v[r] * sc : v[r] * sc;
+        }
+      }
+    } else if (kc < g.Kc) {
       const float v[4] = {sum.x, sum.y, sum.z, sum.w};
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -266,22 +283,23 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgradReduceArgs g) {
   // reduction the longest thing in the launch: 19.8 us of kernel time at 384 x 384, S = 57.)
   if (g.db && g.Pb) {
     const long long n = (long long)blockIdx.x * 64 + qi;
+    const int nb = g.bias_len > 0 ? g.bias_len : g.N;
     float bs = 0.f;
-    if (n < g.N) {
+    if (n < nb) {
       int s = slice;
       for (; s + 28 < g.S; s += 32) {
         float v[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = g.Pb[(long long)(s + 4 * i) * g.N + n];
+        for (int i = 0; i < 8; ++i) v[i] = g.Pb[(long long)(s + 4 * i) * nb + n];
 #pragma unroll
         for (int i = 0; i < 8; ++i) bs += v[i];
       }
-      for (; s < g.S; s += 4) bs += g.Pb[(long long)s * g.N + n];
+      for (; s < g.S; s += 4) bs += g.Pb[(long long)s * nb + n];
     }
     __syncthreads();                               // (the tile sums above have been read out of `red`)
     red[slice][qi].x = bs;
     __syncthreads();
-    if (slice == 0 && n < g.N) {
+    if (slice == 0 && n < nb) {
       const float tot = (red[0][qi].x + red[1][qi].x) + (red[2][qi].x + red[3][qi].x);
       g.db[n] = g.accumulate ? g.db[n] + tot : tot;
     }
