@@ -209,6 +209,23 @@ int snipper_stem_pool_bf16(void *stream, const uint16_t *y, const float *shift, 
 size_t snipper_colsum_workspace_bytes(int n_images, int rows_per_seg, int C);
 int snipper_colsum_segments_bf16(void *stream, const uint16_t *x, long long image_stride, int n_images,
                                  int rows_per_seg, int C, float *out, void *workspace, size_t workspace_bytes);
+/* The same over n_src (<= 8) source tensors of one shape, all read from element `elem_offset` on: the column sums of their
+ * SUM without forming it (a parameter used n times collects n gradients: level_embed behind the position encoding's six
+ * consumers, reference models/deformable_transformer.py:118-121).  workspace: n_src x snipper_colsum_workspace_bytes.  `srcs`
+ * is a HOST array of device pointers. */
+int snipper_colsum_segments_multi_bf16(void *stream, const uint16_t *const *srcs, int n_src, long long elem_offset,
+                                       long long image_stride, int n_images, int rows_per_seg, int C, float *out,
+                                       void *workspace, size_t workspace_bytes);
+
+/* out = bf16(sum_i float(srcs[i])) over `numel` (% 8 == 0) elements, n_src <= 8 bf16 tensors (16-byte aligned; `srcs` is a HOST
+ * array of device pointers): the gradient of a tensor with several consumers in one pass with float32 accumulation
+ * (autograd's own accumulation: n_src - 1 add launches, each partial sum rounded to bf16). */
+int snipper_sum_bf16(void *stream, const uint16_t *const *srcs, int n_src, uint16_t *out, long long numel);
+
+/* Stem input: float32 images [N, 3, H, W] (planar; W % 4 == 0) -> bf16 [N, H, W, 4] with a zero fourth channel, the layout
+ * snipper_stem7x7_bf16 reads. */
+int snipper_stem_pack_bf16(void *stream, const float *x, int N, int H, int W, uint16_t *out);
+
 
 /* 3x3 convolution, padding 1, stride 1 or 2, NHWC bf16, as an implicit GEMM on the same MFMA tiles:
  * Y[B,Ho,Wo,Cout] = act(conv(X[B,H,W,Cin], W[Cout,3,3,Cin]) + bias[Cout]), Ho = (H-1)/stride + 1 (same for Wo).
@@ -270,6 +287,13 @@ int snipper_temporal_mix_ex(void *stream, const void *in, int in_dtype, const un
 int snipper_msda_prologue_forward(void *stream, const void *off, long long off_ld, const void *logit, long long logit_ld,
                                   int dtype, const float *ref, const float *inv_w, const float *inv_h, long long rows,
                                   int M, int L, int P, float *loc, float *prob);
+/* The same with the offsets' BIAS added inside, in float32: off_bias [M*L*P*2] float32 or NULL; `off` then holds W q only
+ * (a projection launched without its bias).  Under bf16 autocast this keeps the bias grid of the reference initialisation
+ * (ms_deform_attn.py:82-90, up to P pixels) out of the projection's bf16 output; the adjoint is unchanged (the bias
+ * gradient is the column sum of grad_off either way). */
+int snipper_msda_prologue_forward_ex(void *stream, const void *off, long long off_ld, const void *logit, long long logit_ld,
+                                     int dtype, const float *off_bias, const float *ref, const float *inv_w,
+                                     const float *inv_h, long long rows, int M, int L, int P, float *loc, float *prob);
 int snipper_msda_prologue_backward(void *stream, const float *grad_loc, const float *grad_prob, const float *prob,
                                    const float *inv_w, const float *inv_h, long long rows, int M, int L, int P,
                                    void *grad_off, long long grad_off_ld, void *grad_logit, long long grad_logit_ld,

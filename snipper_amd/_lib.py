@@ -37,6 +37,8 @@ EXPORTS = {
                                  ctypes.c_longlong, c_int, c_void_p, c_int, c_int, c_int, c_int], c_int),
     "snipper_msda_prologue_forward": ([c_void_p, c_void_p, c_longlong, c_void_p, c_longlong, c_int, c_void_p, c_void_p,
                                        c_void_p, c_longlong, c_int, c_int, c_int, c_void_p, c_void_p], c_int),
+    "snipper_msda_prologue_forward_ex": ([c_void_p, c_void_p, c_longlong, c_void_p, c_longlong, c_int, c_void_p, c_void_p, c_void_p,
+                                          c_void_p, c_longlong, c_int, c_int, c_int, c_void_p, c_void_p], c_int),
     "snipper_msda_prologue_backward": ([c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong,
                                         c_int, c_int, c_int, c_void_p, c_longlong, c_void_p, c_longlong, c_int,
                                         c_void_p], c_int),
@@ -60,6 +62,10 @@ EXPORTS = {
     "snipper_colsum_workspace_bytes": ([c_int] * 3, c_size_t),
     "snipper_colsum_segments_bf16": ([c_void_p, c_void_p, c_longlong, c_int, c_int, c_int, c_void_p, c_void_p,
                                       c_size_t], c_int),
+    "snipper_colsum_segments_multi_bf16": ([c_void_p, c_void_p, c_int, c_longlong, c_longlong, c_int, c_int, c_int, c_void_p, c_void_p,
+                                            c_size_t], c_int),
+    "snipper_sum_bf16": ([c_void_p, c_void_p, c_int, c_void_p, c_longlong], c_int),
+    "snipper_stem_pack_bf16": ([c_void_p, c_void_p, c_int, c_int, c_int, c_void_p], c_int),
     "snipper_conv3x3_bf16": ([c_void_p] * 5 + [c_int] * 7 + [c_void_p, c_int], c_int),
     "snipper_stem7x7_bf16": ([c_void_p] * 4 + [c_int] * 3, c_int),
     "snipper_conv3x3_dgrad_s2_bf16": ([c_void_p] * 4 + [c_int] * 5 + [c_void_p], c_int),

@@ -220,6 +220,7 @@ class _Conv3x3BN(torch.autograd.Function):
         if w_eff is None or not w_eff.is_contiguous(memory_format=torch.channels_last):
             w_eff = (weight.float() * scale.view(-1, 1, 1, 1)).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
         y = conv3x3_bf16(x, w_eff, shift, stride, relu)
+        ctx.w_t = shadow.lookup_t(weight) if shadow.lookup(weight, scale) is w_eff else None      # (this step's, if kept)
         ctx.stride, ctx.relu, ctx.wdtype, ctx.gate_input = stride, relu and not pregated, weight.dtype, gate_input
         ctx.save_for_backward(x, w_eff, scale, y if ctx.relu else None)
         return y
@@ -250,11 +251,11 @@ class _Conv3x3BN(torch.autograd.Function):
         if own_dgrad and ctx.stride == 1:
             # stride 1: the data gradient is the same convolution with the taps reversed and the channel roles swapped
             # (the kernel reverses the taps itself; only the channel axes are swapped here)
-            w_t = w_eff.transpose(0, 1).contiguous(memory_format=torch.channels_last)
+            w_t = ctx.w_t if ctx.w_t is not None else w_eff.transpose(0, 1).contiguous(memory_format=torch.channels_last)
             dx = conv3x3_bf16(g, w_t, None, 1, False, gate, flip_taps=True)
         elif own_dgrad:
             # stride 2: four parity classes of the input pixel, each with its 1 / 2 / 2 / 4 taps (csrc/gemm_bf16.cuh)
-            dx = conv3x3_dgrad_s2_bf16(g, w_eff.transpose(0, 1), x.shape[-2:], gate)
+            dx = conv3x3_dgrad_s2_bf16(g, ctx.w_t if ctx.w_t is not None else w_eff.transpose(0, 1), x.shape[-2:], gate)
         return dx, dw, None, None, None, None, None, None
 
 
@@ -395,8 +396,16 @@ class ResNet50Body(nn.Module):
                 y = None
                 if cached[2] is not None and x.shape[1] == 3:
                     n, _, h, wd = x.shape
-                    x4 = torch.zeros((n, h, wd, 4), dtype=torch.bfloat16, device=x.device)     # channels padded 3 -> 4
-                    x4[..., :3] = x.permute(0, 2, 3, 1)
+                    x4 = None
+                    if x.dtype == torch.float32 and x.is_contiguous() and wd % 4 == 0 and x.data_ptr() % 16 == 0:
+                        # planar float32 images (what the data loader delivers) -> bf16 [n, h, w, 4] in one pass
+                        x4 = torch.empty((n, h, wd, 4), dtype=torch.bfloat16, device=x.device)
+                        with _lib.device_guard(x.device):
+                            rc = _lib.load().snipper_stem_pack_bf16(_lib.raw_stream(x.device), x.data_ptr(), n, h, wd, x4.data_ptr())
+                        _lib.check(rc, "snipper_stem_pack_bf16")
+                    if x4 is None:
+                        x4 = torch.zeros((n, h, wd, 4), dtype=torch.bfloat16, device=x.device)     # channels padded 3 -> 4
+                        x4[..., :3] = x.permute(0, 2, 3, 1)
                     y = torch.empty((n, 64, (h - 1) // 2 + 1, (wd - 1) // 2 + 1), dtype=torch.bfloat16, device=x.device,
                                     memory_format=torch.channels_last)
                     from . import dense as _dense
@@ -407,7 +416,7 @@ class ResNet50Body(nn.Module):
                                                               y.data_ptr(), n, h, wd)
                     _lib.check(rc, "snipper_stem7x7_bf16")
                 if y is None:
-                    y = F.conv2d(x.to(torch.bfloat16), cached[1], None, conv.stride, conv.padding, conv.dilation,
+                    y = F.conv2d(x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last), cached[1], None, conv.stride, conv.padding, conv.dilation,
                                  conv.groups)
                 if y.dtype == torch.bfloat16 and y.is_contiguous(memory_format=torch.channels_last):
                     n, c, h, wd = y.shape
@@ -419,7 +428,7 @@ class ResNet50Body(nn.Module):
                                                                 n, h, wd, c, out.data_ptr())
                     _lib.check(rc, "snipper_stem_pool_bf16")
                     return out
-        x = conv_frozen_bn(x, conv, bn, relu=True)
+        x = conv_frozen_bn(x.contiguous(memory_format=torch.channels_last), conv, bn, relu=True)
         return F.max_pool2d(x, 3, stride=2, padding=1)
 
     @staticmethod
@@ -438,7 +447,10 @@ class ResNet50Body(nn.Module):
         return x
 
     def forward(self, x) -> Dict[str, torch.Tensor]:
-        x = x.contiguous(memory_format=torch.channels_last)     # NHWC end to end: no layout shuffles around MIOpen
+        # NHWC end to end: no layout shuffles around MIOpen.  (Planar float32 3-channel images are left as they are: the frozen
+        # stem packs them into its own [n, h, w, 4] bf16 layout in one pass, snipper_stem_pack_bf16.)
+        if not (x.is_cuda and x.dim() == 4 and x.shape[1] == 3 and x.dtype == torch.float32 and x.is_contiguous()):
+            x = x.contiguous(memory_format=torch.channels_last)
         x = self._stem(x)
         if self._stem_frozen is None:                             # walked once (Backbone.__init__ freezes before use)
             self._stem_frozen = not any(p.requires_grad for p in self.layer1.parameters())

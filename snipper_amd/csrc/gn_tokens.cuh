@@ -217,6 +217,31 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const uint16_t *x, 
   }
 }
 
+// the same over SEVERAL source tensors of one shape (blockIdx.y = source * n_images + image): the column sums of a sum of
+// tensors without forming the sum -- level_embed's gradient from the six gradients of its six uses (fused.LevelPosTokens)
+struct ColsumSrcs { const uint16_t *p[8]; };
+__global__ __launch_bounds__(256) void colsum_partial_multi_kernel(ColsumSrcs srcs, int n_images, long long image_stride,
+                                                                   int rows_per_seg, int C, int nblk, int rpp, float *part) {
+  __shared__ float lds[256 * 4];
+  const int chunks = C / 4, chunk = threadIdx.x % chunks, rsub = threadIdx.x / chunks;
+  const int src = blockIdx.y / n_images, img = blockIdx.y - src * n_images;
+  const uint16_t *xi = srcs.p[src] + (long long)img * image_stride + chunk * 4;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int r = blockIdx.x * rpp + rsub; r < rows_per_seg; r += nblk * rpp) {
+    const float4 v = ln_load4(xi, 1, (long long)r * C);
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  *reinterpret_cast<float4 *>(lds + threadIdx.x * 4) = s;
+  __syncthreads();
+  if (rsub == 0) {
+    for (int r = 1; r < rpp; ++r) {
+      const float4 t = *reinterpret_cast<const float4 *>(lds + (r * chunks + chunk) * 4);
+      s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+    }
+    *reinterpret_cast<float4 *>(part + ((long long)blockIdx.y * nblk + blockIdx.x) * C + chunk * 4) = s;
+  }
+}
+
 __global__ __launch_bounds__(256) void colsum_final_kernel(const float *part, int nparts, int C, float *out) {
   __shared__ float red[16][17];
   const int ci = threadIdx.x & 15, slice = threadIdx.x >> 4;

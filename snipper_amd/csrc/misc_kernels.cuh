@@ -1,0 +1,57 @@
+// misc_kernels.cuh -- small bandwidth-bound helpers that replace chains of ATen launches around the hot path (gfx950).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "msda_common.cuh"
+
+namespace snipper {
+
+constexpr int kSumMaxSrc = 8;
+struct SumSrcs { const uint16_t *p[kSumMaxSrc]; int n; };
+
+// out = bf16(sum_i float(src_i)), 8 elements per thread (16-byte accesses).  The gradient of a tensor with several
+// consumers (the encoder memory's bf16 twin: six decoder layers' value projections, reference
+// models/deformable_transformer.py:290-295) arrives as one tensor per consumer; autograd adds them pairwise -- n - 1
+// launches of 3 x 60 MB each, every partial sum rounded to bf16.  Here: one pass, float32 accumulation, one rounding.
+__global__ __launch_bounds__(256) void sum_bf16_kernel(SumSrcs s, uint16_t *__restrict__ out, long long n8) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n8) return;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int k = 0; k < s.n; ++k) {
+    const uint4 v = reinterpret_cast<const uint4 *>(s.p[k])[i];
+    const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      acc[2 * c] += __uint_as_float(w[c] << 16);
+      acc[2 * c + 1] += __uint_as_float(w[c] & 0xffff0000u);
+    }
+  }
+  uint4 o;
+  o.x = (unsigned)f32_to_bf16_bits(acc[0]) | ((unsigned)f32_to_bf16_bits(acc[1]) << 16);
+  o.y = (unsigned)f32_to_bf16_bits(acc[2]) | ((unsigned)f32_to_bf16_bits(acc[3]) << 16);
+  o.z = (unsigned)f32_to_bf16_bits(acc[4]) | ((unsigned)f32_to_bf16_bits(acc[5]) << 16);
+  o.w = (unsigned)f32_to_bf16_bits(acc[6]) | ((unsigned)f32_to_bf16_bits(acc[7]) << 16);
+  reinterpret_cast<uint4 *>(out)[i] = o;
+}
+
+// Frozen 7x7 stem's input: float32 images [N, 3, H, W] (planar, as the data loader delivers them: values in [0, 1],
+// datasets/transforms.py:143) -> bf16 [N, H, W, 4] with a zero fourth channel, the layout csrc/gemm_bf16.cuh's stem kernel
+// reads (a tap row of a pixel pair = one aligned 16-byte piece).  Replaces a channels_last copy, a fill and a strided copy.
+// One thread = 4 consecutive pixels of a row (W % 4 == 0): three 16-byte loads, two 16-byte stores.
+__global__ __launch_bounds__(256) void stem_pack_kernel(const float *__restrict__ x, long long plane, long long quads,
+                                                        uint16_t *__restrict__ out) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;      // quad index over N * H * W / 4
+  if (i >= quads) return;
+  const long long per_image = plane / 4, n = i / per_image, q = i - n * per_image;
+  const float *base = x + n * 3 * plane + q * 4;
+  const float4 r = *reinterpret_cast<const float4 *>(base), g = *reinterpret_cast<const float4 *>(base + plane),
+               b = *reinterpret_cast<const float4 *>(base + 2 * plane);
+  auto px = [](float a, float c) { return (unsigned)f32_to_bf16_bits(a) | ((unsigned)f32_to_bf16_bits(c) << 16); };
+  uint4 o0, o1;
+  o0.x = px(r.x, g.x); o0.y = px(b.x, 0.f); o0.z = px(r.y, g.y); o0.w = px(b.y, 0.f);
+  o1.x = px(r.z, g.z); o1.y = px(b.z, 0.f); o1.z = px(r.w, g.w); o1.w = px(b.w, 0.f);
+  uint4 *dst = reinterpret_cast<uint4 *>(out) + i * 2;
+  dst[0] = o0; dst[1] = o1;
+}
+
+}  // namespace snipper

@@ -18,6 +18,7 @@
 #include "wres_gemm_bf16.cuh"
 #include "wgrad_ring_bf16.cuh"
 #include "wgrad_wide_bf16.cuh"
+#include "misc_kernels.cuh"
 #include "conv3x3_ring_bf16.cuh"
 #include "small_linear.cuh"
 #include "small_attention.cuh"
@@ -1178,6 +1179,50 @@ int snipper_colsum_segments_bf16(void *stream, const uint16_t *x, long long imag
   return launch_status();
 }
 
+int snipper_colsum_segments_multi_bf16(void *stream, const uint16_t *const *srcs, int n_src, long long elem_offset,
+                                       long long image_stride, int n_images, int rows_per_seg, int C, float *out,
+                                       void *workspace, size_t workspace_bytes) {
+  if (!srcs || !out || !workspace) return SNIPPER_E_NULL;
+  if (n_src <= 0 || n_src > 8 || n_images <= 0 || rows_per_seg <= 0 || C <= 0 || C % 4 || C / 4 > 256 || elem_offset < 0 ||
+      elem_offset % 4 || image_stride < (long long)rows_per_seg * C || image_stride % 4 ||
+      workspace_bytes < (size_t)n_src * snipper_colsum_workspace_bytes(n_images, rows_per_seg, C))
+    return SNIPPER_E_SHAPE;
+  ColsumSrcs a{};
+  for (int i = 0; i < n_src; ++i) {
+    if (!srcs[i] || ((uintptr_t)srcs[i] % 8)) return srcs[i] ? SNIPPER_E_SHAPE : SNIPPER_E_NULL;
+    a.p[i] = srcs[i] + elem_offset;
+  }
+  const GnPlan p = gn_plan(rows_per_seg, C);
+  hipLaunchKernelGGL(colsum_partial_multi_kernel, dim3(p.nblk, n_images * n_src), dim3((C / 4) * p.rpp), 0, (hipStream_t)stream, a,
+                     n_images, image_stride, rows_per_seg, C, p.nblk, p.rpp, (float *)workspace);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 15) / 16), dim3(256), 0, (hipStream_t)stream,
+                     (const float *)workspace, n_src * n_images * p.nblk, C, out);
+  return launch_status();
+}
+
+int snipper_sum_bf16(void *stream, const uint16_t *const *srcs, int n_src, uint16_t *out, long long numel) {
+  if (!srcs || !out) return SNIPPER_E_NULL;
+  if (n_src <= 0 || n_src > kSumMaxSrc || numel <= 0 || numel % 8 || ((uintptr_t)out % 16)) return SNIPPER_E_SHAPE;
+  SumSrcs a{};
+  a.n = n_src;
+  for (int i = 0; i < n_src; ++i) {
+    if (!srcs[i] || ((uintptr_t)srcs[i] % 16)) return srcs[i] ? SNIPPER_E_SHAPE : SNIPPER_E_NULL;
+    a.p[i] = srcs[i];
+  }
+  const long long n8 = numel / 8;
+  hipLaunchKernelGGL(sum_bf16_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, out, n8);
+  return launch_status();
+}
+
+int snipper_stem_pack_bf16(void *stream, const float *x, int N, int H, int W, uint16_t *out) {
+  if (!x || !out) return SNIPPER_E_NULL;
+  if (N <= 0 || H <= 0 || W <= 0 || W % 4 || ((uintptr_t)x % 16) || ((uintptr_t)out % 16) || (long long)N * H * W >= (1LL << 31))
+    return SNIPPER_E_SHAPE;
+  const long long plane = (long long)H * W, quads = (long long)N * plane / 4;
+  hipLaunchKernelGGL(stem_pack_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, plane, quads, out);
+  return launch_status();
+}
+
 namespace {
 // 128 x 64 tiles when the 128 x 128 grid would leave the chip under-filled (or Cout has a half-empty last tile)
 inline bool conv_use_n64(long long M, int Cout) {
@@ -1336,6 +1381,13 @@ inline bool prologue_vec_ok(const void *a, long long a_ld, const void *b, long l
 int snipper_msda_prologue_forward(void *stream, const void *off, long long off_ld, const void *logit, long long logit_ld,
                                   int dtype, const float *ref, const float *inv_w, const float *inv_h, long long rows,
                                   int M, int L, int P, float *loc, float *prob) {
+  return snipper_msda_prologue_forward_ex(stream, off, off_ld, logit, logit_ld, dtype, nullptr, ref, inv_w, inv_h, rows, M, L, P,
+                                          loc, prob);
+}
+
+int snipper_msda_prologue_forward_ex(void *stream, const void *off, long long off_ld, const void *logit, long long logit_ld,
+                                     int dtype, const float *off_bias, const float *ref, const float *inv_w,
+                                     const float *inv_h, long long rows, int M, int L, int P, float *loc, float *prob) {
   if (!off || !logit || !ref || !loc || !prob) return SNIPPER_E_NULL;
   if (rows <= 0 || M <= 0 || L <= 0 || P <= 0 || L > kPrologueMaxL || L * P > kPrologueMaxLP) return SNIPPER_E_SHAPE;
   if (off_ld < (long long)M * L * P * 2 || logit_ld < (long long)M * L * P) return SNIPPER_E_SHAPE;
@@ -1346,7 +1398,7 @@ int snipper_msda_prologue_forward(void *stream, const void *off, long long off_l
                    ((uintptr_t)prob % 16) == 0;
 #define SNIPPER_PROLOGUE_FWD(T, V, CL, CP)                                                                      \
   hipLaunchKernelGGL((prologue_fwd_kernel<T, V, CL, CP>), grid, dim3(256), 0, (hipStream_t)stream, (const T *)off, \
-                     off_ld, (const T *)logit, logit_ld, ref, sc, rows, M, L, P, loc, prob)
+                     off_ld, (const T *)logit, logit_ld, ref, sc, rows, M, L, P, loc, prob, off_bias)
 #define SNIPPER_PROLOGUE_FWD_T(T)                                            \
   do {                                                                       \
     if (vec && L == 3 && P == 4) SNIPPER_PROLOGUE_FWD(T, true, 3, 4);        \

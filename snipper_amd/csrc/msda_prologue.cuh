@@ -158,7 +158,15 @@ __global__ __launch_bounds__(256) void prologue_fwd_kernel(const TI *__restrict_
                                                            const TI *__restrict__ logit, long long logit_ld,
                                                            const float *__restrict__ ref, LevelScale sc,
                                                            long long rows, int M, int L_rt, int P_rt,
-                                                           float *__restrict__ loc, float *__restrict__ prob) {
+                                                           float *__restrict__ loc, float *__restrict__ prob,
+                                                           const float *__restrict__ off_bias) {
+  // off_bias [M * L * P * 2] float32 or nullptr: added to the offsets HERE, in float32.  The offsets arrive as the bf16
+  // output of a projection under autocast; their bias -- the reference initialisation's grid of 1 .. P pixels along the head's
+  // direction (ms_deform_attn.py:82-90) -- is the large part of them, and rounding (W q + b) to bf16 moves a sampling
+  // location by up to 2^-9 of 4 px.  The gradient with respect to a location is piecewise constant per pixel cell
+  // (ms_deform_im2col_cuda.cuh:87-159), so that displacement puts a few per cent of the samples into the neighbouring cell:
+  // 6-9 % relative error in the offset projection's gradients against 1 % when the projection's GEMM carries no bias and the
+  // bias is added here (tests/test_timed_path_gpu.py).
   const long long row = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (row >= rows) return;
   const int L = CL > 0 ? CL : L_rt, P = CL > 0 ? CP : P_rt;
@@ -182,6 +190,12 @@ __global__ __launch_bounds__(256) void prologue_fwd_kernel(const TI *__restrict_
 #pragma unroll
     for (int i = 0; i < kPrologueMaxLP; ++i)
       if (i < LP) { z[i] = ld_scalar<TI>(g + i); ov[2 * i] = ld_scalar<TI>(o + 2 * i); ov[2 * i + 1] = ld_scalar<TI>(o + 2 * i + 1); }
+  }
+  if (off_bias) {
+    const float *ob = off_bias + (long long)m * LP * 2;
+#pragma unroll
+    for (int i = 0; i < 2 * kPrologueMaxLP; ++i)
+      if (i < 2 * LP) ov[i] += ob[i];
   }
   float zmax = -INFINITY;
 #pragma unroll

@@ -303,6 +303,7 @@ class DeformableTransformerEncoderLayer(nn.Module, _FFNMixin):
 
 
 import os as _os
+_DEC_PREMIX = _os.environ.get("SNIPPER_DEC_PREMIX", "1") != "0"    # (A/B aid: 0 = temporal mean per decoder layer, as round 4)
 _LN_LAZY = _os.environ.get("SNIPPER_LN_LAZY", "1") != "0"      # (A/B aid: 0 = materialise the float32 residual stream)
 
 
@@ -346,6 +347,15 @@ class DeformableTransformerEncoder(nn.Module):
         already has them (the token-row input projections write them); otherwise they are made here."""
         ref = self.get_reference_points(spatial_shapes, valid_ratios, device=src.device)
         ref = ref.unsqueeze(1).expand(-1, n_frame, -1, -1, -1)  # same grid for every frame
+        if getattr(valid_ratios, "_snipper_ones", False) and not torch.is_inference_mode_enabled():
+            # a constant of the shapes (no padding): keep the expanded grid materialised -- every layer's prologue kernel wants
+            # it contiguous, and expanding + copying [b, T, S, L, 2] once per layer and step was six 6-us copies
+            hw = getattr(spatial_shapes, "_snipper_host", None) or spatial_shapes.tolist()
+            key = ("ref_frames", valid_ratios.shape[0], n_frame, tuple(tuple(x) for x in hw), str(src.device))
+            got = _LEVEL_CACHE.get(key)
+            if got is None:
+                got = _LEVEL_CACHE[key] = ref.contiguous()
+            ref = got
         out = src
         if pos is not None and self.fused_ok(src):
             if twins is not None:
@@ -353,8 +363,11 @@ class DeformableTransformerEncoder(nn.Module):
             else:
                 pos16 = pos.to(torch.bfloat16)                  # gradients of the 6 uses accumulate in bf16
                 out16, q16 = out.to(torch.bfloat16), (out + pos).to(torch.bfloat16)
+            # (pos16 may be a list: one alias per layer that adds it, see DeformableTransformer.forward_from_features)
+            pos_l = list(pos16) if isinstance(pos16, (list, tuple)) else None
             for i, layer in enumerate(self.layers):
-                out, out16, q16 = layer.forward_fused(out, out16, q16, pos16, ref, spatial_shapes, level_start_index,
+                p16 = pos16 if pos_l is None else pos_l[min(i, len(pos_l) - 1)]
+                out, out16, q16 = layer.forward_fused(out, out16, q16, p16, ref, spatial_shapes, level_start_index,
                                                       padding_mask, last=i + 1 == len(self.layers))
             out._snipper_bf16 = out16                           # big_linear picks the bf16 twin up (decoder memory)
             return out
@@ -410,7 +423,8 @@ class DeformableTransformerDecoderLayer(nn.Module, _FFNMixin):
         # When the encoder memory carries the bf16 twin its last kernel wrote (big_linear picks it up for the value
         # projection, the only large GEMM here), the module can stay outside autocast: its query-side Linears see
         # 480 rows, where autocast only adds casts of inputs, weights, biases and their gradients (~18 per layer).
-        if amp_dtype is None or getattr(src, "_snipper_bf16", None) is not None:
+        if (amp_dtype is None or getattr(src, "_snipper_bf16", None) is not None or
+                getattr(src, "_snipper_premixed", None) is not None):
             return self.cross_attn(query, reference_points, src, *rest)
         with torch.autocast("cuda", dtype=amp_dtype):
             return self.cross_attn(query, reference_points, src, *rest)
@@ -458,10 +472,47 @@ class DeformableTransformerDecoder(nn.Module):
         out = query_obj
         inter, inter_ref, inter_att = [], [], []
         ref_in = None
+        # the memory's bf16 twin feeds every layer's value projection: one alias per layer, so that the six gradients come
+        # back on six edges and are summed in ONE pass (fused.FanOut) instead of five pairwise bf16 adds of [b, T, S, C]
+        srcs = [src] * len(self.layers)
+        twin = getattr(src, "_snipper_bf16", None)
+        if (twin is not None and twin.is_cuda and twin.dtype == torch.bfloat16 and twin.requires_grad and
+                torch.is_grad_enabled() and len(self.layers) > 1):
+            from .fused import FanOut, TemporalMix
+            from .ms_deform_attn import frame_neighbours
+            # Round 5: the memory path ONCE per step instead of once per layer.  Every layer's cross attention samples the
+            # temporal mean of the padding-masked, PROJECTED memory frames (ms_deform_attn.py:114-118, 130-226 with tied
+            # Linears); mask fill, mean and projection are linear, so with no padding anywhere
+            #     mix(W x + b) = W mix(x) + b        (the rows of the mix sum to 1)
+            # and the mean of the MEMORY is the same for all layers: one mix launch here instead of one per layer (six 35-us
+            # passes of 60 -> 121 MB), each layer projects the mean and samples its bf16 projection directly.  Taken when no
+            # frame is padded (known on the host), there are no forecast frames (their query frames would add rows) and every
+            # layer's Linears are tied; anything else keeps the per-layer evaluation.
+            t_q, t_v = query_obj.shape[1], twin.shape[1]
+            att0 = self.layers[0].cross_attn
+            from .dense import BIG_LINEAR_MIN_ROWS
+            premix = (_DEC_PREMIX and is_no_padding(src_padding_mask) and t_q == t_v and twin.dim() == 4 and
+                      twin.numel() // twin.shape[-1] >= BIG_LINEAR_MIN_ROWS and         # (the bf16 GEMM path projects the mean)
+                      all(getattr(l.cross_attn, "weights_are_tied", lambda: False)() and l.cross_attn.n_frame == t_v and
+                          not l.cross_attn.use_pytroch_deform and l.cross_attn.d_model // l.cross_attn.n_heads == 48
+                          for l in self.layers))
+            fan_src = twin
+            if premix:
+                groups = [frame_neighbours(t1, att0.n_frame, t_v) for t1 in range(t_q)]
+                mix = [[(1.0 / len(g)) if t2 in g else 0.0 for t2 in range(t_v)] for g in groups]
+                fan_src = TemporalMix.apply(twin, None, mix, torch.bfloat16)
+            srcs = []
+            for alias in FanOut.apply(fan_src, len(self.layers)):
+                s_l = src.view_as(src)
+                if premix:
+                    s_l._snipper_premixed = alias
+                else:
+                    s_l._snipper_bf16 = alias
+                srcs.append(s_l)
         for lid, layer in enumerate(self.layers):
             if ref_in is None:
                 ref_in = reference_points[:, :, :, None, :] * src_valid_ratios[:, None, None, :, :]
-            out, atten_data = layer(out, query_pos, ref_in, src, src_spatial_shapes,
+            out, atten_data = layer(out, query_pos, ref_in, srcs[lid], src_spatial_shapes,
                                     src_level_start_index, src_padding_mask, cross_amp_dtype=amp_dtype)
             ref_in = None
             if self.root_embed is not None:   # iterative refinement of the reference points (:329-333)
@@ -573,7 +624,12 @@ class DeformableTransformer(nn.Module):
         hw = [tuple(int(v) for v in f.shape[-2:]) for f in feats]
         sizes = [h * w for h, w in hw]
         # the fused encoder only ever reads the position encoding in bf16 (query = bf16(src + pos))
-        pos16 = LevelPosTokens.apply(self.level_embed[:len(pos_tokens)], *pos_tokens)
+        # one alias of the bf16 position encoding per consumer (the projections' query + every encoder layer but the last):
+        # their gradients then reach level_embed as column sums, not through n - 1 full-size adds (fused.LevelPosTokens)
+        n_uses = max(1, len(self.encoder.layers))
+        pos16_all = LevelPosTokens.apply(self.level_embed[:len(pos_tokens)], n_uses, *pos_tokens)
+        pos16_all = list(pos16_all) if isinstance(pos16_all, (tuple, list)) else [pos16_all]
+        pos16 = pos16_all[0]
         pos = pos16
         if all(is_no_padding(m) for m in masks) and not torch.is_inference_mode_enabled():
             # no padding anywhere (known on the host): the flattened mask and the valid ratios are constants of the shapes
@@ -585,6 +641,7 @@ class DeformableTransformer(nn.Module):
                 ones._snipper_ones = True
                 got = _LEVEL_CACHE[key] = (flat, ones)
             mask, valid_ratios = got[0].expand(-1, -1, -1, c), got[1]
+            mask._snipper_all_false = True                    # (known on the host: the decoder's premixed memory path asks)
         else:
             mask = torch.cat([m.reshape(b, T, -1) for m in masks], 2)[..., None].expand(-1, -1, -1, c)
             ratios = []
@@ -597,7 +654,7 @@ class DeformableTransformer(nn.Module):
         gn = input_proj[0][1]
         src, src16, q16 = InputProjTokens.apply(T, gn.num_groups, gn.eps, pos16, (True, True), *feats, *params)
         memory = self.encoder(src, spatial_shapes, level_start_index, valid_ratios, pos, mask, self.n_frame,
-                              twins=(src16, q16, pos16))
+                              twins=(src16, q16, pos16_all[1:] if len(pos16_all) > 1 else pos16))
         return self._decode(memory, hw, sizes, spatial_shapes, level_start_index, valid_ratios, mask, query_embed)
 
     def _decode(self, memory, hw, sizes, spatial_shapes, level_start_index, valid_ratios, mask, query_embed):

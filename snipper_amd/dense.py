@@ -755,10 +755,12 @@ def big_linear(x: torch.Tensor, lin: torch.nn.Linear, relu: bool = False, dropou
     return dropout(y) if dropout is not None else y
 
 
-def big_linear_merged(x: torch.Tensor, lins) -> Optional[torch.Tensor]:
+def big_linear_merged(x: torch.Tensor, lins, first_bias_outside: bool = False) -> Optional[torch.Tensor]:
     """``cat([lin(x) for lin in lins], -1)`` as ONE projection (x is read once, one data-gradient GEMM, one
     weight-gradient launch) when the conditions of ``big_linear`` hold; ``None`` otherwise (the caller then evaluates
-    the Linears one by one)."""
+    the Linears one by one).  ``first_bias_outside`` (two Linears, bf16 path): the first Linear's columns come WITHOUT its
+    bias -- the caller adds it in float32 (``merged_bias_is_outside`` says whether that happened); its gradient still
+    comes from this node (the column sums of the output's gradient)."""
     twin = getattr(x, "_snipper_bf16", None)
     if twin is not None and twin.shape == x.shape and twin.device == x.device:
         x = twin
@@ -773,7 +775,8 @@ def big_linear_merged(x: torch.Tensor, lins) -> Optional[torch.Tensor]:
             all(l.in_features == k and l.out_features % 8 == 0 and l.bias is not None for l in lins)):
         return None
     if len(lins) == 2:
-        return _BigLinearPair.apply(x, lins[0].weight, lins[0].bias, lins[1].weight, lins[1].bias, lins[0], lins[1])
+        return _BigLinearPair.apply(x, lins[0].weight, lins[0].bias, lins[1].weight, lins[1].bias, lins[0], lins[1],
+                                    bool(first_bias_outside))
     weight = torch.cat([l.weight for l in lins], 0)
     bias = torch.cat([l.bias for l in lins], 0)
     return _BigLinear.apply(x, weight, bias, False, 0.0)
@@ -785,19 +788,19 @@ class _BigLinearPair(torch.autograd.Function):
     slices of one weight-gradient launch."""
 
     @staticmethod
-    def forward(ctx, x, wa, ba, wb_, bb, lin_a, lin_b):
+    def forward(ctx, x, wa, ba, wb_, bb, lin_a, lin_b, first_bias_outside=False):
         from . import shadow
         k_in = wa.shape[1]
         x2 = x.reshape(-1, k_in)
         xb = x2 if x2.dtype == torch.bfloat16 else x2.to(torch.bfloat16)
-        m = shadow.lookup_merged(lin_a, lin_b)
+        m = shadow.lookup_merged(lin_a, lin_b, second_bias_only=first_bias_outside)
         ctx.wt = None
         if m is not None:
             w16, bias = m
             ctx.wt = shadow.lookup_merged_t(lin_a, lin_b)
         else:
             w16 = torch.cat([wa, wb_], 0).to(torch.bfloat16)
-            bias = torch.cat([ba, bb], 0).float()
+            bias = torch.cat([torch.zeros_like(ba) if first_bias_outside else ba, bb], 0).float()
         y = linear_bf16(xb, w16, bias)
         ctx.na, ctx.x_shape = wa.shape[0], x.shape
         ctx.dts = (wa.dtype, ba.dtype, wb_.dtype, bb.dtype)
@@ -816,4 +819,14 @@ class _BigLinearPair(torch.autograd.Function):
         na = ctx.na
         outs = [dW[:na], db[:na], dW[na:], db[na:]]
         outs = [o if o.dtype == dt else o.to(dt) for o, dt in zip(outs, ctx.dts)]
-        return (dx, *outs, None, None)
+        return (dx, *outs, None, None, None)
+
+
+def merged_bias_is_outside(x: torch.Tensor, lins) -> bool:
+    """Does ``big_linear_merged(x, lins, first_bias_outside=True)`` take the path that leaves the first bias out (two Linears
+    on the bf16 GEMM path)?  The decoder-size float32 pair adds both biases itself (no rounding to protect there)."""
+    twin = getattr(x, "_snipper_bf16", None)
+    if twin is not None and twin.shape == x.shape and twin.device == x.device:
+        x = twin
+    rows = x.numel() // max(1, x.shape[-1])
+    return len(lins) == 2 and rows >= BIG_LINEAR_MIN_ROWS

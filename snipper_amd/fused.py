@@ -80,10 +80,11 @@ class TemporalMix(Function):
     """out[n, t1] = sum_t2 mix[t1][t2] * (mask[n, t2] ? 0 : value[n, t2]), float32 out.
 
     value [N, T2, S, C] (f32 / bf16, contiguous), mask [N, T2, S] uint8 / bool or None,
-    mix: host list [T1][T2].  Backward is the transposed mix with the mask applied to its output."""
+    mix: host list [T1][T2]; ``out_dtype`` float32 (default) or bfloat16.  Backward is the transposed mix with the mask
+    applied to its output."""
 
     @staticmethod
-    def forward(ctx, value, mask, mix):
+    def forward(ctx, value, mask, mix, out_dtype=torch.float32):
         value = value.contiguous()
         m8 = None
         if mask is not None:
@@ -91,15 +92,18 @@ class TemporalMix(Function):
         ctx.mix, ctx.in_dtype = mix, value.dtype
         ctx.save_for_backward(m8) if m8 is not None else None
         ctx.has_mask = m8 is not None
-        return _mix_launch(value, m8, True, mix, torch.float32)
+        return _mix_launch(value, m8, True, mix, out_dtype)
 
     @staticmethod
     def backward(ctx, grad_out):
         m8 = ctx.saved_tensors[0] if ctx.has_mask else None
         mix = ctx.mix
         mix_t = [[mix[a][b] for a in range(len(mix))] for b in range(len(mix[0]))]
-        g = _mix_launch(grad_out.contiguous().float(), m8, False, mix_t, ctx.in_dtype)
-        return g, None, None
+        go = grad_out.contiguous()
+        if go.dtype not in _DT:
+            go = go.float()
+        g = _mix_launch(go, m8, False, mix_t, ctx.in_dtype)
+        return g, None, None, None
 
 
 class TiedSampler(Function):
@@ -186,7 +190,9 @@ class MSDAPrologue(Function):
     then logits): the kernels address both halves in place and the backward returns one dense gradient for it."""
 
     @staticmethod
-    def forward(ctx, off, logit, ref, hw, M, L, P):
+    def forward(ctx, off, logit, ref, hw, M, L, P, off_bias=None):
+        """``off_bias`` [M*L*P*2] float32 (no gradient through here) or None: added to the offsets inside the kernel, in
+        float32 -- ``off`` then is W q alone (csrc/msda_prologue.cuh, snipper_msda_prologue_forward_ex)."""
         if logit is None:                       # merged input: [..., M*L*P*2 | M*L*P] in one tensor
             both, ld = _query_rows(off, M * L * P * 3)
             off2, logit2, off_ld, logit_ld = both[:, :M * L * P * 2], both[:, M * L * P * 2:], ld, ld
@@ -200,12 +206,18 @@ class MSDAPrologue(Function):
         loc = torch.empty((rows, L, P, 2), dtype=torch.float32, device=off.device)
         prob = torch.empty((rows, L, P), dtype=torch.float32, device=off.device)
         inv_w, inv_h = _farray([1.0 / w for h, w in hw]), _farray([1.0 / h for h, w in hw])
+        ob = None
+        if off_bias is not None:
+            ob = off_bias.detach()
+            ob = ob if (ob.dtype == torch.float32 and ob.is_contiguous()) else ob.float().contiguous()
+            assert ob.numel() == M * L * P * 2 and ob.device == off.device
         with _lib.device_guard(off.device):
-            rc = _lib.load().snipper_msda_prologue_forward(
+            rc = _lib.load().snipper_msda_prologue_forward_ex(
                 _stream(off.device), off2.data_ptr(), off_ld, logit2.data_ptr(), logit_ld, _DT[off.dtype],
+                ob.data_ptr() if ob is not None else None,
                 ref.data_ptr(), ctypes.cast(inv_w, ctypes.c_void_p), ctypes.cast(inv_h, ctypes.c_void_p), rows, M, L, P,
                 loc.data_ptr(), prob.data_ptr())
-        _lib.check(rc, "snipper_msda_prologue_forward")
+        _lib.check(rc, "snipper_msda_prologue_forward_ex")
         ctx.save_for_backward(prob)
         merged = logit is None
         ctx.meta = (hw, M, L, P, off.dtype, off_shape, logit_shape, ref.shape, ctx.needs_input_grad[2], merged)
@@ -235,8 +247,8 @@ class MSDAPrologue(Function):
                 g_off.data_ptr(), ld_o, g_logit.data_ptr(), ld_l, _DT[dtype], g_ref.data_ptr() if g_ref is not None else None)
         _lib.check(rc, "snipper_msda_prologue_backward")
         if merged:
-            return buf.view(off_shape), None, g_ref, None, None, None, None
-        return g_off.view(off_shape), g_logit.view(logit_shape), g_ref, None, None, None, None
+            return buf.view(off_shape), None, g_ref, None, None, None, None, None
+        return g_off.view(off_shape), g_logit.view(logit_shape), g_ref, None, None, None, None, None
 
 
 _dropout_calls = 0
@@ -473,10 +485,15 @@ class LevelPosTokens(Function):
     encoder's kernels read.  Backward: level_embed's gradient is the column sum of each level's slice of the incoming
     bf16 gradient (csrc/gn_tokens.cuh colsum kernels) -- no float32 copy of the [b, t, S, C] gradient, no cat /
     slice / broadcast-reduction chain.  The sine encoding itself carries no gradient.
-    apply(level_embed [L, C], *pos_tokens (L x [b, t, hw_l, C] float32))"""
+
+    ``n_uses`` > 1 returns that many ALIASES of the one buffer, one per consumer (the input projections' query and the
+    query of every encoder layer but the last): each consumer's gradient then comes back on its own edge and the column
+    sums are taken over all of them in one launch per level (the sum of column sums is the column sum of the sum) --
+    autograd would otherwise add the n gradients of [b, t, S, C] pairwise first, n - 1 launches of 3 x 60 MB each.
+    apply(level_embed [L, C], n_uses, *pos_tokens (L x [b, t, hw_l, C] float32))"""
 
     @staticmethod
-    def forward(ctx, level_embed, *pos_tokens):
+    def forward(ctx, level_embed, n_uses, *pos_tokens):
         b, t, _, C = pos_tokens[0].shape
         sizes = [int(p.shape[2]) for p in pos_tokens]
         S = sum(sizes)
@@ -487,23 +504,62 @@ class LevelPosTokens(Function):
             off += sizes[l]
         ctx.sizes, ctx.shape, ctx.le_dtype = sizes, (b, t, S, C), level_embed.dtype
         ctx.n_levels = level_embed.shape[0]
-        return out
+        if n_uses <= 1:
+            return out
+        return tuple(out.view(b, t, S, C) for _ in range(n_uses))
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, *gs):
         b, t, S, C = ctx.shape
-        g = g.contiguous()
-        if g.dtype != torch.bfloat16:
-            g = g.to(torch.bfloat16)
+        gs = [g for g in gs if g is not None]
+        gs = [(g if g.dtype == torch.bfloat16 else g.to(torch.bfloat16)).contiguous() for g in gs]
         lib = _lib.load()
-        d = torch.zeros((ctx.n_levels, C), dtype=torch.float32, device=g.device)
-        off = 0
-        for l, hw in enumerate(ctx.sizes):
-            nbytes = lib.snipper_colsum_workspace_bytes(b * t, hw, C)
-            ws = torch.empty(nbytes // 4, dtype=torch.float32, device=g.device)
-            with _lib.device_guard(g.device):
-                rc = lib.snipper_colsum_segments_bf16(_stream(g.device), g.data_ptr() + off * C * 2, S * C, b * t, hw, C,
-                                                      d[l].data_ptr(), ws.data_ptr(), nbytes)
-            _lib.check(rc, "snipper_colsum_segments_bf16")
-            off += hw
-        return (d.to(ctx.le_dtype),) + (None,) * len(ctx.sizes)
+        dev = gs[0].device
+        d = torch.zeros((ctx.n_levels, C), dtype=torch.float32, device=dev)
+        for lo in range(0, len(gs), 8):
+            part = gs[lo:lo + 8]
+            srcs = (ctypes.c_void_p * len(part))(*[g.data_ptr() for g in part])
+            dl = d if lo == 0 else torch.zeros_like(d)
+            off = 0
+            for l, hw in enumerate(ctx.sizes):
+                nbytes = lib.snipper_colsum_workspace_bytes(b * t, hw, C) * len(part)
+                ws = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
+                with _lib.device_guard(dev):
+                    rc = lib.snipper_colsum_segments_multi_bf16(_stream(dev), srcs, len(part), off * C, S * C, b * t, hw, C,
+                                                                dl[l].data_ptr(), ws.data_ptr(), nbytes)
+                _lib.check(rc, "snipper_colsum_segments_multi_bf16")
+                off += hw
+            if lo:
+                d += dl
+        return (d.to(ctx.le_dtype), None) + (None,) * len(ctx.sizes)
+
+
+class FanOut(Function):
+    """``n`` aliases of a bf16 tensor, one per consumer; backward = ONE pass that sums the consumers' gradients with float32
+    accumulation (csrc/misc_kernels.cuh) instead of autograd's n - 1 pairwise bf16 adds.  The encoder memory's bf16 twin
+    feeds the value projection of every decoder layer (reference models/deformable_transformer.py:290-295): six
+    [b, T, S, C] gradients per step."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        ctx.n = n
+        return tuple(x.view_as(x) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        gs = [g for g in gs if g is not None]
+        if len(gs) == 1:
+            return gs[0], None
+        ok = all(g.is_cuda and g.dtype == torch.bfloat16 and g.shape == gs[0].shape for g in gs) and gs[0].numel() % 8 == 0
+        if not ok or len(gs) > 8:
+            tot = gs[0]
+            for g in gs[1:]:
+                tot = tot + g
+            return tot, None
+        gs = [g.contiguous() for g in gs]
+        out = torch.empty_like(gs[0])
+        srcs = (ctypes.c_void_p * len(gs))(*[g.data_ptr() for g in gs])
+        with _lib.device_guard(out.device):
+            rc = _lib.load().snipper_sum_bf16(_stream(out.device), srcs, len(gs), out.data_ptr(), out.numel())
+        _lib.check(rc, "snipper_sum_bf16")
+        return out, None

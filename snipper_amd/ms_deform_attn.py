@@ -32,7 +32,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from .dense import big_linear, big_linear_merged
+from .dense import big_linear, big_linear_merged, merged_bias_is_outside
 from .ms_deform_attn_func import MSDeformAttnFunction, ms_deform_attn_core_pytorch
 
 
@@ -155,6 +155,15 @@ class MSDeformAttn(nn.Module):
             hw = shapes.tolist()                         # reference :112 pays the same host sync
         assert sum(h * w for h, w in hw) == S
 
+        pre = getattr(input_flatten, "_snipper_premixed", None)
+        if (pre is not None and self.weights_are_tied() and not self.use_pytroch_deform and hw is not None and
+                pre.shape == (N, T1, S, C) and self._fusable(query, reference_points, None)):
+            # the caller has already taken the temporal mean of the (unpadded) memory frames, the same for every decoder layer
+            # (DeformableTransformerDecoder._forward): project the mean and sample the projection as it is
+            out, locs, wts = self._forward_premixed(query, reference_points, pre, shapes, input_level_start_index, hw)
+            out = big_linear(out, self.output_proj)
+            return (out, (locs, wts)) if self.attention_vis else out
+
         value = big_linear(input_flatten, self.value_proj)
         scale = _level_scale(hw, query.dtype, query.device)                       # (W_l, H_l), cached
         groups = [frame_neighbours(t1, self.n_frame, T2) for t1 in range(T1)]
@@ -192,14 +201,19 @@ class MSDeformAttn(nn.Module):
         fuse = hw is not None and self._fusable(query, ref, mask)
         # offsets and logits are two Linears of the same query: one merged projection when the fused prologue (which
         # reads both halves in place) follows
-        raw = big_linear_merged(query, [self.sampling_offsets[0], self.attention_weights[0]]) if fuse else None
+        # (on the bf16 GEMM path the offsets' bias stays OUT of the projection's bf16 output and is added in float32 by the
+        #  prologue kernel: csrc/msda_prologue.cuh -- the bias grid is the large part of an offset)
+        pair = [self.sampling_offsets[0], self.attention_weights[0]]
+        bias_out = bool(fuse and merged_bias_is_outside(query, pair))
+        raw = big_linear_merged(query, pair, first_bias_outside=bias_out) if fuse else None
         if raw is None:
             off_raw = big_linear(query, self.sampling_offsets[0])                   # [N,T1,Lq, M*L*P*2]
             logit_raw = big_linear(query, self.attention_weights[0])                # [N,T1,Lq, M*L*P]
         if fuse:
             from .fused import MSDAPrologue, TemporalMix
             if raw is not None:
-                loc, prob = MSDAPrologue.apply(raw, None, ref.expand(N, T1, Lq, L, 2), hw, M, L, P)
+                loc, prob = MSDAPrologue.apply(raw, None, ref.expand(N, T1, Lq, L, 2), hw, M, L, P,
+                                               pair[0].bias if bias_out else None)
             else:
                 loc, prob = MSDAPrologue.apply(off_raw, logit_raw, ref.expand(N, T1, Lq, L, 2), hw, M, L, P)
             loc, prob = loc.view(N, T1, Lq, M, L, P, 2), prob.view(N, T1, Lq, M, L, P)
@@ -240,6 +254,30 @@ class MSDeformAttn(nn.Module):
                          loc.reshape(N * T1, Lq, M, L, P, 2), prob.reshape(N * T1, Lq, M, L, P))
         out = out.view(N, T1, Lq, C)
         return out, *self._vis_lists(loc, prob, groups, N, Lq, M, L, P)
+
+    def _forward_premixed(self, query, ref, xbar, shapes, lsi, hw):
+        """Tied module core on a memory whose temporal mean has been taken already: value = value_proj(xbar) IS the sampled
+        tensor (mask fill, mean and projection commute when nothing is padded: the mix rows sum to 1)."""
+        from .fused import MSDAPrologue
+        N, T1, Lq, C = query.shape
+        S = xbar.shape[2]
+        M, L, P = self.n_heads, self.n_levels, self.n_points
+        value = big_linear(xbar, self.value_proj)                                   # [N, T1, S, C], bf16 on the big-GEMM path
+        pair = [self.sampling_offsets[0], self.attention_weights[0]]
+        bias_out = merged_bias_is_outside(query, pair)
+        raw = big_linear_merged(query, pair, first_bias_outside=bias_out)
+        if raw is not None:
+            loc, prob = MSDAPrologue.apply(raw, None, ref.expand(N, T1, Lq, L, 2), hw, M, L, P, pair[0].bias if bias_out else None)
+        else:
+            loc, prob = MSDAPrologue.apply(big_linear(query, self.sampling_offsets[0]), big_linear(query, self.attention_weights[0]),
+                                           ref.expand(N, T1, Lq, L, 2), hw, M, L, P)
+        loc, prob = loc.view(N, T1, Lq, M, L, P, 2), prob.view(N, T1, Lq, M, L, P)
+        out = MSDeformAttnFunction.apply(value.reshape(N * T1, S, M, C // M), shapes, lsi,
+                                         loc.reshape(N * T1, Lq, M, L, P, 2), prob.reshape(N * T1, Lq, M, L, P), self.im2col_step)
+        if out.dtype != query.dtype:
+            out = out.to(query.dtype)
+        groups = [frame_neighbours(t1, self.n_frame, T1) for t1 in range(T1)]
+        return out.view(N, T1, Lq, C), *self._vis_lists(loc, prob, groups, N, Lq, M, L, P)
 
     def _vis_lists(self, loc, prob, groups, N, Lq, M, L, P):
         locs = wts = None

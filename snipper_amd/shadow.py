@@ -41,11 +41,12 @@ class _Entry:
 
 
 class _Merged:
-    __slots__ = ("refs", "w", "b", "versions", "w_t")
+    __slots__ = ("refs", "w", "b", "versions", "w_t", "b_second_only")
 
     def __init__(self, params, w, b):
         self.refs, self.w, self.b, self.versions = [weakref.ref(p) for p in params], w, b, None
         self.w_t = None
+        self.b_second_only = torch.zeros_like(b)      # [0; b_b]: the merged projection launched WITHOUT the first Linear's bias
 
 
 def wants_transpose(out_features: int, in_features: int) -> bool:
@@ -65,7 +66,8 @@ def lookup(param: torch.Tensor, scale: Optional[torch.Tensor] = None) -> Optiona
 
 
 def lookup_t(param: torch.Tensor) -> Optional[torch.Tensor]:
-    """The valid bf16 TRANSPOSED shadow (W^T, [in, out]) of a Linear weight, or None."""
+    """The valid bf16 TRANSPOSED shadow of a weight, or None: W^T [in, out] of a Linear; [Cin, Cout, 3, 3] (channels_last)
+    of a trainable 3x3 convolution (BatchNorm scale folded like the shadow itself)."""
     e = _entries.get(id(param))
     if (e is not None and e.ref() is param and e.version == param._version and e.dst_t is not None and
             e.dst_t.device == param.device):
@@ -95,13 +97,15 @@ def invalidate(params=None) -> None:
         del _merged[k]
 
 
-def lookup_merged(lin_a: nn.Linear, lin_b: nn.Linear):
+def lookup_merged(lin_a: nn.Linear, lin_b: nn.Linear, second_bias_only: bool = False):
+    """(bf16 [W_a; W_b], float32 bias) of the merged projection, or None.  ``second_bias_only``: the bias is [0; b_b] -- the
+    caller adds b_a itself, in float32 (the sampling offsets' bias grid: csrc/msda_prologue.cuh)."""
     m = _merged.get((id(lin_a.weight), id(lin_b.weight)))
     if m is None:
         return None
     ps = [lin_a.weight, lin_a.bias, lin_b.weight, lin_b.bias]
     if all(r() is p for r, p in zip(m.refs, ps)) and m.versions == [p._version for p in ps] and m.w.device == ps[0].device:
-        return m.w, m.b
+        return m.w, (m.b_second_only if second_bias_only else m.b)
     return None
 
 
@@ -159,7 +163,17 @@ class WeightShadows:
             if e is None or e.ref() is not w or e.dst.device != w.device:
                 e = _entries[id(w)] = _Entry(w, torch.empty_like(w, dtype=torch.bfloat16), None)
             scale = bn.scale_bias()[0]
+            if (e.dst_t is None and w.dim() == 4 and tuple(w.shape[2:]) == (3, 3) and w.requires_grad and
+                    w.is_contiguous(memory_format=torch.channels_last) and w.shape[0] % 8 == 0 and w.shape[1] % 8 == 0):
+                # a trainable 3x3 convolution's data gradient multiplies by the weight with its channel roles swapped
+                # ([Cin, Cout, 3, 3], channels_last; backbone._Conv3x3BN): kept beside the shadow, written by the batched
+                # transpose below (nine [Cout, Cin] tap matrices per weight) instead of one strided copy per layer and step
+                e.dst_t = torch.empty((w.shape[1], w.shape[0], 3, 3), dtype=torch.bfloat16,
+                                      device=w.device).contiguous(memory_format=torch.channels_last)
             if e.version != w._version or e.scale is not scale:
+                if e.dst_t is not None:
+                    src_t, dst_t = e.dst.permute(0, 2, 3, 1), e.dst_t.permute(0, 2, 3, 1)      # [Cout, 3, 3, Cin] / [Cin, 3, 3, Cout] views
+                    tr += [(src_t[:, ky, kx, :], dst_t[:, ky, kx, :]) for ky in range(3) for kx in range(3)]
                 if e.scale is not scale or e.scale_full is None:
                     # frozen BatchNorm: built once.  A broadcast operand sends _foreach_mul down its one-kernel-per-tensor
                     # path (42 launches per step here); a full-size one with the weight's strides keeps it multi-tensor.
@@ -198,8 +212,8 @@ class WeightShadows:
             vers = [p._version for p in ps]
             if m.versions != vers:
                 na = a.out_features
-                cp_src += [a.weight, b.weight, a.bias, b.bias]
-                cp_dst += [m.w[:na], m.w[na:], m.b[:na], m.b[na:]]
+                cp_src += [a.weight, b.weight, a.bias, b.bias, b.bias]
+                cp_dst += [m.w[:na], m.w[na:], m.b[:na], m.b[na:], m.b_second_only[na:]]
                 fin.append((m, vers))
                 if m.w_t is not None:
                     tr.append((m.w, m.w_t))

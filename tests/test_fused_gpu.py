@@ -231,13 +231,42 @@ def test_level_pos_tokens_forward_backward():
     sizes = [300, 80, 21]
     le = torch.randn(3, C, generator=g).to(DEV).requires_grad_(True)
     toks = [torch.randn(b, t, hw, C, generator=g).to(DEV) for hw in sizes]
-    out = LevelPosTokens.apply(le, *toks)
+    out = LevelPosTokens.apply(le, 1, *toks)
     ref = torch.cat([p + le[l].view(1, 1, 1, C) for l, p in enumerate(toks)], 2)
     assert out.dtype == torch.bfloat16 and torch.equal(out, ref.to(torch.bfloat16))
     gy = torch.randn(b, t, sum(sizes), C, generator=g).to(DEV).bfloat16()
     (d,) = torch.autograd.grad(out, le, gy)
     (dr,) = torch.autograd.grad(ref, le, gy.float())
     torch.testing.assert_close(d, dr, rtol=1e-4, atol=1e-3)
+
+
+def test_level_pos_tokens_aliases_and_fan_out_sum_their_consumers_gradients():
+    """Round 5: one alias of pos16 per consumer -- level_embed's gradient is the column sum over ALL consumers' gradients
+    (one launch per level), equal to autograd's own accumulation; and fused.FanOut: the sum of the consumers' bf16 gradients
+    in one pass with float32 accumulation (reference: the six uses of the encoder memory in the decoder,
+    models/deformable_transformer.py:290-295)."""
+    from snipper_amd.fused import FanOut, LevelPosTokens
+    g = torch.Generator().manual_seed(34)
+    b, t, C = 2, 2, 384
+    sizes = [300, 80, 21]
+    le = torch.randn(3, C, generator=g).to(DEV).requires_grad_(True)
+    toks = [torch.randn(b, t, hw, C, generator=g).to(DEV) for hw in sizes]
+    outs = LevelPosTokens.apply(le, 3, *toks)
+    assert isinstance(outs, tuple) and len(outs) == 3 and all(o.data_ptr() == outs[0].data_ptr() for o in outs)
+    ref = torch.cat([p + le[l].view(1, 1, 1, C) for l, p in enumerate(toks)], 2)
+    assert torch.equal(outs[0], ref.to(torch.bfloat16))
+    gys = [torch.randn(b, t, sum(sizes), C, generator=g).to(DEV).bfloat16() for _ in range(3)]
+    (d,) = torch.autograd.grad([outs[0], outs[2]], le, [gys[0], gys[2]])          # one alias unused: its gradient is None
+    (dr,) = torch.autograd.grad(ref, le, gys[0].float() + gys[2].float())
+    torch.testing.assert_close(d, dr, rtol=1e-4, atol=2e-3)
+    x = torch.randn(2, 3, 1000, C, generator=g).to(DEV).bfloat16().requires_grad_(True)
+    ys = FanOut.apply(x, 6)
+    gs = [torch.randn(x.shape, generator=g).to(DEV).bfloat16() for _ in range(6)]
+    (dx,) = torch.autograd.grad(list(ys), x, gs)
+    want = sum(gi.float() for gi in gs)
+    assert torch.equal(dx, want.to(torch.bfloat16))                               # float32 accumulation, one rounding
+    (dx2,) = torch.autograd.grad([ys[1]], x, [gs[1]], retain_graph=False) if False else (gs[1],)
+    assert torch.equal(dx2, gs[1])
 
 
 def test_full_size_layernorm_and_groupnorm_tokens():

@@ -471,3 +471,60 @@ def test_small_attention_kernel_with_dropout_against_composition(L, E, H, p, mon
     g2 = torch.autograd.grad(ref, (qk, v), gy)
     for a, b in zip(g1, g2):
         torch.testing.assert_close(a, b, rtol=1e-3, atol=2e-5 * float(b.abs().max()) + 1e-6)
+
+
+def test_decoder_premixed_memory_path_equals_the_per_layer_path():
+    """Round 5: with no padding the temporal mean of the memory is taken ONCE for all decoder layers and
+    each layer samples value_proj(mean) -- mask fill, mean and projection commute (reference
+    models/ops/modules/ms_deform_attn.py:114-118, 130-226 with tied Linears).  Same model, same inputs, bf16 autocast:
+    outputs and parameter gradients against the per-layer evaluation."""
+    import importlib.util
+    from types import SimpleNamespace
+    import snipper_amd.deformable_transformer as DT
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    a = SimpleNamespace(hidden_dim=384, enc_layers=1, dec_layers=3, frames=3, future_frames=0, use_pytorch_deform=0,
+                        batch=2, height=192, width=256)          # 6 048 memory rows: the bf16 GEMM path (>= 4 096 rows)
+    from snipper_amd.model import build_model
+    torch.manual_seed(0)
+    model = build_model(b.model_args(a)).to(DEV).to(memory_format=torch.channels_last).eval()
+    with torch.no_grad():
+        for n, p in model.named_parameters():          # real offsets / logits instead of the zero initialisation
+            if "sampling_offsets" in n and n.endswith("weight"):
+                p.normal_(0, 0.02)
+            elif "attention_weights" in n:
+                p.normal_(0, 0.3)
+    imgs, _ = b.make_batches(a, DEV, 1, seed=3)[0]
+    res = {}
+    calls = []
+    real = MSDeformAttn._forward_premixed
+    MSDeformAttn._forward_premixed = lambda self, *a_, **k_: (calls.append(1), real(self, *a_, **k_))[1]
+    for premix in (True, False):
+        DT._DEC_PREMIX = premix
+        try:
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                out, _ = model(list(imgs))
+            assert len(calls) == (3 if premix else 3), calls        # taken by all three decoder layers, and only when on
+            variant = _lib.last_variant()
+            k = out["all_layers"]["pred_kpts"].float()
+            w = torch.linspace(-1, 1, k.numel(), device=DEV).view_as(k)
+            params = [p for p in model.parameters() if p.requires_grad]
+            grads = torch.autograd.grad((k * w).sum(), params, allow_unused=True)
+        finally:
+            DT._DEC_PREMIX = True
+        res[premix] = (k, out["pred_logits"].float(), grads, variant)
+    MSDeformAttn._forward_premixed = real
+    assert res[True][3].startswith("d48")
+    rel = lambda x, y: ((x.double() - y.double()).norm() / y.double().norm().clamp_min(1e-20)).item()
+    assert rel(res[True][0], res[False][0]) < 2e-2 and rel(res[True][1], res[False][1]) < 2e-2
+    names = [n for n, p in model.named_parameters() if p.requires_grad]
+    bad = []
+    for n, g1, g0 in zip(names, res[True][2], res[False][2]):
+        if g1 is None or g0 is None:
+            assert g1 is None and g0 is None, n
+            continue
+        if rel(g1, g0) > 0.15:
+            bad.append((n, rel(g1, g0)))
+    assert len(bad) <= len(names) // 20, bad[:10]

@@ -140,6 +140,10 @@ def test_module_goldens_under_bf16_autocast_take_the_head_major_path(golden_dir,
     calls = []
     real = fused._head_major_config
     monkeypatch.setattr(fused, "_head_major_config", lambda: (calls.append(1), real())[1])
+    # the golden has 252-504 token rows: let the module take the kernels it takes at the bench's 79 000 (the bf16 GEMM kernels,
+    # the merged offset + logit projection WITHOUT the offsets' bias, which the prologue kernel adds in float32)
+    from snipper_amd import dense
+    monkeypatch.setattr(dense, "BIG_LINEAR_MIN_ROWS", 128)
     with torch.autocast("cuda", dtype=torch.bfloat16):
         res = mod(q, r, s, shapes, mv(b["lsi"]), mv(b["mask"]))
     assert _lib.last_variant() == "d48_lp12" and calls, "the head-major bf16 path was not taken"
@@ -154,5 +158,40 @@ def test_module_goldens_under_bf16_autocast_take_the_head_major_path(golden_dir,
         errs[k] = rel(g, b["param_grads"][k])
     print(name, {k: round(v, 4) for k, v in errs.items()})
     assert errs["out"] < 1.5e-2, errs
-    bad = {k: v for k, v in errs.items() if v > 4e-2}
+    # Everything that does not pass through the sampling LOCATIONS is at bf16 accuracy ...
+    loc_side = ("grad_query", "grad_ref", "sampling_offsets.0.weight", "sampling_offsets.0.bias")
+    bad = {k: v for k, v in errs.items() if k not in loc_side and v > 4e-2}
     assert not bad, bad
+    # ... and the location side's error (0.22 on the first encoder layer's sampling_offsets gradient,
+    # "nobody has shown which layer contributes it") is NOT the sampling kernels' bf16 value / rows: the gradient with respect
+    # to a sampling location is piecewise constant per pixel cell and jumps at cell borders (ms_deform_im2col_cuda.cuh:87-159:
+    # differences of the four taps), so a location moved by a few 1e-3 px lands a few per cent of the samples in the neighbouring
+    # cell.  Two things move it under autocast: the bf16 rounding of the offset projection's OUTPUT (bias grid of up to P px
+    # included: 6-15 % here with torch's F.linear) -- removed in round 5 by keeping the bias out of the GEMM and adding it in
+    # float32 in the prologue kernel -- and the rounding of its INPUTS, which remains.  Shown by two float32 arms of the same
+    # module on the float32 kernels: (B) only the query and the offset / logit Linears rounded to bf16 gives what is left,
+    # (C) only src and value_proj rounded gives nothing.
+    def f32_arm(round_names, round_query, round_src):
+        m2 = MSDeformAttn(cfg["d_model"], cfg["n_levels"], cfg["n_heads"], cfg["n_points"], cfg["n_frame"], cfg["mode"], False, False)
+        m2.load_state_dict(b["state_dict"], strict=True)
+        m2 = m2.to(DEV)
+        with torch.no_grad():
+            for k, p in m2.named_parameters():
+                if any(k.startswith(r) for r in round_names):
+                    p.copy_(p.to(torch.bfloat16).float())
+        rq = lambda x, on: (x.to(torch.bfloat16).float() if on else x).clone().requires_grad_(True)
+        q2, r2, s2 = rq(mv(b["query"]), round_query), mv(b["ref"]).clone().requires_grad_(True), rq(mv(b["src"]), round_src)
+        res2 = m2(q2, r2, s2, shapes, mv(b["lsi"]), mv(b["mask"]))
+        g2 = torch.autograd.grad(res2, [q2, r2] + [m2.sampling_offsets[0].weight, m2.sampling_offsets[0].bias], mv(b["grad_out"]))
+        return {"grad_query": rel(g2[0], b["grad_query"]), "grad_ref": rel(g2[1], b["grad_ref"]),
+                "sampling_offsets.0.weight": rel(g2[2], b["param_grads"]["sampling_offsets.0.weight"]),
+                "sampling_offsets.0.bias": rel(g2[3], b["param_grads"]["sampling_offsets.0.bias"])}
+    arm_b = f32_arm(("sampling_offsets", "attention_weights"), True, False)
+    arm_c = f32_arm(("value_proj",), False, True)
+    print(name, "float32 kernels, bf16-rounded offset-projection inputs:", {k: round(v, 4) for k, v in arm_b.items()})
+    print(name, "float32 kernels, bf16-rounded value-projection inputs :", {k: round(v, 4) for k, v in arm_c.items()})
+    for k in loc_side:
+        assert arm_c[k] < 2e-2, (k, arm_c)                       # the value side alone: small
+        # the autocast run: what the rounded inputs alone give + the rounding of W q itself to bf16 (measured: enc_d48 0.08-0.125
+        # against 0.065-0.10 for arm B, 0.09-0.15 before the bias left the GEMM; enc_t1_d48 0.05 against 0.01, 0.06-0.09 before)
+        assert errs[k] < 2.0 * arm_b[k] + 5e-2, (k, errs[k], arm_b[k])
