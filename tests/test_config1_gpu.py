@@ -101,14 +101,19 @@ def test_config1_bf16_autocast_path_runs_the_tied_sampler_with_one_frame():
     rel = lambda a, b: float((a.detach().float() - b.detach().float()).norm() / b.detach().float().norm().clamp_min(1e-20))
     errs = {k: rel(oa[k], of[k]) for k in ("pred_logits", "pred_kpts2d", "pred_depth")}
     gerrs = {n: rel(a, b) for n, a, b in zip(GRAD_NAMES, ga, gf)}
-    print("[config1 bf16 vs fp32] outputs", {k: f"{v:.3e}" for k, v in errs.items()}, "grads", {".".join(k.split(".")[-3:]): f"{v:.3e}" for k, v in gerrs.items()})
+    print("[config1 bf16 vs fp32] outputs", {k: f"{v:.3e}" for k, v in errs.items()}, "grads", {".".join(k.split(".")[1:]): f"{v:.3e}" for k, v in gerrs.items()})
     # measured: outputs 3.0-4.5e-2 (bf16 backbone 0.9 % -> encoder 1.4 % -> four decoder layers); the shadow bug that this
     # test found (merged offset bias lost under autocast) gave 0.39-0.55
     for k, v in errs.items():
         assert v <= 8e-2, (k, v)
-    # measured (round 4): the first encoder layer's sampling_offsets weight 0.22 (its gradient passes through every bf16 layer
-    # above it and the bilinear kernel's derivative), every other gradient 3.0e-2 .. 6.7e-2: bounds = ~2x the other ones,
-    # 1.35x the worst
+    # measured (round 5): the two sampling_offsets weights (first encoder layer 0.18, last decoder layer 0.21), every other
+    # gradient 3.0e-2 .. 7.1e-2: bounds = ~2x the other ones, 1.4x the worst.  WHICH layer the 0.2 comes from:
+    # none -- tools/dbg_attribution.py, profiles/r05_bf16_attribution.jsonl: switching the value projection, the output
+    # projection or the offset / logit projection of the encoder back to float32 leaves it at 0.16-0.20, while in PURE float32 a
+    # 2^-9 relative perturbation of the input images (one bf16 rounding) already moves these two gradients by 2.3-2.6 % and all
+    # the others by 0.4-0.8 %: the gradient with respect to a sampling location is piecewise constant per pixel cell
+    # (ms_deform_im2col_cuda.cuh:87-159), so ANY upstream perturbation is amplified 4-6x on the location side -- the bf16
+    # step's general 3-7 % lands at ~0.2 there.
     for n, v in gerrs.items():
         assert v <= (0.30 if "sampling_offsets" in n else 0.14), (n, v)
 
