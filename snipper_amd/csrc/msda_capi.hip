@@ -213,9 +213,15 @@ int backward_d48_f32(hipStream_t st, const float *grad_out, const float *value, 
 // grad_value tile edge of a level class (0 big, 1 mid, 2 small).  tile_edge = 0 (the default) lets the grad_value-side kernel
 // pick: 16 / 8 / 4 for the vector / LDS kernel (round 1-3 sweeps), 16 / 8 / 8 for the matrix-pipe kernel, whose cost is per
 // hit and per workgroup, not per tap (whole backward at N = 8, sigma 0 / 3 px: 0.669 / 0.844 ms against 0.677 / 0.861)
+// Round 5: 8 / 8 / 8 for the matrix-pipe kernel.  Once its workgroups walk the (n, m) pairs of an XCD TILE-major (t3_order in
+// msda_d48_tilemm.cuh: a tile's hit rows are fetched once for all heads) the 8 x 8-tile instance at five workgroups per CU
+// beats the 16 x 16-tile instance on the finest level as well: tile kernels 121 + 113 -> 188 us at sigma 0, 178 + 155 -> 261 us
+// at 3 px (query side + 2 ... + 7 us for the extra mark words); 8 / 8 / 4, 8 / 4 / 4, 4 / 4 / 4: 196 / 206 / 245 us and a
+// query side of 210 / 291 / 592 us (profiles/r05_tile_order_and_edges.txt).
 int patch_edge(const snipper_msda_config &cfg, int cls, bool mfma_tiles) {
   if (cfg.tile_edge[cls] > 0) return cfg.tile_edge[cls];
-  return cls == 0 ? 16 : (cls == 1 ? 8 : (mfma_tiles ? 8 : 4));
+  if (mfma_tiles) return 8;
+  return cls == 0 ? 16 : (cls == 1 ? 8 : 4);
 }
 // which grad_value-side kernel a backward call with these row / value types takes (config.tile_kernel: 1 forces the vector one)
 bool patch_uses_mfma(const CoreDims &d, const snipper_msda_config &cfg, int go_bf16) {
@@ -330,8 +336,12 @@ int backward_d48_patch(hipStream_t st, const void *grad_out, const VT *value, co
   const long long nblk_tiles = ((nm + 7) / 8) * 8 * plan.total_tiles;
   if (nblk_padded >= (1LL << 31) || nblk_tiles >= (1LL << 31)) return SNIPPER_E_SHAPE;
   if (go_bf16) {
-    hipLaunchKernelGGL((msda_bwd_d48_patchbin_kernel<VT, true>), dim3((unsigned)nblk_padded), dim3(kPatchThreads), 0, st, grad_out,
-                       value, loc, attn, d, plan, grad_value, grad_loc, grad_attn, (int)nblk_padded);
+    if (plan.L <= 3)
+      hipLaunchKernelGGL((msda_bwd_d48_patchbin_kernel<VT, true, 3>), dim3((unsigned)nblk_padded), dim3(kPatchThreads), 0, st, grad_out,
+                         value, loc, attn, d, plan, grad_value, grad_loc, grad_attn, (int)nblk_padded);
+    else
+      hipLaunchKernelGGL((msda_bwd_d48_patchbin_kernel<VT, true, 4>), dim3((unsigned)nblk_padded), dim3(kPatchThreads), 0, st, grad_out,
+                         value, loc, attn, d, plan, grad_value, grad_loc, grad_attn, (int)nblk_padded);
     if (int rc = launch_status()) return rc;
     // grad_value side: dense per-tile scatter on the matrix pipe (msda_d48_tilemm.cuh) unless the caller asks for the
     // vector / LDS kernel (config.tile_kernel = 1), see patch_uses_mfma

@@ -52,7 +52,9 @@ constexpr int kPatchP = 4;
 constexpr int kPatchB = 8;                       // query block edge
 constexpr int kPatchThreads = 256;               // = 64 rows x 4 points (decode) = 32 rows x 8 lanes (gather) = 16 rows x 16 lanes (atomics)
 constexpr int kPatchRowBytes = kD48 * 4;         // 192
-constexpr int kPatchMaxTiles = 64;               // tiles one (block, level) may mark
+constexpr int kPatchMaxTiles = 152;              // tiles one (block, level) may mark: a block of the coarsest of three levels
+                                                 // (8 queries = 32 px of the finest) at radius 24 px reaches 12 x 12 tiles of 8 x 8
+                                                 // there; tiles past this bound are nobody's (their taps take the far list)
 constexpr int kPatchMaxCand = 256;               // candidate blocks per tile (one per thread of the tile kernel)
 
 struct PatchLevel {
@@ -290,7 +292,8 @@ __device__ __forceinline__ unsigned long long patch_rows_of(unsigned long long b
 //      into the same word serialise in the LDS atomic unit);
 //   2. store the marks, gather + dot + reduce (32 rows x 8 lanes, twice) and store grad_loc / grad_attn for all levels,
 //      then the far taps' HBM atomics of the levels that have any.
-template <typename VT, bool GO_BF16>
+// NL = levels the LDS is sized for (3: the usual three-level plan -- 31.5 KB, four workgroups per CU; 4: 42 KB, three)
+template <typename VT, bool GO_BF16, int NL = kPatchMaxLevels>
 __global__ __launch_bounds__(kPatchThreads) void msda_bwd_d48_patchbin_kernel(
     const void *__restrict__ grad_out, const VT *__restrict__ value, const float *__restrict__ loc,
     const float *__restrict__ attn, CoreDims d, PatchPlan plan, float *__restrict__ grad_value,
@@ -302,18 +305,17 @@ __global__ __launch_bounds__(kPatchThreads) void msda_bwd_d48_patchbin_kernel(
 #else
   constexpr int kStampBytes = 0;
 #endif
-  __shared__ __attribute__((aligned(16))) unsigned char smem[kPatchMaxLevels * kPatchThreads * sizeof(PatchRec) +
-                                                           kPatchMaxLevels * kPatchMaxTiles * 16 + kStampBytes];
+  __shared__ __attribute__((aligned(16))) unsigned char smem[NL * kPatchThreads * sizeof(PatchRec) + NL * kPatchMaxTiles * 16 + kStampBytes];
   PatchRec *recs = reinterpret_cast<PatchRec *>(smem);                                                   // [level][row][point]
-  unsigned long long *s_mask = reinterpret_cast<unsigned long long *>(recs + kPatchMaxLevels * kPatchThreads);   // [level][tile]
-  long long *s_slot = reinterpret_cast<long long *>(s_mask + kPatchMaxLevels * kPatchMaxTiles);          // [level][tile]
+  unsigned long long *s_mask = reinterpret_cast<unsigned long long *>(recs + NL * kPatchThreads);         // [level][tile]
+  long long *s_slot = reinterpret_cast<long long *>(s_mask + NL * kPatchMaxTiles);                       // [level][tile]
   PatchBlock b;
   if (!patch_block(plan, d, nblk_padded, b)) return;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // (uniform: the level tables below are then SCALAR loads)
 #ifdef TILE2_STAMPS
   // (tools/tile2_stamps.py: the second half of the stamp buffer, wave 0 of every 97th workgroup)
-  unsigned long long *pst = reinterpret_cast<unsigned long long *>(s_slot + kPatchMaxLevels * kPatchMaxTiles);
+  unsigned long long *pst = reinterpret_cast<unsigned long long *>(s_slot + NL * kPatchMaxTiles);
   unsigned long long *pst_out = (plan.stamps && blockIdx.x % 97 == 0 && blockIdx.x / 97 < 256) ? plan.stamps + 256 * 128 + (blockIdx.x / 97) * 64 : nullptr;
   int pst_n = 0;
 #define PATCH_STAMP(slot) do { if (pst_out && tid == 0 && pst_n < 64) { pst[pst_n] = ((unsigned long long)(slot) << 56) | (__builtin_amdgcn_s_memtime() & 0x00ffffffffffffffull); ++pst_n; } } while (0)
@@ -384,16 +386,19 @@ __global__ __launch_bounds__(kPatchThreads) void msda_bwd_d48_patchbin_kernel(
     }
   }
   // mark-word slots of every level: thread (wave = level, lane = tile of the level's box)
-  if (wave < plan.L) {
-    const PatchTileBox tb = patch_tile_box(plan, b, wave);
+  // (wave-uniform level: the plan's tables stay scalar loads.  A wave without a level of its own -- wave 3 of a three-level
+  //  plan -- takes every other 64 tiles of level 0, whose box is the largest: 81 tiles of 8 x 8 for a block of the finest level)
+  const int slot_lv = wave < plan.L ? wave : 0;
+  const int slot_first = wave < plan.L ? lane : lane + 64;
+  const int slot_step = (slot_lv == 0 && plan.L < kPatchThreads / 64) ? 128 : 64;
+  {
+    const PatchTileBox tb = patch_tile_box(plan, b, slot_lv);
     const int nt = min(tb.ntx * tb.nty, kPatchMaxTiles);
-    long long sl = -1;
-    if (lane < nt) {
-      const int tiy = lane / tb.ntx, tix = lane - tiy * tb.ntx;
-      sl = patch_slot(plan, b, d.M, wave, tb.ty0 + tiy, tb.tx0 + tix);
+    for (int ti = slot_first; ti < nt; ti += slot_step) {
+      const int tiy = ti / tb.ntx, tix = ti - tiy * tb.ntx;
+      s_slot[slot_lv * kPatchMaxTiles + ti] = patch_slot(plan, b, d.M, slot_lv, tb.ty0 + tiy, tb.tx0 + tix);
+      s_mask[slot_lv * kPatchMaxTiles + ti] = 0ull;
     }
-    s_slot[wave * kPatchMaxTiles + lane] = sl;
-    s_mask[wave * kPatchMaxTiles + lane] = 0ull;
   }
   PATCH_STAMP(1);
   lds_barrier();                 // slots and cleared masks visible (the global loads stay in flight)
@@ -493,10 +498,14 @@ __global__ __launch_bounds__(kPatchThreads) void msda_bwd_d48_patchbin_kernel(
   PATCH_STAMP(4);
 
   // ---- phase 2: marks out, gathers ----
-  if (wave < plan.L) {
-    const long long sl = s_slot[wave * kPatchMaxTiles + lane];
-    const unsigned long long mk = s_mask[wave * kPatchMaxTiles + lane];
-    if (sl >= 0 && mk != 0ull) plan.marks[sl] = mk;
+  {
+    const PatchTileBox tb = patch_tile_box(plan, b, slot_lv);
+    const int nt = min(tb.ntx * tb.nty, kPatchMaxTiles);
+    for (int ti = slot_first; ti < nt; ti += slot_step) {
+      const long long sl = s_slot[slot_lv * kPatchMaxTiles + ti];
+      const unsigned long long mk = s_mask[slot_lv * kPatchMaxTiles + ti];
+      if (sl >= 0 && mk != 0ull) plan.marks[sl] = mk;
+    }
   }
   PATCH_STAMP(5);
   // The gathers: per (level, pass) 16 tap loads in flight, then the dots and the reduction.  (Measured and dropped, round 4:

@@ -369,6 +369,28 @@ struct T3Class {
   int base[kPatchMaxLevels];        // class-local index of the level's first tile, or -1 when the level is not in the class
 };
 
+// Which (n, m) pair and which tile workgroup jb of XCD `xcd` takes.  An XCD owns a contiguous run of (n, m) pairs (N * M / 8:
+// at the bench geometry the eight heads of one sample).  Round 3-4 walked it pair by pair -- all tiles of (n, 0), then all
+// tiles of (n, 1) ... -- so the eight workgroups that need the SAME query rows of grad_out / loc / attn (a query's eight
+// 96-byte head rows are one 768-byte run: six 128-byte lines shared by neighbouring heads) ran a whole pair's worth of
+// tiles apart, and by then the lines had left the 4 MB L2 (one sample's grad_out + loc + attn is 19 MB): FETCH_SIZE of the
+// tile kernels was 5.4x the algorithmic input.  Round 5: TILE-major -- the pairs of the XCD take the
+// same tile back to back, so a tile's hit rows are fetched once for all heads.  Measured (N = 8, head-major bf16 value, rocprofv3,
+// sigma 0 / 3 px): the 8 x 8-tile instance 162 -> 119 us / 226 -> 178 us; the 16 x 16-tile instance (two workgroups per CU: 64 per
+// XCD were already most of two heads' tiles) 110 -> 112 / 152 -> 151 us: it keeps the pair-major walk.  (plan.debug bit 64 flips
+// either choice for A/B runs: results are the same.)
+__device__ __forceinline__ void t3_order(const CoreDims &d, const PatchPlan &plan, int tiles, int xcd, int jb, bool tile_major,
+                                         int &nm, int &ct) {
+  const int per_xcd = (d.N * d.M + 7) >> 3;
+  if (tile_major == ((plan.debug & 64) != 0)) {
+    nm = xcd * per_xcd + jb / tiles;
+    ct = tiles - 1 - jb % tiles;
+  } else {
+    nm = xcd * per_xcd + jb % per_xcd;
+    ct = tiles - 1 - jb / per_xcd;
+  }
+}
+
 // ---- 16 x 16 tiles on EIGHT waves (512 threads) ----------------------------------------------------------------------
 // The 256-pixel instance is held to two workgroups per CU by its 64 KB of Wt, and the kernel is latency-bound (above): a
 // workgroup of 8 waves doubles the waves per CU at the same footprint.  Item = (hit, point, tap ROW): 64 x 4 x 2 = 512
@@ -620,9 +642,9 @@ void msda_bwd_d48_tile3_wide_kernel(const void *__restrict__ grad_out, const flo
   __shared__ Tile3LdsWide S;
   const int tiles = cls.tiles;
   const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
-  const int nm = xcd * ((d.N * d.M + 7) >> 3) + jb / tiles;
+  int nm, ct;
+  t3_order(d, plan, tiles, xcd, jb, false, nm, ct);
   if (nm >= d.N * d.M) return;
-  const int ct = tiles - 1 - jb % tiles;
   const int m = nm % d.M, n = nm / d.M;
   int l = 0, t = 0;
   for (int i = 0; i < plan.L; ++i)
@@ -639,9 +661,9 @@ void msda_bwd_d48_tile3_kernel(const void *__restrict__ grad_out, const float *_
   // first: they are reached by the most queries, i.e. they are the longest-running workgroups
   const int tiles = cls.tiles;
   const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
-  const int nm = xcd * ((d.N * d.M + 7) >> 3) + jb / tiles;
+  int nm, ct;
+  t3_order(d, plan, tiles, xcd, jb, WPX != 256, nm, ct);
   if (nm >= d.N * d.M) return;
-  const int ct = tiles - 1 - jb % tiles;
   const int m = nm % d.M, n = nm / d.M;
   int l = 0, t = 0;
   for (int i = 0; i < plan.L; ++i)
