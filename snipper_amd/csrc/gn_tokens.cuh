@@ -220,16 +220,18 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const uint16_t *x, 
 // the same over SEVERAL source tensors of one shape (blockIdx.y = source * n_images + image): the column sums of a sum of
 // tensors without forming the sum -- level_embed's gradient from the six gradients of its six uses (fused.LevelPosTokens)
 struct ColsumSrcs { const uint16_t *p[8]; };
-__global__ __launch_bounds__(256) void colsum_partial_multi_kernel(ColsumSrcs srcs, int n_images, long long image_stride,
+__global__ __launch_bounds__(256) void colsum_partial_multi_kernel(ColsumSrcs srcs, int n_src, long long image_stride,
                                                                    int rows_per_seg, int C, int nblk, int rpp, float *part) {
+  // (blockIdx.y = image; the sources are summed HERE, row by row, so the second pass sees as many partial rows as for one
+  //  source -- with a partial row per (source, image, block) its 16 slices walked 3 072 rows serially: 82 us)
   __shared__ float lds[256 * 4];
   const int chunks = C / 4, chunk = threadIdx.x % chunks, rsub = threadIdx.x / chunks;
-  const int src = blockIdx.y / n_images, img = blockIdx.y - src * n_images;
-  const uint16_t *xi = srcs.p[src] + (long long)img * image_stride + chunk * 4;
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int r = blockIdx.x * rpp + rsub; r < rows_per_seg; r += nblk * rpp) {
-    const float4 v = ln_load4(xi, 1, (long long)r * C);
-    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    for (int k = 0; k < n_src; ++k) {
+      const float4 v = ln_load4(srcs.p[k] + (long long)blockIdx.y * image_stride + chunk * 4, 1, (long long)r * C);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
   }
   *reinterpret_cast<float4 *>(lds + threadIdx.x * 4) = s;
   __syncthreads();

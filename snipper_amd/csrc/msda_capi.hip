@@ -182,8 +182,8 @@ int forward_d48(hipStream_t st, const VT *value, const int64_t *shapes, const in
                      : forward_d48_t<VT, 24>(st, value, shapes, lsi, loc, attn, d, out, out_bf16);
 }
 
-template <int DT>
-int backward_d48_f32_t(hipStream_t st, const float *grad_out, const float *value, const int64_t *shapes,
+template <int DT, typename VT = float>
+int backward_d48_f32_t(hipStream_t st, const float *grad_out, const VT *value, const int64_t *shapes,
                        const int64_t *lsi, const float *loc, const float *attn, CoreDims d,
                        float *grad_value, float *grad_loc, float *grad_attn, int go_bf16) {
   constexpr int kRows = kD48Block / (DT / 3);
@@ -194,10 +194,10 @@ int backward_d48_f32_t(hipStream_t st, const float *grad_out, const float *value
   const size_t lds = (size_t)kRows * (LP * sizeof(BwdRecord) + 16);
   if (LP == 12 && d.P == 4) {
     g_last_variant = DT == kD48 ? "d48_lp12" : "d24_lp12";
-    hipLaunchKernelGGL((msda_bwd_d48_f32_kernel<12, DT>), dim3(nblk_padded), dim3(kD48Block), lds, st, grad_out, value, shapes, lsi, loc, attn, d, grad_value, grad_loc, grad_attn, nblk_padded, go_bf16);
+    hipLaunchKernelGGL((msda_bwd_d48_f32_kernel<12, DT, VT>), dim3(nblk_padded), dim3(kD48Block), lds, st, grad_out, value, shapes, lsi, loc, attn, d, grad_value, grad_loc, grad_attn, nblk_padded, go_bf16);
   } else {
     g_last_variant = DT == kD48 ? "d48" : "d24";
-    hipLaunchKernelGGL((msda_bwd_d48_f32_kernel<0, DT>), dim3(nblk_padded), dim3(kD48Block), lds, st, grad_out, value, shapes, lsi, loc, attn, d, grad_value, grad_loc, grad_attn, nblk_padded, go_bf16);
+    hipLaunchKernelGGL((msda_bwd_d48_f32_kernel<0, DT, VT>), dim3(nblk_padded), dim3(kD48Block), lds, st, grad_out, value, shapes, lsi, loc, attn, d, grad_value, grad_loc, grad_attn, nblk_padded, go_bf16);
   }
   return launch_status();
 }
@@ -510,8 +510,16 @@ int snipper_msda_backward_ex(void *stream, const snipper_msda_config *cfg, const
         return backward_d48_patch<uint16_t>(st, grad_out, (const uint16_t *)value, (const float *)loc, (const float *)attn, d,
                                             plan, workspace, (float *)grad_value, (float *)grad_loc, (float *)grad_attn, 1, mf);
     }
-    if (d.head_major) return SNIPPER_E_UNSUPPORTED;       // (bf16 value without the owner path: generic kernels, reference layout only)
+    if (d.head_major) return SNIPPER_E_UNSUPPORTED;       // (bf16 value without the owner path: the reference layout only)
     if (int rc = zero_grad_value(st, (float *)grad_value, d)) return rc;      // (the atomic kernels accumulate)
+    if (d48_eligible<float>(d, c.policy) && (long long)N * S * M * D * 4 < (1LL << 31)) {      // (float32 grad_value offsets)
+      // the decoder's shape (Lq = 60 queries) on a bf16 value: the tuned atomic kernel reading bf16 tap rows and bf16 rows
+      const float *go = (const float *)grad_out;
+      return d.D == kD48 ? backward_d48_f32_t<kD48, uint16_t>(st, go, (const uint16_t *)value, shapes, level_start, (const float *)loc,
+                                                               (const float *)attn, d, (float *)grad_value, (float *)grad_loc, (float *)grad_attn, 1)
+                         : backward_d48_f32_t<24, uint16_t>(st, go, (const uint16_t *)value, shapes, level_start, (const float *)loc,
+                                                             (const float *)attn, d, (float *)grad_value, (float *)grad_loc, (float *)grad_attn, 1);
+    }
     return backward_generic<uint16_t, float, float>(st, (const uint16_t *)grad_out, (const uint16_t *)value, shapes,
                                                     level_start, (const float *)loc, (const float *)attn, d,
                                                     (float *)grad_value, (float *)grad_loc, (float *)grad_attn);
@@ -1203,10 +1211,10 @@ int snipper_colsum_segments_multi_bf16(void *stream, const uint16_t *const *srcs
     a.p[i] = srcs[i] + elem_offset;
   }
   const GnPlan p = gn_plan(rows_per_seg, C);
-  hipLaunchKernelGGL(colsum_partial_multi_kernel, dim3(p.nblk, n_images * n_src), dim3((C / 4) * p.rpp), 0, (hipStream_t)stream, a,
-                     n_images, image_stride, rows_per_seg, C, p.nblk, p.rpp, (float *)workspace);
+  hipLaunchKernelGGL(colsum_partial_multi_kernel, dim3(p.nblk, n_images), dim3((C / 4) * p.rpp), 0, (hipStream_t)stream, a,
+                     n_src, image_stride, rows_per_seg, C, p.nblk, p.rpp, (float *)workspace);
   hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 15) / 16), dim3(256), 0, (hipStream_t)stream,
-                     (const float *)workspace, n_src * n_images * p.nblk, C, out);
+                     (const float *)workspace, n_images * p.nblk, C, out);
   return launch_status();
 }
 

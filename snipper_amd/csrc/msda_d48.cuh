@@ -242,9 +242,12 @@ __device__ __forceinline__ float row8_sum_d(float v) {
   return v;
 }
 
-template <int LP_T, int DT = kD48>
+// VT = storage type of `value` (float, or uint16_t = bfloat16 bits: the decoder's cross attention samples the bf16 projection
+// of the premixed memory, round 5); grad_value is float32 either way, so a tap's byte offset there is (4 / sizeof(VT)) x its
+// offset in `value` (both are (n S M + pixel M + m) rows of DT elements, or head-major alike).
+template <int LP_T, int DT = kD48, typename VT = float>
 __global__ __launch_bounds__(kD48Block) void msda_bwd_d48_f32_kernel(
-    const float *__restrict__ grad_out, const float *__restrict__ value,
+    const float *__restrict__ grad_out, const VT *__restrict__ value,
     const int64_t *__restrict__ shapes, const int64_t *__restrict__ level_start,
     const float *__restrict__ loc, const float *__restrict__ attn, CoreDims d,
     float *__restrict__ grad_value, float *__restrict__ grad_loc, float *__restrict__ grad_attn,
@@ -266,8 +269,8 @@ __global__ __launch_bounds__(kD48Block) void msda_bwd_d48_f32_kernel(
   if (live) {
     const int m = (int)(row % d.M);
     const long long n = row / ((long long)d.M * d.Lq);
-    const unsigned px_stride = msda_px_stride(d, DT * 4u);
-    const unsigned base = msda_row_base(d, (unsigned)n, (unsigned)m, DT * 4u);
+    const unsigned px_stride = msda_px_stride(d, DT * (unsigned)sizeof(VT));
+    const unsigned base = msda_row_base(d, (unsigned)n, (unsigned)m, DT * (unsigned)sizeof(VT));
     for (int s = lane; s < LP; s += G) {
       const int l = s / d.P;
       const int H = lv.H[l], W = lv.W[l];
@@ -296,10 +299,15 @@ __global__ __launch_bounds__(kD48Block) void msda_bwd_d48_f32_kernel(
   // the DPP reduction stays inside a 16-lane row, which is either fully live or fully dead).
   if (!live) return;
 
-  const unsigned value_bytes = (unsigned)((size_t)d.N * d.S * d.M * DT * 4u);
-  const auto vsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(value), 0, (int)value_bytes, 0x00020000);
-  const auto gsrc = __builtin_amdgcn_make_buffer_rsrc(grad_value, 0, (int)value_bytes, 0x00020000);
-  const unsigned lane_off = (unsigned)lane * 4u;
+  constexpr unsigned kVE = (unsigned)sizeof(VT), kGS = 4u / kVE;      // bytes per value element; grad_value offset = kGS x value offset
+  const unsigned value_bytes = (unsigned)((size_t)d.N * d.S * d.M * DT * kVE);
+  const auto vsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<VT *>(value), 0, (int)value_bytes, 0x00020000);
+  const auto gsrc = __builtin_amdgcn_make_buffer_rsrc(grad_value, 0, (int)(value_bytes * kGS), 0x00020000);
+  const unsigned lane_off = (unsigned)lane * kVE;
+  auto ldv = [&](unsigned o) -> float {
+    if constexpr (sizeof(VT) == 4) return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(vsrc, o, 0, 0));
+    else return __uint_as_float((unsigned)__builtin_amdgcn_raw_buffer_load_b16(vsrc, o, 0, 0) << 16);
+  };
   const size_t gi = (size_t)row * DT + lane;
   const float g0 = ld_go(grad_out, gi, go_bf16), g1 = ld_go(grad_out, gi + G, go_bf16), g2 = ld_go(grad_out, gi + 2 * G, go_bf16);
 
@@ -315,14 +323,14 @@ __global__ __launch_bounds__(kD48Block) void msda_bwd_d48_f32_kernel(
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const unsigned o = off[k] + lane_off;
-      const float v0 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(vsrc, o, 0, 0));
-      const float v1 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(vsrc, o + 4u * G, 0, 0));
-      const float v2 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(vsrc, o + 8u * G, 0, 0));
+      const float v0 = ldv(o), v1 = ldv(o + kVE * G), v2 = ldv(o + 2u * kVE * G);
       dot[k] = g0 * v0 + g1 * v1 + g2 * v2;
       const float wa = w[k] * a;
-      __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(wa * g0, gsrc, o, 0, 0);
-      __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(wa * g1, gsrc, o + 4u * G, 0, 0);
-      __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(wa * g2, gsrc, o + 8u * G, 0, 0);
+      // (an out-of-map tap: kOobOffset stays out of range in grad_value as well -- never doubled into range)
+      const unsigned og = off[k] == kOobOffset ? kOobOffset : o * kGS;
+      __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(wa * g0, gsrc, og, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(wa * g1, gsrc, og + 4u * G, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(wa * g2, gsrc, og + 8u * G, 0, 0);
     }
     float pa = w[0] * dot[0] + w[1] * dot[1] + w[2] * dot[2] + w[3] * dot[3];
     float px = hh * (dot[1] - dot[0]) + lh * (dot[3] - dot[2]);

@@ -198,6 +198,8 @@ def test_hip_bf16_against_fp32_oracle(name):
     assert out.dtype == torch.bfloat16
     np.testing.assert_allclose(out.float().cpu().numpy(), ref_out, rtol=2 ** -7, atol=2e-2)
     gv, gl, ga = MSDA.ms_deform_attn_backward(v_b.to(DEV), ts, ti, tl, ta, go_b.to(DEV), 64)
+    # round 5: a bf16 value off the encoder shape (the decoder's premixed cross attention) takes the tuned atomic kernel
+    assert _lib.last_variant().startswith(("d48", "d24")), _lib.last_variant()
     np.testing.assert_allclose(gv.float().cpu().numpy(), ref_gv, rtol=2 ** -7, atol=2e-2)
     np.testing.assert_allclose(ga.cpu().numpy(), ref_ga, rtol=1e-3, atol=1e-3)
     scale = float(np.abs(ref_gl).max())
