@@ -92,7 +92,7 @@ __global__ __launch_bounds__(kLnThreads) void ln_fused_fwd_kernel(LnFwdArgs a) {
   if (row >= a.rows) return;                       // whole waves leave together: no partial-EXEC shuffles below
   const long long base = (long long)row * a.C;
   const float keep_scale = a.p > 0.f ? 1.f / (1.f - a.p) : 1.f;
-  const uint32_t thresh = (uint32_t)fminf(a.p * 4294967296.f, 4294967040.f);
+  const uint32_t thresh16 = (uint32_t)fminf(a.p * 65536.f + 0.5f, 65535.f);
   float4 v[kLnMaxIter];
   float sum = 0.f;
   const float xm = a.x_mean ? a.x_mean[row] : 0.f, xr = a.x_mean ? a.x_rstd[row] : 1.f;
@@ -110,9 +110,14 @@ __global__ __launch_bounds__(kLnThreads) void ln_fused_fwd_kernel(LnFwdArgs a) {
       if (a.z) {
         float4 z = ln_load4(a.z, a.z_dt, base + c);
         if (a.p > 0.f) {
-          const uint32_t e = (uint32_t)(base + c);
-          const bool k0 = ln_rand(e, a.seed_lo, a.seed_hi) >= thresh, k1 = ln_rand(e + 1, a.seed_lo, a.seed_hi) >= thresh;
-          const bool k2 = ln_rand(e + 2, a.seed_lo, a.seed_hi) >= thresh, k3 = ln_rand(e + 3, a.seed_lo, a.seed_hi) >= thresh;
+          // ONE counter-based hash per 4-element chunk (a function of (seed, element index), as before) + one xorshift32 step
+          // give the chunk's four 16-bit uniforms, compared with p * 2^16 (csrc/wres_gemm_bf16.cuh's scheme).  Round 1-4
+          // hashed every element twice over: 16 v_mul_lo_u32 per chunk, a quarter-rate instruction -- a third of this
+          // kernel's vector time for bits the backward reads from `keep` anyway.
+          uint32_t h1 = ln_rand((uint32_t)(base + c), a.seed_lo, a.seed_hi) | 1u, h2 = h1;
+          h2 ^= h2 << 13; h2 ^= h2 >> 17; h2 ^= h2 << 5;
+          const bool k0 = (h1 & 0xffffu) >= thresh16, k1 = (h1 >> 16) >= thresh16;
+          const bool k2 = (h2 & 0xffffu) >= thresh16, k3 = (h2 >> 16) >= thresh16;
           z.x = k0 ? z.x * keep_scale : 0.f; z.y = k1 ? z.y * keep_scale : 0.f;
           z.z = k2 ? z.z * keep_scale : 0.f; z.w = k3 ? z.w * keep_scale : 0.f;
           if (a.keep) a.keep[((long long)row * a.C + c) >> 2] = (uint8_t)(k0 | (k1 << 1) | (k2 << 2) | (k3 << 3));

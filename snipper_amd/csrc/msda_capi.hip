@@ -353,15 +353,20 @@ int backward_d48_patch(hipStream_t st, const void *grad_out, const VT *value, co
       //  the read-modify-write of grad_value)
       // two instances by tile size (their LDS footprints differ 2.4x: two against five workgroups per CU); small tiles first:
       // they hold the longest-running workgroups (coarse levels)
-      T3Class big{}, small{};
+      T3Class big{}, small{}, tiny{};      // 16 x 16 | 8 x 8 | 4 x 4 and smaller tiles: one kernel instance each
       for (int l = 0; l < kPatchMaxLevels; ++l) {
-        big.base[l] = small.base[l] = -1;
+        big.base[l] = small.base[l] = tiny.base[l] = -1;
         if (l >= plan.L) continue;
-        T3Class &c = plan.lv[l].shift >= 4 ? big : small;
+        T3Class &c = plan.lv[l].shift >= 4 ? big : (plan.lv[l].shift == 3 ? small : tiny);
         c.base[l] = c.tiles;
         c.tiles += plan.lv[l].ntx * plan.lv[l].nty;
       }
       const long long nm8 = ((nm + 7) / 8) * 8;
+      if (tiny.tiles) {
+        hipLaunchKernelGGL(msda_bwd_d48_tile3_kernel<16>, dim3((unsigned)(nm8 * tiny.tiles)), dim3(kPatchThreads), 0, st, grad_out,
+                           loc, attn, d, plan, tiny, grad_value);
+        if (int rc = launch_status()) return rc;
+      }
       if (small.tiles) {
         hipLaunchKernelGGL(msda_bwd_d48_tile3_kernel<64>, dim3((unsigned)(nm8 * small.tiles)), dim3(kPatchThreads), 0, st, grad_out,
                            loc, attn, d, plan, small, grad_value);

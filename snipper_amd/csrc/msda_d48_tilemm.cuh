@@ -669,13 +669,11 @@ void msda_bwd_d48_tile3_kernel(const void *__restrict__ grad_out, const float *_
   for (int i = 0; i < plan.L; ++i)
     if (cls.base[i] >= 0 && ct >= cls.base[i]) { l = i; t = ct - cls.base[i]; }
   const unsigned char *go = reinterpret_cast<const unsigned char *>(grad_out);
-  const int shift = plan.lv[l].shift;
-  if constexpr (WPX == 256) {
-    tile3_body<16>(S, go, loc, attn, d, plan, grad_value, n, m, l, t);
-  } else {
-    if (shift == 3) tile3_body<4>(S, go, loc, attn, d, plan, grad_value, n, m, l, t);
-    else tile3_body<1>(S, go, loc, attn, d, plan, grad_value, n, m, l, t);
-  }
+  // one body per instance (round 5; the 64-pixel instance used to carry the 16-pixel body as well and spilled 2 VGPRs + 4 SGPRs
+  // at its 96-register budget): 256 = 16 x 16 tiles, 64 = 8 x 8 tiles, 16 = 4 x 4 and smaller
+  if constexpr (WPX == 256) tile3_body<16>(S, go, loc, attn, d, plan, grad_value, n, m, l, t);
+  else if constexpr (WPX == 64) tile3_body<4>(S, go, loc, attn, d, plan, grad_value, n, m, l, t);
+  else tile3_body<1>(S, go, loc, attn, d, plan, grad_value, n, m, l, t);
 }
 
 }  // namespace snipper
