@@ -327,7 +327,7 @@ def msda_alg_bytes(d, bwd):
     return e * v + re * o + ge * v + ce * 6 * lp
 
 
-PMC_PROFILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r04_pmc_bench_step.csv")
+PMC_PROFILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r05_pmc_bench_step.csv")
 
 
 BWD_KERNELS = ("msda_bwd_d48_patchbin", "msda_bwd_d48_tile3", "msda_bwd_d48_far")   # query side; grad_value side (bf16 rows: two kernels, by tile size); far list
@@ -1189,7 +1189,7 @@ def main():
                                        (None, None, "the dominant launch is not the bf16 encoder backward the PMC profile covers"))
             line["roofline"] = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                 "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": corrected, "traffic_raw_counters": raw,
-                                "traffic_source": ("NOT measured in this run: read from the committed profiles/r04_pmc_bench_step.csv "
+                                "traffic_source": ("NOT measured in this run: read from the committed profiles/r05_pmc_bench_step.csv "
                                                    "(collected with THIS library: its source hash is recorded in the file and checked) = "
                                                    "rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE (separate passes, tools/collect_profiles.sh) of "
                                                    "this command at the same kernels, query-side + grad_value-side kernel; "
@@ -1199,12 +1199,19 @@ def main():
                                 "kernel": f"msda_{dom[0]}_{dom[1]} N={d['N']} Lq={d['Lq']}",
                                 "avg_launch_ms": round(avg_ms, 4), "alg_bytes_per_launch": bts,
                                 "launches_timed": len(times)}
+            # the same launch at trained-like offsets ("put the sigma = 3 figure beside the sigma = 0 one"):
+            # reference bias grid + N(0, sigma) px per coordinate, from the locality sweep after the timed region
+            if dom[0] == "bwd" and locality:
+                line["roofline"]["at_offset_sigma_px"] = {
+                    str(x["offset_sigma_px"]): {"avg_launch_ms": x["encoder_bwd_ms_per_launch"],
+                                                "frac": round(bts / (x["encoder_bwd_ms_per_launch"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
+                    for x in locality if x.get("encoder_bwd_ms_per_launch")}
             line["msda_launch_ms_per_step"] = {f"{k[0]}_{k[1]}_N{k[2]}_Lq{k[3]}": round(v / 2, 3) for k, v in tot.items()}
         if dense_launches:
             # the dense parts against the MFMA peak.  Aggregate over every GEMM-shaped launch of this
             # library in two eager steps (linear / weight-stationary / NN data gradient / weight gradient / 3x3 / stem; the
             # decoder-size float32 products are not in it): FLOPs of the products as defined (no padding) over the sum of
-            # the launches' durations (events on the launch stream); per-layer table: profiles/r04_backbone_roofline.csv
+            # the launches' durations (events on the launch stream); per-layer table: profiles/r05_backbone_roofline.csv
             fl = sum(x[2] for x in dense_launches)
             ms = sum(x[4] for x in dense_launches)
             by_kind = {}

@@ -652,8 +652,11 @@ void msda_bwd_d48_tile3_wide_kernel(const void *__restrict__ grad_out, const flo
   tile3_body_wide(S, reinterpret_cast<const unsigned char *>(grad_out), loc, attn, d, plan, grad_value, n, m, l, t);
 }
 
+#ifndef T3_SMALL_WAVES
+#define T3_SMALL_WAVES 5
+#endif
 template <int WPX>
-__global__ __launch_bounds__(kPatchThreads) __attribute__((amdgpu_waves_per_eu(WPX == 256 ? 2 : 5, WPX == 256 ? 2 : 5)))
+__global__ __launch_bounds__(kPatchThreads) __attribute__((amdgpu_waves_per_eu(WPX == 256 ? 2 : T3_SMALL_WAVES, WPX == 256 ? 2 : T3_SMALL_WAVES)))
 void msda_bwd_d48_tile3_kernel(const void *__restrict__ grad_out, const float *__restrict__ loc, const float *__restrict__ attn,
                                CoreDims d, PatchPlan plan, T3Class cls, float *__restrict__ grad_value) {
   __shared__ Tile3Lds<WPX> S;
