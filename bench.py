@@ -973,6 +973,18 @@ def main():
         h2 = time.perf_counter()
         print(f"[bench] issue {1e3 * (h1 - h0) / n_issue:.2f} ms/step, retire {1e3 * (h2 - h0) / n_issue:.2f} ms/step "
               f"({n_issue} steps)", file=sys.stderr)
+    if os.environ.get("SNIPPER_CPROFILE"):        # where the host's issue time goes, by Python function (development aid)
+        import cProfile, pstats
+        torch.cuda.synchronize()
+        pr = cProfile.Profile()
+        pr.enable()
+        for i in range(10):
+            step(i)
+        pr.disable()
+        torch.cuda.synchronize()
+        for key in ("tottime", "cumulative"):
+            st = pstats.Stats(pr, stream=sys.stderr)
+            st.sort_stats(key).print_stats(45)
     if os.environ.get("SNIPPER_HOST_REGIONS"):
         torch.cuda.synchronize()
         region_on[0] = True

@@ -257,6 +257,22 @@ int snipper_wgrad_conv3x3_bf16(void *stream, const uint16_t *G, const uint16_t *
  * stride-1 data gradient (no flipped copy of the weight). */
 int snipper_conv3x3_bf16(void *stream, const uint16_t *X, const uint16_t *W, const float *bias, uint16_t *Y,
                          int B, int H, int Wd, int Cin, int Cout, int stride, int relu, const uint16_t *gate, int flip_taps);
+/* Stride-1 3x3 convolution with the input patch of a 2-D output tile resident in LDS and the weight streamed from a PACKED
+ * copy (csrc/conv3x3_patch_bf16.cuh; same arithmetic as snipper_conv3x3_bf16 with stride 1 up to the order of the float32
+ * accumulation).  Replaces the same cuDNN / torchvision convolutions as snipper_conv3x3_bf16 (reference models/backbone.py:67-111).
+ *   snipper_conv3x3_pack_bf16: packs n weights in one launch.  src[i] = [cout[i]][3][3][cin[i]] bf16 (a channels_last conv
+ *     weight), dst[i] = cout[i] * 9 * cin[i] bf16, 16-byte aligned, cout and cin multiples of 64.  transposed[i] == 0: the
+ *     forward's weight.  != 0: the stride-1 DATA GRADIENT's weight (channel roles swapped, taps reversed): pass it to
+ *     snipper_conv3x3_patch_bf16 with Cin = cout[i], Cout = cin[i].
+ *   snipper_conv3x3_patch_supported: 1 when snipper_conv3x3_patch_bf16 takes the shape (Cin, Cout multiples of 64, W >= 4,
+ *     32-bit byte offsets), else 0.
+ *   snipper_conv3x3_patch_bf16: Y = act(conv(X, W, padding 1) + bias); X [B][H][W][Cin], Y [B][H][W][Cout] bf16; relu / gate as
+ *     snipper_conv3x3_bf16. */
+int snipper_conv3x3_pack_bf16(void *stream, int n, const void *const *src, void *const *dst, const int *cout, const int *cin,
+                              const int *transposed);
+int snipper_conv3x3_patch_supported(int B, int H, int Wd, int Cin, int Cout);
+int snipper_conv3x3_patch_bf16(void *stream, const uint16_t *X, const uint16_t *Wp, const float *bias, uint16_t *Y,
+                               int B, int H, int Wd, int Cin, int Cout, int relu, const uint16_t *gate);
 
 /* ---- element-wise fusions around the core op (csrc/msda_prologue.cuh) --------------------------------
  * dtype codes: 0 = float32, 1 = bfloat16 bits.

@@ -214,12 +214,19 @@ class _Conv3x3BN(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, scale, shift, stride, relu, gate_input=False, pregated=False):
-        from .dense import conv3x3_bf16
+        from .dense import conv3x3_bf16, conv3x3_patch_bf16, conv3x3_patch_supported
         from . import shadow
         w_eff = shadow.lookup(weight, scale)
         if w_eff is None or not w_eff.is_contiguous(memory_format=torch.channels_last):
             w_eff = (weight.float() * scale.view(-1, 1, 1, 1)).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
-        y = conv3x3_bf16(x, w_eff, shift, stride, relu)
+        # stride 1 with a packed shadow: the patch-resident kernel (csrc/conv3x3_patch_bf16.cuh), forward and data gradient
+        pk = shadow.lookup_packed(weight, scale) if (stride == 1 and shadow.lookup(weight, scale) is w_eff) else None
+        ctx.packed_t = None
+        if pk is not None and conv3x3_patch_supported(x.shape[0], x.shape[2], x.shape[3], x.shape[1], w_eff.shape[0]):
+            y = conv3x3_patch_bf16(x, pk[0], w_eff.shape[0], shift, relu)
+            ctx.packed_t = pk[1]
+        else:
+            y = conv3x3_bf16(x, w_eff, shift, stride, relu)
         ctx.w_t = shadow.lookup_t(weight) if shadow.lookup(weight, scale) is w_eff else None      # (this step's, if kept)
         ctx.stride, ctx.relu, ctx.wdtype, ctx.gate_input = stride, relu and not pregated, weight.dtype, gate_input
         ctx.save_for_backward(x, w_eff, scale, y if ctx.relu else None)
@@ -248,7 +255,10 @@ class _Conv3x3BN(torch.autograd.Function):
             # split-reduction kernel, BN scale folded into its second pass; float32, channels_last like the parameter
             dw = wgrad_conv3x3_bf16(g, x, ctx.stride, scale).to(ctx.wdtype)
         gate = x if ctx.gate_input else None      # x came out of a ReLU that left its backward to this node
-        if own_dgrad and ctx.stride == 1:
+        if own_dgrad and ctx.stride == 1 and ctx.packed_t is not None:
+            from .dense import conv3x3_patch_bf16
+            dx = conv3x3_patch_bf16(g, ctx.packed_t, cin, None, False, gate, dgrad=True)
+        elif own_dgrad and ctx.stride == 1:
             # stride 1: the data gradient is the same convolution with the taps reversed and the channel roles swapped
             # (the kernel reverses the taps itself; only the channel axes are swapped here)
             w_t = ctx.w_t if ctx.w_t is not None else w_eff.transpose(0, 1).contiguous(memory_format=torch.channels_last)

@@ -1,0 +1,258 @@
+// conv3x3_patch_bf16.cuh -- stride-1 3x3 convolution (NHWC, bf16 in / out, float32 accumulate) with the INPUT PATCH of a
+// 2-D output tile resident in LDS for all nine taps and the weights streamed straight into MFMA fragment registers (gfx950).
+//
+// Reference: the 3x3 convolutions of the ResNet-50 body behind /root/reference/models/backbone.py:67-111 (torchvision
+// Bottleneck.conv2; 13 of the 16 are stride 1) -- forward, and with the packed weight's channel roles swapped and taps reversed
+// their data gradients.
+//
+// Why (round 5, VERDICT r04 #1a): the implicit-GEMM kernels (csrc/gemm_bf16.cuh, csrc/conv3x3_ring_bf16.cuh) stage a fresh
+// 128-pixel x 64-channel activation tile AND a weight tile through LDS for every (tap, 64-channel slice): 24 KB written and
+// 48 KB read per 64 MFMAs of a workgroup -- 576 LDS cycles for 256 matrix cycles, so the LDS, not the matrix pipe, was their
+// ceiling (measured 11-17 % of the bf16 peak, profiles/r04_backbone_roofline.csv), and X was re-read from L2 nine times.
+// Here:
+//   * a workgroup owns a TH x TW tile of output pixels of one image (TH * TW <= 128, chosen by the host so that the image
+//     tiles with little padding: 5 x 25 at the 600 x 800 geometry).  Its input patch (TH + 2) x (TW + 2) pixels x 64 channels
+//     is written ONCE per 64-channel slice by LDS-DMA (buffer_load ... lds, 16 B per lane; pixels outside the image get an
+//     offset outside the descriptor and arrive as zeros: no border logic anywhere else), double-buffered across slices.  The
+//     nine taps read their fragments from shifted rows of the same patch: X crosses L2 -> LDS 1.5 x instead of 9 x.
+//   * the weights never touch LDS: the host keeps them PACKED in MFMA fragment order (conv3x3_pack_kernel: [Cout / 16]
+//     [Cin / 64][tap][k half][lane][8]), so a lane's operand is one 16-byte buffer load, contiguous per wave (1 KB), with a
+//     scalar offset -- and the next tap's weights are in flight while this tap multiplies.
+//   * LDS traffic per tap and 64-channel slice: 8 fragment reads per wave (32 KB per workgroup) for 32 MFMAs per wave: half the
+//     matrix time instead of 2.25 x.
+//   * rows of 128 B with the 16-byte chunks XOR-swizzled by (row >> 1) & 7 (applied to the SOURCE chunk of the DMA): the 16
+//     rows of a fragment read are consecutive patch rows whatever the tap shift, and cover the 64 banks once.
+// Accumulator layout and store phase as the other kernels of this family (bias, ReLU or gate = ReLU backward, whole 16-byte
+// pieces of a pixel's channels staged through LDS).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "gemm_bf16.cuh"
+
+namespace snipper {
+
+constexpr int kCpThreads = 256;
+constexpr int kCpRows = 192;                 // patch rows per buffer: (TH + 2) * (TW + 2) <= 192 (six DMA rounds of 32 rows)
+constexpr int kCpBufB = kCpRows * 128;       // 24 KB
+constexpr int kCpPackMax = 32;
+
+struct ConvPatchArgs {
+  const uint16_t *X;        // [B][H][W][Cin]
+  const uint16_t *Wp;       // packed weight, conv3x3_pack_kernel
+  const float *bias;        // [Cout] or nullptr
+  uint16_t *Y;              // [B][H][W][Cout]
+  const uint16_t *gate;     // layout of Y or nullptr: outputs whose gate is not > 0 are written as 0
+  int B, H, Wd, Cin, Cout;
+  int TH, TW, nty, ntx;     // output tile and tiles per image
+};
+
+// ---- weight packing: one launch for a list of weights -----------------------------------------------------------------
+// dst piece (n16, c, tap, kh, lane) = 8 consecutive reduction channels  c * 64 + kh * 32 + (lane >> 4) * 8 ...  of output channel
+// n16 * 16 + (lane & 15) under tap `tap`.  transposed == 0: source W [Cout][3][3][Cin] as it is (forward).  transposed != 0:
+// the data gradient's weight -- output channels are the source's Cin, reduction channels its Cout, taps reversed:
+// element = W[reduction channel][8 - tap][output channel].
+struct ConvPackItem { const uint16_t *src; uint16_t *dst; int cout, cin, transposed, piece_end; };
+struct ConvPackBatch { ConvPackItem it[kCpPackMax]; int count; };
+
+__global__ __launch_bounds__(256) void conv3x3_pack_kernel(ConvPackBatch b) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  int i = 0;
+  while (i + 1 < b.count && p >= b.it[i].piece_end) ++i;
+  const ConvPackItem &t = b.it[i];
+  const int local = p - (i ? b.it[i - 1].piece_end : 0);
+  if (p >= t.piece_end) return;
+  const int n_out = t.transposed ? t.cin : t.cout, n_red = t.transposed ? t.cout : t.cin;     // roles in the packed weight
+  const int nc = n_red >> 6;
+  const int lane = local & 63, kh = (local >> 6) & 1;
+  int r = local >> 7;
+  const int tap = r % 9; r /= 9;
+  const int c = r % nc, n16 = r / nc;
+  const int o = n16 * 16 + (lane & 15), k0 = c * 64 + kh * 32 + (lane >> 4) * 8;
+  (void)n_out;
+  gemm_u32x4 v;
+  if (!t.transposed) {
+    v = *reinterpret_cast<const gemm_u32x4 *>(t.src + ((long long)o * 9 + tap) * t.cin + k0);
+  } else {
+    uint16_t e[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) e[j] = t.src[((long long)(k0 + j) * 9 + (8 - tap)) * t.cin + o];
+    v = gemm_u32x4{(unsigned)e[0] | ((unsigned)e[1] << 16), (unsigned)e[2] | ((unsigned)e[3] << 16),
+                   (unsigned)e[4] | ((unsigned)e[5] << 16), (unsigned)e[6] | ((unsigned)e[7] << 16)};
+  }
+  reinterpret_cast<gemm_u32x4 *>(t.dst)[local] = v;
+}
+
+// ---- the convolution ---------------------------------------------------------------------------------------------------
+// BN = 128 or 64 output channels per workgroup; four waves as 2 (pixels) x 2 (channels): a wave multiplies 64 pixels x BN / 2
+// channels.
+template <bool RELU, int BN>
+__global__ __launch_bounds__(kCpThreads) __attribute__((amdgpu_waves_per_eu(2, 3)))
+void conv3x3_patch_kernel(ConvPatchArgs g) {
+  constexpr int NI = BN / 32, CTS = BN + 8;
+  static_assert(2 * kCpBufB >= 128 * CTS * 2, "the staging tile of the store phase lives in the patch buffers");
+  __shared__ __attribute__((aligned(128))) unsigned char smem[2 * kCpBufB];       // ONE LDS object
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave & 1, wn = wave >> 1;
+  const int tiles_n = g.Cout / BN, tpi = g.nty * g.ntx, tiles_m = g.B * tpi;
+  const int xcd = blockIdx.x & 7, jb = (int)(blockIdx.x >> 3);
+  const int tm = xcd + 8 * (jb / tiles_n), tn = jb % tiles_n;
+  if (tm >= tiles_m) return;
+  const int b = tm / tpi, tt = tm - b * tpi;
+  const int tyi = tt / g.ntx, txi = tt - tyi * g.ntx;
+  const int y0 = tyi * g.TH, x0 = txi * g.TW, n0 = tn * BN;
+  const int PW = g.TW + 2, prow_n = (g.TH + 2) * PW;
+  const int nc = g.Cin >> 6;
+
+  // ---- DMA geometry: piece p = tid + 256 j: patch row r = p >> 3 = (tid >> 3) + 32 j, slot p & 7 holds source chunk
+  // (p & 7) ^ ((r >> 1) & 7) = (tid & 7) ^ ((tid >> 4) & 7)  (32 j does not change (r >> 1) & 7)
+  const unsigned src_chunk = (unsigned)(((tid & 7) ^ ((tid >> 4) & 7)) * 16);
+  unsigned xoff[6];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    const int r = (tid >> 3) + 32 * j;
+    const int py = r / PW, px = r - py * PW;
+    const int gy = y0 - 1 + py, gx = x0 - 1 + px;
+    const bool ok = r < prow_n && gy >= 0 && gy < g.H && gx >= 0 && gx < g.Wd;
+    xoff[j] = ok ? (unsigned)(((b * g.H + gy) * g.Wd + gx)) * (unsigned)g.Cin * 2u + src_chunk : 0x80000000u;
+  }
+  const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint16_t *>(g.X), 0, (int)((long long)g.B * g.H * g.Wd * g.Cin * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint16_t *>(g.Wp), 0, (int)((long long)g.Cout * 9 * g.Cin * 2), 0x00020000);
+  typedef __attribute__((address_space(3))) void lds_void;
+  const int lds_piece = (tid - lane) * 16;
+  auto issue_round = [&](int c, int j) {                  // round j (0..5) of slice c's patch into buffer c & 1
+    unsigned char *dst = smem + (c & 1) * kCpBufB + lds_piece + 4096 * j;
+    const unsigned off = (xoff[j] & 0x80000000u) ? 0x80000000u : xoff[j] + (unsigned)c * 128u;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrc, (lds_void *)dst, 16, off, 0, 0, 0);
+  };
+
+  // ---- fragment addressing.  Pixel i = wm * 64 + 16 j + (lane & 15) of the tile (clamped into it: the results of the padding
+  // lanes are dropped by the store phase) sits at patch row ty * PW + tx for tap (0, 0); tap (ky, kx) adds ky * PW + kx.
+  const int frag_row = lane & 15, g4 = lane >> 4;
+  int base_row[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int i = min(wm * 64 + 16 * j + frag_row, g.TH * g.TW - 1);
+    const int ty = i / g.TW;
+    base_row[j] = ty * PW + (i - ty * g.TW);
+  }
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem;
+  // weights: lane offset 16 * lane; scalar offset of (n16, c, tap, kh) = ((((n16 * nc + c) * 9 + tap) * 2 + kh) * 1024
+  const unsigned w_lane = (unsigned)lane * 16u;
+  const unsigned w_n16 = (unsigned)((n0 + wn * (BN / 2)) >> 4);
+  const unsigned w_istride = (unsigned)nc * 9u * 2048u;
+  auto load_w = [&](gemm_u32x4 (&w)[2][NI], int c, int tap) {
+    const unsigned s0 = ((w_n16 * (unsigned)nc + (unsigned)c) * 9u + (unsigned)tap) * 2048u;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      w[0][i] = __builtin_amdgcn_raw_buffer_load_b128(wsrc, w_lane, s0 + (unsigned)i * w_istride, 0);
+      w[1][i] = __builtin_amdgcn_raw_buffer_load_b128(wsrc, w_lane, s0 + (unsigned)i * w_istride + 1024u, 0);
+    }
+  };
+
+  gemm_f32x4 acc[NI][4];
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = gemm_f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+  for (int j = 0; j < 6; ++j) issue_round(0, j);
+  gemm_u32x4 wcur[2][NI], wnext[2][NI];
+  load_w(wcur, 0, 0);
+
+  for (int c = 0; c < nc; ++c) {
+    // slice c's patch has landed (this wave's DMAs; then everybody's), and every wave is done reading slice c - 1's buffer
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const unsigned bufb = lds0 + (unsigned)((c & 1) * kCpBufB);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      // the next slice's patch, spread over this slice's taps (rounds 0-5 behind taps 0-5), and the next tap's weights
+      if (tap < 6 && c + 1 < nc) issue_round(c + 1, tap);
+      if (tap < 8) load_w(wnext, c, tap + 1);
+      else if (c + 1 < nc) load_w(wnext, c + 1, 0);
+      const int shift = (tap / 3) * PW + (tap % 3);
+      // (inline assembly: next to a pending LDS-DMA hipcc puts vmcnt(0) in front of a compiler-visible LDS read; the waits
+      //  below carry the fragments as operands so that no MFMA is scheduled above them)
+      gemm_u32x4 xf[2][4];
+      unsigned a0[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const unsigned row = (unsigned)(base_row[j] + shift);
+        a0[j] = bufb + row * 128u + 16u * ((unsigned)g4 ^ ((row >> 1) & 7u));
+        asm volatile("ds_read_b128 %0, %1" : "=v"(xf[0][j]) : "v"(a0[j]));
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const unsigned a1 = a0[j] ^ 64u;
+        asm volatile("ds_read_b128 %0, %1" : "=v"(xf[1][j]) : "v"(a1));
+      }
+      asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(xf[0][0]), "+v"(xf[0][1]), "+v"(xf[0][2]), "+v"(xf[0][3]));
+#pragma unroll
+      for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(gemm_bf16x8, wcur[0][i]),
+                                                              __builtin_bit_cast(gemm_bf16x8, xf[0][j]), acc[i][j], 0, 0, 0);
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xf[1][0]), "+v"(xf[1][1]), "+v"(xf[1][2]), "+v"(xf[1][3]));
+#pragma unroll
+      for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(gemm_bf16x8, wcur[1][i]),
+                                                              __builtin_bit_cast(gemm_bf16x8, xf[1][j]), acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+        for (int i = 0; i < NI; ++i) wcur[kh][i] = wnext[kh][i];
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();                                   // the staging below overwrites the patch buffers
+
+  // ---- store phase: bias, ReLU; the tile's pixels x BN channels staged as rows of BN + 8 elements, then whole 16-byte pieces
+  uint16_t *stage = reinterpret_cast<uint16_t *>(smem);
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int nl = wn * (BN / 2) + i * 16 + (lane >> 4) * 4;
+    gemm_f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (g.bias) bv = *reinterpret_cast<const gemm_f32x4 *>(g.bias + n0 + nl);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = wm * 64 + j * 16 + (lane & 15);
+      gemm_f32x4 v = acc[i][j] + bv;
+      if (RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      uint2 o;
+      o.x = gemm_pack2(v.x, v.y);
+      o.y = gemm_pack2(v.z, v.w);
+      *reinterpret_cast<uint2 *>(stage + row * CTS + nl) = o;
+    }
+  }
+  __syncthreads();
+  constexpr int CH = BN / 8, ITER = 128 * CH / 256;
+#pragma unroll
+  for (int it = 0; it < ITER; ++it) {
+    const int idx = tid + 256 * it, row = idx / CH, ch = idx % CH;
+    if (row >= g.TH * g.TW) continue;
+    const int ty = row / g.TW, tx = row - ty * g.TW;
+    const int oy = y0 + ty, ox = x0 + tx;
+    if (oy >= g.H || ox >= g.Wd) continue;
+    const long long m = ((long long)b * g.H + oy) * g.Wd + ox;
+    uint4 v = *reinterpret_cast<const uint4 *>(stage + row * CTS + ch * 8);
+    if (g.gate) {
+      const uint4 a = *reinterpret_cast<const uint4 *>(g.gate + m * g.Cout + n0 + ch * 8);
+      auto keep = [](unsigned av, unsigned vv) {
+        const unsigned lo = ((av & 0x8000u) == 0u && (av & 0x7fffu) != 0u) ? 0x0000ffffu : 0u;
+        const unsigned hi = ((av & 0x80000000u) == 0u && (av & 0x7fff0000u) != 0u) ? 0xffff0000u : 0u;
+        return vv & (lo | hi);
+      };
+      v.x = keep(a.x, v.x); v.y = keep(a.y, v.y); v.z = keep(a.z, v.z); v.w = keep(a.w, v.w);
+    }
+    *reinterpret_cast<uint4 *>(g.Y + m * g.Cout + n0 + ch * 8) = v;
+  }
+}
+
+}  // namespace snipper

@@ -20,6 +20,7 @@
 #include "wgrad_wide_bf16.cuh"
 #include "misc_kernels.cuh"
 #include "conv3x3_ring_bf16.cuh"
+#include "conv3x3_patch_bf16.cuh"
 #include "small_linear.cuh"
 #include "small_attention.cuh"
 #include "match_cost.cuh"
@@ -362,6 +363,11 @@ int backward_d48_patch(hipStream_t st, const void *grad_out, const VT *value, co
         c.tiles += plan.lv[l].ntx * plan.lv[l].nty;
       }
       const long long nm8 = ((nm + 7) / 8) * 8;
+      if (plan.debug & 128) {         // (debug bit 128: the walk region by region instead of level after level, for A/B runs --
+                                      //  same results; measured SLOWER, profiles/r05_region_order_ab.txt)
+        t3_region_order(plan, tiny);
+        t3_region_order(plan, small);
+      }
       if (tiny.tiles) {
         hipLaunchKernelGGL(msda_bwd_d48_tile3_kernel<16>, dim3((unsigned)(nm8 * tiny.tiles)), dim3(kPatchThreads), 0, st, grad_out,
                            loc, attn, d, plan, tiny, grad_value);
@@ -1292,6 +1298,76 @@ int snipper_conv3x3_bf16(void *stream, const uint16_t *X, const uint16_t *W, con
     hipLaunchKernelGGL((conv3x3_bf16_kernel<true, 128>), grid, dim3(kGemmThreads), 0, (hipStream_t)stream, g);
   else
     hipLaunchKernelGGL((conv3x3_bf16_kernel<false, 128>), grid, dim3(kGemmThreads), 0, (hipStream_t)stream, g);
+  return launch_status();
+}
+
+namespace {
+// output tile of the patch-resident 3x3 kernel (csrc/conv3x3_patch_bf16.cuh): TH x TW <= 128 pixels whose input patch
+// (TH + 2) x (TW + 2) fits the kernel's 192 LDS rows, with the fewest tiles per image (then the smallest patch)
+bool conv_patch_tile(int H, int Wd, int &TH, int &TW) {
+  long long best = -1;
+  for (int tw = 4; tw <= 62 && tw <= std::max(Wd, 4); ++tw) {
+    int th = std::min(128 / tw, H);
+    while (th >= 1 && (th + 2) * (tw + 2) > kCpRows) --th;
+    if (th < 1) continue;
+    const long long tiles = (long long)((H + th - 1) / th) * ((Wd + tw - 1) / tw);
+    const long long cost = tiles * 1024 + (th + 2) * (tw + 2);
+    if (best < 0 || cost < best) { best = cost; TH = th; TW = tw; }
+  }
+  return best >= 0;
+}
+bool conv_patch_ok(int B, int H, int Wd, int Cin, int Cout) {
+  return B > 0 && H > 0 && Wd >= 4 && Cin > 0 && Cout > 0 && Cin % 64 == 0 && Cout % 64 == 0 &&
+         (long long)B * H * Wd * Cin < (1LL << 30) && (long long)B * H * Wd * Cout < (1LL << 30);
+}
+}  // namespace
+
+int snipper_conv3x3_patch_supported(int B, int H, int Wd, int Cin, int Cout) { return conv_patch_ok(B, H, Wd, Cin, Cout) ? 1 : 0; }
+
+int snipper_conv3x3_pack_bf16(void *stream, int n, const void *const *src, void *const *dst, const int *cout, const int *cin,
+                              const int *transposed) {
+  if (n < 0 || (n > 0 && (!src || !dst || !cout || !cin || !transposed))) return SNIPPER_E_NULL;
+  for (int lo = 0; lo < n; lo += kCpPackMax) {
+    ConvPackBatch b{};
+    b.count = std::min(n - lo, kCpPackMax);
+    long long pieces = 0;
+    for (int i = 0; i < b.count; ++i) {
+      const int co = cout[lo + i], ci = cin[lo + i], tr = transposed[lo + i] ? 1 : 0;
+      if (!src[lo + i] || !dst[lo + i]) return SNIPPER_E_NULL;
+      if (co <= 0 || ci <= 0 || co % 64 || ci % 64 || (((uintptr_t)src[lo + i] | (uintptr_t)dst[lo + i]) & 15)) return SNIPPER_E_SHAPE;
+      pieces += (long long)co * ci * 9 / 8;
+      if (pieces >= (1LL << 31)) return SNIPPER_E_SHAPE;
+      b.it[i] = ConvPackItem{(const uint16_t *)src[lo + i], (uint16_t *)dst[lo + i], co, ci, tr, (int)pieces};
+    }
+    hipLaunchKernelGGL(conv3x3_pack_kernel, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, (hipStream_t)stream, b);
+    if (int rc = launch_status()) return rc;
+  }
+  return SNIPPER_OK;
+}
+
+int snipper_conv3x3_patch_bf16(void *stream, const uint16_t *X, const uint16_t *Wp, const float *bias, uint16_t *Y,
+                               int B, int H, int Wd, int Cin, int Cout, int relu, const uint16_t *gate) {
+  if (!X || !Wp || !Y) return SNIPPER_E_NULL;
+  if (gate && (((uintptr_t)gate & 15) || relu)) return SNIPPER_E_SHAPE;
+  if (!conv_patch_ok(B, H, Wd, Cin, Cout) || (((uintptr_t)X | (uintptr_t)Wp | (uintptr_t)Y) & 15)) return SNIPPER_E_SHAPE;
+  int TH = 0, TW = 0;
+  if (!conv_patch_tile(H, Wd, TH, TW)) return SNIPPER_E_SHAPE;
+  const int nty = (H + TH - 1) / TH, ntx = (Wd + TW - 1) / TW;
+  const ConvPatchArgs g{X, Wp, bias, Y, gate, B, H, Wd, Cin, Cout, TH, TW, nty, ntx};
+  const long long tiles_m = (long long)B * nty * ntx;
+  // 128 output channels per workgroup unless that leaves CUs without one (SNIPPER_CONV_PATCH_MIN128: workgroups below which
+  // the 64-channel instance is taken)
+  static const long long min128 = [] { const char *e = getenv("SNIPPER_CONV_PATCH_MIN128"); return e ? atoll(e) : 256LL; }();
+  const bool n128 = Cout % 128 == 0 && tiles_m * (Cout / 128) >= min128;
+  const int bn = n128 ? 128 : 64;
+  const dim3 grid((unsigned)((Cout / bn) * 8 * ((tiles_m + 7) / 8)));
+  if (n128) {
+    if (relu) hipLaunchKernelGGL((conv3x3_patch_kernel<true, 128>), grid, dim3(kCpThreads), 0, (hipStream_t)stream, g);
+    else hipLaunchKernelGGL((conv3x3_patch_kernel<false, 128>), grid, dim3(kCpThreads), 0, (hipStream_t)stream, g);
+  } else {
+    if (relu) hipLaunchKernelGGL((conv3x3_patch_kernel<true, 64>), grid, dim3(kCpThreads), 0, (hipStream_t)stream, g);
+    else hipLaunchKernelGGL((conv3x3_patch_kernel<false, 64>), grid, dim3(kCpThreads), 0, (hipStream_t)stream, g);
+  }
   return launch_status();
 }
 

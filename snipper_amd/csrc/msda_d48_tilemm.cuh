@@ -364,10 +364,67 @@ __device__ __forceinline__ void tile3_body(LDS &S, const unsigned char *__restri
 }
 
 // the tiles one kernel instance serves: levels whose tiles have <= WPX pixels (and, for WPX = 256, more than 64)
+constexpr int kT3OrderMax = 768;
 struct T3Class {
   int tiles;                        // per (n, m)
   int base[kPatchMaxLevels];        // class-local index of the level's first tile, or -1 when the level is not in the class
+  // order[k] = class-local index of the k-th tile of the walk when `ordered` (t3_region_order below), else the walk is
+  // tiles - 1 ... 0 (coarse levels first)
+  int ordered;
+  uint16_t order[kT3OrderMax];
 };
+
+// The walk of a class with several levels, REGION by region (round 5).  A query's grad_out / loc / attn rows are needed by
+// the tiles around its reference point on EVERY level; walking level after level touched each row in as many separate
+// time windows as there are levels, a sample's 19 MB apart (L2: 4 MB), so the tile kernels fetched 2.7 x their input from
+// HBM even with the heads of a tile back to back.  Regions = the tiles of the class's coarsest level; a finer tile belongs
+// to the region its centre falls in; the walk takes a region's coarse tile, then its finer tiles level by level, then the
+// next region -- all uses of a row fall within one or two regions of the walk.
+// MEASURED SLOWER than level after level (N = 8, 600 x 800, sigma 0 / 3 / 8 px: 198-202 against 177-181 us, 272 against 247-258,
+// 328-336 against 306-310; profiles/r05_region_order_ab.txt): kept behind debug bit 128 for A/B runs only.
+inline void t3_region_order(const PatchPlan &plan, T3Class &c) {
+  c.ordered = 0;
+  int lv[kPatchMaxLevels], nl = 0;
+  for (int l = 0; l < plan.L; ++l)
+    if (c.base[l] >= 0) lv[nl++] = l;
+  if (nl < 2 || c.tiles > kT3OrderMax) return;
+  for (int i = 1; i < nl; ++i)                      // coarse (fewest tiles) first; ties keep the higher level first
+    for (int j = i; j > 0; --j) {
+      const PatchLevel &a = plan.lv[lv[j - 1]], &b = plan.lv[lv[j]];
+      if (b.ntx * b.nty < a.ntx * a.nty || (b.ntx * b.nty == a.ntx * a.nty && lv[j] > lv[j - 1])) std::swap(lv[j - 1], lv[j]);
+      else break;
+    }
+  const PatchLevel &C = plan.lv[lv[0]];
+  if (C.nty > 64 || C.ntx > 64) return;
+  const long long ec = 1 << C.shift;
+  // lo[i][r] = first tile row / column of level lv[i] whose centre lies in region row / column >= r (monotone in the tile index)
+  int ylo[kPatchMaxLevels][66], xlo[kPatchMaxLevels][66];
+  for (int i = 0; i < nl; ++i) {
+    const PatchLevel &A = plan.lv[lv[i]];
+    const long long e = 1 << A.shift;
+    auto fill = [&](int *lo, int n_tiles, long long size_a, long long size_c, int n_regions) {
+      int r = 0;
+      lo[0] = 0;
+      for (int t = 0; t < n_tiles; ++t) {
+        long long rt = ((2 * t * e + e) * size_c) / (2 * size_a * ec);
+        if (rt > n_regions - 1) rt = n_regions - 1;
+        while (r < rt) lo[++r] = t;
+      }
+      while (r < n_regions) lo[++r] = n_tiles;
+    };
+    fill(ylo[i], A.nty, A.H, C.H, C.nty);
+    fill(xlo[i], A.ntx, A.W, C.W, C.ntx);
+  }
+  int k = 0;
+  for (int ry = 0; ry < C.nty; ++ry)
+    for (int rx = 0; rx < C.ntx; ++rx)
+      for (int i = 0; i < nl; ++i) {
+        const PatchLevel &A = plan.lv[lv[i]];
+        for (int ty = ylo[i][ry]; ty < ylo[i][ry + 1]; ++ty)
+          for (int tx = xlo[i][rx]; tx < xlo[i][rx + 1]; ++tx) c.order[k++] = (uint16_t)(c.base[lv[i]] + ty * A.ntx + tx);
+      }
+  c.ordered = (k == c.tiles) ? 1 : 0;
+}
 
 // Which (n, m) pair and which tile workgroup jb of XCD `xcd` takes.  An XCD owns a contiguous run of (n, m) pairs (N * M / 8:
 // at the bench geometry the eight heads of one sample).  Round 3-4 walked it pair by pair -- all tiles of (n, 0), then all
@@ -667,6 +724,7 @@ void msda_bwd_d48_tile3_kernel(const void *__restrict__ grad_out, const float *_
   int nm, ct;
   t3_order(d, plan, tiles, xcd, jb, WPX != 256, nm, ct);
   if (nm >= d.N * d.M) return;
+  if (cls.ordered) ct = cls.order[tiles - 1 - ct];
   const int m = nm % d.M, n = nm / d.M;
   int l = 0, t = 0;
   for (int i = 0; i < plan.L; ++i)

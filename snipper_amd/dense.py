@@ -122,27 +122,47 @@ def linear_wres_bf16(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch
     return out
 
 
+_TRANSPOSE_ARGS: dict = {}      # tuple of the tensors' ids -> (weak references, prepared argument arrays per launch)
+
+
 def transpose_batch_bf16(pairs) -> None:
     """dst[c][r] = src[r][c] for a list of (src [rows, cols], dst [cols, rows]) bf16 matrices (unit inner strides) in ONE
-    launch per 48 matrices (csrc/wres_gemm_bf16.cuh, transpose_batch_bf16_kernel)."""
+    launch per 48 matrices (csrc/wres_gemm_bf16.cuh, transpose_batch_bf16_kernel).  The argument arrays of a list that
+    recurs (the per-step refresh of the weight shadows: the same ~150 views every step) are built once."""
     import ctypes
+    import weakref
     pairs = list(pairs)
+    if not pairs:
+        return
     lib = _lib.load()
-    for lo in range(0, len(pairs), 48):
-        part = pairs[lo:lo + 48]
-        n = len(part)
-        for s_, d_ in part:
-            assert s_.dtype == torch.bfloat16 and d_.dtype == torch.bfloat16 and s_.stride(1) == 1 and d_.stride(1) == 1
-            assert d_.shape == (s_.shape[1], s_.shape[0]) and s_.is_cuda and d_.device == s_.device
-        src = (ctypes.c_void_p * n)(*[s_.data_ptr() for s_, _ in part])
-        dst = (ctypes.c_void_p * n)(*[d_.data_ptr() for _, d_ in part])
-        rows = (ctypes.c_int * n)(*[s_.shape[0] for s_, _ in part])
-        cols = (ctypes.c_int * n)(*[s_.shape[1] for s_, _ in part])
-        lds = (ctypes.c_longlong * n)(*[s_.stride(0) for s_, _ in part])
-        ldd = (ctypes.c_longlong * n)(*[d_.stride(0) for _, d_ in part])
-        with _lib.device_guard(part[0][0].device):
-            rc = lib.snipper_transpose_batch_bf16(_lib.raw_stream(part[0][0].device), n, src, dst, rows, cols, lds, ldd)
-        _lib.check(rc, "snipper_transpose_batch_bf16")
+    key = tuple(id(t) for pr in pairs for t in pr)
+    hit = _TRANSPOSE_ARGS.get(key)
+    if hit is not None and all(r() is t for r, t in zip(hit[0], (t for pr in pairs for t in pr))) and \
+            all(t.data_ptr() == ptr for ptr, t in zip(hit[2], (t for pr in pairs for t in pr))):
+        launches = hit[1]
+    else:
+        launches = []
+        for lo in range(0, len(pairs), 48):
+            part = pairs[lo:lo + 48]
+            n = len(part)
+            for s_, d_ in part:
+                assert s_.dtype == torch.bfloat16 and d_.dtype == torch.bfloat16 and s_.stride(1) == 1 and d_.stride(1) == 1
+                assert d_.shape == (s_.shape[1], s_.shape[0]) and s_.is_cuda and d_.device == s_.device
+            launches.append((n, (ctypes.c_void_p * n)(*[s_.data_ptr() for s_, _ in part]),
+                             (ctypes.c_void_p * n)(*[d_.data_ptr() for _, d_ in part]),
+                             (ctypes.c_int * n)(*[s_.shape[0] for s_, _ in part]),
+                             (ctypes.c_int * n)(*[s_.shape[1] for s_, _ in part]),
+                             (ctypes.c_longlong * n)(*[s_.stride(0) for s_, _ in part]),
+                             (ctypes.c_longlong * n)(*[d_.stride(0) for _, d_ in part])))
+        if len(_TRANSPOSE_ARGS) > 16:
+            _TRANSPOSE_ARGS.clear()
+        flat = [t for pr in pairs for t in pr]
+        _TRANSPOSE_ARGS[key] = ([weakref.ref(t) for t in flat], launches, [t.data_ptr() for t in flat])
+    dev = pairs[0][0].device
+    with _lib.device_guard(dev):
+        for n, src, dst, rows, cols, lds, ldd in launches:
+            rc = lib.snipper_transpose_batch_bf16(_lib.raw_stream(dev), n, src, dst, rows, cols, lds, ldd)
+            _lib.check(rc, "snipper_transpose_batch_bf16")
 
 
 def _gate_ptr(gate: Optional[torch.Tensor], like: torch.Tensor):
@@ -182,6 +202,65 @@ def conv3x3_bf16(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Ten
             bias.data_ptr() if bias is not None else None, out.data_ptr(), B, H, W, Cin, Cout, int(stride), int(relu), gp,
             int(flip_taps))
     _lib.check(rc, "snipper_conv3x3_bf16")
+    return out
+
+
+_PACK_ARGS: dict = {}
+
+
+def conv3x3_pack_bf16(items) -> None:
+    """Pack 3x3 convolution weights for ``conv3x3_patch_bf16`` in one launch (csrc/conv3x3_patch_bf16.cuh).  ``items``: a list
+    of (src, dst, transposed) -- src [Cout, Cin, 3, 3] bf16 in channels_last memory, dst a flat bf16 tensor of the same number
+    of elements; transposed = True packs the stride-1 data gradient's weight (channel roles swapped, taps reversed)."""
+    import ctypes
+    items = list(items)
+    if not items:
+        return
+    key = tuple((s_.data_ptr(), d_.data_ptr(), bool(t_)) for s_, d_, t_ in items)
+    args = _PACK_ARGS.get(key)
+    if args is None:
+        n = len(items)
+        for s_, d_, _ in items:
+            assert s_.is_cuda and s_.dtype == torch.bfloat16 and d_.dtype == torch.bfloat16 and s_.dim() == 4
+            assert tuple(s_.shape[2:]) == (3, 3) and s_.is_contiguous(memory_format=torch.channels_last)
+            assert d_.is_contiguous() and d_.numel() == s_.numel() and d_.device == s_.device
+        args = (n, (ctypes.c_void_p * n)(*[s_.data_ptr() for s_, _, _ in items]),
+                (ctypes.c_void_p * n)(*[d_.data_ptr() for _, d_, _ in items]),
+                (ctypes.c_int * n)(*[s_.shape[0] for s_, _, _ in items]), (ctypes.c_int * n)(*[s_.shape[1] for s_, _, _ in items]),
+                (ctypes.c_int * n)(*[int(bool(t_)) for _, _, t_ in items]))
+        if len(_PACK_ARGS) > 8:
+            _PACK_ARGS.clear()
+        _PACK_ARGS[key] = args
+    dev = items[0][0].device
+    with _lib.device_guard(dev):
+        rc = _lib.load().snipper_conv3x3_pack_bf16(_lib.raw_stream(dev), *args)
+    _lib.check(rc, "snipper_conv3x3_pack_bf16")
+
+
+def conv3x3_patch_supported(B: int, H: int, W: int, Cin: int, Cout: int) -> bool:
+    return bool(_lib.load().snipper_conv3x3_patch_supported(int(B), int(H), int(W), int(Cin), int(Cout)))
+
+
+def conv3x3_patch_bf16(x: torch.Tensor, packed: torch.Tensor, cout: int, bias: Optional[torch.Tensor] = None,
+                       relu: bool = False, gate: Optional[torch.Tensor] = None, dgrad: bool = False) -> torch.Tensor:
+    """act(conv2d(x, w, padding=1) + bias) for a weight packed by ``conv3x3_pack_bf16`` (stride 1): the input patch of a 2-D
+    output tile stays in LDS for all nine taps, the weight streams into registers (csrc/conv3x3_patch_bf16.cuh).
+    x [B, Cin, H, W] bf16 channels_last  ->  [B, cout, H, W] bf16 channels_last.  ``dgrad`` only labels the timing record."""
+    assert x.is_cuda and x.dtype == torch.bfloat16 and packed.dtype == torch.bfloat16
+    assert x.is_contiguous(memory_format=torch.channels_last)
+    B, Cin, H, W = x.shape
+    assert packed.numel() == cout * 9 * Cin
+    out = torch.empty((B, cout, H, W), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
+    if bias is not None and bias.dtype != torch.float32:
+        bias = bias.float()
+    gp, _keep = _gate_ptr(gate, out)
+    with _timed("conv3x3" + ("_dgrad" if dgrad else ""), (B, H, W, Cin, cout, 1), 2 * B * H * W * cout * 9 * Cin,
+                2 * (B * H * W * Cin + 9 * Cin * cout + B * H * W * cout * (2 if gate is not None else 1)), x.device), \
+            _lib.device_guard(x.device):
+        rc = _lib.load().snipper_conv3x3_patch_bf16(
+            _lib.raw_stream(x.device), x.data_ptr(), packed.data_ptr(), bias.data_ptr() if bias is not None else None,
+            out.data_ptr(), B, H, W, Cin, int(cout), int(relu), gp)
+    _lib.check(rc, "snipper_conv3x3_patch_bf16")
     return out
 
 

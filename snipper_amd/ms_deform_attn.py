@@ -26,6 +26,7 @@ as the reference's flag does.
 from __future__ import annotations
 
 import math
+from collections.abc import Sequence
 from typing import List, Optional
 
 import torch
@@ -56,6 +57,28 @@ def _level_scale(hw, dtype, device):
         t = torch.tensor([[w, h] for h, w in hw], dtype=dtype, device=device)
         _SCALE_CACHE[key] = t
     return t
+
+
+class _LazyList(Sequence):
+    """A list whose items are built when first looked at (the attention-visualisation lists of the reference,
+    ms_deform_attn.py:228-233: one entry per query frame)."""
+
+    def __init__(self, build, n):
+        self._build, self._n, self._items = build, n, None
+
+    def _get(self):
+        if self._items is None:
+            self._items, self._build = self._build(), None
+        return self._items
+
+    def __len__(self):
+        return self._n
+
+    def __getitem__(self, i):
+        return self._get()[i]
+
+    def __iter__(self):
+        return iter(self._get())
 
 
 class MSDeformAttn(nn.Module):
@@ -281,15 +304,20 @@ class MSDeformAttn(nn.Module):
 
     def _vis_lists(self, loc, prob, groups, N, Lq, M, L, P):
         locs = wts = None
-        if self.attention_vis:   # same lists as reference :228-233, built as views
-            locs, wts = [], []
-            pd = prob.detach()
-            ks = sorted({len(g) for g in groups})
-            scaled = {k: pd / k for k in ks}                  # one division per distinct group size, not per frame
-            for t1, g in enumerate(groups):
-                k = len(g)
-                locs.append(loc[:, t1].detach().unsqueeze(-2).expand(N, Lq, M, L, P, k, 2))
-                wts.append(scaled[k][:, t1].unsqueeze(-1).expand(N, Lq, M, L, P, k))
+        if self.attention_vis:   # same lists as reference :228-233, built as views -- and only when somebody looks at them
+            # (a training step never does: the decoder hands them through to the model's output tuple, model.py:221; building
+            #  them eagerly was one division launch and ~30 view operations per decoder layer and step)
+            sizes = [len(g) for g in groups]
+            ld, pd = loc.detach(), prob.detach()
+
+            def build_locs():
+                return [ld[:, t1].unsqueeze(-2).expand(N, Lq, M, L, P, k, 2) for t1, k in enumerate(sizes)]
+
+            def build_wts():
+                scaled = {k: pd / k for k in sorted(set(sizes))}      # one division per distinct group size, not per frame
+                return [scaled[k][:, t1].unsqueeze(-1).expand(N, Lq, M, L, P, k) for t1, k in enumerate(sizes)]
+
+            locs, wts = _LazyList(build_locs, len(sizes)), _LazyList(build_wts, len(sizes))
         return locs, wts
 
     # -- the reference's per-pair evaluation, for untied Linears ------------------------------

@@ -32,12 +32,15 @@ _merged: Dict[Tuple[int, int], "_Merged"] = {}
 
 
 class _Entry:
-    __slots__ = ("ref", "dst", "scale", "scale_full", "version", "dst_t")
+    __slots__ = ("ref", "dst", "scale", "scale_full", "version", "dst_t", "tap_pairs", "packed", "packed_t")
 
     def __init__(self, param, dst, scale=None):
         self.ref, self.dst, self.scale, self.version = weakref.ref(param), dst, scale, -1
         self.scale_full = None     # the BN scale expanded to the weight's shape AND strides (multi-tensor fast path)
         self.dst_t = None          # bf16 W^T [in, out], kept for the Linears whose data gradient wants it
+        self.tap_pairs = None      # 3x3 weights: the nine (source, destination) tap views of the batched transpose, built once
+        self.packed = None         # stride-1 3x3 weights in MFMA fragment order (csrc/conv3x3_patch_bf16.cuh), forward ...
+        self.packed_t = None       # ... and data gradient (channel roles swapped, taps reversed; trainable weights only)
 
 
 class _Merged:
@@ -72,6 +75,21 @@ def lookup_t(param: torch.Tensor) -> Optional[torch.Tensor]:
     if (e is not None and e.ref() is param and e.version == param._version and e.dst_t is not None and
             e.dst_t.device == param.device):
         return e.dst_t
+    return None
+
+
+# the patch-resident 3x3 kernel for the stride-1 convolutions (SNIPPER_CONV_PATCH=0: the implicit-GEMM kernels, for A/B runs)
+import os as _os
+CONV_PATCH = _os.environ.get("SNIPPER_CONV_PATCH", "1") != "0"
+
+
+def lookup_packed(param: torch.Tensor, scale: Optional[torch.Tensor] = None):
+    """(packed, packed_t) of a stride-1 3x3 convolution weight whose shadow is valid -- the folded bf16 weight in the fragment
+    order of csrc/conv3x3_patch_bf16.cuh for the forward and (trainable weights; else None) for the data gradient -- or None."""
+    e = _entries.get(id(param))
+    if (e is not None and e.packed is not None and e.ref() is param and e.version == param._version and
+            e.packed.device == param.device and (scale is None or e.scale is None or e.scale is scale)):
+        return e.packed, e.packed_t
     return None
 
 
@@ -154,7 +172,7 @@ class WeightShadows:
     @torch.no_grad()
     def refresh(self) -> None:
         """Bring every stale shadow up to date (multi-tensor launches; nothing to do for unchanged parameters)."""
-        mul_src, mul_scale, mul_dst, cp_src, cp_dst, tr = [], [], [], [], [], []
+        mul_src, mul_scale, mul_dst, cp_src, cp_dst, tr, packs = [], [], [], [], [], [], []
         for conv, bn in self.convs:
             w = conv.weight
             if not (w.is_cuda and w.dtype == torch.float32):
@@ -163,7 +181,15 @@ class WeightShadows:
             if e is None or e.ref() is not w or e.dst.device != w.device:
                 e = _entries[id(w)] = _Entry(w, torch.empty_like(w, dtype=torch.bfloat16), None)
             scale = bn.scale_bias()[0]
-            if (e.dst_t is None and w.dim() == 4 and tuple(w.shape[2:]) == (3, 3) and w.requires_grad and
+            patch = (CONV_PATCH and w.dim() == 4 and tuple(w.shape[2:]) == (3, 3) and tuple(conv.stride) == (1, 1) and
+                     w.is_contiguous(memory_format=torch.channels_last) and w.shape[0] % 64 == 0 and w.shape[1] % 64 == 0)
+            if patch and e.packed is None:
+                # a stride-1 3x3 convolution runs on the patch-resident kernel: its weight in fragment order, written by ONE
+                # pack launch below for all of them (and no tap-transposed copy: that kernel's data gradient has its own pack)
+                e.packed = torch.empty(w.numel(), dtype=torch.bfloat16, device=w.device)
+                if w.requires_grad:
+                    e.packed_t = torch.empty(w.numel(), dtype=torch.bfloat16, device=w.device)
+            if (not patch and e.dst_t is None and w.dim() == 4 and tuple(w.shape[2:]) == (3, 3) and w.requires_grad and
                     w.is_contiguous(memory_format=torch.channels_last) and w.shape[0] % 8 == 0 and w.shape[1] % 8 == 0):
                 # a trainable 3x3 convolution's data gradient multiplies by the weight with its channel roles swapped
                 # ([Cin, Cout, 3, 3], channels_last; backbone._Conv3x3BN): kept beside the shadow, written by the batched
@@ -172,8 +198,14 @@ class WeightShadows:
                                       device=w.device).contiguous(memory_format=torch.channels_last)
             if e.version != w._version or e.scale is not scale:
                 if e.dst_t is not None:
-                    src_t, dst_t = e.dst.permute(0, 2, 3, 1), e.dst_t.permute(0, 2, 3, 1)      # [Cout, 3, 3, Cin] / [Cin, 3, 3, Cout] views
-                    tr += [(src_t[:, ky, kx, :], dst_t[:, ky, kx, :]) for ky in range(3) for kx in range(3)]
+                    if e.tap_pairs is None:       # (18 slicing calls per weight: ~0.4 ms of host time per step when rebuilt every time)
+                        src_t, dst_t = e.dst.permute(0, 2, 3, 1), e.dst_t.permute(0, 2, 3, 1)  # [Cout, 3, 3, Cin] / [Cin, 3, 3, Cout] views
+                        e.tap_pairs = [(src_t[:, ky, kx, :], dst_t[:, ky, kx, :]) for ky in range(3) for kx in range(3)]
+                    tr += e.tap_pairs
+                if e.packed is not None:
+                    packs.append((e.dst, e.packed, False))
+                    if e.packed_t is not None:
+                        packs.append((e.dst, e.packed_t, True))
                 if e.scale is not scale or e.scale_full is None:
                     # frozen BatchNorm: built once.  A broadcast operand sends _foreach_mul down its one-kernel-per-tensor
                     # path (42 launches per step here); a full-size one with the weight's strides keeps it multi-tensor.
@@ -238,6 +270,9 @@ class WeightShadows:
             for d, w in zip(cp_dst, cp_src):
                 if isinstance(d, _Entry):
                     d.version = w._version
+        if packs:                               # (after the folded bf16 copies they read have been written)
+            from .dense import conv3x3_pack_bf16
+            conv3x3_pack_bf16(packs)
         if tr:                                  # W^T of the freshly written bf16 copies: one launch for all of them
             from .dense import transpose_batch_bf16
             transpose_batch_bf16(tr)

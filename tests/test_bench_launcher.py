@@ -64,3 +64,25 @@ def test_parent_starts_ranks_and_forwards_the_line(tmp_path):
     p = subprocess.run([sys.executable, str(driver), "--gpus", "2", "--fail"], capture_output=True, text=True, env=env,
                        timeout=300)
     assert p.returncode != 0                               # the child's failure is the parent's
+
+
+def test_pick_cpus_follows_the_gpus_numa_node(tmp_path):
+    """bench.pick_cpus against a made-up two-socket topology: ranks whose GPUs hang off the same node get consecutive
+    blocks of THAT node's CPUs, and a platform that does not expose the topology falls back to block = local rank."""
+    import bench
+    for node, cpus in ((0, "0-31,64-95"), (1, "32-63,96-127")):
+        d = tmp_path / "devices" / "system" / "node" / f"node{node}"
+        d.mkdir(parents=True)
+        (d / "cpulist").write_text(cpus + "\n")
+    node_of = {0: 0, 1: 0, 2: 1, 3: 1, 4: None}.get
+    allowed = list(range(128))
+    got = [bench.pick_cpus(r, 8, allowed, node_of=node_of, n_gpus=5, sysfs=str(tmp_path)) for r in range(5)]
+    assert got[0] == (list(range(0, 8)), 0, "numa")
+    assert got[1] == (list(range(8, 16)), 0, "numa")
+    assert got[2] == (list(range(32, 40)), 1, "numa")
+    assert got[3] == (list(range(40, 48)), 1, "numa")
+    assert got[4] == (list(range(32, 40)), None, "block")          # no topology: 8 x local rank over the allowed CPUs
+    # an affinity mask that leaves fewer than n CPUs of the node: the block rule again
+    cpus, node, rule = bench.pick_cpus(2, 8, list(range(0, 36)), node_of=node_of, n_gpus=5, sysfs=str(tmp_path))
+    assert rule == "block" and node == 1 and cpus == list(range(16, 24))
+    assert bench._parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]

@@ -101,6 +101,41 @@ def test_conv3x3_kernel(cin, cout, h, w, stride, relu):
     assert err <= 2e-2 * max(1.0, ref.abs().max().item()), err
 
 
+@pytest.mark.parametrize("cin,cout,h,w", [(64, 64, 150, 200), (128, 128, 75, 100), (256, 256, 38, 50), (512, 512, 19, 25),
+                                          (64, 192, 5, 7), (128, 64, 1, 9), (64, 64, 23, 4), (256, 128, 45, 80)])
+@pytest.mark.parametrize("mode", ["plain", "relu", "dgrad_gate"])
+def test_conv3x3_patch_kernel(cin, cout, h, w, mode):
+    """The patch-resident 3x3 kernel (csrc/conv3x3_patch_bf16.cuh) against F.conv2d in float32 on the same bf16-rounded
+    operands -- forward (with / without ReLU) and, with the weight packed transposed, the stride-1 data gradient with a ReLU
+    gate in its store phase -- and against the implicit-GEMM kernel it replaces (same operands, other summation order)."""
+    from snipper_amd.dense import conv3x3_bf16, conv3x3_pack_bf16, conv3x3_patch_bf16, conv3x3_patch_supported
+    nb = 3
+    assert conv3x3_patch_supported(nb, h, w, cin, cout)
+    g = torch.Generator().manual_seed(cin + 3 * h + w)
+    wt = (torch.randn(cout, cin, 3, 3, generator=g) / (3 * cin ** 0.5)).to(DEV).bfloat16().contiguous(memory_format=torch.channels_last)
+    packed = torch.empty(wt.numel(), dtype=torch.bfloat16, device=DEV)
+    packed_t = torch.empty(wt.numel(), dtype=torch.bfloat16, device=DEV)
+    conv3x3_pack_bf16([(wt, packed, False), (wt, packed_t, True)])
+    if mode == "dgrad_gate":
+        gy = torch.randn(nb, cout, h, w, generator=g).to(DEV).bfloat16().contiguous(memory_format=torch.channels_last)
+        gate = torch.randn(nb, cin, h, w, generator=g).to(DEV).bfloat16().contiguous(memory_format=torch.channels_last)
+        got = conv3x3_patch_bf16(gy, packed_t, cin, None, False, gate, dgrad=True)
+        ref = F.conv_transpose2d(gy.float(), wt.float(), None, 1, 1) * (gate.float() > 0)
+        old = conv3x3_bf16(gy, wt.transpose(0, 1).contiguous(memory_format=torch.channels_last), None, 1, False, gate, flip_taps=True)
+    else:
+        x = torch.randn(nb, cin, h, w, generator=g).to(DEV).bfloat16().contiguous(memory_format=torch.channels_last)
+        b = torch.randn(cout, generator=g).to(DEV)
+        got = conv3x3_patch_bf16(x, packed, cout, b, mode == "relu")
+        ref = F.conv2d(x.float(), wt.float(), b, 1, 1)
+        if mode == "relu":
+            ref = ref.relu()
+        old = conv3x3_bf16(x, wt, b, 1, mode == "relu")
+    assert got.shape == ref.shape and got.is_contiguous(memory_format=torch.channels_last)
+    scale = max(1.0, ref.abs().max().item())
+    assert (got.float() - ref).abs().max().item() <= 2e-2 * scale
+    assert (got.float() - old.float()).abs().max().item() <= 2e-2 * scale
+
+
 def test_conv3x3_bn_function_grads():
     """The autograd wrapper used by the bottleneck: gradients against the plain composition."""
     from snipper_amd.backbone import _Conv3x3BN

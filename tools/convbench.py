@@ -42,4 +42,20 @@ for cin, cout, h, w, st in SHAPES:
         torch.cuda.synchronize()
         rec["dgrad_s2_us"] = round(e0.elapsed_time(e1) * 1e3 / 20, 1)
         rec["dgrad_checksum"] = float(d.float().abs().sum())
+    if st == 1 and os.environ.get("SNIPPER_CONV_PATCH", "1") != "0":
+        from snipper_amd.dense import conv3x3_pack_bf16, conv3x3_patch_bf16
+        packed = torch.empty(wt.numel(), dtype=torch.bfloat16, device=dev)
+        conv3x3_pack_bf16([(wt, packed, False)])
+        rp = lambda: conv3x3_patch_bf16(x, packed, cout, b, True)
+        yp = rp()
+        for _ in range(3):
+            rp()
+        e0.record()
+        for _ in range(20):
+            rp()
+        e1.record()
+        torch.cuda.synchronize()
+        pus = e0.elapsed_time(e1) * 1e3 / 20
+        rec.update({"patch_us": round(pus, 1), "patch_frac_mfma": round(flops / pus / 1e6 / 2500, 3),
+                    "patch_max_abs_diff": float((yp.float() - y.float()).abs().max())})
     print(json.dumps(rec), flush=True)
