@@ -273,6 +273,18 @@ int snipper_conv3x3_pack_bf16(void *stream, int n, const void *const *src, void 
 int snipper_conv3x3_patch_supported(int B, int H, int Wd, int Cin, int Cout);
 int snipper_conv3x3_patch_bf16(void *stream, const uint16_t *X, const uint16_t *Wp, const float *bias, uint16_t *Y,
                                int B, int H, int Wd, int Cin, int Cout, int relu, const uint16_t *gate);
+/* The same machinery for a plain product on rows (the 1x1 convolutions of the ResNet body in NHWC, reference
+ * models/backbone.py:67-111, and Linears): Y[M, N] = act(X[M, K] . W^T + bias + res), X / Y / res / gate contiguous rows,
+ * N, K multiples of 64.
+ *   snipper_linear_pack_bf16: src[i] = [N[i]][K[i]] bf16 row-major -> dst[i]; transposed[i] != 0 packs the data gradient's
+ *     operand (pass it to snipper_linear_patch_bf16 with N and K swapped: dX[M, K] = dY[M, N] . W).
+ *   snipper_linear_patch_bf16: relu / gate as above (not both); res (8-byte aligned) is added before the activation;
+ *     bn = 0 (the launcher picks 128 or 64 output columns per workgroup), 64 or 128. */
+int snipper_linear_pack_bf16(void *stream, int n, const void *const *src, void *const *dst, const int *N, const int *K,
+                             const int *transposed);
+int snipper_linear_patch_supported(long long M, int N, int K);
+int snipper_linear_patch_bf16(void *stream, const uint16_t *X, const uint16_t *Wp, const float *bias, const uint16_t *res,
+                              uint16_t *Y, int M, int N, int K, int relu, const uint16_t *gate, int bn);
 
 /* ---- element-wise fusions around the core op (csrc/msda_prologue.cuh) --------------------------------
  * dtype codes: 0 = float32, 1 = bfloat16 bits.

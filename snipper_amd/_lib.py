@@ -115,6 +115,10 @@ EXPORTS = {
     "snipper_conv3x3_pack_bf16": ([c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p], c_int),
     "snipper_conv3x3_patch_supported": ([c_int] * 5, c_int),
     "snipper_conv3x3_patch_bf16": ([c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p], c_int),
+    "snipper_linear_pack_bf16": ([c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p], c_int),
+    "snipper_linear_patch_supported": ([c_longlong, c_int, c_int], c_int),
+    "snipper_linear_patch_bf16": ([c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                   c_void_p, c_int], c_int),
     "snipper_relu_dropout_backward_bf16": ([c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, ctypes.c_float], c_int),
 }
 

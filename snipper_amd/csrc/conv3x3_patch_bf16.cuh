@@ -44,6 +44,10 @@ struct ConvPatchArgs {
   const uint16_t *gate;     // layout of Y or nullptr: outputs whose gate is not > 0 are written as 0
   int B, H, Wd, Cin, Cout;
   int TH, TW, nty, ntx;     // output tile and tiles per image
+  // TAPS == 1 (a plain product Y[M, Cout] = X[M, Cin] . W^T on rows, same machinery without a halo): rows, an optional
+  // residual (layout of Y) added before the activation, and Y's row stride is Cout
+  int M;
+  const uint16_t *res;
 };
 
 // ---- weight packing: one launch for a list of weights -----------------------------------------------------------------
@@ -51,7 +55,7 @@ struct ConvPatchArgs {
 // n16 * 16 + (lane & 15) under tap `tap`.  transposed == 0: source W [Cout][3][3][Cin] as it is (forward).  transposed != 0:
 // the data gradient's weight -- output channels are the source's Cin, reduction channels its Cout, taps reversed:
 // element = W[reduction channel][8 - tap][output channel].
-struct ConvPackItem { const uint16_t *src; uint16_t *dst; int cout, cin, transposed, piece_end; };
+struct ConvPackItem { const uint16_t *src; uint16_t *dst; int cout, cin, transposed, piece_end, taps; };   // taps: 9, or 1 = a [cout][cin] matrix
 struct ConvPackBatch { ConvPackItem it[kCpPackMax]; int count; };
 
 __global__ __launch_bounds__(256) void conv3x3_pack_kernel(ConvPackBatch b) {
@@ -65,36 +69,46 @@ __global__ __launch_bounds__(256) void conv3x3_pack_kernel(ConvPackBatch b) {
   const int nc = n_red >> 6;
   const int lane = local & 63, kh = (local >> 6) & 1;
   int r = local >> 7;
-  const int tap = r % 9; r /= 9;
+  const int tap = r % t.taps; r /= t.taps;
   const int c = r % nc, n16 = r / nc;
   const int o = n16 * 16 + (lane & 15), k0 = c * 64 + kh * 32 + (lane >> 4) * 8;
   (void)n_out;
   gemm_u32x4 v;
   if (!t.transposed) {
-    v = *reinterpret_cast<const gemm_u32x4 *>(t.src + ((long long)o * 9 + tap) * t.cin + k0);
+    v = *reinterpret_cast<const gemm_u32x4 *>(t.src + ((long long)o * t.taps + tap) * t.cin + k0);
   } else {
     uint16_t e[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) e[j] = t.src[((long long)(k0 + j) * 9 + (8 - tap)) * t.cin + o];
+    for (int j = 0; j < 8; ++j) e[j] = t.src[((long long)(k0 + j) * t.taps + (t.taps - 1 - tap)) * t.cin + o];
     v = gemm_u32x4{(unsigned)e[0] | ((unsigned)e[1] << 16), (unsigned)e[2] | ((unsigned)e[3] << 16),
                    (unsigned)e[4] | ((unsigned)e[5] << 16), (unsigned)e[6] | ((unsigned)e[7] << 16)};
   }
   reinterpret_cast<gemm_u32x4 *>(t.dst)[local] = v;
 }
 
+inline int conv_patch_lds_bytes(int Cin, int bn, int taps = 9) {
+  const int stage = 128 * (bn + 8) * 2, patch = (Cin > 64 ? 2 : 1) * (taps == 9 ? kCpBufB : 128 * 128);
+  return patch > stage ? patch : stage;
+}
+
 // ---- the convolution ---------------------------------------------------------------------------------------------------
 // BN = 128 or 64 output channels per workgroup; four waves as 2 (pixels) x 2 (channels): a wave multiplies 64 pixels x BN / 2
 // channels.
-template <bool RELU, int BN>
-__global__ __launch_bounds__(kCpThreads) __attribute__((amdgpu_waves_per_eu(2, 3)))
+template <bool RELU, int BN, int TAPS = 9>
+__global__ __launch_bounds__(kCpThreads) __attribute__((amdgpu_waves_per_eu(BN == 128 ? 2 : 3, BN == 128 ? 3 : 4)))
 void conv3x3_patch_kernel(ConvPatchArgs g) {
+  static_assert(TAPS == 9 || TAPS == 1, "3x3 convolution or plain product");
+  constexpr int NR = TAPS == 9 ? 6 : 4;            // DMA rounds of 32 patch rows per 64-channel slice
+  constexpr int BUFB = NR * 4096;                  // bytes per patch buffer
   constexpr int NI = BN / 32, CTS = BN + 8;
-  static_assert(2 * kCpBufB >= 128 * CTS * 2, "the staging tile of the store phase lives in the patch buffers");
-  __shared__ __attribute__((aligned(128))) unsigned char smem[2 * kCpBufB];       // ONE LDS object
+  // dynamic LDS (conv_patch_lds_bytes): two patch buffers, or ONE when the reduction is a single 64-channel slice (layer1 of
+  // the ResNet: 24 KB instead of 48 -- a fourth workgroup per CU where the kernel is pure latency); never less than the store
+  // phase's staging tile
+  extern __shared__ __attribute__((aligned(128))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave & 1, wn = wave >> 1;
-  const int tiles_n = g.Cout / BN, tpi = g.nty * g.ntx, tiles_m = g.B * tpi;
+  const int tiles_n = g.Cout / BN, tpi = TAPS == 9 ? g.nty * g.ntx : 1, tiles_m = TAPS == 9 ? g.B * tpi : (g.M + 127) >> 7;
   const int xcd = blockIdx.x & 7, jb = (int)(blockIdx.x >> 3);
   const int tm = xcd + 8 * (jb / tiles_n), tn = jb % tiles_n;
   if (tm >= tiles_m) return;
@@ -103,27 +117,33 @@ void conv3x3_patch_kernel(ConvPatchArgs g) {
   const int y0 = tyi * g.TH, x0 = txi * g.TW, n0 = tn * BN;
   const int PW = g.TW + 2, prow_n = (g.TH + 2) * PW;
   const int nc = g.Cin >> 6;
+  const int m0 = tm * 128;                                // (TAPS == 1)
 
   // ---- DMA geometry: piece p = tid + 256 j: patch row r = p >> 3 = (tid >> 3) + 32 j, slot p & 7 holds source chunk
   // (p & 7) ^ ((r >> 1) & 7) = (tid & 7) ^ ((tid >> 4) & 7)  (32 j does not change (r >> 1) & 7)
   const unsigned src_chunk = (unsigned)(((tid & 7) ^ ((tid >> 4) & 7)) * 16);
-  unsigned xoff[6];
+  unsigned xoff[NR];
 #pragma unroll
-  for (int j = 0; j < 6; ++j) {
+  for (int j = 0; j < NR; ++j) {
     const int r = (tid >> 3) + 32 * j;
-    const int py = r / PW, px = r - py * PW;
-    const int gy = y0 - 1 + py, gx = x0 - 1 + px;
-    const bool ok = r < prow_n && gy >= 0 && gy < g.H && gx >= 0 && gx < g.Wd;
-    xoff[j] = ok ? (unsigned)(((b * g.H + gy) * g.Wd + gx)) * (unsigned)g.Cin * 2u + src_chunk : 0x80000000u;
+    if (TAPS == 9) {
+      const int py = r / PW, px = r - py * PW;
+      const int gy = y0 - 1 + py, gx = x0 - 1 + px;
+      const bool ok = r < prow_n && gy >= 0 && gy < g.H && gx >= 0 && gx < g.Wd;
+      xoff[j] = ok ? (unsigned)(((b * g.H + gy) * g.Wd + gx)) * (unsigned)g.Cin * 2u + src_chunk : 0x80000000u;
+    } else {
+      xoff[j] = m0 + r < g.M ? (unsigned)(m0 + r) * (unsigned)g.Cin * 2u + src_chunk : 0x80000000u;
+    }
   }
+  const long long n_px = TAPS == 9 ? (long long)g.B * g.H * g.Wd : (long long)g.M;
   const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<uint16_t *>(g.X), 0, (int)((long long)g.B * g.H * g.Wd * g.Cin * 2), 0x00020000);
+      const_cast<uint16_t *>(g.X), 0, (int)(n_px * g.Cin * 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<uint16_t *>(g.Wp), 0, (int)((long long)g.Cout * 9 * g.Cin * 2), 0x00020000);
+      const_cast<uint16_t *>(g.Wp), 0, (int)((long long)g.Cout * TAPS * g.Cin * 2), 0x00020000);
   typedef __attribute__((address_space(3))) void lds_void;
   const int lds_piece = (tid - lane) * 16;
   auto issue_round = [&](int c, int j) {                  // round j (0..5) of slice c's patch into buffer c & 1
-    unsigned char *dst = smem + (c & 1) * kCpBufB + lds_piece + 4096 * j;
+    unsigned char *dst = smem + (c & 1) * BUFB + lds_piece + 4096 * j;
     const unsigned off = (xoff[j] & 0x80000000u) ? 0x80000000u : xoff[j] + (unsigned)c * 128u;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrc, (lds_void *)dst, 16, off, 0, 0, 0);
   };
@@ -134,17 +154,21 @@ void conv3x3_patch_kernel(ConvPatchArgs g) {
   int base_row[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const int i = min(wm * 64 + 16 * j + frag_row, g.TH * g.TW - 1);
-    const int ty = i / g.TW;
-    base_row[j] = ty * PW + (i - ty * g.TW);
+    if (TAPS == 9) {
+      const int i = min(wm * 64 + 16 * j + frag_row, g.TH * g.TW - 1);
+      const int ty = i / g.TW;
+      base_row[j] = ty * PW + (i - ty * g.TW);
+    } else {
+      base_row[j] = wm * 64 + 16 * j + frag_row;
+    }
   }
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem;
   // weights: lane offset 16 * lane; scalar offset of (n16, c, tap, kh) = ((((n16 * nc + c) * 9 + tap) * 2 + kh) * 1024
   const unsigned w_lane = (unsigned)lane * 16u;
   const unsigned w_n16 = (unsigned)((n0 + wn * (BN / 2)) >> 4);
-  const unsigned w_istride = (unsigned)nc * 9u * 2048u;
+  const unsigned w_istride = (unsigned)nc * (unsigned)TAPS * 2048u;
   auto load_w = [&](gemm_u32x4 (&w)[2][NI], int c, int tap) {
-    const unsigned s0 = ((w_n16 * (unsigned)nc + (unsigned)c) * 9u + (unsigned)tap) * 2048u;
+    const unsigned s0 = ((w_n16 * (unsigned)nc + (unsigned)c) * (unsigned)TAPS + (unsigned)tap) * 2048u;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       w[0][i] = __builtin_amdgcn_raw_buffer_load_b128(wsrc, w_lane, s0 + (unsigned)i * w_istride, 0);
@@ -159,7 +183,7 @@ void conv3x3_patch_kernel(ConvPatchArgs g) {
     for (int j = 0; j < 4; ++j) acc[i][j] = gemm_f32x4{0.f, 0.f, 0.f, 0.f};
 
 #pragma unroll
-  for (int j = 0; j < 6; ++j) issue_round(0, j);
+  for (int j = 0; j < NR; ++j) issue_round(0, j);
   gemm_u32x4 wcur[2][NI], wnext[2][NI];
   load_w(wcur, 0, 0);
 
@@ -167,14 +191,27 @@ void conv3x3_patch_kernel(ConvPatchArgs g) {
     // slice c's patch has landed (this wave's DMAs; then everybody's), and every wave is done reading slice c - 1's buffer
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    const unsigned bufb = lds0 + (unsigned)((c & 1) * kCpBufB);
+    const unsigned bufb = lds0 + (unsigned)((c & 1) * BUFB);
+    // (opaque to the optimiser: otherwise the 36 swizzled tap addresses, invariant across slices, are kept in registers
+    //  for the whole kernel -- 36 VGPRs for ~5 VALU instructions each per slice)
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
+    for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(base_row[j]));
+#pragma unroll
+    for (int tap = 0; tap < TAPS; ++tap) {
+      __builtin_amdgcn_sched_barrier(0);        // (nothing of this tap moves above the previous tap's MFMAs: registers)
       // the next slice's patch, spread over this slice's taps (rounds 0-5 behind taps 0-5), and the next tap's weights
-      if (tap < 6 && c + 1 < nc) issue_round(c + 1, tap);
-      if (tap < 8) load_w(wnext, c, tap + 1);
-      else if (c + 1 < nc) load_w(wnext, c + 1, 0);
-      const int shift = (tap / 3) * PW + (tap % 3);
+      if (TAPS == 9) {
+        if (tap < 6 && c + 1 < nc) issue_round(c + 1, tap);
+        if (tap < 8) load_w(wnext, c, tap + 1);
+        else if (c + 1 < nc) load_w(wnext, c + 1, 0);
+      } else {
+        if (c + 1 < nc) {
+#pragma unroll
+          for (int j = 0; j < NR; ++j) issue_round(c + 1, j);
+        }
+        load_w(wnext, c + 1, 0);                // (past the last slice: some other block's weights or zeros, never multiplied)
+      }
+      const int shift = TAPS == 9 ? (tap / 3) * PW + (tap % 3) : 0;
       // (inline assembly: next to a pending LDS-DMA hipcc puts vmcnt(0) in front of a compiler-visible LDS read; the waits
       //  below carry the fragments as operands so that no MFMA is scheduled above them)
       gemm_u32x4 xf[2][4];
@@ -224,6 +261,11 @@ void conv3x3_patch_kernel(ConvPatchArgs g) {
     for (int j = 0; j < 4; ++j) {
       const int row = wm * 64 + j * 16 + (lane & 15);
       gemm_f32x4 v = acc[i][j] + bv;
+      if (TAPS == 1 && g.res && m0 + row < g.M) {
+        const uint2 r2 = *reinterpret_cast<const uint2 *>(g.res + (long long)(m0 + row) * g.Cout + n0 + nl);
+        v.x += __uint_as_float(r2.x << 16); v.y += __uint_as_float(r2.x & 0xffff0000u);
+        v.z += __uint_as_float(r2.y << 16); v.w += __uint_as_float(r2.y & 0xffff0000u);
+      }
       if (RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
       uint2 o;
       o.x = gemm_pack2(v.x, v.y);
@@ -236,11 +278,17 @@ void conv3x3_patch_kernel(ConvPatchArgs g) {
 #pragma unroll
   for (int it = 0; it < ITER; ++it) {
     const int idx = tid + 256 * it, row = idx / CH, ch = idx % CH;
-    if (row >= g.TH * g.TW) continue;
-    const int ty = row / g.TW, tx = row - ty * g.TW;
-    const int oy = y0 + ty, ox = x0 + tx;
-    if (oy >= g.H || ox >= g.Wd) continue;
-    const long long m = ((long long)b * g.H + oy) * g.Wd + ox;
+    long long m;
+    if (TAPS == 9) {
+      if (row >= g.TH * g.TW) continue;
+      const int ty = row / g.TW, tx = row - ty * g.TW;
+      const int oy = y0 + ty, ox = x0 + tx;
+      if (oy >= g.H || ox >= g.Wd) continue;
+      m = ((long long)b * g.H + oy) * g.Wd + ox;
+    } else {
+      if (m0 + row >= g.M) continue;
+      m = m0 + row;
+    }
     uint4 v = *reinterpret_cast<const uint4 *>(stage + row * CTS + ch * 8);
     if (g.gate) {
       const uint4 a = *reinterpret_cast<const uint4 *>(g.gate + m * g.Cout + n0 + ch * 8);

@@ -1324,8 +1324,9 @@ bool conv_patch_ok(int B, int H, int Wd, int Cin, int Cout) {
 
 int snipper_conv3x3_patch_supported(int B, int H, int Wd, int Cin, int Cout) { return conv_patch_ok(B, H, Wd, Cin, Cout) ? 1 : 0; }
 
-int snipper_conv3x3_pack_bf16(void *stream, int n, const void *const *src, void *const *dst, const int *cout, const int *cin,
-                              const int *transposed) {
+namespace {
+int conv_pack(void *stream, int n, const void *const *src, void *const *dst, const int *cout, const int *cin,
+              const int *transposed, int taps) {
   if (n < 0 || (n > 0 && (!src || !dst || !cout || !cin || !transposed))) return SNIPPER_E_NULL;
   for (int lo = 0; lo < n; lo += kCpPackMax) {
     ConvPackBatch b{};
@@ -1335,14 +1336,51 @@ int snipper_conv3x3_pack_bf16(void *stream, int n, const void *const *src, void 
       const int co = cout[lo + i], ci = cin[lo + i], tr = transposed[lo + i] ? 1 : 0;
       if (!src[lo + i] || !dst[lo + i]) return SNIPPER_E_NULL;
       if (co <= 0 || ci <= 0 || co % 64 || ci % 64 || (((uintptr_t)src[lo + i] | (uintptr_t)dst[lo + i]) & 15)) return SNIPPER_E_SHAPE;
-      pieces += (long long)co * ci * 9 / 8;
+      pieces += (long long)co * ci * taps / 8;
       if (pieces >= (1LL << 31)) return SNIPPER_E_SHAPE;
-      b.it[i] = ConvPackItem{(const uint16_t *)src[lo + i], (uint16_t *)dst[lo + i], co, ci, tr, (int)pieces};
+      b.it[i] = ConvPackItem{(const uint16_t *)src[lo + i], (uint16_t *)dst[lo + i], co, ci, tr, (int)pieces, taps};
     }
     hipLaunchKernelGGL(conv3x3_pack_kernel, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, (hipStream_t)stream, b);
     if (int rc = launch_status()) return rc;
   }
   return SNIPPER_OK;
+}
+}  // namespace
+
+int snipper_conv3x3_pack_bf16(void *stream, int n, const void *const *src, void *const *dst, const int *cout, const int *cin,
+                              const int *transposed) {
+  return conv_pack(stream, n, src, dst, cout, cin, transposed, 9);
+}
+
+int snipper_linear_pack_bf16(void *stream, int n, const void *const *src, void *const *dst, const int *N, const int *K,
+                             const int *transposed) {
+  return conv_pack(stream, n, src, dst, N, K, transposed, 1);
+}
+
+int snipper_linear_patch_supported(long long M, int N, int K) {
+  return (M >= 256 && M < (1LL << 30) && N > 0 && K > 0 && N % 64 == 0 && K % 64 == 0 && M * K < (1LL << 30) && M * N < (1LL << 30)) ? 1 : 0;
+}
+
+int snipper_linear_patch_bf16(void *stream, const uint16_t *X, const uint16_t *Wp, const float *bias, const uint16_t *res,
+                              uint16_t *Y, int M, int N, int K, int relu, const uint16_t *gate, int bn) {
+  if (!X || !Wp || !Y) return SNIPPER_E_NULL;
+  if (!snipper_linear_patch_supported(M, N, K) || (gate && relu) ||
+      (((uintptr_t)X | (uintptr_t)Wp | (uintptr_t)Y | (uintptr_t)gate) & 15) || ((uintptr_t)res & 7) || (bn != 0 && bn != 64 && bn != 128))
+    return SNIPPER_E_SHAPE;
+  const ConvPatchArgs g{X, Wp, bias, Y, gate, 1, 1, 1, K, N, 1, 1, 1, 1, M, res};
+  const long long tiles_m = ((long long)M + 127) / 128;
+  const bool n128 = N % 128 == 0 && (bn == 128 || (bn == 0 && tiles_m * (N / 128) >= 512));
+  const int b_n = n128 ? 128 : 64;
+  const dim3 grid((unsigned)((N / b_n) * 8 * ((tiles_m + 7) / 8)));
+  const unsigned lds = (unsigned)conv_patch_lds_bytes(K, b_n, 1);
+  if (n128) {
+    if (relu) hipLaunchKernelGGL((conv3x3_patch_kernel<true, 128, 1>), grid, dim3(kCpThreads), lds, (hipStream_t)stream, g);
+    else hipLaunchKernelGGL((conv3x3_patch_kernel<false, 128, 1>), grid, dim3(kCpThreads), lds, (hipStream_t)stream, g);
+  } else {
+    if (relu) hipLaunchKernelGGL((conv3x3_patch_kernel<true, 64, 1>), grid, dim3(kCpThreads), lds, (hipStream_t)stream, g);
+    else hipLaunchKernelGGL((conv3x3_patch_kernel<false, 64, 1>), grid, dim3(kCpThreads), lds, (hipStream_t)stream, g);
+  }
+  return launch_status();
 }
 
 int snipper_conv3x3_patch_bf16(void *stream, const uint16_t *X, const uint16_t *Wp, const float *bias, uint16_t *Y,
@@ -1353,20 +1391,23 @@ int snipper_conv3x3_patch_bf16(void *stream, const uint16_t *X, const uint16_t *
   int TH = 0, TW = 0;
   if (!conv_patch_tile(H, Wd, TH, TW)) return SNIPPER_E_SHAPE;
   const int nty = (H + TH - 1) / TH, ntx = (Wd + TW - 1) / TW;
-  const ConvPatchArgs g{X, Wp, bias, Y, gate, B, H, Wd, Cin, Cout, TH, TW, nty, ntx};
+  const ConvPatchArgs g{X, Wp, bias, Y, gate, B, H, Wd, Cin, Cout, TH, TW, nty, ntx, 0, nullptr};
   const long long tiles_m = (long long)B * nty * ntx;
   // 128 output channels per workgroup unless that leaves CUs without one (SNIPPER_CONV_PATCH_MIN128: workgroups below which
   // the 64-channel instance is taken)
-  static const long long min128 = [] { const char *e = getenv("SNIPPER_CONV_PATCH_MIN128"); return e ? atoll(e) : 256LL; }();
+  // (measured, tools/convbench.py: 256 workgroups of 128 channels at 38 x 50 x 256 take 23.2 us, 512 of 64 channels 21.2;
+  //  480 / 960 at 75 x 100 x 128: 22.5 / 26.1; 128 / 256 at 19 x 25 x 512: 35.4 / 27.3)
+  static const long long min128 = [] { const char *e = getenv("SNIPPER_CONV_PATCH_MIN128"); return e ? atoll(e) : 384LL; }();
   const bool n128 = Cout % 128 == 0 && tiles_m * (Cout / 128) >= min128;
   const int bn = n128 ? 128 : 64;
   const dim3 grid((unsigned)((Cout / bn) * 8 * ((tiles_m + 7) / 8)));
+  const unsigned lds = (unsigned)conv_patch_lds_bytes(Cin, bn);
   if (n128) {
-    if (relu) hipLaunchKernelGGL((conv3x3_patch_kernel<true, 128>), grid, dim3(kCpThreads), 0, (hipStream_t)stream, g);
-    else hipLaunchKernelGGL((conv3x3_patch_kernel<false, 128>), grid, dim3(kCpThreads), 0, (hipStream_t)stream, g);
+    if (relu) hipLaunchKernelGGL((conv3x3_patch_kernel<true, 128>), grid, dim3(kCpThreads), lds, (hipStream_t)stream, g);
+    else hipLaunchKernelGGL((conv3x3_patch_kernel<false, 128>), grid, dim3(kCpThreads), lds, (hipStream_t)stream, g);
   } else {
-    if (relu) hipLaunchKernelGGL((conv3x3_patch_kernel<true, 64>), grid, dim3(kCpThreads), 0, (hipStream_t)stream, g);
-    else hipLaunchKernelGGL((conv3x3_patch_kernel<false, 64>), grid, dim3(kCpThreads), 0, (hipStream_t)stream, g);
+    if (relu) hipLaunchKernelGGL((conv3x3_patch_kernel<true, 64>), grid, dim3(kCpThreads), lds, (hipStream_t)stream, g);
+    else hipLaunchKernelGGL((conv3x3_patch_kernel<false, 64>), grid, dim3(kCpThreads), lds, (hipStream_t)stream, g);
   }
   return launch_status();
 }

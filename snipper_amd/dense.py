@@ -237,6 +237,66 @@ def conv3x3_pack_bf16(items) -> None:
     _lib.check(rc, "snipper_conv3x3_pack_bf16")
 
 
+_LPACK_ARGS: dict = {}
+
+
+def linear_pack_bf16(items) -> None:
+    """Pack [N, K] bf16 matrices (contiguous rows) for ``linear_patch_bf16`` in one launch.  ``items``: (src, dst, transposed);
+    transposed = True packs the operand of the data gradient dX[M, K] = dY[M, N] . W (call linear_patch_bf16 with N = K)."""
+    import ctypes
+    items = list(items)
+    if not items:
+        return
+    key = tuple((s_.data_ptr(), d_.data_ptr(), bool(t_)) for s_, d_, t_ in items)
+    args = _LPACK_ARGS.get(key)
+    if args is None:
+        n = len(items)
+        for s_, d_, _ in items:
+            assert s_.is_cuda and s_.dtype == torch.bfloat16 and d_.dtype == torch.bfloat16 and s_.dim() == 2 and s_.is_contiguous()
+            assert d_.is_contiguous() and d_.numel() == s_.numel() and d_.device == s_.device
+        args = (n, (ctypes.c_void_p * n)(*[s_.data_ptr() for s_, _, _ in items]),
+                (ctypes.c_void_p * n)(*[d_.data_ptr() for _, d_, _ in items]),
+                (ctypes.c_int * n)(*[s_.shape[0] for s_, _, _ in items]), (ctypes.c_int * n)(*[s_.shape[1] for s_, _, _ in items]),
+                (ctypes.c_int * n)(*[int(bool(t_)) for _, _, t_ in items]))
+        if len(_LPACK_ARGS) > 8:
+            _LPACK_ARGS.clear()
+        _LPACK_ARGS[key] = args
+    dev = items[0][0].device
+    with _lib.device_guard(dev):
+        rc = _lib.load().snipper_linear_pack_bf16(_lib.raw_stream(dev), *args)
+    _lib.check(rc, "snipper_linear_pack_bf16")
+
+
+def linear_patch_supported(M: int, N: int, K: int) -> bool:
+    return bool(_lib.load().snipper_linear_patch_supported(int(M), int(N), int(K)))
+
+
+def linear_patch_bf16(x: torch.Tensor, packed: torch.Tensor, N: int, bias: Optional[torch.Tensor] = None,
+                      residual: Optional[torch.Tensor] = None, relu: bool = False, gate: Optional[torch.Tensor] = None,
+                      bn: int = 0, kind: str = "linear") -> torch.Tensor:
+    """act(x @ W^T + bias + residual) (or gate > 0 ? . : 0) for a weight packed by ``linear_pack_bf16``: the X tile is
+    streamed through LDS in 64-channel slices, W goes straight into MFMA operand registers (csrc/conv3x3_patch_bf16.cuh with
+    one tap).  x [M, K] bf16 contiguous  ->  [M, N] bf16."""
+    assert x.is_cuda and x.dtype == torch.bfloat16 and packed.dtype == torch.bfloat16 and x.dim() == 2 and x.is_contiguous()
+    M, K = x.shape
+    assert packed.numel() == N * K
+    out = torch.empty((M, N), dtype=torch.bfloat16, device=x.device)
+    if bias is not None and bias.dtype != torch.float32:
+        bias = bias.float()
+    if residual is not None:
+        assert residual.dtype == torch.bfloat16 and residual.shape == (M, N) and residual.is_contiguous()
+    if gate is not None:
+        assert gate.dtype == torch.bfloat16 and gate.shape == (M, N) and gate.is_contiguous()
+    extra = (1 if residual is not None else 0) + (1 if gate is not None else 0)
+    with _timed(kind, (M, N, K), 2 * M * N * K, 2 * (M * K + N * K + M * N * (1 + extra)), x.device), _lib.device_guard(x.device):
+        rc = _lib.load().snipper_linear_patch_bf16(
+            _lib.raw_stream(x.device), x.data_ptr(), packed.data_ptr(), bias.data_ptr() if bias is not None else None,
+            residual.data_ptr() if residual is not None else None, out.data_ptr(), M, N, K, int(relu),
+            gate.data_ptr() if gate is not None else None, int(bn))
+    _lib.check(rc, "snipper_linear_patch_bf16")
+    return out
+
+
 def conv3x3_patch_supported(B: int, H: int, W: int, Cin: int, Cout: int) -> bool:
     return bool(_lib.load().snipper_conv3x3_patch_supported(int(B), int(H), int(W), int(Cin), int(Cout)))
 
@@ -488,7 +548,13 @@ class _BigFFN(torch.autograd.Function):
             from .fused import _next_seed
             seed = _next_seed()
         h = linear_bf16(xb, w1b, b1.float(), None, True, dropout_p, seed)
-        z = linear_bf16(h, w2b, b2.float())
+        # the 1024-deep products on the one-tap patch kernel when this step's packs are there (shadow.lookup_lpacked)
+        pk2, pk1 = shadow.lookup_lpacked(w2), shadow.lookup_lpacked(w1)
+        if pk2 is not None and pk2[0] is not None and shadow.lookup(w2) is w2b and linear_patch_supported(h.shape[0], w2.shape[0], w2.shape[1]):
+            z = linear_patch_bf16(h, pk2[0], w2.shape[0], b2, None, False, None, 64)
+        else:
+            z = linear_bf16(h, w2b, b2.float())
+        ctx.w1tp = pk1[1] if (pk1 is not None and shadow.lookup(w1) is w1b) else None
         ctx.p, ctx.x_shape = float(dropout_p), x.shape
         ctx.dts = (w1.dtype, b1.dtype, w2.dtype, b2.dtype)
         ctx.w2t = shadow.lookup_t(w2)                        # W2^T [d_ffn, d_model]: dH = dZ . W2 on the weight-stationary kernel
@@ -505,7 +571,12 @@ class _BigFFN(torch.autograd.Function):
         dW2, db2 = wgrad_bf16(g, h)
         gh = _dgrad(g, w2b, None, h, wt=ctx.w2t, gate_scale=1.0 / (1.0 - ctx.p))    # gradient w.r.t. linear1's pre-activation
         dW1, db1 = wgrad_bf16(gh, xb)
-        dx = _dgrad(gh, w1b).view(ctx.x_shape) if ctx.needs_input_grad[0] else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if ctx.w1tp is not None and gh.is_contiguous() and linear_patch_supported(gh.shape[0], w1b.shape[1], w1b.shape[0]):
+                dx = linear_patch_bf16(gh, ctx.w1tp, w1b.shape[1], None, None, False, None, 64, kind="linear_nn").view(ctx.x_shape)
+            else:
+                dx = _dgrad(gh, w1b).view(ctx.x_shape)
         outs = [dW1, db1, dW2, db2]
         outs = [o if o.dtype == dt else o.to(dt) for o, dt in zip(outs, ctx.dts)]
         return (dx, *outs, None)

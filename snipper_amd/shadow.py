@@ -93,6 +93,32 @@ def lookup_packed(param: torch.Tensor, scale: Optional[torch.Tensor] = None):
     return None
 
 
+# The one-tap form of the patch kernel for the 1x1 convolutions' / the feed-forward block's 1024-deep products: OPT-IN
+# (SNIPPER_LINEAR_PATCH=1).  In isolation it beats the tile kernels on most data gradients by 10-30 % and on the forward
+# products with a reduction >= 256 by 5-20 % (tools/linpatchbench.py, profiles/r05_linear_patch_bench.jsonl); inside the step the
+# 42 + 13 launches it takes over cost 2.21 ms against 2.28 ms, the four pack launches add 0.075 ms and the extra look-ups
+# ~1 ms of host issue time: same-box step 22.40 / 22.44 ms without, 23.5 / 25.8 ms with (host-bound in places).
+LINEAR_PATCH = _os.environ.get("SNIPPER_LINEAR_PATCH", "0") == "1"
+
+
+def lookup_lpacked(param: torch.Tensor, scale: Optional[torch.Tensor] = None):
+    """(packed, packed_t) of a 1x1 convolution weight or a Linear weight whose shadow is valid -- the (folded) bf16 matrix
+    [out, in] in the fragment order of csrc/conv3x3_patch_bf16.cuh (one tap) for the forward (None where the tile kernel is
+    kept) and for the data gradient (None for frozen weights) -- or None."""
+    e = _entries.get(id(param))
+    if (e is not None and (e.packed is not None or e.packed_t is not None) and e.ref() is param and
+            e.version == param._version and e.dst.device == param.device and
+            (scale is None or e.scale is None or e.scale is scale)):
+        return e.packed, e.packed_t
+    return None
+
+
+def patch_forward_pays(out_features: int, in_features: int) -> bool:
+    """Forward products where the one-tap patch kernel beat the tile kernels (tools/linpatchbench.py, profiles/
+    r05_linear_patch_bench.jsonl): a reduction of at least 256 channels into at least 128 columns, no residual."""
+    return in_features >= 256 and out_features >= 128 and in_features % 64 == 0 and out_features % 64 == 0
+
+
 def lookup_merged_t(lin_a: nn.Linear, lin_b: nn.Linear) -> Optional[torch.Tensor]:
     if lookup_merged(lin_a, lin_b) is None:
         return None
@@ -172,7 +198,7 @@ class WeightShadows:
     @torch.no_grad()
     def refresh(self) -> None:
         """Bring every stale shadow up to date (multi-tensor launches; nothing to do for unchanged parameters)."""
-        mul_src, mul_scale, mul_dst, cp_src, cp_dst, tr, packs = [], [], [], [], [], [], []
+        mul_src, mul_scale, mul_dst, cp_src, cp_dst, tr, packs, lpacks = [], [], [], [], [], [], [], []
         for conv, bn in self.convs:
             w = conv.weight
             if not (w.is_cuda and w.dtype == torch.float32):
@@ -183,6 +209,15 @@ class WeightShadows:
             scale = bn.scale_bias()[0]
             patch = (CONV_PATCH and w.dim() == 4 and tuple(w.shape[2:]) == (3, 3) and tuple(conv.stride) == (1, 1) and
                      w.is_contiguous(memory_format=torch.channels_last) and w.shape[0] % 64 == 0 and w.shape[1] % 64 == 0)
+            pw = (LINEAR_PATCH and w.dim() == 4 and tuple(w.shape[2:]) == (1, 1) and w.shape[0] % 64 == 0 and
+                  w.shape[1] % 64 == 0 and e.dst.stride(0) == w.shape[1] and e.dst.stride(1) == 1)     # dense [Cout][Cin] memory
+            if pw and e.packed is None and e.packed_t is None:
+                # a 1x1 convolution = a product on NHWC rows: packed for the one-tap patch kernel where it pays (forward) and,
+                # for trainable weights, for the data gradient
+                if patch_forward_pays(w.shape[0], w.shape[1]):
+                    e.packed = torch.empty(w.numel(), dtype=torch.bfloat16, device=w.device)
+                if w.requires_grad:
+                    e.packed_t = torch.empty(w.numel(), dtype=torch.bfloat16, device=w.device)
             if patch and e.packed is None:
                 # a stride-1 3x3 convolution runs on the patch-resident kernel: its weight in fragment order, written by ONE
                 # pack launch below for all of them (and no tap-transposed copy: that kernel's data gradient has its own pack)
@@ -202,7 +237,13 @@ class WeightShadows:
                         src_t, dst_t = e.dst.permute(0, 2, 3, 1), e.dst_t.permute(0, 2, 3, 1)  # [Cout, 3, 3, Cin] / [Cin, 3, 3, Cout] views
                         e.tap_pairs = [(src_t[:, ky, kx, :], dst_t[:, ky, kx, :]) for ky in range(3) for kx in range(3)]
                     tr += e.tap_pairs
-                if e.packed is not None:
+                if pw:
+                    m2 = e.dst.as_strided((w.shape[0], w.shape[1]), (w.shape[1], 1))      # (a VIEW of the shadow: it is written below)
+                    if e.packed is not None:
+                        lpacks.append((m2, e.packed, False))
+                    if e.packed_t is not None:
+                        lpacks.append((m2, e.packed_t, True))
+                elif e.packed is not None:
                     packs.append((e.dst, e.packed, False))
                     if e.packed_t is not None:
                         packs.append((e.dst, e.packed_t, True))
@@ -223,11 +264,21 @@ class WeightShadows:
                 e = _entries[id(w)] = _Entry(w, torch.empty_like(w, dtype=torch.bfloat16))
                 if w.dim() == 2 and wants_transpose(w.shape[0], w.shape[1]):
                     e.dst_t = torch.empty((w.shape[1], w.shape[0]), dtype=torch.bfloat16, device=w.device)
+                if LINEAR_PATCH and w.dim() == 2 and w.shape[0] % 64 == 0 and w.shape[1] % 64 == 0:
+                    # the feed-forward block's 1024-deep products: linear2's forward, linear1's data gradient
+                    if w.shape[1] >= 512 and w.shape[0] >= 128:
+                        e.packed = torch.empty(w.numel(), dtype=torch.bfloat16, device=w.device)
+                    if w.shape[0] >= 512 and w.shape[1] >= 128 and w.requires_grad:
+                        e.packed_t = torch.empty(w.numel(), dtype=torch.bfloat16, device=w.device)
             if e.version != w._version:
                 cp_src.append(w)
                 cp_dst.append(e)
                 if e.dst_t is not None:
                     tr.append((e.dst, e.dst_t))
+                if w.dim() == 2 and e.packed is not None:
+                    lpacks.append((e.dst, e.packed, False))
+                if w.dim() == 2 and e.packed_t is not None:
+                    lpacks.append((e.dst, e.packed_t, True))
         fin = []
         for a, b in self.pairs:
             ps = [a.weight, a.bias, b.weight, b.bias]
@@ -273,6 +324,9 @@ class WeightShadows:
         if packs:                               # (after the folded bf16 copies they read have been written)
             from .dense import conv3x3_pack_bf16
             conv3x3_pack_bf16(packs)
+        if lpacks:
+            from .dense import linear_pack_bf16
+            linear_pack_bf16(lpacks)
         if tr:                                  # W^T of the freshly written bf16 copies: one launch for all of them
             from .dense import transpose_batch_bf16
             transpose_batch_bf16(tr)

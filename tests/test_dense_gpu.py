@@ -646,3 +646,44 @@ print(h.hexdigest())
         assert r.returncode == 0, r.stderr[-2000:]
         out[mode] = r.stdout.strip().splitlines()[-1]
     assert out["0"] == out["2"], out
+
+
+@pytest.mark.parametrize("M,K,N,mode", [(8192, 256, 128, "fwd"), (4100, 64, 256, "res"), (8200, 1024, 384, "plain"),
+                                        (4097, 512, 128, "dgrad"), (16384, 64, 64, "dgrad_skip")])
+@pytest.mark.parametrize("bn", [0, 64, 128])
+def test_linear_patch_kernel(M, K, N, mode, bn):
+    """One-tap form of the patch kernel (snipper_linear_patch_bf16) against float64 on the same bf16 operands: forward with
+    bias / ReLU / residual, data gradient (transposed pack) with a ReLU gate and with the skip connection's gradient added."""
+    from snipper_amd.dense import linear_pack_bf16, linear_patch_bf16, linear_patch_supported
+    g = torch.Generator().manual_seed(M + K + N)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(DEV).bfloat16()
+    packed = torch.empty(w.numel(), dtype=torch.bfloat16, device=DEV)
+    if mode.startswith("dgrad"):
+        if bn == 128 and K % 128:
+            pytest.skip("64 output columns only")
+        assert linear_patch_supported(M, K, N)
+        linear_pack_bf16([(w, packed, True)])
+        gy = torch.randn(M, N, generator=g).to(DEV).bfloat16()
+        gate = torch.randn(M, K, generator=g).to(DEV).relu().bfloat16()
+        skip = torch.randn(M, K, generator=g).to(DEV).bfloat16() if mode == "dgrad_skip" else None
+        got = linear_patch_bf16(gy, packed, K, None, skip, False, gate, bn)
+        ref = gy.double() @ w.double()
+        if skip is not None:
+            ref = ref + skip.double()
+        ref = torch.where(gate.double() > 0, ref, torch.zeros_like(ref))
+    else:
+        if bn == 128 and N % 128:
+            pytest.skip("64 output columns only")
+        assert linear_patch_supported(M, N, K)
+        linear_pack_bf16([(w, packed, False)])
+        x = torch.randn(M, K, generator=g).to(DEV).bfloat16()
+        b = torch.randn(N, generator=g).to(DEV)
+        res = torch.randn(M, N, generator=g).to(DEV).bfloat16() if mode == "res" else None
+        got = linear_patch_bf16(x, packed, N, b, res, mode in ("fwd", "res"), None, bn)
+        ref = x.double() @ w.double().t() + b.double()
+        if res is not None:
+            ref = ref + res.double()
+        if mode in ("fwd", "res"):
+            ref = ref.relu()
+    err = (got.double() - ref).abs().max().item()
+    assert err <= ref.abs().max().item() * 2 ** -8 * 1.01 + 1e-6, err
