@@ -232,25 +232,28 @@ __global__ __launch_bounds__(kLnThreads) __attribute__((amdgpu_waves_per_eu(NIT 
   }
 }
 
-// dgamma[c] = sum_b part[b][0][c], dbeta[c] = sum_b part[b][1][c]: 16 channels x 16 slices of b per workgroup
-// (the 16 lanes of a slice read 64 contiguous bytes; the slices meet in LDS), summed in a fixed order
+// dgamma[c] = sum_b part[b][0][c], dbeta[c] = sum_b part[b][1][c]: kLnPgCh channels x (256 / kLnPgCh) slices of b per workgroup
+// (the lanes of a slice read 32 contiguous bytes; the slices meet in LDS), summed in a fixed order.  Round 5: 8 channels x 32
+// slices instead of 16 x 16 -- twice the workgroups (96 for C = 384) and half the dependent loads per thread: the 4.7 MB of
+// partial rows of an encoder LayerNorm were read at 0.7 TB/s by 48 workgroups.
+constexpr int kLnPgCh = 8, kLnPgSlices = 256 / kLnPgCh;
 __global__ __launch_bounds__(256) void ln_param_grad_kernel(const float *part, int nparts, int C, float *dgamma, float *dbeta) {
-  __shared__ float red[16][17];
-  const int ci = threadIdx.x & 15, slice = threadIdx.x >> 4;
-  const int e = blockIdx.x * 16 + ci;                  // over 2*C
+  __shared__ float red[kLnPgSlices][kLnPgCh + 1];
+  const int ci = threadIdx.x % kLnPgCh, slice = threadIdx.x / kLnPgCh;
+  const int e = blockIdx.x * kLnPgCh + ci;                  // over 2*C
   float sum = 0.f;
   if (e < 2 * C) {
     const int which = e >= C, c = which ? e - C : e;
     const float *p = part + (long long)which * C + c;
-#pragma unroll 4
-    for (int b = slice; b < nparts; b += 16) sum += p[(long long)b * 2 * C];
+#pragma unroll 8
+    for (int b = slice; b < nparts; b += kLnPgSlices) sum += p[(long long)b * 2 * C];
   }
   red[slice][ci] = sum;
   __syncthreads();
   if (slice == 0 && e < 2 * C) {
     sum = 0.f;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) sum += red[k][ci];
+    for (int k = 0; k < kLnPgSlices; ++k) sum += red[k][ci];
     if (e >= C) dbeta[e - C] = sum; else dgamma[e] = sum;
   }
 }

@@ -1109,7 +1109,7 @@ int snipper_add_dropout_layernorm_backward(void *stream, const float *g32, const
     case 3: hipLaunchKernelGGL(ln_fused_bwd_kernel<3>, dim3(blocks), dim3(kLnThreads), 0, (hipStream_t)stream, a); break;
     default: hipLaunchKernelGGL(ln_fused_bwd_kernel<4>, dim3(blocks), dim3(kLnThreads), 0, (hipStream_t)stream, a); break;
   }
-  hipLaunchKernelGGL(ln_param_grad_kernel, dim3((2 * C + 15) / 16), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(ln_param_grad_kernel, dim3((2 * C + kLnPgCh - 1) / kLnPgCh), dim3(256), 0, (hipStream_t)stream,
                      (const float *)workspace, blocks, C, dgamma, dbeta);
   return launch_status();
 }
@@ -1173,7 +1173,7 @@ int snipper_groupnorm_tokens_backward(void *stream, const uint16_t *x, const flo
   const dim3 grid(p.nblk, n), block((C / 4) * p.rpp);
   hipLaunchKernelGGL(gn_bwd_stats_kernel, grid, block, 0, (hipStream_t)stream, a);
   hipLaunchKernelGGL(gn_bwd_apply_kernel, grid, block, 0, (hipStream_t)stream, a);
-  hipLaunchKernelGGL(ln_param_grad_kernel, dim3((2 * C + 15) / 16), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(ln_param_grad_kernel, dim3((2 * C + kLnPgCh - 1) / kLnPgCh), dim3(256), 0, (hipStream_t)stream,
                      (const float *)a.part_param, n * p.nblk, C, dgamma, dbeta);
   return launch_status();
 }
