@@ -286,6 +286,13 @@ int snipper_linear_patch_supported(long long M, int N, int K);
 int snipper_linear_patch_bf16(void *stream, const uint16_t *X, const uint16_t *Wp, const float *bias, const uint16_t *res,
                               uint16_t *Y, int M, int N, int K, int relu, const uint16_t *gate, int bn);
 
+/* Deep reductions into 384 columns on full-width tiles (csrc/conv3x3_patch_bf16.cuh, linear_wide_kernel): Y[M, 384] =
+ * X[M, K] . W^T + bias, K a multiple of 128, M >= 8192, X / Y contiguous rows, Wp = snipper_linear_pack_bf16's pack of W
+ * [384][K] (transposed == 0) or, for a data gradient dX[M, 384] = dY[M, K] . W with W [K][384], its transposed pack.  The
+ * encoder feed-forward block's linear2 forward and linear1 data gradient (reference models/deformable_transformer.py:194-198). */
+int snipper_linear_wide_supported(long long M, int N, int K);
+int snipper_linear_wide_bf16(void *stream, const uint16_t *X, const uint16_t *Wp, const float *bias, uint16_t *Y, int M, int N, int K);
+
 /* ---- element-wise fusions around the core op (csrc/msda_prologue.cuh) --------------------------------
  * dtype codes: 0 = float32, 1 = bfloat16 bits.
  *

@@ -119,6 +119,8 @@ EXPORTS = {
     "snipper_linear_patch_supported": ([c_longlong, c_int, c_int], c_int),
     "snipper_linear_patch_bf16": ([c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                    c_void_p, c_int], c_int),
+    "snipper_linear_wide_supported": ([c_longlong, c_int, c_int], c_int),
+    "snipper_linear_wide_bf16": ([c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int], c_int),
     "snipper_relu_dropout_backward_bf16": ([c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, ctypes.c_float], c_int),
 }
 

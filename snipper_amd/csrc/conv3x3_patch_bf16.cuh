@@ -188,8 +188,11 @@ void conv3x3_patch_kernel(ConvPatchArgs g) {
   load_w(wcur, 0, 0);
 
   for (int c = 0; c < nc; ++c) {
-    // slice c's patch has landed (this wave's DMAs; then everybody's), and every wave is done reading slice c - 1's buffer
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // slice c's patch has landed (this wave's DMAs; then everybody's), and every wave is done reading slice c - 1's buffer.
+    // Vector-memory loads retire in order and the only ones issued AFTER the slice's last DMA round are the 2 * NI weight loads
+    // of its first tap: waiting for all but those leaves the weight prefetch in flight across the slice boundary.
+    if (NI == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     const unsigned bufb = lds0 + (unsigned)((c & 1) * BUFB);
     // (opaque to the optimiser: otherwise the 36 swizzled tap addresses, invariant across slices, are kept in registers
@@ -300,6 +303,156 @@ void conv3x3_patch_kernel(ConvPatchArgs g) {
       v.x = keep(a.x, v.x); v.y = keep(a.y, v.y); v.z = keep(a.z, v.z); v.w = keep(a.w, v.w);
     }
     *reinterpret_cast<uint4 *>(g.Y + m * g.Cout + n0 + ch * 8) = v;
+  }
+}
+
+// ---- deep reductions into 384 columns: Y[M, 384] = X[M, K] . W^T + bias on FULL-WIDTH tiles (8 waves) ------------------------
+// The feed-forward block's 1024-deep products (linear2's forward, linear1's data gradient: reference
+// models/deformable_transformer.py:194-198 on 79 000 token rows) ran on 128 x 128 / 128 x 64 tiles: X re-read once per column
+// tile, 1.0-1.45 GB through L2 per launch for 224 MB of operands, 82-92 us (profiles/r05_backbone_roofline.csv).  Here a
+// workgroup of 8 waves owns MT * 32 rows x ALL 384 columns: X crosses L2 once (LDS-DMA, 128-channel slices, double-buffered),
+// W (the one-tap pack of conv3x3_pack_kernel) streams from L2 into MFMA operands once per row tile, and the slice boundary
+// costs one barrier (the weight prefetch stays in flight across it: vector-memory loads retire in order).  Waves as 2 (row
+// halves) x 4 (96-column groups): MT x 6 accumulator tiles each.  MT = 5 (160 rows) when that fills the CUs' rounds better
+// than MT = 4 (79 000 rows: 494 tiles = 1.93 rounds of 256 against 618 = 2.41).
+constexpr int kLwThreads = 512, kLwN = 384;
+struct LinearWideArgs {
+  const uint16_t *X;       // [M][K]
+  const uint16_t *Wp;      // one-tap pack of W [384][K] (or, transposed, of W [K][384] for a data gradient)
+  const float *bias;       // [384] or nullptr
+  uint16_t *Y;             // [M][384]
+  int M, K;
+};
+template <int MT> constexpr int linear_wide_lds_bytes() {
+  constexpr int rows = MT * 32, stage = rows * (kLwN + 8) * 2, bufs = 2 * rows * 256;
+  return stage > bufs ? stage : bufs;
+}
+
+template <int MT>
+__global__ __launch_bounds__(kLwThreads) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void linear_wide_kernel(LinearWideArgs g) {
+  static_assert(MT == 4 || MT == 5, "128- or 160-row tiles");
+  constexpr int ROWS = MT * 32, BUFB = ROWS * 256, NRND = ROWS * 16 / kLwThreads, CTS = kLwN + 8;
+  extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave & 1, wn = wave >> 1;
+  const int m0 = blockIdx.x * ROWS;
+  const int nch = g.K >> 7, nc64 = g.K >> 6;              // 128-channel slices; 64-channel slices of the pack
+  typedef __attribute__((address_space(3))) void lds_void;
+
+  // DMA: piece p = tid + 512 j: row (tid >> 4) + 32 j, slot tid & 15 holds source chunk (tid & 15) ^ (row & 15)
+  const unsigned src_chunk = (unsigned)(((tid & 15) ^ ((tid >> 4) & 15)) * 16);
+  unsigned xoff[NRND];
+#pragma unroll
+  for (int j = 0; j < NRND; ++j) {
+    const int r = (tid >> 4) + 32 * j;
+    xoff[j] = m0 + r < g.M ? (unsigned)(m0 + r) * (unsigned)g.K * 2u + src_chunk : 0x80000000u;
+  }
+  const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint16_t *>(g.X), 0, (int)((long long)g.M * g.K * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint16_t *>(g.Wp), 0, (int)((long long)kLwN * g.K * 2), 0x00020000);
+  const int lds_piece = (tid - lane) * 16;
+  auto issue_slice = [&](int c) {
+    if (c >= nch) return;
+#pragma unroll
+    for (int j = 0; j < NRND; ++j) {
+      unsigned char *dst = smem + (c & 1) * BUFB + lds_piece + 8192 * j;
+      const unsigned off = (xoff[j] & 0x80000000u) ? 0x80000000u : xoff[j] + (unsigned)c * 256u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrc, (lds_void *)dst, 16, off, 0, 0, 0);
+    }
+  };
+  // weights: step (c, s) = 32 channels c * 128 + s * 32 .. of the 6 column blocks of this wave
+  const unsigned w_lane = (unsigned)lane * 16u;
+  const unsigned w_n16 = (unsigned)(wn * 6);
+  const unsigned w_istride = (unsigned)nc64 * 2048u;
+  auto load_w = [&](gemm_u32x4 (&w)[6], int c, int st) {   // (past the last slice: other blocks' weights or zeros, never multiplied)
+    const unsigned s0 = ((w_n16 * (unsigned)nc64 + (unsigned)(2 * c + (st >> 1))) * 2u + (unsigned)(st & 1)) * 1024u;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) w[i] = __builtin_amdgcn_raw_buffer_load_b128(wsrc, w_lane, s0 + (unsigned)i * w_istride, 0);
+  };
+  const int frag_row = lane & 15, g4 = lane >> 4;
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem;
+  const unsigned a_row = lds0 + (unsigned)((wm * (ROWS / 2) + frag_row) * 256);
+
+  gemm_f32x4 acc[6][MT];
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int j = 0; j < MT; ++j) acc[i][j] = gemm_f32x4{0.f, 0.f, 0.f, 0.f};
+
+  issue_slice(0);
+  gemm_u32x4 wcur[6], wnext[6];
+  load_w(wcur, 0, 0);
+  for (int c = 0; c < nch; ++c) {
+    // slice c has landed for this wave (loads retire in order; the only ones issued after its DMAs are the six weight loads
+    // of its first step), then for everybody; every wave is done with slice c - 1's buffer
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    issue_slice(c + 1);
+    const unsigned bufb = a_row + (unsigned)((c & 1) * BUFB);
+    // fragments one step ahead of the MFMAs within a slice (LDS reads retire in order: lgkmcnt(MT) = "all but the newest MT")
+    gemm_u32x4 xf[MT], xn[MT];
+    {
+      const unsigned a = bufb + 16u * ((unsigned)g4 ^ (unsigned)frag_row);
+#pragma unroll
+      for (int j = 0; j < MT; ++j) asm volatile("ds_read_b128 %0, %1" : "=v"(xf[j]) : "v"(a + (unsigned)(j * 4096)));
+    }
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+      __builtin_amdgcn_sched_barrier(0);
+      if (st < 3) load_w(wnext, c, st + 1);
+      else load_w(wnext, c + 1, 0);
+      if (st < 3) {
+        const unsigned a = bufb + 16u * ((unsigned)((st + 1) * 4 + g4) ^ (unsigned)frag_row);
+#pragma unroll
+        for (int j = 0; j < MT; ++j) asm volatile("ds_read_b128 %0, %1" : "=v"(xn[j]) : "v"(a + (unsigned)(j * 4096)));
+        if constexpr (MT == 4) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(xf[0]), "+v"(xf[1]), "+v"(xf[2]), "+v"(xf[3]));
+        else asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(xf[0]), "+v"(xf[1]), "+v"(xf[2]), "+v"(xf[3]), "+v"(xf[4]));
+      } else {
+        if constexpr (MT == 4) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xf[0]), "+v"(xf[1]), "+v"(xf[2]), "+v"(xf[3]));
+        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xf[0]), "+v"(xf[1]), "+v"(xf[2]), "+v"(xf[3]), "+v"(xf[4]));
+      }
+#pragma unroll
+      for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < MT; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(gemm_bf16x8, wcur[i]),
+                                                              __builtin_bit_cast(gemm_bf16x8, xf[j]), acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) wcur[i] = wnext[i];
+      if (st < 3) {
+#pragma unroll
+        for (int j = 0; j < MT; ++j) xf[j] = xn[j];
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  // ---- store phase: bias; rows of 384 + 8 elements staged over the slice buffers, then whole 16-byte pieces
+  uint16_t *stage = reinterpret_cast<uint16_t *>(smem);
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    const int nl = wn * 96 + i * 16 + g4 * 4;
+    gemm_f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (g.bias) bv = *reinterpret_cast<const gemm_f32x4 *>(g.bias + nl);
+#pragma unroll
+    for (int j = 0; j < MT; ++j) {
+      const int row = wm * (ROWS / 2) + j * 16 + frag_row;
+      const gemm_f32x4 v = acc[i][j] + bv;
+      uint2 o;
+      o.x = gemm_pack2(v.x, v.y);
+      o.y = gemm_pack2(v.z, v.w);
+      *reinterpret_cast<uint2 *>(stage + row * CTS + nl) = o;
+    }
+  }
+  __syncthreads();
+  constexpr int PIECES = ROWS * (kLwN / 8);
+  for (int idx = tid; idx < PIECES; idx += kLwThreads) {
+    const int row = idx / (kLwN / 8), ch = idx - row * (kLwN / 8);
+    if (m0 + row >= g.M) continue;
+    *reinterpret_cast<uint4 *>(g.Y + (long long)(m0 + row) * kLwN + ch * 8) = *reinterpret_cast<const uint4 *>(stage + row * CTS + ch * 8);
   }
 }
 

@@ -1412,6 +1412,37 @@ int snipper_conv3x3_patch_bf16(void *stream, const uint16_t *X, const uint16_t *
   return launch_status();
 }
 
+int snipper_linear_wide_supported(long long M, int N, int K) {
+  return (M >= 8192 && N == kLwN && K >= 256 && K % 128 == 0 && M * K < (1LL << 30)) ? 1 : 0;
+}
+
+int snipper_linear_wide_bf16(void *stream, const uint16_t *X, const uint16_t *Wp, const float *bias, uint16_t *Y, int M, int N, int K) {
+  if (!X || !Wp || !Y) return SNIPPER_E_NULL;
+  if (!snipper_linear_wide_supported(M, N, K) || (((uintptr_t)X | (uintptr_t)Wp | (uintptr_t)Y) & 15) || (bias && ((uintptr_t)bias & 15)))
+    return SNIPPER_E_SHAPE;
+  const LinearWideArgs g{X, Wp, bias, Y, M, K};
+  // 160-row tiles when they fill the rounds of one workgroup per CU better than 128-row tiles (SNIPPER_LINEAR_WIDE_MT = 4 / 5 forces)
+  static const int forced = [] { const char *e = getenv("SNIPPER_LINEAR_WIDE_MT"); return e ? atoi(e) : 0; }();
+  static const int cus = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    return n;
+  }();
+  auto cost = [&](int rows) { const long long t = ((long long)M + rows - 1) / rows; return (double)((t + cus - 1) / cus) * rows; };
+  const int mt = forced == 4 || forced == 5 ? forced : (cost(160) < cost(128) ? 5 : 4);
+  // (more than 64 KB of dynamic LDS: the limit is raised once per process and kernel)
+  static const hipError_t attr4 = hipFuncSetAttribute(reinterpret_cast<const void *>(&linear_wide_kernel<4>),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, linear_wide_lds_bytes<4>());
+  static const hipError_t attr5 = hipFuncSetAttribute(reinterpret_cast<const void *>(&linear_wide_kernel<5>),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, linear_wide_lds_bytes<5>());
+  if (attr4 != hipSuccess || attr5 != hipSuccess) return (int)(attr4 != hipSuccess ? attr4 : attr5);
+  if (mt == 5)
+    hipLaunchKernelGGL(linear_wide_kernel<5>, dim3((unsigned)((M + 159) / 160)), dim3(kLwThreads), linear_wide_lds_bytes<5>(), (hipStream_t)stream, g);
+  else
+    hipLaunchKernelGGL(linear_wide_kernel<4>, dim3((unsigned)((M + 127) / 128)), dim3(kLwThreads), linear_wide_lds_bytes<4>(), (hipStream_t)stream, g);
+  return launch_status();
+}
+
 int snipper_stem7x7_bf16(void *stream, const uint16_t *X4, const uint16_t *Wp, uint16_t *Y, int B, int H, int Wd) {
   if (!X4 || !Wp || !Y) return SNIPPER_E_NULL;
   if (B <= 0 || H <= 0 || Wd <= 0) return SNIPPER_E_SHAPE;

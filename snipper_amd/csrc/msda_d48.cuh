@@ -164,7 +164,7 @@ __global__ __launch_bounds__(kD48Block) void msda_fwd_d48_kernel(
   float acc[CPL];
 #pragma unroll
   for (int c = 0; c < CPL; ++c) acc[c] = 0.f;
-#pragma unroll(LP_T ? LP_T : 4)
+#pragma unroll LP_T ? LP_T : 4
   for (int s = 0; s < LP; ++s) {
     const FwdRecord r = *reinterpret_cast<const FwdRecord *>(my_recs + s * sizeof(FwdRecord));
     const u32x3 v0 = __builtin_amdgcn_raw_buffer_load_b96(rsrc, r.off.x + lane_off, 0, 0);
@@ -312,7 +312,7 @@ __global__ __launch_bounds__(kD48Block) void msda_bwd_d48_f32_kernel(
   const float g0 = ld_go(grad_out, gi, go_bf16), g1 = ld_go(grad_out, gi + G, go_bf16), g2 = ld_go(grad_out, gi + 2 * G, go_bf16);
 
   float keep_a = 0.f, keep_x = 0.f, keep_y = 0.f;
-#pragma unroll(LP_T ? 2 : 1)
+#pragma unroll LP_T ? 2 : 1
   for (int s = 0; s < LP; ++s) {
     const BwdRecord r = *reinterpret_cast<const BwdRecord *>(my_recs + s * sizeof(BwdRecord));
     const float lh = r.q0.x, lw = r.q0.y, a = r.q0.z;

@@ -297,6 +297,26 @@ def linear_patch_bf16(x: torch.Tensor, packed: torch.Tensor, N: int, bias: Optio
     return out
 
 
+def linear_wide_supported(M: int, N: int, K: int) -> bool:
+    return bool(_lib.load().snipper_linear_wide_supported(int(M), int(N), int(K)))
+
+
+def linear_wide_bf16(x: torch.Tensor, packed: torch.Tensor, bias: Optional[torch.Tensor] = None, kind: str = "linear") -> torch.Tensor:
+    """x [M, K] @ W^T + bias -> [M, 384] bf16 on full-width tiles (csrc/conv3x3_patch_bf16.cuh, linear_wide_kernel): K a multiple of
+    128, ``packed`` = linear_pack_bf16's pack of W [384, K] (or the transposed pack of W [K, 384] for a data gradient)."""
+    assert x.is_cuda and x.dtype == torch.bfloat16 and packed.dtype == torch.bfloat16 and x.dim() == 2 and x.is_contiguous()
+    M, K = x.shape
+    assert packed.numel() == 384 * K
+    if bias is not None and bias.dtype != torch.float32:
+        bias = bias.float()
+    out = torch.empty((M, 384), dtype=torch.bfloat16, device=x.device)
+    with _timed(kind, (M, 384, K), 2 * M * 384 * K, 2 * (M * K + 384 * K + M * 384), x.device), _lib.device_guard(x.device):
+        rc = _lib.load().snipper_linear_wide_bf16(_lib.raw_stream(x.device), x.data_ptr(), packed.data_ptr(),
+                                                  bias.data_ptr() if bias is not None else None, out.data_ptr(), M, 384, K)
+    _lib.check(rc, "snipper_linear_wide_bf16")
+    return out
+
+
 def conv3x3_patch_supported(B: int, H: int, W: int, Cin: int, Cout: int) -> bool:
     return bool(_lib.load().snipper_conv3x3_patch_supported(int(B), int(H), int(W), int(Cin), int(Cout)))
 
@@ -550,7 +570,11 @@ class _BigFFN(torch.autograd.Function):
         h = linear_bf16(xb, w1b, b1.float(), None, True, dropout_p, seed)
         # the 1024-deep products on the one-tap patch kernel when this step's packs are there (shadow.lookup_lpacked)
         pk2, pk1 = shadow.lookup_lpacked(w2), shadow.lookup_lpacked(w1)
-        if pk2 is not None and pk2[0] is not None and shadow.lookup(w2) is w2b and linear_patch_supported(h.shape[0], w2.shape[0], w2.shape[1]):
+        if pk2 is not None and pk2[0] is not None and shadow.lookup(w2) is w2b and shadow.LINEAR_WIDE and \
+                linear_wide_supported(h.shape[0], w2.shape[0], w2.shape[1]):
+            z = linear_wide_bf16(h, pk2[0], b2)                   # full-width tiles: the hidden activation crosses L2 once
+        elif pk2 is not None and pk2[0] is not None and shadow.lookup(w2) is w2b and shadow.LINEAR_PATCH and \
+                linear_patch_supported(h.shape[0], w2.shape[0], w2.shape[1]):
             z = linear_patch_bf16(h, pk2[0], w2.shape[0], b2, None, False, None, 64)
         else:
             z = linear_bf16(h, w2b, b2.float())
@@ -573,7 +597,12 @@ class _BigFFN(torch.autograd.Function):
         dW1, db1 = wgrad_bf16(gh, xb)
         dx = None
         if ctx.needs_input_grad[0]:
-            if ctx.w1tp is not None and gh.is_contiguous() and linear_patch_supported(gh.shape[0], w1b.shape[1], w1b.shape[0]):
+            from . import shadow
+            if ctx.w1tp is not None and gh.is_contiguous() and shadow.LINEAR_WIDE and \
+                    linear_wide_supported(gh.shape[0], w1b.shape[1], w1b.shape[0]):
+                dx = linear_wide_bf16(gh, ctx.w1tp, None, kind="linear_nn").view(ctx.x_shape)
+            elif ctx.w1tp is not None and gh.is_contiguous() and shadow.LINEAR_PATCH and \
+                    linear_patch_supported(gh.shape[0], w1b.shape[1], w1b.shape[0]):
                 dx = linear_patch_bf16(gh, ctx.w1tp, w1b.shape[1], None, None, False, None, 64, kind="linear_nn").view(ctx.x_shape)
             else:
                 dx = _dgrad(gh, w1b).view(ctx.x_shape)

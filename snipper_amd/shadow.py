@@ -99,6 +99,9 @@ def lookup_packed(param: torch.Tensor, scale: Optional[torch.Tensor] = None):
 # 42 + 13 launches it takes over cost 2.21 ms against 2.28 ms, the four pack launches add 0.075 ms and the extra look-ups
 # ~1 ms of host issue time: same-box step 22.40 / 22.44 ms without, 23.5 / 25.8 ms with (host-bound in places).
 LINEAR_PATCH = _os.environ.get("SNIPPER_LINEAR_PATCH", "0") == "1"
+# Full-width (128 / 160 rows x 384 columns, 8 waves) tiles for the deep reductions into 384 columns: the feed-forward block's
+# linear2 forward and linear1 data gradient (csrc/conv3x3_patch_bf16.cuh, linear_wide_kernel).  SNIPPER_LINEAR_WIDE=0: tile kernels.
+LINEAR_WIDE = _os.environ.get("SNIPPER_LINEAR_WIDE", "1") != "0"
 
 
 def lookup_lpacked(param: torch.Tensor, scale: Optional[torch.Tensor] = None):
@@ -264,11 +267,16 @@ class WeightShadows:
                 e = _entries[id(w)] = _Entry(w, torch.empty_like(w, dtype=torch.bfloat16))
                 if w.dim() == 2 and wants_transpose(w.shape[0], w.shape[1]):
                     e.dst_t = torch.empty((w.shape[1], w.shape[0]), dtype=torch.bfloat16, device=w.device)
+                if LINEAR_WIDE and w.dim() == 2 and e.packed is None and w.shape[0] == 384 and w.shape[1] >= 512 and w.shape[1] % 128 == 0:
+                    e.packed = torch.empty(w.numel(), dtype=torch.bfloat16, device=w.device)        # forward: deep reduction -> 384
+                if (LINEAR_WIDE and w.dim() == 2 and e.packed_t is None and w.shape[1] == 384 and w.shape[0] >= 512 and
+                        w.shape[0] % 128 == 0 and w.requires_grad):
+                    e.packed_t = torch.empty(w.numel(), dtype=torch.bfloat16, device=w.device)      # its data gradient likewise
                 if LINEAR_PATCH and w.dim() == 2 and w.shape[0] % 64 == 0 and w.shape[1] % 64 == 0:
                     # the feed-forward block's 1024-deep products: linear2's forward, linear1's data gradient
-                    if w.shape[1] >= 512 and w.shape[0] >= 128:
+                    if w.shape[1] >= 512 and w.shape[0] >= 128 and e.packed is None:
                         e.packed = torch.empty(w.numel(), dtype=torch.bfloat16, device=w.device)
-                    if w.shape[0] >= 512 and w.shape[1] >= 128 and w.requires_grad:
+                    if w.shape[0] >= 512 and w.shape[1] >= 128 and w.requires_grad and e.packed_t is None:
                         e.packed_t = torch.empty(w.numel(), dtype=torch.bfloat16, device=w.device)
             if e.version != w._version:
                 cp_src.append(w)

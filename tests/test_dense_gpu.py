@@ -687,3 +687,48 @@ def test_linear_patch_kernel(M, K, N, mode, bn):
             ref = ref.relu()
     err = (got.double() - ref).abs().max().item()
     assert err <= ref.abs().max().item() * 2 ** -8 * 1.01 + 1e-6, err
+
+
+@pytest.mark.parametrize("M,K,mode", [(8192, 1024, "fwd"), (8193 + 70, 512, "fwd"), (79000, 1024, "fwd"), (79000, 1024, "dgrad")])
+@pytest.mark.parametrize("mt", [0, 4, 5])
+def test_linear_wide_kernel(M, K, mode, mt, monkeypatch):
+    """Full-width tiles for deep reductions into 384 columns (linear_wide_kernel, 128- and 160-row tiles, ragged last tile)
+    against float64 on the same bf16 operands and against the tile kernels: forward with a bias, and the data gradient through
+    the transposed pack.  (SNIPPER_LINEAR_WIDE_MT is read once per process: the forced tile heights run in child processes.)"""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent(f"""
+        import torch
+        from snipper_amd.dense import linear_bf16, linear_nn_bf16, linear_pack_bf16, linear_wide_bf16, linear_wide_supported
+        M, K, mode = {M}, {K}, {mode!r}
+        g = torch.Generator().manual_seed(M + K)
+        dev = "cuda:0"
+        assert linear_wide_supported(M, 384, K)
+        if mode == "fwd":
+            w = (torch.randn(384, K, generator=g) / K ** 0.5).to(dev).bfloat16()
+            x = torch.randn(M, K, generator=g).to(dev).bfloat16()
+            b = torch.randn(384, generator=g).to(dev)
+            packed = torch.empty(w.numel(), dtype=torch.bfloat16, device=dev)
+            linear_pack_bf16([(w, packed, False)])
+            got = linear_wide_bf16(x, packed, b)
+            ref = x.double() @ w.double().t() + b.double()
+            old = linear_bf16(x, w, b)
+        else:
+            w = (torch.randn(K, 384, generator=g) / K ** 0.5).to(dev).bfloat16()      # a Linear 384 -> K: dX = dY . W
+            gy = torch.randn(M, K, generator=g).to(dev).bfloat16()
+            packed = torch.empty(w.numel(), dtype=torch.bfloat16, device=dev)
+            linear_pack_bf16([(w, packed, True)])
+            got = linear_wide_bf16(gy, packed, None)
+            ref = gy.double() @ w.double()
+            old = linear_nn_bf16(gy, w)
+        err = (got.double() - ref).abs().max().item()
+        assert err <= ref.abs().max().item() * 2 ** -8 * 1.01 + 1e-6, err
+        assert (got.float() - old.float()).abs().max().item() <= 2 ** -7 * old.float().abs().max().item()
+        print("ok")
+    """)
+    import os
+    env = dict(os.environ)
+    if mt:
+        env["SNIPPER_LINEAR_WIDE_MT"] = str(mt)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600,
+                         cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
