@@ -349,3 +349,36 @@ def test_head_major_value_layout_equals_the_reference_layout():
     with pytest.raises(RuntimeError):
         MSDA.ms_deform_attn_forward(val71, sh1, torch.zeros(1, dtype=torch.int64, device=DEV),
                                     torch.rand(1, 7, 5, 1, 4, 2, device=DEV), torch.rand(1, 7, 5, 1, 4, device=DEV), 64, config=cfg)
+
+
+def test_tile_walk_orders_give_identical_results():
+    """The order in which the matrix-pipe tile kernel's workgroups take the tiles -- tile-major (default), pair-major (debug
+    bit 64), region by region (debug bit 128: csrc/msda_d48_tilemm.cuh, t3_region_order) -- is a scheduling choice: every
+    gradient must come out bit for bit the same (all taps near, so no unordered atomics).  Debug bits need
+    SNIPPER_MSDA_ALLOW_DEBUG=1 at library load: a child process."""
+    import os, subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import numpy as np, torch, sys
+        sys.path.insert(0, "tests")
+        from test_owner_gpu import grid_case, MSDA, _lib, DEV
+        N, shapes, M, P = 2, [(75, 100), (38, 50), (19, 25)], 8, 4
+        v, sh, lsi, loc, attn, go = grid_case(N, shapes, M, P, seed=11, spread_px=2.0, frac_far=0.0)
+        t = lambda a: torch.from_numpy(a).to(DEV)
+        hs = [tuple(x) for x in sh.tolist()]
+        val, got = t(v).to(torch.bfloat16), t(go).to(torch.bfloat16)
+        res = []
+        for dbg in (0, 64, 128, 192):
+            cfg = _lib.Config.defaults()
+            cfg.debug_ablation, cfg.tile_kernel = dbg, 2        # (2 = the matrix-pipe tile kernel also with debug bits set)
+            out = MSDA.ms_deform_attn_backward(val, t(sh), t(lsi), t(loc), t(attn), got, 64, host_shapes=hs,
+                                               grad_value_f32=True, config=cfg)
+            assert _lib.last_variant().startswith("d48_owner_mfma"), _lib.last_variant()
+            res.append([o.clone() for o in out])
+        for r in res[1:]:
+            assert all(torch.equal(a, b) for a, b in zip(res[0], r))
+        print("ok")
+    """)
+    env = dict(os.environ, SNIPPER_MSDA_ALLOW_DEBUG="1")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600,
+                         cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert out.returncode == 0 and "ok" in out.stdout, (out.stdout[-500:], out.stderr[-2000:])
