@@ -65,6 +65,14 @@ from snipper_amd.shadow import WeightShadows
 sh = WeightShadows(model)
 sh.refresh()
 eager = lambda: step(body)
+MODE = os.environ.get("GB_MODE", "")            # "eager" / "graph": only that mode, 12 steps (for a kernel trace of each)
+if MODE:
+    fn = eager if MODE == "eager" else (lambda g=graphed_segments(body, x): step(g))
+    for _ in range(12):
+        fn()
+    torch.cuda.synchronize()
+    print(json.dumps({"mode": MODE, "timing": run(fn)}))
+    sys.exit(0)
 for _ in range(3):
     eager()
 f_ref = [f.detach().float().clone() for f in eager()]
