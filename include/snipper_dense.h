@@ -293,6 +293,22 @@ int snipper_linear_patch_bf16(void *stream, const uint16_t *X, const uint16_t *W
 int snipper_linear_wide_supported(long long M, int N, int K);
 int snipper_linear_wide_bf16(void *stream, const uint16_t *X, const uint16_t *Wp, const float *bias, uint16_t *Y, int M, int N, int K);
 
+/* ---- heat-map targets and loss of the criterion (csrc/heatmap_loss.cuh; reference models/model.py:447-483) ----------------
+ * snipper_heatmap_scatter_f32: one-hot joint maps of all levels in one launch.  kpts [n_person][Tk][K][3] float32 (x, y in
+ *   [0, 1), visibility), sample [n_person] int64; level l's maps [bs][K][T][h[l]][w[l]] start at element base[l] of `out`,
+ *   which the caller has zeroed; a visible joint whose pixel (trunc(x * w), trunc(y * h)) lies inside the map stores 1.0.
+ * snipper_heatmap_loss_forward_f32: partial[i] = block sums of (tm - mem)^2 over the first K channels of each of the nhead
+ *   heads of every position; mem [bs * T * S][C] float32 (the encoder memory), tm[l] the level's blurred targets
+ *   [bs][K][T][hw[l]], start[l] the level's first position in S (levels tile S in order).  The loss is sum(partial) / nhead.
+ * snipper_heatmap_loss_backward_f32: gmem [bs * T * S][C] = gscale[0] * 2 * (mem - tm) on those channels, 0 elsewhere
+ *   (every element written); gscale is a DEVICE scalar. */
+int snipper_heatmap_scatter_f32(void *stream, const float *kpts, const long long *sample, int n_person, int Tk, int T, int K,
+                                int levels, const int *h, const int *w, const long long *base, float *out);
+int snipper_heatmap_loss_forward_f32(void *stream, const float *mem, const float *const *tm, const int *hw, const int *start,
+                                     int levels, int bs, int T, int S, int C, int nhead, int K, float *partial, int n_partial);
+int snipper_heatmap_loss_backward_f32(void *stream, const float *mem, const float *const *tm, const int *hw, const int *start,
+                                      int levels, int bs, int T, int S, int C, int nhead, int K, const float *gscale, float *gmem);
+
 /* ---- element-wise fusions around the core op (csrc/msda_prologue.cuh) --------------------------------
  * dtype codes: 0 = float32, 1 = bfloat16 bits.
  *

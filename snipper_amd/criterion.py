@@ -299,6 +299,69 @@ class PairLosses(torch.autograd.Function):
         return dsk, dsd, None, None, None, None, None
 
 
+class HeatmapLoss(torch.autograd.Function):
+    """sum over levels of mse_loss(target, heat-map views, reduction="sum") / n_heads as ONE node on the encoder memory the
+    views are views of (csrc/heatmap_loss.cuh): one forward launch over all levels (deterministic block sums), one backward
+    launch that writes the whole gradient of the memory.  Reference: models/model.py:447-483."""
+
+    @staticmethod
+    def try_apply(heatmaps, tmaps):
+        src = getattr(heatmaps, "source", None)
+        if src is None or not tmaps:
+            return None
+        memory, hw, nhead, K = src
+        if not (memory.is_cuda and memory.dtype == torch.float32 and memory.is_contiguous() and memory.dim() == 4 and
+                len(hw) == len(tmaps) <= 4 and memory.shape[-1] % nhead == 0 and (memory.shape[-1] // nhead) % 4 == 0):
+            return None
+        bs, T, S, C = memory.shape
+        raws = []
+        for (h, w), tm, hm in zip(hw, tmaps, heatmaps):
+            raw = tm.permute(0, 4, 1, 2, 3)                 # back to the blur's [bs, K, t, h, w]
+            if not (raw.is_contiguous() and raw.dtype == torch.float32 and raw.shape == (bs, K, T, h, w) and
+                    not raw.requires_grad and tuple(hm.shape) == (bs, T, h, w, nhead, K)):
+                return None
+            raws.append(raw)
+        if sum(h * w for h, w in hw) != S:
+            return None
+        return HeatmapLoss.apply(memory, nhead, K, tuple(hw), *raws)
+
+    @staticmethod
+    def _call(fn_name, memory, nhead, K, hw, raws, *tail):
+        import ctypes
+        from . import _lib
+        bs, T, S, C = memory.shape
+        nl = len(hw)
+        tm = (ctypes.c_void_p * nl)(*[r.data_ptr() for r in raws])
+        px = (ctypes.c_int * nl)(*[h * w for h, w in hw])
+        starts, pos = [], 0
+        for h, w in hw:
+            starts.append(pos)
+            pos += h * w
+        st = (ctypes.c_int * nl)(*starts)
+        with _lib.device_guard(memory.device):
+            rc = getattr(_lib.load(), fn_name)(_lib.raw_stream(memory.device), memory.data_ptr(), tm, px, st, nl, bs, T, S, C,
+                                              nhead, K, *tail)
+        _lib.check(rc, fn_name)
+
+    @staticmethod
+    def forward(ctx, memory, nhead, K, hw, *raws):
+        n_partial = 1024
+        partial = torch.empty(n_partial, dtype=torch.float32, device=memory.device)
+        HeatmapLoss._call("snipper_heatmap_loss_forward_f32", memory, nhead, K, hw, raws, partial.data_ptr(), n_partial)
+        ctx.save_for_backward(memory, *raws)
+        ctx.geom = (nhead, K, hw)
+        return partial.sum() / nhead
+
+    @staticmethod
+    def backward(ctx, g):
+        memory, *raws = ctx.saved_tensors
+        nhead, K, hw = ctx.geom
+        gs = (g.float() / nhead).contiguous()               # device scalar: d loss / d (sum of squared differences)
+        gmem = torch.empty_like(memory)
+        HeatmapLoss._call("snipper_heatmap_loss_backward_f32", memory, nhead, K, hw, raws, gs.data_ptr(), gmem.data_ptr())
+        return (gmem, None, None, None) + (None,) * len(raws)
+
+
 class SetCriterion(nn.Module):
     def __init__(self, matcher, losses, eos_coef, weight_dict, cont_weights=None):
         super().__init__()
@@ -383,14 +446,18 @@ class SetCriterion(nn.Module):
         maps = []
         bs = len(targets)
         counts = [int(tgt["kpts2d"].shape[0]) for tgt in targets]
-        sample = torch.cat([torch.full((n,), i, dtype=torch.long, device=device) for i, n in enumerate(counts)])
+        skey = (tuple(counts), str(device))
+        if getattr(self, "_sample_key", None) != skey:               # (a constant of the persons per sample: built once)
+            self._sample = torch.cat([torch.full((n,), i, dtype=torch.long, device=device) for i, n in enumerate(counts)])
+            self._sample_key = skey
+        sample = self._sample
         t_all = max(t for t, _, _ in spatial)
         k_all = torch.cat([tgt["kpts2d"][:, :t_all] for tgt in targets], 0)         # [Nsum, t, K, 3]
         K = k_all.shape[2]
         # pixel coordinates and validity for ALL levels in one set of launches: [levels, Nsum, t, K]
         whs = torch.tensor([[w, h] for _, h, w in spatial], dtype=k_all.dtype).to(device, non_blocking=True) \
-            if getattr(self, "_wh_key", None) != tuple(spatial) else self._wh
-        self._wh_key, self._wh = tuple(spatial), whs
+            if getattr(self, "_wh_key", None) != (tuple(spatial), str(device), k_all.dtype) else self._wh
+        self._wh_key, self._wh = (tuple(spatial), str(device), k_all.dtype), whs
         xy = (k_all[None, ..., 0:2] * whs[:, None, None, None, :]).long()
         lim = whs.long()[:, None, None, None, :]
         ok_all = (k_all[None, ..., 2] > 0) & ((xy >= 0) & (xy < lim)).all(-1)
@@ -405,6 +472,29 @@ class SetCriterion(nn.Module):
         if all(t == t_all for t, _, _ in spatial):
             # all levels in ONE buffer and one set of launches: level l's maps start at base[l]
             sizes = [bs * K * t_all * h * w for _, h, w in spatial]
+            if (k_all.is_cuda and k_all.dtype == torch.float32 and len(spatial) <= 4 and k_all.shape[-1] == 3 and
+                    not (k_all.requires_grad and torch.is_grad_enabled())):
+                # ONE launch for the whole index arithmetic below (csrc/heatmap_loss.cuh, heatmap_scatter_kernel): a visible
+                # joint inside the map stores 1.0 -- the blur clamps at 1, so it never sees the count of joints on a pixel
+                import ctypes
+                from . import _lib
+                k_all = k_all.contiguous()
+                hm_all = torch.zeros(sum(sizes), device=device)
+                nl = len(spatial)
+                hh = (ctypes.c_int * nl)(*[h for _, h, _ in spatial])
+                ww = (ctypes.c_int * nl)(*[w for _, _, w in spatial])
+                base = (ctypes.c_longlong * nl)(*[sum(sizes[:i]) for i in range(nl)])
+                with _lib.device_guard(k_all.device):
+                    rc = _lib.load().snipper_heatmap_scatter_f32(
+                        _lib.raw_stream(k_all.device), k_all.data_ptr(), sample.data_ptr(), k_all.shape[0], k_all.shape[1], t_all,
+                        K, nl, hh, ww, base, hm_all.data_ptr())
+                _lib.check(rc, "snipper_heatmap_scatter_f32")
+                off = 0
+                for (t, h, w), n, ksize in zip(spatial, sizes, ksizes):
+                    hm = hm_all[off:off + n].view(bs, K, t, h, w)
+                    off += n
+                    maps.append(gaussian_blur(hm, ksize, clamp_max=1.0).permute(0, 2, 3, 4, 1))   # [bs, t, h, w, K]
+                return maps
             key = ("hm_geom", tuple(spatial), bs, K, str(device))
             geom = getattr(self, "_hm_geom", None)
             if geom is None or geom[0] != key:
@@ -436,6 +526,9 @@ class SetCriterion(nn.Module):
     def loss_heatmap(self, outputs, targets):
         heatmaps = outputs["heatmaps"]                                               # [(bs, t, h, w, nhead, K')]
         tmaps = self.heatmap_targets(targets, [hm.shape[1:4] for hm in heatmaps], heatmaps[0].device)
+        fused = HeatmapLoss.try_apply(heatmaps, tmaps)
+        if fused is not None:
+            return fused
         total = 0
         for hm, tm in zip(heatmaps, tmaps):
             nhead = hm.shape[4]

@@ -28,6 +28,7 @@
 #include "gn_tokens.cuh"
 #include "pair_losses.cuh"
 #include "heatmap_blur.cuh"
+#include "heatmap_loss.cuh"
 #include "msda_prologue.cuh"
 #include "lsap.cuh"
 #include "adamw_flat.cuh"
@@ -797,6 +798,62 @@ int snipper_heatmap_blur_f32(void *stream, const float *in, float *out, int n_im
   for (int i = 0; i < ksize; ++i) a.w[i] = weights[i];              // (host array: the taps travel in the kernel argument)
   const long long total = (long long)n_images * H * W;
   hipLaunchKernelGGL(heatmap_blur_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+  return launch_status();
+}
+
+int snipper_heatmap_scatter_f32(void *stream, const float *kpts, const long long *sample, int n_person, int Tk, int T, int K,
+                                int levels, const int *h, const int *w, const long long *base, float *out) {
+  if (!kpts || !sample || !h || !w || !base || !out) return SNIPPER_E_NULL;
+  if (n_person < 0 || Tk <= 0 || T <= 0 || T > Tk || K <= 0 || levels <= 0 || levels > kHlMaxLevels) return SNIPPER_E_SHAPE;
+  if (n_person == 0) return SNIPPER_OK;
+  HeatmapScatterArgs a{};
+  a.kpts = kpts; a.sample = sample; a.out = out; a.levels = levels; a.n_person = n_person; a.Tk = Tk; a.T = T; a.K = K;
+  for (int l = 0; l < levels; ++l) {
+    if (h[l] <= 0 || w[l] <= 0 || base[l] < 0) return SNIPPER_E_SHAPE;
+    a.h[l] = h[l]; a.w[l] = w[l]; a.base[l] = base[l];
+  }
+  const long long total = (long long)levels * n_person * T * K;
+  hipLaunchKernelGGL(heatmap_scatter_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+  return launch_status();
+}
+
+namespace {
+int heatmap_loss_args(HeatmapLossArgs &a, const float *mem, const float *const *tm, const int *hw, const int *start, int levels,
+                      int bs, int T, int S, int C, int nhead, int K) {
+  if (!mem || !tm || !hw || !start) return SNIPPER_E_NULL;
+  if (levels <= 0 || levels > kHlMaxLevels || bs <= 0 || T <= 0 || S <= 0 || C <= 0 || nhead <= 0 || C % nhead || (C / nhead) % 4 ||
+      K <= 0 || K > C / nhead || ((uintptr_t)mem & 15) || (long long)bs * T * S * C >= (1LL << 40))
+    return SNIPPER_E_SHAPE;
+  a = HeatmapLossArgs{};
+  a.mem = mem; a.levels = levels; a.bs = bs; a.T = T; a.S = S; a.C = C; a.nhead = nhead; a.D = C / nhead; a.K = K;
+  int pos = 0;
+  for (int l = 0; l < levels; ++l) {
+    if (!tm[l] || hw[l] <= 0 || start[l] != pos) return SNIPPER_E_SHAPE;        // levels tile S in order
+    a.tm[l] = tm[l]; a.hw[l] = hw[l]; a.start[l] = start[l];
+    pos += hw[l];
+  }
+  return pos == S ? SNIPPER_OK : SNIPPER_E_SHAPE;
+}
+}  // namespace
+
+int snipper_heatmap_loss_forward_f32(void *stream, const float *mem, const float *const *tm, const int *hw, const int *start,
+                                     int levels, int bs, int T, int S, int C, int nhead, int K, float *partial, int n_partial) {
+  HeatmapLossArgs a;
+  if (int rc = heatmap_loss_args(a, mem, tm, hw, start, levels, bs, T, S, C, nhead, K)) return rc;
+  if (!partial || n_partial <= 0) return SNIPPER_E_NULL;
+  a.partial = partial;
+  hipLaunchKernelGGL(heatmap_loss_fwd_kernel, dim3((unsigned)n_partial), dim3(256), 0, (hipStream_t)stream, a);
+  return launch_status();
+}
+
+int snipper_heatmap_loss_backward_f32(void *stream, const float *mem, const float *const *tm, const int *hw, const int *start,
+                                      int levels, int bs, int T, int S, int C, int nhead, int K, const float *gscale, float *gmem) {
+  HeatmapLossArgs a;
+  if (int rc = heatmap_loss_args(a, mem, tm, hw, start, levels, bs, T, S, C, nhead, K)) return rc;
+  if (!gscale || !gmem || ((uintptr_t)gmem & 15)) return SNIPPER_E_NULL;
+  a.gscale = gscale; a.gmem = gmem;
+  const long long total = (long long)bs * T * S * (C / 4);
+  hipLaunchKernelGGL(heatmap_loss_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
   return launch_status();
 }
 

@@ -659,10 +659,13 @@ class DeformableTransformer(nn.Module):
 
     def _decode(self, memory, hw, sizes, spatial_shapes, level_start_index, valid_ratios, mask, query_embed):
         bs, _, _, c = memory.shape
-        heatmaps = []   # first num_keypoints channels of every head, per level (views; reference :141-149)
+        heatmaps = HeatmapViews()   # first num_keypoints channels of every head, per level (views; reference :141-149)
         for chunk, (h, w) in zip(memory.split(sizes, dim=2), hw):
             grid = chunk.reshape(bs, self.n_frame, h, w, self.nhead, c // self.nhead)
             heatmaps.append(grid[..., 0:self.num_keypoints])
+        # (what the views are views OF: the criterion's fused heat-map loss reads the memory itself and writes its whole
+        #  gradient in one launch -- criterion.HeatmapLoss)
+        heatmaps.source = (memory, [tuple(x) for x in hw], self.nhead, self.num_keypoints)
 
         t_all = self.n_frame + self.n_future_frame
         n_query = query_embed.shape[0] // t_all
@@ -675,6 +678,12 @@ class DeformableTransformer(nn.Module):
         hs, inter_references, inter_att = self.decoder(query_obj, init_reference, memory, spatial_shapes,
                                                        level_start_index, valid_ratios, query_pos, mask)
         return hs, heatmaps, init_reference, inter_references, inter_att
+
+
+class HeatmapViews(list):
+    """The per-level heat-map views of the encoder memory (a plain list for every consumer) with a note of where they
+    came from: ``source`` = (memory [bs, T, S, C], [(h, w)] per level, n_heads, n_keypoints)."""
+    source = None
 
 
 def build_deforamble_transformer(args):

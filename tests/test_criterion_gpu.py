@@ -124,3 +124,54 @@ def test_heatmap_blur_kernel_matches_the_convolution_formulation(h, w, k):
     torch.testing.assert_close(got.cpu(), want, rtol=1e-5, atol=1e-6)
     noclamp = gaussian_blur(img.to(DEV), k)
     torch.testing.assert_close(noclamp.cpu(), gaussian_blur(img, k), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("bs,T,hw,counts", [(2, 4, [(19, 25), (10, 13), (5, 7)], [3, 2]), (1, 3, [(12, 9), (6, 5)], [4]),
+                                             (2, 4, [(75, 100), (38, 50), (19, 25)], [2, 0])])
+def test_fused_heatmap_targets_and_loss_equal_the_tensor_formulation(bs, T, hw, counts):
+    """csrc/heatmap_loss.cuh: the one-launch scatter of the joint maps and the one-node heat-map loss on the encoder memory
+    (value and the WHOLE gradient of the memory) against the tensor formulation of models/model.py:447-483 on the same inputs
+    (views of the memory as models/deformable_transformer.py:141-149 makes them; joints outside the map, invisible joints,
+    several joints on one pixel, a sample without persons)."""
+    from snipper_amd.criterion import SetCriterion, HeatmapLoss
+    from snipper_amd.deformable_transformer import HeatmapViews
+    torch.manual_seed(sum(counts) + T)
+    nhead, K, C = 8, 15, 384
+    S = sum(h * w for h, w in hw)
+    crit = SetCriterion(None, ["heatmap"], 0.5, {}).to(DEV)
+    targets = []
+    for n in counts:
+        k = torch.rand(n, T + 1, K, 3, device=DEV)
+        k[..., 0:2] = k[..., 0:2] * 1.3 - 0.15                       # some joints outside the image
+        k[..., 2] = (k[..., 2] > 0.3).float()                        # some invisible
+        if n > 1:
+            k[1, :, :3] = k[0, :, :3]                                # several joints on one pixel
+        targets.append({"kpts2d": k})
+
+    def views(mem):
+        out = HeatmapViews()
+        pos = 0
+        for h, w in hw:
+            grid = mem[:, :, pos:pos + h * w].reshape(bs, T, h, w, nhead, C // nhead)
+            out.append(grid[..., 0:K])
+            pos += h * w
+        return out
+
+    mem_a = torch.randn(bs, T, S, C, device=DEV, requires_grad=True)
+    mem_b = mem_a.detach().clone().requires_grad_(True)
+    va, vb = views(mem_a), views(mem_b)
+    va.source = (mem_a, hw, nhead, K)
+    la = crit.loss_heatmap({"heatmaps": va}, targets)
+    assert la.grad_fn is not None and "HeatmapLoss" in type(la.grad_fn).__name__
+    # the reference formulation: plain list (no source), and the tensor path of the targets (CPU copy of the keypoints)
+    tm_ref = crit.heatmap_targets([{"kpts2d": t["kpts2d"].cpu()} for t in targets], [v.shape[1:4] for v in vb], torch.device("cpu"))
+    tm_gpu = crit.heatmap_targets(targets, [v.shape[1:4] for v in vb], torch.device(DEV))
+    for a, b in zip(tm_gpu, tm_ref):
+        torch.testing.assert_close(a.cpu(), b, rtol=1e-5, atol=1e-6)
+    lb = crit.loss_heatmap({"heatmaps": list(vb)}, targets)
+    torch.testing.assert_close(la, lb, rtol=2e-5, atol=1e-4)
+    w = torch.tensor(0.37, device=DEV)
+    (la * w).backward()
+    (lb * w).backward()
+    torch.testing.assert_close(mem_a.grad, mem_b.grad, rtol=1e-5, atol=1e-6)
+    assert torch.equal(la, crit.loss_heatmap({"heatmaps": va}, targets))          # deterministic
