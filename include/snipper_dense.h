@@ -293,6 +293,13 @@ int snipper_linear_patch_bf16(void *stream, const uint16_t *X, const uint16_t *W
 int snipper_linear_wide_supported(long long M, int N, int K);
 int snipper_linear_wide_bf16(void *stream, const uint16_t *X, const uint16_t *Wp, const float *bias, uint16_t *Y, int M, int N, int K);
 
+/* bf16 working copies of many float32 tensors in one launch: dst[e] = bf16(src[e] * scale[e / inner]) (scale == NULL: a plain
+ * cast).  `items` is a DEVICE array of n_items records {const float *src; uint16_t *dst; const float *scale; int64 numel;
+ * int32 inner; int32 pad} (40 bytes; numel % 8 == 0; inner % 8 == 0 where a scale is given; 16-byte aligned src / dst),
+ * `block_end` a DEVICE array of the running count of 2 048-element blocks (block_end[n_items - 1] == n_blocks).  Replaces the
+ * autocast casts of the weights (and the frozen-BatchNorm folding, reference models/backbone.py:27-64) once per step. */
+int snipper_cast_scale_table_bf16(void *stream, const void *items, const int *block_end, int n_items, int n_blocks);
+
 /* ---- heat-map targets and loss of the criterion (csrc/heatmap_loss.cuh; reference models/model.py:447-483) ----------------
  * snipper_heatmap_scatter_f32: one-hot joint maps of all levels in one launch.  kpts [n_person][Tk][K][3] float32 (x, y in
  *   [0, 1), visibility), sample [n_person] int64; level l's maps [bs][K][T][h[l]][w[l]] start at element base[l] of `out`,

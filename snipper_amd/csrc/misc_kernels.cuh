@@ -54,4 +54,36 @@ __global__ __launch_bounds__(256) void stem_pack_kernel(const float *__restrict_
   dst[0] = o0; dst[1] = o1;
 }
 
+// ---- bf16 working copies of many float32 weights in ONE launch, a per-output-channel scale folded in ----------------------
+// dst[e] = bf16(src[e] * scale[e / inner]) (scale == nullptr: plain cast) for a TABLE of tensors that lives in device memory
+// (the per-step refresh of the weight shadows, snipper_amd/shadow.py: ~160 tensors, 41 M elements; the table is a constant of
+// the model and is uploaded once).  PyTorch's multi-tensor path for the same work is a _foreach_mul by full-size copies of the
+// frozen-BN scales into temporaries plus _foreach_copy_ casts: 162 us and 93 MB of scale copies per step; this reads every
+// weight once and writes its bf16 copy: ~45 us.  Block b belongs to the item i with block_end[i - 1] <= b < block_end[i]
+// (binary search); 2 048 elements per block, 8 per thread; numel % 8 == 0, inner % 8 == 0 or no scale.
+struct CastItem {
+  const float *src; uint16_t *dst; const float *scale;
+  long long numel;
+  int inner, pad;
+};
+__global__ __launch_bounds__(256) void cast_scale_table_kernel(const CastItem *__restrict__ items, const int *__restrict__ block_end,
+                                                                int n_items) {
+  int lo = 0, hi = n_items - 1;
+  while (lo < hi) {                                   // first item whose block_end exceeds this block
+    const int mid = (lo + hi) >> 1;
+    if ((int)blockIdx.x < block_end[mid]) hi = mid; else lo = mid + 1;
+  }
+  const CastItem it = items[lo];
+  const long long e = ((long long)((int)blockIdx.x - (lo ? block_end[lo - 1] : 0)) * 256 + threadIdx.x) * 8;
+  if (e >= it.numel) return;
+  const float4 a = *reinterpret_cast<const float4 *>(it.src + e), b = *reinterpret_cast<const float4 *>(it.src + e + 4);
+  const float sc = it.scale ? it.scale[e / it.inner] : 1.f;
+  typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+  auto pk = [](float x, float y) {
+    return (unsigned)__builtin_bit_cast(uint16_t, (__bf16)x) | ((unsigned)__builtin_bit_cast(uint16_t, (__bf16)y) << 16);
+  };
+  const u32x4 o = {pk(a.x * sc, a.y * sc), pk(a.z * sc, a.w * sc), pk(b.x * sc, b.y * sc), pk(b.z * sc, b.w * sc)};
+  *reinterpret_cast<u32x4 *>(it.dst + e) = o;
+}
+
 }  // namespace snipper

@@ -801,6 +801,14 @@ int snipper_heatmap_blur_f32(void *stream, const float *in, float *out, int n_im
   return launch_status();
 }
 
+int snipper_cast_scale_table_bf16(void *stream, const void *items, const int *block_end, int n_items, int n_blocks) {
+  if (!items || !block_end) return SNIPPER_E_NULL;
+  if (n_items <= 0 || n_blocks <= 0 || (((uintptr_t)items | (uintptr_t)block_end) & 7) || sizeof(CastItem) != 40) return SNIPPER_E_SHAPE;
+  hipLaunchKernelGGL(cast_scale_table_kernel, dim3((unsigned)n_blocks), dim3(256), 0, (hipStream_t)stream,
+                     (const CastItem *)items, block_end, n_items);
+  return launch_status();
+}
+
 int snipper_heatmap_scatter_f32(void *stream, const float *kpts, const long long *sample, int n_person, int Tk, int T, int K,
                                 int levels, const int *h, const int *w, const long long *base, float *out) {
   if (!kpts || !sample || !h || !w || !base || !out) return SNIPPER_E_NULL;

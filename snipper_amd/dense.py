@@ -122,6 +122,55 @@ def linear_wres_bf16(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch
     return out
 
 
+_CAST_TABLES: dict = {}
+
+
+def _dense_layout(t: torch.Tensor) -> bool:
+    return t.is_contiguous() or (t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last))
+
+
+def cast_scale_table_bf16(items) -> bool:
+    """dst = bf16(src * scale[out channel]) for a list of (src float32, dst bf16 with src's layout, scale [src.shape[0]] float32 or
+    None) in ONE launch (csrc/misc_kernels.cuh, cast_scale_table_kernel).  The table of pointers is uploaded once per distinct
+    list (the per-step refresh of the weight shadows passes the same tensors every step).  Returns False -- nothing launched --
+    when a tensor does not fit the kernel (the caller then takes its PyTorch path)."""
+    import numpy as np
+    items = list(items)
+    if not items:
+        return True
+    key = tuple((s_.data_ptr(), d_.data_ptr(), 0 if sc is None else sc.data_ptr(), s_.numel()) for s_, d_, sc in items)
+    hit = _CAST_TABLES.get(key)
+    if hit is None:
+        dev = items[0][0].device
+        rec = np.zeros(len(items), dtype=np.dtype([("src", "<u8"), ("dst", "<u8"), ("scale", "<u8"), ("numel", "<i8"),
+                                                   ("inner", "<i4"), ("pad", "<i4")]))
+        ends, blocks = [], 0
+        for i, (s_, d_, sc) in enumerate(items):
+            n = s_.numel()
+            inner = n // max(1, s_.shape[0])
+            ok = (s_.is_cuda and s_.device == dev and d_.device == dev and s_.dtype == torch.float32 and d_.dtype == torch.bfloat16 and
+                  s_.shape == d_.shape and s_.stride() == d_.stride() and _dense_layout(s_) and n % 8 == 0 and n > 0 and
+                  s_.data_ptr() % 16 == 0 and d_.data_ptr() % 16 == 0 and
+                  (sc is None or (sc.dtype == torch.float32 and sc.is_contiguous() and sc.numel() == s_.shape[0] and
+                                  sc.device == dev and inner % 8 == 0)))
+            if not ok:
+                return False
+            rec[i] = (s_.data_ptr(), d_.data_ptr(), 0 if sc is None else sc.data_ptr(), n, inner, 0)
+            blocks += (n + 2047) // 2048
+            ends.append(blocks)
+        table = torch.from_numpy(rec.view(np.uint8).copy()).to(dev)
+        block_end = torch.tensor(ends, dtype=torch.int32).to(dev)
+        if len(_CAST_TABLES) > 8:
+            _CAST_TABLES.clear()
+        hit = _CAST_TABLES[key] = (table, block_end, len(items), blocks)
+    table, block_end, n_items, blocks = hit
+    with _lib.device_guard(table.device):
+        rc = _lib.load().snipper_cast_scale_table_bf16(_lib.raw_stream(table.device), table.data_ptr(), block_end.data_ptr(),
+                                                       n_items, blocks)
+    _lib.check(rc, "snipper_cast_scale_table_bf16")
+    return True
+
+
 _TRANSPOSE_ARGS: dict = {}      # tuple of the tensors' ids -> (weak references, prepared argument arrays per launch)
 
 

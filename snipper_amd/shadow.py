@@ -99,6 +99,7 @@ def lookup_packed(param: torch.Tensor, scale: Optional[torch.Tensor] = None):
 # 42 + 13 launches it takes over cost 2.21 ms against 2.28 ms, the four pack launches add 0.075 ms and the extra look-ups
 # ~1 ms of host issue time: same-box step 22.40 / 22.44 ms without, 23.5 / 25.8 ms with (host-bound in places).
 LINEAR_PATCH = _os.environ.get("SNIPPER_LINEAR_PATCH", "0") == "1"
+CAST_TABLE = _os.environ.get("SNIPPER_CAST_TABLE", "1") != "0"      # one-launch weight casts (0: PyTorch multi-tensor ops, A/B)
 # Full-width (128 / 160 rows x 384 columns, 8 waves) tiles for the deep reductions into 384 columns: the feed-forward block's
 # linear2 forward and linear1 data gradient (csrc/conv3x3_patch_bf16.cuh, linear_wide_kernel).  SNIPPER_LINEAR_WIDE=0: tile kernels.
 LINEAR_WIDE = _os.environ.get("SNIPPER_LINEAR_WIDE", "1") != "0"
@@ -250,9 +251,10 @@ class WeightShadows:
                     packs.append((e.dst, e.packed, False))
                     if e.packed_t is not None:
                         packs.append((e.dst, e.packed_t, True))
-                if e.scale is not scale or e.scale_full is None:
-                    # frozen BatchNorm: built once.  A broadcast operand sends _foreach_mul down its one-kernel-per-tensor
-                    # path (42 launches per step here); a full-size one with the weight's strides keeps it multi-tensor.
+                if not CAST_TABLE and (e.scale is not scale or e.scale_full is None):
+                    # (the multi-tensor fallback) frozen BatchNorm: built once.  A broadcast operand sends _foreach_mul down its
+                    # one-kernel-per-tensor path (42 launches per step here); a full-size one with the weight's strides keeps
+                    # it multi-tensor.
                     e.scale_full = torch.empty_like(w).copy_(scale.view(-1, 1, 1, 1).expand_as(w))
                 mul_src.append(w)
                 mul_scale.append(e.scale_full)
@@ -308,8 +310,32 @@ class WeightShadows:
                 fin.append((m, vers))
                 if m.w_t is not None:
                     tr.append((m.w, m.w_t))
+        # ONE launch for every bf16 <- float32 weight copy of the step, the frozen-BN scale folded in per output channel
+        # (csrc/misc_kernels.cuh, cast_scale_table_kernel; the pointer table is uploaded once): it replaces a _foreach_mul by
+        # full-size scale copies into temporaries and three _foreach_copy_ casts (162 -> ~45 us per step).  Tensors the kernel
+        # does not take (and the float32 <- float32 bias copies) keep the multi-tensor path below.
+        if CAST_TABLE and (mul_src or cp_src):
+            items = [(w, e.dst, e.scale) for w, e in zip(mul_src, mul_dst)]
+            rest_src, rest_dst = [], []
+            for d, w in zip(cp_dst, cp_src):
+                t = d.dst if isinstance(d, _Entry) else d
+                if t.dtype == torch.bfloat16 and w.dtype == torch.float32:
+                    items.append((w, t, None))
+                else:
+                    rest_src.append(w)
+                    rest_dst.append(d)
+            from .dense import cast_scale_table_bf16
+            if all(sc is None or (sc.dtype == torch.float32 and sc.dim() == 1) for _, _, sc in items) and cast_scale_table_bf16(items):
+                for e, w in zip(mul_dst, mul_src):
+                    e.version = w._version
+                for d, w in zip(cp_dst, cp_src):
+                    if isinstance(d, _Entry):
+                        d.version = w._version
+                mul_src, cp_src, cp_dst = [], rest_src, rest_dst
         if mul_src:
-            tmp = torch._foreach_mul(mul_src, mul_scale)
+            tmp = torch._foreach_mul(mul_src, [e.scale_full if e.scale_full is not None else
+                                               torch.empty_like(w).copy_(e.scale.view(-1, 1, 1, 1).expand_as(w))
+                                               for e, w in zip(mul_dst, mul_src)])
             torch._foreach_copy_([e.dst for e in mul_dst], tmp)
             for e, w in zip(mul_dst, mul_src):
                 e.version = w._version
