@@ -293,6 +293,11 @@ int snipper_linear_patch_bf16(void *stream, const uint16_t *X, const uint16_t *W
 int snipper_linear_wide_supported(long long M, int N, int K);
 int snipper_linear_wide_bf16(void *stream, const uint16_t *X, const uint16_t *Wp, const float *bias, uint16_t *Y, int M, int N, int K);
 
+/* out[bt][S][C] (bf16) = cat over levels of pos[l][bt][hw[l]][C] (float32) + level_embed[l][C]: the encoder's position +
+ * level embedding (reference models/deformable_transformer.py:118-121) written once in the dtype its kernels read. */
+int snipper_level_pos_bf16(void *stream, const float *const *pos, const int *hw, int levels, const float *level_embed, int bt,
+                           int C, uint16_t *out);
+
 /* bf16 working copies of many float32 tensors in one launch: dst[e] = bf16(src[e] * scale[e / inner]) (scale == NULL: a plain
  * cast).  `items` is a DEVICE array of n_items records {const float *src; uint16_t *dst; const float *scale; int64 numel;
  * int32 inner; int32 pad} (40 bytes; numel % 8 == 0; inner % 8 == 0 where a scale is given; 16-byte aligned src / dst),

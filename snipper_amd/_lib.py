@@ -121,6 +121,7 @@ EXPORTS = {
                                    c_void_p, c_int], c_int),
     "snipper_linear_wide_supported": ([c_longlong, c_int, c_int], c_int),
     "snipper_linear_wide_bf16": ([c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int], c_int),
+    "snipper_level_pos_bf16": ([c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p], c_int),
     "snipper_cast_scale_table_bf16": ([c_void_p, c_void_p, c_void_p, c_int, c_int], c_int),
     "snipper_heatmap_scatter_f32": ([c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                      c_void_p], c_int),

@@ -178,6 +178,7 @@ class _PointwiseConvBN(torch.autograd.Function):
             y = linear_bf16(x2, w_eff, shift, res2, relu)
         ctx.relu, ctx.has_res = relu and not pregated, res2 is not None
         ctx.wshape, ctx.wdtype, ctx.wstride = weight.shape, weight.dtype, weight.stride()
+        ctx.w_ref = weight
         ctx.save_for_backward(x2, w_eff, scale, y if ctx.relu else None)
         ctx.fork, ctx.gate_input = fork, gate_input
         if fork:
@@ -195,9 +196,12 @@ class _PointwiseConvBN(torch.autograd.Function):
         dw = None
         if ctx.needs_input_grad[1]:
             from .dense import wgrad_bf16
-            dw, _ = wgrad_bf16(g, x2, want_bias=False, scale=scale)     # BN scale folded into the reduction kernel
+            from .dense import _grad_out_conv
+            gv = _grad_out_conv(ctx.w_ref) if ctx.wdtype == torch.float32 else None      # the flat gradient buffer's slice, if any
+            out2 = None if gv is None else gv.as_strided((ctx.wshape[0], ctx.wshape[1]), (ctx.wshape[1], 1))
+            dw, _ = wgrad_bf16(g, x2, want_bias=False, scale=scale, out=out2)     # BN scale folded into the reduction kernel
             # same memory, the parameter's own strides (NHWC weights: DDP aliases its bucket only when they match)
-            dw = dw.to(ctx.wdtype).as_strided(ctx.wshape, ctx.wstride)
+            dw = gv if gv is not None else dw.to(ctx.wdtype).as_strided(ctx.wshape, ctx.wstride)
         dx = None
         if ctx.needs_input_grad[0]:
             skip = gskip if ctx.fork else None
@@ -244,6 +248,7 @@ class _Conv3x3BN(torch.autograd.Function):
             y = conv3x3_bf16(x, w_eff, shift, stride, relu)
         ctx.w_t = shadow.lookup_t(weight) if shadow.lookup(weight, scale) is w_eff else None      # (this step's, if kept)
         ctx.stride, ctx.relu, ctx.wdtype, ctx.gate_input = stride, relu and not pregated, weight.dtype, gate_input
+        ctx.w_ref = weight
         ctx.save_for_backward(x, w_eff, scale, y if ctx.relu else None)
         return y
 
@@ -268,7 +273,9 @@ class _Conv3x3BN(torch.autograd.Function):
                 dx = torch.ops.aten.threshold_backward(dx, x, 0)
         if own_wgrad:
             # split-reduction kernel, BN scale folded into its second pass; float32, channels_last like the parameter
-            dw = wgrad_conv3x3_bf16(g, x, ctx.stride, scale).to(ctx.wdtype)
+            from .dense import _grad_out_conv
+            gv = _grad_out_conv(ctx.w_ref) if ctx.wdtype == torch.float32 else None
+            dw = wgrad_conv3x3_bf16(g, x, ctx.stride, scale, out=gv).to(ctx.wdtype)
         gate = x if ctx.gate_input else None      # x came out of a ReLU that left its backward to this node
         if own_dgrad and ctx.stride == 1 and ctx.packed_t is not None:
             from .dense import conv3x3_patch_bf16

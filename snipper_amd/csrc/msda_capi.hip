@@ -801,6 +801,26 @@ int snipper_heatmap_blur_f32(void *stream, const float *in, float *out, int n_im
   return launch_status();
 }
 
+int snipper_level_pos_bf16(void *stream, const float *const *pos, const int *hw, int levels, const float *level_embed, int bt,
+                           int C, uint16_t *out) {
+  if (!pos || !hw || !level_embed || !out) return SNIPPER_E_NULL;
+  if (levels <= 0 || levels > kLpMaxLevels || bt <= 0 || C <= 0 || C % 8 || (((uintptr_t)level_embed | (uintptr_t)out) & 15))
+    return SNIPPER_E_SHAPE;
+  LevelPosArgs a{};
+  a.level_embed = level_embed; a.out = out; a.levels = levels; a.bt = bt; a.C = C;
+  int S = 0;
+  for (int l = 0; l < levels; ++l) {
+    if (!pos[l] || hw[l] <= 0 || ((uintptr_t)pos[l] & 15)) return SNIPPER_E_SHAPE;
+    a.pos[l] = pos[l]; a.hw[l] = hw[l]; a.start[l] = S;
+    S += hw[l];
+  }
+  a.S = S;
+  const long long total = (long long)bt * S * (C / 8);
+  if (total >= (1LL << 40)) return SNIPPER_E_SHAPE;
+  hipLaunchKernelGGL(level_pos_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+  return launch_status();
+}
+
 int snipper_cast_scale_table_bf16(void *stream, const void *items, const int *block_end, int n_items, int n_blocks) {
   if (!items || !block_end) return SNIPPER_E_NULL;
   if (n_items <= 0 || n_blocks <= 0 || (((uintptr_t)items | (uintptr_t)block_end) & 7) || sizeof(CastItem) != 40) return SNIPPER_E_SHAPE;

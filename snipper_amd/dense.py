@@ -417,7 +417,8 @@ def conv3x3_dgrad_s2_bf16(g: torch.Tensor, weight_t: torch.Tensor, in_hw, gate: 
     return dx
 
 
-def wgrad_conv3x3_bf16(g: torch.Tensor, x: torch.Tensor, stride: int, scale: Optional[torch.Tensor] = None) -> torch.Tensor:
+def wgrad_conv3x3_bf16(g: torch.Tensor, x: torch.Tensor, stride: int, scale: Optional[torch.Tensor] = None,
+                       out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Weight gradient of a padding-1 3x3 convolution (stride 1 or 2) on the split-reduction MFMA kernel.
 
     g [B, Cout, Ho, Wo] = dL/dy and x [B, Cin, H, W] = the input, both bf16 channels_last; ``scale`` [Cout] float32
@@ -432,7 +433,12 @@ def wgrad_conv3x3_bf16(g: torch.Tensor, x: torch.Tensor, stride: int, scale: Opt
     if scale is not None and scale.dtype != torch.float32:
         scale = scale.float()
     ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=g.device)
-    dw = torch.empty((Cout, 3, 3, Cin), dtype=torch.float32, device=g.device)
+    if out is not None:                     # a [Cout, Cin, 3, 3] float32 tensor in channels_last memory (e.g. the parameter's
+        assert (out.dtype == torch.float32 and tuple(out.shape) == (Cout, Cin, 3, 3) and       # slice of a flat gradient buffer)
+                out.is_contiguous(memory_format=torch.channels_last) and out.data_ptr() % 16 == 0)
+        dw = out.permute(0, 2, 3, 1)        # its memory as [Cout, 3, 3, Cin]
+    else:
+        dw = torch.empty((Cout, 3, 3, Cin), dtype=torch.float32, device=g.device)
     Ho_, Wo_ = g.shape[2], g.shape[3]
     with _timed("conv3x3_wgrad", (B, H, W, Cin, Cout, int(stride)), 2 * B * Ho_ * Wo_ * Cout * 9 * Cin,
                 2 * (B * H * W * Cin + B * Ho_ * Wo_ * Cout) + 4 * 9 * Cin * Cout, g.device), _lib.device_guard(g.device):
@@ -440,7 +446,7 @@ def wgrad_conv3x3_bf16(g: torch.Tensor, x: torch.Tensor, stride: int, scale: Opt
                                             int(stride), scale.data_ptr() if scale is not None else None, dw.data_ptr(),
                                             0, ws.data_ptr(), nbytes)
     _lib.check(rc, "snipper_wgrad_conv3x3_bf16")
-    return dw.permute(0, 3, 1, 2)            # [Cout, Cin, 3, 3] logical, channels_last memory
+    return out if out is not None else dw.permute(0, 3, 1, 2)            # [Cout, Cin, 3, 3] logical, channels_last memory
 
 
 def linear_nn_bf16(x: torch.Tensor, w: torch.Tensor, residual: Optional[torch.Tensor] = None,
@@ -543,6 +549,32 @@ def wgrad_bf16(g: torch.Tensor, x: torch.Tensor, want_bias: bool = True, scale: 
     return dW, db
 
 
+def _grad_out(param, shape) -> Optional[torch.Tensor]:
+    """Where a weight-gradient kernel may write ``param``'s gradient directly: its slice of a FlatParameters' flat gradient
+    buffer (flat_params.claim_grad_view: once per backward pass, float32, contiguous rows of the expected shape) or None."""
+    if param is None or not isinstance(param, torch.nn.Parameter) or param.dtype != torch.float32:
+        return None
+    from .flat_params import claim_grad_view
+    if getattr(param, "_snipper_flat_owner", None) is None or tuple(param.shape) != tuple(shape) or not param.is_contiguous():
+        return None
+    return claim_grad_view(param)
+
+
+def _grad_out_conv(param) -> Optional[torch.Tensor]:
+    """``_grad_out`` for a convolution weight [Cout, Cin, kh, kw] whose memory is [Cout][kh][kw][Cin] (channels_last, or any
+    layout when kh = kw = 1): the parameter's gradient view, or None."""
+    if param is None or not isinstance(param, torch.nn.Parameter) or param.dtype != torch.float32 or param.dim() != 4:
+        return None
+    if getattr(param, "_snipper_flat_owner", None) is None:
+        return None
+    one = tuple(param.shape[2:]) == (1, 1)
+    if not (param.is_contiguous(memory_format=torch.channels_last) or (one and param.is_contiguous())):
+        return None
+    from .flat_params import claim_grad_view
+    v = claim_grad_view(param)
+    return v if (v is not None and v.data_ptr() % 16 == 0) else None
+
+
 class _BigLinear(torch.autograd.Function):
     """act(x @ W^T + b) for activations with tens of thousands of rows (the encoder's 79 000 tokens), in bf16 on this
     repository's kernels: forward on ``linear_bf16`` (bias / ReLU in the epilogue), weight + bias gradient on the
@@ -572,6 +604,7 @@ class _BigLinear(torch.autograd.Function):
         ctx.x_shape, ctx.w_dtype = x.shape, weight.dtype
         ctx.b_dtype = None if bias is None else bias.dtype
         ctx.wt = shadow.lookup_t(weight) if weight.dtype != torch.bfloat16 else None     # W^T of THIS step's weight, if kept
+        ctx.w_ref, ctx.b_ref = weight, bias                  # (parameters: for flat_params.claim_grad_view in the backward)
         ctx.save_for_backward(xb, wb, y if relu else None)
         return y.view(*x.shape[:-1], n_out)
 
@@ -586,7 +619,9 @@ class _BigLinear(torch.autograd.Function):
             g = _relu_dropout_backward(g, y, ctx.drop_p)
         dW = db = None
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            dW, db = wgrad_bf16(g, xb, want_bias=ctx.has_bias and ctx.needs_input_grad[2])
+            want_b = ctx.has_bias and ctx.needs_input_grad[2]
+            dW, db = wgrad_bf16(g, xb, want_bias=want_b, out=_grad_out(ctx.w_ref, (wb.shape[0], xb.shape[1])),
+                                out_bias=_grad_out(ctx.b_ref, (wb.shape[0],)) if want_b else None)
             if dW.dtype != ctx.w_dtype:
                 dW = dW.to(ctx.w_dtype)
             if db is not None and db.dtype != ctx.b_dtype:
@@ -631,6 +666,7 @@ class _BigFFN(torch.autograd.Function):
         ctx.p, ctx.x_shape = float(dropout_p), x.shape
         ctx.dts = (w1.dtype, b1.dtype, w2.dtype, b2.dtype)
         ctx.w2t = shadow.lookup_t(w2)                        # W2^T [d_ffn, d_model]: dH = dZ . W2 on the weight-stationary kernel
+        ctx.prefs = (w1, b1, w2, b2)                         # (parameters: for flat_params.claim_grad_view in the backward)
         ctx.save_for_backward(xb, w1b, w2b, h)
         return z.view(*x.shape[:-1], w2.shape[0])
 
@@ -641,9 +677,10 @@ class _BigFFN(torch.autograd.Function):
         if g.dtype != torch.bfloat16:
             g = g.to(torch.bfloat16)
         g = g.contiguous()
-        dW2, db2 = wgrad_bf16(g, h)
+        w1, b1, w2, b2 = ctx.prefs
+        dW2, db2 = wgrad_bf16(g, h, out=_grad_out(w2, w2b.shape), out_bias=_grad_out(b2, (w2b.shape[0],)))
         gh = _dgrad(g, w2b, None, h, wt=ctx.w2t, gate_scale=1.0 / (1.0 - ctx.p))    # gradient w.r.t. linear1's pre-activation
-        dW1, db1 = wgrad_bf16(gh, xb)
+        dW1, db1 = wgrad_bf16(gh, xb, out=_grad_out(w1, w1b.shape), out_bias=_grad_out(b1, (w1b.shape[0],)))
         dx = None
         if ctx.needs_input_grad[0]:
             from . import shadow

@@ -27,7 +27,32 @@ import torch
 from torch import nn
 
 
+def claim_grad_view(p) -> Optional[torch.Tensor]:
+    """The slice of a FlatParameters' flat gradient buffer that belongs to parameter ``p`` (its shape and strides), for a
+    backward function that can write the parameter's gradient THERE instead of into a fresh tensor: autograd then adopts the
+    view as ``p.grad`` and ``FlatParameters.pack()`` (or the staged all-reduce's pack) has nothing to copy for it (164 MB of
+    gradient copies per step otherwise).  Granted at most once per backward pass and only while ``p.grad is None`` -- a second
+    gradient of the same parameter (a module used twice, gradient accumulation over micro-batches) must arrive in its own
+    tensor, because the accumulation would otherwise add a buffer to itself.  None = use a fresh tensor."""
+    owner = getattr(p, "_snipper_flat_owner", None)
+    if owner is None or p.grad is not None:
+        return None
+    flat = owner()
+    if flat is None or not flat.direct_grads:
+        return None
+    i = flat._index.get(id(p))
+    if i is None or i in flat._claimed:
+        return None
+    flat._claimed.add(i)
+    v = flat.grad_views[i]
+    # a fresh alias: autograd adopts a gradient without copying only when nobody else holds the tensor object
+    return v.as_strided(v.shape, v.stride(), v.storage_offset())
+
+
 class FlatParameters:
+    # write the big weight gradients straight into the flat buffer (claim_grad_view); SNIPPER_FLAT_DIRECT_GRADS=0 for A/B runs
+    direct_grads = __import__("os").environ.get("SNIPPER_FLAT_DIRECT_GRADS", "1") != "0"
+
     def __init__(self, groups: Sequence[Sequence[nn.Parameter]], grad_flat: Optional[torch.Tensor] = None):
         self.groups: List[List[nn.Parameter]] = [[p for p in g if p.requires_grad] for g in groups]
         self.params: List[nn.Parameter] = [p for g in self.groups for p in g]
@@ -58,6 +83,12 @@ class FlatParameters:
                     k += 1
                 end = offsets[k] if k < len(offsets) else total
                 self.ranges.append((start, end))          # padding elements are zeros with zero gradients: they stay zero
+        import weakref
+        self._index = {id(p): i for i, p in enumerate(self.params)}
+        self._claimed = set()                                  # parameters whose gradient view was handed out this backward
+        ref = weakref.ref(self)
+        for p in self.params:
+            p._snipper_flat_owner = ref
         # one leaf per group; it shares the group's slice of the flat buffer
         self.leaves: List[nn.Parameter] = [nn.Parameter(self.flat[a:b]) for a, b in self.ranges if b > a]
         self._leaf_ranges = [(a, b) for a, b in self.ranges if b > a]
@@ -78,6 +109,7 @@ class FlatParameters:
         """``p.grad = None`` for every parameter: autograd then hands its gradient buffers over without an add."""
         for p in self.params:
             p.grad = None
+        self._claimed.clear()
 
     @torch.no_grad()
     def pack(self) -> None:

@@ -498,10 +498,22 @@ class LevelPosTokens(Function):
         sizes = [int(p.shape[2]) for p in pos_tokens]
         S = sum(sizes)
         out = torch.empty((b, t, S, C), dtype=torch.bfloat16, device=level_embed.device)
-        off = 0
-        for l, p in enumerate(pos_tokens):
-            torch.add(p, level_embed[l].view(1, 1, 1, C), out=out[:, :, off:off + sizes[l]])
-            off += sizes[l]
+        if (level_embed.is_cuda and level_embed.dtype == torch.float32 and level_embed.is_contiguous() and C % 8 == 0 and
+                len(pos_tokens) <= 4 and all(p.dtype == torch.float32 and p.is_contiguous() and p.shape[:2] == (b, t) and
+                                             p.shape[3] == C for p in pos_tokens)):
+            # one launch for all levels (csrc/misc_kernels.cuh, level_pos_kernel)
+            nl = len(pos_tokens)
+            ptrs = (ctypes.c_void_p * nl)(*[p.data_ptr() for p in pos_tokens])
+            hws = (ctypes.c_int * nl)(*sizes)
+            with _lib.device_guard(out.device):
+                rc = _lib.load().snipper_level_pos_bf16(_stream(out.device), ptrs, hws, nl, level_embed.data_ptr(), b * t, C,
+                                                        out.data_ptr())
+            _lib.check(rc, "snipper_level_pos_bf16")
+        else:
+            off = 0
+            for l, p in enumerate(pos_tokens):
+                torch.add(p, level_embed[l].view(1, 1, 1, C), out=out[:, :, off:off + sizes[l]])
+                off += sizes[l]
         ctx.sizes, ctx.shape, ctx.le_dtype = sizes, (b, t, S, C), level_embed.dtype
         ctx.n_levels = level_embed.shape[0]
         if n_uses <= 1:
