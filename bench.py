@@ -766,7 +766,8 @@ def main():
             g_main, g_backbone, g_slow = optimizer_groups(list(model.named_parameters()))
             if gsync is not None:
                 assert [id(p) for p in gsync.params] == [id(p) for p in g_main + g_slow + g_backbone]
-            flatp = FlatParameters([g_main, g_slow, g_backbone], grad_flat=gsync.flat if gsync is not None else None)
+            flatp = FlatParameters([g_main, g_slow, g_backbone], grad_flat=gsync.flat if gsync is not None else None,
+                                   grad_guard=gsync.slice_is_free if gsync is not None else None)
         opt = build_optimizer(list(model.named_parameters()), capturable=bool(a.graph), flat=flatp)
         if flatp is not None and a.optimizer == "flat-kernel" and not a.graph and not os.environ.get("SNIPPER_OPT_PLAIN"):
             from snipper_amd.flat_params import FlatAdamW

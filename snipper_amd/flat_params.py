@@ -43,6 +43,8 @@ def claim_grad_view(p) -> Optional[torch.Tensor]:
     i = flat._index.get(id(p))
     if i is None or i in flat._claimed:
         return None
+    if flat.grad_guard is not None and not flat.grad_guard(p):      # (e.g. FlatGradSync.slice_is_free: an all-reduce in flight)
+        return None
     flat._claimed.add(i)
     v = flat.grad_views[i]
     # a fresh alias: autograd adopts a gradient without copying only when nobody else holds the tensor object
@@ -53,7 +55,10 @@ class FlatParameters:
     # write the big weight gradients straight into the flat buffer (claim_grad_view); SNIPPER_FLAT_DIRECT_GRADS=0 for A/B runs
     direct_grads = __import__("os").environ.get("SNIPPER_FLAT_DIRECT_GRADS", "1") != "0"
 
-    def __init__(self, groups: Sequence[Sequence[nn.Parameter]], grad_flat: Optional[torch.Tensor] = None):
+    def __init__(self, groups: Sequence[Sequence[nn.Parameter]], grad_flat: Optional[torch.Tensor] = None, grad_guard=None):
+        """``grad_guard(p) -> bool``: asked before a backward kernel is allowed to write ``p``'s gradient straight into the flat
+        buffer (claim_grad_view); pass ``FlatGradSync.slice_is_free`` when ``grad_flat`` is that object's buffer."""
+        self.grad_guard = grad_guard
         self.groups: List[List[nn.Parameter]] = [[p for p in g if p.requires_grad] for g in groups]
         self.params: List[nn.Parameter] = [p for g in self.groups for p in g]
         assert self.params, "no trainable parameters"

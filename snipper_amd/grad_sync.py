@@ -135,6 +135,7 @@ class FlatGradSync:
         # one (through pinned memory and an event of its own: no wait on the step in flight), so that all ranks raise together
         self._err_dev = self._err_host = self._err_event = None
         self._err_text = ""
+        self._index = index
         self.late_idx: Optional[List[int]] = None if late is None else sorted(index[id(p)] for p in late if id(p) in index)
         if not self.stages:
             self.late_idx = []                    # nothing is launched before sync(): nothing can arrive late
@@ -145,6 +146,21 @@ class FlatGradSync:
                 for p in st.triggers:
                     p.register_post_accumulate_grad_hook(lambda _p, st=st: self._on_trigger(st))
 
+    def slice_is_free(self, p: torch.nn.Parameter) -> bool:
+        """May a backward kernel write ``p``'s gradient straight into its slice of the flat buffer right now
+        (flat_params.claim_grad_view with this buffer as the FlatParameters' ``grad_flat``)?  Not once the slice's stage is
+        ready or launched -- an all-reduce may be reading and writing it: such a (late) gradient must arrive in a tensor of
+        its own, so that ``sync()`` sees it and reduces it again -- and never for the agreed late set."""
+        if self.late_idx is None:                  # (the late set is agreed on at the first sync(): no direct writes before)
+            return False
+        i = self._index.get(id(p))
+        if i is None or i in self.late_idx:
+            return False
+        for st in self.stages:
+            if st.lo <= i < st.hi:
+                return not (st.ready or st.launched)
+        return True
+
     # ------------------------------------------------------------------------------------------------------------
     def _pack(self, lo: int, hi: int) -> None:
         stale = [i for i in range(lo, hi) if self.params[i].grad is not None and id(self.params[i].grad) in self._view_ids]
@@ -152,7 +168,10 @@ class FlatGradSync:
             raise RuntimeError(
                 "FlatGradSync: a parameter's .grad still is last step's view of the flat buffer (autograd accumulated into "
                 "it in place). Reset gradients with set_to_none=True / FlatParameters.drop_param_grads() before backward.")
-        have = [(v, p.grad) for v, p in zip(self.views[lo:hi], self.params[lo:hi]) if p.grad is not None]
+        # (a gradient that a backward kernel wrote straight into its slice -- flat_params.claim_grad_view with this buffer as
+        #  the FlatParameters' grad_flat -- is already where it belongs)
+        have = [(v, p.grad) for v, p in zip(self.views[lo:hi], self.params[lo:hi])
+                if p.grad is not None and p.grad.data_ptr() != v.data_ptr()]
         missing = [v for v, p in zip(self.views[lo:hi], self.params[lo:hi]) if p.grad is None]
         if missing:
             torch._foreach_zero_(missing)

@@ -147,3 +147,55 @@ def test_flat_adamw_is_an_optimizer_schedulers_and_torch_state_dicts_work():
     opt2.param_groups[1]["eps"] = 1e-6
     with pytest.raises(RuntimeError):
         opt2.step(0.0)
+
+
+def test_weight_gradients_written_straight_into_the_flat_buffer():
+    """flat_params.claim_grad_view: the big Linears' weight-gradient kernels write into the parameter's slice of the flat
+    gradient buffer and autograd adopts that view -- same gradients as through fresh tensors + pack(); a parameter used TWICE
+    in one backward gets the view for one use and a tensor of its own for the other (their sum is right); a parameter whose
+    .grad is still set gets none (accumulation over micro-batches keeps working); a guard can veto it."""
+    from snipper_amd.dense import big_linear
+    torch.manual_seed(0)
+    dev = "cuda:0"
+    lin = nn.Linear(384, 384).to(dev)
+    lin2 = nn.Linear(384, 1024).to(dev)
+    x = torch.randn(8192, 384, device=dev)
+
+    def grads(direct, guard=None, twice=True):
+        for p in list(lin.parameters()) + list(lin2.parameters()):
+            p.grad = None
+        flat = FlatParameters([list(lin.parameters()) + list(lin2.parameters())], grad_guard=guard)
+        old = FlatParameters.direct_grads
+        FlatParameters.direct_grads = direct
+        try:
+            flat.drop_param_grads()
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                y = big_linear(x, lin)
+                z = big_linear(y.float(), lin) if twice else y          # the same Linear a second time
+                out = big_linear(z.float(), lin2)
+            out.float().square().mean().backward()
+            in_place = [p.grad.data_ptr() == v.data_ptr() for p, v in zip(flat.params, flat.grad_views)]
+            flat.pack()
+            return flat.grad_flat.clone(), in_place
+        finally:
+            FlatParameters.direct_grads = old
+
+    ref, in_ref = grads(False)
+    got, in_got = grads(True)
+    assert not any(in_ref)
+    assert in_got[2] and in_got[3]                       # lin2 (used once): weight and bias live in the flat buffer
+    torch.testing.assert_close(got, ref, rtol=1e-5, atol=1e-6)        # (lin: one use in place, the other added to it)
+    vetoed, in_v = grads(True, guard=lambda p: False)
+    assert not any(in_v)
+    torch.testing.assert_close(vetoed, ref, rtol=1e-5, atol=1e-6)
+    # gradient accumulation: .grad is kept between two backward passes -> the second pass must not claim
+    flat = FlatParameters([list(lin2.parameters())])
+    flat.drop_param_grads()
+    for _ in range(2):
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            big_linear(x, lin2).float().square().mean().backward()
+    twice_grad = lin2.weight.grad.clone()
+    flat.drop_param_grads()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        big_linear(x, lin2).float().square().mean().backward()
+    torch.testing.assert_close(twice_grad, 2 * lin2.weight.grad, rtol=1e-5, atol=1e-7)
