@@ -178,12 +178,28 @@ def ms_deform_attn_backward(value: torch.Tensor, spatial_shapes: torch.Tensor,
     _require(grad_output.dtype == value.dtype or go_bf16, "grad_output dtype must match value")
     N, S, M, D, L, Lq, P = _dims(value, spatial_shapes, sampling_loc, attn_weight)
     _require(grad_output.numel() == N * Lq * M * D, "grad_output shape mismatch")
+    lib = _lib.load()
+    if (value.dtype == torch.bfloat16 and grad_output.dtype == torch.bfloat16 and not grad_value_f32 and config is None and
+            Lq != S and D == 48 and Lq <= 64):
+        # few queries on a large bf16 value (the decoder's cross attention): grad_value without atomics, float32 buffer or
+        # cast pass (csrc/msda_d48_sparse.cuh); any other shape answers E_UNSUPPORTED and takes the general entry below
+        gv = torch.empty(value.shape, dtype=torch.bfloat16, device=value.device)
+        gl, ga = torch.empty_like(sampling_loc), torch.empty_like(attn_weight)
+        dims_s = dict(N=N, S=S, M=M, D=D, L=L, Lq=Lq, P=P, esize=2, row_esize=2)
+        with _lib.device_guard(value.device), _Timed("bwd", dims_s, value.device):
+            rc = lib.snipper_msda_backward_sparse_bf16(
+                _stream(value.device), grad_output.data_ptr(), value.data_ptr(), spatial_shapes.data_ptr(),
+                level_start_index.data_ptr(), sampling_loc.data_ptr(), attn_weight.data_ptr(), N, S, M, D, L, Lq, P,
+                gv.data_ptr(), gl.data_ptr(), ga.data_ptr())
+        if rc == 0:
+            return [gv, gl, ga]
+        if rc != _lib.E_UNSUPPORTED:
+            _lib.check(rc, "snipper_msda_backward_sparse_bf16")
     acc_dtype = torch.float32 if value.dtype == torch.bfloat16 else value.dtype
     # grad_value is fully written by the callee, no pre-zeroing (include/snipper_msda.h, "Outputs")
     grad_value = torch.empty(value.shape, dtype=acc_dtype, device=value.device)
     grad_loc = torch.empty_like(sampling_loc)
     grad_attn = torch.empty_like(attn_weight)
-    lib = _lib.load()
     dims = dict(N=N, S=S, M=M, D=D, L=L, Lq=Lq, P=P, esize=value.element_size(),
                 row_esize=grad_output.element_size())
     _keep, hs_p = _host_shapes_ptr(host_shapes, L)

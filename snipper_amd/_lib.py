@@ -127,6 +127,7 @@ EXPORTS = {
                                      c_void_p], c_int),
     "snipper_heatmap_loss_forward_f32": ([c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 7 + [c_void_p, c_int], c_int),
     "snipper_heatmap_loss_backward_f32": ([c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 7 + [c_void_p, c_void_p], c_int),
+    "snipper_msda_backward_sparse_bf16": ([c_void_p] * 7 + [c_int] * 7 + [c_void_p] * 3, c_int),
     "snipper_relu_dropout_backward_bf16": ([c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, ctypes.c_float], c_int),
 }
 

@@ -35,6 +35,7 @@
 #include "msda_d48.cuh"
 #include "msda_d48_patch.cuh"
 #include "msda_d48_tilemm.cuh"
+#include "msda_d48_sparse.cuh"
 #include "msda_generic.cuh"
 
 using namespace snipper;
@@ -551,6 +552,31 @@ int snipper_msda_backward_ex(void *stream, const snipper_msda_config *cfg, const
   if (d48_eligible<float>(d, c.policy))
     return backward_d48_f32(st, (const float *)grad_out, v, shapes, level_start, lo, at, d, gv, gl, ga, go_bf16);
   return backward_generic<float, float, float>(st, (const float *)grad_out, v, shapes, level_start, lo, at, d, gv, gl, ga);
+}
+
+// grad_value of a bf16 value for FEW queries (the decoder's cross attention) without atomics, float32 buffer or cast:
+// csrc/msda_d48_sparse.cuh.  grad_value [N][S][M][48] bf16 (fully written: zeroed here, touched pixels stored once),
+// grad_loc / grad_attn float32 from the tuned atomic kernel run without its atomics.  SNIPPER_E_UNSUPPORTED when the shape is
+// not this one (the caller then takes snipper_msda_backward_ex).
+int snipper_msda_backward_sparse_bf16(void *stream, const uint16_t *grad_out, const uint16_t *value, const int64_t *shapes,
+                                      const int64_t *level_start, const float *loc, const float *attn, int N, int S, int M, int D,
+                                      int L, int Lq, int P, uint16_t *grad_value, float *grad_loc, float *grad_attn) {
+  if (!grad_out || !value || !shapes || !level_start || !loc || !attn || !grad_value || !grad_loc || !grad_attn) return SNIPPER_E_NULL;
+  if (int rc = check_dims(N, S, M, D, L, Lq, P)) return rc;
+  const CoreDims d{N, S, M, D, L, Lq, P, 0};
+  static const bool on = [] { const char *e = getenv("SNIPPER_MSDA_SPARSE"); return !(e && e[0] == '0'); }();
+  if (!on || D != kSpD || Lq > kSpMaxLq || Lq * P * 4 > kSpTaps || L > kMaxLevelsFast || S >= (1 << 22) ||
+      !d48_eligible<float>(d, 0) || (long long)N * S * M * D * 2 >= (1LL << 31) || ((uintptr_t)grad_value & 15))
+    return SNIPPER_E_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  if (const hipError_t e = hipMemsetAsync(grad_value, 0, (size_t)N * S * M * D * 2, st); e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(msda_bwd_d48_sparse_gv_kernel, dim3((unsigned)(N * M * L)), dim3(256), 0, st, grad_out, shapes, level_start, loc, attn,
+                     d, grad_value);
+  if (int rc = launch_status()) return rc;
+  const int rc = backward_d48_f32_t<kD48, uint16_t>(st, (const float *)grad_out, value, shapes, level_start, loc, attn, d, nullptr,
+                                                    grad_loc, grad_attn, 1);
+  if (rc == SNIPPER_OK) g_last_variant = "d48_sparse";
+  return rc;
 }
 
 // ---- the reference launchers' one-for-one replacements (default configuration, level shapes on the device only) ----

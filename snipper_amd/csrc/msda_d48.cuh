@@ -302,7 +302,7 @@ __global__ __launch_bounds__(kD48Block) void msda_bwd_d48_f32_kernel(
   constexpr unsigned kVE = (unsigned)sizeof(VT), kGS = 4u / kVE;      // bytes per value element; grad_value offset = kGS x value offset
   const unsigned value_bytes = (unsigned)((size_t)d.N * d.S * d.M * DT * kVE);
   const auto vsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<VT *>(value), 0, (int)value_bytes, 0x00020000);
-  const auto gsrc = __builtin_amdgcn_make_buffer_rsrc(grad_value, 0, (int)(value_bytes * kGS), 0x00020000);
+  const auto gsrc = __builtin_amdgcn_make_buffer_rsrc(grad_value, 0, grad_value ? (int)(value_bytes * kGS) : 0, 0x00020000);
   const unsigned lane_off = (unsigned)lane * kVE;
   auto ldv = [&](unsigned o) -> float {
     if constexpr (sizeof(VT) == 4) return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(vsrc, o, 0, 0));
@@ -328,9 +328,11 @@ __global__ __launch_bounds__(kD48Block) void msda_bwd_d48_f32_kernel(
       const float wa = w[k] * a;
       // (an out-of-map tap: kOobOffset stays out of range in grad_value as well -- never doubled into range)
       const unsigned og = off[k] == kOobOffset ? kOobOffset : o * kGS;
-      __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(wa * g0, gsrc, og, 0, 0);
-      __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(wa * g1, gsrc, og + 4u * G, 0, 0);
-      __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(wa * g2, gsrc, og + 8u * G, 0, 0);
+      if (grad_value) {        // (nullptr: grad_value comes from csrc/msda_d48_sparse.cuh; this kernel then only makes grad_loc / grad_attn)
+        __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(wa * g0, gsrc, og, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(wa * g1, gsrc, og + 4u * G, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(wa * g2, gsrc, og + 8u * G, 0, 0);
+      }
     }
     float pa = w[0] * dot[0] + w[1] * dot[1] + w[2] * dot[2] + w[3] * dot[3];
     float px = hh * (dot[1] - dot[0]) + lh * (dot[3] - dot[2]);

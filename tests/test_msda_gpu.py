@@ -384,3 +384,41 @@ def test_bf16_rows_unsupported_shape_falls_back_to_cast():
     b = MSDA.ms_deform_attn_backward(value, sh, lsi, loc, attn, go16.float(), 64)
     for x, y in zip(a, b):
         torch.testing.assert_close(x, y, rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("N,Lq", [(8, 60), (2, 64), (3, 7)])
+def test_sparse_backward_for_few_queries_on_bf16_value(N, Lq):
+    """csrc/msda_d48_sparse.cuh (the decoder's cross attention: few queries on the whole bf16 memory): grad_value without atomics
+    -- against the C oracle on the bf16-rounded inputs and against the float32-accumulating atomic path (``grad_value_f32``)
+    rounded once; samples outside the maps, on their borders, and many taps on the same pixels (every query of a head at the
+    same reference point); bit-reproducible."""
+    shapes = np.array(ENC_SHAPES, dtype=np.int64)
+    S = int(shapes.prod(1).sum())
+    M, D, L, P = 8, 48, 3, 4
+    g = torch.Generator(device="cpu").manual_seed(N * 100 + Lq)
+    value = torch.randn(N, S, M, D, generator=g).bfloat16()
+    loc = torch.rand(N, Lq, M, L, P, 2, generator=g) * 1.2 - 0.1              # some samples outside [0, 1]
+    loc[:, : Lq // 2, 0] = loc[:, :1, 0]                                      # head 0: half of the queries share their taps
+    loc = (torch.round(loc * 4096) + 0.5) / 4096
+    attn = torch.softmax(torch.randn(N, Lq, M, L * P, generator=g), -1).view(N, Lq, M, L, P)
+    go = torch.randn(N, Lq, M * D, generator=g).bfloat16()
+    ts = torch.from_numpy(shapes).to(DEV)
+    ti = lsi_of(torch.from_numpy(shapes)).to(DEV)
+    args = (value.to(DEV), ts, ti, loc.to(DEV), attn.to(DEV), go.to(DEV), 64)
+    gv, gl, ga = MSDA.ms_deform_attn_backward(*args)
+    assert _lib.last_variant() == "d48_sparse", _lib.last_variant()
+    assert gv.dtype == torch.bfloat16
+    gv32, gl2, ga2 = MSDA.ms_deform_attn_backward(*args, grad_value_f32=True)
+    assert _lib.last_variant() == "d48_lp12"
+    assert torch.equal(gl, gl2) and torch.equal(ga, ga2)                      # (the same kernel makes them either way)
+    # one bf16 rounding of sums that differ only in their float32 summation order
+    diff = (gv.float() - gv32.bfloat16().float()).abs()
+    assert float(diff.max()) <= 2 ** -7 * float(gv32.abs().max()) + 1e-6
+    assert float((diff > 0).float().mean()) < 0.02
+    if N <= 3:
+        ref_gv, _, _ = O.core_c_backward(value.float().numpy().astype(np.float64), shapes, ti.cpu().numpy(),
+                                         loc.numpy().astype(np.float64), attn.numpy().astype(np.float64),
+                                         go.float().numpy().astype(np.float64))
+        np.testing.assert_allclose(gv.float().cpu().numpy(), ref_gv, rtol=2 ** -7, atol=2e-2)
+    again = MSDA.ms_deform_attn_backward(*args)[0]
+    assert torch.equal(gv, again)
