@@ -570,7 +570,7 @@ int snipper_msda_backward_sparse_bf16(void *stream, const uint16_t *grad_out, co
     return SNIPPER_E_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   if (const hipError_t e = hipMemsetAsync(grad_value, 0, (size_t)N * S * M * D * 2, st); e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL(msda_bwd_d48_sparse_gv_kernel, dim3((unsigned)(N * M * L)), dim3(256), 0, st, grad_out, shapes, level_start, loc, attn,
+  hipLaunchKernelGGL(msda_bwd_d48_sparse_gv_kernel, dim3((unsigned)(N * M * L)), dim3(kSpTaps), 0, st, grad_out, shapes, level_start, loc, attn,
                      d, grad_value);
   if (int rc = launch_status()) return rc;
   const int rc = backward_d48_f32_t<kD48, uint16_t>(st, (const float *)grad_out, value, shapes, level_start, loc, attn, d, nullptr,

@@ -6,11 +6,17 @@
 // positions (models/deformable_transformer.py:290-295): 184 000 taps per launch touch at most 29 % of the 632 000
 // (position, head) rows, but the atomic formulation paid for all of them three times -- a 121 MB float32 memset, the atomics,
 // and a 121 -> 60 MB cast to the bf16 gradient its consumers (the value projection's weight / data gradient) read:
-// 83 us per decoder layer.  Here one workgroup owns one (sample, head, level):
-//   1. its <= 1 024 taps (queries x points x 4 corners) become 32-bit keys  pixel << 10 | tap  in LDS (out-of-map taps: ~0);
-//   2. a bitonic sort in LDS brings the taps of a pixel together, in tap order;
-//   3. the thread that holds the first tap of a pixel adds up its taps' weight * attention * grad_out rows (float32, the
-//      grad_out rows of the (sample, head) staged in LDS) and stores the pixel's 48 channels ONCE, as bf16.
+// 83 us per decoder layer.  Here one workgroup of 1 024 threads owns one (sample, head, level) and one thread one tap:
+//   1. the <= 1 024 taps (queries x points x 4 corners) become 32-bit keys  pixel << 10 | tap  (out-of-map taps: ~0);
+//   2. a bitonic sort brings the taps of a pixel together, in tap order: the key stays in its thread's register, the 45 stages
+//      with a partner inside the wave are lane exchanges, the 10 with a partner in another wave go through LDS;
+//   3. the runs of equal pixels are numbered (ballot + prefix over the 16 waves); thread (run, c) adds up the run's
+//      weight * attention * grad_out rows for channels 4c .. 4c + 3 (float32; the grad_out rows of the (sample, head) staged in
+//      LDS) and stores them ONCE, as bf16 -- 12 neighbouring threads write a pixel's 96 bytes.
+// The work of step 3 is spread over (run, channel group) items, so a workgroup whose queries all sample the same few pixels (the
+// decoder at initialisation) costs little more than one with 1 024 distinct pixels: the whole call (memset + this kernel + query
+// kernel) 36 / 47 us against 51 / 326 us when 256 threads sorted in LDS and one thread summed a whole run; this kernel in the
+// training step 36 -> 16 us (tools/sparsebench.py, profiles/r05_sparse_backward_bench.jsonl).
 // grad_value is zeroed by the launcher as bf16 (60 MB); untouched rows stay zero.  Deterministic (sorted order), one rounding
 // per element.  grad_loc / grad_attn still come from msda_bwd_d48_f32_kernel (launched without its atomics).
 #pragma once
@@ -20,34 +26,44 @@
 
 namespace snipper {
 
-constexpr int kSpTaps = 1024, kSpMaxLq = 64, kSpD = 48;
+constexpr int kSpTaps = 1024, kSpMaxLq = 64, kSpD = 48, kSpC4 = kSpD / 4;
 
-__global__ __launch_bounds__(256) void msda_bwd_d48_sparse_gv_kernel(
+__global__ __launch_bounds__(kSpTaps) void msda_bwd_d48_sparse_gv_kernel(
     const uint16_t *__restrict__ grad_out,      // [N][Lq][M][48] bf16
     const int64_t *__restrict__ shapes, const int64_t *__restrict__ level_start,
     const float *__restrict__ loc, const float *__restrict__ attn, CoreDims d,
     uint16_t *__restrict__ grad_value) {        // [N][S][M][48] bf16, zeroed
   __shared__ __attribute__((aligned(16))) float g[kSpMaxLq * kSpD];
-  __shared__ unsigned keys[kSpTaps];
-  __shared__ float wa[kSpTaps];
-  const int tid = threadIdx.x;
+  __shared__ unsigned keys[kSpTaps + 1];
+  __shared__ float wa[kSpTaps];                 // weight * attention by TAP, then (ws) by sorted position
+  __shared__ float ws[kSpTaps];
+  __shared__ unsigned short qs[kSpTaps], run_start[kSpTaps + 1];
+  __shared__ int wave_runs[kSpTaps / 64], n_valid;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l = blockIdx.x % d.L;
   const int nm = blockIdx.x / d.L;
   const int m = nm % d.M, n = nm / d.M;
   const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1], start = (int)level_start[l];
-  const int ntap = d.Lq * d.P * 4;
+  const int ntap = d.Lq * d.P * 4, P4 = d.P * 4;
 
-  // ---- grad_out rows of this (sample, head)
-  for (int e = tid; e < d.Lq * kSpD; e += 256) {
-    const int q = e / kSpD, c = e - q * kSpD;
-    g[e] = bf16_bits_to_f32(grad_out[(((size_t)n * d.Lq + q) * d.M + m) * kSpD + c]);
+  // ---- grad_out rows of this (sample, head): 16-byte pieces, 6 per row
+  if (tid < d.Lq * 6) {
+    const int q = tid / 6, c8 = tid - q * 6;
+    const uint4 raw = *reinterpret_cast<const uint4 *>(grad_out + (((size_t)n * d.Lq + q) * d.M + m) * kSpD + c8 * 8);
+    float4 lo, hi;
+    lo.x = __uint_as_float(raw.x << 16); lo.y = __uint_as_float(raw.x & 0xffff0000u);
+    lo.z = __uint_as_float(raw.y << 16); lo.w = __uint_as_float(raw.y & 0xffff0000u);
+    hi.x = __uint_as_float(raw.z << 16); hi.y = __uint_as_float(raw.z & 0xffff0000u);
+    hi.z = __uint_as_float(raw.w << 16); hi.w = __uint_as_float(raw.w & 0xffff0000u);
+    reinterpret_cast<float4 *>(g)[2 * tid] = lo;
+    reinterpret_cast<float4 *>(g)[2 * tid + 1] = hi;
   }
-  // ---- taps -> keys (the arithmetic of msda_bwd_d48_f32_kernel: same in-map tests, same weights)
-  for (int tp = tid; tp < kSpTaps; tp += 256) {
-    unsigned key = 0xffffffffu;
+  // ---- this thread's tap -> key (the arithmetic of msda_bwd_d48_f32_kernel: same in-map tests, same weights)
+  unsigned key = 0xffffffffu;
+  {
     float w = 0.f;
-    if (tp < ntap) {
-      const int corner = tp & 3, sp = tp >> 2, p = sp % d.P, q = sp / d.P;
+    if (tid < ntap) {
+      const int corner = tid & 3, sp = tid >> 2, q = sp / d.P, p = sp - q * d.P;
       const long long li = ((((long long)n * d.Lq + q) * d.M + m) * d.L + l) * d.P + p;
       const float lx = loc[2 * li], ly = loc[2 * li + 1], a = attn[li];
       const float y = px_coord(ly, H), x = px_coord(lx, W);
@@ -57,59 +73,71 @@ __global__ __launch_bounds__(256) void msda_bwd_d48_sparse_gv_kernel(
       const int yy = (int)yf + (corner >> 1), xx = (int)xf + (corner & 1);
       if (inside && yy >= 0 && yy <= H - 1 && xx >= 0 && xx <= W - 1) {
         w = ((corner >> 1) ? lh : 1.f - lh) * ((corner & 1) ? lw : 1.f - lw) * a;
-        key = ((unsigned)(yy * W + xx) << 10) | (unsigned)tp;
+        key = ((unsigned)(yy * W + xx) << 10) | (unsigned)tid;
       }
     }
-    keys[tp] = key;
-    wa[tp] = w;
+    wa[tid] = w;
   }
-  __syncthreads();
-  // ---- bitonic sort of the 1 024 keys (ascending): 55 stages, two compare-exchanges per thread and stage
+  // ---- bitonic sort, ascending: element e = tid; a stage (k, j) leaves min(key, partner's) in the lower element of a pair of
+  // an ascending block and max in the upper (descending blocks the other way round)
   for (unsigned k = 2; k <= kSpTaps; k <<= 1)
     for (unsigned j = k >> 1; j > 0; j >>= 1) {
-#pragma unroll
-      for (int rep = 0; rep < 2; ++rep) {
-        const unsigned t = (unsigned)tid + 256u * rep;            // pair index 0 .. 511
-        const unsigned i = ((t & ~(j - 1)) << 1) | (t & (j - 1)); // the lower element of the pair
-        const unsigned ixj = i | j;
-        const unsigned a = keys[i], b = keys[ixj];
-        const bool up = (i & k) == 0;
-        if ((a > b) == up) { keys[i] = b; keys[ixj] = a; }
+      unsigned other;
+      if (j < 64) {
+        other = (unsigned)__shfl_xor((int)key, (int)j, 64);
+      } else {
+        __syncthreads();                          // (the previous LDS stage's reads are done)
+        keys[tid] = key;
+        __syncthreads();
+        other = keys[tid ^ j];
       }
-      __syncthreads();
+      const bool keep_min = (((unsigned)tid & k) == 0) == (((unsigned)tid & j) == 0);
+      key = keep_min ? min(key, other) : max(key, other);
     }
-  // ---- one store per touched pixel
-  const int P4 = d.P * 4;
-  for (int i = tid; i < kSpTaps; i += 256) {
-    const unsigned key = keys[i];
-    if (key == 0xffffffffu) continue;
-    const unsigned pix = key >> 10;
-    if (i > 0 && (keys[i - 1] >> 10) == pix) continue;            // not the first tap of its pixel
-    float acc[kSpD];
+  // ---- runs of equal pixels.  Sorted position tid: is it the first tap of its pixel?  Which run is that?
+  __syncthreads();
+  keys[tid + 1] = key;
+  if (tid == 0) { keys[0] = 0xffffffffu; n_valid = 0; }
+  __syncthreads();
+  const bool valid = key != 0xffffffffu;
+  const unsigned prev = keys[tid];              // (keys[0]: the invalid key -- its "pixel" 2^22 - 1 is no pixel of a level)
+  const bool is_head = valid && (prev >> 10) != (key >> 10);
+  const unsigned long long heads = __ballot(is_head);
+  if (lane == 0) wave_runs[wave] = __popcll(heads);
+  {
+    const unsigned tp = key & 1023u;
+    ws[tid] = valid ? wa[tp] : 0.f;
+    qs[tid] = (unsigned short)(tp / (unsigned)P4);
+  }
+  if (valid && (tid == kSpTaps - 1)) n_valid = kSpTaps;
+  __syncthreads();
+  if (!valid && (prev != 0xffffffffu || tid == 0)) n_valid = tid;      // the first invalid position = the number of valid taps
+  int run = __popcll(heads & ((1ull << lane) - 1ull)), runs = 0;
 #pragma unroll
-    for (int c = 0; c < kSpD; ++c) acc[c] = 0.f;
-    for (int j = i; j < kSpTaps; ++j) {
-      const unsigned kj = keys[j];
-      if (kj == 0xffffffffu || (kj >> 10) != pix) break;
-      const unsigned tp = kj & 1023u;
-      const float w = wa[tp];
-      const float4 *row = reinterpret_cast<const float4 *>(g + (tp / P4) * kSpD);
-#pragma unroll
-      for (int c4 = 0; c4 < kSpD / 4; ++c4) {
-        const float4 v = row[c4];
-        acc[4 * c4] = fmaf(w, v.x, acc[4 * c4]); acc[4 * c4 + 1] = fmaf(w, v.y, acc[4 * c4 + 1]);
-        acc[4 * c4 + 2] = fmaf(w, v.z, acc[4 * c4 + 2]); acc[4 * c4 + 3] = fmaf(w, v.w, acc[4 * c4 + 3]);
-      }
+  for (int w = 0; w < kSpTaps / 64; ++w) {
+    const int c = wave_runs[w];
+    if (w < wave) run += c;
+    runs += c;
+  }
+  if (is_head) run_start[run] = (unsigned short)tid;
+  __syncthreads();
+  if (tid == 0) run_start[runs] = (unsigned short)n_valid;
+  __syncthreads();
+  // ---- one store per touched pixel and 4 channels: item = run * 12 + c
+  for (int item = tid; item < runs * kSpC4; item += kSpTaps) {
+    const int r = item / kSpC4, c = item - r * kSpC4;
+    const int b = run_start[r], e = run_start[r + 1];
+    const unsigned pix = keys[b + 1] >> 10;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j = b; j < e; ++j) {
+      const float w = ws[j];
+      const float4 v = reinterpret_cast<const float4 *>(g)[qs[j] * kSpC4 + c];
+      acc.x = fmaf(w, v.x, acc.x); acc.y = fmaf(w, v.y, acc.y); acc.z = fmaf(w, v.z, acc.z); acc.w = fmaf(w, v.w, acc.w);
     }
-    uint4 *dst = reinterpret_cast<uint4 *>(grad_value + (((size_t)n * d.S + start + pix) * d.M + m) * kSpD);
-#pragma unroll
-    for (int c8 = 0; c8 < kSpD / 8; ++c8) {
-      auto pk = [](float x, float y) { return (unsigned)f32_to_bf16_bits(x) | ((unsigned)f32_to_bf16_bits(y) << 16); };
-      uint4 o;
-      o.x = pk(acc[8 * c8], acc[8 * c8 + 1]); o.y = pk(acc[8 * c8 + 2], acc[8 * c8 + 3]);
-      o.z = pk(acc[8 * c8 + 4], acc[8 * c8 + 5]); o.w = pk(acc[8 * c8 + 6], acc[8 * c8 + 7]);
-      dst[c8] = o;
-    }
+    auto pk = [](float x, float y) { return (unsigned)f32_to_bf16_bits(x) | ((unsigned)f32_to_bf16_bits(y) << 16); };
+    uint2 o;
+    o.x = pk(acc.x, acc.y); o.y = pk(acc.z, acc.w);
+    reinterpret_cast<uint2 *>(grad_value + (((size_t)n * d.S + start + pix) * d.M + m) * kSpD)[c] = o;
   }
 }
 

@@ -386,12 +386,14 @@ def test_bf16_rows_unsupported_shape_falls_back_to_cast():
         torch.testing.assert_close(x, y, rtol=1e-6, atol=1e-7)
 
 
-@pytest.mark.parametrize("N,Lq", [(8, 60), (2, 64), (3, 7)])
-def test_sparse_backward_for_few_queries_on_bf16_value(N, Lq):
+@pytest.mark.parametrize("N,Lq,mode", [(8, 60, "mixed"), (2, 64, "mixed"), (3, 7, "mixed"), (2, 60, "collapsed"),
+                                       (2, 64, "one_pixel"), (2, 60, "outside")])
+def test_sparse_backward_for_few_queries_on_bf16_value(N, Lq, mode):
     """csrc/msda_d48_sparse.cuh (the decoder's cross attention: few queries on the whole bf16 memory): grad_value without atomics
     -- against the C oracle on the bf16-rounded inputs and against the float32-accumulating atomic path (``grad_value_f32``)
     rounded once; samples outside the maps, on their borders, and many taps on the same pixels (every query of a head at the
-    same reference point); bit-reproducible."""
+    same reference point -- "collapsed": ALL queries at the same points, "one_pixel": every tap of a level in one pixel cell,
+    "outside": no tap in any map); bit-reproducible."""
     shapes = np.array(ENC_SHAPES, dtype=np.int64)
     S = int(shapes.prod(1).sum())
     M, D, L, P = 8, 48, 3, 4
@@ -399,6 +401,12 @@ def test_sparse_backward_for_few_queries_on_bf16_value(N, Lq):
     value = torch.randn(N, S, M, D, generator=g).bfloat16()
     loc = torch.rand(N, Lq, M, L, P, 2, generator=g) * 1.2 - 0.1              # some samples outside [0, 1]
     loc[:, : Lq // 2, 0] = loc[:, :1, 0]                                      # head 0: half of the queries share their taps
+    if mode == "collapsed":
+        loc = loc[:, :1].expand(-1, Lq, -1, -1, -1, -1).clone()
+    elif mode == "one_pixel":
+        loc = loc[:, :1, :, :, :1].expand(-1, Lq, -1, -1, P, -1).clamp(0.1, 0.9).clone()
+    elif mode == "outside":
+        loc = loc + 2.0
     loc = (torch.round(loc * 4096) + 0.5) / 4096
     attn = torch.softmax(torch.randn(N, Lq, M, L * P, generator=g), -1).view(N, Lq, M, L, P)
     go = torch.randn(N, Lq, M * D, generator=g).bfloat16()
@@ -415,6 +423,8 @@ def test_sparse_backward_for_few_queries_on_bf16_value(N, Lq):
     diff = (gv.float() - gv32.bfloat16().float()).abs()
     assert float(diff.max()) <= 2 ** -7 * float(gv32.abs().max()) + 1e-6
     assert float((diff > 0).float().mean()) < 0.02
+    if mode == "outside":
+        assert not bool(gv.any())
     if N <= 3:
         ref_gv, _, _ = O.core_c_backward(value.float().numpy().astype(np.float64), shapes, ti.cpu().numpy(),
                                          loc.numpy().astype(np.float64), attn.numpy().astype(np.float64),
