@@ -791,6 +791,32 @@ def main():
             host_ms[name] = host_ms.get(name, 0.0) + 1e3 * (time.perf_counter() - t0)
         return time.perf_counter()
 
+    # SNIPPER_REGION_EVENTS=<steps>: at every region boundary of a step the host's clock AND an event on the stream -- where the
+    # GPU reaches a boundary only just after the host issued it, the GPU is waiting for the host there (development aid)
+    boundary_log = []
+    boundary_on = [False]
+
+    def boundary(name):
+        if boundary_on[0]:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            boundary_log.append((name, time.perf_counter(), ev))
+
+    if os.environ.get("SNIPPER_REGION_EVENTS"):
+        def bounded(mod, name):
+            def after(m, a, o):
+                boundary("fwd." + name + " end")
+                first = o
+                while isinstance(first, (tuple, list, dict)):
+                    first = next(iter(first.values())) if isinstance(first, dict) else first[0]
+                first = getattr(first, "tensors", first)
+                if torch.is_tensor(first) and first.requires_grad:
+                    first.register_hook(lambda g: (boundary("bwd reaches " + name + " output"), None)[1])
+            mod.register_forward_hook(after)
+        bounded(model.backbone, "backbone")
+        bounded(model.transformer.encoder, "encoder")
+        bounded(model.transformer.decoder, "decoder")
+
     if os.environ.get("SNIPPER_HOST_REGIONS"):
         def timed(mod, name):
             mod.register_forward_pre_hook(lambda m, a: setattr(m, "_t0", time.perf_counter()))
@@ -801,15 +827,18 @@ def main():
 
     def train_step(imgs, tgt):
         t = time.perf_counter()
+        boundary("step start")
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
             out, _ = net(list(imgs))
         t = mark("fwd.model(total)", t)
+        boundary("fwd end")
         if criterion is not None:        # Hungarian matching + the six loss families (models/model.py:240-545)
             losses, _ = criterion(out, tgt["targets"])
             loss = criterion.weighted_sum(losses)
         else:
             loss = surrogate_loss(out, tgt)
         t = mark("criterion", t)
+        boundary("criterion end")
         if masters is None:
             if flatp is not None:
                 flatp.drop_param_grads()
@@ -817,6 +846,7 @@ def main():
                 opt.zero_grad(set_to_none=True)
             loss.backward()
             t = mark("backward", t)
+            boundary("backward end")
             if gsync is not None:
                 gsync.sync()
             if own_opt is not None:
@@ -834,6 +864,7 @@ def main():
                 if flatp is not None:
                     flatp.after_step()
             t = mark("optimizer", t)
+            boundary("optimizer end")
         else:
             mp, pp = masters
             for p in pp:
@@ -961,6 +992,35 @@ def main():
             torch.cuda.synchronize()
         print(prof.key_averages().table(sort_by="self_cpu_time_total", row_limit=70, max_name_column_width=60),
               file=sys.stderr)
+    if os.environ.get("SNIPPER_REGION_EVENTS"):
+        n_ev = max(int(os.environ["SNIPPER_REGION_EVENTS"]), 4)
+        torch.cuda.synchronize()
+        boundary_on[0] = True
+        for i in range(n_ev):
+            step(i)
+        torch.cuda.synchronize()
+        boundary_on[0] = False
+        # per boundary: median over the steps (the first two dropped) of host ms and GPU ms since the step's start, and of
+        # the GPU's lag behind the host there (GPU clock aligned to the host's at the FIRST boundary of the run, where the GPU
+        # was idle: lag = how long after the host issued the boundary the GPU reached it)
+        name0, h0, e0 = boundary_log[0]
+        steps_log, cur = [], []
+        for name, h, e in boundary_log:
+            if name == "step start" and cur:
+                steps_log.append(cur); cur = []
+            cur.append((name, 1e3 * (h - h0), e0.elapsed_time(e)))
+        steps_log.append(cur)
+        steps_log = [s_ for s_ in steps_log[2:] if len(s_) == len(steps_log[-1])]
+        med = lambda v: sorted(v)[len(v) // 2]
+        print("[bench] boundary                          host ms   GPU ms   GPU lag behind host (ms)", file=sys.stderr)
+        rows_out = []
+        for k, (name, _, _) in enumerate(steps_log[-1]):
+            hs_ = med([s_[k][1] - s_[0][1] for s_ in steps_log])
+            gs_ = med([s_[k][2] - s_[0][2] for s_ in steps_log])
+            lag = med([s_[k][2] - s_[k][1] for s_ in steps_log])
+            rows_out.append({"boundary": name, "host_ms": round(hs_, 3), "gpu_ms": round(gs_, 3), "gpu_lag_ms": round(lag, 3)})
+            print(f"[bench] {name:36s} {hs_:8.3f} {gs_:8.3f} {lag:8.3f}", file=sys.stderr)
+        print("[bench] region_events " + json.dumps(rows_out), file=sys.stderr)
     if os.environ.get("SNIPPER_ISSUE_TIME"):      # is the host or the GPU the limiter?  (development aid)
         # host time to ISSUE a few steps (no synchronisation) against the time until the GPU has retired them
         n_issue = int(os.environ.get("SNIPPER_ISSUE_TIME", "3")) if os.environ.get("SNIPPER_ISSUE_TIME", "1").isdigit() else 3
