@@ -157,8 +157,8 @@ int snipper_msda_backward_bf16(void *stream, const uint16_t *grad_out, const uin
                                float *grad_value, float *grad_loc, float *grad_attn);
 
 /* grad_value of a bfloat16 `value` for FEW queries (Lq <= 64 and Lq * P * 4 <= 1024, D == 48: the decoder's cross attention)
- * WITHOUT float atomics: one workgroup per (sample, head, level) sorts its taps by pixel (one tap per thread) and stores every
- * touched pixel's row once (csrc/msda_d48_sparse.cuh; reference ms_deform_im2col_cuda.cuh:87-159).  grad_value [N][S][M][D] bfloat16 is
+ * WITHOUT float atomics: one workgroup per (sample, head, level) sorts its taps by pixel in LDS and stores every touched
+ * pixel's row once (csrc/msda_d48_sparse.cuh; reference ms_deform_im2col_cuda.cuh:87-159).  grad_value [N][S][M][D] bfloat16 is
  * fully written by the callee (zeroed, then the touched rows), deterministic, one rounding per element; grad_loc / grad_attn
  * float32 as snipper_msda_backward_bf16.  Returns SNIPPER_E_UNSUPPORTED for any other shape: call snipper_msda_backward_ex. */
 int snipper_msda_backward_sparse_bf16(void *stream, const uint16_t *grad_out, const uint16_t *value, const int64_t *shapes,
