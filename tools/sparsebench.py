@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Decoder-shaped core-op backward on a bf16 value through snipper_msda_backward_sparse_bf16 (memset + per-(sample, head, level)
 sort kernel + atomic-free query kernel): time per call for uniformly random sampling points and for the decoder's situation at
-initialisation (all queries of a head around the same few points).  SNIPPER_SPARSE_STOP=1/2 (diagnostic builds only) ends the
-sort kernel after its key phase / after the sort."""
+initialisation (all queries of a head around the same few points).  (The per-phase figures in
+profiles/r05_sparse_backward_bench.jsonl came from a diagnostic build that ended the kernel after its key phase / after the sort.)"""
 import json, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from snipper_amd import MultiScaleDeformableAttention as MSDA, _lib
@@ -24,7 +24,7 @@ def t(fn, n=100):
     for _ in range(n): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
-out = {"stop": os.environ.get("SNIPPER_SPARSE_STOP", "")}
+out = {}
 for name, loc in (("uniform", torch.rand(N, Lq, M, L, P, 2, generator=g)),
                   ("clustered", (0.5 + 0.02 * torch.randn(N, 1, M, L, P, 2, generator=g) + 0.002 * torch.randn(N, Lq, M, L, P, 2, generator=g)).clamp(0, 1))):
     loc = loc.to(dev)
