@@ -146,3 +146,71 @@ def test_flat_adamw_state_dict_is_in_the_reference_optimizers_parameter_order():
     # every trainable parameter exactly once
     with pytest.raises(ValueError):
         FlatAdamW(fp, [1e-4, 1e-5, 1e-5], reference_groups=[ref_groups[0], ref_groups[1]])
+
+
+class _LinearIntoView(torch.autograd.Function):
+    """y = x W^T with the weight gradient written where flat_params.claim_grad_view says (what dense._BigLinear's backward does
+    with its kernels) -- pure PyTorch, so that the CPU suite covers the claim / adopt / veto logic."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.save_for_backward(x, w)
+        ctx.w_param = w
+        return x @ w.t()
+
+    @staticmethod
+    def backward(ctx, g):
+        from snipper_amd.flat_params import claim_grad_view
+        x, w = ctx.saved_tensors
+        out = claim_grad_view(ctx.w_param)
+        if out is None:
+            out = torch.empty_like(w)
+        torch.mm(g.t(), x, out=out)
+        return g @ w, out
+
+
+def test_claimed_gradient_views_are_adopted_once_per_backward_and_can_be_vetoed():
+    """flat_params.claim_grad_view on the CPU (the GPU counterpart with the real kernels:
+    tests/test_flat_adamw_gpu.py::test_weight_gradients_written_straight_into_the_flat_buffer)."""
+    from snipper_amd.flat_params import FlatParameters
+    torch.manual_seed(0)
+    w1 = torch.nn.Parameter(torch.randn(6, 5))
+    w2 = torch.nn.Parameter(torch.randn(5, 6))
+    x = torch.randn(7, 5)
+
+    def run(direct, guard=None):
+        w1.grad = w2.grad = None
+        flat = FlatParameters([[w1, w2]], grad_guard=guard)
+        old = FlatParameters.direct_grads
+        FlatParameters.direct_grads = direct
+        try:
+            flat.drop_param_grads()
+            y = _LinearIntoView.apply(x, w1)                       # w1 once
+            z = _LinearIntoView.apply(_LinearIntoView.apply(y, w2), w1)    # ... and a second time
+            z.square().sum().backward()
+            in_place = [p.grad.data_ptr() == v.data_ptr() for p, v in zip(flat.params, flat.grad_views)]
+            flat.pack()
+            return flat.grad_flat.clone(), in_place
+        finally:
+            FlatParameters.direct_grads = old
+
+    ref, in_ref = run(False)
+    assert not any(in_ref)
+    got, in_got = run(True)
+    # w2 (used once) lives in the flat buffer; w1's two gradients -- one in the view, one in a tensor of its own -- are summed
+    # by the engine into a new tensor, which pack() copies
+    assert in_got == [False, True]
+    torch.testing.assert_close(got, ref)
+    vetoed, in_v = run(True, guard=lambda p: p is not w2)
+    assert in_v == [False, False]
+    torch.testing.assert_close(vetoed, ref)
+    # .grad kept between two backward passes (micro-batches): the second pass gets no view, the sum is right
+    w1.grad = w2.grad = None
+    flat = FlatParameters([[w2]])
+    flat.drop_param_grads()
+    for _ in range(2):
+        _LinearIntoView.apply(torch.randn(3, 6, generator=torch.Generator().manual_seed(1)), w2).square().sum().backward()
+    twice = w2.grad.clone()
+    flat.drop_param_grads()
+    _LinearIntoView.apply(torch.randn(3, 6, generator=torch.Generator().manual_seed(1)), w2).square().sum().backward()
+    torch.testing.assert_close(twice, 2 * w2.grad)
