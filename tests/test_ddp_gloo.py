@@ -201,12 +201,40 @@ def _toy_worker(rank, world, port, out_dir, case):
         else:                             # two staged runs + an uncovered tail
             gs = FlatGradSync(ps, stages=[([c, d], [c]), ([a, b], [a])], chunks=1)
             assert gs.rest == [(4, 6)]
+        flatp = None
+        if case == "direct":
+            # bench.py's wiring: the optimizer's FlatParameters shares the reducer's buffer, and backward functions may write
+            # a gradient straight into its slice while the reducer says the slice is free (FlatGradSync.slice_is_free)
+            from snipper_amd.flat_params import FlatParameters, claim_grad_view
+            flatp = FlatParameters([ps], grad_flat=gs.flat, grad_guard=gs.slice_is_free)
+            in_place = []
+
+            class Scaled(torch.autograd.Function):      # loss term (p * xi).sum() whose backward writes into the claimed view
+                @staticmethod
+                def forward(ctx, p_, xi):
+                    ctx.p_, ctx.xi = p_, xi
+                    return (p_ * xi).sum()
+
+                @staticmethod
+                def backward(ctx, g):
+                    out = claim_grad_view(ctx.p_)
+                    in_place.append(out is not None)
+                    if out is None:
+                        out = torch.empty_like(ctx.p_)
+                    out.copy_(g * ctx.xi.expand_as(out))
+                    return out, None
         local = []
         for step in range(3):
+            if flatp is not None:
+                flatp.drop_param_grads()
             for p in ps:
                 p.grad = None
             x = torch.randn(6, generator=torch.Generator().manual_seed(100 * rank + step))
-            loss = sum((p * xi).sum() for p, xi in zip(ps, x))
+            if case == "direct":
+                in_place.clear()
+                loss = sum(Scaled.apply(p, xi) for p, xi in zip(ps, x))
+            else:
+                loss = sum((p * xi).sum() for p, xi in zip(ps, x))
             if case == "unused_trigger" and rank == 1 and step >= 1:
                 # rank 1's batch leaves stage 0's trigger (c) unused from step 1 on: its hook never fires there, stage 1's
                 # does -- the collectives must still be issued in stage order on both ranks
@@ -221,6 +249,12 @@ def _toy_worker(rank, world, port, out_dir, case):
             if case == "unexpected_late" and rank == 1 and step == 1:
                 a.grad = a.grad * 2.0        # late on ONE rank and outside the set agreed at step 0 ({b})
             local.append([None if p.grad is None else p.grad.clone() for p in ps])
+            if case == "direct":
+                # local gradients are x[i] everywhere, whichever way they arrived; nothing is written in place before the late
+                # set has been agreed on (first sync()), afterwards every slice that is still free when its gradient arrives
+                for i, p in enumerate(ps):
+                    torch.testing.assert_close(local[-1][i], torch.full_like(p, float(x[i])))
+                assert (not any(in_place)) if step == 0 else any(in_place), (step, in_place)
             if case == "unexpected_late" and step == 2:
                 # rank 1 must not raise alone at step 1 (rank 0 would hang in its next all-reduce): the step
                 # completes everywhere and BOTH ranks raise from the next sync()
@@ -249,7 +283,7 @@ def _toy_worker(rank, world, port, out_dir, case):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("case", ["unstaged", "staged", "unused_trigger", "late", "unexpected_late"])
+@pytest.mark.parametrize("case", ["unstaged", "staged", "unused_trigger", "late", "unexpected_late", "direct"])
 def test_flat_grad_sync_toy_cases(tmp_path, case):
     """uncovered parameters are reduced as runs (message count); VERDICT r02 #6: a trigger parameter without a
     gradient on ONE rank must not change the order of the collectives; a late gradient is re-reduced on every rank."""
