@@ -291,12 +291,43 @@ def gpu_numa_node(index, sysfs="/sys"):
         return None
 
 
-def pick_cpus(local_rank, n, allowed, node_of=gpu_numa_node, n_gpus=None, sysfs="/sys"):
+def cpu_busy(sample_s=0.15, proc_stat="/proc/stat"):
+    """{cpu: fraction of the last ``sample_s`` seconds it was not idle} from two readings of /proc/stat, or {}."""
+    def read():
+        out = {}
+        for line in open(proc_stat):
+            f = line.split()
+            if f and f[0].startswith("cpu") and f[0][3:].isdigit():
+                v = [int(x) for x in f[1:]]
+                out[int(f[0][3:])] = (sum(v), v[3] + (v[4] if len(v) > 4 else 0))      # total, idle + iowait
+        return out
+    try:
+        a = read()
+        time.sleep(sample_s)
+        b = read()
+        return {c: 1.0 - (b[c][1] - a[c][1]) / max(b[c][0] - a[c][0], 1) for c in b if c in a}
+    except Exception:
+        return {}
+
+
+def _smt_sibling(cpu, sysfs="/sys"):
+    try:
+        sib = _parse_cpulist(open(f"{sysfs}/devices/system/cpu/cpu{cpu}/topology/thread_siblings_list").read())
+        return [c for c in sib if c != cpu]
+    except Exception:
+        return []
+
+
+def pick_cpus(local_rank, n, allowed, node_of=gpu_numa_node, n_gpus=None, sysfs="/sys", busy=None):
     """The block of ``n`` CPUs this rank's two issuing threads are pinned to -> (cpus, numa node or None, rule).
     Rule "numa": CPUs of the NUMA node the rank's GPU hangs off (the reference starts 8 processes on a 2-socket host,
     README.md:67; a step here is within 20 % of its host-issue floor, so submitting to a GPU across the socket link is
     what would eat the scaling target), the k-th block of that node for the k-th GPU of that node.  Rule "block": the
-    round-4 rule (block = local rank over the allowed CPUs) when the platform does not expose the topology."""
+    round-4 rule (block = local rank over the allowed CPUs) when the platform does not expose the topology.
+    ``busy`` ({cpu: busy fraction}, cpu_busy()): rule "numa+idle" -- the node's CPUs are split into one share per GPU of the
+    node and the rank takes the block of its share that was the least busy (a core's SMT sibling counted half) instead of
+    the share's first block: the boxes are shared, and a step is host-bound as soon as a neighbour's thread sits on one of
+    the two cores that issue it (24.6 instead of 21.3 ms measured on a box with a load average of 100)."""
     node = node_of(local_rank)
     if node is not None:
         try:
@@ -304,6 +335,13 @@ def pick_cpus(local_rank, n, allowed, node_of=gpu_numa_node, n_gpus=None, sysfs=
             n_gpus = torch.cuda.device_count() if n_gpus is None else n_gpus
             k = sum(1 for j in range(min(local_rank, n_gpus)) if node_of(j) == node)      # GPUs of this node before mine
             if len(node_cpus) >= n:
+                on_node = max(1, sum(1 for j in range(n_gpus) if node_of(j) == node))
+                share = len(node_cpus) // on_node
+                if busy and share >= n and k < on_node:
+                    mine = node_cpus[k * share:(k + 1) * share]
+                    cost = {c: busy.get(c, 0.0) + 0.5 * sum(busy.get(sb, 0.0) for sb in _smt_sibling(c, sysfs)) for c in mine}
+                    best = min(range(0, len(mine) - n + 1), key=lambda st: (round(sum(cost[c] for c in mine[st:st + n]), 2), st))
+                    return mine[best:best + n], node, "numa+idle"
                 start = (k * n) % (len(node_cpus) - n + 1)
                 return node_cpus[start:start + n], node, "numa"
         except Exception:
@@ -705,9 +743,14 @@ def main():
     affinity0 = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else None
     pin_info = {"cpus": None, "numa_node": None, "rule": "unpinned"}
     if affinity0 is not None and a.pin_cores > 0 and len(affinity0) >= 2 * a.pin_cores:
-        cpus, node, rule = pick_cpus(local_rank, a.pin_cores, sorted(affinity0))
+        cpus, node, rule = pick_cpus(local_rank, a.pin_cores, sorted(affinity0),
+                                     busy=cpu_busy() if os.environ.get("SNIPPER_PIN_IDLE", "1") != "0" else None)
         os.sched_setaffinity(0, set(cpus))
         pin_info = {"cpus": _ranges(cpus), "numa_node": node, "rule": rule}
+        try:
+            pin_info["loadavg"] = open("/proc/loadavg").read().split()[0]
+        except OSError:
+            pass
     from snipper_amd import MultiScaleDeformableAttention as MSDA
     from snipper_amd import _lib
     from snipper_amd.model import build_model
@@ -1223,7 +1266,8 @@ def main():
                                    "fp32 parameters" + (" under bf16 autocast" if amp else "")),
                        "host": (f"gc.collect every {a.gc_every} steps, automatic collector off" if a.gc_every else "default gc") +
                                (f"; process pinned to {a.pin_cores} neighbouring CPUs: {pin_info['cpus']} "
-                                f"(rule {pin_info['rule']}, GPU's NUMA node {pin_info['numa_node']})" if a.pin_cores else ""),
+                                f"(rule {pin_info['rule']}, GPU's NUMA node {pin_info['numa_node']}; host load average "
+                                f"{pin_info.get('loadavg', '?')})" if a.pin_cores else ""),
                        "optimizer": ("global-norm clipping + AdamW on the flat parameter buffer in two launches "
                                      "(snipper_amd.flat_params.FlatAdamW, csrc/adamw_flat.cuh: the arithmetic of "
                                      "torch.optim.AdamW + clip_grad_norm_)" if own_opt is not None else

@@ -86,3 +86,21 @@ def test_pick_cpus_follows_the_gpus_numa_node(tmp_path):
     cpus, node, rule = bench.pick_cpus(2, 8, list(range(0, 36)), node_of=node_of, n_gpus=5, sysfs=str(tmp_path))
     assert rule == "block" and node == 1 and cpus == list(range(16, 24))
     assert bench._parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
+    # load-aware choice (rule "numa+idle"): node 0 holds two of the GPUs, so each rank chooses inside its half of the node's
+    # CPUs; the least busy block wins, a busy SMT sibling counts half, ties go to the first block
+    for c in range(128):
+        d = tmp_path / "devices" / "system" / "cpu" / f"cpu{c}" / "topology"
+        d.mkdir(parents=True)
+        (d / "thread_siblings_list").write_text(f"{c % 64},{c % 64 + 64}\n")
+    busy = {c: 0.0 for c in range(128)}
+    busy.update({0: 0.9, 1: 0.8, 9: 0.3, 64 + 20: 1.0})          # node 0 = 0-31 + 64-95; rank 0's half = CPUs 0-31
+    cpus, node, rule = bench.pick_cpus(0, 8, allowed, node_of=node_of, n_gpus=5, sysfs=str(tmp_path), busy=busy)
+    assert rule == "numa+idle" and node == 0 and cpus == list(range(10, 18))     # past 0, 1 and 9; 20's sibling is busy
+    cpus, node, rule = bench.pick_cpus(1, 8, allowed, node_of=node_of, n_gpus=5, sysfs=str(tmp_path), busy=busy)
+    assert rule == "numa+idle" and cpus == list(range(74, 82))     # the other half, 64-95: siblings of 0, 1, 9 and CPU 84 avoided
+    idle = {c: 0.0 for c in range(128)}
+    assert bench.pick_cpus(0, 8, allowed, node_of=node_of, n_gpus=5, sysfs=str(tmp_path), busy=idle)[0] == list(range(0, 8))
+    # /proc/stat sampling: two readings of a made-up file
+    stat = tmp_path / "stat"
+    stat.write_text("cpu  10 0 10 80 0 0 0 0 0 0\ncpu0 5 0 5 40 0 0 0 0 0 0\ncpu1 5 0 5 40 0 0 0 0 0 0\n")
+    assert bench.cpu_busy(sample_s=0.0, proc_stat=str(stat)) == {0: 1.0, 1: 1.0}     # (no time passed: nothing idle)
