@@ -25,6 +25,7 @@ import math
 from typing import Dict, List
 
 import torch
+from ._autograd import Function as _Fn
 import torch.nn.functional as F
 from torch import nn
 
@@ -71,7 +72,7 @@ class FrozenBatchNorm2d(nn.Module):
 FOLD_RELU_BACKWARD = True
 
 
-class _ReluGate(torch.autograd.Function):
+class _ReluGate(_Fn):
     """Identity whose backward zeroes the gradient where ``x`` (a ReLU output) is 0: the explicit form of the ReLU
     backward that the data-gradient kernels otherwise apply in their store phase (``gate_input`` below).  Only taken when
     a consumer cannot do that itself (shapes outside the kernels' requirements)."""
@@ -124,7 +125,7 @@ def conv_frozen_bn(x, conv: nn.Conv2d, bn: FrozenBatchNorm2d, relu: bool, residu
     return F.relu(y, inplace=True)
 
 
-class _PregatedRelu(torch.autograd.Function):
+class _PregatedRelu(_Fn):
     """relu(y) whose gradient is passed through unchanged: the consumer of the result was told (``gate_input``) to zero
     the gradient where the result is 0, which is exactly this ReLU's backward."""
 
@@ -145,7 +146,7 @@ def _hip_pointwise_ok(x, conv, w) -> bool:
             conv.out_channels % 64 == 0 and x.is_contiguous(memory_format=torch.channels_last))
 
 
-class _PointwiseConvBN(torch.autograd.Function):
+class _PointwiseConvBN(_Fn):
     """relu?(X . (W * scale)^T + shift (+ residual)) on [M, C] views of NHWC tensors, forward and backward.
 
     Forward and the data gradient run on this repository's MFMA kernel (one launch each, epilogue fused); the
@@ -225,7 +226,7 @@ def _hip_conv3x3_ok(x, conv) -> bool:
             x.is_contiguous(memory_format=torch.channels_last))
 
 
-class _Conv3x3BN(torch.autograd.Function):
+class _Conv3x3BN(_Fn):
     """relu?(conv3x3(x, W * scale) + shift): forward on this repository's implicit-GEMM kernel (one launch, BN and
     ReLU in the epilogue); the stride-1 data gradient on the same kernel (taps reversed, channel roles swapped), the
     stride-2 data gradient as four parity-class launches of it, the weight gradient on the split-reduction kernel
@@ -291,7 +292,7 @@ class _Conv3x3BN(torch.autograd.Function):
         return dx, dw, None, None, None, None, None, None
 
 
-class _Subsample(torch.autograd.Function):
+class _Subsample(_Fn):
     """x[:, :, ::sh, ::sw] as a dense channels-last tensor (the input of a strided 1x1 convolution).  Autograd's own
     backward of the two slices is fill + copy twice into a contiguous (NCHW-strided) buffer, which then meets the other
     gradients of x in the generic strided add kernel (measured 100-190 us per downsample block); here it is one fill

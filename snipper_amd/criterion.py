@@ -21,6 +21,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
+from ._autograd import Function as _Fn
 import torch.nn.functional as F
 from scipy.optimize import linear_sum_assignment
 from torch import nn
@@ -261,7 +262,7 @@ _PAIR_TERMS = ("loss_root", "loss_root_depth", "loss_root_vis", "loss_joint_disp
                "loss_joint", "loss_joint_depth", "loss_joint_vis", "loss_cont")
 
 
-class PairLosses(torch.autograd.Function):
+class PairLosses(_Fn):
     """The nine keypoint / depth / continuity terms of every matched pair of every decoder layer in one launch each way
     (csrc/pair_losses.cuh; the PyTorch formulation below it in ``_all_losses`` is the specification and the CPU path).
     sk / sd / tk / td as in ``_all_losses``; -> [n_dec, Msum, 9] per-pair terms in ``_PAIR_TERMS`` order."""
@@ -299,7 +300,7 @@ class PairLosses(torch.autograd.Function):
         return dsk, dsd, None, None, None, None, None
 
 
-class HeatmapLoss(torch.autograd.Function):
+class HeatmapLoss(_Fn):
     """sum over levels of mse_loss(target, heat-map views, reduction="sum") / n_heads as ONE node on the encoder memory the
     views are views of (csrc/heatmap_loss.cuh): one forward launch over all levels (deterministic block sums), one backward
     launch that writes the whole gradient of the memory.  Reference: models/model.py:447-483."""

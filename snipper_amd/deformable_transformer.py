@@ -14,6 +14,7 @@ import copy
 from typing import List, Optional
 
 import torch
+from ._autograd import Function as _Fn
 import torch.nn.functional as F
 from torch import nn
 
@@ -100,7 +101,7 @@ def _residual_norm(x, z, norm, drop):
     return norm(x + drop(z))
 
 
-class _QKVProj(torch.autograd.Function):
+class _QKVProj(_Fn):
     """The packed input projection of nn.MultiheadAttention for "query is key, value differs" (the decoder's
     self-attention: q = k = tgt + pos, v = tgt), batch-first: [q | k] = x_qk @ W[:2E]^T + b[:2E], v = x_v @ W[2E:]^T +
     b[2E:].  Two GEMMs instead of three, and dW / db are assembled here -- the module's own path slices the packed
@@ -151,7 +152,7 @@ class _QKVProj(torch.autograd.Function):
         return dxa, dxb, dW, db
 
 
-class _SmallAttention(torch.autograd.Function):
+class _SmallAttention(_Fn):
     """softmax(q k^T / sqrt(hd)) with dropout, times v, for the decoder's few hundred queries: one launch forward, one
     backward (csrc/small_attention.cuh).  ``qk`` [bs, L, 2E] is the packed q | k projection output, read in place; its
     gradient comes back as one [bs, L, 2E] tensor (no concatenation)."""

@@ -4,6 +4,7 @@ from __future__ import annotations
 from typing import Optional
 
 import torch
+from ._autograd import Function as _Fn
 
 from . import _lib
 
@@ -575,7 +576,7 @@ def _grad_out_conv(param) -> Optional[torch.Tensor]:
     return v if (v is not None and v.data_ptr() % 16 == 0) else None
 
 
-class _BigLinear(torch.autograd.Function):
+class _BigLinear(_Fn):
     """act(x @ W^T + b) for activations with tens of thousands of rows (the encoder's 79 000 tokens), in bf16 on this
     repository's kernels: forward on ``linear_bf16`` (bias / ReLU in the epilogue), weight + bias gradient on the
     split-reduction ``wgrad_bf16`` (float32 results straight into the parameter's dtype: no cast kernels), data
@@ -630,7 +631,7 @@ class _BigLinear(torch.autograd.Function):
         return dx, dW, db, None, None
 
 
-class _BigFFN(torch.autograd.Function):
+class _BigFFN(_Fn):
     """linear2(dropout(relu(linear1(x)))) -- the feed-forward block of a transformer layer on 79 000 token rows
     (reference models/deformable_transformer.py:194-198) as one autograd node: the hidden activation is written once
     (ReLU and dropout in linear1's epilogue) and, in the backward, the gradient with respect to it gets its
@@ -730,7 +731,7 @@ def _relu_dropout_backward(g: torch.Tensor, y: torch.Tensor, p: float) -> torch.
     return out
 
 
-class _SmallLinear(torch.autograd.Function):
+class _SmallLinear(_Fn):
     """x @ W^T + b for a few hundred float32 rows (the decoder): identical arithmetic to F.linear, but the bias
     gradient is a [1, rows] x [rows, N] product instead of a column reduction -- PyTorch's reduce kernel needs ~25 us
     for a 480 x 384 column sum (one workgroup per few columns), a GEMM launch ~9 us; 48 of them per step."""
@@ -873,7 +874,7 @@ def small_linear_backward(g: torch.Tensor, x: torch.Tensor, w: torch.Tensor, nee
     return dx, dw, db
 
 
-class _SmallFFN(torch.autograd.Function):
+class _SmallFFN(_Fn):
     """linear2(dropout(relu(linear1(x)))) for a few hundred float32 rows (the decoder's feed-forward block, reference
     models/deformable_transformer.py:266-275) on the small-GEMM kernel: ReLU + dropout in linear1's epilogue; in the
     backward the gate of the hidden gradient in the data-gradient product of linear2, and each layer's (dX | dH, dW, db)
@@ -929,7 +930,7 @@ def small_ffn(x: torch.Tensor, lin1: torch.nn.Linear, lin2: torch.nn.Linear, dro
     return _SmallFFN.apply(x, lin1.weight, lin1.bias, lin2.weight, lin2.bias, float(p))
 
 
-class _SmallLinearPair(torch.autograd.Function):
+class _SmallLinearPair(_Fn):
     """cat([x @ Wa^T + ba, x @ Wb^T + bb], -1) for decoder-size float32 rows (the cross attention's offset and weight
     projections): one launch forward (two column blocks of one output), one launch backward (the shared input's gradient
     as ONE product over the stacked weights [Wa; Wb] read in place, both weight gradients, both bias gradients)."""
@@ -1047,7 +1048,7 @@ def big_linear_merged(x: torch.Tensor, lins, first_bias_outside: bool = False) -
     return _BigLinear.apply(x, weight, bias, False, 0.0)
 
 
-class _BigLinearPair(torch.autograd.Function):
+class _BigLinearPair(_Fn):
     """cat([x @ Wa^T + ba, x @ Wb^T + bb], -1) as one projection (see big_linear_merged); the merged bf16 weight and
     bias come from the per-step shadows when they are valid, and the gradients go back to the four parameters as
     slices of one weight-gradient launch."""

@@ -7,7 +7,7 @@ import ctypes
 from typing import List, Optional, Sequence
 
 import torch
-from torch.autograd import Function
+from ._autograd import Function
 from torch.autograd.function import once_differentiable
 
 from . import _lib
