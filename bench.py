@@ -410,6 +410,40 @@ def pmc_traffic(path=PMC_PROFILE):
         return None, None, f"no PMC profile ({type(e).__name__})"
 
 
+def kernel_census(run_step, n_steps: int = 2):
+    """{"launches_per_step", "kernel_ms_per_step", "kernels_under_20us": {"launches_per_step", "ms_per_step"}, "memops_per_step"}
+    from torch.profiler's device records of ``n_steps`` calls of ``run_step(i)`` (one unrecorded call first: the profiler's
+    start-up allocations), or {"error": ...} when the platform's tracer yields no device records."""
+    try:
+        from torch.profiler import profile, ProfilerActivity
+        run_step(0)
+        torch.cuda.synchronize()
+        with profile(activities=[ProfilerActivity.CUDA]) as prof:
+            for i in range(n_steps):
+                run_step(i)
+            torch.cuda.synchronize()
+        kernels, memops = [], 0
+        for ev in prof.events():
+            if str(getattr(ev, "device_type", "")).endswith("CUDA"):
+                name = ev.name or ""
+                dur = float(getattr(ev, "device_time_total", 0.0) or getattr(ev, "cuda_time_total", 0.0) or 0.0)    # us
+                if name.startswith(("Memcpy", "Memset")) or "memcpy" in name.lower() and "kernel" not in name.lower():
+                    memops += 1
+                else:
+                    kernels.append(dur)
+        if not kernels:
+            return {"error": "the profiler returned no device kernel records"}
+        small = [d for d in kernels if d < 20.0]
+        return {"launches_per_step": round(len(kernels) / n_steps, 1),
+                "kernel_ms_per_step": round(sum(kernels) / n_steps / 1e3, 3),
+                "kernels_under_20us": {"launches_per_step": round(len(small) / n_steps, 1),
+                                       "ms_per_step": round(sum(small) / n_steps / 1e3, 3)},
+                "memops_per_step": round(memops / n_steps, 1),
+                "source": f"torch.profiler device activity over {n_steps} eager steps after the timed region"}
+    except Exception as e:                       # a measurement aid must never take the bench line down
+        return {"error": f"{type(e).__name__}: {e}"}
+
+
 def physical_cores():
     """(physical cores, the lscpu lines that say so) of the host."""
     import subprocess
@@ -1105,6 +1139,17 @@ def main():
     elapsed = time.perf_counter() - t0
     if gsync is not None:
         gsync.check_errors()          # a late gradient flagged by the LAST step's sync() would otherwise never be reported
+    # ---- how long the HOST needs to issue a step: three steps issued back to back on an idle GPU, the
+    #      clock read BEFORE the device is waited for.  While this stays below ms_per_step the step is GPU-bound; a rank whose
+    #      figure exceeds its ms_per_step is host-bound (a slow or shared core), which a per-rank step time alone cannot tell
+    #      from a slow link.  Every rank measures (the steps contain the collectives), rank 0 reports.
+    host_issue_ms = None
+    if not a.no_extras and graph is None:
+        h0 = time.perf_counter()
+        for i in range(3):
+            step(a.warmup + a.steps + i)
+        host_issue_ms = round((time.perf_counter() - h0) / 3 * 1e3, 3)
+        fence()
     loss_val = float(loss.detach())
     per_rank_ms = None
     if use_ddp:
@@ -1114,6 +1159,8 @@ def main():
         per_rank_ms = [round(float(x) / a.steps * 1e3, 3) for x in every]
         per_rank_pin = [None] * world               # every rank's CPU set and its GPU's NUMA node
         dist.all_gather_object(per_rank_pin, pin_info)
+        per_rank_issue = [None] * world             # every rank's host-issue time per step
+        dist.all_gather_object(per_rank_issue, host_issue_ms)
         t = mine.clone()
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
@@ -1138,6 +1185,18 @@ def main():
     if use_ddp and not a.no_extras:      # the other ranks must run the same eager steps (collectives inside)
         if rank != 0:
             for i in range(2):
+                train_step(*batches[i % len(batches)])
+        fence()
+
+    # ---- kernel census of a step: every device kernel of two eager steps from the profiler's device activity
+    #      (roctracer): launches per step, their summed duration, and the part of it in kernels shorter than 20 us -- the
+    #      launch-bound tail, whose kernels cannot fill 256 CUs.  Memcpy / memset records are counted apart.
+    census = None
+    if rank == 0 and not a.no_extras and graph is None:
+        census = kernel_census(lambda i: train_step(*batches[i % len(batches)]), 2)
+    if use_ddp and not a.no_extras and graph is None:
+        if rank != 0:
+            for i in range(3):                      # (one warm-up step inside kernel_census + the two counted ones)
                 train_step(*batches[i % len(batches)])
         fence()
 
@@ -1246,7 +1305,10 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32" if not amp else "bf16", "data": "synthetic",
             "config": {"workload": (f"T={a.frames}+{a.future_frames} enc{a.enc_layers}/dec{a.dec_layers} "
                                     f"hidden_dim={a.hidden_dim} L=3 nq=60 {a.height}x{a.width} ResNet-50, "
-                                    f"train step fwd+bwd+clip+AdamW (BASELINE configs[2]/[3])"),
+                                    f"train step fwd+bwd+clip+AdamW (" +
+                                    ("BASELINE configs[4], the forecast model, on one node's worth of ranks" if a.future_frames else
+                                     "BASELINE configs[2]/[3]" if (a.height, a.width) == (600, 800) else
+                                     "the reference README's JTA / Panoptic input size, README.md:145-146,208-209") + ")"),
                        "global_batch": a.batch * world, "per_gpu_batch": a.batch, "parallelism": f"dp{world}",
                        "loss": ("SetCriterion + Hungarian matcher (reference coefficients, 6+8 synthetic persons)"
                                 if a.loss == "criterion" else "fixed-assignment surrogate"),
@@ -1286,9 +1348,21 @@ def main():
                                    "per_rank_ms_per_step": per_rank_ms,
                                    "per_rank_ms_per_step_min_max": [min(per_rank_ms), max(per_rank_ms)],
                                    "per_rank_cpu_pinning": per_rank_pin,
+                                   "per_rank_host_issue_ms_per_step": per_rank_issue,
                                    "grad_allreduce_mbytes_per_step": round(gsync.flat.numel() * 4 / 1e6, 2) if gsync is not None else None}
+        line["host_issue_ms"] = host_issue_ms          # host time to issue one step (no device wait); < ms_per_step = GPU-bound
+        if census is not None:
+            line["launches_per_step"] = census.get("launches_per_step")
+            line["kernels_under_20us_ms"] = (census.get("kernels_under_20us") or {}).get("ms_per_step")
+            line["kernel_census"] = census
         if locality:
             line["locality"] = locality
+            # the representative operating point once training has left the initialisation: the same step with
+            # the encoder's sampling offsets spread by N(0, 3 px) around the reference's bias grid
+            s3 = [x for x in locality if x["offset_sigma_px"] == 3.0]
+            if s3:
+                line["ms_per_step_at_offset_sigma_3px"] = s3[0]["ms_per_step"]
+                line["value_at_offset_sigma_3px"] = round(a.batch * world / (s3[0]["ms_per_step"] * 1e-3), 4)
         if sync_trace:
             line["grad_sync_trace"] = sync_trace
         if launches:

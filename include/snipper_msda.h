@@ -68,8 +68,9 @@ enum {
 int snipper_msda_abi_version(void);
 /* Human-readable text for a code returned by any entry point (static storage). */
 const char *snipper_msda_strerror(int code);
-/* Name of the kernel variant the last forward / backward call of this process dispatched to ("generic", "d48_lp12",
- * "d48_owner", ...): a diagnostic for tests and profiles, never an input of any computation. */
+/* Name of the kernel variant the last forward / backward call OF THE CALLING THREAD dispatched to ("generic", "d48_lp12",
+ * "d48_owner", ...; "none" before the thread's first call): a diagnostic for tests and profiles, never an input of any
+ * computation.  Thread-local storage: the library keeps no process-wide mutable state. */
 const char *snipper_msda_last_variant(void);
 
 /* The library keeps NO tuning state: everything that can change which kernels run travels in this struct, passed by the

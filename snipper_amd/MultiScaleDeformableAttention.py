@@ -97,6 +97,7 @@ class _Timed:
         return self
 
     def __exit__(self, *exc):
+        _lib.note_variant()
         if _timing is not None and exc[0] is None:
             end = torch.cuda.Event(enable_timing=True)
             end.record(torch.cuda.current_stream(self.device))

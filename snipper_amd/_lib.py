@@ -210,8 +210,20 @@ def check(code: int, what: str) -> None:
         raise RuntimeError(f"{what} failed: {msg} (code {code})")
 
 
+_last_variant = "none"
+
+
+def note_variant() -> None:
+    """Record, on the Python side, the variant of the core-op call THIS thread has just made (the C diagnostic is thread-local;
+    the wrappers call this right after every core-op entry point, so a test on the main thread can ask about a backward that
+    ran on the autograd engine's thread)."""
+    global _last_variant
+    _last_variant = load().snipper_msda_last_variant().decode()
+
+
 def last_variant() -> str:
-    return load().snipper_msda_last_variant().decode()
+    """Kernel variant of the most recent core-op call made through this package's wrappers, on whichever thread."""
+    return _last_variant
 
 
 class SmallGemm(ctypes.Structure):

@@ -455,17 +455,22 @@ class SetCriterion(nn.Module):
         t_all = max(t for t, _, _ in spatial)
         k_all = torch.cat([tgt["kpts2d"][:, :t_all] for tgt in targets], 0)         # [Nsum, t, K, 3]
         K = k_all.shape[2]
-        # pixel coordinates and validity for ALL levels in one set of launches: [levels, Nsum, t, K]
-        whs = torch.tensor([[w, h] for _, h, w in spatial], dtype=k_all.dtype).to(device, non_blocking=True) \
-            if getattr(self, "_wh_key", None) != (tuple(spatial), str(device), k_all.dtype) else self._wh
-        self._wh_key, self._wh = (tuple(spatial), str(device), k_all.dtype), whs
-        xy = (k_all[None, ..., 0:2] * whs[:, None, None, None, :]).long()
-        lim = whs.long()[:, None, None, None, :]
-        ok_all = (k_all[None, ..., 2] > 0) & ((xy >= 0) & (xy < lim)).all(-1)
-        xy = torch.minimum(xy.clamp(min=0), lim - 1)
-        ti = torch.arange(t_all, device=device)[None, :, None]
-        ki = torch.arange(K, device=device)[None, None, :]
         ksizes = [max(h // 10 + h // 10 % 2 - 1, w // 10 + w // 10 % 2 - 1) for _, h, w in spatial]
+
+        def pixel_indices():
+            """Pixel coordinates and validity for ALL levels in one set of launches: [levels, Nsum, t, K] (the PyTorch paths
+            only: the fused scatter kernel below does this arithmetic itself)."""
+            whs = torch.tensor([[w, h] for _, h, w in spatial], dtype=k_all.dtype).to(device, non_blocking=True) \
+                if getattr(self, "_wh_key", None) != (tuple(spatial), str(device), k_all.dtype) else self._wh
+            self._wh_key, self._wh = (tuple(spatial), str(device), k_all.dtype), whs
+            xy = (k_all[None, ..., 0:2] * whs[:, None, None, None, :]).long()
+            lim = whs.long()[:, None, None, None, :]
+            ok_all = (k_all[None, ..., 2] > 0) & ((xy >= 0) & (xy < lim)).all(-1)
+            xy = torch.minimum(xy.clamp(min=0), lim - 1)
+            ti = torch.arange(t_all, device=device)[None, :, None]
+            ki = torch.arange(K, device=device)[None, None, :]
+            return xy, ok_all, ti, ki
+
         # One scatter-add over the flattened [bs, K, t, h, w] maps.  No boolean-mask indexing (it would read the count
         # back to the host) and no multi-index index_put_ (its accumulate path range-checks every index tensor with
         # separate reductions and sorts: ~50 launches per call): invalid joints add 0 at a clamped position, valid ones
@@ -496,6 +501,7 @@ class SetCriterion(nn.Module):
                     off += n
                     maps.append(gaussian_blur(hm, ksize, clamp_max=1.0).permute(0, 2, 3, 4, 1))   # [bs, t, h, w, K]
                 return maps
+            xy, ok_all, ti, ki = pixel_indices()
             key = ("hm_geom", tuple(spatial), bs, K, str(device))
             geom = getattr(self, "_hm_geom", None)
             if geom is None or geom[0] != key:
@@ -515,6 +521,7 @@ class SetCriterion(nn.Module):
                 off += n
                 maps.append(gaussian_blur(hm, ksize, clamp_max=1.0).permute(0, 2, 3, 4, 1))   # [bs, t, h, w, K]
             return maps
+        xy, ok_all, ti, ki = pixel_indices()
         for lvl, (t, h, w) in enumerate(spatial):
             x, y, ok = xy[lvl, :, :t, :, 0], xy[lvl, :, :t, :, 1], ok_all[lvl, :, :t]
             lin = (((sample[:, None, None] * K + ki) * t + ti[:, :t]) * h + y) * w + x

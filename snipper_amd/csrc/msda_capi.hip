@@ -42,9 +42,11 @@ using namespace snipper;
 
 namespace {
 
-// name of the kernel variant the last core-op call dispatched to: a diagnostic for tests and profiles (the backward
-// runs on the autograd engine's thread, so it is process-wide rather than thread-local; it never influences a result)
-std::atomic<const char *> g_last_variant{"none"};
+// name of the kernel variant the last core-op call OF THE CALLING THREAD dispatched to: a diagnostic for tests and profiles that
+// never influences a result.  Thread-local: the library holds no process-wide mutable state (two callers -- the autograd
+// engine's thread and the main thread -- used to race on one global; a caller that wants the variant of a call made on another
+// thread reads it there, right after the call, as snipper_amd/MultiScaleDeformableAttention.py does)
+thread_local const char *g_last_variant = "none";
 
 constexpr int kWgradWgs = 512;          // workgroups of the split-reduction weight gradient (2 per CU; 384 .. 1024 measured)
 constexpr int kLnBwdBlocks = 1536;      // 6 workgroups per CU x 256 CUs: one residency wave of the LayerNorm backward
@@ -439,7 +441,7 @@ const char *snipper_msda_strerror(int code) {
   }
 }
 
-const char *snipper_msda_last_variant(void) { return g_last_variant.load(); }
+const char *snipper_msda_last_variant(void) { return g_last_variant; }
 
 void snipper_msda_config_init(snipper_msda_config *cfg) {
   if (cfg) *cfg = default_config();
@@ -621,15 +623,25 @@ int snipper_msda_backward_bf16(void *stream, const uint16_t *grad_out, const uin
 }
 
 namespace {
-// compute units of the current device (one persistent workgroup each in the weight-stationary kernel); read once
+// compute units of the CURRENT device (one persistent workgroup each in the weight-stationary kernel): read once per device --
+// a process may drive several GPUs (a cache keyed on nothing would hand the second one the first one's answer)
+constexpr int kMaxDevices = 64;
+int current_device_index() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
+  return dev;
+}
 int device_cu_count() {
-  static const int n = [] {
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-      cus = 256;
-    return cus;
-  }();
-  return n;
+  static std::atomic<int> cache[kMaxDevices];          // zero-initialised: 0 = not read yet
+  const int dev = current_device_index();
+  if (dev < kMaxDevices) {
+    const int got = cache[dev].load(std::memory_order_relaxed);
+    if (got > 0) return got;
+  }
+  int cus = 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+  if (dev < kMaxDevices) cache[dev].store(cus, std::memory_order_relaxed);
+  return cus;
 }
 // SNIPPER_GEMM_WRES=0 in the environment at load time keeps every product on the tile kernels (A/B measurements)
 int wres_debug() {       // SNIPPER_WRES_DEBUG: timing ablations of the weight-stationary / ring kernels (WRONG results), read once;
@@ -1534,19 +1546,22 @@ int snipper_linear_wide_bf16(void *stream, const uint16_t *X, const uint16_t *Wp
   const LinearWideArgs g{X, Wp, bias, Y, M, K};
   // 160-row tiles when they fill the rounds of one workgroup per CU better than 128-row tiles (SNIPPER_LINEAR_WIDE_MT = 4 / 5 forces)
   static const int forced = [] { const char *e = getenv("SNIPPER_LINEAR_WIDE_MT"); return e ? atoi(e) : 0; }();
-  static const int cus = [] {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-    return n;
-  }();
+  const int cus = device_cu_count();
   auto cost = [&](int rows) { const long long t = ((long long)M + rows - 1) / rows; return (double)((t + cus - 1) / cus) * rows; };
   const int mt = forced == 4 || forced == 5 ? forced : (cost(160) < cost(128) ? 5 : 4);
-  // (more than 64 KB of dynamic LDS: the limit is raised once per process and kernel)
-  static const hipError_t attr4 = hipFuncSetAttribute(reinterpret_cast<const void *>(&linear_wide_kernel<4>),
-                                                      hipFuncAttributeMaxDynamicSharedMemorySize, linear_wide_lds_bytes<4>());
-  static const hipError_t attr5 = hipFuncSetAttribute(reinterpret_cast<const void *>(&linear_wide_kernel<5>),
-                                                      hipFuncAttributeMaxDynamicSharedMemorySize, linear_wide_lds_bytes<5>());
-  if (attr4 != hipSuccess || attr5 != hipSuccess) return (int)(attr4 != hipSuccess ? attr4 : attr5);
+  // (more than 64 KB of dynamic LDS: the limit is a per-DEVICE function attribute -- raised once per device and kernel)
+  {
+    static std::atomic<int> raised[kMaxDevices];       // 0 = not yet, 1 = done
+    const int dev = current_device_index();
+    if (dev >= kMaxDevices || raised[dev].load(std::memory_order_acquire) == 0) {
+      const hipError_t attr4 = hipFuncSetAttribute(reinterpret_cast<const void *>(&linear_wide_kernel<4>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, linear_wide_lds_bytes<4>());
+      const hipError_t attr5 = hipFuncSetAttribute(reinterpret_cast<const void *>(&linear_wide_kernel<5>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, linear_wide_lds_bytes<5>());
+      if (attr4 != hipSuccess || attr5 != hipSuccess) return (int)(attr4 != hipSuccess ? attr4 : attr5);
+      if (dev < kMaxDevices) raised[dev].store(1, std::memory_order_release);
+    }
+  }
   if (mt == 5)
     hipLaunchKernelGGL(linear_wide_kernel<5>, dim3((unsigned)((M + 159) / 160)), dim3(kLwThreads), linear_wide_lds_bytes<5>(), (hipStream_t)stream, g);
   else

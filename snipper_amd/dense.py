@@ -139,7 +139,7 @@ def cast_scale_table_bf16(items) -> bool:
     items = list(items)
     if not items:
         return True
-    key = tuple((s_.data_ptr(), d_.data_ptr(), 0 if sc is None else sc.data_ptr(), s_.numel()) for s_, d_, sc in items)
+    key = tuple((s_.data_ptr(), d_.data_ptr(), 0 if sc is None else sc.data_ptr(), tuple(s_.shape), s_.stride()) for s_, d_, sc in items)
     hit = _CAST_TABLES.get(key)
     if hit is None:
         dev = items[0][0].device
@@ -266,7 +266,7 @@ def conv3x3_pack_bf16(items) -> None:
     items = list(items)
     if not items:
         return
-    key = tuple((s_.data_ptr(), d_.data_ptr(), bool(t_)) for s_, d_, t_ in items)
+    key = tuple((s_.data_ptr(), d_.data_ptr(), bool(t_), tuple(s_.shape)) for s_, d_, t_ in items)
     args = _PACK_ARGS.get(key)
     if args is None:
         n = len(items)
@@ -297,7 +297,7 @@ def linear_pack_bf16(items) -> None:
     items = list(items)
     if not items:
         return
-    key = tuple((s_.data_ptr(), d_.data_ptr(), bool(t_)) for s_, d_, t_ in items)
+    key = tuple((s_.data_ptr(), d_.data_ptr(), bool(t_), tuple(s_.shape)) for s_, d_, t_ in items)
     args = _LPACK_ARGS.get(key)
     if args is None:
         n = len(items)
@@ -359,6 +359,8 @@ def linear_wide_bf16(x: torch.Tensor, packed: torch.Tensor, bias: Optional[torch
     assert packed.numel() == 384 * K
     if bias is not None and bias.dtype != torch.float32:
         bias = bias.float()
+    if bias is not None and (bias.data_ptr() % 16 or not bias.is_contiguous()):
+        bias = bias.contiguous().clone()       # (the kernel reads it in 16-byte pieces; snipper_linear_wide_supported sees no pointers)
     out = torch.empty((M, 384), dtype=torch.bfloat16, device=x.device)
     with _timed(kind, (M, 384, K), 2 * M * 384 * K, 2 * (M * K + 384 * K + M * 384), x.device), _lib.device_guard(x.device):
         rc = _lib.load().snipper_linear_wide_bf16(_lib.raw_stream(x.device), x.data_ptr(), packed.data_ptr(),

@@ -45,8 +45,10 @@ def claim_grad_view(p) -> Optional[torch.Tensor]:
         return None
     if flat.grad_guard is not None and not flat.grad_guard(p):      # (e.g. FlatGradSync.slice_is_free: an all-reduce in flight)
         return None
-    flat._claimed.add(i)
     v = flat.grad_views[i]
+    if v.data_ptr() % 16:             # (the weight-gradient kernels store 16-byte pieces; claim only what they can take)
+        return None
+    flat._claimed.add(i)
     # a fresh alias: autograd adopts a gradient without copying only when nobody else holds the tensor object
     return v.as_strided(v.shape, v.stride(), v.storage_offset())
 
@@ -72,6 +74,10 @@ class FlatParameters:
         if grad_flat is None:
             grad_flat = torch.zeros(total, dtype=torch.float32, device=dev)
         assert grad_flat.shape == (total,) and grad_flat.dtype == torch.float32 and grad_flat.device == dev
+        # (slices are 256-byte aligned relative to the buffer's start: a caller's buffer must start aligned too, or the
+        #  kernels that write gradients straight into a slice would be handed misaligned pointers)
+        # (CPU allocations are 64-byte aligned and no kernel writes into them; claim_grad_view checks each view besides)
+        assert not grad_flat.is_cuda or grad_flat.data_ptr() % 256 == 0, "grad_flat must start on a 256-byte boundary"
         self.grad_flat = grad_flat
         self.grad_views: List[torch.Tensor] = []
         self.ranges = []
@@ -109,6 +115,9 @@ class FlatParameters:
         """(Re-)attach every leaf to its slice of the flat gradient buffer (``zero_grad(set_to_none=True)`` drops it)."""
         for leaf, (a, b) in zip(self.leaves, self._leaf_ranges):
             leaf.grad = self.grad_flat[a:b]
+        # a new pass begins: whatever reset the gradients (drop_param_grads, model.zero_grad(set_to_none=True), p.grad = None
+        # by hand), the claims of the last pass are spent -- leaving them set would switch the direct path off for good
+        self._claimed.clear()
 
     def drop_param_grads(self) -> None:
         """``p.grad = None`` for every parameter: autograd then hands its gradient buffers over without an add."""

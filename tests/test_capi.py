@@ -102,3 +102,77 @@ def test_config_reserved_fields_and_owner_map_bounds_are_checked():
     assert ws(None, wide.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), 40000, 1) == 0
     ok = np.array([[1, 30000]], dtype=np.int64)
     assert ws(None, ok.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), 30000, 1) > 0
+
+
+# ---- argument lists: header prototype <-> ctypes tuple, parameter by parameter --------------------------
+def _prototypes():
+    """{name: (return class, [parameter classes])} parsed from include/*.h.  Classes: 'p' pointer, 'q' 64-bit integer,
+    'i' 32-bit integer, 'f' float, 'd' double, 'v' void (return only)."""
+    def klass(decl: str) -> str:
+        decl = decl.strip()
+        if "*" in decl or "[" in decl:
+            return "p"
+        words = [w for w in re.split(r"\s+", decl) if w not in ("const", "unsigned", "signed", "volatile")]
+        # drop the parameter name (the last identifier) when a type word precedes it
+        types = words[:-1] if len(words) > 1 else words
+        t = " ".join(types)
+        if t in ("long long", "int64_t", "uint64_t", "size_t", "long long int"):
+            return "q"
+        if t in ("int", "int32_t", "uint32_t"):
+            return "i"
+        if t == "float":
+            return "f"
+        if t == "double":
+            return "d"
+        if t == "void":
+            return "v"
+        raise AssertionError(f"unclassified C type in a prototype: {decl!r}")
+
+    protos = {}
+    inc = os.path.join(ROOT, "include")
+    for f in sorted(os.listdir(inc)):
+        text = open(os.path.join(inc, f)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        text = re.sub(r"//[^\n]*", "", text)
+        text = re.sub(r"^\s*#[^\n]*", "", text, flags=re.M)             # preprocessor lines
+        for m in re.finditer(r"([A-Za-z_][\w \t\*]*?)\b(snipper_\w+)\s*\(([^()]*)\)\s*;", text):
+            ret, name, params = m.group(1).strip(), m.group(2), m.group(3).strip()
+            rclass = "p" if "*" in ret else klass(ret + " x")
+            plist = [] if params in ("", "void") else [klass(q) for q in params.split(",")]
+            protos[name] = (rclass, plist)
+    return protos
+
+
+def _ctypes_class(t) -> str:
+    if t is None:
+        return "v"
+    if t in (ctypes.c_void_p, ctypes.c_char_p) or isinstance(t, type(ctypes.POINTER(ctypes.c_int))):
+        return "p"
+    if t in (ctypes.c_longlong, ctypes.c_ulonglong, ctypes.c_int64, ctypes.c_uint64, ctypes.c_size_t, ctypes.c_ssize_t):
+        return "q"
+    if t in (ctypes.c_int, ctypes.c_uint, ctypes.c_int32, ctypes.c_uint32):
+        return "i"
+    if t is ctypes.c_float:
+        return "f"
+    if t is ctypes.c_double:
+        return "d"
+    raise AssertionError(f"unclassified ctypes type {t}")
+
+
+def test_ctypes_argument_lists_match_the_header_prototypes():
+    """Every entry of ``_lib.EXPORTS`` has the parameter COUNT and, parameter by parameter, the WIDTH CLASS (pointer / 64-bit
+    integer / 32-bit integer / float) of its prototype in include/*.h, and the same return class: a drifted ``c_int`` /
+    ``c_longlong`` would otherwise be silent until it corrupts a launch."""
+    protos = _prototypes()
+    assert set(protos) == set(_lib.EXPORTS), sorted(set(protos) ^ set(_lib.EXPORTS))
+    bad = []
+    for name, (argtypes, restype) in sorted(_lib.EXPORTS.items()):
+        rclass, plist = protos[name]
+        got = [_ctypes_class(t) for t in argtypes]
+        if got != plist:
+            first = next((i for i, (a, b) in enumerate(zip(got, plist)) if a != b), min(len(got), len(plist)))
+            bad.append(f"{name}: header {''.join(plist)} ({len(plist)}) vs ctypes {''.join(got)} ({len(got)}), first difference at "
+                       f"parameter {first}")
+        if _ctypes_class(restype) != rclass:
+            bad.append(f"{name}: return class header {rclass} vs ctypes {_ctypes_class(restype)}")
+    assert not bad, "\n".join(bad)

@@ -66,6 +66,7 @@ def test_st_entry_matches_composition(encoder, vdt):
                                      shapes.data_ptr(), lsi.data_ptr(), cv(hs), N, T, T, S, M, D, L, Lq, P,
                                      vbar2.data_ptr(), loc2.data_ptr(), prob2.data_ptr(), out2.data_ptr(), 0)
     _lib.check(rc, "snipper_st_msda_forward")
+    _lib.note_variant()                 # (the C diagnostic is thread-local; this thread made the call)
     assert _lib.last_variant() == "d48_lp12", _lib.last_variant()
     torch.testing.assert_close(out2, out.detach(), rtol=0, atol=0)
 
@@ -79,6 +80,7 @@ def test_st_entry_matches_composition(encoder, vdt):
                                       gv2.data_ptr(), vd, goff2.data_ptr(), M * L * P * 2, glogit2.data_ptr(), M * L * P,
                                       0, gref2.data_ptr())
     _lib.check(rc, "snipper_st_msda_backward")
+    _lib.note_variant()
     # the encoder shape must run the owner-computes kernels (the ones the training step runs), the decoder shape the
     # atomic D=48 kernel
     assert _lib.last_variant() == ("d48_owner" if encoder else "d48_lp12"), _lib.last_variant()
