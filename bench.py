@@ -1145,11 +1145,14 @@ def main():
     #      from a slow link.  Every rank measures (the steps contain the collectives), rank 0 reports.
     host_issue_ms = None
     if not a.no_extras and graph is None:
-        h0 = time.perf_counter()
-        for i in range(3):
-            step(a.warmup + a.steps + i)
-        host_issue_ms = round((time.perf_counter() - h0) / 3 * 1e3, 3)
-        fence()
+        rounds = []
+        for r in range(3):         # best of three rounds (shared hosts: a neighbour's burst on an issuing core shows up in one of them)
+            h0 = time.perf_counter()
+            for i in range(3):
+                step(a.warmup + a.steps + 3 * r + i)
+            rounds.append((time.perf_counter() - h0) / 3 * 1e3)
+            fence()
+        host_issue_ms = round(min(rounds), 3)
     loss_val = float(loss.detach())
     per_rank_ms = None
     if use_ddp:

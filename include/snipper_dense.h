@@ -222,6 +222,27 @@ int snipper_colsum_segments_multi_bf16(void *stream, const uint16_t *const *srcs
  * (autograd's own accumulation: n_src - 1 add launches, each partial sum rounded to bf16). */
 int snipper_sum_bf16(void *stream, const uint16_t *const *srcs, int n_src, uint16_t *out, long long numel);
 
+/* out = sum of n_src (<= 16) float32 arrays of numel elements (numel % 4 == 0, 16-byte aligned) in one pass: the gradients of
+ * the aliases of a float32 tensor with several consumers (query_pos feeds two additions per decoder layer, reference
+ * models/deformable_transformer.py:252-254), which autograd would add pairwise, one launch per pair. */
+int snipper_sum_f32(void *stream, const float *const *srcs, int n_src, float *out, long long numel);
+
+/* Decoder-size residual + dropout + LayerNorm (csrc/small_ln.cuh; reference models/deformable_transformer.py:266-300), float32,
+ * rows <= 16384, C % 4 == 0, C <= 1024, all arrays 16-byte aligned:
+ *   forward : y = LayerNorm(x + dropout_p(z)) * gamma + beta and, with pos != NULL, yq = y + pos (the reference's
+ *             with_pos_embed, :252-254, for the projection that consumes the result) in ONE launch; z / pos / yq / keep may be
+ *             NULL; s_save, mean, rstd, keep are what the backward reads (all NULL: inference).  The dropout mask is the one
+ *             snipper_add_dropout_layernorm_forward draws for the same (seed, element index).
+ *   backward: ONE launch; the gradient of y is the SUM of g0 .. g3 (each may be NULL, not all): the outputs' consumers hand
+ *             their gradients over separately (a gradient of yq counts as one of y).  dx = dL/dx, dz = dL/dz (masked, rescaled),
+ *             dgamma / dbeta [C] are fully written (column workgroups of the same launch; deterministic). */
+int snipper_small_ln_forward_f32(void *stream, const float *x, const float *z, const float *pos, const float *gamma, const float *beta,
+                                 int rows, int C, float p, float eps, uint64_t seed, float *s_save, float *mean, float *rstd,
+                                 uint8_t *keep, float *y, float *yq);
+int snipper_small_ln_backward_f32(void *stream, const float *g0, const float *g1, const float *g2, const float *g3,
+                                  const float *s_save, const float *mean, const float *rstd, const float *gamma, const uint8_t *keep,
+                                  int rows, int C, float p, float *dx, float *dz, float *dgamma, float *dbeta);
+
 /* Stem input: float32 images [N, 3, H, W] (planar; W % 4 == 0) -> bf16 [N, H, W, 4] with a zero fourth channel, the layout
  * snipper_stem7x7_bf16 reads. */
 int snipper_stem_pack_bf16(void *stream, const float *x, int N, int H, int W, uint16_t *out);
@@ -434,6 +455,12 @@ int snipper_match_cost_f32(void *stream, const float *kpts, long long kp_sl, lon
 int snipper_refine_reference_f32(void *stream, const float *delta, long long ld_delta, const float *ref,
                                  const float *valid_ratios, int rows, int rows_per_batch, int L, float eps,
                                  float *new_ref, float *ref_in);
+/* The same with the head evaluated in place: delta[row][c] = x[row] . W[c] + b[c] for c = 0, 1 -- the root head of the
+ * reference's model is ONE Linear(C -> 4) (models/model.py:95) of which only the first two outputs reach the refinement
+ * (models/deformable_transformer.py:329-333); x [rows][C], W [>= 2][C] row-major, b [>= 2] or NULL; C % 4 == 0. */
+int snipper_refine_reference_linear_f32(void *stream, const float *x, const float *W, const float *b, const float *ref,
+                                        const float *valid_ratios, int rows, int C, int rows_per_batch, int L, float eps,
+                                        float *new_ref, float *ref_in);
 
 /* ---- Hungarian matching on the device (csrc/lsap.cuh) ---------------------------------------------------
  * Replaces the host round trip of models/matcher.py:132 (`linear_sum_assignment(cost.cpu())`).

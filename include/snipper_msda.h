@@ -165,6 +165,11 @@ int snipper_msda_backward_bf16(void *stream, const uint16_t *grad_out, const uin
 int snipper_msda_backward_sparse_bf16(void *stream, const uint16_t *grad_out, const uint16_t *value, const int64_t *shapes,
                                       const int64_t *level_start, const float *loc, const float *attn, int N, int S, int M, int D,
                                       int L, int Lq, int P, uint16_t *grad_value, float *grad_loc, float *grad_attn);
+/* The same with FLOAT32 grad_out rows [N][Lq][M*D] (the consumer of the sampled rows -- the decoder's float32 output
+ * projection -- hands its data gradient over as it is; no bf16 cast launch in front of the call). */
+int snipper_msda_backward_sparse_f32rows(void *stream, const float *grad_out, const uint16_t *value, const int64_t *shapes,
+                                         const int64_t *level_start, const float *loc, const float *attn, int N, int S, int M, int D,
+                                         int L, int Lq, int P, uint16_t *grad_value, float *grad_loc, float *grad_attn);
 
 #ifdef __cplusplus
 }

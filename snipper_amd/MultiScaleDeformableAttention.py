@@ -123,11 +123,13 @@ def _host_shapes_ptr(host_shapes, L):
 def ms_deform_attn_forward(value: torch.Tensor, spatial_shapes: torch.Tensor,
                            level_start_index: torch.Tensor, sampling_loc: torch.Tensor,
                            attn_weight: torch.Tensor, im2col_step: int, out_bf16: bool = False,
-                           host_shapes=None, config=None) -> torch.Tensor:
+                           host_shapes=None, config=None, out_f32: bool = False) -> torch.Tensor:
     """-> Tensor[N, Lq, M*D]   (ms_deform_attn_cuda.cu:20-80)
 
     Extensions (all optional): ``out_bf16`` -- float32 ``value``, output rows written as bfloat16 by the kernel (exactly
     the float32 result rounded once; shapes without a bf16-row kernel get the float32 result cast here);
+    ``out_f32`` -- bfloat16 ``value``, output rows written as float32 by the kernel (the float32 sums as they are, for a
+    float32 consumer: the decoder's output projection; shapes without such a kernel get the bfloat16 result cast here);
     ``host_shapes`` -- the values of ``spatial_shapes`` as a host list [(H, W), ...], which lets the library run its
     encoder-shape kernels (include/snipper_msda.h) without a device-to-host copy; ``config`` -- a ``_lib.Config``."""
     _check_common([("value", value), ("spatial_shapes", spatial_shapes),
@@ -139,10 +141,11 @@ def ms_deform_attn_forward(value: torch.Tensor, spatial_shapes: torch.Tensor,
     N, S, M, D, L, Lq, P = _dims(value, spatial_shapes, sampling_loc, attn_weight)
     lib = _lib.load()
     rows16 = out_bf16 and value.dtype == torch.float32
+    rows32 = out_f32 and value.dtype == torch.bfloat16
     dims = dict(N=N, S=S, M=M, D=D, L=L, Lq=Lq, P=P, esize=value.element_size(),
-                row_esize=2 if rows16 else value.element_size())
+                row_esize=2 if rows16 else (4 if rows32 else value.element_size()))
     _keep, hs_p = _host_shapes_ptr(host_shapes, L)
-    for out_dtype in ((torch.bfloat16, value.dtype) if rows16 else (value.dtype,)):
+    for out_dtype in ((torch.bfloat16, value.dtype) if rows16 else ((torch.float32, value.dtype) if rows32 else (value.dtype,))):
         out = torch.empty((N, Lq, M * D), dtype=out_dtype, device=value.device)
         with _lib.device_guard(value.device), _Timed("fwd", dims, value.device):
             rc = lib.snipper_msda_forward_ex(
@@ -153,6 +156,8 @@ def ms_deform_attn_forward(value: torch.Tensor, spatial_shapes: torch.Tensor,
             continue                                      # no bf16-row kernel for this shape: float32, cast below
         _lib.check(rc, "ms_deform_attn_forward")
         break
+    if rows32 and out.dtype != torch.float32:
+        return out.float()
     return out.to(torch.bfloat16) if (rows16 and out.dtype != torch.bfloat16) else out
 
 
@@ -176,26 +181,29 @@ def ms_deform_attn_backward(value: torch.Tensor, spatial_shapes: torch.Tensor,
     _require(sampling_loc.dtype == cd and attn_weight.dtype == cd,
              f"sampling_loc/attn_weight must be {cd} for {value.dtype} value")
     go_bf16 = grad_output.dtype == torch.bfloat16 and value.dtype == torch.float32      # extension: bf16 rows in
-    _require(grad_output.dtype == value.dtype or go_bf16, "grad_output dtype must match value")
+    go_f32 = grad_output.dtype == torch.float32 and value.dtype == torch.bfloat16       # extension: float32 rows beside a bf16 value
+    _require(grad_output.dtype == value.dtype or go_bf16 or go_f32, "grad_output dtype must match value")
     N, S, M, D, L, Lq, P = _dims(value, spatial_shapes, sampling_loc, attn_weight)
     _require(grad_output.numel() == N * Lq * M * D, "grad_output shape mismatch")
     lib = _lib.load()
-    if (value.dtype == torch.bfloat16 and grad_output.dtype == torch.bfloat16 and not grad_value_f32 and config is None and
-            Lq != S and D == 48 and Lq <= 64):
+    if (value.dtype == torch.bfloat16 and not grad_value_f32 and config is None and Lq != S and D == 48 and Lq <= 64):
         # few queries on a large bf16 value (the decoder's cross attention): grad_value without atomics, float32 buffer or
         # cast pass (csrc/msda_d48_sparse.cuh); any other shape answers E_UNSUPPORTED and takes the general entry below
         gv = torch.empty(value.shape, dtype=torch.bfloat16, device=value.device)
         gl, ga = torch.empty_like(sampling_loc), torch.empty_like(attn_weight)
-        dims_s = dict(N=N, S=S, M=M, D=D, L=L, Lq=Lq, P=P, esize=2, row_esize=2)
+        dims_s = dict(N=N, S=S, M=M, D=D, L=L, Lq=Lq, P=P, esize=2, row_esize=4 if go_f32 else 2)
+        entry = lib.snipper_msda_backward_sparse_f32rows if go_f32 else lib.snipper_msda_backward_sparse_bf16
         with _lib.device_guard(value.device), _Timed("bwd", dims_s, value.device):
-            rc = lib.snipper_msda_backward_sparse_bf16(
+            rc = entry(
                 _stream(value.device), grad_output.data_ptr(), value.data_ptr(), spatial_shapes.data_ptr(),
                 level_start_index.data_ptr(), sampling_loc.data_ptr(), attn_weight.data_ptr(), N, S, M, D, L, Lq, P,
                 gv.data_ptr(), gl.data_ptr(), ga.data_ptr())
         if rc == 0:
             return [gv, gl, ga]
         if rc != _lib.E_UNSUPPORTED:
-            _lib.check(rc, "snipper_msda_backward_sparse_bf16")
+            _lib.check(rc, "snipper_msda_backward_sparse")
+    if go_f32:
+        grad_output = grad_output.to(torch.bfloat16)         # (every other bf16-value kernel reads bf16 rows)
     acc_dtype = torch.float32 if value.dtype == torch.bfloat16 else value.dtype
     # grad_value is fully written by the callee, no pre-zeroing (include/snipper_msda.h, "Outputs")
     grad_value = torch.empty(value.shape, dtype=acc_dtype, device=value.device)

@@ -128,6 +128,12 @@ EXPORTS = {
     "snipper_heatmap_loss_forward_f32": ([c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 7 + [c_void_p, c_int], c_int),
     "snipper_heatmap_loss_backward_f32": ([c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 7 + [c_void_p, c_void_p], c_int),
     "snipper_msda_backward_sparse_bf16": ([c_void_p] * 7 + [c_int] * 7 + [c_void_p] * 3, c_int),
+    "snipper_msda_backward_sparse_f32rows": ([c_void_p] * 7 + [c_int] * 7 + [c_void_p] * 3, c_int),
+    "snipper_sum_f32": ([c_void_p, c_void_p, c_int, c_void_p, c_longlong], c_int),
+    "snipper_small_ln_forward_f32": ([c_void_p] * 6 + [c_int, c_int, ctypes.c_float, ctypes.c_float, ctypes.c_uint64] +
+                                     [c_void_p] * 6, c_int),
+    "snipper_small_ln_backward_f32": ([c_void_p] * 10 + [c_int, c_int, ctypes.c_float] + [c_void_p] * 4, c_int),
+    "snipper_refine_reference_linear_f32": ([c_void_p] * 6 + [c_int] * 4 + [ctypes.c_float, c_void_p, c_void_p], c_int),
     "snipper_relu_dropout_backward_bf16": ([c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, ctypes.c_float], c_int),
 }
 

@@ -25,6 +25,7 @@
 #include "small_attention.cuh"
 #include "match_cost.cuh"
 #include "ln_fused.cuh"
+#include "small_ln.cuh"
 #include "gn_tokens.cuh"
 #include "pair_losses.cuh"
 #include "heatmap_blur.cuh"
@@ -465,10 +466,11 @@ int snipper_msda_forward_ex(void *stream, const snipper_msda_config *cfg, const 
                                            (const double *)attn, d, (double *)out);
   }
   if (value_dtype == 1) {
-    if (out_dtype != 1) return SNIPPER_E_UNSUPPORTED;
-    if (d48_eligible<uint16_t>(d, c.policy))
+    if (out_dtype != 1 && out_dtype != 0) return SNIPPER_E_UNSUPPORTED;
+    if (d48_eligible<uint16_t>(d, c.policy))      // (out_dtype 0: float32 rows from a bf16 value -- the tuned kernels only)
       return forward_d48<uint16_t>(st, (const uint16_t *)value, shapes, level_start, (const float *)loc, (const float *)attn, d,
-                                   (uint16_t *)out);
+                                   (uint16_t *)out, out_dtype == 0);
+    if (out_dtype != 1) return SNIPPER_E_UNSUPPORTED;
     return forward_generic<uint16_t, float>(st, (const uint16_t *)value, shapes, level_start, (const float *)loc,
                                             (const float *)attn, d, (uint16_t *)out);
   }
@@ -560,25 +562,41 @@ int snipper_msda_backward_ex(void *stream, const snipper_msda_config *cfg, const
 // csrc/msda_d48_sparse.cuh.  grad_value [N][S][M][48] bf16 (fully written: zeroed here, touched pixels stored once),
 // grad_loc / grad_attn float32 from the tuned atomic kernel run without its atomics.  SNIPPER_E_UNSUPPORTED when the shape is
 // not this one (the caller then takes snipper_msda_backward_ex).
-int snipper_msda_backward_sparse_bf16(void *stream, const uint16_t *grad_out, const uint16_t *value, const int64_t *shapes,
-                                      const int64_t *level_start, const float *loc, const float *attn, int N, int S, int M, int D,
-                                      int L, int Lq, int P, uint16_t *grad_value, float *grad_loc, float *grad_attn) {
+namespace {
+int backward_sparse(void *stream, const void *grad_out, int go_f32, const uint16_t *value, const int64_t *shapes,
+                    const int64_t *level_start, const float *loc, const float *attn, int N, int S, int M, int D,
+                    int L, int Lq, int P, uint16_t *grad_value, float *grad_loc, float *grad_attn) {
   if (!grad_out || !value || !shapes || !level_start || !loc || !attn || !grad_value || !grad_loc || !grad_attn) return SNIPPER_E_NULL;
   if (int rc = check_dims(N, S, M, D, L, Lq, P)) return rc;
   const CoreDims d{N, S, M, D, L, Lq, P, 0};
   static const bool on = [] { const char *e = getenv("SNIPPER_MSDA_SPARSE"); return !(e && e[0] == '0'); }();
   if (!on || D != kSpD || Lq > kSpMaxLq || Lq * P * 4 > kSpTaps || L > kMaxLevelsFast || S >= (1 << 22) ||
-      !d48_eligible<float>(d, 0) || (long long)N * S * M * D * 2 >= (1LL << 31) || ((uintptr_t)grad_value & 15))
+      !d48_eligible<float>(d, 0) || (long long)N * S * M * D * 2 >= (1LL << 31) || ((uintptr_t)grad_value & 15) ||
+      ((uintptr_t)grad_out & 15))
     return SNIPPER_E_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   if (const hipError_t e = hipMemsetAsync(grad_value, 0, (size_t)N * S * M * D * 2, st); e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL(msda_bwd_d48_sparse_gv_kernel, dim3((unsigned)(N * M * L)), dim3(kSpTaps), 0, st, grad_out, shapes, level_start, loc, attn,
-                     d, grad_value);
+  hipLaunchKernelGGL(msda_bwd_d48_sparse_gv_kernel, dim3((unsigned)(N * M * L)), dim3(kSpTaps), 0, st, (const uint16_t *)grad_out, shapes,
+                     level_start, loc, attn, d, grad_value, go_f32);
   if (int rc = launch_status()) return rc;
   const int rc = backward_d48_f32_t<kD48, uint16_t>(st, (const float *)grad_out, value, shapes, level_start, loc, attn, d, nullptr,
-                                                    grad_loc, grad_attn, 1);
+                                                    grad_loc, grad_attn, go_f32 ? 0 : 1);
   if (rc == SNIPPER_OK) g_last_variant = "d48_sparse";
   return rc;
+}
+}  // namespace
+
+int snipper_msda_backward_sparse_bf16(void *stream, const uint16_t *grad_out, const uint16_t *value, const int64_t *shapes,
+                                      const int64_t *level_start, const float *loc, const float *attn, int N, int S, int M, int D,
+                                      int L, int Lq, int P, uint16_t *grad_value, float *grad_loc, float *grad_attn) {
+  return backward_sparse(stream, grad_out, 0, value, shapes, level_start, loc, attn, N, S, M, D, L, Lq, P, grad_value, grad_loc, grad_attn);
+}
+// the same with FLOAT32 grad_out rows (a float32 consumer of the sampled rows -- the decoder's output projection -- hands its
+// data gradient over as it is: no bf16 cast launch in front of this call)
+int snipper_msda_backward_sparse_f32rows(void *stream, const float *grad_out, const uint16_t *value, const int64_t *shapes,
+                                         const int64_t *level_start, const float *loc, const float *attn, int N, int S, int M, int D,
+                                         int L, int Lq, int P, uint16_t *grad_value, float *grad_loc, float *grad_attn) {
+  return backward_sparse(stream, grad_out, 1, value, shapes, level_start, loc, attn, N, S, M, D, L, Lq, P, grad_value, grad_loc, grad_attn);
 }
 
 // ---- the reference launchers' one-for-one replacements (default configuration, level shapes on the device only) ----
@@ -1234,6 +1252,59 @@ int snipper_add_dropout_layernorm_backward(void *stream, const float *g32, const
   }
   hipLaunchKernelGGL(ln_param_grad_kernel, dim3((2 * C + kLnPgCh - 1) / kLnPgCh), dim3(256), 0, (hipStream_t)stream,
                      (const float *)workspace, blocks, C, dgamma, dbeta);
+  return launch_status();
+}
+
+// ---- decoder-size residual + dropout + LayerNorm chain (csrc/small_ln.cuh) ----
+int snipper_small_ln_forward_f32(void *stream, const float *x, const float *z, const float *pos, const float *gamma, const float *beta,
+                                 int rows, int C, float p, float eps, uint64_t seed, float *s_save, float *mean, float *rstd,
+                                 uint8_t *keep, float *y, float *yq) {
+  if (!x || !gamma || !beta || !y) return SNIPPER_E_NULL;
+  if ((yq && !pos) || ((mean == nullptr) != (rstd == nullptr))) return SNIPPER_E_NULL;
+  if (rows <= 0 || rows > kSmallLnMaxRows || C <= 0 || C % 4 || C > kLnMaxIter * 256 || !(p >= 0.f && p < 1.f)) return SNIPPER_E_SHAPE;
+  if (((uintptr_t)x | (uintptr_t)z | (uintptr_t)pos | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)s_save | (uintptr_t)y | (uintptr_t)yq) & 15)
+    return SNIPPER_E_SHAPE;
+  const SmallLnFwdArgs a{x, z, pos, gamma, beta, s_save, mean, rstd, (z && p > 0.f) ? keep : nullptr, y, yq, rows, C, z ? p : 0.f, eps,
+                         (uint32_t)seed, (uint32_t)(seed >> 32)};
+  hipLaunchKernelGGL(small_ln_fwd_kernel, dim3((rows + 3) / 4), dim3(kLnThreads), 0, (hipStream_t)stream, a);
+  return launch_status();
+}
+
+int snipper_small_ln_backward_f32(void *stream, const float *g0, const float *g1, const float *g2, const float *g3,
+                                  const float *s_save, const float *mean, const float *rstd, const float *gamma, const uint8_t *keep,
+                                  int rows, int C, float p, float *dx, float *dz, float *dgamma, float *dbeta) {
+  if (!s_save || !mean || !rstd || !gamma || !dgamma || !dbeta || (!g0 && !g1 && !g2 && !g3)) return SNIPPER_E_NULL;
+  if (rows <= 0 || rows > kSmallLnMaxRows || C <= 0 || C % 4 || C > kLnMaxIter * 256 || !(p >= 0.f && p < 1.f)) return SNIPPER_E_SHAPE;
+  if (((uintptr_t)g0 | (uintptr_t)g1 | (uintptr_t)g2 | (uintptr_t)g3 | (uintptr_t)s_save | (uintptr_t)gamma | (uintptr_t)dx | (uintptr_t)dz) & 15)
+    return SNIPPER_E_SHAPE;
+  const int row_blocks = (rows + 3) / 4, col_blocks = (C + kSmallLnColsPerWg - 1) / kSmallLnColsPerWg;
+  const SmallLnBwdArgs a{{g0, g1, g2, g3}, s_save, mean, rstd, gamma, p > 0.f ? keep : nullptr, dx, dz, dgamma, dbeta, rows, C,
+                         row_blocks, p};
+  hipLaunchKernelGGL(small_ln_bwd_kernel, dim3(row_blocks + col_blocks), dim3(kLnThreads), 0, (hipStream_t)stream, a);
+  return launch_status();
+}
+
+int snipper_sum_f32(void *stream, const float *const *srcs, int n_src, float *out, long long numel) {
+  if (!srcs || !out) return SNIPPER_E_NULL;
+  if (n_src <= 0 || n_src > kSumF32MaxSrc || numel <= 0 || numel % 4 || ((uintptr_t)out % 16)) return SNIPPER_E_SHAPE;
+  SumF32Srcs a{};
+  a.n = n_src;
+  for (int i = 0; i < n_src; ++i) {
+    if (!srcs[i] || ((uintptr_t)srcs[i] % 16)) return srcs[i] ? SNIPPER_E_SHAPE : SNIPPER_E_NULL;
+    a.p[i] = srcs[i];
+  }
+  const long long n4 = numel / 4;
+  hipLaunchKernelGGL(sum_f32_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, out, n4);
+  return launch_status();
+}
+
+int snipper_refine_reference_linear_f32(void *stream, const float *x, const float *W, const float *b, const float *ref,
+                                        const float *valid_ratios, int rows, int C, int rows_per_batch, int L, float eps,
+                                        float *new_ref, float *ref_in) {
+  if (!x || !W || !ref || !valid_ratios || !new_ref || !ref_in) return SNIPPER_E_NULL;
+  if (rows <= 0 || C <= 0 || C % 4 || rows_per_batch <= 0 || L <= 0 || (((uintptr_t)x | (uintptr_t)W) & 15)) return SNIPPER_E_SHAPE;
+  hipLaunchKernelGGL(refine_reference_linear_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, W, b, ref, valid_ratios,
+                     rows, C, rows_per_batch, L, eps, new_ref, ref_in);
   return launch_status();
 }
 

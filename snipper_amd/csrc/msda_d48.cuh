@@ -107,8 +107,8 @@ __global__ __launch_bounds__(kD48Block) void msda_fwd_d48_kernel(
     const VT *__restrict__ value, const int64_t *__restrict__ shapes,
     const int64_t *__restrict__ level_start, const float *__restrict__ loc,
     const float *__restrict__ attn, CoreDims d, VT *__restrict__ out, int nblk_padded, int out_bf16) {
-  // out_bf16 (float kernel only): `out` holds bfloat16 rows -- the consumer (the output projection) rounds to bf16
-  // anyway, so writing it here saves the cast pass and half the store traffic without changing any result
+  // out_bf16 = "rows of the other type": float kernel -- `out` holds bfloat16 rows (the consumer, the output projection,
+  // rounds to bf16 anyway: no cast pass, half the store traffic, same results); bf16 kernel -- `out` holds float32 rows
   using TR = D48Fwd<VT>;
   constexpr int G = TR::G * DT / kD48, CPL = TR::CPL, kRows = kD48Block / G;
   __shared__ LevelTable lv;
@@ -180,6 +180,14 @@ __global__ __launch_bounds__(kD48Block) void msda_fwd_d48_kernel(
     if (out_bf16) {
       uint16_t *o16 = reinterpret_cast<uint16_t *>(out) + (size_t)row * DT + lane * 3;
       o16[0] = f32_to_bf16_bits(acc[0]); o16[1] = f32_to_bf16_bits(acc[1]); o16[2] = f32_to_bf16_bits(acc[2]);
+      return;
+    }
+  } else {
+    if (out_bf16) {        // bf16 kernel: the flag means the OTHER row type -- float32 rows (the decoder's cross attention: a bf16
+      // value projection sampled for float32 queries; the float32 sums are stored as they are, no bf16 rounding + cast pass)
+      float *o32 = reinterpret_cast<float *>(out) + (size_t)row * DT + lane * CPL;
+#pragma unroll
+      for (int c = 0; c < CPL; c += 2) *reinterpret_cast<float2 *>(o32 + c) = make_float2(acc[c], acc[c + 1]);
       return;
     }
   }

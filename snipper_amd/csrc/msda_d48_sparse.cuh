@@ -29,10 +29,11 @@ namespace snipper {
 constexpr int kSpTaps = 1024, kSpMaxLq = 64, kSpD = 48, kSpC4 = kSpD / 4;
 
 __global__ __launch_bounds__(kSpTaps) void msda_bwd_d48_sparse_gv_kernel(
-    const uint16_t *__restrict__ grad_out,      // [N][Lq][M][48] bf16
+    const uint16_t *__restrict__ grad_out,      // [N][Lq][M][48] bf16, or float32 (go_f32)
     const int64_t *__restrict__ shapes, const int64_t *__restrict__ level_start,
     const float *__restrict__ loc, const float *__restrict__ attn, CoreDims d,
-    uint16_t *__restrict__ grad_value) {        // [N][S][M][48] bf16, zeroed
+    uint16_t *__restrict__ grad_value,          // [N][S][M][48] bf16, zeroed
+    int go_f32) {
   __shared__ __attribute__((aligned(16))) float g[kSpMaxLq * kSpD];
   __shared__ unsigned keys[kSpTaps + 1];
   __shared__ float wa[kSpTaps];                 // weight * attention by TAP, then (ws) by sorted position
@@ -46,8 +47,14 @@ __global__ __launch_bounds__(kSpTaps) void msda_bwd_d48_sparse_gv_kernel(
   const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1], start = (int)level_start[l];
   const int ntap = d.Lq * d.P * 4, P4 = d.P * 4;
 
-  // ---- grad_out rows of this (sample, head): 16-byte pieces, 6 per row
-  if (tid < d.Lq * 6) {
+  // ---- grad_out rows of this (sample, head): 16-byte pieces -- 6 per bf16 row, 12 per float32 row (go_f32)
+  if (go_f32) {
+    if (tid < d.Lq * kSpC4) {
+      const int q = tid / kSpC4, c4 = tid - q * kSpC4;
+      reinterpret_cast<float4 *>(g)[tid] = *reinterpret_cast<const float4 *>(
+          reinterpret_cast<const float *>(grad_out) + (((size_t)n * d.Lq + q) * d.M + m) * kSpD + c4 * 4);
+    }
+  } else if (tid < d.Lq * 6) {
     const int q = tid / 6, c8 = tid - q * 6;
     const uint4 raw = *reinterpret_cast<const uint4 *>(grad_out + (((size_t)n * d.Lq + q) * d.M + m) * kSpD + c8 * 8);
     float4 lo, hi;

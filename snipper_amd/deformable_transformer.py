@@ -39,11 +39,29 @@ def _refine_reference(head, out, reference_points, valid_ratios):
         return None
     from . import _lib
     with torch.no_grad():
-        tmp = head(out)
         bs, t, lq = reference_points.shape[:3]
+        lin = _single_linear(head)
+        L = valid_ratios.shape[1]
+        if (lin is not None and lin.out_features >= 2 and lin.weight.dtype == torch.float32 and lin.weight.is_contiguous() and
+                out.is_contiguous() and out.shape[-1] % 4 == 0 and out.numel() // out.shape[-1] == bs * t * lq and
+                out.data_ptr() % 16 == 0 and lin.weight.data_ptr() % 16 == 0 and
+                (lin.bias is None or lin.bias.dtype == torch.float32)):
+            # the head is ONE Linear (the reference's MLP(hidden, hidden, 4, 1), models/model.py:95) and only its first two
+            # outputs are used here: two dot products per row inside the refinement launch (csrc/small_ln.cuh)
+            ref = reference_points.contiguous()
+            vr = valid_ratios.contiguous()
+            new_ref = torch.empty_like(ref)
+            ref_in = torch.empty((bs, t, lq, L, 2), dtype=torch.float32, device=out.device)
+            with _lib.device_guard(out.device):
+                rc = _lib.load().snipper_refine_reference_linear_f32(
+                    _lib.raw_stream(out.device), out.data_ptr(), lin.weight.data_ptr(),
+                    lin.bias.data_ptr() if lin.bias is not None else None, ref.data_ptr(), vr.data_ptr(), bs * t * lq,
+                    out.shape[-1], t * lq, L, 1e-5, new_ref.data_ptr(), ref_in.data_ptr())
+            _lib.check(rc, "snipper_refine_reference_linear_f32")
+            return new_ref, ref_in
+        tmp = head(out)
         if tmp.dtype != torch.float32 or tmp.shape[:3] != (bs, t, lq) or tmp.stride(-1) != 1 or not tmp.is_contiguous():
             return None
-        L = valid_ratios.shape[1]
         ref = reference_points.contiguous()
         vr = valid_ratios.contiguous()
         new_ref = torch.empty_like(ref)
@@ -54,6 +72,16 @@ def _refine_reference(head, out, reference_points, valid_ratios):
                                                           new_ref.data_ptr(), ref_in.data_ptr())
         _lib.check(rc, "snipper_refine_reference_f32")
     return new_ref, ref_in
+
+
+def _single_linear(head):
+    """The nn.Linear a head consists of (an nn.Linear, or an MLP-like module whose ``layers`` hold exactly one), else None."""
+    if isinstance(head, nn.Linear):
+        return head
+    layers = getattr(head, "layers", None)
+    if layers is not None and len(layers) == 1 and isinstance(layers[0], nn.Linear):
+        return layers[0]
+    return None
 
 
 from .misc import BoundedCache  # noqa: E402
@@ -445,6 +473,57 @@ class DeformableTransformerDecoderLayer(nn.Module, _FFNMixin):
         return self.forward_ffn(tgt), atten_data
 
 
+    # -- round 6: the layer as a chain without element-wise launches ------------------------------------------------------
+    chain = __import__("os").environ.get("SNIPPER_DEC_CHAIN", "1") != "0"      # (A/B aid: 0 = the node-per-module form above)
+
+    def chain_ok(self, tgt) -> bool:
+        """Can ``forward_chain`` run?  Float32 CUDA rows outside autocast, the fused decoder-size kernels for every piece
+        (csrc/small_ln.cuh, small_linear.cuh, small_attention.cuh), ReLU feed-forward."""
+        from .fused import small_ln_ok
+        mha = self.self_attn
+        c = tgt.shape[-1]
+        probe = tgt.reshape(-1, c)
+        return (self.chain and tgt.is_cuda and tgt.dtype == torch.float32 and not torch.is_autocast_enabled('cuda') and
+                torch.is_grad_enabled() and self.activation is F.relu and
+                all(small_ln_ok(probe, n) for n in (self.norm1, self.norm2, self.norm3)) and
+                all(isinstance(d, nn.Dropout) for d in (self.dropout1, self.dropout2, self.dropout3, self.dropout4)) and
+                mha._qkv_same_embed_dim and mha.in_proj_bias is not None and mha.bias_k is None and not mha.add_zero_attn and
+                not mha.batch_first and mha.out_proj.bias is not None and c // mha.num_heads in (32, 48) and
+                mha.in_proj_weight.dtype == torch.float32 and 16 <= probe.shape[0])
+
+    def forward_chain(self, state, pos_a, pos_b, reference_points, src, src_spatial_shapes, level_start_index,
+                      src_padding_mask, amp_dtype, shape, last: bool):
+        """One decoder layer (reference :276-300) on ``state = (x_v, x_res, x_q)``: three handles of the layer input -- the
+        value input of the self-attention, the residual of norm2, and input + query_pos (the q / k input) -- all [bs, T * nq, C]
+        float32.  ``pos_a`` / ``pos_b``: this layer's two aliases of query_pos (fused.FanOut).  Returns (next state or None,
+        layer output [bs, T, nq, C], attention data).  Every residual + dropout + LayerNorm is ONE launch that also writes the
+        position-added copy the next projection wants (fused.SmallLayerNorm); no ``with_pos_embed`` add, no gradient-accumulation
+        add in the backward (every consumer of a LayerNorm output holds its own alias)."""
+        from .dense import _SmallLinear, small_ffn
+        from .fused import small_layer_norm
+        bs, t, lq, c = shape
+        x_v, x_res, x_q = state
+        mha = self.self_attn
+        if x_q.shape[1] > SMALL_ATTENTION_MAX_L:
+            return None
+        qk, v = _QKVProj.apply(x_q, x_v, mha.in_proj_weight, mha.in_proj_bias)
+        att = _SmallAttention.apply(qk.contiguous(), v.contiguous(), mha.num_heads, mha.dropout if mha.training else 0.0)
+        mixed = _SmallLinear.apply(att, mha.out_proj.weight, mha.out_proj.bias)
+        t2_res, t2_q = small_layer_norm(x_res, mixed, self.norm2, self.dropout2.p, self.training, pos=pos_a, n_alias=1)
+        attended, atten_data = self._cross(amp_dtype, t2_q.view(bs, t, lq, c), reference_points, src, src_spatial_shapes,
+                                           level_start_index, src_padding_mask)
+        t3_ffn, t3_res = small_layer_norm(t2_res, attended.reshape(bs, t * lq, c), self.norm1, self.dropout1.p, self.training,
+                                          n_alias=2)
+        y = small_ffn(t3_ffn, self.linear1, self.linear2, self.dropout3)
+        if y is None:
+            y = self.linear2(self.dropout3(F.relu(self.linear1(t3_ffn))))
+        if last:
+            (out,) = small_layer_norm(t3_res, y, self.norm3, self.dropout4.p, self.training, n_alias=1)
+            return None, out.view(bs, t, lq, c), atten_data
+        n_v, n_res, out, n_q = small_layer_norm(t3_res, y, self.norm3, self.dropout4.p, self.training, pos=pos_b, n_alias=3)
+        return (n_v, n_res, n_q), out.view(bs, t, lq, c), atten_data
+
+
 class DeformableTransformerDecoder(nn.Module):
     def __init__(self, decoder_layer, num_layers, return_intermediate=False):
         super().__init__()
@@ -510,11 +589,30 @@ class DeformableTransformerDecoder(nn.Module):
                 else:
                     s_l._snipper_bf16 = alias
                 srcs.append(s_l)
+        # round 6: the layers as ONE chain of fused launches (DeformableTransformerDecoderLayer.forward_chain) when every layer
+        # can: the layer input travels as three handles, query_pos as one alias per use (summed by one launch in the backward)
+        state = pos_aliases = None
+        n_l = len(self.layers)
+        if (query_pos is not None and out.dim() == 4 and query_pos.shape == out.shape and
+                all(hasattr(l, "chain_ok") and l.chain_ok(out) for l in self.layers) and
+                out.shape[1] * out.shape[2] <= SMALL_ATTENTION_MAX_L):
+            from .fused import FanOut
+            bs_, t_, lq_, c_ = out.shape
+            flat = out.reshape(bs_, t_ * lq_, c_).contiguous()
+            pos_flat = query_pos.reshape(bs_, t_ * lq_, c_).contiguous()
+            pos_aliases = list(FanOut.apply(pos_flat, 2 * n_l)) if pos_flat.requires_grad else [pos_flat] * (2 * n_l)
+            state = (flat, flat, flat + pos_aliases[0])
         for lid, layer in enumerate(self.layers):
             if ref_in is None:
                 ref_in = reference_points[:, :, :, None, :] * src_valid_ratios[:, None, None, :, :]
-            out, atten_data = layer(out, query_pos, ref_in, srcs[lid], src_spatial_shapes,
-                                    src_level_start_index, src_padding_mask, cross_amp_dtype=amp_dtype)
+            if state is not None:
+                got = layer.forward_chain(state, pos_aliases[2 * lid + 1], pos_aliases[(2 * lid + 2) % (2 * n_l)], ref_in,
+                                          srcs[lid], src_spatial_shapes, src_level_start_index, src_padding_mask, amp_dtype,
+                                          tuple(out.shape), last=lid + 1 == n_l)
+                state, out, atten_data = got
+            else:
+                out, atten_data = layer(out, query_pos, ref_in, srcs[lid], src_spatial_shapes,
+                                        src_level_start_index, src_padding_mask, cross_amp_dtype=amp_dtype)
             ref_in = None
             if self.root_embed is not None:   # iterative refinement of the reference points (:329-333)
                 fused = _refine_reference(self.root_embed[lid], out, reference_points, src_valid_ratios)

@@ -547,10 +547,11 @@ class LevelPosTokens(Function):
 
 
 class FanOut(Function):
-    """``n`` aliases of a bf16 tensor, one per consumer; backward = ONE pass that sums the consumers' gradients with float32
-    accumulation (csrc/misc_kernels.cuh) instead of autograd's n - 1 pairwise bf16 adds.  The encoder memory's bf16 twin
-    feeds the value projection of every decoder layer (reference models/deformable_transformer.py:290-295): six
-    [b, T, S, C] gradients per step."""
+    """``n`` aliases of a tensor, one per consumer; backward = ONE pass that sums the consumers' gradients with float32
+    accumulation (csrc/misc_kernels.cuh, csrc/small_ln.cuh) instead of autograd's n - 1 pairwise adds.  bf16: the encoder
+    memory's twin feeds the value projection of every decoder layer (reference models/deformable_transformer.py:290-295): six
+    [b, T, S, C] gradients per step.  float32 (round 6): ``query_pos`` is added in front of two projections per decoder layer
+    (:252-254): twelve [b, T * queries, C] gradients per step."""
 
     @staticmethod
     def forward(ctx, x, n):
@@ -562,16 +563,110 @@ class FanOut(Function):
         gs = [g for g in gs if g is not None]
         if len(gs) == 1:
             return gs[0], None
-        ok = all(g.is_cuda and g.dtype == torch.bfloat16 and g.shape == gs[0].shape for g in gs) and gs[0].numel() % 8 == 0
-        if not ok or len(gs) > 8:
-            tot = gs[0]
-            for g in gs[1:]:
-                tot = tot + g
-            return tot, None
-        gs = [g.contiguous() for g in gs]
-        out = torch.empty_like(gs[0])
-        srcs = (ctypes.c_void_p * len(gs))(*[g.data_ptr() for g in gs])
-        with _lib.device_guard(out.device):
-            rc = _lib.load().snipper_sum_bf16(_stream(out.device), srcs, len(gs), out.data_ptr(), out.numel())
-        _lib.check(rc, "snipper_sum_bf16")
-        return out, None
+        same = all(g.is_cuda and g.dtype == gs[0].dtype and g.shape == gs[0].shape for g in gs)
+        if same and gs[0].dtype == torch.bfloat16 and gs[0].numel() % 8 == 0 and len(gs) <= 8:
+            gs = [g.contiguous() for g in gs]
+            out = torch.empty_like(gs[0])
+            srcs = (ctypes.c_void_p * len(gs))(*[g.data_ptr() for g in gs])
+            with _lib.device_guard(out.device):
+                rc = _lib.load().snipper_sum_bf16(_stream(out.device), srcs, len(gs), out.data_ptr(), out.numel())
+            _lib.check(rc, "snipper_sum_bf16")
+            return out, None
+        if same and gs[0].dtype == torch.float32 and gs[0].numel() % 4 == 0 and len(gs) <= 16:
+            gs = [g.contiguous() for g in gs]
+            if all(g.data_ptr() % 16 == 0 for g in gs):
+                out = torch.empty_like(gs[0])
+                srcs = (ctypes.c_void_p * len(gs))(*[g.data_ptr() for g in gs])
+                with _lib.device_guard(out.device):
+                    rc = _lib.load().snipper_sum_f32(_stream(out.device), srcs, len(gs), out.data_ptr(), out.numel())
+                _lib.check(rc, "snipper_sum_f32")
+                return out, None
+        tot = gs[0]
+        for g in gs[1:]:
+            tot = tot + g
+        return tot, None
+
+
+class SmallLayerNorm(Function):
+    """``LayerNorm(x + dropout_p(z))`` for decoder-size float32 rows as one launch each way (csrc/small_ln.cuh; reference
+    models/deformable_transformer.py:266-300), with what keeps the decoder's chain free of element-wise launches:
+
+    * ``n_alias`` aliases of the result, one per consumer, and -- with ``pos`` -- ``yq = y + pos`` (the reference's
+      ``with_pos_embed``, :252-254) from the same launch;
+    * the backward takes every consumer's gradient on its own edge and sums them in registers (up to four), and writes
+      dgamma / dbeta itself (no second kernel).
+
+    apply(x, z, pos, gamma, beta, p, eps, n_alias, want_q) -> (alias_1, ..., alias_n[, yq])"""
+
+    @staticmethod
+    def forward(ctx, x, z, pos, gamma, beta, p, eps, n_alias, want_q):
+        x = x.contiguous()
+        z = z.contiguous() if z is not None else None
+        pos = pos.contiguous() if (pos is not None and want_q) else None
+        C = x.shape[-1]
+        rows = x.numel() // C
+        dev = x.device
+        p = float(p) if z is not None else 0.0
+        need_bwd = any(ctx.needs_input_grad[:5])
+        s_save = torch.empty((rows, C), dtype=torch.float32, device=dev) if need_bwd else None
+        stats = torch.empty((2, rows), dtype=torch.float32, device=dev) if need_bwd else None
+        keep = torch.empty((rows, C // 4), dtype=torch.uint8, device=dev) if (need_bwd and p > 0) else None
+        y = torch.empty(x.shape, dtype=torch.float32, device=dev)
+        yq = torch.empty(x.shape, dtype=torch.float32, device=dev) if pos is not None else None
+        ptr = lambda t: t.data_ptr() if t is not None else None
+        with _lib.device_guard(dev):
+            rc = _lib.load().snipper_small_ln_forward_f32(
+                _stream(dev), x.data_ptr(), ptr(z), ptr(pos), gamma.data_ptr(), beta.data_ptr(), rows, C, p, float(eps),
+                _next_seed() if p > 0 else 0, ptr(s_save), stats[0].data_ptr() if stats is not None else None,
+                stats[1].data_ptr() if stats is not None else None, ptr(keep), y.data_ptr(), ptr(yq))
+        _lib.check(rc, "snipper_small_ln_forward_f32")
+        ctx.meta = (p, x.shape, z is not None, pos is not None, n_alias)
+        ctx.save_for_backward(s_save, stats, keep, gamma)
+        outs = tuple(y.view_as(y) for _ in range(n_alias))
+        return outs + ((yq,) if yq is not None else ())
+
+    @staticmethod
+    def backward(ctx, *gs):
+        s_save, stats, keep, gamma = ctx.saved_tensors
+        p, shape, has_z, has_pos, n_alias = ctx.meta
+        rows, C = s_save.shape
+        dev = s_save.device
+        gq = gs[n_alias] if has_pos else None
+        live = [g.contiguous() for g in gs if g is not None]
+        if not live:
+            return (None,) * 9
+        if any(g.dtype != torch.float32 for g in live):
+            live = [g.float() for g in live]
+        while len(live) > 4:                        # (more consumers than the kernel has sources: fold the extras first)
+            live = live[:3] + [sum(live[3:])]
+        dx = torch.empty(shape, dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
+        dz = torch.empty(shape, dtype=torch.float32, device=dev) if (has_z and ctx.needs_input_grad[1]) else None
+        dgb = torch.empty((2, C), dtype=torch.float32, device=dev)
+        g4 = [g.data_ptr() for g in live] + [None] * (4 - len(live))
+        ptr = lambda t: t.data_ptr() if t is not None else None
+        with _lib.device_guard(dev):
+            rc = _lib.load().snipper_small_ln_backward_f32(
+                _stream(dev), g4[0], g4[1], g4[2], g4[3], s_save.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(),
+                gamma.data_ptr(), ptr(keep), rows, C, p, ptr(dx), ptr(dz), dgb[0].data_ptr(), dgb[1].data_ptr())
+        _lib.check(rc, "snipper_small_ln_backward_f32")
+        dpos = gq if (has_pos and ctx.needs_input_grad[2]) else None
+        return (dx, dz, dpos, dgb[0] if ctx.needs_input_grad[3] else None, dgb[1] if ctx.needs_input_grad[4] else None,
+                None, None, None, None)
+
+
+SMALL_LN_MAX_ROWS = 16384      # csrc/small_ln.cuh: kSmallLnMaxRows
+
+
+def small_ln_ok(x: torch.Tensor, norm: torch.nn.LayerNorm) -> bool:
+    """Float32 CUDA rows outside autocast, few enough for the decoder-size kernels, an affine float32 LayerNorm over C."""
+    C = x.shape[-1]
+    return (x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled('cuda') and
+            isinstance(norm, torch.nn.LayerNorm) and norm.elementwise_affine and norm.bias is not None and
+            norm.weight.dtype == torch.float32 and norm.weight.is_contiguous() and norm.bias.is_contiguous() and
+            tuple(norm.normalized_shape) == (C,) and C % 4 == 0 and C <= 1024 and 0 < x.numel() // C <= SMALL_LN_MAX_ROWS)
+
+
+def small_layer_norm(x, z, norm: torch.nn.LayerNorm, p: float, training: bool, pos=None, n_alias: int = 1):
+    """``norm(x + dropout(z, p, training))`` on the decoder-size kernel -> (alias_1, ..., alias_n[, y + pos]).  The caller checks
+    ``small_ln_ok`` first."""
+    return SmallLayerNorm.apply(x, z, pos, norm.weight, norm.bias, p if training else 0.0, norm.eps, n_alias, pos is not None)

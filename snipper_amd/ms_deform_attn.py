@@ -295,8 +295,10 @@ class MSDeformAttn(nn.Module):
             loc, prob = MSDAPrologue.apply(big_linear(query, self.sampling_offsets[0]), big_linear(query, self.attention_weights[0]),
                                            ref.expand(N, T1, Lq, L, 2), hw, M, L, P)
         loc, prob = loc.view(N, T1, Lq, M, L, P, 2), prob.view(N, T1, Lq, M, L, P)
+        # (float32 queries beside the bf16 projection -- the decoder under bf16 autocast: the kernels write / read float32 rows)
         out = MSDeformAttnFunction.apply(value.reshape(N * T1, S, M, C // M), shapes, lsi,
-                                         loc.reshape(N * T1, Lq, M, L, P, 2), prob.reshape(N * T1, Lq, M, L, P), self.im2col_step)
+                                         loc.reshape(N * T1, Lq, M, L, P, 2), prob.reshape(N * T1, Lq, M, L, P), self.im2col_step,
+                                         False, query.dtype == torch.float32 and value.dtype == torch.bfloat16)
         if out.dtype != query.dtype:
             out = out.to(query.dtype)
         groups = [frame_neighbours(t1, self.n_frame, T1) for t1 in range(T1)]

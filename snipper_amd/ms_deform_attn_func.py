@@ -22,16 +22,19 @@ from . import MultiScaleDeformableAttention as MSDA
 
 class MSDeformAttnFunction(Function):
     """apply(value, spatial_shapes, level_start_index, sampling_locations, attention_weights, im2col_step
-             [, rows_bf16=False])
+             [, rows_bf16=False[, rows_f32=False]])
 
     ``rows_bf16`` (extension, float32 ``value`` only): the output is produced, and its gradient consumed, as bfloat16
-    rows by the kernels themselves -- for callers whose neighbouring projections compute in bf16."""
+    rows by the kernels themselves -- for callers whose neighbouring projections compute in bf16.  ``rows_f32`` (extension,
+    bfloat16 ``value`` only): float32 output rows and a float32 gradient for them -- a float32 consumer beside a bf16 value
+    (the decoder's cross attention under bf16 autocast), no cast launch either way."""
 
     @staticmethod
     def forward(ctx, value, value_spatial_shapes, value_level_start_index,
-                sampling_locations, attention_weights, im2col_step, rows_bf16=False):
+                sampling_locations, attention_weights, im2col_step, rows_bf16=False, rows_f32=False):
         ctx.im2col_step = im2col_step
         ctx.rows_bf16 = bool(rows_bf16) and value.dtype == torch.float32
+        ctx.rows_f32 = bool(rows_f32) and value.dtype == torch.bfloat16
         # host copy of the level shapes, when our transformer attached one (spares a device sync)
         ctx.host_shapes = getattr(value_spatial_shapes, "_snipper_host", None)
         if value.dtype == torch.bfloat16:   # coordinates and weights stay fp32 beside bf16 values
@@ -39,7 +42,7 @@ class MSDeformAttnFunction(Function):
             attention_weights = attention_weights.float()
         out = MSDA.ms_deform_attn_forward(value, value_spatial_shapes, value_level_start_index, sampling_locations,
                                           attention_weights, im2col_step, out_bf16=ctx.rows_bf16,
-                                          host_shapes=ctx.host_shapes)
+                                          host_shapes=ctx.host_shapes, out_f32=ctx.rows_f32)
         ctx.save_for_backward(value, value_spatial_shapes, value_level_start_index,
                               sampling_locations, attention_weights)
         return out
@@ -49,11 +52,12 @@ class MSDeformAttnFunction(Function):
     def backward(ctx, grad_output):
         value, shapes, lsi, loc, attn = ctx.saved_tensors
         grad_output = grad_output.contiguous()
-        if grad_output.dtype != value.dtype and not (ctx.rows_bf16 and grad_output.dtype == torch.bfloat16):
+        if grad_output.dtype != value.dtype and not (ctx.rows_bf16 and grad_output.dtype == torch.bfloat16) and \
+                not (ctx.rows_f32 and grad_output.dtype == torch.float32):
             grad_output = grad_output.to(value.dtype)
         grad_value, grad_loc, grad_attn = MSDA.ms_deform_attn_backward(
             value, shapes, lsi, loc, attn, grad_output, ctx.im2col_step, host_shapes=ctx.host_shapes)
-        return grad_value, None, None, grad_loc, grad_attn, None, None   # reference :42
+        return grad_value, None, None, grad_loc, grad_attn, None, None, None   # reference :42
 
 
 def ms_deform_attn_core_pytorch(value, value_spatial_shapes, sampling_locations, attention_weights):
