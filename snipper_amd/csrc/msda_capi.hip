@@ -973,9 +973,16 @@ int snipper_small_attention_backward_f32(void *stream, const float *q, long long
   a.dk = dk; a.dk_ld = dk_ld; a.dk_bs = dk_bs; a.dv = dv; a.dv_ld = dv_ld; a.dv_bs = dv_bs;
   a.bs = bs; a.H = H; a.L = L; a.scale = scale; a.drop_p = dropout_p;
   a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32);
-  const dim3 grid((unsigned)(bs * H * 2 * ((L + kSaRows - 1) / kSaRows)));
-  if (hd == 48) hipLaunchKernelGGL(small_attn_bwd_kernel<48>, grid, dim3(kSaThreads), 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL(small_attn_bwd_kernel<32>, grid, dim3(kSaThreads), 0, (hipStream_t)stream, a);
+  // 16 rows per workgroup while that is one residency round (one 140-KB workgroup per CU), 32 rows (512 threads) beyond: at the
+  // decoder's L = 240 the 480 sixteen-row workgroups were two rounds (csrc/small_attention.cuh)
+  static const int forced_rows = [] { const char *e = getenv("SNIPPER_SMALL_ATTN_ROWS"); return e ? atoi(e) : 0; }();      // (A/B aid)
+  const int wg16 = bs * H * 2 * ((L + 15) / 16);
+  const int rows = forced_rows == 16 || forced_rows == 32 ? forced_rows : (wg16 > device_cu_count() ? 32 : 16);
+  const dim3 grid((unsigned)(bs * H * 2 * ((L + rows - 1) / rows)));
+  if (hd == 48 && rows == 32) hipLaunchKernelGGL((small_attn_bwd_kernel<48, 32>), grid, dim3(512), 0, (hipStream_t)stream, a);
+  else if (hd == 48) hipLaunchKernelGGL((small_attn_bwd_kernel<48, 16>), grid, dim3(256), 0, (hipStream_t)stream, a);
+  else if (rows == 32) hipLaunchKernelGGL((small_attn_bwd_kernel<32, 32>), grid, dim3(512), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((small_attn_bwd_kernel<32, 16>), grid, dim3(256), 0, (hipStream_t)stream, a);
   return launch_status();
 }
 

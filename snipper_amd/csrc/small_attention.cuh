@@ -68,8 +68,9 @@ template <int HD> struct SaLds {
 
 // rows [0, L) of a strided [L][HD] matrix -> LDS rows of kPad floats
 // (rows [L, round-up-to-4 of L) are zeroed: the combination loops below walk the rows four at a time)
-template <int HD>
+template <int HD, int THREADS = kSaThreads>
 __device__ __forceinline__ void sa_stage(float *dst, const float *src, long long ld, int L, int tid) {
+  constexpr int kSaThreads = THREADS;
   constexpr int kPad = HD + 4, kV = HD / 4, kIter = (kSaMaxL * kV + kSaThreads - 1) / kSaThreads;
   const int L4 = (L + 3) & ~3;
   float4 t[kIter];
@@ -164,25 +165,38 @@ __global__ __launch_bounds__(kSaThreads) void small_attn_fwd_kernel(SmallAttnArg
     *reinterpret_cast<float4 *>(g.out + b * g.o_bs + (long long)i * g.o_ld + h * HD + 4 * c) = make_float4(o[0], o[1], o[2], o[3]);
 }
 
-// backward: blocks [0, nblk) of a (b, h) are the row kind, [nblk, 2 nblk) the column kind
-template <int HD>
-__global__ __launch_bounds__(kSaThreads) void small_attn_bwd_kernel(SmallAttnArgs g) {
-  __shared__ SaLds<HD> S;
-  constexpr int kPad = HD + 4, kLanes = HD / 4;
+// backward: blocks [0, nblk) of a (b, h) are the row kind, [nblk, 2 nblk) the column kind.
+// Round 6: ROWS = 32 queries (or keys) per workgroup of 512 threads.  With 16 rows a launch at L = 240 was 480 workgroups of
+// 139 KB of LDS -- one per CU, i.e. TWO residency rounds of ~20 us each on 256 CUs (46 us per launch, profiles/r05 kernel
+// table); 32 rows make it 240 workgroups = one round, and the staging of K / V (or dO / Q), which every workgroup repeats, is
+// paid half as often.  The column kind's second coefficient row (the dropped probabilities, for dV) no longer has an LDS row
+// of its own: the lane keeps its <= 16 values in registers and writes them over the dS row once dK has been combined.
+template <int HD, int ROWS> struct SaLdsB {
+  static constexpr int kPad = HD + 4;
+  float a[kSaMaxL * kPad];
+  float b[kSaMaxL * kPad];
+  float p[ROWS][kSaMaxL];
+  float delta[kSaMaxL];
+};
+
+template <int HD, int ROWS>
+__global__ __launch_bounds__(ROWS * 16) void small_attn_bwd_kernel(SmallAttnArgs g) {
+  __shared__ SaLdsB<HD, ROWS> S;
+  constexpr int kPad = HD + 4, kLanes = HD / 4, kThreads = ROWS * 16;
   const int tid = threadIdx.x, grp = tid >> 4, c = tid & 15;
   const int L4 = (g.L + 3) & ~3;
-  const int nblk = (g.L + kSaRows - 1) / kSaRows;
+  const int nblk = (g.L + ROWS - 1) / ROWS;
   const int per_bh = 2 * nblk;
   const int bh = blockIdx.x / per_bh, r = blockIdx.x % per_bh, h = bh % g.H, b = bh / g.H;
   const bool col_kind = r >= nblk;
-  const int x0 = (col_kind ? r - nblk : r) * kSaRows + grp;         // this group's query (row kind) or key (column kind)
+  const int x0 = (col_kind ? r - nblk : r) * ROWS + grp;            // this group's query (row kind) or key (column kind)
   const bool x_ok = x0 < g.L;
   const float keep_scale = g.drop_p > 0.f ? 1.f / (1.f - g.drop_p) : 1.f;
   const uint32_t thresh = (uint32_t)fminf(g.drop_p * 4294967296.f, 4294967040.f);
   const float *dO = g.dout + b * g.do_bs + h * HD;
   const float *O = g.out + b * g.o_bs + h * HD;
   // delta_i = dO_i . O_i for every query
-  for (int i = tid; i < g.L; i += kSaThreads) {
+  for (int i = tid; i < g.L; i += kThreads) {
     float d = 0.f;
 #pragma unroll
     for (int e = 0; e < HD; e += 4) {
@@ -194,8 +208,8 @@ __global__ __launch_bounds__(kSaThreads) void small_attn_bwd_kernel(SmallAttnArg
   }
   float xv[HD];      // row kind: dO_i; column kind: V_j
   if (!col_kind) {
-    sa_stage<HD>(S.a, g.v + b * g.v_bs + h * HD, g.v_ld, g.L, tid);      // V rows (scored against dO_i)
-    sa_stage<HD>(S.b, g.k + b * g.k_bs + h * HD, g.k_ld, g.L, tid);      // K rows (combined into dQ)
+    sa_stage<HD, kThreads>(S.a, g.v + b * g.v_bs + h * HD, g.v_ld, g.L, tid);      // V rows (scored against dO_i)
+    sa_stage<HD, kThreads>(S.b, g.k + b * g.k_bs + h * HD, g.k_ld, g.L, tid);      // K rows (combined into dQ)
     const float *p = dO + (long long)(x_ok ? x0 : 0) * g.do_ld;
 #pragma unroll
     for (int e = 0; e < HD; e += 4) {
@@ -203,8 +217,8 @@ __global__ __launch_bounds__(kSaThreads) void small_attn_bwd_kernel(SmallAttnArg
       xv[e] = t.x; xv[e + 1] = t.y; xv[e + 2] = t.z; xv[e + 3] = t.w;
     }
   } else {
-    sa_stage<HD>(S.a, dO, g.do_ld, g.L, tid);                             // dO rows (scored against V_j; combined into dV)
-    sa_stage<HD>(S.b, g.q + b * g.q_bs + h * HD, g.q_ld, g.L, tid);      // Q rows (combined into dK)
+    sa_stage<HD, kThreads>(S.a, dO, g.do_ld, g.L, tid);                             // dO rows (scored against V_j; combined into dV)
+    sa_stage<HD, kThreads>(S.b, g.q + b * g.q_bs + h * HD, g.q_ld, g.L, tid);      // Q rows (combined into dK)
     const float *p = g.v + b * g.v_bs + (long long)(x_ok ? x0 : 0) * g.v_ld + h * HD;
 #pragma unroll
     for (int e = 0; e < HD; e += 4) {
@@ -228,40 +242,49 @@ __global__ __launch_bounds__(kSaThreads) void small_attn_bwd_kernel(SmallAttnArg
 #pragma unroll
   for (int t = 0; t < kPer; ++t) {
     const int y = c + 16 * t;
-    if (y >= g.L) break;
-    const float *yr = S.a + y * kPad;
-    float dot = 0.f;
+    if (y < g.L) {
+      const float *yr = S.a + y * kPad;
+      float dot = 0.f;
 #pragma unroll
-    for (int e = 0; e < HD; e += 4) {
-      const float4 v4 = *reinterpret_cast<const float4 *>(yr + e);
-      dot = fmaf(xv[e], v4.x, dot); dot = fmaf(xv[e + 1], v4.y, dot); dot = fmaf(xv[e + 2], v4.z, dot); dot = fmaf(xv[e + 3], v4.w, dot);
+      for (int e = 0; e < HD; e += 4) {
+        const float4 v4 = *reinterpret_cast<const float4 *>(yr + e);
+        dot = fmaf(xv[e], v4.x, dot); dot = fmaf(xv[e + 1], v4.y, dot); dot = fmaf(xv[e + 2], v4.z, dot); dot = fmaf(xv[e + 3], v4.w, dot);
+      }
+      const int i = col_kind ? y : x0, j = col_kind ? x0 : y;
+      const float p = pv[t];
+      const float ks = sa_keep(g, thresh, keep_scale, bh, i, j);
+      const float ds = p * (ks * dot - S.delta[i]);
+      S.p[grp][y] = ds * g.scale;
+      pv[t] = p * ks;                               // (column kind: the dropped probability, written over the dS row below)
     }
-    const int i = col_kind ? y : x0, j = col_kind ? x0 : y;
-    const float p = pv[t];
-    const float ks = sa_keep(g, thresh, keep_scale, bh, i, j);
-    const float ds = p * (ks * dot - S.delta[i]);
-    S.p[grp][y] = ds * g.scale;
-    if (col_kind) S.p2[grp][y] = p * ks;
   }
-  if (c < L4 - g.L) { S.p[grp][g.L + c] = 0.f; S.p2[grp][g.L + c] = 0.f; }
+  if (c < L4 - g.L) S.p[grp][g.L + c] = 0.f;
   __syncthreads();
-  if (c >= kLanes) return;
   if (!col_kind) {
+    if (c >= kLanes) return;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     sa_combine<HD>(acc, S.p[grp], S.b, L4, c);                       // dQ_i = scale * sum_j dS_ij K_j
     if (x_ok)
       *reinterpret_cast<float4 *>(g.dq + b * g.dq_bs + (long long)x0 * g.dq_ld + h * HD + 4 * c) =
           make_float4(acc[0], acc[1], acc[2], acc[3]);
-  } else {
-    float ak[4] = {0.f, 0.f, 0.f, 0.f}, av[4] = {0.f, 0.f, 0.f, 0.f};
-    sa_combine<HD>(ak, S.p[grp], S.b, L4, c);                        // dK_j = scale * sum_i dS_ij Q_i
-    sa_combine<HD>(av, S.p2[grp], S.a, L4, c);                       // dV_j = sum_i Pd_ij dO_i
-    if (x_ok) {
-      *reinterpret_cast<float4 *>(g.dk + b * g.dk_bs + (long long)x0 * g.dk_ld + h * HD + 4 * c) =
-          make_float4(ak[0], ak[1], ak[2], ak[3]);
-      *reinterpret_cast<float4 *>(g.dv + b * g.dv_bs + (long long)x0 * g.dv_ld + h * HD + 4 * c) =
-          make_float4(av[0], av[1], av[2], av[3]);
-    }
+    return;
+  }
+  float ak[4] = {0.f, 0.f, 0.f, 0.f}, av[4] = {0.f, 0.f, 0.f, 0.f};
+  if (c < kLanes) sa_combine<HD>(ak, S.p[grp], S.b, L4, c);          // dK_j = scale * sum_i dS_ij Q_i
+  __syncthreads();                                                   // (every lane of the group has read the dS row)
+#pragma unroll
+  for (int t = 0; t < kPer; ++t) {
+    const int y = c + 16 * t;
+    if (y < g.L) S.p[grp][y] = pv[t];
+  }
+  __syncthreads();
+  if (c >= kLanes) return;
+  sa_combine<HD>(av, S.p[grp], S.a, L4, c);                          // dV_j = sum_i Pd_ij dO_i
+  if (x_ok) {
+    *reinterpret_cast<float4 *>(g.dk + b * g.dk_bs + (long long)x0 * g.dk_ld + h * HD + 4 * c) =
+        make_float4(ak[0], ak[1], ak[2], ak[3]);
+    *reinterpret_cast<float4 *>(g.dv + b * g.dv_bs + (long long)x0 * g.dv_ld + h * HD + 4 * c) =
+        make_float4(av[0], av[1], av[2], av[3]);
   }
 }
 
