@@ -134,6 +134,12 @@ EXPORTS = {
                                      [c_void_p] * 6, c_int),
     "snipper_small_ln_backward_f32": ([c_void_p] * 10 + [c_int, c_int, ctypes.c_float] + [c_void_p] * 4, c_int),
     "snipper_refine_reference_linear_f32": ([c_void_p] * 6 + [c_int] * 4 + [ctypes.c_float, c_void_p, c_void_p], c_int),
+    "snipper_layers_abi_version": ([], c_int),
+    "snipper_decoder_layer_supported": ([c_char_p], c_int),
+    "snipper_decoder_layer_arena_bytes": ([c_char_p], c_size_t),
+    "snipper_decoder_layer_scratch_bytes": ([c_char_p], c_size_t),
+    "snipper_decoder_layer_forward": ([c_void_p, c_char_p], c_int),
+    "snipper_decoder_layer_backward": ([c_void_p, c_char_p], c_int),
     "snipper_relu_dropout_backward_bf16": ([c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, ctypes.c_float], c_int),
 }
 

@@ -13,6 +13,7 @@
 
 #include "../../include/snipper_msda.h"
 #include "../../include/snipper_dense.h"
+#include "../../include/snipper_layers.h"
 #include "gemm_bf16.cuh"
 #include "wgrad_bf16.cuh"
 #include "wres_gemm_bf16.cuh"
@@ -1949,6 +1950,247 @@ int snipper_lsap_f32(void *stream, const float *cost, int P, int n, int m, long 
   if (P <= 0 || m <= 0 || n < m || n > kLsapMaxCols || m > kLsapMaxRows) return SNIPPER_E_SHAPE;
   hipLaunchKernelGGL(lsap_kernel, dim3(P), dim3(64), 0, (hipStream_t)stream, cost, n, m, out_src, out_tgt);
   return launch_status();
+}
+
+}  // extern "C"
+
+// ================================================================================================================
+// One native call per decoder layer and direction (include/snipper_layers.h).  Pure sequencing: every launch below is an
+// entry point of this library with the arguments the Python host used to pass one by one (snipper_amd/deformable_transformer.py
+// DeformableTransformerDecoderLayer.forward_chain), in the same order -- results are bit-identical to that sequence.
+// ================================================================================================================
+namespace {
+struct DlArena {            // byte offsets into the forward's arena (all 256-byte aligned)
+  size_t qk, v, att, P, mixed, s2, st2, keep2, t2, t2q, raw, sampled, attended, s1, st1, keep1, t3, h, y, s3, st3, keep3, total;
+};
+struct DlScratch {          // byte offsets into the backward's scratch
+  size_t d_y, gh, d_t3a, d_t3b, d_att_out, d_sampled, g_loc, g_prob, g_raw, d_t2b, d_mixed, d_att, dqk, dv, total;
+};
+inline size_t dl_up(size_t x) { return (x + 255) & ~(size_t)255; }
+inline bool dl_dims_ok(const snipper_decoder_layer_dims *d) {
+  if (!d || d->struct_bytes != (int32_t)sizeof(snipper_decoder_layer_dims)) return false;
+  if (d->bs <= 0 || d->tokens <= 0 || d->frames <= 0 || d->queries <= 0 || d->frames * d->queries != d->tokens) return false;
+  if (d->C <= 0 || d->C % 4 || d->C > kLnMaxIter * 256 || d->heads <= 0 || d->C % d->heads) return false;
+  const int hd = d->C / d->heads;
+  if ((hd != 32 && hd != 48) || d->tokens > kSaMaxL || (long long)d->bs * d->tokens > kSmallLnMaxRows) return false;
+  if (d->d_ffn <= 0 || d->d_ffn % 4 || d->levels <= 0 || d->levels > 8 || d->points <= 0 || d->levels * d->points > 16) return false;
+  if ((d->heads & (d->heads - 1)) || d->heads > 64 || d->S <= 0) return false;
+  if ((d->heads * d->levels * d->points * 2) % 32) return false;       // (the pair's stacked-weight product splits there)
+  if (d->value_dtype != 0 && d->value_dtype != 1) return false;
+  if (d->value_dtype == 1 &&
+      (hd != kSpD || d->queries > kSpMaxLq || d->queries * d->points * 4 > kSpTaps || d->S >= (1 << 22) ||
+       (long long)d->bs * d->frames * d->S * d->C * 2 >= (1LL << 31)))
+    return false;                                                        // (bf16 value: the sort-by-pixel backward's shape)
+  for (float p : {d->p_attn, d->p_norm2, d->p_norm1, d->p_ffn, d->p_norm3})
+    if (!(p >= 0.f && p < 1.f)) return false;
+  return true;
+}
+inline DlArena dl_arena(const snipper_decoder_layer_dims &d) {
+  const size_t R = (size_t)d.bs * d.tokens, C = d.C, f = sizeof(float);
+  const size_t nraw = (size_t)d.heads * d.levels * d.points * 3;
+  DlArena a{};
+  size_t o = 0;
+  auto take = [&](size_t bytes) { const size_t at = o; o += dl_up(bytes); return at; };
+  a.qk = take(R * 2 * C * f); a.v = take(R * C * f); a.att = take(R * C * f);
+  a.P = take((size_t)d.bs * d.heads * d.tokens * d.tokens * f);
+  a.mixed = take(R * C * f);
+  a.s2 = take(R * C * f); a.st2 = take(2 * R * f); a.keep2 = take(R * C / 4);
+  a.t2 = take(R * C * f); a.t2q = take(R * C * f);
+  a.raw = take(R * nraw * f); a.sampled = take(R * C * f); a.attended = take(R * C * f);
+  a.s1 = take(R * C * f); a.st1 = take(2 * R * f); a.keep1 = take(R * C / 4);
+  a.t3 = take(R * C * f); a.h = take(R * (size_t)d.d_ffn * f); a.y = take(R * C * f);
+  a.s3 = take(R * C * f); a.st3 = take(2 * R * f); a.keep3 = take(R * C / 4);
+  a.total = o;
+  return a;
+}
+inline DlScratch dl_scratch(const snipper_decoder_layer_dims &d) {
+  const size_t R = (size_t)d.bs * d.tokens, C = d.C, f = sizeof(float);
+  const size_t nlp = (size_t)d.heads * d.levels * d.points;
+  DlScratch s{};
+  size_t o = 0;
+  auto take = [&](size_t bytes) { const size_t at = o; o += dl_up(bytes); return at; };
+  s.d_y = take(R * C * f); s.gh = take(R * (size_t)d.d_ffn * f); s.d_t3a = take(R * C * f); s.d_t3b = take(R * C * f);
+  s.d_att_out = take(R * C * f); s.d_sampled = take(R * C * f);
+  s.g_loc = take(R * nlp * 2 * f); s.g_prob = take(R * nlp * f); s.g_raw = take(R * nlp * 3 * f);
+  s.d_t2b = take(R * C * f); s.d_mixed = take(R * C * f); s.d_att = take(R * C * f);
+  s.dqk = take(R * 2 * C * f); s.dv = take(R * C * f);
+  s.total = o;
+  return s;
+}
+inline snipper_small_gemm dl_prob(const float *A, long long lda, int a_tr, const float *B, long long ldb, int b_tr, float *out,
+                                  long long ldo, const float *bias, float *colsum, int I, int J, int Rr) {
+  snipper_small_gemm g{};
+  g.A = A; g.lda = lda; g.a_transposed = a_tr; g.B = B; g.ldb = ldb; g.b_transposed = b_tr; g.out = out; g.ldo = ldo;
+  g.bias = bias; g.colsum = colsum; g.I = I; g.J = J; g.R = Rr;
+  return g;
+}
+}  // namespace
+
+extern "C" {
+
+int snipper_layers_abi_version(void) { return SNIPPER_LAYERS_ABI_VERSION; }
+int snipper_decoder_layer_supported(const snipper_decoder_layer_dims *d) { return dl_dims_ok(d) ? 1 : 0; }
+size_t snipper_decoder_layer_arena_bytes(const snipper_decoder_layer_dims *d) { return dl_dims_ok(d) ? dl_arena(*d).total : 0; }
+size_t snipper_decoder_layer_scratch_bytes(const snipper_decoder_layer_dims *d) { return dl_dims_ok(d) ? dl_scratch(*d).total : 0; }
+
+int snipper_decoder_layer_forward(void *stream, const snipper_decoder_layer_fwd *a) {
+  if (!a) return SNIPPER_E_NULL;
+  const snipper_decoder_layer_dims &d = a->d;
+  if (!dl_dims_ok(&d)) return SNIPPER_E_SHAPE;
+  const snipper_decoder_layer_params &w = a->w;
+  if (!a->x_v || !a->x_res || !a->x_q || !a->pos_a || !a->value || !a->shapes || !a->level_start || !a->ref_in || !a->inv_w ||
+      !a->inv_h || !a->out || !a->loc || !a->prob || !a->arena || (a->out_q && !a->pos_b))
+    return SNIPPER_E_NULL;
+  for (const float *p : {w.so_w, w.so_b, w.aw_w, w.aw_b, w.op_w, w.op_b, w.norm1_w, w.norm1_b, w.in_proj_w, w.in_proj_b, w.out_proj_w,
+                         w.out_proj_b, w.norm2_w, w.norm2_b, w.lin1_w, w.lin1_b, w.lin2_w, w.lin2_b, w.norm3_w, w.norm3_b})
+    if (!p) return SNIPPER_E_NULL;
+  if (a->root_w && (!a->ref_points || !a->valid_ratios || !a->new_ref || !a->ref_in_next)) return SNIPPER_E_NULL;
+  const DlArena L = dl_arena(d);
+  if (a->arena_bytes < L.total || ((uintptr_t)a->arena & 255)) return SNIPPER_E_SHAPE;
+  unsigned char *ar = (unsigned char *)a->arena;
+  auto F = [&](size_t off) { return (float *)(ar + off); };
+  const int R = d.bs * d.tokens, C = d.C, E = d.C, hd = d.C / d.heads, nlp = d.heads * d.levels * d.points;
+  int rc;
+  // 1. packed q | k and v projections of the self-attention (reference :282-287 through nn.MultiheadAttention's in_proj)
+  {
+    snipper_small_gemm pr[2] = {dl_prob(a->x_q, E, 0, w.in_proj_w, E, 1, F(L.qk), 2 * E, w.in_proj_b, nullptr, R, 2 * E, E),
+                                dl_prob(a->x_v, E, 0, w.in_proj_w + (size_t)2 * E * E, E, 1, F(L.v), E, w.in_proj_b + 2 * E, nullptr, R, E, E)};
+    if ((rc = snipper_small_gemm_batch_f32(stream, pr, 2))) return rc;
+  }
+  // 2. attention, 3. its output projection, 4. norm2(x + dropout(.)) and the position-added copy for the cross attention's query
+  if ((rc = snipper_small_attention_forward_f32(stream, F(L.qk), 2 * E, (long long)d.tokens * 2 * E, F(L.qk) + E, 2 * E,
+                                                (long long)d.tokens * 2 * E, F(L.v), E, (long long)d.tokens * E, F(L.att), E,
+                                                (long long)d.tokens * E, F(L.P), d.bs, d.heads, d.tokens, hd, d.attn_scale,
+                                                d.p_attn, d.seed_attn)))
+    return rc;
+  if ((rc = snipper_small_linear_forward_f32(stream, F(L.att), E, w.out_proj_w, E, w.out_proj_b, R, E, E, F(L.mixed), E))) return rc;
+  if ((rc = snipper_small_ln_forward_f32(stream, a->x_res, F(L.mixed), a->pos_a, w.norm2_w, w.norm2_b, R, C, d.p_norm2, d.eps_norm2,
+                                         d.seed_norm2, F(L.s2), F(L.st2), F(L.st2) + R, ar + L.keep2, F(L.t2), F(L.t2q))))
+    return rc;
+  // 5. offsets | logits of the cross attention as one product pair, 6. locations + softmax, 7. the core op, 8. output projection
+  {
+    float *raw = F(L.raw);
+    snipper_small_gemm pr[2] = {dl_prob(F(L.t2q), E, 0, w.so_w, E, 1, raw, 3 * nlp, w.so_b, nullptr, R, 2 * nlp, E),
+                                dl_prob(F(L.t2q), E, 0, w.aw_w, E, 1, raw + 2 * nlp, 3 * nlp, w.aw_b, nullptr, R, nlp, E)};
+    if ((rc = snipper_small_gemm_batch_f32(stream, pr, 2))) return rc;
+    if ((rc = snipper_msda_prologue_forward_ex(stream, raw, 3 * nlp, raw + 2 * nlp, 3 * nlp, 0, nullptr, a->ref_in, a->inv_w, a->inv_h,
+                                               (long long)R * d.heads, d.heads, d.levels, d.points, a->loc, a->prob)))
+      return rc;
+  }
+  if ((rc = snipper_msda_forward_ex(stream, nullptr, a->host_shapes, a->value, d.value_dtype, a->shapes, a->level_start, a->loc, a->prob,
+                                    d.bs * d.frames, d.S, d.heads, hd, d.levels, d.queries, d.points, F(L.sampled), 0)))
+    return rc;
+  if ((rc = snipper_small_linear_forward_f32(stream, F(L.sampled), E, w.op_w, E, w.op_b, R, E, E, F(L.attended), E))) return rc;
+  // 9. norm1, 10-11. feed-forward block, 12. norm3 (+ the position-added copy for the next layer's q / k input)
+  if ((rc = snipper_small_ln_forward_f32(stream, F(L.t2), F(L.attended), nullptr, w.norm1_w, w.norm1_b, R, C, d.p_norm1, d.eps_norm1,
+                                         d.seed_norm1, F(L.s1), F(L.st1), F(L.st1) + R, ar + L.keep1, F(L.t3), nullptr)))
+    return rc;
+  {
+    snipper_small_gemm p1 = dl_prob(F(L.t3), E, 0, w.lin1_w, E, 1, F(L.h), d.d_ffn, w.lin1_b, nullptr, R, d.d_ffn, E);
+    p1.relu = 1; p1.dropout_p = d.p_ffn; p1.seed = d.seed_ffn;
+    if ((rc = snipper_small_gemm_batch_f32(stream, &p1, 1))) return rc;
+    snipper_small_gemm p2 = dl_prob(F(L.h), d.d_ffn, 0, w.lin2_w, d.d_ffn, 1, F(L.y), E, w.lin2_b, nullptr, R, E, d.d_ffn);
+    if ((rc = snipper_small_gemm_batch_f32(stream, &p2, 1))) return rc;
+  }
+  if ((rc = snipper_small_ln_forward_f32(stream, F(L.t3), F(L.y), a->out_q ? a->pos_b : nullptr, w.norm3_w, w.norm3_b, R, C, d.p_norm3,
+                                         d.eps_norm3, d.seed_norm3, F(L.s3), F(L.st3), F(L.st3) + R, ar + L.keep3, a->out, a->out_q)))
+    return rc;
+  // 13. reference-point refinement for the next layer (reference :329-333), no gradient
+  if (a->root_w)
+    if ((rc = snipper_refine_reference_linear_f32(stream, a->out, a->root_w, a->root_b, a->ref_points, a->valid_ratios, R, C, d.tokens,
+                                                  d.levels, 1e-5f, a->new_ref, a->ref_in_next)))
+      return rc;
+  return SNIPPER_OK;
+}
+
+int snipper_decoder_layer_backward(void *stream, const snipper_decoder_layer_bwd *a) {
+  if (!a) return SNIPPER_E_NULL;
+  const snipper_decoder_layer_dims &d = a->d;
+  if (!dl_dims_ok(&d)) return SNIPPER_E_SHAPE;
+  const snipper_decoder_layer_params &w = a->w, &g = a->dw;
+  if (!a->x_v || !a->x_q || !a->value || !a->shapes || !a->level_start || !a->inv_w || !a->inv_h || !a->loc || !a->prob || !a->arena ||
+      !a->scratch || !a->d_xv || !a->d_xres || !a->d_xq || !a->d_pos_a || !a->d_value || (!a->g[0] && !a->g[1] && !a->g[2] && !a->g[3]))
+    return SNIPPER_E_NULL;
+  for (const float *p : {w.so_w, w.aw_w, w.op_w, w.norm1_w, w.in_proj_w, w.out_proj_w, w.norm2_w, w.lin1_w, w.lin2_w, w.norm3_w, g.so_w, g.so_b,
+                         g.aw_w, g.aw_b, g.op_w, g.op_b, g.norm1_w, g.norm1_b, g.in_proj_w, g.in_proj_b, g.out_proj_w, g.out_proj_b, g.norm2_w,
+                         g.norm2_b, g.lin1_w, g.lin1_b, g.lin2_w, g.lin2_b, g.norm3_w, g.norm3_b})
+    if (!p) return SNIPPER_E_NULL;
+  const DlArena L = dl_arena(d);
+  const DlScratch S = dl_scratch(d);
+  if (a->scratch_bytes < S.total || ((uintptr_t)a->scratch & 255) || ((uintptr_t)a->arena & 255)) return SNIPPER_E_SHAPE;
+  const unsigned char *ar = (const unsigned char *)a->arena;
+  unsigned char *sc = (unsigned char *)a->scratch;
+  auto F = [&](size_t off) { return (const float *)(ar + off); };
+  auto W = [&](size_t off) { return (float *)(sc + off); };
+  const int R = d.bs * d.tokens, C = d.C, E = d.C, hd = d.C / d.heads, nlp = d.heads * d.levels * d.points;
+  int rc;
+  // norm3
+  if ((rc = snipper_small_ln_backward_f32(stream, a->g[0], a->g[1], a->g[2], a->g[3], F(L.s3), F(L.st3), F(L.st3) + R, w.norm3_w,
+                                          ar + L.keep3, R, C, d.p_norm3, W(S.d_t3b), W(S.d_y), g.norm3_w, g.norm3_b)))
+    return rc;
+  // feed-forward block: [dH (gated by the hidden activation), dW2 + db2], then [dX, dW1 + db1]
+  {
+    snipper_small_gemm pr[2] = {dl_prob(W(S.d_y), E, 0, w.lin2_w, d.d_ffn, 0, W(S.gh), d.d_ffn, nullptr, nullptr, R, d.d_ffn, E),
+                                dl_prob(W(S.d_y), E, 1, F(L.h), d.d_ffn, 0, g.lin2_w, d.d_ffn, nullptr, g.lin2_b, E, d.d_ffn, R)};
+    pr[0].gate = F(L.h); pr[0].ldgate = d.d_ffn; pr[0].gate_scale = 1.f / (1.f - d.p_ffn);
+    if ((rc = snipper_small_gemm_batch_f32(stream, pr, 2))) return rc;
+    snipper_small_gemm p2[2] = {dl_prob(W(S.gh), d.d_ffn, 0, w.lin1_w, E, 0, W(S.d_t3a), E, nullptr, nullptr, R, E, d.d_ffn),
+                                dl_prob(W(S.gh), d.d_ffn, 1, F(L.t3), E, 0, g.lin1_w, E, nullptr, g.lin1_b, d.d_ffn, E, R)};
+    if ((rc = snipper_small_gemm_batch_f32(stream, p2, 2))) return rc;
+  }
+  // norm1 (its result fed the feed-forward block and norm3's residual)
+  if ((rc = snipper_small_ln_backward_f32(stream, W(S.d_t3a), W(S.d_t3b), nullptr, nullptr, F(L.s1), F(L.st1), F(L.st1) + R, w.norm1_w,
+                                          ar + L.keep1, R, C, d.p_norm1, W(S.d_t2b), W(S.d_att_out), g.norm1_w, g.norm1_b)))
+    return rc;
+  // cross attention: output projection, core op, locations + softmax, offset | logit pair
+  if ((rc = snipper_small_linear_backward_f32(stream, W(S.d_att_out), E, F(L.sampled), E, w.op_w, E, R, E, E, W(S.d_sampled), E, g.op_w, E,
+                                              g.op_b)))
+    return rc;
+  if (d.value_dtype == 1) {
+    if ((rc = snipper_msda_backward_sparse_f32rows(stream, W(S.d_sampled), (const uint16_t *)a->value, a->shapes, a->level_start, a->loc,
+                                                   a->prob, d.bs * d.frames, d.S, d.heads, hd, d.levels, d.queries, d.points,
+                                                   (uint16_t *)a->d_value, W(S.g_loc), W(S.g_prob))))
+      return rc;
+  } else {
+    if ((rc = snipper_msda_backward_ex(stream, nullptr, a->host_shapes, nullptr, 0, W(S.d_sampled), 0, a->value, 0, a->shapes,
+                                       a->level_start, a->loc, a->prob, d.bs * d.frames, d.S, d.heads, hd, d.levels, d.queries, d.points,
+                                       a->d_value, W(S.g_loc), W(S.g_prob))))
+      return rc;
+  }
+  {
+    float *graw = W(S.g_raw);
+    if ((rc = snipper_msda_prologue_backward(stream, W(S.g_loc), W(S.g_prob), a->prob, a->inv_w, a->inv_h, (long long)R * d.heads, d.heads,
+                                             d.levels, d.points, graw, 3 * nlp, graw + 2 * nlp, 3 * nlp, 0, a->d_ref_in)))
+      return rc;
+    snipper_small_gemm pr[3] = {dl_prob(graw, 3 * nlp, 0, w.so_w, E, 0, a->d_pos_a, E, nullptr, nullptr, R, E, 3 * nlp),
+                                dl_prob(graw, 3 * nlp, 1, F(L.t2q), E, 0, g.so_w, E, nullptr, g.so_b, 2 * nlp, E, R),
+                                dl_prob(graw + 2 * nlp, 3 * nlp, 1, F(L.t2q), E, 0, g.aw_w, E, nullptr, g.aw_b, nlp, E, R)};
+    pr[0].B2 = w.aw_w; pr[0].ldb2 = E; pr[0].r_split = 2 * nlp;
+    if ((rc = snipper_small_gemm_batch_f32(stream, pr, 3))) return rc;
+  }
+  // norm2 (its result fed norm1's residual; its position-added copy the pair above: d_pos_a is that copy's gradient)
+  if ((rc = snipper_small_ln_backward_f32(stream, W(S.d_t2b), a->d_pos_a, nullptr, nullptr, F(L.s2), F(L.st2), F(L.st2) + R, w.norm2_w,
+                                          ar + L.keep2, R, C, d.p_norm2, a->d_xres, W(S.d_mixed), g.norm2_w, g.norm2_b)))
+    return rc;
+  // self-attention: output projection, attention, packed input projections
+  if ((rc = snipper_small_linear_backward_f32(stream, W(S.d_mixed), E, F(L.att), E, w.out_proj_w, E, R, E, E, W(S.d_att), E, g.out_proj_w, E,
+                                              g.out_proj_b)))
+    return rc;
+  if ((rc = snipper_small_attention_backward_f32(stream, F(L.qk), 2 * E, (long long)d.tokens * 2 * E, F(L.qk) + E, 2 * E,
+                                                 (long long)d.tokens * 2 * E, F(L.v), E, (long long)d.tokens * E, F(L.att), E,
+                                                 (long long)d.tokens * E, F(L.P), W(S.d_att), E, (long long)d.tokens * E, W(S.dqk), 2 * E,
+                                                 (long long)d.tokens * 2 * E, W(S.dqk) + E, 2 * E, (long long)d.tokens * 2 * E, W(S.dv), E,
+                                                 (long long)d.tokens * E, d.bs, d.heads, d.tokens, hd, d.attn_scale, d.p_attn,
+                                                 d.seed_attn)))
+    return rc;
+  {
+    snipper_small_gemm pr[4] = {dl_prob(W(S.dqk), 2 * E, 0, w.in_proj_w, E, 0, a->d_xq, E, nullptr, nullptr, R, E, 2 * E),
+                                dl_prob(W(S.dqk), 2 * E, 1, a->x_q, E, 0, g.in_proj_w, E, nullptr, g.in_proj_b, 2 * E, E, R),
+                                dl_prob(W(S.dv), E, 0, w.in_proj_w + (size_t)2 * E * E, E, 0, a->d_xv, E, nullptr, nullptr, R, E, E),
+                                dl_prob(W(S.dv), E, 1, a->x_v, E, 0, g.in_proj_w + (size_t)2 * E * E, E, nullptr, g.in_proj_b + 2 * E, E, E, R)};
+    if ((rc = snipper_small_gemm_batch_f32(stream, pr, 4))) return rc;
+  }
+  return SNIPPER_OK;
 }
 
 }  // extern "C"

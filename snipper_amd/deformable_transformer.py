@@ -524,6 +524,49 @@ class DeformableTransformerDecoderLayer(nn.Module, _FFNMixin):
         return (n_v, n_res, n_q), out.view(bs, t, lq, c), atten_data
 
 
+    # -- round 6: the same chain from ONE native call per direction (include/snipper_layers.h, decoder_native.py) ------------
+    native = __import__("os").environ.get("SNIPPER_DEC_NATIVE", "1") != "0"    # (A/B aid: 0 = forward_chain's Python sequencing)
+
+    def native_plan(self, shape, src, hw):
+        """The decoder_native.LayerPlan for this layer when the native composites apply: the chain's conditions (checked by the
+        caller), a premixed bf16 memory (DeformableTransformerDecoder._forward), tied Linears, contiguous float32 parameters."""
+        pre = getattr(src, "_snipper_premixed", None)
+        ca = self.cross_attn
+        if not (self.native and pre is not None and hw is not None and pre.dtype == torch.bfloat16 and pre.dim() == 4 and
+                ca.weights_are_tied() and not ca.use_pytroch_deform and ca.fused_elementwise):
+            return None
+        bs, t, lq, c = shape
+        if pre.shape[0] != bs or pre.shape[1] != t or pre.shape[3] != c:
+            return None
+        from .decoder_native import layer_params, make_plan
+        if not all(p.dtype == torch.float32 and p.is_contiguous() and p.data_ptr() % 16 == 0 for p in layer_params(self)):
+            return None
+        return make_plan(self, bs, t, lq, c, int(pre.shape[2]), hw, torch.bfloat16)
+
+    def forward_native(self, plan, state, pos_a, pos_b, ref_in, ref_points, valid_ratios, src, shapes, lsi, root_lin, shape,
+                       last: bool):
+        """``forward_chain`` through decoder_native.DecoderLayerFn; also refines the reference points when ``root_lin`` (the
+        root head as one nn.Linear) is given.  Returns (state, out, atten_data, (new_ref, ref_in_next) or None)."""
+        from .decoder_native import DecoderLayerFn, layer_params
+        bs, t, lq, c = shape
+        x_v, x_res, x_q = state
+        ca = self.cross_attn
+        value = big_linear(src._snipper_premixed, ca.value_proj)           # [bs, t, S, c] bf16: the full-size product stays outside
+        rw = rb = None
+        if root_lin is not None:
+            rw, rb = root_lin.weight.detach(), (root_lin.bias.detach() if root_lin.bias is not None else None)
+        n_v, n_res, out, n_q, new_ref, ref_next, loc, prob = DecoderLayerFn.apply(
+            plan, not last, x_v, x_res, x_q, pos_a, None if last else pos_b, value.contiguous(), ref_in.contiguous(),
+            ref_points.contiguous() if rw is not None else None, valid_ratios.contiguous() if rw is not None else None,
+            shapes, lsi, rw, rb, *layer_params(self))
+        M, L, P = ca.n_heads, ca.n_levels, ca.n_points
+        atten = ca._vis_lists(loc.view(bs, t, lq, M, L, P, 2), prob.view(bs, t, lq, M, L, P), plan.groups, bs, lq, M, L, P)
+        refined = None
+        if rw is not None:
+            refined = (new_ref.view(bs, t, lq, 2), ref_next.view(bs, t, lq, L, 2))
+        return (None if last else (n_v, n_res, n_q)), out.view(bs, t, lq, c), atten, refined
+
+
 class DeformableTransformerDecoder(nn.Module):
     def __init__(self, decoder_layer, num_layers, return_intermediate=False):
         super().__init__()
@@ -605,16 +648,35 @@ class DeformableTransformerDecoder(nn.Module):
         for lid, layer in enumerate(self.layers):
             if ref_in is None:
                 ref_in = reference_points[:, :, :, None, :] * src_valid_ratios[:, None, None, :, :]
+            refined = None
             if state is not None:
-                got = layer.forward_chain(state, pos_aliases[2 * lid + 1], pos_aliases[(2 * lid + 2) % (2 * n_l)], ref_in,
-                                          srcs[lid], src_spatial_shapes, src_level_start_index, src_padding_mask, amp_dtype,
-                                          tuple(out.shape), last=lid + 1 == n_l)
-                state, out, atten_data = got
+                shape4 = tuple(out.shape)
+                hw_host = getattr(src_spatial_shapes, "_snipper_host", None)
+                plan = layer.native_plan(shape4, srcs[lid], hw_host) if hasattr(layer, "native_plan") else None
+                if plan is not None:
+                    root_lin = None
+                    if (self.root_embed is not None and reference_points.dtype == torch.float32 and reference_points.dim() == 4 and
+                            reference_points.shape[-1] == 2 and src_valid_ratios.dtype == torch.float32):
+                        root_lin = _single_linear(self.root_embed[lid])
+                        if root_lin is not None and not (root_lin.out_features >= 2 and root_lin.weight.dtype == torch.float32 and
+                                                         root_lin.weight.is_contiguous() and root_lin.weight.data_ptr() % 16 == 0 and
+                                                         (root_lin.bias is None or root_lin.bias.dtype == torch.float32)):
+                            root_lin = None
+                    state, out, atten_data, refined = layer.forward_native(
+                        plan, state, pos_aliases[2 * lid + 1], pos_aliases[(2 * lid + 2) % (2 * n_l)], ref_in, reference_points,
+                        src_valid_ratios, srcs[lid], src_spatial_shapes, src_level_start_index, root_lin, shape4,
+                        last=lid + 1 == n_l)
+                else:
+                    state, out, atten_data = layer.forward_chain(
+                        state, pos_aliases[2 * lid + 1], pos_aliases[(2 * lid + 2) % (2 * n_l)], ref_in, srcs[lid],
+                        src_spatial_shapes, src_level_start_index, src_padding_mask, amp_dtype, shape4, last=lid + 1 == n_l)
             else:
                 out, atten_data = layer(out, query_pos, ref_in, srcs[lid], src_spatial_shapes,
                                         src_level_start_index, src_padding_mask, cross_amp_dtype=amp_dtype)
             ref_in = None
-            if self.root_embed is not None:   # iterative refinement of the reference points (:329-333)
+            if refined is not None:           # (the native layer call has refined the reference points already)
+                reference_points, ref_in = refined
+            elif self.root_embed is not None:   # iterative refinement of the reference points (:329-333)
                 fused = _refine_reference(self.root_embed[lid], out, reference_points, src_valid_ratios)
                 if fused is not None:
                     reference_points, ref_in = fused
