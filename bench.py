@@ -365,7 +365,7 @@ def msda_alg_bytes(d, bwd):
     return e * v + re * o + ge * v + ce * 6 * lp
 
 
-PMC_PROFILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r05_pmc_bench_step.csv")
+PMC_PROFILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r06_pmc_bench_step.csv")
 
 
 BWD_KERNELS = ("msda_bwd_d48_patchbin", "msda_bwd_d48_tile3", "msda_bwd_d48_far")   # query side; grad_value side (bf16 rows: two kernels, by tile size); far list
@@ -1319,8 +1319,12 @@ def main():
                                           "stem, 1x1 and 3x3 forward, data and weight gradients; nothing in MIOpen"),
                        "grad_sync": ("none (1 GPU)" if not use_ddp else
                                      ("DistributedDataParallel" if a.ddp == "torch" else
-                                      "flat buffer, 5 stages (decoder side, encoder side, layer4, layer3, layer2) all-reduced over RCCL "
-                                      "from autograd hooks while backward runs (snipper_amd/grad_sync.py)")),
+                                      "flat buffer, 8 stages (decoder side, upper encoder half, the rest, layer4 block by block, layer3, "
+                                      "layer2) all-reduced over RCCL from autograd hooks while backward runs (snipper_amd/grad_sync.py)")),
+                       "layer_calls": ("one native call and one autograd node per encoder layer and per decoder layer and direction "
+                                       "(include/snipper_layers.h; the same launches as the per-module sequence, bit-identical)"
+                                       if (os.environ.get("SNIPPER_ENC_NATIVE", "1") != "0" and os.environ.get("SNIPPER_DEC_NATIVE", "1") != "0"
+                                           and amp) else "per-module autograd nodes (SNIPPER_ENC_NATIVE / SNIPPER_DEC_NATIVE = 0, or float32)"),
                        "msda_path": "pytorch grid_sample" if a.use_pytorch_deform else
                                     ("snipper_amd HIP (tied single-launch" +
                                      ("; encoder's bf16 temporal mean and grad_value head-major [n, head, position, 48] inside the "
@@ -1383,7 +1387,7 @@ def main():
                                        (None, None, "the dominant launch is not the bf16 encoder backward the PMC profile covers"))
             line["roofline"] = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                 "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": corrected, "traffic_raw_counters": raw,
-                                "traffic_source": ("NOT measured in this run: read from the committed profiles/r05_pmc_bench_step.csv "
+                                "traffic_source": ("NOT measured in this run: read from the committed profiles/r06_pmc_bench_step.csv "
                                                    "(collected with THIS library: its source hash is recorded in the file and checked) = "
                                                    "rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE (separate passes, tools/collect_profiles.sh) of "
                                                    "this command at the same kernels, query-side + grad_value-side kernel; "
@@ -1405,7 +1409,7 @@ def main():
             # the dense parts against the MFMA peak.  Aggregate over every GEMM-shaped launch of this
             # library in two eager steps (linear / weight-stationary / NN data gradient / weight gradient / 3x3 / stem; the
             # decoder-size float32 products are not in it): FLOPs of the products as defined (no padding) over the sum of
-            # the launches' durations (events on the launch stream); per-layer table: profiles/r05_backbone_roofline.csv
+            # the launches' durations (events on the launch stream); per-layer table: profiles/r06_backbone_roofline.csv
             fl = sum(x[2] for x in dense_launches)
             ms = sum(x[4] for x in dense_launches)
             by_kind = {}

@@ -96,6 +96,79 @@ typedef struct snipper_decoder_layer_bwd {
                                                  written: zeroed + touched rows), float32 for a float32 value             */
 } snipper_decoder_layer_bwd;
 
+/* ---------------------------------------------------------------------------------------------------------------------------
+ * Encoder layer under bf16 autocast (reference DeformableTransformerEncoderLayer.forward, models/deformable_transformer.py:
+ * 200-216: deformable self-attention over the memory with tied per-frame Linears -- ms_deform_attn.py:99-243 --, residual +
+ * LayerNorm, feed-forward block, residual + LayerNorm) as the launches of DeformableTransformerEncoderLayer.forward_fused in ONE
+ * call per direction: 9 launches forward, ~25 backward on 79 000 token rows.  float32 residual stream with "lazy" LayerNorm
+ * inputs (csrc/ln_fused.cuh), bf16 activations, bf16 weight shadows (snipper_amd/shadow.py) and their transposes / packs, the
+ * bf16 temporal mean head-major (snipper_msda_config.value_layout = 1) when cfg says so; no padding mask (the training case:
+ * every snippet is warped to the input size, datasets/transforms.py:137-144).  R = bs * frames * S rows. */
+typedef struct snipper_encoder_layer_dims {
+  int32_t struct_bytes;
+  int32_t bs, frames, S;                 /* R = bs * frames * S token rows; the core op sees N = bs * frames, Lq = S              */
+  int32_t C, heads, d_ffn, levels, points;
+  int32_t last;                          /* 1: norm2's float32 result is written (y32) and no position-added copy is made         */
+  int32_t head_major;                    /* layout of the temporal mean / its gradient (must match cfg->value_layout)             */
+  int32_t reserved;
+  float p_norm1, p_ffn, p_norm2, eps_norm1, eps_norm2;
+  float reserved_f;
+  uint64_t seed_norm1, seed_ffn, seed_norm2;
+} snipper_encoder_layer_dims;
+
+typedef struct snipper_encoder_layer_weights {
+  /* bf16 shadows: value_proj [C,C], merged offsets|logits [3 heads L P, C], output_proj [C,C], linear1 [d_ffn,C], linear2 packed
+   * for snipper_linear_wide_bf16; backward: the transposes W^T of value_proj / merged / output_proj / linear2 and the
+   * transposed pack of linear1 */
+  const uint16_t *wv, *wm, *wo, *w1, *w2_packed, *wv_t, *wm_t, *wo_t, *w2_t, *w1_tpacked;
+  /* float32: biases (bm = [0; attention_weights.bias]: the offsets' bias so_bias is added in float32 by the prologue),
+   * LayerNorm gains / shifts */
+  const float *bv, *bm, *so_bias, *bo, *b1, *b2, *norm1_w, *norm1_b, *norm2_w, *norm2_b;
+} snipper_encoder_layer_weights;
+
+typedef struct snipper_encoder_layer_fwd {
+  snipper_encoder_layer_dims d;
+  snipper_encoder_layer_weights w;
+  const snipper_msda_config *cfg;        /* HOST, or NULL                                                                         */
+  const float *x32;                      /* [R, C] residual stream -- or, with x_mean != NULL, the producing LayerNorm's saved sum   */
+  const float *x_mean, *x_rstd, *x_gamma, *x_beta;
+  const uint16_t *src16, *q16, *pos16;   /* bf16 [R, C]: the stream, stream + pos, pos (pos16 NULL when d.last)                    */
+  const float *ref;                      /* [R, levels, 2]                                                                         */
+  const int64_t *shapes, *level_start, *host_shapes;
+  const float *inv_w, *inv_h, *mix;      /* HOST: [levels], [levels], [frames * frames] temporal mix                               */
+  /* outputs */
+  float *s2, *mean2, *rstd2;             /* norm2's pre-norm sum and statistics (the lazy form of the float32 result)              */
+  float *y32;                            /* norm2's float32 result, or NULL (lazy)                                                 */
+  uint16_t *y16, *yq16;                  /* bf16 result, bf16(result + pos) (NULL when d.last)                                     */
+  void *arena; size_t arena_bytes;       /* >= snipper_encoder_layer_arena_bytes(&d): what the backward reads + scratch           */
+} snipper_encoder_layer_fwd;
+
+typedef struct snipper_encoder_layer_grads {
+  float *wv, *bv, *wm, *bm, *wo, *bo, *w1, *b1, *w2, *b2, *norm1_w, *norm1_b, *norm2_w, *norm2_b;
+} snipper_encoder_layer_grads;            /* wm [3 heads L P, C], bm [3 heads L P]: the caller splits them into the two Linears'   */
+
+typedef struct snipper_encoder_layer_bwd {
+  snipper_encoder_layer_dims d;
+  snipper_encoder_layer_weights w;
+  snipper_encoder_layer_grads dw;
+  const snipper_msda_config *cfg;
+  const float *g32; const uint16_t *g16, *gq16;      /* gradients of the float32 / bf16 / position-added results, each may be NULL */
+  const uint16_t *src16, *q16;           /* the forward's inputs                                                                    */
+  const float *s2, *mean2, *rstd2;       /* the forward's outputs                                                                   */
+  const int64_t *shapes, *level_start, *host_shapes;
+  const float *inv_w, *inv_h, *mix_t;    /* HOST; mix_t = the transposed mix                                                        */
+  const void *arena;                     /* the forward's arena                                                                     */
+  void *scratch; size_t scratch_bytes;   /* >= snipper_encoder_layer_scratch_bytes(&d, cfg, host_shapes)                            */
+  /* outputs */
+  float *d_x32; uint16_t *d_src16, *d_q16;
+} snipper_encoder_layer_bwd;
+
+int snipper_encoder_layer_supported(const snipper_encoder_layer_dims *d);
+size_t snipper_encoder_layer_arena_bytes(const snipper_encoder_layer_dims *d);
+size_t snipper_encoder_layer_scratch_bytes(const snipper_encoder_layer_dims *d, const snipper_msda_config *cfg, const int64_t *host_shapes);
+int snipper_encoder_layer_forward(void *stream, const snipper_encoder_layer_fwd *a);
+int snipper_encoder_layer_backward(void *stream, const snipper_encoder_layer_bwd *a);
+
 int snipper_layers_abi_version(void);
 /* 1 when the composites take this layer shape, 0 otherwise (then the caller sequences the per-module calls itself). */
 int snipper_decoder_layer_supported(const snipper_decoder_layer_dims *d);

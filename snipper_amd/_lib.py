@@ -140,6 +140,11 @@ EXPORTS = {
     "snipper_decoder_layer_scratch_bytes": ([c_char_p], c_size_t),
     "snipper_decoder_layer_forward": ([c_void_p, c_char_p], c_int),
     "snipper_decoder_layer_backward": ([c_void_p, c_char_p], c_int),
+    "snipper_encoder_layer_supported": ([c_char_p], c_int),
+    "snipper_encoder_layer_arena_bytes": ([c_char_p], c_size_t),
+    "snipper_encoder_layer_scratch_bytes": ([c_char_p, c_void_p, c_void_p], c_size_t),
+    "snipper_encoder_layer_forward": ([c_void_p, c_char_p], c_int),
+    "snipper_encoder_layer_backward": ([c_void_p, c_char_p], c_int),
     "snipper_relu_dropout_backward_bf16": ([c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, ctypes.c_float], c_int),
 }
 

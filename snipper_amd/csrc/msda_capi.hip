@@ -2194,3 +2194,170 @@ int snipper_decoder_layer_backward(void *stream, const snipper_decoder_layer_bwd
 }
 
 }  // extern "C"
+
+// ================================================================================================================
+// Encoder layer composites (include/snipper_layers.h): the launches of DeformableTransformerEncoderLayer.forward_fused
+// (snipper_amd/deformable_transformer.py) and of its autograd nodes' backwards, in their order, from one call each.
+// ================================================================================================================
+namespace {
+struct ElArena { size_t value, raw, loc, prob, vbar, samp, att, s1, st1, keep1, y16, h, z, keep2, total; };
+struct ElScratch { size_t dz2, gh, dxf, dz1, dsamp, gv, gl, ga, gval, graw, ws_ln, ws_wg, ws_msda, total; size_t ln_bytes, wg_bytes; long long msda_bytes; };
+inline bool el_dims_ok(const snipper_encoder_layer_dims *d) {
+  if (!d || d->struct_bytes != (int32_t)sizeof(snipper_encoder_layer_dims)) return false;
+  if (d->bs <= 0 || d->frames <= 0 || d->frames > 4 || d->S <= 0 || d->C <= 0 || d->C % 64 || d->heads <= 0 || d->C % d->heads) return false;
+  if (d->C / d->heads != kD48 || d->d_ffn <= 0 || d->d_ffn % 128 || d->levels <= 0 || d->levels > 4 || d->points != 4) return false;
+  if ((d->heads & (d->heads - 1)) || d->heads > 64) return false;
+  const long long R = (long long)d->bs * d->frames * d->S;
+  if (R < 8192 || R * d->d_ffn >= (1LL << 32) || R * d->C >= (1LL << 31)) return false;
+  if (!snipper_linear_wres_supported((int)R, d->C, d->C) || !snipper_linear_wide_supported(R, d->C, d->d_ffn)) return false;
+  for (float p : {d->p_norm1, d->p_ffn, d->p_norm2})
+    if (!(p >= 0.f && p < 1.f)) return false;
+  return true;
+}
+inline ElArena el_arena(const snipper_encoder_layer_dims &d) {
+  const size_t R = (size_t)d.bs * d.frames * d.S, C = d.C, nlp = (size_t)d.heads * d.levels * d.points;
+  ElArena a{};
+  size_t o = 0;
+  auto take = [&](size_t bytes) { const size_t at = o; o += dl_up(bytes); return at; };
+  a.value = take(R * C * 2); a.raw = take(R * 3 * nlp * 2);
+  a.loc = take(R * nlp * 2 * 4); a.prob = take(R * nlp * 4);
+  a.vbar = take(R * C * 2); a.samp = take(R * C * 2); a.att = take(R * C * 2);
+  a.s1 = take(R * C * 4); a.st1 = take(2 * R * 4); a.keep1 = take(R * C / 4);
+  a.y16 = take(R * C * 2); a.h = take(R * (size_t)d.d_ffn * 2); a.z = take(R * C * 2); a.keep2 = take(R * C / 4);
+  a.total = o;
+  return a;
+}
+inline ElScratch el_scratch(const snipper_encoder_layer_dims &d, const snipper_msda_config *cfg, const int64_t *host_shapes) {
+  const size_t R = (size_t)d.bs * d.frames * d.S, C = d.C, nlp = (size_t)d.heads * d.levels * d.points;
+  ElScratch s{};
+  size_t o = 0;
+  auto take = [&](size_t bytes) { const size_t at = o; o += dl_up(bytes); return at; };
+  s.dz2 = take(R * C * 2); s.gh = take(R * (size_t)d.d_ffn * 2); s.dxf = take(R * C * 2); s.dz1 = take(R * C * 2);
+  s.dsamp = take(R * C * 2); s.gv = take(R * C * 4); s.gl = take(R * nlp * 2 * 4); s.ga = take(R * nlp * 4);
+  s.gval = take(R * C * 2); s.graw = take(R * 3 * nlp * 2);
+  s.ln_bytes = snipper_add_dropout_layernorm_workspace_bytes((int)R, (int)C);
+  s.wg_bytes = std::max(std::max(snipper_wgrad_workspace_bytes((int)R, (int)C, (int)C), snipper_wgrad_workspace_bytes((int)R, (int)(3 * nlp), (int)C)),
+                        std::max(snipper_wgrad_workspace_bytes((int)R, (int)C, d.d_ffn), snipper_wgrad_workspace_bytes((int)R, d.d_ffn, (int)C)));
+  s.msda_bytes = host_shapes ? snipper_msda_backward_ex_workspace_bytes(cfg, host_shapes, 1, d.bs * d.frames, d.S, d.heads, d.C / d.heads,
+                                                                        d.levels, d.S, d.points) : 0;
+  s.ws_ln = take(s.ln_bytes); s.ws_wg = take(s.wg_bytes); s.ws_msda = take((size_t)std::max(0LL, s.msda_bytes));
+  s.total = o;
+  return s;
+}
+}  // namespace
+
+extern "C" {
+
+int snipper_encoder_layer_supported(const snipper_encoder_layer_dims *d) { return el_dims_ok(d) ? 1 : 0; }
+size_t snipper_encoder_layer_arena_bytes(const snipper_encoder_layer_dims *d) { return el_dims_ok(d) ? el_arena(*d).total : 0; }
+size_t snipper_encoder_layer_scratch_bytes(const snipper_encoder_layer_dims *d, const snipper_msda_config *cfg, const int64_t *host_shapes) {
+  return el_dims_ok(d) ? el_scratch(*d, cfg, host_shapes).total : 0;
+}
+
+int snipper_encoder_layer_forward(void *stream, const snipper_encoder_layer_fwd *a) {
+  if (!a) return SNIPPER_E_NULL;
+  const snipper_encoder_layer_dims &d = a->d;
+  if (!el_dims_ok(&d)) return SNIPPER_E_SHAPE;
+  const snipper_encoder_layer_weights &w = a->w;
+  if (!a->x32 || !a->src16 || !a->q16 || !a->ref || !a->shapes || !a->level_start || !a->inv_w || !a->inv_h || !a->mix || !a->s2 ||
+      !a->mean2 || !a->rstd2 || !a->y16 || !a->arena || (d.last ? !a->y32 : (!a->pos16 || !a->yq16)))
+    return SNIPPER_E_NULL;
+  if (!w.wv || !w.wm || !w.wo || !w.w1 || !w.w2_packed || !w.bv || !w.bm || !w.so_bias || !w.bo || !w.b1 || !w.b2 || !w.norm1_w || !w.norm1_b ||
+      !w.norm2_w || !w.norm2_b)
+    return SNIPPER_E_NULL;
+  const ElArena L = el_arena(d);
+  if (a->arena_bytes < L.total || ((uintptr_t)a->arena & 255)) return SNIPPER_E_SHAPE;
+  unsigned char *ar = (unsigned char *)a->arena;
+  auto H = [&](size_t off) { return (uint16_t *)(ar + off); };
+  auto F = [&](size_t off) { return (float *)(ar + off); };
+  const int R = d.bs * d.frames * d.S, C = d.C, nlp = d.heads * d.levels * d.points, hd = d.C / d.heads;
+  int rc;
+  // value projection; merged offset | logit projection (the offsets' bias stays out: added in float32 by the prologue)
+  if ((rc = snipper_linear_bf16(stream, a->src16, C, w.wv, w.bv, nullptr, 0, H(L.value), C, R, C, C, 0, 0.f, 0))) return rc;
+  if ((rc = snipper_linear_bf16(stream, a->q16, C, w.wm, w.bm, nullptr, 0, H(L.raw), 3 * nlp, R, 3 * nlp, C, 0, 0.f, 0))) return rc;
+  if ((rc = snipper_msda_prologue_forward_ex(stream, H(L.raw), 3 * nlp, H(L.raw) + 2 * nlp, 3 * nlp, 1, w.so_bias, a->ref, a->inv_w, a->inv_h,
+                                             (long long)R * d.heads, d.heads, d.levels, d.points, F(L.loc), F(L.prob))))
+    return rc;
+  // temporal mean of the neighbouring value frames (bf16, head-major when the configuration says so), then the core op on it
+  if ((rc = snipper_temporal_mix_ex(stream, H(L.value), 1, nullptr, 1, a->mix, d.bs, d.frames, d.frames, d.S, C, H(L.vbar), 1, hd, 0, d.head_major)))
+    return rc;
+  if ((rc = snipper_msda_forward_ex(stream, a->cfg, a->host_shapes, H(L.vbar), 1, a->shapes, a->level_start, F(L.loc), F(L.prob),
+                                    d.bs * d.frames, d.S, d.heads, hd, d.levels, d.S, d.points, H(L.samp), 1)))
+    return rc;
+  if ((rc = snipper_linear_bf16(stream, H(L.samp), C, w.wo, w.bo, nullptr, 0, H(L.att), C, R, C, C, 0, 0.f, 0))) return rc;
+  // norm1 (lazy float32 result: only its saved sum is written), feed-forward block, norm2
+  if ((rc = snipper_add_dropout_layernorm_forward_ex(stream, a->x32, 0, a->x_mean, a->x_rstd, a->x_gamma, a->x_beta, H(L.att), 1, nullptr, 0,
+                                                     w.norm1_w, w.norm1_b, R, C, d.p_norm1, d.eps_norm1, d.seed_norm1, F(L.s1), F(L.st1),
+                                                     F(L.st1) + R, ar + L.keep1, nullptr, H(L.y16), nullptr)))
+    return rc;
+  if ((rc = snipper_linear_bf16(stream, H(L.y16), C, w.w1, w.b1, nullptr, 0, H(L.h), d.d_ffn, R, d.d_ffn, C, 1, d.p_ffn, d.seed_ffn))) return rc;
+  if ((rc = snipper_linear_wide_bf16(stream, H(L.h), w.w2_packed, w.b2, H(L.z), R, C, d.d_ffn))) return rc;
+  if ((rc = snipper_add_dropout_layernorm_forward_ex(stream, F(L.s1), 0, F(L.st1), F(L.st1) + R, w.norm1_w, w.norm1_b, H(L.z), 1, a->pos16, 1,
+                                                     w.norm2_w, w.norm2_b, R, C, d.p_norm2, d.eps_norm2, d.seed_norm2, a->s2, a->mean2, a->rstd2,
+                                                     ar + L.keep2, a->y32, a->y16, d.last ? nullptr : a->yq16)))
+    return rc;
+  return SNIPPER_OK;
+}
+
+int snipper_encoder_layer_backward(void *stream, const snipper_encoder_layer_bwd *a) {
+  if (!a) return SNIPPER_E_NULL;
+  const snipper_encoder_layer_dims &d = a->d;
+  if (!el_dims_ok(&d)) return SNIPPER_E_SHAPE;
+  const snipper_encoder_layer_weights &w = a->w;
+  const snipper_encoder_layer_grads &g = a->dw;
+  if ((!a->g32 && !a->g16 && !a->gq16) || !a->src16 || !a->q16 || !a->s2 || !a->mean2 || !a->rstd2 || !a->shapes || !a->level_start ||
+      !a->host_shapes || !a->inv_w || !a->inv_h || !a->mix_t || !a->arena || !a->scratch || !a->d_x32 || !a->d_src16 || !a->d_q16)
+    return SNIPPER_E_NULL;
+  if (!w.wv_t || !w.wm_t || !w.wo_t || !w.w2_t || !w.w1_tpacked || !w.norm1_w || !w.norm2_w) return SNIPPER_E_NULL;
+  for (const float *p : {g.wv, g.bv, g.wm, g.bm, g.wo, g.bo, g.w1, g.b1, g.w2, g.b2, g.norm1_w, g.norm1_b, g.norm2_w, g.norm2_b})
+    if (!p) return SNIPPER_E_NULL;
+  const ElArena L = el_arena(d);
+  const ElScratch S = el_scratch(d, a->cfg, a->host_shapes);
+  if (a->scratch_bytes < S.total || ((uintptr_t)a->scratch & 255) || ((uintptr_t)a->arena & 255) || S.msda_bytes <= 0) return SNIPPER_E_SHAPE;
+  const unsigned char *ar = (const unsigned char *)a->arena;
+  unsigned char *sc = (unsigned char *)a->scratch;
+  auto H = [&](size_t off) { return (const uint16_t *)(ar + off); };
+  auto F = [&](size_t off) { return (const float *)(ar + off); };
+  auto WH = [&](size_t off) { return (uint16_t *)(sc + off); };
+  auto WF = [&](size_t off) { return (float *)(sc + off); };
+  const int R = d.bs * d.frames * d.S, C = d.C, nlp = d.heads * d.levels * d.points, hd = d.C / d.heads;
+  int rc;
+  // norm2: d(saved sum of norm1) stays in d_x32 for the moment (norm1's float32 result was lazy: its consumer's dx IS its g32)
+  if ((rc = snipper_add_dropout_layernorm_backward(stream, a->g32, a->g16, a->gq16, a->s2, a->mean2, a->rstd2, w.norm2_w, ar + L.keep2, R, C,
+                                                   d.p_norm2, a->d_x32, 0, WH(S.dz2), 1, g.norm2_w, g.norm2_b, sc + S.ws_ln, S.ln_bytes)))
+    return rc;
+  // feed-forward block (dense._BigFFN.backward): dW2, gated hidden gradient, dW1, input gradient
+  if ((rc = snipper_wgrad_bf16(stream, WH(S.dz2), C, H(L.h), d.d_ffn, R, C, d.d_ffn, nullptr, g.w2, d.d_ffn, g.b2, 0, sc + S.ws_wg, S.wg_bytes))) return rc;
+  if ((rc = snipper_linear_wres_bf16(stream, WH(S.dz2), C, w.w2_t, C, nullptr, H(L.h), d.d_ffn, 1.f / (1.f - d.p_ffn), WH(S.gh), d.d_ffn, R,
+                                     d.d_ffn, C, 0, 0.f, 0)))
+    return rc;
+  if ((rc = snipper_wgrad_bf16(stream, WH(S.gh), d.d_ffn, H(L.y16), C, R, d.d_ffn, C, nullptr, g.w1, C, g.b1, 0, sc + S.ws_wg, S.wg_bytes))) return rc;
+  if ((rc = snipper_linear_wide_bf16(stream, WH(S.gh), w.w1_tpacked, nullptr, WH(S.dxf), R, C, d.d_ffn))) return rc;
+  // norm1: gradients of its (lazy) float32 result = norm2's dx, of its bf16 result = the feed-forward block's dx
+  if ((rc = snipper_add_dropout_layernorm_backward(stream, a->d_x32, WH(S.dxf), nullptr, F(L.s1), F(L.st1), F(L.st1) + R, w.norm1_w, ar + L.keep1, R,
+                                                   C, d.p_norm1, a->d_x32, 0, WH(S.dz1), 1, g.norm1_w, g.norm1_b, sc + S.ws_ln, S.ln_bytes)))
+    return rc;
+  // output projection (dense._BigLinear.backward: weight gradient, then data gradient on the weight-stationary kernel)
+  if ((rc = snipper_wgrad_bf16(stream, WH(S.dz1), C, H(L.samp), C, R, C, C, nullptr, g.wo, C, g.bo, 0, sc + S.ws_wg, S.wg_bytes))) return rc;
+  if ((rc = snipper_linear_wres_bf16(stream, WH(S.dz1), C, w.wo_t, C, nullptr, nullptr, 0, 1.f, WH(S.dsamp), C, R, C, C, 0, 0.f, 0))) return rc;
+  // core op (owner-computes backward), transposed temporal mix
+  if ((rc = snipper_msda_backward_ex(stream, a->cfg, a->host_shapes, sc + S.ws_msda, S.msda_bytes, WH(S.dsamp), 1, H(L.vbar), 1, a->shapes,
+                                     a->level_start, F(L.loc), F(L.prob), d.bs * d.frames, d.S, d.heads, hd, d.levels, d.S, d.points, WF(S.gv),
+                                     WF(S.gl), WF(S.ga))))
+    return rc;
+  if ((rc = snipper_temporal_mix_ex(stream, WF(S.gv), 0, nullptr, 0, a->mix_t, d.bs, d.frames, d.frames, d.S, C, WH(S.gval), 1, hd, d.head_major, 0)))
+    return rc;
+  // locations / softmax adjoint, merged offset | logit projection (data gradient first: dense._BigLinearPair.backward)
+  if ((rc = snipper_msda_prologue_backward(stream, WF(S.gl), WF(S.ga), F(L.prob), a->inv_w, a->inv_h, (long long)R * d.heads, d.heads, d.levels,
+                                           d.points, WH(S.graw), 3 * nlp, WH(S.graw) + 2 * nlp, 3 * nlp, 1, nullptr)))
+    return rc;
+  if ((rc = snipper_linear_wres_bf16(stream, WH(S.graw), 3 * nlp, w.wm_t, 3 * nlp, nullptr, nullptr, 0, 1.f, a->d_q16, C, R, C, 3 * nlp, 0, 0.f, 0)))
+    return rc;
+  if ((rc = snipper_wgrad_bf16(stream, WH(S.graw), 3 * nlp, a->q16, C, R, 3 * nlp, C, nullptr, g.wm, C, g.bm, 0, sc + S.ws_wg, S.wg_bytes))) return rc;
+  // value projection
+  if ((rc = snipper_wgrad_bf16(stream, WH(S.gval), C, a->src16, C, R, C, C, nullptr, g.wv, C, g.bv, 0, sc + S.ws_wg, S.wg_bytes))) return rc;
+  if ((rc = snipper_linear_wres_bf16(stream, WH(S.gval), C, w.wv_t, C, nullptr, nullptr, 0, 1.f, a->d_src16, C, R, C, C, 0, 0.f, 0))) return rc;
+  return SNIPPER_OK;
+}
+
+}  // extern "C"

@@ -180,6 +180,9 @@ class DecoderLayerFn(Function):
         _lib.check(rc, "snipper_decoder_layer_forward")
         _lib.note_variant()
         ctx.plan, ctx.seeds, ctx.want_q, ctx.ref_shape = plan, seeds, want_q, ref_in.shape
+        # (an output nobody differentiates -- the refined references, loc / prob, the last layer's unused aliases -- must reach the
+        #  backward as None, not as a freshly zero-filled tensor: 26 fill launches per step otherwise)
+        ctx.set_materialize_grads(False)
         ctx.save_for_backward(x_v, x_q, value, shapes, lsi, loc, prob, arena, *params)
         outs = (out.view_as(out), out.view_as(out), out, out_q, new_ref, ref_next, loc, prob)
         ctx.mark_non_differentiable(*[t for t in (new_ref, ref_next, loc, prob) if t is not None])

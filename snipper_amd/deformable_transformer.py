@@ -304,6 +304,7 @@ class DeformableTransformerEncoderLayer(nn.Module, _FFNMixin):
 
     # -- the same layer with the bf16 companions of the residual stream carried along -----------------------
     fused_residual = True        # class-level switch (tests compare both formulations)
+    native = __import__("os").environ.get("SNIPPER_ENC_NATIVE", "1") != "0"     # (A/B aid: 0 = one autograd node per module)
 
     def fused_ok(self, src) -> bool:
         from .fused import ln_fusable
@@ -318,6 +319,19 @@ class DeformableTransformerEncoderLayer(nn.Module, _FFNMixin):
         the fused LayerNorm backward, which adds them to the residual gradient in registers -- no cast, add or
         gradient-accumulation kernels in between.  Returns (src32, src16, q16) of the next layer."""
         from .fused import add_dropout_layer_norm
+        if (self.native and _LN_LAZY and torch.is_grad_enabled() and src32.requires_grad and src32.is_contiguous() and
+                is_no_padding(padding_mask) and src32.dim() == 4 and src16.dtype == torch.bfloat16 and q16.dtype == torch.bfloat16 and
+                (last or (torch.is_tensor(pos16) and pos16.dtype == torch.bfloat16))):
+            # round 6: the whole layer from ONE native call per direction (include/snipper_layers.h, encoder_native.py)
+            from . import encoder_native as EN
+            hw = getattr(spatial_shapes, "_snipper_host", None)
+            if hw is not None and EN.timing_off():
+                bs_, t_, s_, _c = src32.shape
+                plan = EN.make_plan(self, bs_, t_, s_, hw, last)
+                shadows = EN.lookup_shadows(self) if plan is not None else None
+                if shadows is not None:
+                    return EN.layer_forward(self, plan, shadows, src32, src16, q16, pos16, reference_points, spatial_shapes,
+                                            level_start_index, last)
         attended = self.self_attn(q16, reference_points, src16, spatial_shapes, level_start_index, padding_mask)
         # (the float32 result of norm1 feeds norm2's residual only, and -- unless this is the last layer -- norm2's feeds the
         #  next layer's norm1 only: neither is materialised, the consuming kernel recomputes it from the saved pre-norm sum)
@@ -532,7 +546,8 @@ class DeformableTransformerDecoderLayer(nn.Module, _FFNMixin):
         caller), a premixed bf16 memory (DeformableTransformerDecoder._forward), tied Linears, contiguous float32 parameters."""
         pre = getattr(src, "_snipper_premixed", None)
         ca = self.cross_attn
-        if not (self.native and pre is not None and hw is not None and pre.dtype == torch.bfloat16 and pre.dim() == 4 and
+        from .encoder_native import timing_off
+        if not (self.native and timing_off() and pre is not None and hw is not None and pre.dtype == torch.bfloat16 and pre.dim() == 4 and
                 ca.weights_are_tied() and not ca.use_pytroch_deform and ca.fused_elementwise):
             return None
         bs, t, lq, c = shape

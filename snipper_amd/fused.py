@@ -622,6 +622,7 @@ class SmallLayerNorm(Function):
         _lib.check(rc, "snipper_small_ln_forward_f32")
         ctx.meta = (p, x.shape, z is not None, pos is not None, n_alias)
         ctx.save_for_backward(s_save, stats, keep, gamma)
+        ctx.set_materialize_grads(False)               # (an unused alias costs nothing: its gradient arrives as None)
         outs = tuple(y.view_as(y) for _ in range(n_alias))
         return outs + ((yq,) if yq is not None else ())
 
