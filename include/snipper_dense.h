@@ -75,7 +75,8 @@ int snipper_hbm_copy_probe(void *stream, const void *src, void *dst, long long b
  * a dropped or inactive one y == 0, so grad_pre = y > 0 ? grad_y / (1 - p) : 0 (p = 0: plain ReLU backward).
  * bf16 bits, n % 8 == 0, 16-byte aligned. */
 /* The decoder's dense self-attention (reference models/deformable_transformer.py:282-287: nn.MultiheadAttention over the
- * nq * T object queries of a sample) for L <= 256 queries and heads of 48 or 32 channels, one launch each way:
+ * nq * T object queries of a sample) for L <= 384 queries (up to 256: K and V staged side by side; beyond: one row buffer
+ * staged twice, 32 queries per workgroup) and heads of 48 or 32 channels, one launch each way:
  *   out[b,i,h,:] = sum_j dropout(softmax_j(scale * q[b,i,h,:] . k[b,j,h,:]))[j] * v[b,j,h,:]
  * Element (b, i, h, e) of q / k / v / out / their gradients is at base + b * X_bs + i * X_ld + h * hd + e (so q and k
  * may be the two halves of a packed projection output and the gradients may be written into the halves of its

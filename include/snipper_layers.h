@@ -14,7 +14,7 @@
  * Conventions as snipper_msda.h: device pointers unless marked HOST, `stream` = hipStream_t as void*, returns 0 or the first
  * non-zero code of a constituent call, no allocation, no host synchronisation, no global state.
  *
- * Scope: float32 decoder rows (R = bs * tokens <= 16384), heads of 32 or 48 channels, tokens <= 256, tied offset / weight
+ * Scope: float32 decoder rows (R = bs * tokens <= 16384), heads of 32 or 48 channels, tokens <= 384, tied offset / weight
  * Linears, the cross attention's VALUE already projected by the caller ([N = bs * frames, S, heads, C / heads] bfloat16 or
  * float32: the projection of the 79 000 memory rows is a full-size product that belongs with the encoder-size kernels).
  */

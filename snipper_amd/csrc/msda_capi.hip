@@ -836,7 +836,7 @@ namespace {
 int small_attn_check(const void *q, long long q_ld, const void *k, long long k_ld, const void *v, long long v_ld,
                      const void *o, long long o_ld, const void *P, int bs, int H, int L, int hd, float p) {
   if (!q || !k || !v || !o || !P) return SNIPPER_E_NULL;
-  if (bs <= 0 || H <= 0 || L <= 0 || L > kSaMaxL || (hd != 48 && hd != 32) || (q_ld | k_ld | v_ld | o_ld) % 4 ||
+  if (bs <= 0 || H <= 0 || L <= 0 || L > kSaMaxL2 || (hd != 48 && hd != 32) || (q_ld | k_ld | v_ld | o_ld) % 4 ||
       !(p >= 0.f && p < 1.f) || (long long)bs * H * L * L >= (1LL << 32))
     return SNIPPER_E_SHAPE;
   if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o) & 15) return SNIPPER_E_SHAPE;
@@ -951,6 +951,12 @@ int snipper_small_attention_forward_f32(void *stream, const float *q, long long 
   a.q = q; a.q_ld = q_ld; a.q_bs = q_bs; a.k = k; a.k_ld = k_ld; a.k_bs = k_bs; a.v = v; a.v_ld = v_ld; a.v_bs = v_bs;
   a.out = out; a.o_ld = o_ld; a.o_bs = o_bs; a.P = P; a.bs = bs; a.H = H; a.L = L; a.scale = scale; a.drop_p = dropout_p;
   a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32);
+  if (L > kSaMaxL) {          // 257 .. 384 queries: one row buffer staged twice, 32 rows per workgroup (csrc/small_attention.cuh)
+    const dim3 grid2((unsigned)(bs * H * ((L + kSaRows2 - 1) / kSaRows2)));
+    if (hd == 48) hipLaunchKernelGGL(small_attn_fwd_seq_kernel<48>, grid2, dim3(kSaThreads2), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(small_attn_fwd_seq_kernel<32>, grid2, dim3(kSaThreads2), 0, (hipStream_t)stream, a);
+    return launch_status();
+  }
   const dim3 grid((unsigned)(bs * H * ((L + kSaRows - 1) / kSaRows)));
   if (hd == 48) hipLaunchKernelGGL(small_attn_fwd_kernel<48>, grid, dim3(kSaThreads), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL(small_attn_fwd_kernel<32>, grid, dim3(kSaThreads), 0, (hipStream_t)stream, a);
@@ -976,6 +982,12 @@ int snipper_small_attention_backward_f32(void *stream, const float *q, long long
   a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32);
   // 16 rows per workgroup while that is one residency round (one 140-KB workgroup per CU), 32 rows (512 threads) beyond: at the
   // decoder's L = 240 the 480 sixteen-row workgroups were two rounds (csrc/small_attention.cuh)
+  if (L > kSaMaxL) {
+    const dim3 grid2((unsigned)(bs * H * 2 * ((L + kSaRows2 - 1) / kSaRows2)));
+    if (hd == 48) hipLaunchKernelGGL(small_attn_bwd_seq_kernel<48>, grid2, dim3(kSaThreads2), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(small_attn_bwd_seq_kernel<32>, grid2, dim3(kSaThreads2), 0, (hipStream_t)stream, a);
+    return launch_status();
+  }
   static const int forced_rows = [] { const char *e = getenv("SNIPPER_SMALL_ATTN_ROWS"); return e ? atoi(e) : 0; }();      // (A/B aid)
   const int wg16 = bs * H * 2 * ((L + 15) / 16);
   const int rows = forced_rows == 16 || forced_rows == 32 ? forced_rows : (wg16 > device_cu_count() ? 32 : 16);
@@ -1972,7 +1984,7 @@ inline bool dl_dims_ok(const snipper_decoder_layer_dims *d) {
   if (d->bs <= 0 || d->tokens <= 0 || d->frames <= 0 || d->queries <= 0 || d->frames * d->queries != d->tokens) return false;
   if (d->C <= 0 || d->C % 4 || d->C > kLnMaxIter * 256 || d->heads <= 0 || d->C % d->heads) return false;
   const int hd = d->C / d->heads;
-  if ((hd != 32 && hd != 48) || d->tokens > kSaMaxL || (long long)d->bs * d->tokens > kSmallLnMaxRows) return false;
+  if ((hd != 32 && hd != 48) || d->tokens > kSaMaxL2 || (long long)d->bs * d->tokens > kSmallLnMaxRows) return false;
   if (d->d_ffn <= 0 || d->d_ffn % 4 || d->levels <= 0 || d->levels > 8 || d->points <= 0 || d->levels * d->points > 16) return false;
   if ((d->heads & (d->heads - 1)) || d->heads > 64 || d->S <= 0) return false;
   if ((d->heads * d->levels * d->points * 2) % 32) return false;       // (the pair's stacked-weight product splits there)

@@ -15,7 +15,8 @@
 //             probabilities for its keys, then dK_j = scale * sum_i dS_ij Q_i and dV_j = sum_i Pd_ij dO_i.
 // Dropout: counter-based hash of (seed, element index) as in gemm_bf16.cuh.  q / k are the two halves of the packed
 // projection output [bs, L, 2E] and are read (and their gradients written) in place through strides.
-// L <= kSaMaxL, head dimension = HD (48 or 32); anything else takes the library path in Python.
+// L <= kSaMaxL (one staging of both row sets) or <= kSaMaxL2 (sequential staging, below), head dimension = HD (48 or 32);
+// anything else takes the library path in Python.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -280,6 +281,203 @@ __global__ __launch_bounds__(ROWS * 16) void small_attn_bwd_kernel(SmallAttnArgs
   __syncthreads();
   if (c >= kLanes) return;
   sa_combine<HD>(av, S.p[grp], S.a, L4, c);                          // dV_j = sum_i Pd_ij dO_i
+  if (x_ok) {
+    *reinterpret_cast<float4 *>(g.dk + b * g.dk_bs + (long long)x0 * g.dk_ld + h * HD + 4 * c) =
+        make_float4(ak[0], ak[1], ak[2], ak[3]);
+    *reinterpret_cast<float4 *>(g.dv + b * g.dv_bs + (long long)x0 * g.dv_ld + h * HD + 4 * c) =
+        make_float4(av[0], av[1], av[2], av[3]);
+  }
+}
+
+
+// ---- 256 < L <= 384 (round 6: the forecast model's 360 object queries, 60 queries x (4 + 2) frames, reference main.py:88-96) --
+// K and V of 384 keys do not fit the LDS side by side (2 x 80 KB + the coefficient rows): ONE row buffer is staged twice --
+// K for the scores, then V for the combination (forward); V / K, or dO / Q (backward) -- with 32 rows per 512-thread workgroup.
+// The column kind of the backward needs dO twice (scores, dV) and Q once (dK): it keeps its dS values in registers while the
+// dropped probabilities sit in the coefficient row for dV, then swaps.  Same arithmetic, same dropout stream, same saved
+// probabilities as the kernels above; the library's fused attention took 63 + 59 + 56 us per decoder layer at this size.
+constexpr int kSaMaxL2 = 384, kSaRows2 = 32, kSaThreads2 = kSaRows2 * 16;
+
+template <int HD> struct SaLds2 {
+  static constexpr int kPad = HD + 4;
+  float buf[kSaMaxL2 * kPad];
+  float p[kSaRows2][kSaMaxL2];
+  float delta[kSaMaxL2];
+};
+
+template <int HD>
+__device__ __forceinline__ void sa_stage2(float *dst, const float *src, long long ld, int L, int tid) {
+  constexpr int kPad = HD + 4, kV = HD / 4, kIter = (kSaMaxL2 * kV + kSaThreads2 - 1) / kSaThreads2;
+  const int L4 = (L + 3) & ~3;
+  float4 t[kIter];
+#pragma unroll
+  for (int it = 0; it < kIter; ++it) {
+    const int x = tid + it * kSaThreads2;
+    const int r = x / kV, c = x - r * kV;
+    t[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < L) t[it] = *reinterpret_cast<const float4 *>(src + (long long)r * ld + 4 * c);
+  }
+#pragma unroll
+  for (int it = 0; it < kIter; ++it) {
+    const int x = tid + it * kSaThreads2;
+    const int r = x / kV, c = x - r * kV;
+    if (r < L4) *reinterpret_cast<float4 *>(dst + r * kPad + 4 * c) = t[it];
+  }
+}
+
+template <int HD>
+__global__ __launch_bounds__(kSaThreads2) void small_attn_fwd_seq_kernel(SmallAttnArgs g) {
+  __shared__ SaLds2<HD> S;
+  constexpr int kPad = HD + 4, kLanes = HD / 4;
+  const int tid = threadIdx.x, grp = tid >> 4, c = tid & 15;
+  const int L4 = (g.L + 3) & ~3;
+  const int nblk = (g.L + kSaRows2 - 1) / kSaRows2;
+  const int blk = blockIdx.x % nblk, bh = blockIdx.x / nblk, h = bh % g.H, b = bh / g.H;
+  const int i = blk * kSaRows2 + grp;
+  const bool row_ok = i < g.L;
+  sa_stage2<HD>(S.buf, g.k + b * g.k_bs + h * HD, g.k_ld, g.L, tid);
+  float qv[HD];
+  {
+    const float *qp = g.q + b * g.q_bs + (long long)(row_ok ? i : 0) * g.q_ld + h * HD;
+#pragma unroll
+    for (int e = 0; e < HD; e += 4) {
+      const float4 t = *reinterpret_cast<const float4 *>(qp + e);
+      qv[e] = t.x * g.scale; qv[e + 1] = t.y * g.scale; qv[e + 2] = t.z * g.scale; qv[e + 3] = t.w * g.scale;
+    }
+  }
+  __syncthreads();
+  float mx = -INFINITY;
+  for (int j = c; j < g.L; j += 16) {
+    const float *kr = S.buf + j * kPad;
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < HD; e += 4) {
+      const float4 t = *reinterpret_cast<const float4 *>(kr + e);
+      s = fmaf(qv[e], t.x, s); s = fmaf(qv[e + 1], t.y, s); s = fmaf(qv[e + 2], t.z, s); s = fmaf(qv[e + 3], t.w, s);
+    }
+    S.p[grp][j] = s;
+    mx = fmaxf(mx, s);
+  }
+  __syncthreads();                                  // every group has read K: the buffer may take V
+  sa_stage2<HD>(S.buf, g.v + b * g.v_bs + h * HD, g.v_ld, g.L, tid);
+  mx = sa_row16_max(mx);
+  float sum = 0.f;
+  for (int j = c; j < g.L; j += 16) {
+    const float e = __expf(S.p[grp][j] - mx);
+    S.p[grp][j] = e;
+    sum += e;
+  }
+  sum = sa_row16_sum(sum);
+  const float inv = 1.f / sum;
+  const float keep_scale = g.drop_p > 0.f ? 1.f / (1.f - g.drop_p) : 1.f;
+  const uint32_t thresh = (uint32_t)fminf(g.drop_p * 4294967296.f, 4294967040.f);
+  float *Prow = g.P + ((long long)bh * g.L + (row_ok ? i : 0)) * g.L;
+  for (int j = c; j < g.L; j += 16) {
+    const float p = S.p[grp][j] * inv;
+    if (row_ok) Prow[j] = p;
+    S.p[grp][j] = p * sa_keep(g, thresh, keep_scale, bh, i, j);
+  }
+  if (c < L4 - g.L) S.p[grp][g.L + c] = 0.f;
+  __syncthreads();
+  float o[4] = {0.f, 0.f, 0.f, 0.f};
+  if (c < kLanes) sa_combine<HD>(o, S.p[grp], S.buf, L4, c);
+  if (row_ok && c < kLanes)
+    *reinterpret_cast<float4 *>(g.out + b * g.o_bs + (long long)i * g.o_ld + h * HD + 4 * c) = make_float4(o[0], o[1], o[2], o[3]);
+}
+
+template <int HD>
+__global__ __launch_bounds__(kSaThreads2) void small_attn_bwd_seq_kernel(SmallAttnArgs g) {
+  __shared__ SaLds2<HD> S;
+  constexpr int kPad = HD + 4, kLanes = HD / 4;
+  const int tid = threadIdx.x, grp = tid >> 4, c = tid & 15;
+  const int L4 = (g.L + 3) & ~3;
+  const int nblk = (g.L + kSaRows2 - 1) / kSaRows2;
+  const int per_bh = 2 * nblk;
+  const int bh = blockIdx.x / per_bh, r = blockIdx.x % per_bh, h = bh % g.H, b = bh / g.H;
+  const bool col_kind = r >= nblk;
+  const int x0 = (col_kind ? r - nblk : r) * kSaRows2 + grp;
+  const bool x_ok = x0 < g.L;
+  const float keep_scale = g.drop_p > 0.f ? 1.f / (1.f - g.drop_p) : 1.f;
+  const uint32_t thresh = (uint32_t)fminf(g.drop_p * 4294967296.f, 4294967040.f);
+  const float *dO = g.dout + b * g.do_bs + h * HD;
+  const float *O = g.out + b * g.o_bs + h * HD;
+  for (int i = tid; i < g.L; i += kSaThreads2) {
+    float d = 0.f;
+#pragma unroll
+    for (int e = 0; e < HD; e += 4) {
+      const float4 a4 = *reinterpret_cast<const float4 *>(dO + (long long)i * g.do_ld + e);
+      const float4 b4 = *reinterpret_cast<const float4 *>(O + (long long)i * g.o_ld + e);
+      d = fmaf(a4.x, b4.x, d); d = fmaf(a4.y, b4.y, d); d = fmaf(a4.z, b4.z, d); d = fmaf(a4.w, b4.w, d);
+    }
+    S.delta[i] = d;
+  }
+  // the rows scored against this group's vector: V (row kind: against dO_i) or dO (column kind: against V_j)
+  sa_stage2<HD>(S.buf, col_kind ? dO : g.v + b * g.v_bs + h * HD, col_kind ? g.do_ld : g.v_ld, g.L, tid);
+  float xv[HD];
+  {
+    const float *p = col_kind ? g.v + b * g.v_bs + (long long)(x_ok ? x0 : 0) * g.v_ld + h * HD : dO + (long long)(x_ok ? x0 : 0) * g.do_ld;
+#pragma unroll
+    for (int e = 0; e < HD; e += 4) {
+      const float4 t = *reinterpret_cast<const float4 *>(p + e);
+      xv[e] = t.x; xv[e + 1] = t.y; xv[e + 2] = t.z; xv[e + 3] = t.w;
+    }
+  }
+  __syncthreads();
+  const float *Pbh = g.P + (long long)bh * g.L * g.L;
+  constexpr int kPer = kSaMaxL2 / 16;
+  float pv[kPer], dsv[kPer];
+#pragma unroll
+  for (int t = 0; t < kPer; ++t) {
+    const int y = c + 16 * t;
+    const int i = col_kind ? y : x0, j = col_kind ? x0 : y;
+    pv[t] = (x_ok && y < g.L) ? Pbh[(long long)i * g.L + j] : 0.f;
+    dsv[t] = 0.f;
+  }
+#pragma unroll
+  for (int t = 0; t < kPer; ++t) {
+    const int y = c + 16 * t;
+    if (y < g.L) {
+      const float *yr = S.buf + y * kPad;
+      float dot = 0.f;
+#pragma unroll
+      for (int e = 0; e < HD; e += 4) {
+        const float4 v4 = *reinterpret_cast<const float4 *>(yr + e);
+        dot = fmaf(xv[e], v4.x, dot); dot = fmaf(xv[e + 1], v4.y, dot); dot = fmaf(xv[e + 2], v4.z, dot); dot = fmaf(xv[e + 3], v4.w, dot);
+      }
+      const int i = col_kind ? y : x0, j = col_kind ? x0 : y;
+      const float p = pv[t];
+      const float ks = sa_keep(g, thresh, keep_scale, bh, i, j);
+      dsv[t] = p * (ks * dot - S.delta[i]) * g.scale;
+      pv[t] = p * ks;
+      S.p[grp][y] = col_kind ? pv[t] : dsv[t];      // column kind: the dropped probabilities first (dV combines them with dO)
+    }
+  }
+  if (c < L4 - g.L) S.p[grp][g.L + c] = 0.f;
+  __syncthreads();
+  if (!col_kind) {
+    // row kind: the buffer takes K for dQ_i = scale * sum_j dS_ij K_j (every group has finished reading V)
+    sa_stage2<HD>(S.buf, g.k + b * g.k_bs + h * HD, g.k_ld, g.L, tid);
+    __syncthreads();
+    if (c >= kLanes) return;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    sa_combine<HD>(acc, S.p[grp], S.buf, L4, c);
+    if (x_ok)
+      *reinterpret_cast<float4 *>(g.dq + b * g.dq_bs + (long long)x0 * g.dq_ld + h * HD + 4 * c) =
+          make_float4(acc[0], acc[1], acc[2], acc[3]);
+    return;
+  }
+  float ak[4] = {0.f, 0.f, 0.f, 0.f}, av[4] = {0.f, 0.f, 0.f, 0.f};
+  if (c < kLanes) sa_combine<HD>(av, S.p[grp], S.buf, L4, c);            // dV_j = sum_i Pd_ij dO_i
+  __syncthreads();                                                        // dO and the Pd rows have been read by every lane
+  sa_stage2<HD>(S.buf, g.q + b * g.q_bs + h * HD, g.q_ld, g.L, tid);     // Q rows for dK
+#pragma unroll
+  for (int t = 0; t < kPer; ++t) {
+    const int y = c + 16 * t;
+    if (y < g.L) S.p[grp][y] = dsv[t];
+  }
+  __syncthreads();
+  if (c >= kLanes) return;
+  sa_combine<HD>(ak, S.p[grp], S.buf, L4, c);                            // dK_j = scale * sum_i dS_ij Q_i
   if (x_ok) {
     *reinterpret_cast<float4 *>(g.dk + b * g.dk_bs + (long long)x0 * g.dk_ld + h * HD + 4 * c) =
         make_float4(ak[0], ak[1], ak[2], ak[3]);

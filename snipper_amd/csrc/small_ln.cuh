@@ -25,7 +25,7 @@ namespace snipper {
 
 constexpr int kSmallLnMaxSrc = 4;
 constexpr int kSmallLnMaxRows = 16384;     // above this the encoder-size pair (csrc/ln_fused.cuh) is the right tool
-constexpr int kSmallLnColsPerWg = 16;      // columns per column-workgroup: 16 columns x 16 row slices = 256 threads
+constexpr int kSmallLnColsPerWg = 4;       // columns per column-workgroup: one float4 chunk x 256 row slices
 
 struct SmallLnFwdArgs {
   const float *x, *z, *pos;          // [rows][C]; z, pos may be nullptr
@@ -124,7 +124,7 @@ __device__ __forceinline__ float4 small_ln_gsum(const SmallLnBwdArgs &a, long lo
 }
 
 // blocks [0, row_blocks): one wave per row -> dx, dz.  blocks [row_blocks, ...): kSmallLnColsPerWg columns each -> dgamma, dbeta
-// (16 row slices x 16 columns; the slices meet in LDS in a fixed order).
+// (256 row slices; the slices meet by wave shuffles and LDS in a fixed order).
 __global__ __launch_bounds__(kLnThreads) void small_ln_bwd_kernel(SmallLnBwdArgs a) {
   if ((int)blockIdx.x < a.row_blocks) {
     const int lane = threadIdx.x & 63;
@@ -172,13 +172,17 @@ __global__ __launch_bounds__(kLnThreads) void small_ln_bwd_kernel(SmallLnBwdArgs
     }
     return;
   }
-  // ---- column workgroups: thread = (row slice, 4-column chunk): 4 chunks x 64 slices
-  __shared__ float red[2][64][kSmallLnColsPerWg + 1];
-  const int chunk = threadIdx.x & 3, slice = threadIdx.x >> 2;             // 64 slices of rows
-  const int c0 = ((int)blockIdx.x - a.row_blocks) * kSmallLnColsPerWg + chunk * 4;
+  // ---- column workgroups: 4 columns each, thread = row slice (256 slices): at 480 rows a thread sums TWO rows -- the first
+  // version (16 columns x 64 slices) walked 8 rows per thread, eight dependent global round trips in a latency-bound launch:
+  // 12 us per launch against 6 for the row part alone.  The slices meet by wave shuffles, then the four waves through LDS, in a
+  // fixed order.
+  __shared__ float red[kLnThreads / 64][8];
+  const int slice = threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c0 = ((int)blockIdx.x - a.row_blocks) * kSmallLnColsPerWg;
   float4 dg = make_float4(0.f, 0.f, 0.f, 0.f), db = dg;
   if (c0 < a.C)
-    for (int row = slice; row < a.rows; row += 64) {
+#pragma unroll 2
+    for (int row = slice; row < a.rows; row += kLnThreads) {
       const long long e = (long long)row * a.C + c0;
       const float4 g = small_ln_gsum(a, e);
       const float4 s = *reinterpret_cast<const float4 *>(a.s_save + e);
@@ -187,18 +191,19 @@ __global__ __launch_bounds__(kLnThreads) void small_ln_bwd_kernel(SmallLnBwdArgs
       dg.z += g.z * ((s.z - mean) * rstd); dg.w += g.w * ((s.w - mean) * rstd);
       db.x += g.x; db.y += g.y; db.z += g.z; db.w += g.w;
     }
-  red[0][slice][chunk * 4 + 0] = dg.x; red[0][slice][chunk * 4 + 1] = dg.y; red[0][slice][chunk * 4 + 2] = dg.z; red[0][slice][chunk * 4 + 3] = dg.w;
-  red[1][slice][chunk * 4 + 0] = db.x; red[1][slice][chunk * 4 + 1] = db.y; red[1][slice][chunk * 4 + 2] = db.z; red[1][slice][chunk * 4 + 3] = db.w;
+  float v8[8] = {dg.x, dg.y, dg.z, dg.w, db.x, db.y, db.z, db.w};
+#pragma unroll
+  for (int k = 0; k < 8; ++k) v8[k] = ln_wave_sum(v8[k]);
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) red[wave][k] = v8[k];
+  }
   __syncthreads();
-  if (threadIdx.x < 2 * kSmallLnColsPerWg) {
-    const int which = threadIdx.x / kSmallLnColsPerWg, ci = threadIdx.x % kSmallLnColsPerWg;
-    const int c = ((int)blockIdx.x - a.row_blocks) * kSmallLnColsPerWg + ci;
-    if (c < a.C) {
-      float sum = 0.f;
-#pragma unroll 8
-      for (int k = 0; k < 64; ++k) sum += red[which][k][ci];
-      (which ? a.dbeta : a.dgamma)[c] = sum;
-    }
+  if (threadIdx.x < 8 && c0 + (int)(threadIdx.x & 3) < a.C) {
+    float sum = 0.f;
+#pragma unroll
+    for (int w = 0; w < kLnThreads / 64; ++w) sum += red[w][threadIdx.x];
+    (threadIdx.x >= 4 ? a.dbeta : a.dgamma)[c0 + (threadIdx.x & 3)] = sum;
   }
 }
 

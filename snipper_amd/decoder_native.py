@@ -101,10 +101,12 @@ def layer_params(layer):
 _PLANS: dict = {}
 
 
-def make_plan(layer, bs, frames, queries, C, S, hw, value_dtype):
-    """LayerPlan for this layer and geometry, or None when the native composites do not take the shape."""
+def make_plan(layer, bs, frames, queries, C, S, hw, value_dtype, value_frames=None):
+    """LayerPlan for this layer and geometry, or None when the native composites do not take the shape.  ``frames`` = query
+    frames (T + F for the forecast model), ``value_frames`` = frames of the memory (T; default: ``frames``)."""
     training = layer.training
-    key = (id(layer), bs, frames, queries, C, S, tuple(hw), value_dtype, training,
+    value_frames = frames if value_frames is None else value_frames
+    key = (id(layer), bs, frames, value_frames, queries, C, S, tuple(hw), value_dtype, training,
            layer.dropout1.p, layer.dropout2.p, layer.dropout3.p, layer.dropout4.p, layer.self_attn.dropout)
     plan = _PLANS.get(key)
     if plan is not None:
@@ -136,7 +138,7 @@ def make_plan(layer, bs, frames, queries, C, S, hw, value_dtype):
     plan.hs = (ctypes.c_int64 * (2 * L))(*[int(v) for p_ in hw for v in p_])
     plan.inv_w_p, plan.inv_h_p, plan.hs_p = (ctypes.addressof(plan.inv_w), ctypes.addressof(plan.inv_h), ctypes.addressof(plan.hs))
     from .ms_deform_attn import frame_neighbours
-    plan.groups = [frame_neighbours(t1, ca.n_frame, frames) for t1 in range(frames)]
+    plan.groups = [frame_neighbours(t1, ca.n_frame, value_frames) for t1 in range(frames)]
     if len(_PLANS) > 64:
         _PLANS.clear()
     _PLANS[key] = plan

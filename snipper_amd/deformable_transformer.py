@@ -227,7 +227,7 @@ class _SmallAttention(_Fn):
         return dqk, dv, None, None
 
 
-SMALL_ATTENTION_MAX_L = 256       # csrc/small_attention.cuh: kSaMaxL
+SMALL_ATTENTION_MAX_L = 384       # csrc/small_attention.cuh: kSaMaxL2 (up to 256: both row sets staged at once)
 
 
 def _self_attention(mha: nn.MultiheadAttention, x_qk, x_v):
@@ -556,7 +556,7 @@ class DeformableTransformerDecoderLayer(nn.Module, _FFNMixin):
         from .decoder_native import layer_params, make_plan
         if not all(p.dtype == torch.float32 and p.is_contiguous() and p.data_ptr() % 16 == 0 for p in layer_params(self)):
             return None
-        return make_plan(self, bs, t, lq, c, int(pre.shape[2]), hw, torch.bfloat16)
+        return make_plan(self, bs, t, lq, c, int(pre.shape[2]), hw, torch.bfloat16, int(src.shape[1]))
 
     def forward_native(self, plan, state, pos_a, pos_b, ref_in, ref_points, valid_ratios, src, shapes, lsi, root_lin, shape,
                        last: bool):
@@ -629,7 +629,11 @@ class DeformableTransformerDecoder(nn.Module):
             t_q, t_v = query_obj.shape[1], twin.shape[1]
             att0 = self.layers[0].cross_attn
             from .dense import BIG_LINEAR_MIN_ROWS
-            premix = (_DEC_PREMIX and is_no_padding(src_padding_mask) and t_q == t_v and twin.dim() == 4 and
+            # (round 6: forecast query frames -- t_q = T + F > t_v = T, reference ms_deform_attn.py:184-223 -- sample the mean of
+            #  ALL value frames: their rows of the mix sum to 1 like everybody's, so the identity holds; the premixed memory then
+            #  has t_q frames, 1.5 x the rows to project at T = 4 + 2, which still beats a temporal mix + float32 atomic backward
+            #  per layer)
+            premix = (_DEC_PREMIX and is_no_padding(src_padding_mask) and t_q >= t_v and t_q <= 8 and twin.dim() == 4 and
                       twin.numel() // twin.shape[-1] >= BIG_LINEAR_MIN_ROWS and         # (the bf16 GEMM path projects the mean)
                       all(getattr(l.cross_attn, "weights_are_tied", lambda: False)() and l.cross_attn.n_frame == t_v and
                           not l.cross_attn.use_pytroch_deform and l.cross_attn.d_model // l.cross_attn.n_heads == 48

@@ -320,7 +320,8 @@ class FlatGradSync:
                     self._err_event.record()
                 else:
                     self._err_event = _DoneEvent()
-            self.flat.mul_(1.0 / self.world)
+            if self.world > 1:                    # (a forced 1-rank group -- the single-GPU test of this path -- has nothing to average)
+                self.flat.mul_(1.0 / self.world)
         else:
             for i in local_late:
                 self.views[i].copy_(self.params[i].grad)

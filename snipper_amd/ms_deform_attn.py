@@ -183,7 +183,7 @@ class MSDeformAttn(nn.Module):
                 pre.shape == (N, T1, S, C) and self._fusable(query, reference_points, None)):
             # the caller has already taken the temporal mean of the (unpadded) memory frames, the same for every decoder layer
             # (DeformableTransformerDecoder._forward): project the mean and sample the projection as it is
-            out, locs, wts = self._forward_premixed(query, reference_points, pre, shapes, input_level_start_index, hw)
+            out, locs, wts = self._forward_premixed(query, reference_points, pre, shapes, input_level_start_index, hw, T2)
             out = big_linear(out, self.output_proj)
             return (out, (locs, wts)) if self.attention_vis else out
 
@@ -278,7 +278,7 @@ class MSDeformAttn(nn.Module):
         out = out.view(N, T1, Lq, C)
         return out, *self._vis_lists(loc, prob, groups, N, Lq, M, L, P)
 
-    def _forward_premixed(self, query, ref, xbar, shapes, lsi, hw):
+    def _forward_premixed(self, query, ref, xbar, shapes, lsi, hw, value_frames=None):
         """Tied module core on a memory whose temporal mean has been taken already: value = value_proj(xbar) IS the sampled
         tensor (mask fill, mean and projection commute when nothing is padded: the mix rows sum to 1)."""
         from .fused import MSDAPrologue
@@ -301,7 +301,7 @@ class MSDeformAttn(nn.Module):
                                          False, query.dtype == torch.float32 and value.dtype == torch.bfloat16)
         if out.dtype != query.dtype:
             out = out.to(query.dtype)
-        groups = [frame_neighbours(t1, self.n_frame, T1) for t1 in range(T1)]
+        groups = [frame_neighbours(t1, self.n_frame, T1 if value_frames is None else value_frames) for t1 in range(T1)]
         return out.view(N, T1, Lq, C), *self._vis_lists(loc, prob, groups, N, Lq, M, L, P)
 
     def _vis_lists(self, loc, prob, groups, N, Lq, M, L, P):

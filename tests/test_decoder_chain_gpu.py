@@ -160,14 +160,13 @@ def test_float32_rows_beside_a_bf16_value_against_the_oracle():
     assert torch.equal(g1[0], gv) and torch.equal(g1[1], gl) and torch.equal(g1[2], ga)
 
 
-@pytest.mark.parametrize("future", [0, 2])
-def test_decoder_chain_equals_the_node_per_module_decoder(future):
+@pytest.mark.parametrize("future,T,nq", [(0, 3, 20), (2, 3, 20), (2, 4, 60)])          # (the last: 360 object queries, BASELINE configs[4])
+def test_decoder_chain_equals_the_node_per_module_decoder(future, T, nq):
     """The whole transformer (float32, d_model 384 so that every decoder-size kernel applies, dropout 0 so that both forms
     are deterministic) with the decoder as a chain and as one node per module: outputs, refined references and every
     parameter gradient."""
     from snipper_amd.deformable_transformer import DeformableTransformer, DeformableTransformerDecoderLayer as Layer
     torch.manual_seed(0)
-    T = 3
     tr = DeformableTransformer(d_model=384, nhead=8, num_encoder_layers=1, num_decoder_layers=3, dim_feedforward=512, dropout=0.0,
                                return_intermediate_dec=True, num_feature_levels=3, dec_n_points=4, enc_n_points=4, n_frame=T,
                                n_future_frame=future, num_keypoints=15).to(DEV)
@@ -182,7 +181,7 @@ def test_decoder_chain_equals_the_node_per_module_decoder(future):
                 p.normal_(0, 0.3)
     g = torch.Generator().manual_seed(5)
     hw = [(12, 16), (6, 8), (3, 4)]
-    bs, nq = 2, 20
+    bs = 2
     srcs = [torch.randn(bs, 384, T, h, w, generator=g).to(DEV) for h, w in hw]
     masks = [torch.zeros(bs, 384, T, h, w, dtype=torch.bool, device=DEV) for h, w in hw]
     pos = [torch.randn(bs, 384, T, h, w, generator=g).to(DEV) for h, w in hw]

@@ -431,7 +431,8 @@ def test_inference_style_padded_snippets_at_540x960():
         torch.testing.assert_close(a, b, rtol=2e-3, atol=5e-4)
 
 
-@pytest.mark.parametrize("L,E,H,p", [(240, 384, 8, 0.1), (60, 384, 8, 0.0), (37, 256, 8, 0.25), (256, 384, 8, 0.1)])
+@pytest.mark.parametrize("L,E,H,p", [(240, 384, 8, 0.1), (60, 384, 8, 0.0), (37, 256, 8, 0.25), (256, 384, 8, 0.1),
+                                     (360, 384, 8, 0.1), (384, 384, 8, 0.0), (301, 256, 8, 0.2), (257, 384, 8, 0.1)])
 def test_small_attention_kernel_with_dropout_against_composition(L, E, H, p, monkeypatch):
     """csrc/small_attention.cuh: forward and the one-launch backward against softmax(q k^T / sqrt(hd)) . v written out in
     PyTorch WITH THE KERNEL'S OWN dropout mask.  The mask is recovered by linearity: for a fixed seed the output is
@@ -473,7 +474,8 @@ def test_small_attention_kernel_with_dropout_against_composition(L, E, H, p, mon
         torch.testing.assert_close(a, b, rtol=1e-3, atol=2e-5 * float(b.abs().max()) + 1e-6)
 
 
-def test_decoder_premixed_memory_path_equals_the_per_layer_path():
+@pytest.mark.parametrize("future", [0, 2])        # (2: forecast query frames sample the mean of ALL value frames, round 6)
+def test_decoder_premixed_memory_path_equals_the_per_layer_path(future):
     """Round 5: with no padding the temporal mean of the memory is taken ONCE for all decoder layers and
     each layer samples value_proj(mean) -- mask fill, mean and projection commute (reference
     models/ops/modules/ms_deform_attn.py:114-118, 130-226 with tied Linears).  Same model, same inputs, bf16 autocast:
@@ -485,7 +487,7 @@ def test_decoder_premixed_memory_path_equals_the_per_layer_path():
     spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
     b = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(b)
-    a = SimpleNamespace(hidden_dim=384, enc_layers=1, dec_layers=3, frames=3, future_frames=0, use_pytorch_deform=0,
+    a = SimpleNamespace(hidden_dim=384, enc_layers=1, dec_layers=3, frames=3, future_frames=future, use_pytorch_deform=0,
                         batch=2, height=192, width=256)          # 6 048 memory rows: the bf16 GEMM path (>= 4 096 rows)
     from snipper_amd.model import build_model
     torch.manual_seed(0)
