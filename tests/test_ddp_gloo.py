@@ -253,6 +253,12 @@ def _toy_worker(rank, world, port, out_dir, case):
                 # local gradients are x[i] everywhere, whichever way they arrived; nothing is written in place before the late
                 # set has been agreed on (first sync()), afterwards every slice that is still free when its gradient arrives
                 for i, p in enumerate(ps):
+                    if p.grad.data_ptr() == gs.views[i].data_ptr() and not gs.slice_is_free(p):
+                        # written in place AND its stage has been launched since: gloo's threads are reducing that slice right
+                        # now, it no longer (reliably) holds the local gradient -- the mean checked after sync() covers it
+                        # (round 6: this read raced with the collective about once in ten runs); what the rank contributed is known
+                        local[-1][i] = torch.full_like(p, float(x[i]))
+                        continue
                     torch.testing.assert_close(local[-1][i], torch.full_like(p, float(x[i])))
                 assert (not any(in_place)) if step == 0 else any(in_place), (step, in_place)
             if case == "unexpected_late" and step == 2:
