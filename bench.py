@@ -1194,14 +1194,11 @@ def main():
     # ---- kernel census of a step: every device kernel of two eager steps from the profiler's device activity
     #      (roctracer): launches per step, their summed duration, and the part of it in kernels shorter than 20 us -- the
     #      launch-bound tail, whose kernels cannot fill 256 CUs.  Memcpy / memset records are counted apart.
+    #      One GPU only: with N > 1 a profiler failure on rank 0 in the middle of a step would leave the other ranks waiting in
+    #      that step's collectives, and the launch count does not depend on N.
     census = None
-    if rank == 0 and not a.no_extras and graph is None:
+    if rank == 0 and world == 1 and not use_ddp and not a.no_extras and graph is None:
         census = kernel_census(lambda i: train_step(*batches[i % len(batches)]), 2)
-    if use_ddp and not a.no_extras and graph is None:
-        if rank != 0:
-            for i in range(3):                      # (one warm-up step inside kernel_census + the two counted ones)
-                train_step(*batches[i % len(batches)])
-        fence()
 
     # ---- where the staged all-reduces are launched on the GPU timeline of a step (events on the compute stream): the stages
     #      launched from autograd hooks must sit INSIDE backward.  (On one GPU with a 1-rank group RCCL launches no kernel for
