@@ -761,14 +761,22 @@ def main():
     if world != a.gpus:       # under a launcher the launcher's world size is authoritative
         a.gpus = world
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
-    device = torch.device("cuda", local_rank)
+    # SNIPPER_SHARE_GPU=1 (path test only, never a measurement): all ranks of the job share the GPUs the box has -- with
+    # SNIPPER_DIST_BACKEND=gloo two ranks can walk the whole N > 1 path (staged all-reduce hooks, rank barriers, gathers,
+    # the cross-rank parameter check) on a 1-GPU box, where RCCL refuses two ranks on one device
+    share_gpu = os.environ.get("SNIPPER_SHARE_GPU") == "1"
+    device = torch.device("cuda", local_rank % torch.cuda.device_count() if share_gpu else local_rank)
     torch.cuda.set_device(device)
     use_ddp = world > 1 or os.environ.get("SNIPPER_FORCE_DDP") == "1"   # the latter: 1-GPU test of the RCCL path
     if use_ddp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29577")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)   # "nccl" is RCCL on ROCm
+        backend = os.environ.get("SNIPPER_DIST_BACKEND", "nccl")                         # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     # The step is issued by two busy threads (Python + the autograd engine).  Left to the scheduler they wander over the
     # 256 logical CPUs of the box: measured host issue time 28.8-35.5 ms per step from run to run; on a block of
@@ -1167,6 +1175,20 @@ def main():
         t = mine.clone()
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
+        # data-parallel invariant (DDP's, main.py:193-196): after any number of steps every rank holds the SAME parameters
+        # -- same initial broadcast, same averaged gradients, same deterministic update.  Checked bit for bit through two
+        # order-sensitive checksums of all trainable parameters (sum and index-weighted sum in float64).
+        with torch.no_grad():
+            ps = [q.detach().double().flatten() for q in model.parameters() if q.requires_grad]
+            chk = torch.stack([torch.stack([q.sum() for q in ps]).sum(),
+                               torch.stack([(q * torch.arange(1, q.numel() + 1, device=q.device, dtype=q.dtype)).sum()
+                                            for q in ps]).sum()])
+        every_chk = [torch.zeros_like(chk) for _ in range(world)]
+        dist.all_gather(every_chk, chk)
+        params_in_sync = all(bool(torch.equal(c, every_chk[0])) for c in every_chk)
+        if not params_in_sync:       # reported, not raised: the line (and the other ranks' collectives) must still complete
+            print(f"[bench] rank {rank}: PARAMETERS DIFFER ACROSS RANKS after {a.warmup + a.steps} steps: "
+                  f"{[c.tolist() for c in every_chk]}", file=sys.stderr)
 
     # kernel launch durations for the roofline: events on the launch stream around every core-op launch.  Under
     # graph replay there is no per-launch host hook, so the same step is run eagerly (same kernels, same
@@ -1353,6 +1375,8 @@ def main():
                                    "per_rank_ms_per_step_min_max": [min(per_rank_ms), max(per_rank_ms)],
                                    "per_rank_cpu_pinning": per_rank_pin,
                                    "per_rank_host_issue_ms_per_step": per_rank_issue,
+                                   "parameters_identical_across_ranks": params_in_sync,
+                                   "shared_gpu_path_test": share_gpu,
                                    "grad_allreduce_mbytes_per_step": round(gsync.flat.numel() * 4 / 1e6, 2) if gsync is not None else None}
         line["host_issue_ms"] = host_issue_ms          # host time to issue one step (no device wait); < ms_per_step = GPU-bound
         if census is not None:
