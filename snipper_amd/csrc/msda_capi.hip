@@ -19,6 +19,7 @@
 #include "wres_gemm_bf16.cuh"
 #include "wgrad_ring_bf16.cuh"
 #include "wgrad_wide_bf16.cuh"
+#include "wgrad_conv_patch_bf16.cuh"
 #include "misc_kernels.cuh"
 #include "conv3x3_ring_bf16.cuh"
 #include "conv3x3_patch_bf16.cuh"
@@ -1184,10 +1185,60 @@ int snipper_wgrad_bf16(void *stream, const uint16_t *G, long long ldg, const uin
   return launch_status();
 }
 
+namespace {
+// stride-1 3x3 weight gradients with the input patch resident in LDS (csrc/wgrad_conv_patch_bf16.cuh)
+struct ConvPatchPlan { bool use; int cb, tiles_co, tiles_ci, S, span, lead, ring, tiles_k128, tiles128, lds; unsigned mag_row, mag_img; };
+ConvPatchPlan wgrad_conv_patch_plan(int B, int H, int Wd, int Cin, int Cout, int stride) {
+  ConvPatchPlan p{};
+  static const bool on = [] { const char *e = getenv("SNIPPER_WGRAD_CONV_PATCH"); return !(e && e[0] == '0'); }();      // (A/B aid)
+  static const int wgs_env = [] { const char *e = getenv("SNIPPER_WGRAD_CONV_WGS"); return e ? atoi(e) : 0; }();       // (measurement aid)
+  if (!on || stride != 1 || Cin % 128 || B <= 0 || H <= 0 || Wd <= 0) return p;
+  p.cb = 2;          // (4 co blocks per wave -- 144 accumulator registers, half the X fragment reads per MFMA -- measured slower:
+                     //  60 / 50 / 55 us against 44 / 47 / 46 at layer2 / 3 / 4, profiles/r06_wgrad_conv_patch_ab.txt)
+  if (Cout % (16 * p.cb)) return p;
+  const long long Wp = Wd + 2, Hp = H + 2, Q = Hp * Wp, T = (long long)B * Q;
+  p.lead = (Wd + 3 + 31) / 32 * 32;
+  p.ring = 2 * p.lead + kWcChunk;
+  p.lds = wgrad_conv_lds_bytes(p.ring, p.cb);
+  if (Q < p.lead || (double)(B + 2) * Q * Wp >= 4294967296.0 || p.lds > 160 * 1024) return p;
+  p.tiles_co = Cout / (16 * p.cb);
+  p.tiles_ci = Cin / kWcCi;
+  const int tiles = p.tiles_co * p.tiles_ci;
+  const int wgs = wgs_env > 0 ? wgs_env : 2 * device_cu_count();       // two workgroups per CU (LDS and registers allow two)
+  int s0 = std::max(1, wgs / tiles);
+  if (s0 >= 8) s0 = s0 / 8 * 8;
+  p.span = (int)(((T + s0 - 1) / s0 + kWcChunk - 1) / kWcChunk * kWcChunk);
+  p.S = (int)((T + p.span - 1) / p.span);
+  if (s0 >= 8) p.S = (p.S + 7) / 8 * 8;               // (ranges past the batch write zero partials)
+  p.tiles_k128 = 9 * Cin / 128;
+  p.tiles128 = (Cout + 127) / 128 * p.tiles_k128;
+  p.mag_row = (unsigned)((4294967296ULL + (unsigned long long)Wp - 1) / (unsigned long long)Wp);
+  p.mag_img = (unsigned)((4294967296ULL + (unsigned long long)Hp - 1) / (unsigned long long)Hp);
+  p.use = true;
+  return p;
+}
+int launch_wgrad_conv_patch(hipStream_t stream, const ConvPatchPlan &p, const WgradConvArgs &a) {
+  static std::atomic<int> raised[kMaxDevices];       // more than 64 KB of dynamic LDS: a per-device function attribute
+  const int dev = current_device_index();
+  if (dev >= kMaxDevices || raised[dev].load(std::memory_order_acquire) == 0) {
+    const hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void *>(&wgrad_conv_patch_kernel<2>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e2 != hipSuccess) return (int)e2;
+    if (dev < kMaxDevices) raised[dev].store(1, std::memory_order_release);
+  }
+  const dim3 grid(p.tiles_co * p.tiles_ci * p.S);
+  hipLaunchKernelGGL(wgrad_conv_patch_kernel<2>, grid, dim3(kWcThreads), p.lds, stream, a);
+  return SNIPPER_OK;
+}
+}  // namespace
+
 size_t snipper_wgrad_conv3x3_workspace_bytes(int B, int H, int Wd, int Cin, int Cout, int stride) {
   if (B <= 0 || H <= 0 || Wd <= 0 || Cin <= 0 || Cout <= 0 || (stride != 1 && stride != 2)) return 0;
   const int Ho = (H - 1) / stride + 1, Wo = (Wd - 1) / stride + 1;
-  return snipper_wgrad_workspace_bytes(B * Ho * Wo, Cout, 9 * Cin);
+  size_t need = snipper_wgrad_workspace_bytes(B * Ho * Wo, Cout, 9 * Cin);
+  const ConvPatchPlan cp = wgrad_conv_patch_plan(B, H, Wd, Cin, Cout, stride);
+  if (cp.use) need = std::max(need, (size_t)cp.S * cp.tiles128 * 16384 * sizeof(float));
+  return need;
 }
 
 int snipper_wgrad_conv3x3_bf16(void *stream, const uint16_t *G, const uint16_t *X, int B, int H, int Wd, int Cin, int Cout,
@@ -1201,9 +1252,20 @@ int snipper_wgrad_conv3x3_bf16(void *stream, const uint16_t *G, const uint16_t *
   const long long M = (long long)B * Ho * Wo;
   if (M >= (1LL << 31) || (long long)B * H * Wd * Cin >= (1LL << 30)) return SNIPPER_E_SHAPE;      // (32-bit byte offsets)
   const int Kc = 9 * Cin;
-  if (workspace_bytes < snipper_wgrad_workspace_bytes((int)M, Cout, Kc)) return SNIPPER_E_SHAPE;
-  const WgradPlan p = wgrad_plan((int)M, Cout, Kc);
+  if (workspace_bytes < snipper_wgrad_conv3x3_workspace_bytes(B, H, Wd, Cin, Cout, stride)) return SNIPPER_E_SHAPE;
   float *P = (float *)workspace;
+  const ConvPatchPlan cp = wgrad_conv_patch_plan(B, H, Wd, Cin, Cout, stride);
+  if (cp.use) {
+    const WgradConvArgs a{G, X, P, B, H, Wd, Cin, Cout, cp.S, cp.span, cp.tiles_co, cp.tiles_ci, cp.lead, cp.ring,
+                          cp.tiles_k128, cp.tiles128, cp.mag_row, cp.mag_img, wres_debug()};
+    const int rc = launch_wgrad_conv_patch((hipStream_t)stream, cp, a);
+    if (rc != SNIPPER_OK) return rc;
+    const WgradReduceArgs r{P, nullptr, dW, Kc, nullptr, scale, Cout, Kc, cp.S, accumulate, (Cout + 127) / 128, cp.tiles_k128};
+    const long long quads = (long long)cp.tiles128 * 4096;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((quads + 63) / 64)), dim3(256), 0, (hipStream_t)stream, r);
+    return launch_status();
+  }
+  const WgradPlan p = wgrad_plan((int)M, Cout, Kc);
   const WgradArgs a{G, Cout, X, Cin, P, nullptr, (int)M, Cout, Kc, p.S, p.rows, p.tiles_n, p.tiles_k, 1, H, Wd, Cin, Ho, Wo, stride};
   hipLaunchKernelGGL(wgrad_bf16_kernel<128>, dim3(p.tiles_n * p.tiles_k * p.S), dim3(kWgThreads), 0, (hipStream_t)stream, a);
   const WgradReduceArgs r{P, nullptr, dW, Kc, nullptr, scale, Cout, Kc, p.S, accumulate, p.tiles_n, p.tiles_k};

@@ -326,7 +326,9 @@ def test_conv3x3_stride2_data_gradient_kernel(cin, cout, h, w):
 
 @pytest.mark.parametrize("cin,cout,h,w,stride", [(128, 128, 150, 200, 2), (128, 128, 75, 100, 1), (256, 256, 38, 50, 1),
                                                  (256, 256, 75, 100, 2), (512, 512, 19, 25, 1), (512, 512, 38, 50, 2),
-                                                 (128, 8, 5, 7, 1), (128, 136, 3, 3, 2), (256, 64, 1, 1, 1)])
+                                                 (128, 8, 5, 7, 1), (128, 136, 3, 3, 2), (256, 64, 1, 1, 1),
+                                                 (128, 64, 17, 23, 1), (128, 96, 9, 40, 1), (256, 32, 4, 131, 1),
+                                                 (128, 160, 33, 14, 1)])
 def test_conv3x3_weight_gradient_kernel(cin, cout, h, w, stride):
     """Conv mode of the split-reduction kernel against autograd through F.conv2d in float64 on the same bf16 operands
     (ResNet-50's conv2 shapes at the 600x800 geometry, plus ragged ones), with and without the folded BN scale."""
