@@ -36,13 +36,14 @@ __global__ __launch_bounds__(kGemmThreads) __attribute__((amdgpu_waves_per_eu(2,
 void conv3x3_ring_kernel(Conv3x3Args g) {
   constexpr int BN = kCrBN, NI = BN / 32, CTS = BN + 8;
   __shared__ __attribute__((aligned(16))) unsigned char smem[kCrSlots * kCrSlotB];      // ONE LDS object (see wres_gemm_bf16.cuh)
+  const int bid = conv_dgrad2_class(g);
   const bool wide = gemm_wide_ok(g.Y, g.Cout, g.Cout) && !g.dgrad2;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave & 1, wn = wave >> 1;
   const int M = g.B * g.Ho * g.Wo;
   const int tiles_n = (g.Cout + BN - 1) / BN;
-  const int xcd = blockIdx.x & 7, jb = (int)(blockIdx.x >> 3);
+  const int xcd = bid & 7, jb = bid >> 3;
   const int tm = xcd + 8 * (jb / tiles_n), tn = jb % tiles_n;
   if ((long long)tm * kGemmBM >= M) return;
   const int m0 = tm * kGemmBM, n0 = tn * BN;

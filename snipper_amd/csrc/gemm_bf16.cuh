@@ -571,6 +571,9 @@ struct Conv3x3Args {
   // MFMA useful.  Here X = G [B][H][W][Cin] (the output gradient, "Cin" = the convolution's Cout), W = W' [Cout'][3][3][Cin]
   // (the weight with its channel roles swapped), Y = dX [B][Hy][Wy][Cout]; a row of the launch is (n, a, b) over the
   // class's grid Ho x Wo and is stored at pixel (2a + cy, 2b + cx) of Y.
+  // dgrad2 == 2: ALL FOUR classes in one launch -- class c = 0..3 = (cy, cx) = (1,1), (1,0), (0,1), (0,0) (most taps first) owns
+  // the blocks [cls_end[c - 1], cls_end[c]) of the grid (multiples of 8: the XCD map works per class); the kernel fills in cy,
+  // cx, Ho, Wo from its block index.  Four separate launches of 4-16 K-steps each were mostly ramp and tail.
   int dgrad2, cy, cx, Hy, Wy;
   // gate (optional, the layout of Y): outputs whose gate value is not > 0 are written as 0 -- when this launch is a data
   // gradient and Y's activation came out of a ReLU, that ReLU's backward happens here, in the store phase
@@ -579,7 +582,23 @@ struct Conv3x3Args {
   // gradient is the same convolution with reversed taps and swapped channel roles, so the caller only has to swap the
   // channel axes of the weight, not to flip it as well
   int flip;
+  int cls_end[4];
 };
+
+// the merged stride-2 data gradient: this block's class and its block index within the class
+__device__ __forceinline__ int conv_dgrad2_class(Conv3x3Args &g) {
+  int bid = (int)blockIdx.x;
+  if (g.dgrad2 == 2) {
+    int c = 0;
+    while (c < 3 && bid >= g.cls_end[c]) ++c;
+    bid -= c ? g.cls_end[c - 1] : 0;
+    g.cy = c < 2 ? 1 : 0;
+    g.cx = (c & 1) ? 0 : 1;
+    g.Ho = (g.Hy - g.cy + 1) / 2;
+    g.Wo = (g.Wy - g.cx + 1) / 2;
+  }
+  return bid;
+}
 
 // BN = 128 or 64 output channels per workgroup (64: each wave 64 x 32, more workgroups per CU; the launcher takes it when
 // the 128-wide grid would not fill the chip -- layer3 / layer4 of the ResNet have 238 / 120 such tiles for 768 slots).
@@ -589,12 +608,13 @@ void conv3x3_bf16_kernel(Conv3x3Args g) {
   constexpr int NI = BN / 32, WL = BN / 32, CTS = BN + 8;      // 16-column blocks per wave, W loads per thread and step
   __shared__ __attribute__((aligned(16))) uint16_t smem[(kGemmBM + BN) * kGemmPad];
   uint16_t *Xs = smem, *Ws = smem + kGemmBM * kGemmPad;
+  const int bid = conv_dgrad2_class(g);
   const bool wide = gemm_wide_ok(g.Y, g.Cout, g.Cout) && !g.dgrad2;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave & 1, wn = wave >> 1;
   const int M = g.B * g.Ho * g.Wo;
   const int tiles_n = (g.Cout + BN - 1) / BN;
-  const int xcd = blockIdx.x & 7, jb = (int)(blockIdx.x >> 3);
+  const int xcd = bid & 7, jb = bid >> 3;
   const int tm = xcd + 8 * (jb / tiles_n), tn = jb % tiles_n;
   if ((long long)tm * kGemmBM >= M) return;
   const int m0 = tm * kGemmBM, n0 = tn * BN;

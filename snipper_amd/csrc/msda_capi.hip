@@ -1744,6 +1744,36 @@ int snipper_conv3x3_dgrad_s2_bf16(void *stream, const uint16_t *G, const uint16_
   if (B <= 0 || Hx <= 0 || Wx <= 0 || Cx <= 0 || Cg <= 0 || Cg % kGemmBK || Cx % 4) return SNIPPER_E_SHAPE;
   const int Hg = (Hx - 1) / 2 + 1, Wg = (Wx - 1) / 2 + 1;          // the stride-2 convolution's output size
   if ((long long)B * Hx * Wx >= (1LL << 31) || (long long)B * Hg * Wg * Cg >= (1LL << 30)) return SNIPPER_E_SHAPE;
+  // all four parity classes as ONE launch when they take the same kernel instance (they do unless a size threshold falls
+  // between two class sizes): four launches of 4-16 K-steps were mostly ramp and tail (round 6; SNIPPER_DGRAD2_MERGE=0: A/B)
+  static const bool merge_on = [] { const char *e = getenv("SNIPPER_DGRAD2_MERGE"); return !(e && e[0] == '0'); }();
+  if (merge_on) {
+    Conv3x3Args g{G, Wt, nullptr, dX, B, Hg, Wg, Cg, Cx, 0, 0, 1, 2, 0, 0, Hx, Wx, gate, 0, {0, 0, 0, 0}};
+    int kind = -1;                  // 0 ring n64, 1 register-prefetch n64, 2 register-prefetch n128
+    bool same = true;
+    unsigned end = 0;
+    for (int c = 0; c < 4; ++c) {
+      const int cy = c < 2 ? 1 : 0, cx = (c & 1) ? 0 : 1;
+      const int Hc = (Hx - cy + 1) / 2, Wc = (Wx - cx + 1) / 2;
+      const long long Mc = (long long)B * Hc * Wc;
+      if (Hc > 0 && Wc > 0) {
+        const int k = conv_use_n64(Mc, Cx) ? (conv_ring_on(Mc) ? 0 : 1) : 2;
+        if (kind < 0) kind = k;
+        same = same && k == kind;
+        end += k == 2 ? gemm_grid_size(Mc, Cx) : conv_grid_n64(Mc, Cx);
+      }
+      g.cls_end[c] = (int)end;
+    }
+    if (same && kind >= 0 && end > 0) {
+      if (kind == 0)
+        hipLaunchKernelGGL(conv3x3_ring_kernel<false>, dim3(end), dim3(kGemmThreads), 0, (hipStream_t)stream, g);
+      else if (kind == 1)
+        hipLaunchKernelGGL((conv3x3_bf16_kernel<false, 64>), dim3(end), dim3(kGemmThreads), 0, (hipStream_t)stream, g);
+      else
+        hipLaunchKernelGGL((conv3x3_bf16_kernel<false, 128>), dim3(end), dim3(kGemmThreads), 0, (hipStream_t)stream, g);
+      return launch_status();
+    }
+  }
   for (int cy = 0; cy < 2; ++cy)
     for (int cx = 0; cx < 2; ++cx) {
       const int Hc = (Hx - cy + 1) / 2, Wc = (Wx - cx + 1) / 2;    // input pixels (2a + cy, 2b + cx) of this class
