@@ -93,12 +93,13 @@ def lookup_packed(param: torch.Tensor, scale: Optional[torch.Tensor] = None):
     return None
 
 
-# The one-tap form of the patch kernel for the 1x1 convolutions' / the feed-forward block's 1024-deep products: OPT-IN
-# (SNIPPER_LINEAR_PATCH=1).  In isolation it beats the tile kernels on most data gradients by 10-30 % and on the forward
-# products with a reduction >= 256 by 5-20 % (tools/linpatchbench.py, profiles/r05_linear_patch_bench.jsonl); inside the step the
-# 42 + 13 launches it takes over cost 2.21 ms against 2.28 ms, the four pack launches add 0.075 ms and the extra look-ups
-# ~1 ms of host issue time: same-box step 22.40 / 22.44 ms without, 23.5 / 25.8 ms with (host-bound in places).
-LINEAR_PATCH = _os.environ.get("SNIPPER_LINEAR_PATCH", "0") == "1"
+# The one-tap form of the patch kernel for the 1x1 convolutions' / the feed-forward block's 1024-deep products.  In isolation it
+# beats the tile kernels on most data gradients by 10-30 % and on the forward products with a reduction >= 256 by 5-20 %
+# (tools/linpatchbench.py, profiles/r05_linear_patch_bench.jsonl).  Round 5 left it opt-in: the extra look-ups cost ~1 ms of host
+# issue time when the step was host-bound (same-box 22.40 / 22.44 ms without, 23.5 / 25.8 ms with).  Round 6 took 6.6 ms off the
+# host (one native call per layer and direction), the step is GPU-bound with a 9 ms margin, and the same switch now measures
+# 21.10 / 21.12 -> 21.00 / 20.97 ms (profiles/r06_linear_patch_step_ab.txt): ON by default, SNIPPER_LINEAR_PATCH=0 = tile kernels.
+LINEAR_PATCH = _os.environ.get("SNIPPER_LINEAR_PATCH", "1") != "0"
 CAST_TABLE = _os.environ.get("SNIPPER_CAST_TABLE", "1") != "0"      # one-launch weight casts (0: PyTorch multi-tensor ops, A/B)
 # Full-width (128 / 160 rows x 384 columns, 8 waves) tiles for the deep reductions into 384 columns: the feed-forward block's
 # linear2 forward and linear1 data gradient (csrc/conv3x3_patch_bf16.cuh, linear_wide_kernel).  SNIPPER_LINEAR_WIDE=0: tile kernels.
