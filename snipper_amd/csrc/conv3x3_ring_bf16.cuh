@@ -37,7 +37,7 @@ void conv3x3_ring_kernel(Conv3x3Args g) {
   constexpr int BN = kCrBN, NI = BN / 32, CTS = BN + 8;
   __shared__ __attribute__((aligned(16))) unsigned char smem[kCrSlots * kCrSlotB];      // ONE LDS object (see wres_gemm_bf16.cuh)
   const int bid = conv_dgrad2_class(g);
-  const bool wide = gemm_wide_ok(g.Y, g.Cout, g.Cout) && !g.dgrad2;
+  const bool wide = gemm_wide_ok(g.Y, g.Cout, g.Cout) && (!g.gate || ((uintptr_t)g.gate % 16) == 0);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave & 1, wn = wave >> 1;
@@ -185,7 +185,17 @@ void conv3x3_ring_kernel(Conv3x3Args g) {
       }
     }
   }
-  if (wide) gemm_flush_tile_n<BN>(stage, g.Y, g.Cout, m0, n0, M, g.Cout, g.gate, g.Cout);
+  if (wide) {
+    if (g.dgrad2) {
+      const int hw = g.Ho * g.Wo;
+      gemm_flush_tile_n_map<BN>(stage, g.Y, g.Cout, m0, n0, M, g.Cout, g.gate, g.Cout, [&](long long m) {
+        const int b = (int)m / hw, r = (int)m - b * hw, a = r / g.Wo;
+        return ((long long)b * g.Hy + 2 * a + g.cy) * g.Wy + 2 * (r - a * g.Wo) + g.cx;
+      });
+    } else {
+      gemm_flush_tile_n<BN>(stage, g.Y, g.Cout, m0, n0, M, g.Cout, g.gate, g.Cout);
+    }
+  }
 }
 
 }  // namespace snipper

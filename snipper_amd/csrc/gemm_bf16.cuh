@@ -101,6 +101,36 @@ __device__ __forceinline__ void gemm_flush_tile_n(const uint16_t *Ct, uint16_t *
   }
 }
 
+// the same with the tile's rows stored at MAPPED rows of Y (and of the gate): rowmap(m) -> row.  The stride-2 data gradient's
+// parity classes write every other pixel of every other image row; as 8-byte pieces straight from the accumulators (each
+// behind its own 8-byte gate load) that store phase outweighed the 4-16 K-steps of a class.
+template <int BN, typename RowMap>
+__device__ __forceinline__ void gemm_flush_tile_n_map(const uint16_t *Ct, uint16_t *Y, long long ldy, int m0, int n0, long long M,
+                                                      int N, const uint16_t *gate, long long ldg, RowMap rowmap) {
+  constexpr int CH = BN / 8, ITER = 128 * CH / 256, CTS = BN + 8;
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < ITER; ++i) {
+    const int idx = threadIdx.x + 256 * i, row = idx / CH, ch = idx % CH;
+    const long long m = (long long)m0 + row;
+    const int n = n0 + ch * 8;
+    if (m < M && n < N) {
+      const long long dst = rowmap(m);
+      uint4 v = *reinterpret_cast<const uint4 *>(Ct + row * CTS + ch * 8);
+      if (gate) {
+        const uint4 a = *reinterpret_cast<const uint4 *>(gate + dst * ldg + n);
+        auto keep = [](unsigned av, unsigned vv) {
+          const unsigned lo = ((av & 0x8000u) == 0u && (av & 0x7fffu) != 0u) ? 0x0000ffffu : 0u;
+          const unsigned hi = ((av & 0x80000000u) == 0u && (av & 0x7fff0000u) != 0u) ? 0xffff0000u : 0u;
+          return vv & (lo | hi);
+        };
+        v.x = keep(a.x, v.x); v.y = keep(a.y, v.y); v.z = keep(a.z, v.z); v.w = keep(a.w, v.w);
+      }
+      *reinterpret_cast<uint4 *>(Y + dst * ldy + n) = v;
+    }
+  }
+}
+
 typedef __attribute__((ext_vector_type(8))) __bf16 gemm_bf16x8;
 typedef __attribute__((ext_vector_type(4))) float gemm_f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned int gemm_u32x4;
@@ -609,7 +639,7 @@ void conv3x3_bf16_kernel(Conv3x3Args g) {
   __shared__ __attribute__((aligned(16))) uint16_t smem[(kGemmBM + BN) * kGemmPad];
   uint16_t *Xs = smem, *Ws = smem + kGemmBM * kGemmPad;
   const int bid = conv_dgrad2_class(g);
-  const bool wide = gemm_wide_ok(g.Y, g.Cout, g.Cout) && !g.dgrad2;
+  const bool wide = gemm_wide_ok(g.Y, g.Cout, g.Cout) && (!g.gate || ((uintptr_t)g.gate % 16) == 0);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave & 1, wn = wave >> 1;
   const int M = g.B * g.Ho * g.Wo;
@@ -727,7 +757,17 @@ void conv3x3_bf16_kernel(Conv3x3Args g) {
       }
     }
   }
-  if (wide) gemm_flush_tile_n<BN>(smem, g.Y, g.Cout, m0, n0, M, g.Cout, g.gate, g.Cout);
+  if (wide) {
+    if (g.dgrad2) {
+      const int hw = g.Ho * g.Wo;
+      gemm_flush_tile_n_map<BN>(smem, g.Y, g.Cout, m0, n0, M, g.Cout, g.gate, g.Cout, [&](long long m) {
+        const int b = (int)m / hw, r = (int)m - b * hw, a = r / g.Wo;
+        return ((long long)b * g.Hy + 2 * a + g.cy) * g.Wy + 2 * (r - a * g.Wo) + g.cx;
+      });
+    } else {
+      gemm_flush_tile_n<BN>(smem, g.Y, g.Cout, m0, n0, M, g.Cout, g.gate, g.Cout);
+    }
+  }
 }
 
 // ---- the ResNet stem: 7x7 convolution, stride 2, padding 3, 3 input channels -> 64, NHWC bf16 ----------------
