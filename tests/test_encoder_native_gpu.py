@@ -78,6 +78,10 @@ def test_native_encoder_layer_equals_the_node_per_module_path(frames, enc_layers
         worst = max(worst, (rel(g1, g0), n))
         worst_self = max(worst_self, (rel(g2, g0), n))
     print(f"native vs per-module: {n_equal}/{len(res[True][2])} gradients bit-equal, worst {worst}; per-module vs itself: worst {worst_self}")
-    # the two forms launch the same kernels on the same data; what can differ is what differs between two runs of ONE form (the
-    # owner-computes backward's far-tap atomics and the bf16 roundings behind them)
-    assert worst[0] <= max(1e-6, 4.0 * worst_self[0]), (worst, worst_self)
+    # the two forms launch the same kernels on the same data; what can differ is what differs between two runs of ONE form: the
+    # owner-computes backward's far-tap atomics are unordered, one flipped bf16 rounding behind them moves a backbone weight
+    # gradient by ~2.5e-3 in relative L2 (measured between two runs of the per-module form: 0 in some pairs of runs, 1.2e-4 ...
+    # 2.6e-3 in others).  ONE self-comparison is a sample of that noise, not its bound (it was exactly 0 in a run where the native
+    # form hit the other rounding: 2.4e-3), hence the floor; a wrong pointer or a missing term in the composite shows up as O(1).
+    assert worst[0] <= max(1e-2, 4.0 * worst_self[0]), (worst, worst_self)
+    assert n_equal >= len(res[True][2]) // 4, n_equal          # (what does not pass through the encoder's backward is bit-equal: 56-59 of 145)

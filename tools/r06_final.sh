@@ -9,6 +9,10 @@ cd $R
 timeout 1500 python3 -m pytest tests -m gpu -x -q > $out/gputests.txt 2>&1; echo "pytest rc=$?" >> $out/gputests.txt
 tail -4 $out/gputests.txt
 bash tools/collect_profiles.sh $tag > $out/collect.log 2>&1
+# the default line once more with this library's counter profile in place (bench.py quotes roofline.traffic from profiles/ only when
+# the profile's source hash equals the loaded library's)
+cp $out/pmc_bench_step.csv profiles/r06_pmc_bench_step.csv
+python3 bench.py > $out/bench_bf16_default.json 2> $out/bench_bf16_default.err
 python3 bench.py --future-frames 2 --no-cpu-baseline > $out/bench_forecast.json 2> $out/bench_forecast.err
 python3 bench.py --height 540 --width 960 --no-cpu-baseline > $out/bench_540x960.json 2> $out/bench_540x960.err
 python3 bench.py --steps 20 --warmup 8 --no-cpu-baseline --no-locality-sweep > $out/bench_plain_20_8.json 2> $out/bench_plain_20_8.err
