@@ -1221,6 +1221,19 @@ def main():
     census = None
     if rank == 0 and world == 1 and not use_ddp and not a.no_extras and graph is None:
         census = kernel_census(lambda i: train_step(*batches[i % len(batches)]), 2)
+    if os.environ.get("SNIPPER_ATEN_OPS") and rank == 0 and world == 1:      # development aid: the ATen residue of a step by operator
+        from torch.profiler import profile, ProfilerActivity
+        train_step(*batches[0])
+        torch.cuda.synchronize()
+        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+            train_step(*batches[0])
+            torch.cuda.synchronize()
+        rows = [e for e in prof.key_averages() if e.key.startswith("aten::") and (getattr(e, "self_device_time_total", 0) or 0) > 0]
+        rows.sort(key=lambda e: -e.self_device_time_total)
+        print(f"[aten] {sum(e.self_device_time_total for e in rows):.0f} us of device time in {sum(e.count for e in rows)} operator calls",
+              file=sys.stderr)
+        for e in rows[:40]:
+            print(f"[aten] {e.key:32s} calls {e.count:4d} device_us {e.self_device_time_total:9.1f}", file=sys.stderr)
 
     # ---- where the staged all-reduces are launched on the GPU timeline of a step (events on the compute stream): the stages
     #      launched from autograd hooks must sit INSIDE backward.  (On one GPU with a 1-rank group RCCL launches no kernel for
