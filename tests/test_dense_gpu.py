@@ -734,3 +734,47 @@ def test_linear_wide_kernel(M, K, mode, mt, monkeypatch):
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600,
                          cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
+
+
+_AB_SCRIPT = r"""
+import sys, torch
+sys.path.insert(0, sys.argv[1])
+from snipper_amd.dense import conv3x3_dgrad_s2_bf16, wgrad_conv3x3_bf16
+dev = "cuda:0"
+gen = torch.Generator().manual_seed(5)
+out = {}
+for (c, h, w) in ((128, 37, 50), (256, 9, 14)):
+    wt = (torch.randn(c, c, 3, 3, generator=gen) / (3 * c ** 0.5)).to(dev).bfloat16()
+    ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    gy = torch.randn(3, c, ho, wo, generator=gen).to(dev).bfloat16().contiguous(memory_format=torch.channels_last)
+    gate = torch.randn(3, c, h, w, generator=gen).relu().to(dev).bfloat16().contiguous(memory_format=torch.channels_last)
+    out[f"dgrad_s2_{c}_{h}x{w}"] = conv3x3_dgrad_s2_bf16(gy, wt.transpose(0, 1), (h, w)).float().cpu()
+    out[f"dgrad_s2_gated_{c}_{h}x{w}"] = conv3x3_dgrad_s2_bf16(gy, wt.transpose(0, 1), (h, w), gate=gate).float().cpu()
+    x = torch.randn(3, c, h, w, generator=gen).to(dev).bfloat16().contiguous(memory_format=torch.channels_last)
+    g1 = torch.randn(3, 64, h, w, generator=gen).to(dev).bfloat16().contiguous(memory_format=torch.channels_last)
+    out[f"wgrad3x3_{c}_{h}x{w}"] = wgrad_conv3x3_bf16(g1, x, 1, None).float().cpu()
+torch.save(out, sys.argv[2])
+"""
+
+
+def test_round6_default_paths_equal_their_ab_alternatives(tmp_path):
+    """The library reads its A/B switches once per process, so the alternatives run in child processes: the merged stride-2 data
+    gradient (one launch, staged store phase) must equal the one-launch-per-parity-class form BIT FOR BIT (same products, same
+    order), with and without the ReLU gate; the patch-resident 3x3 weight gradient must equal the conv mode of the
+    split-reduction kernel up to the order of its float32 partial sums."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "ab.py"
+    script.write_text(_AB_SCRIPT)
+    res = {}
+    for name, env in (("default", {}), ("alt", {"SNIPPER_DGRAD2_MERGE": "0", "SNIPPER_WGRAD_CONV_PATCH": "0"})):
+        path = tmp_path / f"{name}.pt"
+        subprocess.run([sys.executable, str(script), root, str(path)], check=True, env={**os.environ, **env}, timeout=600)
+        res[name] = torch.load(path, weights_only=True)
+    assert res["default"].keys() == res["alt"].keys() and len(res["default"]) == 6
+    for k, v in res["default"].items():
+        a = res["alt"][k]
+        if k.startswith("dgrad_s2"):
+            assert torch.equal(v, a), k
+        else:
+            assert (v - a).abs().max().item() <= 1e-4 * max(1.0, a.abs().max().item()), k
